@@ -1,0 +1,190 @@
+/*
+ * realcam_hip.h -- C ABI of librealcam_hip.so: the MI355X (gfx950) RAW->sRGB hot path.
+ *
+ * Drop-in boundary.  The upstream project (kepengxu/RealCamNet) has no FFI
+ * layer: its hot path is a chain of stock ATen calls made from nn.Module.forward().  Each entry
+ * point below replaces one such call site; the citation gives the reference file:line (paths
+ * relative to the upstream repo).  The Python modules in realcamnet_amd/ keep the reference class
+ * names / state_dict keys / forward() signatures and reach these symbols through ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer named d_* / in desc structs is DEVICE memory on
+ *     the current HIP device unless the comment says "host".
+ *   - activations are NHWC ("pixel-major"): element (b,y,x,c) at ((b*H + y)*W + x)*C + c.
+ *   - dtype: RC_F32 (float) or RC_BF16 (bfloat16 storage, fp32 accumulate).
+ *   - all launches are asynchronous on `stream` (a hipStream_t passed as void*); no host sync, no
+ *     allocation -> HIP-graph capturable.
+ *   - return value: 0 on success, negative rc_status otherwise; rc_last_error() gives the text.
+ *     Shape / alignment violations are reported, never silently "fixed".
+ */
+#ifndef REALCAM_HIP_H
+#define REALCAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RC_ABI_VERSION 1
+
+typedef enum rc_status {
+    RC_OK = 0,
+    RC_ERR_INVALID = -1,     /* bad argument (shape, alignment, null pointer, unsupported combination) */
+    RC_ERR_HIP = -2,         /* a HIP runtime call failed */
+    RC_ERR_UNSUPPORTED = -3  /* valid request, but no kernel instantiation covers it */
+} rc_status;
+
+typedef enum rc_dtype { RC_F32 = 0, RC_BF16 = 1 } rc_dtype;
+
+typedef enum rc_act { RC_ACT_NONE = 0, RC_ACT_RELU = 1, RC_ACT_LEAKY = 2 /* slope in act_slope */ } rc_act;
+
+typedef enum rc_out_mode {
+    RC_OUT_NHWC = 0,           /* out[b][y][x][cout]                                             */
+    RC_OUT_PIXEL_SHUFFLE2 = 1, /* nn.PixelShuffle(2) folded into the store:
+                                  out[b][2y+i][2x+j][c] <- conv channel 4c+2i+j; out is NHWC (2H,2W,cout/4) */
+    RC_OUT_NCHW = 2            /* planar out[b][cout][y][x], cropped to (out_h,out_w); the network's
+                                  final tensor (reference forward returns NCHW)                   */
+} rc_out_mode;
+
+/* ---- library -------------------------------------------------------------------------------- */
+int rc_abi_version(void);
+const char* rc_last_error(void);           /* thread-local, host string */
+const char* rc_build_info(void);           /* "gfx950 <compiler>" */
+/* Device query used by the host mirror to fail loudly on a wrong GPU: writes the gcnArchName. */
+int rc_device_arch(char* buf, size_t buflen);
+
+/* ---- a1/a2: Bayer pixel-unshuffle + zero pad -------------------------------------------------
+ * Replaces: the "Unpixel shuffle" box of assets/networkarch.png (README.md:33-38; upstream has no
+ * code for it, every model already takes the packed tensor, models/LiteISP.py:2670) fused with
+ * pad_to_multiple_of_16 (models/LiteISP.py:84-105).
+ * mosaic: (B, 2*h, 2*w) one plane, dtype `in_dtype`; packed: NHWC (B, hp, wp, 4), hp>=h, wp>=w,
+ * channel k = 2*i + j <- mosaic pixel (2y+i, 2x+j); rows/cols beyond (h,w) are written as zero. */
+int rc_bayer_unshuffle(const void* d_mosaic, int in_dtype, void* d_packed, int out_dtype,
+                       int batch, int h, int w, int hp, int wp, void* stream);
+
+/* ---- layout plumbing at the nn.Module boundary (reference tensors are NCHW) ------------------
+ * nchw (B,C,h,w) -> nhwc (B,hp,wp,C) with zero padding (hp>=h, wp>=w) and dtype conversion. */
+int rc_nchw_to_nhwc(const void* d_src, int src_dtype, void* d_dst, int dst_dtype,
+                    int batch, int c, int h, int w, int hp, int wp, void* stream);
+/* nhwc (B,H,W,C) -> nchw (B,C,h,w) cropping to h<=H, w<=W. */
+int rc_nhwc_to_nchw(const void* d_src, int src_dtype, void* d_dst, int dst_dtype,
+                    int batch, int c, int H, int W, int h, int w, void* stream);
+
+/* ---- a3/a4/a7/a9/a11: KxK convolution, stride 1, "same" zero padding, MFMA implicit GEMM ------
+ * Replaces: nn.Conv2d as built by networks.conv mode 'C' (models/networks.py:146-160) and its
+ * fused neighbours: ReLU / LeakyReLU (networks.py:189-200), the RCAB/RCAGroup/U-Net additive skips
+ * (networks.py:311,335; models/LiteISP.py:2028-2031), Res_GFM's FiLM + LeakyReLU(0.01)
+ * (models/LiteISP.py:553-558), head*(lsc+1) (models/LiteISP.py:2014), nn.PixelShuffle(2)
+ * (models/LiteISP.py:1998) and the CALayer input/gate (networks.py:267-270).
+ *
+ * Weights are re-packed once (host side) into the MFMA fragment order with rc_conv_pack_weights.
+ */
+typedef struct rc_conv_desc {
+    int32_t batch, height, width;   /* input spatial size == conv output size                     */
+    int32_t cin, cout, ksize;       /* ksize: 1 or 3                                              */
+    int32_t dtype;                  /* rc_dtype of activations + packed weights                   */
+    /* input x.  in_gate==NULL: x = in0.
+     * in_gate!=NULL (CALayer gate + RCAB skip, networks.py:270,311): x = in0*gate[b][c] + in1 and,
+     * if in_store!=NULL, x is also written there (it is the next block's skip tensor).           */
+    const void* in0;
+    const void* in1;
+    const float* in_gate;           /* (B, cin) fp32                                              */
+    void* in_store;
+    const void* wpacked;            /* device copy of rc_conv_pack_weights output                 */
+    const float* bias;              /* device, packed order (rc_conv_pack_bias), or NULL          */
+    /* epilogue on v = acc + bias, in this order:
+     *   film_scale!=NULL: v = v*scale[b][c] + shift[b][c] + v        (Res_GFM, LiteISP.py:556)
+     *   act                                                          (none / relu / leaky)
+     *   mul_plus1!=NULL : v = v * (mul_plus1[b][y][x][c] + 1)        (LiteISP.py:2014)
+     *   residual!=NULL  : v = v + residual[b][y][x][c]                                         */
+    const float* film_scale;        /* (B, cout) fp32                                             */
+    const float* film_shift;        /* (B, cout) fp32                                             */
+    int32_t act;                    /* rc_act                                                     */
+    float act_slope;
+    const void* mul_plus1;          /* NHWC (B,H,W,cout), activation dtype                        */
+    const void* residual;           /* NHWC (B,H,W,cout), activation dtype                        */
+    void* out;
+    int32_t out_mode;               /* rc_out_mode                                                */
+    int32_t out_dtype;              /* rc_dtype of `out` (RC_OUT_NCHW may emit fp32 from a bf16 net;
+                                       other modes require out_dtype == dtype)                    */
+    int32_t out_h, out_w;           /* RC_OUT_NCHW crop size (<= height,width); else ignored      */
+    /* optional per-channel partial sums of v (the value stored), for CALayer's global mean
+     * (networks.py:268): fp32 (B, rc_conv_sum_tiles(), cout), reduced in fixed order by rc_ca_gate */
+    float* chan_sums;
+} rc_conv_desc;
+
+/* Size in bytes of the packed weight buffer for (cin,cout,ksize,dtype,out_mode); 0 on error. */
+size_t rc_conv_packed_bytes(int cin, int cout, int ksize, int dtype, int out_mode);
+/* Host-side repack.  w_oihw: host fp32 (cout,cin,k,k) as in the state_dict; dst: host buffer of
+ * rc_conv_packed_bytes() bytes (then copied to the device by the caller). */
+int rc_conv_pack_weights(const float* w_oihw_host, int cin, int cout, int ksize, int dtype,
+                         int out_mode, void* dst_host);
+/* Packed-order length of bias / film vectors (cout rounded up to the kernel's cout tile) and the
+ * host-side permutation: dst[j] = bias[perm(j)] or 0 for padding lanes. */
+int rc_conv_packed_cout(int cin, int cout, int ksize, int dtype, int out_mode);
+int rc_conv_pack_bias(const float* bias_host, int cin, int cout, int ksize, int dtype, int out_mode,
+                      float* dst_host);
+/* Number of spatial tiles per image the conv kernel uses for chan_sums (depends only on H,W). */
+int rc_conv_sum_tiles(int height, int width);
+int rc_conv2d(const rc_conv_desc* desc, void* stream);
+
+/* ---- a8: CALayer gate -------------------------------------------------------------------------
+ * Replaces: AdaptiveAvgPool2d(1) -> Conv1x1(C,C/r) -> ReLU -> Conv1x1(C/r,C) -> Sigmoid
+ * (models/networks.py:259-269).  d_sums: (B, n_tiles, C) partials from rc_conv2d; w0 (Cr,C), b0 (Cr),
+ * w1 (C,Cr), b1 (C) fp32 device; gate: (B,C) fp32.  Fixed-order reduction => run-to-run bitwise stable. */
+int rc_ca_gate(const float* d_sums, int batch, int n_tiles, int c, int cr, float inv_hw,
+               const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,
+               float* d_gate, void* stream);
+
+/* y = r*gate[b][c] + x  (CALayer scale + RCAB skip, networks.py:270,311) for call sites where the
+ * gated tensor is not consumed by a conv.  NHWC, n_pix = H*W per image. */
+int rc_gate_residual(const void* d_r, const float* d_gate, const void* d_x, void* d_y, int dtype,
+                     int batch, int n_pix, int c, void* stream);
+
+/* ---- a10: Haar DWT / IDWT as the reference's frozen grouped conv -----------------------------
+ * Replaces: DWTForward (models/networks.py:224-235) / DWTInverse (:238-249).  taps: device fp32
+ * (4C,1,2,2) exactly as stored in the state_dict ("down1.3.weight", "up1.0.weight").
+ * forward: (B,H,W,C) -> (B,H/2,W/2,4C), channel 4c+k.  inverse: (B,h,w,4C) -> (B,2h,2w,C). */
+int rc_dwt_forward(const void* d_x, void* d_y, const float* d_taps, int dtype,
+                   int batch, int H, int W, int c, void* stream);
+int rc_dwt_inverse(const void* d_x, void* d_y, const float* d_taps, int dtype,
+                   int batch, int h, int w, int c4, void* stream);
+
+/* ---- a6: Color_Condition_GFM (global colour prior) --------------------------------------------
+ * Replaces: color_block (models/LiteISP.py:23-30) = Conv1x1 -> AvgPool2d(3,2,1,count_include_pad)
+ * -> LeakyReLU(0.2) [-> InstanceNorm2d(affine)], and the closing Conv1x1 + AdaptiveAvgPool2d(1)
+ * (models/LiteISP.py:345-361).  All fp32, NCHW (the cond image is small).
+ *   rc_color_block:  y = lrelu_0.2(avgpool3s2p1(conv1x1(x)))   x:(B,cin,h,w) -> y:(B,cout,ho,wo)
+ *                    with ho=(h-1)/2+1; if d_in_mean!=NULL the previous block's InstanceNorm
+ *                    (x-mean)*rstd*gamma+beta is applied to x on load.
+ *   rc_instance_stats: per (b,c) mean and 1/sqrt(var+eps) (biased var, eps 1e-5).
+ *   rc_color_head:   v[b][o] = mean_hw(conv1x1(IN(x)))  -> (B,cout)                               */
+int rc_color_block(const void* d_x, int x_dtype, float* d_y, int batch, int cin, int cout, int h, int w,
+                   const float* d_w, const float* d_b,
+                   const float* d_in_mean, const float* d_in_rstd, const float* d_in_gamma,
+                   const float* d_in_beta, void* stream);
+int rc_instance_stats(const float* d_x, float* d_mean, float* d_rstd, int batch, int c, int hw,
+                      float eps, void* stream);
+int rc_color_head(const float* d_x, float* d_vec, int batch, int cin, int cout, int hw,
+                  const float* d_w, const float* d_b, void* stream);
+
+/* ---- a7: GFM vector MLPs ----------------------------------------------------------------------
+ * Replaces: GFM_{scale,shift}_conv1(leaky_relu(GFM_{scale,shift}_conv0(vec), 0.1))
+ * (models/LiteISP.py:554-555).  vec (B,cond_c); w0 (nf,cond_c) b0 (nf) w1 (c,nf) b1 (c); out (B,c). */
+int rc_gfm_vector(const float* d_vec, int batch, int cond_c, int nf, int c,
+                  const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,
+                  float* d_out, void* stream);
+
+/* ---- measurement helpers (bench.py): HIP-event timing of every rc_conv2d launch on its stream -
+ * rc_prof_enable(1) brackets each subsequent rc_conv2d with hipEventRecord on the launch stream;
+ * rc_prof_collect() synchronises the events and returns launches / total ms / total algorithmic
+ * FLOPs (2*MAC at the padded size) since the last rc_prof_enable(1). */
+int rc_prof_enable(int on);
+int rc_prof_collect(int64_t* n_launches, double* total_ms, double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REALCAM_HIP_H */

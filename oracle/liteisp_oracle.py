@@ -1,0 +1,251 @@
+"""CPU oracle for the RAW->sRGB hot path (LiteISP family).   *** TEST INFRASTRUCTURE ***
+
+This file is a checker, never the thing measured or shipped.  Only tests/, __graft_entry__.smoke()
+and bench.py's `cpu_baseline` leg may import it.  The product path (realcamnet_amd/) never does; it
+raises if the HIP library is missing.
+
+What it is: a functional fp32 PyTorch-CPU restatement of the reference algorithm.  Every function
+takes the reference's *state_dict* (a plain ``{key: tensor}`` mapping -- the checkpoint contract,
+SURVEY.md section 8b) plus NCHW tensors, and cites the reference lines it follows
+(paths relative to the upstream repo kepengxu/RealCamNet @ 2024-10-20).
+
+Pinning: oracle/make_golden.py imports the real reference (build container only) and writes
+tests/golden/*.npz; tests/test_oracle_golden.py replays those fixtures through this file.  The
+reference ships no known-answer vectors of its own, so the fixtures generated
+from the imported reference are the pin.
+"""
+from __future__ import annotations
+
+import math
+from typing import Mapping, Sequence
+
+import torch
+import torch.nn.functional as F
+
+SD = Mapping[str, torch.Tensor]
+
+
+# ----------------------------------------------------------------------------------------------
+# a1 / a2  Bayer unshuffle, padding helpers
+# ----------------------------------------------------------------------------------------------
+def bayer_unshuffle(mosaic: torch.Tensor) -> torch.Tensor:
+    """(B,1,2H,2W) mosaic -> packed (B,4,H,W); channel k=2i+j <- pixel (2y+i, 2x+j).
+
+    Not in upstream code; defined by assets/networkarch.png ("Unpixel shuffle") and README.md:33-38.
+    Equivalent to F.pixel_unshuffle(mosaic, 2).
+    """
+    b, one, h2, w2 = mosaic.shape
+    assert one == 1 and h2 % 2 == 0 and w2 % 2 == 0
+    planes = [mosaic[:, 0, i::2, j::2] for i in (0, 1) for j in (0, 1)]
+    return torch.stack(planes, dim=1)
+
+
+def pad_to_multiple(x: torch.Tensor, mult: int = 16):
+    """Zero-pad bottom/right so H,W % mult == 0.  models/LiteISP.py:84-105 (mult=16 upstream)."""
+    h, w = x.shape[-2:]
+    ph, pw = (-h) % mult, (-w) % mult
+    return F.pad(x, (0, pw, 0, ph), value=0.0), (h, w)
+
+
+def remove_padding(y: torch.Tensor, orig_hw):
+    """Crop the 2x output back to 2*orig size.  models/LiteISP.py:108-128."""
+    h, w = orig_hw
+    return y[..., : min(2 * h, y.shape[-2]), : min(2 * w, y.shape[-1])]
+
+
+# ----------------------------------------------------------------------------------------------
+# a3  conv, a8-a9 channel attention / RCAB / RCAGroup, a10 Haar DWT
+# ----------------------------------------------------------------------------------------------
+def conv(sd: SD, p: str, x: torch.Tensor, pad: int | None = None) -> torch.Tensor:
+    """nn.Conv2d stride 1, zero padding k//2, + bias.  models/networks.py:146-160 (mode 'C')."""
+    w = sd[p + ".weight"]
+    b = sd.get(p + ".bias")
+    if pad is None:
+        pad = w.shape[-1] // 2
+    return F.conv2d(x, w, b, stride=1, padding=pad)
+
+
+def ca_layer(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """Channel attention: x * sigmoid(W1 relu(W0 mean_hw(x)+b0)+b1).  models/networks.py:255-270."""
+    y = x.mean(dim=(2, 3), keepdim=True)
+    y = torch.relu(conv(sd, p + ".conv_du.0", y))
+    y = torch.sigmoid(conv(sd, p + ".conv_du.2", y))
+    return x * y
+
+
+def rcab(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """x + CA(conv(relu(conv(x)))).  models/networks.py:296-311 (mode 'CRC')."""
+    r = conv(sd, p + ".res.2", torch.relu(conv(sd, p + ".res.0", x)))
+    return ca_layer(sd, p + ".ca", r) + x
+
+
+def rcag(sd: SD, p: str, x: torch.Tensor, nb: int = 4) -> torch.Tensor:
+    """nb RCABs + conv, plus group skip.  models/networks.py:317-335."""
+    r = x
+    for i in range(nb):
+        r = rcab(sd, f"{p}.rg.{i}", r)
+    return conv(sd, f"{p}.rg.{nb}", r) + x
+
+
+def dwt_forward(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """Haar analysis as a frozen grouped 2x2 stride-2 conv; taps live in the state_dict.
+    models/networks.py:224-235.  (B,C,h,w) -> (B,4C,h/2,w/2), channel 4c+k."""
+    return F.conv2d(x, sd[p + ".weight"], None, stride=2, groups=x.shape[1])
+
+
+def dwt_inverse(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """Haar synthesis as grouped 2x2 stride-2 transposed conv.  models/networks.py:238-249."""
+    return F.conv_transpose2d(x, sd[p + ".weight"], None, stride=2, groups=x.shape[1] // 4)
+
+
+def pixel_shuffle2(x: torch.Tensor) -> torch.Tensor:
+    """nn.PixelShuffle(2): out[b,c,2y+i,2x+j] = in[b,4c+2i+j,y,x].  models/networks.py:201-202."""
+    return F.pixel_shuffle(x, 2)
+
+
+# ----------------------------------------------------------------------------------------------
+# a5-a7  lens shading, colour prior, global feature modulation
+# ----------------------------------------------------------------------------------------------
+def lens_shading(sd: SD, p: str, coord: torch.Tensor) -> torch.Tensor:
+    """4x Conv1x1 with LeakyReLU(0.1) between.  models/LiteISP.py:363-378."""
+    h = coord
+    for i in (0, 2, 4):
+        h = F.leaky_relu(conv(sd, f"{p}.model.{i}", h), 0.1)
+    return conv(sd, f"{p}.model.6", h)
+
+
+def color_condition_gfm(sd: SD, p: str, cond: torch.Tensor) -> torch.Tensor:
+    """Global colour prior vector.  models/LiteISP.py:345-361, color_block :23-30.
+
+    5 x [Conv1x1 -> AvgPool(3,s2,p1,count_include_pad) -> LeakyReLU(0.2) -> InstanceNorm(affine)]
+    (no norm on the 5th), Dropout (identity in eval), Conv1x1 -> out_c, global average pool.
+    Returns (B, out_c) (the call site squeezes dims 2,3: models/LiteISP.py:2017).
+    """
+    h = cond
+    for blk in range(5):
+        i = 4 * blk
+        h = conv(sd, f"{p}.model.{i}", h)
+        h = F.avg_pool2d(h, 3, stride=2, padding=1, count_include_pad=True)
+        h = F.leaky_relu(h, 0.2)
+        if blk < 4:
+            h = F.instance_norm(h, weight=sd[f"{p}.model.{i + 3}.weight"], bias=sd[f"{p}.model.{i + 3}.bias"],
+                                use_input_stats=True, eps=1e-5)
+    h = conv(sd, f"{p}.model.20", h)
+    return h.mean(dim=(2, 3))
+
+
+def _gfm_vec(sd: SD, p: str, which: str, v: torch.Tensor) -> torch.Tensor:
+    h = F.leaky_relu(F.linear(v, sd[f"{p}.GFM_{which}_conv0.weight"], sd[f"{p}.GFM_{which}_conv0.bias"]), 0.1)
+    return F.linear(h, sd[f"{p}.GFM_{which}_conv1.weight"], sd[f"{p}.GFM_{which}_conv1.bias"])
+
+
+def res_gfm(sd: SD, p: str, x: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """GFT block: conv0 -> f*scale+shift+f -> LeakyReLU(0.01) -> conv1 + x.  models/LiteISP.py:537-559.
+    (nn.LeakyReLU default slope 0.01, :548.)"""
+    f = conv(sd, p + ".conv0", x)
+    c = f.shape[1]
+    s = _gfm_vec(sd, p, "scale", v).view(-1, c, 1, 1)
+    t = _gfm_vec(sd, p, "shift", v).view(-1, c, 1, 1)
+    f = f * s + t + f
+    f = F.leaky_relu(f, 0.01)
+    return conv(sd, p + ".conv1", f) + x
+
+
+# ----------------------------------------------------------------------------------------------
+# a12  full nets
+# ----------------------------------------------------------------------------------------------
+def _unet_trunk(sd: SD, h: torch.Tensor, v: torch.Tensor | None) -> torch.Tensor:
+    """Shared DWT U-Net body of LiteISPNet (models/LiteISP.py:2397-2409) and
+    LiteISPNet_GFM_LSC (:2019-2032); `v` is the GFM vector or None."""
+    def mod(i, t):
+        return res_gfm(sd, f"encoder_modulation{i}", t, v) if v is not None else t
+
+    h = mod(1, h)
+    d1 = conv(sd, "down1.0", h)
+    d1 = rcag(sd, "down1.1", d1)
+    d1 = conv(sd, "down1.2", d1)
+    d1 = dwt_forward(sd, "down1.3", d1)
+
+    d2 = mod(2, d1)
+    d2 = conv(sd, "down2.0", d2)
+    d2 = rcag(sd, "down2.1", d2)
+    d2 = dwt_forward(sd, "down2.2", d2)
+
+    d3 = mod(3, d2)
+    d3 = conv(sd, "down3.0", d3)
+    d3 = rcag(sd, "down3.1", d3)
+    d3 = dwt_forward(sd, "down3.2", d3)
+
+    m = mod(4, d3)
+    m = conv(sd, "middle.0", m)
+    m = rcag(sd, "middle.1", m)
+    m = rcag(sd, "middle.2", m)
+    m = conv(sd, "middle.3", m) + d3
+
+    u = dwt_inverse(sd, "up3.0", m)
+    u = rcag(sd, "up3.1", u)
+    u = conv(sd, "up3.2", u) + d2
+
+    u = dwt_inverse(sd, "up2.0", u)
+    u = rcag(sd, "up2.1", u)
+    u = conv(sd, "up2.2", u) + d1
+
+    u = dwt_inverse(sd, "up1.0", u)
+    u = rcag(sd, "up1.1", u)
+    u = conv(sd, "up1.2", u) + h
+
+    t = conv(sd, "tail.0", u)
+    t = pixel_shuffle2(t)
+    return conv(sd, "tail.2", t)
+
+
+def liteispnet(sd: SD, x: Sequence[torch.Tensor] | torch.Tensor) -> torch.Tensor:
+    """LiteISPNet.forward -- reads only x[0].  models/LiteISP.py:2385-2412."""
+    raw = x if isinstance(x, torch.Tensor) else x[0]
+    return _unet_trunk(sd, conv(sd, "head", raw), None)
+
+
+def liteispnet_gfm_lsc(sd: SD, x: Sequence[torch.Tensor]) -> torch.Tensor:
+    """LiteISPNet_GFM_LSC.forward, x=[raw(B,4,H,W), cond(B,4,h,w), coord(B,2,H,W)].
+    models/LiteISP.py:2002-2035."""
+    raw, cond, coord = x
+    h = conv(sd, "head", raw)
+    h = h * (lens_shading(sd, "lsc", coord) + 1)
+    v = color_condition_gfm(sd, "classifier", cond)
+    return _unet_trunk(sd, h, v)
+
+
+FORWARDS = {"LiteISPNet": liteispnet, "LiteISPNet_GFM_LSC": liteispnet_gfm_lsc}
+
+
+# ----------------------------------------------------------------------------------------------
+# helpers shared by tests / bench (input conventions of SURVEY.md section 8d)
+# ----------------------------------------------------------------------------------------------
+def make_coord(b: int, h: int, w: int) -> torch.Tensor:
+    """Normalised meshgrid (B,2,H,W) in [-1,1]: channel 0 = y, channel 1 = x (build convention,
+    upstream never published its coord generator)."""
+    ys = torch.linspace(-1.0, 1.0, h).view(1, 1, h, 1).expand(b, 1, h, w)
+    xs = torch.linspace(-1.0, 1.0, w).view(1, 1, 1, w).expand(b, 1, h, w)
+    return torch.cat([ys, xs], dim=1).contiguous()
+
+
+def psnr(test: torch.Tensor, ref: torch.Tensor) -> float:
+    """PSNR with peak = range of the reference output."""
+    ref = ref.double()
+    mse = torch.mean((test.double() - ref) ** 2).item()
+    peak = (ref.max() - ref.min()).item()
+    if mse == 0.0:
+        return float("inf")
+    return 10.0 * math.log10(peak * peak / mse)
+
+
+def run_padded(name: str, sd: SD, raw: torch.Tensor, cond=None, coord=None, mult: int = 16) -> torch.Tensor:
+    """Oracle forward with the reference padding convention (pad packed RAW (+coord) bottom/right
+    with zeros to a multiple of `mult`, crop the output to 2x the original size)."""
+    rp, hw = pad_to_multiple(raw, mult)
+    if name == "LiteISPNet":
+        out = liteispnet(sd, [rp])
+    else:
+        cp, _ = pad_to_multiple(coord, mult)
+        out = liteispnet_gfm_lsc(sd, [rp, cond, cp])
+    return remove_padding(out, hw)

@@ -1,0 +1,259 @@
+"""HIP-backed mirror of the reference ISP nets on the RAW->sRGB path (upstream models/LiteISP.py).
+
+Class names, constructor signatures, attribute names (=> state_dict keys) and forward() contracts
+follow the reference:
+    x = [raw (B,4,H,W), cond (B,4,h,w), coord (B,2,H,W)]  ->  sRGB (B,3,2H,2W)
+`forward` is the drop-in entry; `forward_mosaic` adds the ingest step the paper's figure shows in
+front of it (Bayer unshuffle + pad_to_multiple_of_16 + crop), which upstream never published.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import networks as N
+from . import ops
+from ._lib import RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2
+
+
+def color_block(in_filters, out_filters, normalization=False):
+    """Conv1x1 -> AvgPool(3,2,1) -> LeakyReLU(0.2) [-> InstanceNorm(affine)]; upstream LiteISP.py:23-30.
+    The pooling/activation/norm modules are structural (they pin the Sequential indices and hold the
+    affine parameters); execution is rc_color_block / rc_instance_stats."""
+    layers = [N.Conv2d(in_filters, out_filters, 1, stride=1, padding=0),
+              nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=True),
+              nn.LeakyReLU(0.2)]
+    if normalization:
+        layers.append(nn.InstanceNorm2d(out_filters, affine=True))
+    return layers
+
+
+def pad_to_multiple_of_16(x):
+    """Zero-pad NCHW x bottom/right to H,W % 16 == 0 (upstream LiteISP.py:84-105), on the device."""
+    b, c, h, w = x.shape
+    hp, wp = -(-h // 16) * 16, -(-w // 16) * 16
+    return ops.to_nchw(ops.to_nhwc(x, pad_hw=(hp, wp))), (h, w)
+
+
+def remove_padding(x_padded, original_size):
+    """Crop the 2x output to 2*orig (upstream LiteISP.py:108-128)."""
+    h, w = original_size
+    return x_padded[:, :, :min(2 * h, x_padded.shape[-2]), :min(2 * w, x_padded.shape[-1])]
+
+
+class Color_Condition_GFM(nn.Module):
+    """Global colour prior (upstream LiteISP.py:345-361)."""
+
+    def __init__(self, in_channels=4, out_c=32):
+        super().__init__()
+        self.model = nn.Sequential(
+            *color_block(in_channels, 16, normalization=True),
+            *color_block(16, 32, normalization=True),
+            *color_block(32, 64, normalization=True),
+            *color_block(64, 128, normalization=True),
+            *color_block(128, 128),
+            nn.Dropout(p=0.5),
+            N.Conv2d(128, out_c, 1, stride=1, padding=0),
+            nn.AdaptiveAvgPool2d(1),
+        )
+
+    def _vec(self, cond: torch.Tensor) -> torch.Tensor:
+        """(B,4,h,w) NCHW cond image -> (B,out_c) fp32 vector; eval semantics (Dropout = identity)."""
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        m = self.model
+        x, norm, stats = cond, None, None
+        for blk in range(5):
+            i = 4 * blk
+            x = ops.color_block(x, m[i], norm, stats)
+            if blk < 4:
+                norm = m[i + 3]
+                stats = ops.instance_stats(x, norm.eps)
+            else:
+                norm, stats = None, None
+        return ops.color_head(x, m[20])
+
+    def forward(self, img_input):
+        v = self._vec(img_input)
+        return v.to(img_input.dtype).view(v.shape[0], v.shape[1], 1, 1)
+
+
+class Lens_Shading_Correction(N.HipModule):
+    """4x Conv1x1 with LeakyReLU(0.1) between (upstream LiteISP.py:363-378)."""
+
+    def __init__(self, in_channels=2, out_c=32, nf=32):
+        super().__init__()
+        self.model = N.Sequential(
+            N.Conv2d(in_channels, nf, 1, 1),
+            nn.LeakyReLU(negative_slope=0.1, inplace=True),
+            N.Conv2d(nf, nf, 1, 1),
+            nn.LeakyReLU(negative_slope=0.1, inplace=True),
+            N.Conv2d(nf, nf, 1, 1),
+            nn.LeakyReLU(negative_slope=0.1, inplace=True),
+            N.Conv2d(nf, out_c, 1, 1),
+        )
+
+    def _nhwc(self, a):
+        return self.model._nhwc(a)
+
+
+class Res_GFM(nn.Module):
+    """GFT block (upstream LiteISP.py:537-559): conv0 -> f*scale+shift+f -> LeakyReLU(0.01) -> conv1 + x.
+    Tuple in / tuple out so it chains inside Sequential like upstream."""
+
+    def __init__(self, in_nc=32, chan=32, cond_c=32, out_nc=32, nf=64):
+        super().__init__()
+        self.conv0 = N.Conv2d(in_nc, chan, 3, 1, 1)
+        self.conv1 = N.Conv2d(chan, chan, 3, 1, 1)
+        self.GFM_scale_conv0 = nn.Linear(cond_c, nf)
+        self.GFM_scale_conv1 = nn.Linear(nf, chan)
+        self.GFM_shift_conv0 = nn.Linear(cond_c, nf)
+        self.GFM_shift_conv1 = nn.Linear(nf, chan)
+        self.out_nc = chan
+        self.act = nn.LeakyReLU(inplace=True)
+
+    def _nhwc(self, x):
+        a, vec = x
+        scale = ops.gfm_vector(vec, self.GFM_scale_conv0, self.GFM_scale_conv1)
+        shift = ops.gfm_vector(vec, self.GFM_shift_conv0, self.GFM_shift_conv1)
+        f = self.conv0._nhwc(a, film=(scale, shift), act="leaky", slope=float(self.act.negative_slope))
+        return self.conv1._nhwc(f, residual=a), vec
+
+    def forward(self, x):
+        y, vec = self._nhwc((ops.to_nhwc(x[0]), x[1]))
+        return ops.to_nchw(y), vec
+
+
+class _DwtUNet(nn.Module):
+    """Shared trunk of LiteISPNet / LiteISPNet_GFM_LSC (upstream LiteISP.py:2019-2032, 2397-2409)."""
+
+    output_dtype: Optional[torch.dtype] = None  # None: same as the parameters (reference semantics)
+
+    def _act_dtype(self) -> torch.dtype:
+        return self.head.weight.dtype
+
+    def _check(self, raw):
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        if raw.dim() != 4 or raw.shape[1] != 4:
+            raise ValueError(f"raw must be (B,4,H,W), got {tuple(raw.shape)}")
+        if raw.shape[2] % 8 or raw.shape[3] % 8:
+            raise ValueError(f"packed RAW H,W must be multiples of 8 (3 Haar levels), got {raw.shape[2]}x{raw.shape[3]}; "
+                             "use forward_mosaic()/pad_to_multiple_of_16 for other sizes")
+
+    def _trunk(self, h, vec, crop_hw=None):
+        mod = (lambda i, t: getattr(self, f"encoder_modulation{i}")._nhwc((t, vec))[0]) if vec is not None else (lambda i, t: t)
+        h = mod(1, h)
+        d1 = self.down1._nhwc(h)
+        d2 = self.down2._nhwc(mod(2, d1))
+        d3 = self.down3._nhwc(mod(3, d2))
+        m = self.middle._nhwc(mod(4, d3), residual=d3)
+        u3 = self.up3._nhwc(m, residual=d2)
+        u2 = self.up2._nhwc(u3, residual=d1)
+        u1 = self.up1._nhwc(u2, residual=h)
+        t = self.tail[0]._nhwc(u1, out_mode=RC_OUT_PIXEL_SHUFFLE2)
+        return self.tail[2]._nhwc(t, out_mode=RC_OUT_NCHW, crop_hw=crop_hw, out_dtype=self.output_dtype)
+
+
+class LiteISPNet(_DwtUNet):
+    """upstream LiteISP.py:2322-2412 (reads only x[0])."""
+
+    def __init__(self):
+        super().__init__()
+        ch_1, ch_2, ch_3, n_blocks = 64, 128, 128, 4
+        self.head = N.seq(N.conv(4, ch_1, mode='C'))
+        self.down1 = N.seq(N.conv(ch_1, ch_1, mode='C'), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
+                           N.conv(ch_1, ch_1, mode='C'), N.DWTForward(ch_1))
+        self.down2 = N.seq(N.conv(ch_1 * 4, ch_1, mode='C'), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
+                           N.DWTForward(ch_1))
+        self.down3 = N.seq(N.conv(ch_1 * 4, ch_2, mode='C'), N.RCAGroup(in_channels=ch_2, out_channels=ch_2, nb=n_blocks),
+                           N.DWTForward(ch_2))
+        self.middle = N.seq(N.conv(ch_2 * 4, ch_3, mode='C'), N.RCAGroup(in_channels=ch_3, out_channels=ch_3, nb=n_blocks),
+                            N.RCAGroup(in_channels=ch_3, out_channels=ch_3, nb=n_blocks), N.conv(ch_3, ch_2 * 4, mode='C'))
+        self.up3 = N.seq(N.DWTInverse(ch_2 * 4), N.RCAGroup(in_channels=ch_2, out_channels=ch_2, nb=n_blocks),
+                         N.conv(ch_2, ch_1 * 4, mode='C'))
+        self.up2 = N.seq(N.DWTInverse(ch_1 * 4), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
+                         N.conv(ch_1, ch_1 * 4, mode='C'))
+        self.up1 = N.seq(N.DWTInverse(ch_1 * 4), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
+                         N.conv(ch_1, ch_1, mode='C'))
+        self.tail = N.seq(N.conv(ch_1, ch_1 * 4, mode='C'), nn.PixelShuffle(upscale_factor=2), N.conv(ch_1, 3, mode='C'))
+
+    def forward(self, x):
+        raw = x if isinstance(x, torch.Tensor) else x[0]
+        self._check(raw)
+        a = ops.to_nhwc(raw, dtype=self._act_dtype())
+        return self._trunk(self.head._nhwc(a), None)
+
+    def forward_mosaic(self, mosaic, cond=None, coord=None, pad_to: int = 16):
+        """Bayer mosaic (B,1,2h,2w) -> sRGB (B,3,2h,2w): unshuffle + zero-pad to `pad_to`, net, crop."""
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        a = ops.bayer_unshuffle(mosaic, dtype=self._act_dtype(), pad_to=pad_to)
+        return self._trunk(self.head._nhwc(a), None, crop_hw=(mosaic.shape[-2], mosaic.shape[-1]))
+
+
+class LiteISPNet_GFM_LSC(_DwtUNet):
+    """upstream LiteISP.py:1924-2035 -- the net the reference's __main__ builds."""
+
+    def __init__(self):
+        super().__init__()
+        ch_1, ch_2, ch_3, n_blocks, cond_c = 48, 128, 128, 4, 32
+        self.classifier = Color_Condition_GFM(in_channels=4, out_c=cond_c)
+        modulation_blocks = 1
+        self.head = N.seq(N.conv(4, ch_1, mode='C'))
+        self.lsc = Lens_Shading_Correction(in_channels=2, out_c=ch_1, nf=ch_1)
+        self.encoder_modulation1 = N.seq(*[Res_GFM(in_nc=ch_1, chan=ch_1, cond_c=cond_c, out_nc=ch_1, nf=ch_1)
+                                           for _ in range(modulation_blocks)])
+        self.down1 = N.seq(N.conv(ch_1, ch_1, mode='C'), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
+                           N.conv(ch_1, ch_1, mode='C'), N.DWTForward(ch_1))
+        self.encoder_modulation2 = N.seq(*[Res_GFM(in_nc=ch_1 * 4, chan=ch_1 * 4, cond_c=cond_c, out_nc=ch_1 * 4, nf=ch_1)
+                                           for _ in range(modulation_blocks)])
+        self.down2 = N.seq(N.conv(ch_1 * 4, ch_1, mode='C'), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
+                           N.DWTForward(ch_1))
+        self.encoder_modulation3 = N.seq(*[Res_GFM(in_nc=ch_1 * 4, chan=ch_1 * 4, cond_c=cond_c, out_nc=ch_1 * 4, nf=ch_1)
+                                           for _ in range(modulation_blocks)])
+        self.down3 = N.seq(N.conv(ch_1 * 4, ch_2, mode='C'), N.RCAGroup(in_channels=ch_2, out_channels=ch_2, nb=n_blocks),
+                           N.DWTForward(ch_2))
+        self.encoder_modulation4 = N.seq(*[Res_GFM(in_nc=ch_2 * 4, chan=ch_2 * 4, cond_c=cond_c, out_nc=ch_2 * 4, nf=ch_2)
+                                           for _ in range(modulation_blocks)])
+        self.middle = N.seq(N.conv(ch_2 * 4, ch_3, mode='C'), N.RCAGroup(in_channels=ch_3, out_channels=ch_3, nb=n_blocks),
+                            N.RCAGroup(in_channels=ch_3, out_channels=ch_3, nb=n_blocks), N.conv(ch_3, ch_2 * 4, mode='C'))
+        self.up3 = N.seq(N.DWTInverse(ch_2 * 4), N.RCAGroup(in_channels=ch_2, out_channels=ch_2, nb=n_blocks),
+                         N.conv(ch_2, ch_1 * 4, mode='C'))
+        self.up2 = N.seq(N.DWTInverse(ch_1 * 4), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
+                         N.conv(ch_1, ch_1 * 4, mode='C'))
+        self.up1 = N.seq(N.DWTInverse(ch_1 * 4), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
+                         N.conv(ch_1, ch_1, mode='C'))
+        self.tail = N.seq(N.conv(ch_1, ch_1 * 4, mode='C'), nn.PixelShuffle(upscale_factor=2), N.conv(ch_1, 3, mode='C'))
+
+    def _front(self, a, cond, coord_nhwc):
+        lsc = self.lsc._nhwc(coord_nhwc)
+        h = self.head._nhwc(a, mul_plus1=lsc)           # h = head(raw) * (lsc + 1)
+        vec = self.classifier._vec(ops._req(cond, "cond"))
+        return h, vec
+
+    def forward(self, x: Sequence[torch.Tensor]):
+        raw, cond, coord = x[0], x[1], x[2]
+        self._check(raw)
+        if coord.shape[0] != raw.shape[0] or coord.shape[1] != 2 or coord.shape[2:] != raw.shape[2:]:
+            raise ValueError(f"coord must be (B,2,H,W) matching raw, got {tuple(coord.shape)}")
+        dt = self._act_dtype()
+        h, vec = self._front(ops.to_nhwc(raw, dtype=dt), cond, ops.to_nhwc(coord, dtype=dt))
+        return self._trunk(h, vec)
+
+    def forward_mosaic(self, mosaic, cond, coord, pad_to: int = 16):
+        """Bayer mosaic (B,1,2h,2w), cond (B,4,hc,wc), coord (B,2,h,w) -> sRGB (B,3,2h,2w).
+        RAW and coord are zero-padded bottom/right to a multiple of `pad_to` (reference convention,
+        upstream LiteISP.py:84-105) and the output is cropped back."""
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        dt = self._act_dtype()
+        a = ops.bayer_unshuffle(mosaic, dtype=dt, pad_to=pad_to)
+        b, hp, wp, _ = a.shape
+        if coord.shape[-2:] != (mosaic.shape[-2] // 2, mosaic.shape[-1] // 2):
+            raise ValueError("coord must be at packed resolution (h, w)")
+        co = ops.to_nhwc(coord, dtype=dt, pad_hw=(hp, wp))
+        h, vec = self._front(a, cond, co)
+        return self._trunk(h, vec, crop_hw=(mosaic.shape[-2], mosaic.shape[-1]))

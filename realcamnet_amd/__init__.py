@@ -1,0 +1,10 @@
+"""realcamnet_amd -- MI355X (gfx950) native RAW->sRGB learned-ISP inference path.
+
+Host-side mirror of the reference interface (kepengxu/RealCamNet models/networks.py, models/LiteISP.py)
+over the C ABI in include/realcam_hip.h (librealcam_hip.so, hand-written HIP).  No CPU fallback.
+"""
+from . import networks  # noqa: F401
+from . import LiteISP  # noqa: F401
+from .LiteISP import LiteISPNet, LiteISPNet_GFM_LSC  # noqa: F401
+
+__all__ = ["networks", "LiteISP", "LiteISPNet", "LiteISPNet_GFM_LSC"]

@@ -1,0 +1,106 @@
+"""ctypes binding of librealcam_hip.so (include/realcam_hip.h).
+
+There is no CPU fallback: if the library is missing or does not export a declared symbol the import
+fails loudly, and every op refuses non-CUDA tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "librealcam_hip.so"
+HEADER = PKG.parent / "include" / "realcam_hip.h"
+
+RC_F32, RC_BF16 = 0, 1
+RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY = 0, 1, 2
+RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW = 0, 1, 2
+ABI_VERSION = 1
+
+
+class ConvDesc(C.Structure):
+    """Mirror of `struct rc_conv_desc` -- field order and types must match the header exactly."""
+    _fields_ = [
+        ("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+        ("cin", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32),
+        ("dtype", C.c_int32),
+        ("in0", C.c_void_p), ("in1", C.c_void_p), ("in_gate", C.c_void_p), ("in_store", C.c_void_p),
+        ("wpacked", C.c_void_p), ("bias", C.c_void_p),
+        ("film_scale", C.c_void_p), ("film_shift", C.c_void_p),
+        ("act", C.c_int32), ("act_slope", C.c_float),
+        ("mul_plus1", C.c_void_p), ("residual", C.c_void_p),
+        ("out", C.c_void_p), ("out_mode", C.c_int32), ("out_dtype", C.c_int32),
+        ("out_h", C.c_int32), ("out_w", C.c_int32),
+        ("chan_sums", C.c_void_p),
+    ]
+
+
+def declared_symbols() -> list[str]:
+    """Every function the public header declares (used by the CPU-side ABI test)."""
+    text = HEADER.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rc_[a-z0-9_]+)\s*\(", text)))
+
+
+_P, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_SIGS = {
+    "rc_abi_version": (C.c_int, []),
+    "rc_last_error": (C.c_char_p, []),
+    "rc_build_info": (C.c_char_p, []),
+    "rc_device_arch": (C.c_int, [C.c_char_p, _SZ]),
+    "rc_bayer_unshuffle": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "rc_nchw_to_nhwc": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "rc_nhwc_to_nchw": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "rc_conv_packed_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "rc_conv_pack_weights": (C.c_int, [_P, _I, _I, _I, _I, _I, _P]),
+    "rc_conv_packed_cout": (C.c_int, [_I, _I, _I, _I, _I]),
+    "rc_conv_pack_bias": (C.c_int, [_P, _I, _I, _I, _I, _I, _P]),
+    "rc_conv_sum_tiles": (C.c_int, [_I, _I]),
+    "rc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _P]),
+    "rc_ca_gate": (C.c_int, [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
+    "rc_gate_residual": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rc_dwt_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rc_dwt_inverse": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rc_color_block": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "rc_instance_stats": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P]),
+    "rc_color_head": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "rc_gfm_vector": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "rc_prof_enable": (C.c_int, [_I]),
+    "rc_prof_collect": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m realcamnet_amd.build` (hipcc, gfx950). "
+            "There is no CPU / PyTorch fallback for the HIP path.")
+    lib = C.CDLL(os.fspath(LIB_PATH))
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{LIB_PATH.name} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.rc_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"ABI mismatch: library {lib.rc_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = load().rc_last_error().decode(errors="replace")
+        raise HipError(f"{what or 'librealcam_hip'} failed ({code}): {msg}")

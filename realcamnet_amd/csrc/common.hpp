@@ -1,0 +1,93 @@
+// Shared host/device helpers for librealcam_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/realcam_hip.h"
+
+namespace rc {
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define RC_HIP_CHECK(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return ::rc::fail(RC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define RC_REQUIRE(cond, msg)                                             \
+    do {                                                                  \
+        if (!(cond)) return ::rc::fail(RC_ERR_INVALID, std::string(msg)); \
+    } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- element types ------------------------------------------------------------------------------
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct dtype_of;
+template <> struct dtype_of<float> { static constexpr int value = RC_F32; };
+template <> struct dtype_of<bf16_t> { static constexpr int value = RC_BF16; };
+
+__host__ __device__ inline size_t dtype_size(int dt) { return dt == RC_F32 ? 4 : 2; }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return static_cast<float>(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return static_cast<T>(v); }
+
+// 16-byte vector of T viewed as floats and back (UNIT = 16/sizeof(T) elements).
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    __device__ static __forceinline__ void unpack(const uint4& raw, float* f) {
+        f[0] = __uint_as_float(raw.x); f[1] = __uint_as_float(raw.y);
+        f[2] = __uint_as_float(raw.z); f[3] = __uint_as_float(raw.w);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void unpack(const uint4& raw, float* f) {
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ static __forceinline__ uint32_t rne(float v) {  // fp32 -> bf16 bits, round-nearest-even
+        return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, static_cast<bf16_t>(v)));
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = rne(f[2 * i]) | (rne(f[2 * i + 1]) << 16);
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+__host__ inline uint16_t host_f32_to_bf16(float f) {  // round-nearest-even, NaN preserved
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return static_cast<uint16_t>(u >> 16);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    if (act == RC_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == RC_ACT_LEAKY) return v > 0.f ? v : v * slope;
+    return v;
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace rc

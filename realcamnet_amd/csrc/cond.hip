@@ -1,0 +1,222 @@
+// Small conditioning kernels: CALayer gate, Color_Condition_GFM (global colour prior), GFM vector
+// MLPs.  None of them is on the FLOP or byte budget (a few hundred KB per frame); what matters is
+// that every reduction uses a fixed order (no float atomics) so results are run-to-run bitwise
+// stable, and that they stay on the launch stream without host syncs.
+#include "common.hpp"
+
+namespace rc {
+
+// ---- CALayer gate: fixed-order reduction of the conv's per-tile channel sums + 2-layer MLP -------
+__global__ __launch_bounds__(256) void ca_gate_kernel(const float* __restrict__ sums, int n_tiles, int c, int cr,
+                                                      float inv_hw, const float* __restrict__ w0,
+                                                      const float* __restrict__ b0, const float* __restrict__ w1,
+                                                      const float* __restrict__ b1, float* __restrict__ gate) {
+    extern __shared__ float sm[];          // [256] partials | [c] mean | [cr] hidden
+    float* part = sm;
+    float* mean = sm + 256;
+    float* hid = mean + c;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* s = sums + (size_t)b * n_tiles * c;
+    for (int c0 = 0; c0 < c; c0 += 256) {
+        const int cw = (c - c0) < 256 ? (c - c0) : 256;   // channels in this pass
+        const int nparts = 256 / cw;                       // >= 1
+        const int ch = tid % cw, pt = tid / cw;
+        float acc = 0.f;
+        if (pt < nparts)
+            for (int t = pt; t < n_tiles; t += nparts) acc += s[(size_t)t * c + c0 + ch];
+        part[tid] = acc;
+        __syncthreads();
+        if (tid < cw) {
+            float tot = 0.f;
+            for (int p = 0; p < nparts; ++p) tot += part[p * cw + tid];
+            mean[c0 + tid] = tot * inv_hw;
+        }
+        __syncthreads();
+    }
+    for (int j = tid; j < cr; j += 256) {
+        float h = b0[j];
+        for (int k = 0; k < c; ++k) h += w0[(size_t)j * c + k] * mean[k];
+        hid[j] = h > 0.f ? h : 0.f;
+    }
+    __syncthreads();
+    for (int k = tid; k < c; k += 256) {
+        float z = b1[k];
+        for (int j = 0; j < cr; ++j) z += w1[(size_t)k * cr + j] * hid[j];
+        gate[(size_t)b * c + k] = 1.f / (1.f + expf(-z));
+    }
+}
+
+// ---- color_block: conv1x1 -> avgpool(3, s2, p1, count_include_pad) -> LeakyReLU(0.2) -------------
+// x NCHW (B,cin,h,w), optionally instance-normalised on load; y fp32 NCHW (B,cout,ho,wo).
+template <typename TI>
+__global__ void color_block_kernel(const TI* __restrict__ x, float* __restrict__ y, int batch, int cin, int cout,
+                                   int h, int w, int ho, int wo, const float* __restrict__ wgt,
+                                   const float* __restrict__ bias, const float* __restrict__ in_mean,
+                                   const float* __restrict__ in_rstd, const float* __restrict__ in_gamma,
+                                   const float* __restrict__ in_beta) {
+    const size_t total = (size_t)batch * cout * ho * wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % wo), oy = (int)((i / wo) % ho);
+        const int co = (int)((i / ((size_t)wo * ho)) % cout);
+        const int b = (int)(i / ((size_t)wo * ho * cout));
+        float pooled = 0.f;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = 2 * oy + dy;
+            if (yy < 0 || yy >= h) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = 2 * ox + dx;
+                if (xx < 0 || xx >= w) continue;
+                float acc = bias[co];
+                for (int ci = 0; ci < cin; ++ci) {
+                    float v = to_f32(x[(((size_t)b * cin + ci) * h + yy) * w + xx]);
+                    if (in_mean != nullptr) {
+                        const size_t k = (size_t)b * cin + ci;
+                        v = (v - in_mean[k]) * in_rstd[k] * in_gamma[ci] + in_beta[ci];
+                    }
+                    acc += wgt[(size_t)co * cin + ci] * v;
+                }
+                pooled += acc;
+            }
+        }
+        pooled *= (1.f / 9.f);  // count_include_pad=True: padded positions contribute 0, divisor stays 9
+        y[i] = pooled > 0.f ? pooled : 0.2f * pooled;
+    }
+}
+
+// ---- InstanceNorm statistics: per (b,c) mean and rstd (biased variance), two-pass, fixed order ----
+__global__ __launch_bounds__(256) void instance_stats_kernel(const float* __restrict__ x, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, int hw, float eps) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const float* p = x + (size_t)blockIdx.x * hw;
+    float s = 0.f;
+    for (int i = tid; i < hw; i += 256) s += p[i];
+    red[tid] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] += red[tid + k]; __syncthreads(); }
+    const float m = red[0] / (float)hw;
+    __syncthreads();
+    float v = 0.f;
+    for (int i = tid; i < hw; i += 256) { const float d = p[i] - m; v += d * d; }
+    red[tid] = v;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] += red[tid + k]; __syncthreads(); }
+    if (tid == 0) {
+        mean[blockIdx.x] = m;
+        rstd[blockIdx.x] = 1.f / sqrtf(red[0] / (float)hw + eps);
+    }
+}
+
+// ---- closing Conv1x1 + AdaptiveAvgPool2d(1): vec[b][o] = mean_p (sum_ci w[o][ci] x[b][ci][p] + b[o]) ----
+__global__ __launch_bounds__(256) void color_head_kernel(const float* __restrict__ x, float* __restrict__ vec, int cin,
+                                                         int cout, int hw, const float* __restrict__ wgt,
+                                                         const float* __restrict__ bias) {
+    __shared__ float red[256];
+    const int b = blockIdx.x / cout, o = blockIdx.x % cout, tid = threadIdx.x;
+    float s = 0.f;
+    for (int p = tid; p < hw; p += 256) {
+        float acc = bias[o];
+        for (int ci = 0; ci < cin; ++ci) acc += wgt[(size_t)o * cin + ci] * x[((size_t)b * cin + ci) * hw + p];
+        s += acc;
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (tid < k) red[tid] += red[tid + k]; __syncthreads(); }
+    if (tid == 0) vec[(size_t)b * cout + o] = red[0] / (float)hw;
+}
+
+// ---- GFM vector MLP: out[b] = W1 * leaky_relu(W0 * vec[b] + b0, 0.1) + b1 ------------------------
+__global__ __launch_bounds__(256) void gfm_vector_kernel(const float* __restrict__ vec, int cond_c, int nf, int c,
+                                                         const float* __restrict__ w0, const float* __restrict__ b0,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         float* __restrict__ out) {
+    extern __shared__ float sm[];  // [cond_c] vec | [nf] hidden
+    float* v = sm;
+    float* hid = sm + cond_c;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < cond_c; k += 256) v[k] = vec[(size_t)b * cond_c + k];
+    __syncthreads();
+    for (int j = tid; j < nf; j += 256) {
+        float h = b0[j];
+        for (int k = 0; k < cond_c; ++k) h += w0[(size_t)j * cond_c + k] * v[k];
+        hid[j] = h > 0.f ? h : 0.1f * h;
+    }
+    __syncthreads();
+    for (int k = tid; k < c; k += 256) {
+        float z = b1[k];
+        for (int j = 0; j < nf; ++j) z += w1[(size_t)k * nf + j] * hid[j];
+        out[(size_t)b * c + k] = z;
+    }
+}
+
+}  // namespace rc
+
+using namespace rc;
+
+extern "C" {
+
+int rc_ca_gate(const float* d_sums, int batch, int n_tiles, int c, int cr, float inv_hw,
+               const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,
+               float* d_gate, void* stream) {
+    RC_REQUIRE(d_sums && d_w0 && d_b0 && d_w1 && d_b1 && d_gate, "rc_ca_gate: null pointer");
+    RC_REQUIRE(batch >= 1 && n_tiles >= 1 && c >= 1 && cr >= 1, "rc_ca_gate: bad shape");
+    const size_t lds = (256 + (size_t)c + cr) * sizeof(float);
+    RC_REQUIRE(lds <= 64 * 1024, "rc_ca_gate: too many channels");
+    hipLaunchKernelGGL(ca_gate_kernel, dim3(batch), dim3(256), lds, as_stream(stream), d_sums, n_tiles, c, cr, inv_hw,
+                       d_w0, d_b0, d_w1, d_b1, d_gate);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_color_block(const void* d_x, int x_dtype, float* d_y, int batch, int cin, int cout, int h, int w,
+                   const float* d_w, const float* d_b, const float* d_in_mean, const float* d_in_rstd,
+                   const float* d_in_gamma, const float* d_in_beta, void* stream) {
+    RC_REQUIRE(d_x && d_y && d_w && d_b, "rc_color_block: null pointer");
+    RC_REQUIRE(batch >= 1 && cin >= 1 && cout >= 1 && h >= 1 && w >= 1, "rc_color_block: bad shape");
+    RC_REQUIRE(x_dtype == RC_F32 || x_dtype == RC_BF16, "rc_color_block: bad dtype");
+    if (d_in_mean) RC_REQUIRE(d_in_rstd && d_in_gamma && d_in_beta, "rc_color_block: incomplete InstanceNorm arguments");
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+    const size_t total = (size_t)batch * cout * ho * wo;
+    size_t g = (total + 255) / 256; if (g > 65535) g = 65535;
+    if (x_dtype == RC_F32)
+        hipLaunchKernelGGL(color_block_kernel<float>, dim3((unsigned)g), dim3(256), 0, as_stream(stream),
+                           static_cast<const float*>(d_x), d_y, batch, cin, cout, h, w, ho, wo, d_w, d_b,
+                           d_in_mean, d_in_rstd, d_in_gamma, d_in_beta);
+    else
+        hipLaunchKernelGGL(color_block_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_x), d_y, batch, cin, cout, h, w, ho, wo, d_w, d_b,
+                           d_in_mean, d_in_rstd, d_in_gamma, d_in_beta);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_instance_stats(const float* d_x, float* d_mean, float* d_rstd, int batch, int c, int hw, float eps, void* stream) {
+    RC_REQUIRE(d_x && d_mean && d_rstd, "rc_instance_stats: null pointer");
+    RC_REQUIRE(batch >= 1 && c >= 1 && hw >= 1, "rc_instance_stats: bad shape");
+    hipLaunchKernelGGL(instance_stats_kernel, dim3(batch * c), dim3(256), 0, as_stream(stream), d_x, d_mean, d_rstd, hw, eps);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_color_head(const float* d_x, float* d_vec, int batch, int cin, int cout, int hw,
+                  const float* d_w, const float* d_b, void* stream) {
+    RC_REQUIRE(d_x && d_vec && d_w && d_b, "rc_color_head: null pointer");
+    RC_REQUIRE(batch >= 1 && cin >= 1 && cout >= 1 && hw >= 1, "rc_color_head: bad shape");
+    hipLaunchKernelGGL(color_head_kernel, dim3(batch * cout), dim3(256), 0, as_stream(stream), d_x, d_vec, cin, cout, hw, d_w, d_b);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_gfm_vector(const float* d_vec, int batch, int cond_c, int nf, int c, const float* d_w0, const float* d_b0,
+                  const float* d_w1, const float* d_b1, float* d_out, void* stream) {
+    RC_REQUIRE(d_vec && d_w0 && d_b0 && d_w1 && d_b1 && d_out, "rc_gfm_vector: null pointer");
+    RC_REQUIRE(batch >= 1 && cond_c >= 1 && nf >= 1 && c >= 1, "rc_gfm_vector: bad shape");
+    const size_t lds = ((size_t)cond_c + nf) * sizeof(float);
+    RC_REQUIRE(lds <= 64 * 1024, "rc_gfm_vector: vector too long");
+    hipLaunchKernelGGL(gfm_vector_kernel, dim3(batch), dim3(256), lds, as_stream(stream), d_vec, cond_c, nf, c, d_w0, d_b0,
+                       d_w1, d_b1, d_out);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+}  // extern "C"

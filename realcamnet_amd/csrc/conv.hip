@@ -1,0 +1,214 @@
+// Host side of the MFMA convolution: config selection, weight/bias re-packing, launch, timing hooks.
+#include <mutex>
+#include <vector>
+
+#include "conv_kernel.hpp"
+
+namespace rc {
+
+struct ConvPlan {
+    int ck = 0, nt = 0, unit = 0, upt = 0, nu = 0, steps = 0;
+    int n_chunks = 0, n_ct = 0, cout_packed = 0;
+};
+
+// Must mirror ConvCfg<> (static_asserts in check_plan_consistency below keep them in lock-step).
+static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, ConvPlan* p) {
+    if (cin < 1 || cout < 1 || (ksize != 1 && ksize != 3)) return false;
+    if (dtype != RC_F32 && dtype != RC_BF16) return false;
+    p->unit = dtype == RC_F32 ? 4 : 8;
+    if (dtype == RC_BF16) {
+        if (cin <= 8) p->ck = 8;
+        else if (cin % 64 == 0) p->ck = 64;
+        else if (cin % 48 == 0) p->ck = 48;
+        else p->ck = 16;
+    } else {
+        p->ck = cin <= 4 ? 4 : 16;
+    }
+    if (cout % 64 == 0) p->nt = 4;
+    else if (cout % 48 == 0) p->nt = 3;
+    else p->nt = 1;
+    if (out_mode == RC_OUT_PIXEL_SHUFFLE2 && (cout % (16 * p->nt) != 0)) return false;
+    p->upt = p->ck / p->unit;
+    p->nu = ksize * ksize * p->upt;
+    p->steps = (p->nu + 3) / 4;
+    p->n_chunks = ceil_div(cin, p->ck);
+    p->n_ct = ceil_div(cout, 16 * p->nt);
+    p->cout_packed = p->n_ct * 16 * p->nt;
+    return true;
+}
+
+// packed cout index j -> conv output channel (or -1 for padding rows)
+static int packed_to_cout(const ConvPlan& p, int cout, int out_mode, int j) {
+    if (out_mode == RC_OUT_PIXEL_SHUFFLE2) {
+        const int nv = 4 * p.nt;
+        const int t = j / (16 * p.nt), qq = (j / nv) % 4, e = j % nv;
+        return 4 * (t * nv + e) + qq;  // out channel t*nv+e, sub-pixel qq = 2i+j
+    }
+    return j < cout ? j : -1;
+}
+
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+struct ProfRec { hipEvent_t e0, e1; double flops; };
+static std::vector<ProfRec> g_prof;
+
+}  // namespace rc
+
+using namespace rc;
+
+extern "C" {
+
+size_t rc_conv_packed_bytes(int cin, int cout, int ksize, int dtype, int out_mode) {
+    ConvPlan p;
+    if (!make_plan(cin, cout, ksize, dtype, out_mode, &p)) { set_error("rc_conv_packed_bytes: bad shape"); return 0; }
+    return (size_t)p.n_ct * p.n_chunks * p.steps * p.nt * 1024;
+}
+
+int rc_conv_packed_cout(int cin, int cout, int ksize, int dtype, int out_mode) {
+    ConvPlan p;
+    if (!make_plan(cin, cout, ksize, dtype, out_mode, &p)) return fail(RC_ERR_INVALID, "rc_conv_packed_cout: bad shape");
+    return p.cout_packed;
+}
+
+int rc_conv_pack_weights(const float* w, int cin, int cout, int ksize, int dtype, int out_mode, void* dst) {
+    ConvPlan p;
+    RC_REQUIRE(w && dst, "rc_conv_pack_weights: null pointer");
+    RC_REQUIRE(make_plan(cin, cout, ksize, dtype, out_mode, &p), "rc_conv_pack_weights: bad shape");
+    const int kk = ksize * ksize;
+    char* out = static_cast<char*>(dst);
+    // layout: [ct][chunk][step][nt][lane 0..63][UNIT elements]   (16 bytes per lane)
+    for (int ct = 0; ct < p.n_ct; ++ct)
+        for (int chunk = 0; chunk < p.n_chunks; ++chunk)
+            for (int s = 0; s < p.steps; ++s)
+                for (int nt = 0; nt < p.nt; ++nt)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int m = lane & 15, qk = lane >> 4;
+                        const int u = 4 * s + qk;
+                        // MFMA row m of cout tile nt lands in lane group m>>2, register m&3
+                        const int j = ct * 16 * p.nt + (m >> 2) * (4 * p.nt) + nt * 4 + (m & 3);
+                        const int co = packed_to_cout(p, cout, out_mode, j);
+                        for (int e = 0; e < p.unit; ++e) {
+                            float val = 0.f;
+                            if (u < p.nu && co >= 0 && co < cout) {
+                                const int tap = u / p.upt, cu = u % p.upt;
+                                const int ci = chunk * p.ck + cu * p.unit + e;
+                                if (ci < cin) val = w[((size_t)co * cin + ci) * kk + tap];
+                            }
+                            if (dtype == RC_F32) {
+                                *reinterpret_cast<float*>(out) = val; out += 4;
+                            } else {
+                                *reinterpret_cast<uint16_t*>(out) = host_f32_to_bf16(val); out += 2;
+                            }
+                        }
+                    }
+    return RC_OK;
+}
+
+int rc_conv_pack_bias(const float* bias, int cin, int cout, int ksize, int dtype, int out_mode, float* dst) {
+    ConvPlan p;
+    RC_REQUIRE(dst, "rc_conv_pack_bias: null pointer");
+    RC_REQUIRE(make_plan(cin, cout, ksize, dtype, out_mode, &p), "rc_conv_pack_bias: bad shape");
+    for (int j = 0; j < p.cout_packed; ++j) {
+        const int co = packed_to_cout(p, cout, out_mode, j);
+        dst[j] = (bias && co >= 0 && co < cout) ? bias[co] : 0.f;
+    }
+    return RC_OK;
+}
+
+int rc_conv_sum_tiles(int height, int width) { return ceil_div(height, kTH) * ceil_div(width, kTW); }
+
+int rc_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return RC_OK;
+}
+
+int rc_prof_collect(int64_t* n_launches, double* total_ms, double* total_flops) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double ms = 0.0, fl = 0.0;
+    for (auto& r : g_prof) {
+        RC_HIP_CHECK(hipEventSynchronize(r.e1));
+        float t = 0.f;
+        RC_HIP_CHECK(hipEventElapsedTime(&t, r.e0, r.e1));
+        ms += t; fl += r.flops;
+    }
+    if (n_launches) *n_launches = (int64_t)g_prof.size();
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    return RC_OK;
+}
+
+int rc_conv2d(const rc_conv_desc* d, void* stream_) {
+    RC_REQUIRE(d != nullptr, "rc_conv2d: null desc");
+    ConvPlan p;
+    RC_REQUIRE(make_plan(d->cin, d->cout, d->ksize, d->dtype, d->out_mode, &p), "rc_conv2d: unsupported cin/cout/ksize/dtype");
+    RC_REQUIRE(d->batch >= 1 && d->height >= 1 && d->width >= 1, "rc_conv2d: empty tensor");
+    RC_REQUIRE(d->batch <= 65535, "rc_conv2d: batch > 65535");
+    RC_REQUIRE(d->in0 && d->wpacked && d->out, "rc_conv2d: null in0/wpacked/out");
+    RC_REQUIRE(d->out_mode >= RC_OUT_NHWC && d->out_mode <= RC_OUT_NCHW, "rc_conv2d: bad out_mode");
+    RC_REQUIRE(d->act >= RC_ACT_NONE && d->act <= RC_ACT_LEAKY, "rc_conv2d: bad act");
+    if (d->in_gate) RC_REQUIRE(d->in1 != nullptr, "rc_conv2d: in_gate needs in1 (the skip tensor)");
+    RC_REQUIRE((d->film_scale == nullptr) == (d->film_shift == nullptr), "rc_conv2d: film_scale/film_shift must come together");
+    const bool full_tiles = d->cout == p.cout_packed;
+    if (d->mul_plus1 || d->residual)
+        RC_REQUIRE(full_tiles && d->out_mode == RC_OUT_NHWC, "rc_conv2d: mul_plus1/residual need cout % (16*NT) == 0 and RC_OUT_NHWC");
+    if (d->chan_sums) RC_REQUIRE(d->out_mode == RC_OUT_NHWC, "rc_conv2d: chan_sums needs RC_OUT_NHWC");
+    const size_t es = dtype_size(d->dtype);
+    if (d->out_mode == RC_OUT_NHWC) {
+        RC_REQUIRE(d->out_dtype == d->dtype, "rc_conv2d: out_dtype must equal dtype for RC_OUT_NHWC");
+        RC_REQUIRE((d->cout * es) % 8 == 0 || !full_tiles, "rc_conv2d: cout*elem_size must be a multiple of 8 bytes");
+        RC_REQUIRE(reinterpret_cast<uintptr_t>(d->out) % 16 == 0, "rc_conv2d: out must be 16-byte aligned");
+        if (p.nt == 4 && d->dtype == RC_BF16) RC_REQUIRE(d->cout % 8 == 0, "rc_conv2d: cout % 8");
+    } else if (d->out_mode == RC_OUT_PIXEL_SHUFFLE2) {
+        RC_REQUIRE(d->out_dtype == d->dtype, "rc_conv2d: out_dtype must equal dtype for RC_OUT_PIXEL_SHUFFLE2");
+        RC_REQUIRE(full_tiles && ((d->cout / 4) * es) % 16 == 0, "rc_conv2d: pixel-shuffle store needs (cout/4)*elem_size % 16 == 0");
+        RC_REQUIRE(!d->film_scale, "rc_conv2d: film not supported with pixel-shuffle store");
+        RC_REQUIRE(reinterpret_cast<uintptr_t>(d->out) % 16 == 0, "rc_conv2d: out must be 16-byte aligned");
+    } else {
+        RC_REQUIRE(d->out_h >= 1 && d->out_h <= d->height && d->out_w >= 1 && d->out_w <= d->width, "rc_conv2d: bad NCHW crop");
+        RC_REQUIRE(d->out_dtype == RC_F32 || d->out_dtype == RC_BF16, "rc_conv2d: bad out_dtype");
+    }
+    if (d->residual) RC_REQUIRE(reinterpret_cast<uintptr_t>(d->residual) % 16 == 0, "rc_conv2d: residual must be 16-byte aligned");
+    if (d->mul_plus1) RC_REQUIRE(reinterpret_cast<uintptr_t>(d->mul_plus1) % 16 == 0, "rc_conv2d: mul_plus1 must be 16-byte aligned");
+
+    ConvArgs a{};
+    a.batch = d->batch; a.H = d->height; a.W = d->width; a.cin = d->cin; a.cout = d->cout;
+    a.n_chunks = p.n_chunks; a.n_ct = p.n_ct;
+    a.tiles_x = ceil_div(d->width, kTW); a.tiles_y = ceil_div(d->height, kTH);
+    auto aligned16 = [](const void* q) { return q == nullptr || reinterpret_cast<uintptr_t>(q) % 16 == 0; };
+    a.cin_vec_ok = (d->cin % p.unit == 0) && aligned16(d->in0) && aligned16(d->in1) && aligned16(d->in_store) &&
+                   (d->in_gate == nullptr || reinterpret_cast<uintptr_t>(d->in_gate) % 4 == 0);
+    a.in0 = d->in0; a.in1 = d->in1; a.in_gate = d->in_gate; a.in_store = d->in_store;
+    a.wpacked = d->wpacked; a.bias = d->bias;
+    a.film_scale = d->film_scale; a.film_shift = d->film_shift;
+    a.act = d->act; a.act_slope = d->act_slope;
+    a.mul_plus1 = d->mul_plus1; a.residual = d->residual;
+    a.out = d->out; a.out_mode = d->out_mode; a.out_dtype = d->out_dtype; a.out_h = d->out_h; a.out_w = d->out_w;
+    a.chan_sums = d->chan_sums; a.cout_packed = p.cout_packed;
+
+    hipStream_t stream = as_stream(stream_);
+    bool prof;
+    { std::lock_guard<std::mutex> lk(g_prof_mu); prof = g_prof_on; }
+    ProfRec rec{};
+    if (prof) {
+        RC_HIP_CHECK(hipEventCreate(&rec.e0));
+        RC_HIP_CHECK(hipEventCreate(&rec.e1));
+        rec.flops = 2.0 * d->batch * d->height * d->width * (double)d->cin * d->cout * d->ksize * d->ksize;
+        RC_HIP_CHECK(hipEventRecord(rec.e0, stream));
+    }
+    int rcode;
+    if (d->dtype == RC_BF16)
+        rcode = d->ksize == 3 ? dispatch_conv_bf16_k3(p.ck, p.nt, a, stream) : dispatch_conv_bf16_k1(p.ck, p.nt, a, stream);
+    else
+        rcode = d->ksize == 3 ? dispatch_conv_f32_k3(p.ck, p.nt, a, stream) : dispatch_conv_f32_k1(p.ck, p.nt, a, stream);
+    if (prof) {
+        RC_HIP_CHECK(hipEventRecord(rec.e1, stream));
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(rec);
+    }
+    return rcode;
+}
+
+}  // extern "C"

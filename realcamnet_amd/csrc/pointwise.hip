@@ -1,0 +1,304 @@
+// HBM-bound kernels of the RAW->sRGB path: Bayer unshuffle, layout plumbing, Haar DWT/IDWT,
+// CA gate application.  All are pure streaming passes; the design rule is 16-byte accesses per lane
+// on the NHWC side and row-contiguous (coalesced along x) accesses on the planar side.
+#include "common.hpp"
+
+namespace rc {
+
+constexpr int kPwThreads = 256;
+
+static inline int grid_for(size_t n_items, int cap = 256 * 16) {
+    size_t g = (n_items + kPwThreads - 1) / kPwThreads;
+    if (g < 1) g = 1;
+    if (g > (size_t)cap) g = cap;
+    return (int)g;
+}
+
+// ---- Bayer unshuffle + pad: mosaic (B,2h,2w) -> NHWC (B,hp,wp,4) ---------------------------------
+// One thread per packed pixel: reads two 2-element row segments (8 B fp32 / 4 B bf16, neighbours
+// coalesce into full lines), writes one 4-channel pixel (16 B fp32 / 8 B bf16).
+template <typename TI, typename TO>
+__global__ void bayer_unshuffle_kernel(const TI* __restrict__ mosaic, TO* __restrict__ packed,
+                                       int batch, int h, int w, int hp, int wp) {
+    const size_t total = (size_t)batch * hp * wp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % wp);
+        const int y = (int)((i / wp) % hp);
+        const int b = (int)(i / ((size_t)wp * hp));
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (y < h && x < w) {
+            const TI* r0 = mosaic + ((size_t)b * 2 * h + 2 * y) * (2 * (size_t)w) + 2 * x;
+            const TI* r1 = r0 + 2 * (size_t)w;
+            v[0] = to_f32(r0[0]); v[1] = to_f32(r0[1]); v[2] = to_f32(r1[0]); v[3] = to_f32(r1[1]);
+        }
+        TO* o = packed + i * 4;
+        if constexpr (sizeof(TO) == 4) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            uint2 p;
+            p.x = Vec16<bf16_t>::rne(v[0]) | (Vec16<bf16_t>::rne(v[1]) << 16);
+            p.y = Vec16<bf16_t>::rne(v[2]) | (Vec16<bf16_t>::rne(v[3]) << 16);
+            *reinterpret_cast<uint2*>(o) = p;
+        }
+    }
+}
+
+// ---- NCHW <-> NHWC through an LDS transpose tile (32 pixels x 32 channels) -------------------------
+template <typename TI, typename TO>
+__global__ void nchw_to_nhwc_kernel(const TI* __restrict__ src, TO* __restrict__ dst,
+                                    int c, int h, int w, int hp, int wp) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int row = blockIdx.y;                 // y in [0,hp)
+    const int xblk = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, tyy = threadIdx.x >> 5;  // 256 threads: 32 x 8
+    for (int c0 = 0; c0 < c; c0 += 32) {
+        for (int k = tyy; k < 32; k += 8) {     // k = channel within block; tx = pixel
+            const int ch = c0 + k, x = xblk + tx;
+            float v = 0.f;
+            if (ch < c && row < h && x < w) v = to_f32(src[(((size_t)b * c + ch) * h + row) * w + x]);
+            tile[k][tx] = v;
+        }
+        __syncthreads();
+        for (int k = tyy; k < 32; k += 8) {     // k = pixel; tx = channel
+            const int ch = c0 + tx, x = xblk + k;
+            if (ch < c && x < wp) dst[(((size_t)b * hp + row) * wp + x) * c + ch] = from_f32<TO>(tile[tx][k]);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename TI, typename TO>
+__global__ void nhwc_to_nchw_kernel(const TI* __restrict__ src, TO* __restrict__ dst,
+                                    int c, int H, int W, int h, int w) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int row = blockIdx.y;                 // y in [0,h)
+    const int xblk = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, tyy = threadIdx.x >> 5;
+    for (int c0 = 0; c0 < c; c0 += 32) {
+        for (int k = tyy; k < 32; k += 8) {     // k = pixel; tx = channel
+            const int ch = c0 + tx, x = xblk + k;
+            float v = 0.f;
+            if (ch < c && x < w) v = to_f32(src[(((size_t)b * H + row) * W + x) * c + ch]);
+            tile[k][tx] = v;
+        }
+        __syncthreads();
+        for (int k = tyy; k < 32; k += 8) {     // k = channel; tx = pixel
+            const int ch = c0 + k, x = xblk + tx;
+            if (ch < c && x < w) dst[(((size_t)b * c + ch) * h + row) * w + x] = from_f32<TO>(tile[tx][k]);
+        }
+        __syncthreads();
+    }
+}
+
+// ---- y = r*gate[b][c] + x ---------------------------------------------------------------------------
+template <typename T>
+__global__ void gate_residual_kernel(const T* __restrict__ r, const float* __restrict__ gate,
+                                     const T* __restrict__ x, T* __restrict__ y,
+                                     int batch, size_t n_pix, int c) {
+    constexpr int U = Vec16<T>::N;
+    const int vpp = c / U;                      // vectors per pixel
+    const size_t total = (size_t)batch * n_pix * vpp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vpp);
+        const int b = (int)(i / ((size_t)vpp * n_pix));
+        float fr[U], fx[U];
+        Vec16<T>::unpack(reinterpret_cast<const uint4*>(r)[i], fr);
+        Vec16<T>::unpack(reinterpret_cast<const uint4*>(x)[i], fx);
+        const float* g = gate + (size_t)b * c + v * U;
+#pragma unroll
+        for (int e = 0; e < U; ++e) fr[e] = fr[e] * g[e] + fx[e];
+        reinterpret_cast<uint4*>(y)[i] = Vec16<T>::pack(fr);
+    }
+}
+
+// ---- Haar DWT as the reference's frozen grouped conv (taps read from the state_dict tensor) ------
+// forward: x (B,H,W,C) -> y (B,H/2,W/2,4C): y[.., 4c+k] = sum_{i,j} taps[4c+k][i][j] * x[2y+i][2x+j][c]
+// One thread per (output pixel, 16-byte group of input channels).
+template <typename T>
+__global__ void dwt_forward_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ taps,
+                                   int batch, int H, int W, int c) {
+    constexpr int U = Vec16<T>::N;
+    const int h = H / 2, w = W / 2, vpp = c / U;
+    const size_t total = (size_t)batch * h * w * vpp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vpp);
+        const size_t p = i / vpp;
+        const int ox = (int)(p % w), oy = (int)((p / w) % h), b = (int)(p / ((size_t)w * h));
+        float in[4][U];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const size_t src = (((size_t)b * H + 2 * oy + (t >> 1)) * W + 2 * ox + (t & 1)) * c + v * U;
+            Vec16<T>::unpack(*reinterpret_cast<const uint4*>(x + src), in[t]);
+        }
+        float out[4 * U];
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            const float* tp = taps + (size_t)(4 * (v * U + e)) * 4;   // (4C,1,2,2): 4 floats per out channel
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float s = in[0][e] * tp[k * 4 + 0];
+                s += in[1][e] * tp[k * 4 + 1];
+                s += in[2][e] * tp[k * 4 + 2];
+                s += in[3][e] * tp[k * 4 + 3];
+                out[4 * e + k] = s;
+            }
+        }
+        T* dst = y + p * (4 * (size_t)c) + 4 * v * U;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) reinterpret_cast<uint4*>(dst)[j] = Vec16<T>::pack(out + j * U);
+    }
+}
+
+// inverse: x (B,h,w,4C) -> y (B,2h,2w,C): y[2y+i][2x+j][c] = sum_k taps[4c+k][i][j] * x[y][x][4c+k]
+// One thread per (input pixel, 16-byte group of OUTPUT channels) = 4 input vectors -> 4 output vectors.
+template <typename T>
+__global__ void dwt_inverse_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ taps,
+                                   int batch, int h, int w, int c4) {
+    constexpr int U = Vec16<T>::N;
+    const int c = c4 / 4, vpp = c / U;
+    const size_t total = (size_t)batch * h * w * vpp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vpp);
+        const size_t p = i / vpp;
+        const int ix = (int)(p % w), iy = (int)((p / w) % h), b = (int)(p / ((size_t)w * h));
+        float in[4 * U];
+        const T* src = x + p * (size_t)c4 + 4 * v * U;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Vec16<T>::unpack(reinterpret_cast<const uint4*>(src)[j], in + j * U);
+        float out[4][U];
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            const float* tp = taps + (size_t)(4 * (v * U + e)) * 4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float s = in[4 * e + 0] * tp[0 * 4 + t];
+                s += in[4 * e + 1] * tp[1 * 4 + t];
+                s += in[4 * e + 2] * tp[2 * 4 + t];
+                s += in[4 * e + 3] * tp[3 * 4 + t];
+                out[t][e] = s;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const size_t dst = (((size_t)b * 2 * h + 2 * iy + (t >> 1)) * (2 * (size_t)w) + 2 * ix + (t & 1)) * c + v * U;
+            *reinterpret_cast<uint4*>(y + dst) = Vec16<T>::pack(out[t]);
+        }
+    }
+}
+
+}  // namespace rc
+
+using namespace rc;
+
+#define RC_DISPATCH_2(in_dt, out_dt, CALL)                                              \
+    do {                                                                                \
+        if (in_dt == RC_F32 && out_dt == RC_F32) { CALL(float, float); }                \
+        else if (in_dt == RC_F32 && out_dt == RC_BF16) { CALL(float, bf16_t); }         \
+        else if (in_dt == RC_BF16 && out_dt == RC_F32) { CALL(bf16_t, float); }         \
+        else if (in_dt == RC_BF16 && out_dt == RC_BF16) { CALL(bf16_t, bf16_t); }       \
+        else return fail(RC_ERR_INVALID, "bad dtype");                                  \
+    } while (0)
+
+extern "C" {
+
+int rc_bayer_unshuffle(const void* d_mosaic, int in_dtype, void* d_packed, int out_dtype,
+                       int batch, int h, int w, int hp, int wp, void* stream) {
+    RC_REQUIRE(d_mosaic && d_packed, "rc_bayer_unshuffle: null pointer");
+    RC_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && hp >= h && wp >= w, "rc_bayer_unshuffle: bad shape");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_packed) % 16 == 0, "rc_bayer_unshuffle: packed must be 16-byte aligned");
+    const size_t total = (size_t)batch * hp * wp;
+#define CALL(TI, TO)                                                                                           \
+    hipLaunchKernelGGL((bayer_unshuffle_kernel<TI, TO>), dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream), \
+                       static_cast<const TI*>(d_mosaic), static_cast<TO*>(d_packed), batch, h, w, hp, wp)
+    RC_DISPATCH_2(in_dtype, out_dtype, CALL);
+#undef CALL
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_nchw_to_nhwc(const void* d_src, int src_dtype, void* d_dst, int dst_dtype,
+                    int batch, int c, int h, int w, int hp, int wp, void* stream) {
+    RC_REQUIRE(d_src && d_dst, "rc_nchw_to_nhwc: null pointer");
+    RC_REQUIRE(batch >= 1 && c >= 1 && h >= 1 && w >= 1 && hp >= h && wp >= w, "rc_nchw_to_nhwc: bad shape");
+    RC_REQUIRE(hp <= 65535 && batch <= 65535, "rc_nchw_to_nhwc: dimension too large");
+    dim3 grid(ceil_div(wp, 32), hp, batch);
+#define CALL(TI, TO)                                                                               \
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<TI, TO>), grid, dim3(256), 0, as_stream(stream),       \
+                       static_cast<const TI*>(d_src), static_cast<TO*>(d_dst), c, h, w, hp, wp)
+    RC_DISPATCH_2(src_dtype, dst_dtype, CALL);
+#undef CALL
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_nhwc_to_nchw(const void* d_src, int src_dtype, void* d_dst, int dst_dtype,
+                    int batch, int c, int H, int W, int h, int w, void* stream) {
+    RC_REQUIRE(d_src && d_dst, "rc_nhwc_to_nchw: null pointer");
+    RC_REQUIRE(batch >= 1 && c >= 1 && h >= 1 && w >= 1 && h <= H && w <= W, "rc_nhwc_to_nchw: bad shape");
+    RC_REQUIRE(h <= 65535 && batch <= 65535, "rc_nhwc_to_nchw: dimension too large");
+    dim3 grid(ceil_div(w, 32), h, batch);
+#define CALL(TI, TO)                                                                               \
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<TI, TO>), grid, dim3(256), 0, as_stream(stream),       \
+                       static_cast<const TI*>(d_src), static_cast<TO*>(d_dst), c, H, W, h, w)
+    RC_DISPATCH_2(src_dtype, dst_dtype, CALL);
+#undef CALL
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_gate_residual(const void* d_r, const float* d_gate, const void* d_x, void* d_y, int dtype,
+                     int batch, int n_pix, int c, void* stream) {
+    RC_REQUIRE(d_r && d_gate && d_x && d_y, "rc_gate_residual: null pointer");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_gate_residual: bad dtype");
+    RC_REQUIRE(batch >= 1 && n_pix >= 1 && c >= U && c % U == 0, "rc_gate_residual: c must be a multiple of 16 bytes");
+    const size_t total = (size_t)batch * n_pix * (c / U);
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(gate_residual_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const float*>(d_r), d_gate, static_cast<const float*>(d_x), static_cast<float*>(d_y), batch, (size_t)n_pix, c);
+    else
+        hipLaunchKernelGGL(gate_residual_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_r), d_gate, static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_y), batch, (size_t)n_pix, c);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_dwt_forward(const void* d_x, void* d_y, const float* d_taps, int dtype,
+                   int batch, int H, int W, int c, void* stream) {
+    RC_REQUIRE(d_x && d_y && d_taps, "rc_dwt_forward: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_dwt_forward: bad dtype");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    RC_REQUIRE(batch >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "rc_dwt_forward: H and W must be even");
+    RC_REQUIRE(c % U == 0, "rc_dwt_forward: channels must be a multiple of 16 bytes");
+    const size_t total = (size_t)batch * (H / 2) * (W / 2) * (c / U);
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(dwt_forward_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const float*>(d_x), static_cast<float*>(d_y), d_taps, batch, H, W, c);
+    else
+        hipLaunchKernelGGL(dwt_forward_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_y), d_taps, batch, H, W, c);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_dwt_inverse(const void* d_x, void* d_y, const float* d_taps, int dtype,
+                   int batch, int h, int w, int c4, void* stream) {
+    RC_REQUIRE(d_x && d_y && d_taps, "rc_dwt_inverse: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_dwt_inverse: bad dtype");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    RC_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && c4 % 4 == 0 && (c4 / 4) % U == 0,
+               "rc_dwt_inverse: out channels (c4/4) must be a multiple of 16 bytes");
+    const size_t total = (size_t)batch * h * w * (c4 / 4 / U);
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(dwt_inverse_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const float*>(d_x), static_cast<float*>(d_y), d_taps, batch, h, w, c4);
+    else
+        hipLaunchKernelGGL(dwt_inverse_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_y), d_taps, batch, h, w, c4);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+}  // extern "C"

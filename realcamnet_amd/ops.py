@@ -1,0 +1,359 @@
+"""Host-side operator layer: thin, typed wrappers from torch tensors to the C ABI (include/realcam_hip.h).
+
+PyTorch is used for device memory (caching allocator), the current HIP stream and nothing else.
+Internal activations are NHWC tensors of shape (B, H, W, C), contiguous, fp32 or bf16.
+There is NO fallback: CPU tensors or a missing library raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (RC_ACT_LEAKY, RC_ACT_NONE, RC_ACT_RELU, RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC,
+                   RC_OUT_PIXEL_SHUFFLE2, ConvDesc, check)
+
+_DT = {torch.float32: RC_F32, torch.bfloat16: RC_BF16}
+
+# Fold CALayer's "res*gate + skip" into the next conv's input staging (saves one full HBM pass per
+# RCAB).  The unfused form (rc_gate_residual) is kept for A/B checks.
+FUSE_GATE = True
+
+
+def lib():
+    return _lib.load()
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"realcamnet_amd: unsupported dtype {t.dtype} (fp32 / bf16 only)") from None
+
+
+def _req(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; the HIP path has no CPU fallback "
+                           "(use oracle/ for CPU reference results)")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------------------------------
+# parameter caches (never part of the state_dict)
+# --------------------------------------------------------------------------------------------------
+def _key(*params) -> tuple:
+    return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) if p is not None else None for p in params)
+
+
+def _cache(mod) -> dict:
+    c = mod.__dict__.get("_rc_cache")
+    if c is None:
+        c = {}
+        mod.__dict__["_rc_cache"] = c
+    return c
+
+
+def f32_param(mod, name: str) -> torch.Tensor:
+    """fp32 contiguous device view/copy of a (small) parameter, cached per parameter version."""
+    p = getattr(mod, name)
+    if p.dtype == torch.float32 and p.is_contiguous():
+        return _req(p.detach(), name)
+    c = _cache(mod)
+    k = ("f32", name)
+    hit = c.get(k)
+    key = _key(p)
+    if hit is None or hit[0] != key:
+        hit = (key, _req(p.detach(), name).float().contiguous())
+        c[k] = hit
+    return hit[1]
+
+
+class PackedConv:
+    __slots__ = ("wpacked", "bias", "cin", "cout", "ksize", "dtype", "out_mode")
+
+
+def packed_conv(mod, act_dtype: torch.dtype, out_mode: int) -> PackedConv:
+    """MFMA-fragment-ordered copy of a conv's weights (rc_conv_pack_weights), cached on the module."""
+    w, b = mod.weight, mod.bias
+    c = _cache(mod)
+    k = ("conv", act_dtype, out_mode)
+    key = _key(w, b)
+    hit = c.get(k)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if not w.is_cuda:
+        raise RuntimeError("conv weights are not on a HIP device; move the module with .cuda() first")
+    cout, cin, kh, kw = w.shape
+    if kh != kw or kh not in (1, 3):
+        raise NotImplementedError(f"HIP conv supports 1x1 and 3x3 kernels, got {kh}x{kw}")
+    L = lib()
+    dt = _DT[act_dtype]
+    nbytes = L.rc_conv_packed_bytes(cin, cout, kh, dt, out_mode)
+    if nbytes == 0:
+        raise _lib.HipError(f"rc_conv_packed_bytes: {L.rc_last_error().decode()}")
+    w_host = np.ascontiguousarray(w.detach().float().cpu().numpy())
+    dst = np.empty(nbytes, dtype=np.uint8)
+    check(L.rc_conv_pack_weights(w_host.ctypes.data, cin, cout, kh, dt, out_mode, dst.ctypes.data), "rc_conv_pack_weights")
+    n_packed = L.rc_conv_packed_cout(cin, cout, kh, dt, out_mode)
+    bdst = np.zeros(n_packed, dtype=np.float32)
+    if b is not None:
+        b_host = np.ascontiguousarray(b.detach().float().cpu().numpy())
+        check(L.rc_conv_pack_bias(b_host.ctypes.data, cin, cout, kh, dt, out_mode, bdst.ctypes.data), "rc_conv_pack_bias")
+    pc = PackedConv()
+    pc.wpacked = torch.from_numpy(dst).to(w.device)
+    pc.bias = torch.from_numpy(bdst).to(w.device) if b is not None else None
+    pc.cin, pc.cout, pc.ksize, pc.dtype, pc.out_mode = cin, cout, kh, dt, out_mode
+    c[k] = (key, pc)
+    return pc
+
+
+def check_conv_module(mod) -> None:
+    if tuple(mod.stride) != (1, 1) or tuple(mod.dilation) != (1, 1) or mod.groups != 1:
+        raise NotImplementedError("HIP conv: stride 1, dilation 1, groups 1 only")
+    k = mod.kernel_size[0]
+    if tuple(mod.padding) != (k // 2, k // 2) or getattr(mod, "padding_mode", "zeros") != "zeros":
+        raise NotImplementedError("HIP conv: 'same' zero padding only")
+
+
+# --------------------------------------------------------------------------------------------------
+# layout / ingest
+# --------------------------------------------------------------------------------------------------
+def to_nhwc(x: torch.Tensor, dtype: Optional[torch.dtype] = None, pad_hw: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """NCHW (B,C,h,w) -> NHWC (B,hp,wp,C), zero padded bottom/right, converted to `dtype`."""
+    x = _req(x, "to_nhwc input")
+    if x.dim() != 4:
+        raise ValueError(f"expected a 4-D NCHW tensor, got shape {tuple(x.shape)}")
+    b, c, h, w = x.shape
+    hp, wp = pad_hw if pad_hw is not None else (h, w)
+    dtype = dtype or x.dtype
+    out = torch.empty((b, hp, wp, c), dtype=dtype, device=x.device)
+    check(lib().rc_nchw_to_nhwc(x.data_ptr(), _dt(x), out.data_ptr(), _DT[dtype], b, c, h, w, hp, wp, _stream()), "rc_nchw_to_nhwc")
+    return out
+
+
+def to_nchw(a: torch.Tensor, dtype: Optional[torch.dtype] = None, crop_hw: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    a = _req(a, "to_nchw input")
+    b, H, W, c = a.shape
+    h, w = crop_hw if crop_hw is not None else (H, W)
+    dtype = dtype or a.dtype
+    out = torch.empty((b, c, h, w), dtype=dtype, device=a.device)
+    check(lib().rc_nhwc_to_nchw(a.data_ptr(), _dt(a), out.data_ptr(), _DT[dtype], b, c, H, W, h, w, _stream()), "rc_nhwc_to_nchw")
+    return out
+
+
+def bayer_unshuffle(mosaic: torch.Tensor, dtype: Optional[torch.dtype] = None, pad_to: int = 1) -> torch.Tensor:
+    """(B,1,2h,2w) or (B,2h,2w) Bayer mosaic -> packed NHWC (B,hp,wp,4), zero padded to a multiple of
+    `pad_to` (README.md:33-38 'Unpixel shuffle' + models/LiteISP.py:84-105)."""
+    mosaic = _req(mosaic, "mosaic")
+    if mosaic.dim() == 4:
+        if mosaic.shape[1] != 1:
+            raise ValueError("mosaic must have one channel")
+        mosaic = mosaic[:, 0]
+    b, h2, w2 = mosaic.shape
+    if h2 % 2 or w2 % 2:
+        raise ValueError("mosaic height/width must be even")
+    h, w = h2 // 2, w2 // 2
+    hp, wp = -(-h // pad_to) * pad_to, -(-w // pad_to) * pad_to
+    dtype = dtype or mosaic.dtype
+    out = torch.empty((b, hp, wp, 4), dtype=dtype, device=mosaic.device)
+    check(lib().rc_bayer_unshuffle(mosaic.data_ptr(), _dt(mosaic), out.data_ptr(), _DT[dtype], b, h, w, hp, wp, _stream()), "rc_bayer_unshuffle")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# convolution and friends
+# --------------------------------------------------------------------------------------------------
+_ACT = {None: RC_ACT_NONE, "relu": RC_ACT_RELU, "leaky": RC_ACT_LEAKY}
+
+
+def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.0,
+           residual: Optional[torch.Tensor] = None, mul_plus1: Optional[torch.Tensor] = None,
+           film: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+           gate: Optional[torch.Tensor] = None, skip: Optional[torch.Tensor] = None, store_input: bool = False,
+           out_mode: int = RC_OUT_NHWC, want_sums: bool = False,
+           crop_hw: Optional[Tuple[int, int]] = None, out_dtype: Optional[torch.dtype] = None):
+    """KxK stride-1 'same' convolution of NHWC `x` with `mod`'s weights (an nn.Conv2d-shaped module).
+
+    gate/skip: the conv input is x*gate[b,c] + skip (CALayer gate + RCAB skip); with store_input the
+    combined tensor is also materialised and returned.
+    Returns out, or a tuple (out, [stored_input], [chan_sums]) when extras are requested.
+    """
+    check_conv_module(mod)
+    x = _req(x, "conv input")
+    b, H, W, cin = x.shape
+    pc = packed_conv(mod, x.dtype, out_mode)
+    if cin != pc.cin:
+        raise ValueError(f"conv expects {pc.cin} input channels, got {cin}")
+    dev = x.device
+    d = ConvDesc()
+    d.batch, d.height, d.width, d.cin, d.cout, d.ksize, d.dtype = b, H, W, cin, pc.cout, pc.ksize, pc.dtype
+    d.in0 = x.data_ptr()
+    stored = None
+    if gate is not None:
+        if skip is None:
+            raise ValueError("gate needs skip")
+        skip = _req(skip, "skip")
+        gate = _req(gate, "gate")
+        if skip.shape != x.shape or skip.dtype != x.dtype or gate.shape != (b, cin) or gate.dtype != torch.float32:
+            raise ValueError("gate/skip shape or dtype mismatch")
+        d.in1, d.in_gate = skip.data_ptr(), gate.data_ptr()
+        if store_input:
+            stored = torch.empty_like(x)
+            d.in_store = stored.data_ptr()
+    d.wpacked = pc.wpacked.data_ptr()
+    d.bias = _ptr(pc.bias)
+    if film is not None:
+        fs, ft = (_req(t, "film") for t in film)
+        if fs.shape != (b, pc.cout) or ft.shape != (b, pc.cout) or fs.dtype != torch.float32 or ft.dtype != torch.float32:
+            raise ValueError("film tensors must be fp32 (B, cout)")
+        d.film_scale, d.film_shift = fs.data_ptr(), ft.data_ptr()
+    d.act, d.act_slope = _ACT[act], float(slope)
+    for name, t in (("mul_plus1", mul_plus1), ("residual", residual)):
+        if t is not None:
+            t = _req(t, name)
+            if t.shape != (b, H, W, pc.cout) or t.dtype != x.dtype:
+                raise ValueError(f"{name} must be NHWC {(b, H, W, pc.cout)} {x.dtype}, got {tuple(t.shape)} {t.dtype}")
+            setattr(d, name, t.data_ptr())
+    d.out_mode = out_mode
+    if out_mode == RC_OUT_NHWC:
+        out = torch.empty((b, H, W, pc.cout), dtype=x.dtype, device=dev)
+        d.out_dtype = pc.dtype
+    elif out_mode == RC_OUT_PIXEL_SHUFFLE2:
+        out = torch.empty((b, 2 * H, 2 * W, pc.cout // 4), dtype=x.dtype, device=dev)
+        d.out_dtype = pc.dtype
+    else:
+        oh, ow = crop_hw if crop_hw is not None else (H, W)
+        odt = out_dtype or x.dtype
+        out = torch.empty((b, pc.cout, oh, ow), dtype=odt, device=dev)
+        d.out_dtype, d.out_h, d.out_w = _DT[odt], oh, ow
+    d.out = out.data_ptr()
+    sums = None
+    if want_sums:
+        nt = lib().rc_conv_sum_tiles(H, W)
+        sums = torch.empty((b, nt, pc.cout), dtype=torch.float32, device=dev)
+        d.chan_sums = sums.data_ptr()
+    check(lib().rc_conv2d(C.byref(d), _stream()), "rc_conv2d")
+    extras = [t for t in (stored, sums) if t is not None]
+    return (out, *extras) if extras else out
+
+
+def ca_gate(sums: torch.Tensor, hw: int, ca) -> torch.Tensor:
+    """CALayer gate (B,C) from the conv's channel partial sums.  models/networks.py:259-269."""
+    b, nt, c = sums.shape
+    c0, c1 = ca.conv_du[0], ca.conv_du[2]
+    cr = c0.weight.shape[0]
+    gate = torch.empty((b, c), dtype=torch.float32, device=sums.device)
+    check(lib().rc_ca_gate(sums.data_ptr(), b, nt, c, cr, 1.0 / float(hw),
+                           f32_param(c0, "weight").data_ptr(), f32_param(c0, "bias").data_ptr(),
+                           f32_param(c1, "weight").data_ptr(), f32_param(c1, "bias").data_ptr(),
+                           gate.data_ptr(), _stream()), "rc_ca_gate")
+    return gate
+
+
+def gate_residual(r: torch.Tensor, gate: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    r, x, gate = _req(r, "r"), _req(x, "x"), _req(gate, "gate")
+    b, H, W, c = r.shape
+    y = torch.empty_like(r)
+    check(lib().rc_gate_residual(r.data_ptr(), gate.data_ptr(), x.data_ptr(), y.data_ptr(), _dt(r), b, H * W, c, _stream()), "rc_gate_residual")
+    return y
+
+
+def dwt_forward(x: torch.Tensor, mod) -> torch.Tensor:
+    x = _req(x, "dwt input")
+    b, H, W, c = x.shape
+    if H % 2 or W % 2:
+        raise ValueError(f"DWTForward needs even H,W; got {H}x{W}")
+    if mod.weight.shape[0] != 4 * c:
+        raise ValueError("DWTForward channel mismatch")
+    y = torch.empty((b, H // 2, W // 2, 4 * c), dtype=x.dtype, device=x.device)
+    check(lib().rc_dwt_forward(x.data_ptr(), y.data_ptr(), f32_param(mod, "weight").data_ptr(), _dt(x), b, H, W, c, _stream()), "rc_dwt_forward")
+    return y
+
+
+def dwt_inverse(x: torch.Tensor, mod) -> torch.Tensor:
+    x = _req(x, "idwt input")
+    b, h, w, c4 = x.shape
+    if mod.weight.shape[0] != c4:
+        raise ValueError("DWTInverse channel mismatch")
+    y = torch.empty((b, 2 * h, 2 * w, c4 // 4), dtype=x.dtype, device=x.device)
+    check(lib().rc_dwt_inverse(x.data_ptr(), y.data_ptr(), f32_param(mod, "weight").data_ptr(), _dt(x), b, h, w, c4, _stream()), "rc_dwt_inverse")
+    return y
+
+
+# --------------------------------------------------------------------------------------------------
+# conditioning
+# --------------------------------------------------------------------------------------------------
+def color_block(x: torch.Tensor, conv, prev_norm=None, prev_stats=None) -> torch.Tensor:
+    """Conv1x1 -> AvgPool(3,2,1) -> LeakyReLU(0.2) on NCHW x; applies the previous block's InstanceNorm
+    (prev_norm affine params, prev_stats=(mean,rstd)) on load.  models/LiteISP.py:23-30."""
+    x = _req(x, "color_block input")
+    b, cin, h, w = x.shape
+    cout = conv.weight.shape[0]
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty((b, cout, ho, wo), dtype=torch.float32, device=x.device)
+    if prev_norm is not None:
+        mean, rstd = prev_stats
+        args = (mean.data_ptr(), rstd.data_ptr(), f32_param(prev_norm, "weight").data_ptr(), f32_param(prev_norm, "bias").data_ptr())
+    else:
+        args = (None, None, None, None)
+    check(lib().rc_color_block(x.data_ptr(), _dt(x), y.data_ptr(), b, cin, cout, h, w,
+                               f32_param(conv, "weight").data_ptr(), f32_param(conv, "bias").data_ptr(), *args, _stream()), "rc_color_block")
+    return y
+
+
+def instance_stats(x: torch.Tensor, eps: float = 1e-5):
+    b, c, h, w = x.shape
+    mean = torch.empty((b, c), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    check(lib().rc_instance_stats(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), b, c, h * w, float(eps), _stream()), "rc_instance_stats")
+    return mean, rstd
+
+
+def color_head(x: torch.Tensor, conv) -> torch.Tensor:
+    b, cin, h, w = x.shape
+    cout = conv.weight.shape[0]
+    vec = torch.empty((b, cout), dtype=torch.float32, device=x.device)
+    check(lib().rc_color_head(x.data_ptr(), vec.data_ptr(), b, cin, cout, h * w,
+                              f32_param(conv, "weight").data_ptr(), f32_param(conv, "bias").data_ptr(), _stream()), "rc_color_head")
+    return vec
+
+
+def gfm_vector(vec: torch.Tensor, lin0, lin1) -> torch.Tensor:
+    """lin1(leaky_relu(lin0(vec), 0.1)).  models/LiteISP.py:554-555."""
+    vec = _req(vec, "gfm vector")
+    if vec.dtype != torch.float32:
+        vec = vec.float()
+    b, cond_c = vec.shape
+    nf, c = lin0.weight.shape[0], lin1.weight.shape[0]
+    out = torch.empty((b, c), dtype=torch.float32, device=vec.device)
+    check(lib().rc_gfm_vector(vec.data_ptr(), b, cond_c, nf, c,
+                              f32_param(lin0, "weight").data_ptr(), f32_param(lin0, "bias").data_ptr(),
+                              f32_param(lin1, "weight").data_ptr(), f32_param(lin1, "bias").data_ptr(),
+                              out.data_ptr(), _stream()), "rc_gfm_vector")
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# measurement hooks
+# --------------------------------------------------------------------------------------------------
+def prof_enable(on: bool) -> None:
+    check(lib().rc_prof_enable(1 if on else 0), "rc_prof_enable")
+
+
+def prof_collect():
+    n, ms, fl = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
+    check(lib().rc_prof_collect(C.byref(n), C.byref(ms), C.byref(fl)), "rc_prof_collect")
+    return n.value, ms.value, fl.value
