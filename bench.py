@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""RAW->sRGB throughput benchmark (BASELINE.json metric: megapixels/sec at 4K; PSNR vs CPU reference).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path (Bayer unshuffle + pad -> LiteISPNet_GFM_LSC -> cropped sRGB) over
+one batch of `--frames` synthetic 4K mosaics per GPU (weak scaling: cfg3 at N=1, cfg4 = 64 frames at
+N=8).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(name, sd, budget_s=20.0):
+    """Time the CPU oracle (kind 'port': oracle/liteisp_oracle.py, fp32, all host threads) on a bounded
+    sample of the same workload; returns (dict, (mosaic, cond, coord, ref_out)) for the PSNR leg."""
+    import liteisp_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(1234)
+
+    def sample(h2, w2):
+        mosaic = torch.rand(1, 1, h2, w2, generator=g)
+        cond = torch.rand(1, 4, 256, 256, generator=g)
+        coord = O.make_coord(1, h2 // 2, w2 // 2)
+        return mosaic, cond, coord
+
+    def run(mosaic, cond, coord):
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            out = O.run_padded(name, sd, O.bayer_unshuffle(mosaic), cond, coord)
+            return time.perf_counter() - t0, out
+
+    run(*sample(256, 256))                                # warm-up (thread pool, oneDNN primitives)
+    t_probe, _ = run(*sample(512, 512))
+    rate = 512 * 512 / t_probe                            # output pixels / s at small size (optimistic)
+    # largest 16:9 crop of a 4K frame that fits the budget, at most the whole frame
+    frac = min(1.0, (rate * budget_s * 0.6) / (2160 * 3840))
+    scale = frac ** 0.5
+    h2 = max(256, int(2160 * scale) // 32 * 32)
+    w2 = max(256, int(3840 * scale) // 32 * 32)
+    if scale >= 1.0:
+        h2, w2 = 2160, 3840
+    mosaic, cond, coord = sample(h2, w2)
+    t, out = run(mosaic, cond, coord)
+    mp = h2 * w2 / 1e6
+    info = {"value": round(mp / t, 4), "unit": "MP/s", "cores": threads, "kind": "port",
+            "sample": f"1 frame {w2}x{h2} mosaic ({mp:.2f} MP) fp32, oracle/liteisp_oracle.py, {t:.1f} s"}
+    return info, (mosaic, cond, coord, out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=8, help="frames per GPU per step (cfg3: 8)")
+    ap.add_argument("--height", type=int, default=2160, help="mosaic height")
+    ap.add_argument("--width", type=int, default=3840, help="mosaic width")
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--model", default="LiteISPNet_GFM_LSC", choices=["LiteISPNet_GFM_LSC", "LiteISPNet"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import liteisp_oracle as O
+    import realcamnet_amd as M
+    from realcamnet_amd import ops, shard
+
+    rank, world, local_rank = shard.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    torch.manual_seed(0)                                   # random-init weights of the named architecture
+    net = getattr(M, args.model)().eval()
+    sd_cpu = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(device=dev, dtype=dt)
+
+    B, H2, W2 = args.frames, args.height, args.width
+    total_frames = B * world                               # weak scaling: rank r owns frames [r*B, (r+1)*B)
+    s, e = shard.frame_shard(total_frames, rank, world)
+    assert e - s == B
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    mosaic = torch.rand(B, 1, H2, W2, generator=g, device=dev).to(dt)
+    cond = torch.rand(B, 4, 256, 256, generator=g, device=dev).to(dt)
+    coord = O.make_coord(B, H2 // 2, W2 // 2).to(dev, dt)
+
+    def step():
+        with torch.no_grad():
+            return net.forward_mosaic(mosaic, cond, coord)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    shard.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    shard.barrier()
+    torch.cuda.synchronize()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dev)
+    assert out.shape == (B, 3, H2, W2)
+
+    # dominant kernel (MFMA conv): HIP-event time of every launch on its stream, one extra step
+    ops.prof_enable(True)
+    step()
+    n_launch, conv_ms, conv_flops = ops.prof_collect()
+    ops.prof_enable(False)
+
+    if rank != 0:
+        return
+    mp_per_step = total_frames * H2 * W2 / 1e6
+    value = mp_per_step * args.steps / elapsed
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    peak = PEAK_TFLOPS[args.dtype]
+    res = {
+        "metric": "megapixels/sec RAW->sRGB at 4K", "value": round(value, 2), "unit": "MP/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (uniform[0,1) mosaics, seed-0 random-init weights)",
+        "config": {"workload": f"cfg3: {W2}x{H2} Bayer mosaic -> unshuffle+pad16 -> {args.model} -> sRGB {W2}x{H2}, "
+                               f"{B} frames/GPU, {args.dtype} storage / fp32 accumulate (GroupMix block not yet attached)",
+                   "frames_per_gpu": B, "global_frames": total_frames, "parallelism": f"frame-shard x{world}"},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4), "traffic": None,
+                     "kernel": "conv_mfma_kernel (all instantiations)", "launches_per_step": int(n_launch),
+                     "kernel_ms_per_step": round(conv_ms, 3), "flops_per_step": conv_flops},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        info, (m_c, c_c, co_c, ref) = cpu_baseline(args.model, sd_cpu)
+        with torch.no_grad():
+            y = net.forward_mosaic(m_c.to(dev, dt), c_c.to(dev, dt), co_c.to(dev, dt))
+        torch.cuda.synchronize()
+        res["cpu_baseline"] = info
+        res["psnr_db_vs_cpu_fp32"] = round(O.psnr(y.float().cpu(), ref), 2)
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

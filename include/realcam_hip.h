@@ -129,6 +129,8 @@ int rc_conv_pack_bias(const float* bias_host, int cin, int cout, int ksize, int 
 /* Number of spatial tiles per image the conv kernel uses for chan_sums (depends only on H,W). */
 int rc_conv_sum_tiles(int height, int width);
 int rc_conv2d(const rc_conv_desc* desc, void* stream);
+/* sizeof(rc_conv_desc) as compiled into the library: lets an FFI binding verify its struct mirror. */
+size_t rc_conv_desc_size(void);
 
 /* ---- a8: CALayer gate -------------------------------------------------------------------------
  * Replaces: AdaptiveAvgPool2d(1) -> Conv1x1(C,C/r) -> ReLU -> Conv1x1(C/r,C) -> Sigmoid
@@ -160,7 +162,7 @@ int rc_dwt_inverse(const void* d_x, void* d_y, const float* d_taps, int dtype,
  *                    with ho=(h-1)/2+1; if d_in_mean!=NULL the previous block's InstanceNorm
  *                    (x-mean)*rstd*gamma+beta is applied to x on load.
  *   rc_instance_stats: per (b,c) mean and 1/sqrt(var+eps) (biased var, eps 1e-5).
- *   rc_color_head:   v[b][o] = mean_hw(conv1x1(IN(x)))  -> (B,cout)                               */
+ *   rc_color_head:   v[b][o] = mean_hw(conv1x1(x))  -> (B,cout)   (the 5th block has no norm)      */
 int rc_color_block(const void* d_x, int x_dtype, float* d_y, int batch, int cin, int cout, int h, int w,
                    const float* d_w, const float* d_b,
                    const float* d_in_mean, const float* d_in_rstd, const float* d_in_gamma,

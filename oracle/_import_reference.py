@@ -10,6 +10,7 @@ is used by the hot path, so raising placeholders are enough to make the pure-tor
 (SURVEY.md section 8c).
 """
 import sys
+sys.dont_write_bytecode = True
 import types
 import importlib
 

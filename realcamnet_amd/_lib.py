@@ -59,6 +59,7 @@ _SIGS = {
     "rc_conv_pack_bias": (C.c_int, [_P, _I, _I, _I, _I, _I, _P]),
     "rc_conv_sum_tiles": (C.c_int, [_I, _I]),
     "rc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _P]),
+    "rc_conv_desc_size": (_SZ, []),
     "rc_ca_gate": (C.c_int, [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "rc_gate_residual": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rc_dwt_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

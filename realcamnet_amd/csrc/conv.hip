@@ -115,6 +115,8 @@ int rc_conv_pack_bias(const float* bias, int cin, int cout, int ksize, int dtype
     return RC_OK;
 }
 
+size_t rc_conv_desc_size(void) { return sizeof(rc_conv_desc); }
+
 int rc_conv_sum_tiles(int height, int width) { return ceil_div(height, kTH) * ceil_div(width, kTW); }
 
 int rc_prof_enable(int on) {
@@ -158,7 +160,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     const size_t es = dtype_size(d->dtype);
     if (d->out_mode == RC_OUT_NHWC) {
         RC_REQUIRE(d->out_dtype == d->dtype, "rc_conv2d: out_dtype must equal dtype for RC_OUT_NHWC");
-        RC_REQUIRE((d->cout * es) % 8 == 0 || !full_tiles, "rc_conv2d: cout*elem_size must be a multiple of 8 bytes");
+        RC_REQUIRE((d->cout * es) % 8 == 0, "rc_conv2d: cout*elem_size must be a multiple of 8 bytes for RC_OUT_NHWC");
         RC_REQUIRE(reinterpret_cast<uintptr_t>(d->out) % 16 == 0, "rc_conv2d: out must be 16-byte aligned");
         if (p.nt == 4 && d->dtype == RC_BF16) RC_REQUIRE(d->cout % 8 == 0, "rc_conv2d: cout % 8");
     } else if (d->out_mode == RC_OUT_PIXEL_SHUFFLE2) {

@@ -1,0 +1,72 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    out = {}
+    sd = {}
+    for k in z.files:
+        v = z[k]
+        if k.startswith("sd."):
+            sd[k[3:]] = torch.from_numpy(v)
+        elif v.dtype.kind in "US":
+            out[k] = str(v)
+        else:
+            out[k] = torch.from_numpy(v)
+    out["sd"] = sd
+    return out
+
+
+def golden_names(prefix):
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith(prefix) and f.endswith(".npz"))
+
+
+def sd_digest(sd) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for k in sd:
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(sd[k].detach().cpu().float().numpy()).tobytes())
+    return h.hexdigest()
+
+
+_SEED0 = {}
+
+
+def seed0_state_dict(name):
+    """state_dict of the build's mirror module constructed under torch.manual_seed(0) (CPU, fp32)."""
+    if name not in _SEED0:
+        import realcamnet_amd as M
+        torch.manual_seed(0)
+        _SEED0[name] = {k: v.clone() for k, v in getattr(M, name)().eval().state_dict().items()}
+    return _SEED0[name]
+
+
+def rel_err(test, ref):
+    ref = ref.double()
+    return ((test.double() - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The loaded C-ABI library; GPU tests fail (not skip) if it or the device is missing."""
+    from realcamnet_amd import _lib
+    lib = _lib.load()
+    assert torch.cuda.is_available(), "gpu-marked test run without a GPU"
+    return lib

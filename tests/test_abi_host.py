@@ -1,0 +1,137 @@
+"""CPU: the C-ABI library loads, exports every declared symbol, and its host-side packing matches the
+fragment layout the kernel documents (checked by emulating the MFMA dataflow in NumPy)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from realcamnet_amd import _lib
+from realcamnet_amd._lib import RC_BF16, RC_F32, RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/realcam_hip.h but not exported"
+    assert set(declared) == set(_lib._SIGS), "ctypes binding table out of sync with the header"
+    assert lib.rc_abi_version() == _lib.ABI_VERSION
+    assert b"gfx950" in lib.rc_build_info()
+
+
+def test_conv_desc_layout_matches_header():
+    lib = _lib.load()
+    assert lib.rc_conv_desc_size() == C.sizeof(_lib.ConvDesc)
+
+
+def test_bad_arguments_are_reported_not_fixed():
+    lib = _lib.load()
+    assert lib.rc_conv_packed_bytes(16, 16, 5, RC_F32, RC_OUT_NHWC) == 0          # 5x5 unsupported
+    assert b"bad shape" in lib.rc_last_error()
+    assert lib.rc_conv2d(None, None) < 0
+    assert lib.rc_bayer_unshuffle(None, RC_F32, None, RC_F32, 1, 4, 4, 4, 4, None) < 0
+    assert b"null" in lib.rc_last_error()
+    assert lib.rc_dwt_forward(1, 1, 1, RC_F32, 1, 5, 4, 8, None) < 0              # odd height
+    assert lib.rc_conv_sum_tiles(1088, 1920) == 136 * 60
+
+
+def _plan(cin, cout, dtype):
+    unit = 4 if dtype == RC_F32 else 8
+    if dtype == RC_BF16:
+        ck = 8 if cin <= 8 else 64 if cin % 64 == 0 else 48 if cin % 48 == 0 else 16
+    else:
+        ck = 4 if cin <= 4 else 16
+    nt = 4 if cout % 64 == 0 else 3 if cout % 48 == 0 else 1
+    return unit, ck, nt
+
+
+def _bf16_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def _emulate(w, x, dtype, out_mode, ks=3):
+    """Re-run the kernel's dataflow on the host-packed weights: returns conv output (cout', H, W) for one
+    8x32 tile, following realcamnet_amd/csrc/conv_kernel.hpp's documented lane mapping."""
+    lib = _lib.load()
+    cout, cin = w.shape[:2]
+    unit, ck, nt = _plan(cin, cout, dtype)
+    upt = ck // unit
+    nu = ks * ks * upt
+    steps = (nu + 3) // 4
+    n_chunks = -(-cin // ck)
+    n_ct = -(-cout // (16 * nt))
+    nbytes = lib.rc_conv_packed_bytes(cin, cout, ks, dtype, out_mode)
+    assert nbytes == n_ct * n_chunks * steps * nt * 1024
+    buf = np.empty(nbytes, np.uint8)
+    wc = np.ascontiguousarray(w, np.float32)
+    assert lib.rc_conv_pack_weights(wc.ctypes.data, cin, cout, ks, dtype, out_mode, buf.ctypes.data) == 0
+    pk = buf.view(np.float32) if dtype == RC_F32 else _bf16_to_f32(buf.view(np.uint16))
+    pk = pk.reshape(n_ct, n_chunks, steps, nt, 64, unit)
+    halo = ks // 2
+    H, W = 8, 32
+    xp = np.zeros((n_chunks * ck, H + 2 * halo, W + 2 * halo), np.float32)
+    xp[:cin, halo:halo + H, halo:halo + W] = x
+    nv = 4 * nt
+    out = np.zeros((n_ct * 16 * nt, H, W), np.float64)   # indexed by PACKED cout
+    lanes = np.arange(64)
+    m_of, q_of, n_of = lanes & 15, lanes >> 4, lanes & 15
+    for ct in range(n_ct):
+        for wave in range(4):
+            for pt in range(4):
+                row, col0 = 2 * wave + (pt >> 1), (pt & 1) * 16
+                for t in range(nt):
+                    D = np.zeros((16, 16))      # D[m][n]
+                    for chunk in range(n_chunks):
+                        for s in range(steps):
+                            A = np.zeros((16, 4, unit)); B = np.zeros((4, unit, 16))
+                            for lane in range(64):
+                                A[m_of[lane], q_of[lane]] = pk[ct, chunk, s, t, lane]
+                                u = 4 * s + q_of[lane]
+                                if u < nu:
+                                    tap, cu = divmod(u, upt)
+                                    dy, dx = divmod(tap, ks)
+                                    c0 = chunk * ck + cu * unit
+                                    B[q_of[lane], :, n_of[lane]] = xp[c0:c0 + unit, row + dy, col0 + n_of[lane] + dx]
+                            D += np.einsum("mqe,qen->mn", A, B)
+                    for lane in range(64):       # C/D layout: col = lane&15, row = 4*(lane>>4) + r
+                        for r in range(4):
+                            j = ct * 16 * nt + q_of[lane] * nv + t * 4 + r
+                            out[j, row, col0 + n_of[lane]] = D[4 * q_of[lane] + r, n_of[lane]]
+    return out, nt
+
+
+@pytest.mark.parametrize("cin,cout,dtype", [(4, 48, RC_BF16), (48, 48, RC_BF16), (16, 32, RC_F32), (64, 64, RC_BF16),
+                                            (4, 16, RC_F32), (48, 3, RC_BF16), (80, 16, RC_F32)])
+def test_packed_weight_layout_reproduces_conv(cin, cout, dtype):
+    rng = np.random.default_rng(0)
+    w = rng.integers(-4, 5, size=(cout, cin, 3, 3)).astype(np.float32) / 4      # exactly representable in bf16
+    x = rng.integers(-4, 5, size=(cin, 8, 32)).astype(np.float32) / 4
+    out, nt = _emulate(w, x, dtype, RC_OUT_NHWC)
+    ref = F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), padding=1)[0].numpy()
+    np.testing.assert_allclose(out[:cout], ref, atol=1e-4)
+    assert np.all(out[cout:] == 0)
+
+
+def test_pixel_shuffle_packing_permutation():
+    lib = _lib.load()
+    cin, cout = 16, 64
+    rng = np.random.default_rng(1)
+    w = rng.integers(-4, 5, size=(cout, cin, 3, 3)).astype(np.float32) / 4
+    x = rng.integers(-4, 5, size=(cin, 8, 32)).astype(np.float32) / 4
+    out, nt = _emulate(w, x, RC_F32, RC_OUT_PIXEL_SHUFFLE2)
+    nv = 4 * nt
+    ref = F.pixel_shuffle(F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), padding=1), 2)[0].numpy()
+    got = np.zeros_like(ref)
+    for j in range(cout):            # kernel epilogue: packed j -> (out channel, sub-pixel)
+        t, q, e = j // (16 * nt), (j // nv) % 4, j % nv
+        got[t * nv + e, (q >> 1)::2, (q & 1)::2] = out[j]
+    np.testing.assert_allclose(got, ref, atol=1e-4)
+    bias = np.arange(cout, dtype=np.float32)
+    dst = np.zeros(lib.rc_conv_packed_cout(cin, cout, 3, RC_F32, RC_OUT_PIXEL_SHUFFLE2), np.float32)
+    assert lib.rc_conv_pack_bias(bias.ctypes.data, cin, cout, 3, RC_F32, RC_OUT_PIXEL_SHUFFLE2, dst.ctypes.data) == 0
+    for j in range(cout):
+        t, q, e = j // (16 * nt), (j // nv) % 4, j % nv
+        assert dst[j] == 4 * (t * nv + e) + q

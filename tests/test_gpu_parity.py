@@ -1,0 +1,237 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle and the reference's golden
+vectors.  Tolerances (stated here, reported as PSNR in bench.py):
+  fp32: max|err| <= 2e-5 * max|ref| per block, end-to-end PSNR >= 100 dB
+        (exact-f32 MFMA is an fmaf chain; ATen-CPU sums in another order -> ~1e-6 relative)
+  bf16: bf16 storage / fp32 accumulate vs the fp32 CPU oracle: per block <= 3e-2 * max|ref|,
+        end-to-end PSNR >= 50 dB (CPU bf16-vs-fp32 of the same net is ~61 dB)
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import liteisp_oracle as O
+import realcamnet_amd as M
+from realcamnet_amd import networks as N
+from realcamnet_amd import ops
+from conftest import golden_names, load_golden, rel_err, seed0_state_dict
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+FP32_TOL, BF16_TOL = 2e-5, 3e-2
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return FP32_TOL if dt == torch.float32 else BF16_TOL
+
+
+def put(mod, sd, dt):
+    mod.load_state_dict(sd, strict=True)
+    return mod.to(device=DEV, dtype=dt).eval()
+
+
+def run(mod, *xs, dt):
+    with torch.no_grad():
+        y = mod(*[x.to(DEV, dt) if isinstance(x, torch.Tensor) else x for x in xs])
+    torch.cuda.synchronize()
+    return y
+
+
+def test_device_is_gfx950(hip):
+    import ctypes
+    buf = ctypes.create_string_buffer(64)
+    assert hip.rc_device_arch(buf, 64) == 0
+    assert buf.value.decode().startswith("gfx950"), buf.value
+
+
+# ---- a1/a2 ingest ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+def test_bayer_unshuffle_bit_exact(hip, dt):
+    g = torch.Generator().manual_seed(1)
+    mosaic = torch.rand(3, 1, 42, 70, generator=g).to(dt)
+    got = ops.bayer_unshuffle(mosaic.to(DEV), pad_to=16)
+    torch.cuda.synchronize()
+    ref, _ = O.pad_to_multiple(O.bayer_unshuffle(mosaic.float()), 16)
+    assert got.shape == (3, 32, 48, 4)
+    assert torch.equal(got.float().cpu().permute(0, 3, 1, 2), ref.to(dt).float())   # pure data movement: exact
+
+
+def test_layout_roundtrip_and_pad(hip):
+    x = torch.randn(2, 37, 13, 29)
+    a = ops.to_nhwc(x.to(DEV), pad_hw=(16, 32))
+    assert torch.equal(a[:, :13, :29].cpu(), x.permute(0, 2, 3, 1))
+    assert a[:, 13:].abs().max() == 0 and a[:, :, 29:].abs().max() == 0
+    assert torch.equal(ops.to_nchw(a, crop_hw=(13, 29)).cpu(), x)
+    g = load_golden("block_pad16")
+    x = torch.rand(*[int(v) for v in g["x_shape"]])
+    yp, hw = M.LiteISP.pad_to_multiple_of_16(x.to(DEV))
+    assert yp.shape == g["y"].shape and hw == tuple(int(v) for v in g["hw"])
+    assert torch.equal(yp.cpu(), O.pad_to_multiple(x, 16)[0])
+
+
+# ---- golden block fixtures (reference outputs) ------------------------------------------------------
+@pytest.mark.parametrize("dt", DTYPES)
+def test_dwt_blocks_vs_reference(hip, dt):
+    g = load_golden("block_dwt_forward")
+    y = run(put(N.DWTForward(16), g["sd"], dt), g["x"], dt=dt)
+    assert rel_err(y.float().cpu(), g["y"]) <= (1e-6 if dt == torch.float32 else 1e-2)
+    g = load_golden("block_dwt_inverse")
+    y = run(put(N.DWTInverse(64), g["sd"], dt), g["x"], dt=dt)
+    assert rel_err(y.float().cpu(), g["y"]) <= (1e-6 if dt == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv_blocks_vs_reference(hip, dt):
+    g = load_golden("block_conv3x3_16_32")                      # ragged 11x37 image, Cout=32 -> 2 cout tiles
+    y = run(put(N.conv(16, 32, mode="C"), g["sd"], dt), g["x"], dt=dt)
+    assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
+    g = load_golden("block_conv_crc_48")                        # conv-relu-conv at the net's 48 channels
+    y = run(put(N.conv(48, 48, mode="CRC"), g["sd"], dt), g["x"], dt=dt)
+    assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("fuse", [True, False])
+def test_channel_attention_blocks_vs_reference(hip, dt, fuse):
+    old = ops.FUSE_GATE
+    ops.FUSE_GATE = fuse
+    try:
+        g = load_golden("block_rcab_32")
+        y = run(put(N.RCABlock(32, 32), g["sd"], dt), g["x"], dt=dt)
+        assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
+        g = load_golden("block_rcag_32_nb4")
+        y = run(put(N.RCAGroup(32, 32, nb=4), g["sd"], dt), g["x"], dt=dt)
+        assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
+        g = load_golden("block_rcag_48_nb2")
+        y = run(put(N.RCAGroup(48, 48, nb=2), g["sd"], dt), g["x"], dt=dt)
+        assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
+    finally:
+        ops.FUSE_GATE = old
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conditioning_blocks_vs_reference(hip, dt):
+    g = load_golden("block_res_gfm_48")
+    mod = put(M.LiteISP.Res_GFM(48, 48, 32, 48, 48), g["sd"], dt)
+    with torch.no_grad():
+        y, _ = mod((g["x"].to(DEV, dt), g["v"].to(DEV)))
+    assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
+    g = load_golden("block_lsc_48")
+    y = run(put(M.LiteISP.Lens_Shading_Correction(2, 48, 48), g["sd"], dt), g["x"], dt=dt)
+    assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
+    g = load_golden("block_color_condition")
+    mod = put(M.LiteISP.Color_Condition_GFM(4, 32), g["sd"], dt)
+    with torch.no_grad():
+        v = mod._vec(g["x"].to(DEV, dt))
+    assert rel_err(v.cpu(), g["y"]) <= (1e-4 if dt == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_tail_pixel_shuffle_vs_reference(hip, dt):
+    g = load_golden("block_tail_16")
+    tail = N.seq(N.conv(16, 64, mode="C"), torch.nn.PixelShuffle(2), N.conv(16, 3, mode="C"))
+    tail = put(tail, g["sd"], dt)
+    with torch.no_grad():
+        a = ops.to_nhwc(g["x"].to(DEV, dt))
+        t = tail[0]._nhwc(a, out_mode=ops.RC_OUT_PIXEL_SHUFFLE2)
+        y = tail[2]._nhwc(t, out_mode=ops.RC_OUT_NCHW)
+    assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
+
+
+# ---- end to end ---------------------------------------------------------------------------------------
+_NETS = {}
+
+
+def net_on_gpu(name, dt):
+    key = (name, dt)
+    if key not in _NETS:
+        net = getattr(M, name)()
+        net.load_state_dict(seed0_state_dict(name), strict=True)
+        _NETS[key] = net.to(device=DEV, dtype=dt).eval()
+    return _NETS[key]
+
+
+@pytest.mark.parametrize("fixture", golden_names("e2e_"))
+@pytest.mark.parametrize("dt", DTYPES)
+def test_end_to_end_vs_reference_golden(hip, fixture, dt):
+    g = load_golden(fixture)
+    name = "LiteISPNet_GFM_LSC" if "GFM_LSC" in fixture else "LiteISPNet"
+    net = net_on_gpu(name, dt)
+    with torch.no_grad():
+        y = net([g["raw"].to(DEV, dt), g["cond"].to(DEV, dt), g["coord"].to(DEV, dt)])
+    torch.cuda.synchronize()
+    assert y.shape == g["y"].shape and y.dtype == dt
+    p = O.psnr(y.float().cpu(), g["y"])
+    assert p >= (100.0 if dt == torch.float32 else 50.0), p
+
+
+@pytest.mark.parametrize("name", ["LiteISPNet", "LiteISPNet_GFM_LSC"])
+def test_batch_and_ragged_mosaic_vs_oracle(hip, name):
+    """B=3 frames of a 2*(43x61)... mosaic: exercises unshuffle+pad-to-16, partial tiles, batch indexing, crop."""
+    g = torch.Generator().manual_seed(7)
+    h, w = 44, 70                                   # packed size; pads to 48x80
+    mosaic = torch.rand(3, 1, 2 * h, 2 * w, generator=g)
+    cond = torch.rand(3, 4, 32, 48, generator=g)
+    coord = O.make_coord(3, h, w)
+    sd = seed0_state_dict(name)
+    with torch.no_grad():
+        ref = O.run_padded(name, sd, O.bayer_unshuffle(mosaic), cond, coord)
+        y = net_on_gpu(name, torch.float32).forward_mosaic(mosaic.to(DEV), cond.to(DEV), coord.to(DEV))
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape == (3, 3, 2 * h, 2 * w)
+    assert O.psnr(y.cpu(), ref) >= 100.0
+    # frames are independent: frame 1 alone gives the same bits as frame 1 inside the batch
+    with torch.no_grad():
+        y1 = net_on_gpu(name, torch.float32).forward_mosaic(mosaic[1:2].to(DEV), cond[1:2].to(DEV), coord[1:2].to(DEV))
+    assert torch.equal(y1[0], y[1])
+
+
+def test_run_to_run_bitwise_stable(hip):
+    g = load_golden("e2e_LiteISPNet_GFM_LSC_64x64")
+    net = net_on_gpu("LiteISPNet_GFM_LSC", torch.bfloat16)
+    x = [g["raw"].to(DEV, torch.bfloat16), g["cond"].to(DEV, torch.bfloat16), g["coord"].to(DEV, torch.bfloat16)]
+    with torch.no_grad():
+        a = net(x).clone()
+        b = net(x)
+    assert torch.equal(a, b)
+
+
+# ---- size-independent properties at a full 4K frame ----------------------------------------------------
+def test_full_size_properties_4k(hip):
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(3)
+    mosaic = torch.rand(1, 1, 2160, 3840, generator=g).to(DEV, dt)
+    a = ops.bayer_unshuffle(mosaic, pad_to=16)
+    assert a.shape == (1, 1088, 1920, 4)
+    assert torch.equal(a[0, :1080].permute(2, 0, 1), F.pixel_unshuffle(mosaic, 2)[0])   # vs torch's own unshuffle, exact
+    assert a[0, 1080:].abs().max() == 0
+    # Haar analysis -> synthesis is the identity (taps are orthonormal): exact in fp32 up to rounding
+    x = torch.rand(1, 1088, 1920, 48, generator=torch.Generator(device=DEV).manual_seed(5), device=DEV)
+    fwd, inv = N.DWTForward(48).to(DEV), N.DWTInverse(192).to(DEV)
+    back = inv._nhwc(fwd._nhwc(x))
+    assert (back - x).abs().max().item() <= 1e-6
+    # conv linearity at full size: conv(2x) - bias == 2*(conv(x) - bias)
+    c = N.conv(48, 48, mode="C").to(DEV)
+    with torch.no_grad():
+        c.bias.zero_()
+        y1 = c._nhwc(x)
+        y2 = c._nhwc(x * 2)
+    assert torch.equal(y2, y1 * 2)           # exact: scaling by 2 commutes with every fp32 rounding
+    # a full 4K frame runs end to end, output finite and cropped to the mosaic size
+    net = net_on_gpu("LiteISPNet_GFM_LSC", dt)
+    with torch.no_grad():
+        y = net.forward_mosaic(mosaic, torch.rand(1, 4, 256, 256, device=DEV).to(dt), O.make_coord(1, 1080, 1920).to(DEV, dt))
+    torch.cuda.synchronize()
+    assert y.shape == (1, 3, 2160, 3840) and torch.isfinite(y.float()).all()
+
+
+def test_shape_errors_are_raised(hip):
+    net = net_on_gpu("LiteISPNet", torch.float32)
+    with pytest.raises(ValueError, match="multiples of 8"):
+        net([torch.zeros(1, 4, 20, 24, device=DEV)])
+    with pytest.raises(ValueError):
+        ops.dwt_forward(torch.zeros(1, 5, 6, 8, device=DEV), N.DWTForward(8).to(DEV))
+    with pytest.raises(ValueError):
+        ops.conv2d(torch.zeros(1, 8, 8, 12, device=DEV), N.conv(16, 16, mode="C").to(DEV))

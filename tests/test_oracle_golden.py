@@ -1,0 +1,92 @@
+"""CPU: the oracle restatement vs fixtures produced by the imported reference (oracle/make_golden.py)."""
+import pytest
+import torch
+
+import liteisp_oracle as O
+from conftest import golden_names, load_golden, sd_digest, seed0_state_dict
+
+torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
+
+# the oracle equalled the reference bitwise when the fixtures were made (same torch, 1 thread); across
+# thread counts oneDNN may reorder sums, hence a tight tolerance instead of equality.
+TOL = dict(rtol=0, atol=2e-6)
+
+
+def _close(a, b, scale_tol=3e-6):
+    assert a.shape == b.shape
+    err = (a - b).abs().max().item()
+    assert err <= scale_tol * max(1.0, b.abs().max().item()), err
+
+
+def test_dwt_blocks():
+    g = load_golden("block_dwt_forward")
+    _close(O.dwt_forward({"w.weight": g["sd"]["weight"]}, "w", g["x"]), g["y"])
+    g = load_golden("block_dwt_inverse")
+    _close(O.dwt_inverse({"w.weight": g["sd"]["weight"]}, "w", g["x"]), g["y"])
+
+
+def test_dwt_roundtrip_is_identity():
+    g = load_golden("block_dwt_forward")
+    gi = load_golden("block_dwt_inverse")
+    x = g["x"]
+    y = O.dwt_forward({"w.weight": g["sd"]["weight"]}, "w", x)
+    back = O.dwt_inverse({"w.weight": gi["sd"]["weight"][: 4 * x.shape[1]]}, "w", y)
+    _close(back, x)
+
+
+def test_conv_blocks():
+    g = load_golden("block_conv3x3_16_32")
+    _close(O.conv({"c.weight": g["sd"]["weight"], "c.bias": g["sd"]["bias"]}, "c", g["x"]), g["y"])
+    g = load_golden("block_conv_crc_48")
+    sd = g["sd"]
+    y = O.conv(sd, "2", torch.relu(O.conv(sd, "0", g["x"])))
+    _close(y, g["y"])
+
+
+def test_channel_attention_blocks():
+    g = load_golden("block_calayer_32")
+    _close(O.ca_layer({"ca." + k: v for k, v in g["sd"].items()}, "ca", g["x"]), g["y"])
+    g = load_golden("block_rcab_32")
+    _close(O.rcab({"b." + k: v for k, v in g["sd"].items()}, "b", g["x"]), g["y"])
+    g = load_golden("block_rcag_32_nb4")
+    _close(O.rcag({"g." + k: v for k, v in g["sd"].items()}, "g", g["x"], nb=4), g["y"])
+    g = load_golden("block_rcag_48_nb2")
+    _close(O.rcag({"g." + k: v for k, v in g["sd"].items()}, "g", g["x"], nb=2), g["y"])
+
+
+def test_conditioning_blocks():
+    g = load_golden("block_res_gfm_48")
+    _close(O.res_gfm({"m." + k: v for k, v in g["sd"].items()}, "m", g["x"], g["v"]), g["y"])
+    g = load_golden("block_lsc_48")
+    _close(O.lens_shading({"l." + k: v for k, v in g["sd"].items()}, "l", g["x"]), g["y"])
+    g = load_golden("block_color_condition")
+    _close(O.color_condition_gfm({"c." + k: v for k, v in g["sd"].items()}, "c", g["x"]), g["y"])
+
+
+def test_tail_and_padding():
+    g = load_golden("block_tail_16")
+    sd = g["sd"]
+    y = O.conv(sd, "2", O.pixel_shuffle2(O.conv(sd, "0", g["x"])))
+    _close(y, g["y"])
+    g = load_golden("block_pad16")
+    x = torch.zeros(*[int(v) for v in g["x_shape"]])
+    yp, hw = O.pad_to_multiple(x, 16)
+    assert yp.shape == g["y"].shape and tuple(int(v) for v in g["hw"]) == hw
+    assert O.remove_padding(torch.zeros(1, 3, 2 * yp.shape[2], 2 * yp.shape[3]), hw).shape[-2:] == (2 * hw[0], 2 * hw[1])
+
+
+def test_bayer_unshuffle_matches_pixel_unshuffle():
+    x = torch.rand(2, 1, 12, 20)
+    assert torch.equal(O.bayer_unshuffle(x), torch.nn.functional.pixel_unshuffle(x, 2))
+
+
+@pytest.mark.parametrize("fixture", golden_names("e2e_"))
+def test_end_to_end_vs_reference(fixture):
+    g = load_golden(fixture)
+    name = "LiteISPNet_GFM_LSC" if "GFM_LSC" in fixture else "LiteISPNet"
+    sd = seed0_state_dict(name)
+    assert sd_digest(sd) == g["sd_digest"], "mirror module's seed-0 parameters differ from the reference's"
+    with torch.no_grad():
+        y = O.FORWARDS[name](sd, [g["raw"], g["cond"], g["coord"]])
+    _close(y, g["y"], scale_tol=1e-5)
+    assert O.psnr(y, g["y"]) > 120.0
