@@ -135,8 +135,9 @@ size_t rc_conv_desc_size(void);
 /* ---- a8: CALayer gate -------------------------------------------------------------------------
  * Replaces: AdaptiveAvgPool2d(1) -> Conv1x1(C,C/r) -> ReLU -> Conv1x1(C/r,C) -> Sigmoid
  * (models/networks.py:259-269).  d_sums: (B, n_tiles, C) partials from rc_conv2d; w0 (Cr,C), b0 (Cr),
- * w1 (C,Cr), b1 (C) fp32 device; gate: (B,C) fp32.  Fixed-order reduction => run-to-run bitwise stable. */
-int rc_ca_gate(const float* d_sums, int batch, int n_tiles, int c, int cr, float inv_hw,
+ * w1 (C,Cr), b1 (C) fp32 device; gate: (B,C) fp32.  Fixed-order reduction => run-to-run bitwise stable.
+ * d_sums is scratch after the call (large images are folded in place in a first stage). */
+int rc_ca_gate(float* d_sums, int batch, int n_tiles, int c, int cr, float inv_hw,
                const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,
                float* d_gate, void* stream);
 
@@ -148,10 +149,12 @@ int rc_gate_residual(const void* d_r, const float* d_gate, const void* d_x, void
 /* ---- a10: Haar DWT / IDWT as the reference's frozen grouped conv -----------------------------
  * Replaces: DWTForward (models/networks.py:224-235) / DWTInverse (:238-249).  taps: device fp32
  * (4C,1,2,2) exactly as stored in the state_dict ("down1.3.weight", "up1.0.weight").
- * forward: (B,H,W,C) -> (B,H/2,W/2,4C), channel 4c+k.  inverse: (B,h,w,4C) -> (B,2h,2w,C). */
-int rc_dwt_forward(const void* d_x, void* d_y, const float* d_taps, int dtype,
+ * forward: (B,H,W,C) -> (B,H/2,W/2,4C), channel 4c+k.  inverse: (B,h,w,4C) -> (B,2h,2w,C).
+ * taps_uniform != 0: the caller guarantees every channel carries the taps of channel 0 (true for the
+ * reference's Haar init, networks.py:228-233); the kernel then keeps the 16 taps in scalar registers. */
+int rc_dwt_forward(const void* d_x, void* d_y, const float* d_taps, int taps_uniform, int dtype,
                    int batch, int H, int W, int c, void* stream);
-int rc_dwt_inverse(const void* d_x, void* d_y, const float* d_taps, int dtype,
+int rc_dwt_inverse(const void* d_x, void* d_y, const float* d_taps, int taps_uniform, int dtype,
                    int batch, int h, int w, int c4, void* stream);
 
 /* ---- a6: Color_Condition_GFM (global colour prior) --------------------------------------------
@@ -183,6 +186,9 @@ int rc_gfm_vector(const float* d_vec, int batch, int cond_c, int nf, int c,
  * rc_prof_enable(1) brackets each subsequent rc_conv2d with hipEventRecord on the launch stream;
  * rc_prof_collect() synchronises the events and returns launches / total ms / total algorithmic
  * FLOPs (2*MAC at the padded size) since the last rc_prof_enable(1). */
+/* A/B switches for tests and benches.  "persist": 0 routes every conv through the general kernel
+ * instead of the persistent weights-resident variant (results must be identical). */
+int rc_debug_set(const char* key, int value);
 int rc_prof_enable(int on);
 int rc_prof_collect(int64_t* n_launches, double* total_ms, double* total_flops);
 

@@ -62,12 +62,13 @@ _SIGS = {
     "rc_conv_desc_size": (_SZ, []),
     "rc_ca_gate": (C.c_int, [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "rc_gate_residual": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "rc_dwt_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "rc_dwt_inverse": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rc_dwt_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "rc_dwt_inverse": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rc_color_block": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "rc_instance_stats": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "rc_color_head": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "rc_gfm_vector": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "rc_debug_set": (C.c_int, [C.c_char_p, _I]),
     "rc_prof_enable": (C.c_int, [_I]),
     "rc_prof_collect": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

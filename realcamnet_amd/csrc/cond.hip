@@ -7,7 +7,34 @@
 namespace rc {
 
 // ---- CALayer gate: fixed-order reduction of the conv's per-tile channel sums + 2-layer MLP -------
-__global__ __launch_bounds__(256) void ca_gate_kernel(const float* __restrict__ sums, int n_tiles, int c, int cr,
+// Stage 1 (large images): block (k, b) folds tiles [k*L, (k+1)*L) of image b into slot k*L, in place
+// (a block only ever writes inside its own range, so there is no cross-block hazard).  Fixed order.
+__global__ __launch_bounds__(256) void ca_reduce_kernel(float* __restrict__ sums, int n_tiles, int c, int L) {
+    __shared__ float part[256];
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    float* s = sums + (size_t)b * n_tiles * c;
+    const int t0 = k * L, t1 = (t0 + L) < n_tiles ? (t0 + L) : n_tiles;
+    for (int c0 = 0; c0 < c; c0 += 256) {
+        const int cw = (c - c0) < 256 ? (c - c0) : 256;
+        const int nparts = 256 / cw;
+        const int ch = tid % cw, pt = tid / cw;
+        float acc = 0.f;
+        if (pt < nparts)
+            for (int t = t0 + pt; t < t1; t += nparts) acc += s[(size_t)t * c + c0 + ch];
+        part[tid] = acc;
+        __syncthreads();
+        if (tid < cw) {
+            float tot = 0.f;
+            for (int p = 0; p < nparts; ++p) tot += part[p * cw + tid];
+            s[(size_t)t0 * c + c0 + tid] = tot;
+        }
+        __syncthreads();
+    }
+}
+
+// Stage 2: sum `n_tiles` slots spaced `tile_stride` tiles apart, then the 2-layer gate MLP.
+__global__ __launch_bounds__(256) void ca_gate_kernel(const float* __restrict__ sums, int n_tiles, int tile_stride,
+                                                      size_t image_stride, int c, int cr,
                                                       float inv_hw, const float* __restrict__ w0,
                                                       const float* __restrict__ b0, const float* __restrict__ w1,
                                                       const float* __restrict__ b1, float* __restrict__ gate) {
@@ -16,14 +43,14 @@ __global__ __launch_bounds__(256) void ca_gate_kernel(const float* __restrict__ 
     float* mean = sm + 256;
     float* hid = mean + c;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float* s = sums + (size_t)b * n_tiles * c;
+    const float* s = sums + (size_t)b * image_stride;
     for (int c0 = 0; c0 < c; c0 += 256) {
         const int cw = (c - c0) < 256 ? (c - c0) : 256;   // channels in this pass
         const int nparts = 256 / cw;                       // >= 1
         const int ch = tid % cw, pt = tid / cw;
         float acc = 0.f;
         if (pt < nparts)
-            for (int t = pt; t < n_tiles; t += nparts) acc += s[(size_t)t * c + c0 + ch];
+            for (int t = pt; t < n_tiles; t += nparts) acc += s[(size_t)t * tile_stride * c + c0 + ch];
         part[tid] = acc;
         __syncthreads();
         if (tid < cw) {
@@ -155,15 +182,23 @@ using namespace rc;
 
 extern "C" {
 
-int rc_ca_gate(const float* d_sums, int batch, int n_tiles, int c, int cr, float inv_hw,
+int rc_ca_gate(float* d_sums, int batch, int n_tiles, int c, int cr, float inv_hw,
                const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,
                float* d_gate, void* stream) {
     RC_REQUIRE(d_sums && d_w0 && d_b0 && d_w1 && d_b1 && d_gate, "rc_ca_gate: null pointer");
     RC_REQUIRE(batch >= 1 && n_tiles >= 1 && c >= 1 && cr >= 1, "rc_ca_gate: bad shape");
     const size_t lds = (256 + (size_t)c + cr) * sizeof(float);
     RC_REQUIRE(lds <= 64 * 1024, "rc_ca_gate: too many channels");
-    hipLaunchKernelGGL(ca_gate_kernel, dim3(batch), dim3(256), lds, as_stream(stream), d_sums, n_tiles, c, cr, inv_hw,
-                       d_w0, d_b0, d_w1, d_b1, d_gate);
+    RC_REQUIRE(batch <= 65535, "rc_ca_gate: batch > 65535");
+    int slots = n_tiles, stride = 1;
+    if (n_tiles > 128) {  // two-stage: ~64 slices per image folded in place first
+        const int L = ceil_div(n_tiles, 64);
+        slots = ceil_div(n_tiles, L);
+        stride = L;
+        hipLaunchKernelGGL(ca_reduce_kernel, dim3(slots, batch), dim3(256), 0, as_stream(stream), d_sums, n_tiles, c, L);
+    }
+    hipLaunchKernelGGL(ca_gate_kernel, dim3(batch), dim3(256), lds, as_stream(stream), d_sums, slots, stride,
+                       (size_t)n_tiles * c, c, cr, inv_hw, d_w0, d_b0, d_w1, d_b1, d_gate);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

@@ -47,6 +47,7 @@ static int packed_to_cout(const ConvPlan& p, int cout, int out_mode, int j) {
     return j < cout ? j : -1;
 }
 
+static bool g_persist_on = true;   // rc_debug_set("persist", 0) forces the general kernel (A/B checks)
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 struct ProfRec { hipEvent_t e0, e1; double flops; };
@@ -119,6 +120,12 @@ size_t rc_conv_desc_size(void) { return sizeof(rc_conv_desc); }
 
 int rc_conv_sum_tiles(int height, int width) { return ceil_div(height, kTH) * ceil_div(width, kTW); }
 
+int rc_debug_set(const char* key, int value) {
+    RC_REQUIRE(key != nullptr, "rc_debug_set: null key");
+    if (std::string(key) == "persist") { g_persist_on = value != 0; return RC_OK; }
+    return fail(RC_ERR_INVALID, std::string("rc_debug_set: unknown key ") + key);
+}
+
 int rc_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -189,6 +196,16 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     a.mul_plus1 = d->mul_plus1; a.residual = d->residual;
     a.out = d->out; a.out_mode = d->out_mode; a.out_dtype = d->out_dtype; a.out_h = d->out_h; a.out_w = d->out_w;
     a.chan_sums = d->chan_sums; a.cout_packed = p.cout_packed;
+    {
+        static int num_cus = 0;
+        if (num_cus == 0) {
+            int dev = 0;
+            RC_HIP_CHECK(hipGetDevice(&dev));
+            RC_HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        a.num_cus = num_cus;
+        a.persist_ok = g_persist_on ? 1 : 0;
+    }
 
     hipStream_t stream = as_stream(stream_);
     bool prof;

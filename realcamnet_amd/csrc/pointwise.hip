@@ -116,10 +116,15 @@ __global__ void gate_residual_kernel(const T* __restrict__ r, const float* __res
 // ---- Haar DWT as the reference's frozen grouped conv (taps read from the state_dict tensor) ------
 // forward: x (B,H,W,C) -> y (B,H/2,W/2,4C): y[.., 4c+k] = sum_{i,j} taps[4c+k][i][j] * x[2y+i][2x+j][c]
 // One thread per (output pixel, 16-byte group of input channels).
-template <typename T>
+template <typename T, bool UNIFORM>
 __global__ void dwt_forward_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ taps,
                                    int batch, int H, int W, int c) {
     constexpr int U = Vec16<T>::N;
+    float ut[16];
+    if constexpr (UNIFORM) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ut[k] = taps[k];   // wave-uniform -> scalar registers
+    }
     const int h = H / 2, w = W / 2, vpp = c / U;
     const size_t total = (size_t)batch * h * w * vpp;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -135,7 +140,7 @@ __global__ void dwt_forward_kernel(const T* __restrict__ x, T* __restrict__ y, c
         float out[4 * U];
 #pragma unroll
         for (int e = 0; e < U; ++e) {
-            const float* tp = taps + (size_t)(4 * (v * U + e)) * 4;   // (4C,1,2,2): 4 floats per out channel
+            const float* tp = UNIFORM ? ut : taps + (size_t)(4 * (v * U + e)) * 4;   // (4C,1,2,2): 4 floats per out channel
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float s = in[0][e] * tp[k * 4 + 0];
@@ -153,10 +158,15 @@ __global__ void dwt_forward_kernel(const T* __restrict__ x, T* __restrict__ y, c
 
 // inverse: x (B,h,w,4C) -> y (B,2h,2w,C): y[2y+i][2x+j][c] = sum_k taps[4c+k][i][j] * x[y][x][4c+k]
 // One thread per (input pixel, 16-byte group of OUTPUT channels) = 4 input vectors -> 4 output vectors.
-template <typename T>
+template <typename T, bool UNIFORM>
 __global__ void dwt_inverse_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ taps,
                                    int batch, int h, int w, int c4) {
     constexpr int U = Vec16<T>::N;
+    float ut[16];
+    if constexpr (UNIFORM) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ut[k] = taps[k];
+    }
     const int c = c4 / 4, vpp = c / U;
     const size_t total = (size_t)batch * h * w * vpp;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -170,7 +180,7 @@ __global__ void dwt_inverse_kernel(const T* __restrict__ x, T* __restrict__ y, c
         float out[4][U];
 #pragma unroll
         for (int e = 0; e < U; ++e) {
-            const float* tp = taps + (size_t)(4 * (v * U + e)) * 4;
+            const float* tp = UNIFORM ? ut : taps + (size_t)(4 * (v * U + e)) * 4;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float s = in[4 * e + 0] * tp[0 * 4 + t];
@@ -265,7 +275,7 @@ int rc_gate_residual(const void* d_r, const float* d_gate, const void* d_x, void
     return RC_OK;
 }
 
-int rc_dwt_forward(const void* d_x, void* d_y, const float* d_taps, int dtype,
+int rc_dwt_forward(const void* d_x, void* d_y, const float* d_taps, int taps_uniform, int dtype,
                    int batch, int H, int W, int c, void* stream) {
     RC_REQUIRE(d_x && d_y && d_taps, "rc_dwt_forward: null pointer");
     RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_dwt_forward: bad dtype");
@@ -273,17 +283,22 @@ int rc_dwt_forward(const void* d_x, void* d_y, const float* d_taps, int dtype,
     RC_REQUIRE(batch >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "rc_dwt_forward: H and W must be even");
     RC_REQUIRE(c % U == 0, "rc_dwt_forward: channels must be a multiple of 16 bytes");
     const size_t total = (size_t)batch * (H / 2) * (W / 2) * (c / U);
-    if (dtype == RC_F32)
-        hipLaunchKernelGGL(dwt_forward_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+    if (dtype == RC_F32) {
+        if (taps_uniform) hipLaunchKernelGGL((dwt_forward_kernel<float, true>), dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
                            static_cast<const float*>(d_x), static_cast<float*>(d_y), d_taps, batch, H, W, c);
-    else
-        hipLaunchKernelGGL(dwt_forward_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+        else hipLaunchKernelGGL((dwt_forward_kernel<float, false>), dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const float*>(d_x), static_cast<float*>(d_y), d_taps, batch, H, W, c);
+    } else {
+        if (taps_uniform) hipLaunchKernelGGL((dwt_forward_kernel<bf16_t, true>), dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
                            static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_y), d_taps, batch, H, W, c);
+        else hipLaunchKernelGGL((dwt_forward_kernel<bf16_t, false>), dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_y), d_taps, batch, H, W, c);
+    }
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
 
-int rc_dwt_inverse(const void* d_x, void* d_y, const float* d_taps, int dtype,
+int rc_dwt_inverse(const void* d_x, void* d_y, const float* d_taps, int taps_uniform, int dtype,
                    int batch, int h, int w, int c4, void* stream) {
     RC_REQUIRE(d_x && d_y && d_taps, "rc_dwt_inverse: null pointer");
     RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_dwt_inverse: bad dtype");
@@ -291,12 +306,17 @@ int rc_dwt_inverse(const void* d_x, void* d_y, const float* d_taps, int dtype,
     RC_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && c4 % 4 == 0 && (c4 / 4) % U == 0,
                "rc_dwt_inverse: out channels (c4/4) must be a multiple of 16 bytes");
     const size_t total = (size_t)batch * h * w * (c4 / 4 / U);
-    if (dtype == RC_F32)
-        hipLaunchKernelGGL(dwt_inverse_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+    if (dtype == RC_F32) {
+        if (taps_uniform) hipLaunchKernelGGL((dwt_inverse_kernel<float, true>), dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
                            static_cast<const float*>(d_x), static_cast<float*>(d_y), d_taps, batch, h, w, c4);
-    else
-        hipLaunchKernelGGL(dwt_inverse_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+        else hipLaunchKernelGGL((dwt_inverse_kernel<float, false>), dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const float*>(d_x), static_cast<float*>(d_y), d_taps, batch, h, w, c4);
+    } else {
+        if (taps_uniform) hipLaunchKernelGGL((dwt_inverse_kernel<bf16_t, true>), dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
                            static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_y), d_taps, batch, h, w, c4);
+        else hipLaunchKernelGGL((dwt_inverse_kernel<bf16_t, false>), dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_y), d_taps, batch, h, w, c4);
+    }
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

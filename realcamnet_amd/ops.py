@@ -271,6 +271,19 @@ def gate_residual(r: torch.Tensor, gate: torch.Tensor, x: torch.Tensor) -> torch
     return y
 
 
+def _taps_uniform(mod) -> int:
+    """1 if every channel of a DWT module carries the same 4x(2x2) taps (the reference's Haar init);
+    checked once per parameter version on the host."""
+    c = _cache(mod)
+    key = _key(mod.weight)
+    hit = c.get("taps_uniform")
+    if hit is None or hit[0] != key:
+        w = mod.weight.detach().float().reshape(-1, 4, 4)
+        hit = (key, int(bool((w == w[:1]).all().item())))
+        c["taps_uniform"] = hit
+    return hit[1]
+
+
 def dwt_forward(x: torch.Tensor, mod) -> torch.Tensor:
     x = _req(x, "dwt input")
     b, H, W, c = x.shape
@@ -279,7 +292,7 @@ def dwt_forward(x: torch.Tensor, mod) -> torch.Tensor:
     if mod.weight.shape[0] != 4 * c:
         raise ValueError("DWTForward channel mismatch")
     y = torch.empty((b, H // 2, W // 2, 4 * c), dtype=x.dtype, device=x.device)
-    check(lib().rc_dwt_forward(x.data_ptr(), y.data_ptr(), f32_param(mod, "weight").data_ptr(), _dt(x), b, H, W, c, _stream()), "rc_dwt_forward")
+    check(lib().rc_dwt_forward(x.data_ptr(), y.data_ptr(), f32_param(mod, "weight").data_ptr(), _taps_uniform(mod), _dt(x), b, H, W, c, _stream()), "rc_dwt_forward")
     return y
 
 
@@ -289,7 +302,7 @@ def dwt_inverse(x: torch.Tensor, mod) -> torch.Tensor:
     if mod.weight.shape[0] != c4:
         raise ValueError("DWTInverse channel mismatch")
     y = torch.empty((b, 2 * h, 2 * w, c4 // 4), dtype=x.dtype, device=x.device)
-    check(lib().rc_dwt_inverse(x.data_ptr(), y.data_ptr(), f32_param(mod, "weight").data_ptr(), _dt(x), b, h, w, c4, _stream()), "rc_dwt_inverse")
+    check(lib().rc_dwt_inverse(x.data_ptr(), y.data_ptr(), f32_param(mod, "weight").data_ptr(), _taps_uniform(mod), _dt(x), b, h, w, c4, _stream()), "rc_dwt_inverse")
     return y
 
 

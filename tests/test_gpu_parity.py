@@ -235,3 +235,45 @@ def test_shape_errors_are_raised(hip):
         ops.dwt_forward(torch.zeros(1, 5, 6, 8, device=DEV), N.DWTForward(8).to(DEV))
     with pytest.raises(ValueError):
         ops.conv2d(torch.zeros(1, 8, 8, 12, device=DEV), N.conv(16, 16, mode="C").to(DEV))
+
+
+def test_persistent_kernel_equals_general_kernel(hip):
+    """The weights-resident persistent conv (single chunk, single cout tile) and the general kernel are the
+    same arithmetic in the same order: outputs, stored inputs and channel sums must match bit for bit."""
+    g = torch.Generator().manual_seed(11)
+    for dt in DTYPES:
+        for (cin, cout, hw) in ((48, 48, (40, 100)), (48, 3, (24, 64)), (4, 48, (16, 40))):
+            c = N.conv(cin, cout, mode="C").to(DEV, dt)
+            x = torch.randn(3, hw[0], hw[1], cin, generator=g).to(DEV, dt)
+            skip = torch.randn(3, hw[0], hw[1], cin, generator=g).to(DEV, dt)
+            gate = torch.rand(3, cin, generator=g).to(DEV)
+            outs = []
+            for persist in (1, 0):
+                assert hip.rc_debug_set(b"persist", persist) == 0
+                if cout == 3:
+                    r = (ops.conv2d(x, c, out_mode=ops.RC_OUT_NCHW, crop_hw=(hw[0] - 3, hw[1] - 5)),)
+                else:
+                    r = ops.conv2d(x, c, act="relu", gate=gate, skip=skip, store_input=True, want_sums=True)
+                torch.cuda.synchronize()
+                outs.append([t.clone() for t in r])
+            hip.rc_debug_set(b"persist", 1)
+            for a_, b_ in zip(*outs):
+                assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_dwt_with_arbitrary_per_channel_taps(hip, dt):
+    """The DWT taps are state_dict parameters; a checkpoint with non-Haar, per-channel taps must be honoured."""
+    g = torch.Generator().manual_seed(5)
+    fwd, inv = N.DWTForward(16), N.DWTInverse(64)
+    with torch.no_grad():
+        fwd.weight.copy_(torch.randn(fwd.weight.shape, generator=g))
+        inv.weight.copy_(torch.randn(inv.weight.shape, generator=g))
+    x = torch.randn(2, 16, 12, 20, generator=g)
+    ref_f = O.dwt_forward({"w.weight": fwd.weight.detach()}, "w", x)
+    ref_i = O.dwt_inverse({"w.weight": inv.weight.detach()}, "w", ref_f)
+    t = 1e-6 if dt == torch.float32 else 2e-2
+    yf = run(fwd.to(DEV, dt).eval(), x, dt=dt)
+    assert rel_err(yf.float().cpu(), ref_f) <= t
+    yi = run(inv.to(DEV, dt).eval(), ref_f, dt=dt)
+    assert rel_err(yi.float().cpu(), ref_i) <= t
