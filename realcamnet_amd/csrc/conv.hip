@@ -30,7 +30,7 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
     if (out_mode == RC_OUT_PIXEL_SHUFFLE2 && (cout % (16 * p->nt) != 0)) return false;
     p->upt = p->ck / p->unit;
     p->nu = ksize * ksize * p->upt;
-    p->steps = (p->nu + 3) / 4;
+    p->steps = unit_map_steps(p->upt, ksize * ksize);
     p->n_chunks = ceil_div(cin, p->ck);
     p->n_ct = ceil_div(cout, 16 * p->nt);
     p->cout_packed = p->n_ct * 16 * p->nt;
@@ -84,14 +84,14 @@ int rc_conv_pack_weights(const float* w, int cin, int cout, int ksize, int dtype
                 for (int nt = 0; nt < p.nt; ++nt)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int m = lane & 15, qk = lane >> 4;
-                        const int u = 4 * s + qk;
+                        int tap = 0, cu = 0;
+                        const bool live = unit_map(p.upt, kk, s, qk, tap, cu);
                         // MFMA row m of cout tile nt lands in lane group m>>2, register m&3
                         const int j = ct * 16 * p.nt + (m >> 2) * (4 * p.nt) + nt * 4 + (m & 3);
                         const int co = packed_to_cout(p, cout, out_mode, j);
                         for (int e = 0; e < p.unit; ++e) {
                             float val = 0.f;
-                            if (u < p.nu && co >= 0 && co < cout) {
-                                const int tap = u / p.upt, cu = u % p.upt;
+                            if (live && co >= 0 && co < cout) {
                                 const int ci = chunk * p.ck + cu * p.unit + e;
                                 if (ci < cin) val = w[((size_t)co * cin + ci) * kk + tap];
                             }
@@ -179,6 +179,11 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
         RC_REQUIRE(d->out_h >= 1 && d->out_h <= d->height && d->out_w >= 1 && d->out_w <= d->width, "rc_conv2d: bad NCHW crop");
         RC_REQUIRE(d->out_dtype == RC_F32 || d->out_dtype == RC_BF16, "rc_conv2d: bad out_dtype");
     }
+    {   // buffer descriptors use signed 32-bit byte offsets inside one image
+        const double lim = 2147483647.0;
+        RC_REQUIRE((double)d->height * d->width * d->cin * es < lim, "rc_conv2d: one input image must be < 2 GiB");
+        RC_REQUIRE((double)d->height * d->width * d->cout * 4.0 < lim, "rc_conv2d: one output image must be < 2 GiB");
+    }
     if (d->residual) RC_REQUIRE(reinterpret_cast<uintptr_t>(d->residual) % 16 == 0, "rc_conv2d: residual must be 16-byte aligned");
     if (d->mul_plus1) RC_REQUIRE(reinterpret_cast<uintptr_t>(d->mul_plus1) % 16 == 0, "rc_conv2d: mul_plus1 must be 16-byte aligned");
 
@@ -205,6 +210,8 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
         }
         a.num_cus = num_cus;
         a.persist_ok = g_persist_on ? 1 : 0;
+        a.inv_tiles_x = 1.0f / (float)a.tiles_x;
+        a.inv_sp_total = 1.0f / (float)(a.tiles_x * a.tiles_y);
     }
 
     hipStream_t stream = as_stream(stream_);

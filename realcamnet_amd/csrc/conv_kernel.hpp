@@ -10,14 +10,18 @@
 // One "step" = 4 units (one per 16-lane group q = lane>>4):
 //   bf16: 1 x v_mfma_f32_16x16x32_bf16 (K = 32 channels-of-taps)
 //   fp32: 4 x v_mfma_f32_16x16x4_f32   (element j of each unit in MFMA j; K = 4 each)
-// Units are numbered tap-major, so a step may span two taps (Cin = 48 -> 6 units per tap); each
-// lane group simply reads its own (tap, channel) address from a per-lane table.
+// Which (tap, channel-unit) a lane group handles in a step is fixed by unit_map() below, shared with
+// the host-side weight packer.  For Cin chunks of 6 units (48 bf16 channels -- the flagship width) the
+// map keeps every LDS address "per-lane constant + compile-time immediate" (no address table).
 //
 // Block = 256 threads = 4 waves; block tile = 8 rows x 32 cols of pixels x (16*NT) couts;
 // wave w owns rows 2w, 2w+1 (4 pixel tiles of 16) x NT cout tiles -> 4*NT accumulator tiles.
 // The input halo tile (10 x 34 pixels x CK channels) is staged once per Cin chunk in LDS with a
 // pixel stride == 32 (mod 64) bytes, which makes the 16-lane-group ds_read_b128 conflict-free.
-// Packed weights are streamed through LDS G steps at a time.
+//
+// Memory instructions are buffer loads/stores against per-image descriptors with 32-bit offsets:
+// zero padding, ragged edges and crops are hardware bounds checks (offset = kOOB -> load 0 / store
+// dropped), so there are no divergent branches in the staging or store paths.
 #pragma once
 #include "common.hpp"
 
@@ -35,6 +39,7 @@ struct ConvArgs {
     void* out; int out_mode; int out_dtype; int out_h, out_w;
     float* chan_sums; int cout_packed;
     int num_cus; int persist_ok;
+    float inv_tiles_x, inv_sp_total;   // reciprocals for the persistent kernel's tile decode
 };
 
 constexpr int kTH = 8, kTW = 32, kThreads = 256;
@@ -46,6 +51,26 @@ constexpr int pix_stride_bytes(int ck_bytes) {
     return s;
 }
 
+// ---- unit map: which (tap, channel unit) does lane group q handle in MFMA step s? ------------------
+// Shared by the device kernels and the host packer (rc_conv_pack_weights).
+//   upt % 4 == 0 : linear, a step never spans taps                       (64 bf16 / 16 fp32 channels)
+//   upt == 6     : step t < taps  -> tap t, units 0..3;                  (48 bf16 channels)
+//                  step taps + p  -> units 4,5 of taps 2p (q=0,1) and 2p+1 (q=2,3)
+//   otherwise    : linear over (tap, unit); steps may span taps          (tiny Cin: head, lens shading)
+__host__ __device__ constexpr int unit_map_steps(int upt, int taps) {
+    return upt == 6 ? taps + (taps + 1) / 2 : (taps * upt + 3) / 4;
+}
+__host__ __device__ constexpr bool unit_map(int upt, int taps, int s, int q, int& tap, int& cu) {
+    if (upt == 6) {
+        if (s < taps) { tap = s; cu = q; return true; }
+        tap = 2 * (s - taps) + (q >> 1); cu = 4 + (q & 1);
+        return tap < taps;
+    }
+    const int u = 4 * s + q;
+    tap = u / upt; cu = u % upt;
+    return u < taps * upt;
+}
+
 template <typename T, int CK_, int NT_, int KS_>
 struct ConvCfg {
     using elem = T;
@@ -54,8 +79,7 @@ struct ConvCfg {
     static_assert(CK % UNIT == 0, "CK must be a whole number of 16-byte units");
     static constexpr int UPT = CK / UNIT;         // units per tap
     static constexpr int TAPS = KS * KS;
-    static constexpr int NU = TAPS * UPT;         // units per Cin chunk
-    static constexpr int STEPS = (NU + 3) / 4;    // MFMA steps per Cin chunk
+    static constexpr int STEPS = unit_map_steps(UPT, TAPS);  // MFMA steps per Cin chunk
     static constexpr int HALO = KS / 2;
     static constexpr int THH = kTH + 2 * HALO, TWH = kTW + 2 * HALO;
     static constexpr int SPIX = pix_stride_bytes(CK * (int)sizeof(T));
@@ -63,13 +87,31 @@ struct ConvCfg {
     static constexpr int G_RAW = (80 * 1024 - IN_BYTES) / (NT * 1024);
     static constexpr int G_CAP = G_RAW < 1 ? 1 : (G_RAW > STEPS ? STEPS : G_RAW);
     static constexpr int NSUB = (STEPS + G_CAP - 1) / G_CAP;
-    static constexpr int G = (STEPS + NSUB - 1) / NSUB;  // steps of weights resident in LDS
+    static constexpr int G = (STEPS + NSUB - 1) / NSUB;  // steps of weights resident in LDS (general kernel)
     static constexpr int W_BYTES = G * NT * 1024;
-    static constexpr int RED_BYTES = 4 * 16 * NT * 4;     // per-wave channel partial sums
-    static constexpr int LDS_BYTES = IN_BYTES + (W_BYTES > RED_BYTES ? W_BYTES : RED_BYTES);
     static constexpr int COUT_TILE = 16 * NT;
+    static constexpr int RED_BYTES = 4 * COUT_TILE * 4;   // per-wave channel partial sums
+    static constexpr int LDS_BYTES = IN_BYTES + (W_BYTES > RED_BYTES ? W_BYTES : RED_BYTES);
     static constexpr size_t CHUNK_W_BYTES = (size_t)STEPS * NT * 1024;  // packed weights per (ct, chunk)
 };
+
+// Out-of-bounds sentinel for buffer offsets: stays >= num_records (< 2 GiB by contract, checked on the host)
+// after a row's immediate offsets are added -- unlike ~0, which wraps back into the image.
+constexpr int kOOB = (int)0x80000000;
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, int voff, const uint4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, r, voff, 0, 0);
+}
 
 // ---- MFMA wrappers -------------------------------------------------------------------------------
 template <typename T> struct Mma;
@@ -87,47 +129,56 @@ template <> struct Mma<float> {
     }
 };
 
-// Store NV consecutive elements (given as floats) of type TO at dst (alignment ALIGN bytes).
-template <typename TO, int NV>
-__device__ __forceinline__ void store_row(TO* dst, const float* v) {
-    constexpr int BYTES = NV * (int)sizeof(TO);
-    if constexpr (sizeof(TO) == 4) {
-        static_assert(NV % 4 == 0, "");
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return Vec16<bf16_t>::rne(lo) | (Vec16<bf16_t>::rne(hi) << 16);
+}
+
+// Store / load NV consecutive elements of type TT at byte offset voff of a buffer (OOB -> dropped / 0).
+template <typename TT, int NV>
+__device__ __forceinline__ void buf_store_row(__amdgpu_buffer_rsrc_t r, int voff, const float* v) {
+    if constexpr (sizeof(TT) == 4) {
 #pragma unroll
         for (int i = 0; i < NV; i += 4)
-            *reinterpret_cast<float4*>(dst + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
-    } else {
-        if constexpr (BYTES % 16 == 0) {
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v[i]), __float_as_uint(v[i + 1]), __float_as_uint(v[i + 2]), __float_as_uint(v[i + 3])},
+                                                   r, voff + 4 * i, 0, 0);
+    } else if constexpr ((NV * 2) % 16 == 0) {
 #pragma unroll
-            for (int i = 0; i < NV; i += 8) *reinterpret_cast<uint4*>(dst + i) = Vec16<bf16_t>::pack(v + i);
-        } else {  // 8-byte pieces (NT = 3 or 1 with bf16: 24 / 8 bytes per lane)
+        for (int i = 0; i < NV; i += 8)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pack_bf16x2(v[i], v[i + 1]), pack_bf16x2(v[i + 2], v[i + 3]),
+                                                           pack_bf16x2(v[i + 4], v[i + 5]), pack_bf16x2(v[i + 6], v[i + 7])},
+                                                   r, voff + 2 * i, 0, 0);
+    } else {  // 8-byte pieces (bf16 with NT = 3 or 1: 24 / 8 bytes per lane)
 #pragma unroll
-            for (int i = 0; i < NV; i += 4) {
-                uint2 p;
-                p.x = Vec16<bf16_t>::rne(v[i]) | (Vec16<bf16_t>::rne(v[i + 1]) << 16);
-                p.y = Vec16<bf16_t>::rne(v[i + 2]) | (Vec16<bf16_t>::rne(v[i + 3]) << 16);
-                *reinterpret_cast<uint2*>(dst + i) = p;
-            }
-        }
+        for (int i = 0; i < NV; i += 4)
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack_bf16x2(v[i], v[i + 1]), pack_bf16x2(v[i + 2], v[i + 3])}, r, voff + 2 * i, 0, 0);
     }
 }
 
-template <typename TI, int NV>
-__device__ __forceinline__ void load_row(const TI* src, float* v) {
-    if constexpr (sizeof(TI) == 4) {
+template <typename TT, int NV>
+__device__ __forceinline__ void buf_load_row(__amdgpu_buffer_rsrc_t r, int voff, float* v) {
+    if constexpr (sizeof(TT) == 4) {
 #pragma unroll
         for (int i = 0; i < NV; i += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(src + i);
-            v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+            const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 4 * i, 0, 0);
+            v[i] = __uint_as_float(t.x); v[i + 1] = __uint_as_float(t.y); v[i + 2] = __uint_as_float(t.z); v[i + 3] = __uint_as_float(t.w);
         }
     } else {
 #pragma unroll
         for (int i = 0; i < NV; i += 4) {
-            const uint2 p = *reinterpret_cast<const uint2*>(src + i);
+            const u32x2_t p = __builtin_amdgcn_raw_buffer_load_b64(r, voff + 2 * i, 0, 0);
             v[i] = __uint_as_float(p.x << 16); v[i + 1] = __uint_as_float(p.x & 0xffff0000u);
             v[i + 2] = __uint_as_float(p.y << 16); v[i + 3] = __uint_as_float(p.y & 0xffff0000u);
         }
     }
+}
+
+// exact t / d for 0 <= t < 2^24 using a float reciprocal (+-1 correction); no integer division.
+__device__ __forceinline__ int fast_div(int t, int d, float inv_d) {
+    int q = (int)((float)t * inv_d);
+    int r = t - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) ++q;
+    return q;
 }
 
 // ==================================================================================================
@@ -136,48 +187,98 @@ __device__ __forceinline__ void load_row(const TI* src, float* v) {
 template <class Cfg>
 struct ConvDev {
     using T = typename Cfg::elem;
-    static constexpr int CK = Cfg::CK, NT = Cfg::NT, KS = Cfg::KS, UNIT = Cfg::UNIT, UPT = Cfg::UPT;
-    static constexpr int NU = Cfg::NU, STEPS = Cfg::STEPS, HALO = Cfg::HALO, THH = Cfg::THH, TWH = Cfg::TWH;
-    static constexpr int SPIX = Cfg::SPIX, NV = 4 * NT;
+    static constexpr int CK = Cfg::CK, NT = Cfg::NT, KS = Cfg::KS, UNIT = Cfg::UNIT, UPT = Cfg::UPT, TAPS = Cfg::TAPS;
+    static constexpr int STEPS = Cfg::STEPS, HALO = Cfg::HALO, THH = Cfg::THH, TWH = Cfg::TWH;
+    static constexpr int SPIX = Cfg::SPIX, NV = 4 * NT, ES = (int)sizeof(T);
     static constexpr int VPP = UPT;                       // 16-byte vectors per pixel
     static constexpr int NPIX = THH * TWH;                // pixels in one halo tile
-    static constexpr int TOTAL = NPIX * VPP;              // vectors in one halo tile
     // staging map: thread t always owns channel group v = t % VPP and walks pixels t/VPP + k*PPP, so
-    // per-channel data (the CALayer gate) is loaded once per tile, and consecutive threads touch
-    // consecutive 16-byte pieces (coalesced global loads, conflict-free LDS writes).
+    // per-channel data (the CALayer gate) is loaded once per tile, consecutive threads touch consecutive
+    // 16-byte pieces (coalesced loads, conflict-free LDS writes) and LDS addresses are lane-const + imm.
     static constexpr int PPP = kThreads / VPP;            // pixels per pass
     static constexpr int ACTIVE = PPP * VPP;              // threads that take part in staging
     static constexpr int NI = (NPIX + PPP - 1) / PPP;     // passes
+    static constexpr bool TABLE = (UPT % 4 != 0) && (UPT != 6);   // generic map needs a per-lane address table
 
-    // per-lane LDS byte offset of this lane group's unit for every step of a chunk
-    __device__ static __forceinline__ void unit_offsets(int q, int (&uoff)[STEPS]) {
+    __device__ static constexpr int tap_off(int tap) { return ((tap / KS) * TWH + (tap % KS)) * SPIX; }
+
+    // per-lane operand-address state (bytes into the LDS input tile, relative to the pixel-tile origin)
+    struct LaneOff {
+        int a;   // q*16                                   : steps whose 4 units are consecutive in one tap
+        int b;   // (q>>1)*SPIX          + (4+(q&1))*16    : paired step, second tap = next column
+        int c;   // (q>>1)*(TWH-2)*SPIX  + (4+(q&1))*16    : paired step, second tap = first column of next row
+        int tab[TABLE ? STEPS : 1];
+    };
+    __device__ static __forceinline__ void lane_offsets(int q, LaneOff& lo) {
+        lo.a = q * 16;
+        lo.b = (q >> 1) * SPIX + (4 + (q & 1)) * 16;
+        lo.c = (q >> 1) * (TWH - 2) * SPIX + (4 + (q & 1)) * 16;
+        if constexpr (TABLE) {
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            int u = 4 * s + q;
-            if (u >= NU) u = NU - 1;  // padded unit: any valid address; the operand is zeroed in mma_steps
-            const int tap = u / UPT, cu = u % UPT;
-            uoff[s] = ((tap / KS) * TWH + (tap % KS)) * SPIX + cu * 16;
+            for (int s = 0; s < STEPS; ++s) {
+                int tap = 0, cu = 0;
+                if (!unit_map(UPT, TAPS, s, q, tap, cu)) { tap = TAPS - 1; cu = UPT - 1; }  // padded: any valid address
+                lo.tab[s] = tap_off(tap) + cu * 16;
+            }
+        } else {
+            lo.tab[0] = 0;
         }
     }
+    // byte offset of this lane group's unit for step s (s is a compile-time constant after unrolling)
+    __device__ static __forceinline__ int step_off(int s, const LaneOff& lo) {
+        if constexpr (TABLE) {
+            return lo.tab[s];
+        } else if constexpr (UPT == 6) {
+            if (s < TAPS) return lo.a + tap_off(s);
+            const int t0 = 2 * (s - TAPS);
+            const bool wrap = (t0 + 1 < TAPS) && ((t0 + 1) % KS == 0);   // second tap starts a new kernel row
+            return (wrap ? lo.c : lo.b) + tap_off(t0);
+        } else {
+            const int u = 4 * s;
+            return lo.a + tap_off(u / UPT) + (u % UPT) * 16;
+        }
+    }
+    // does some lane group of step s carry a padding unit (operand must be zeroed)?
+    __device__ static constexpr bool step_has_pad(int s) {
+        int tap = 0, cu = 0;
+        return !unit_map(UPT, TAPS, s, 3, tap, cu);
+    }
+    __device__ static __forceinline__ bool lane_is_pad(int s, int q) {
+        if constexpr (UPT == 6) return q >= 2;            // only the odd tap of the last pair can be missing
+        else return 4 * s + q >= TAPS * UPT;
+    }
 
-    // element offset of (halo pixel pix, channel group v) in the NHWC tensor, or -1 (zero padding / idle)
-    __device__ static __forceinline__ long tile_vec_offset(const ConvArgs& a, size_t img_base, int y0, int x0,
-                                                           int chunk, int pix, int v, bool live, bool& center) {
+    // ---- input staging ----------------------------------------------------------------------------
+    struct TileSrc {
+        __amdgpu_buffer_rsrc_t r0, r1, rst;   // in0 / in1 (skip) / in_store, one image each
+        int gy0, gx0;                         // global coords of halo pixel (0,0)
+    };
+    __device__ static __forceinline__ TileSrc tile_src(const ConvArgs& a, int b, int y0, int x0) {
+        const size_t img = (size_t)a.H * a.W * a.cin;
+        const unsigned bytes = (unsigned)(img * ES);
+        TileSrc t;
+        t.r0 = make_rsrc(static_cast<const T*>(a.in0) + (size_t)b * img, bytes);
+        t.r1 = make_rsrc(a.in1 ? static_cast<const T*>(a.in1) + (size_t)b * img : nullptr, a.in1 ? bytes : 0u);
+        t.rst = make_rsrc(a.in_store ? static_cast<T*>(a.in_store) + (size_t)b * img : nullptr, a.in_store ? bytes : 0u);
+        t.gy0 = y0 - HALO; t.gx0 = x0 - HALO;
+        return t;
+    }
+    // byte offset of (halo pixel pix, channel group v) inside the image, or kOOB (-> zero fill / dropped)
+    __device__ static __forceinline__ int vec_off(const ConvArgs& a, const TileSrc& t, int chunk, int pix, int v,
+                                                  bool live, bool& center) {
         const int py = pix / TWH, px = pix - py * TWH;
-        const int gy = y0 + py - HALO, gx = x0 + px - HALO;
+        const int gy = t.gy0 + py, gx = t.gx0 + px;
         const int c0 = chunk * CK + v * UNIT;
         center = py >= HALO && py < HALO + kTH && px >= HALO && px < HALO + kTW;
-        const bool ok = live && pix < NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c0 < a.cin;
-        return ok ? (long)((img_base + (size_t)gy * a.W + gx) * a.cin + c0) : -1;
+        const bool ok = live && pix < NPIX && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && c0 < a.cin;
+        return ok ? ((gy * a.W + gx) * a.cin + c0) * ES : kOOB;
     }
 
     // Issue every global load of one halo tile back-to-back into registers (vector path only).
     template <bool GATED>
-    __device__ static __forceinline__ void load_tile(const ConvArgs& a, size_t img_base, int b, int y0, int x0,
-                                                     int chunk, int tid, uint4 (&r0)[NI], uint4 (&r1)[GATED ? NI : 1],
+    __device__ static __forceinline__ void load_tile(const ConvArgs& a, const TileSrc& t, int b, int chunk, int tid,
+                                                     uint4 (&r0)[NI], uint4 (&r1)[GATED ? NI : 1],
                                                      float (&gv)[GATED ? UNIT : 1]) {
-        const T* in0 = static_cast<const T*>(a.in0);
-        const T* in1 = static_cast<const T*>(a.in1);
         const int v = tid % VPP, p0 = tid / VPP;
         const bool live = tid < ACTIVE;
         if constexpr (GATED) {
@@ -188,58 +289,55 @@ struct ConvDev {
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             bool center;
-            const long off = tile_vec_offset(a, img_base, y0, x0, chunk, p0 + k * PPP, v, live, center);
-            r0[k] = make_uint4(0u, 0u, 0u, 0u);
-            if constexpr (GATED) r1[k] = make_uint4(0u, 0u, 0u, 0u);
-            if (off >= 0) {
-                r0[k] = *reinterpret_cast<const uint4*>(in0 + off);
-                if constexpr (GATED) r1[k] = *reinterpret_cast<const uint4*>(in1 + off);
-            }
+            const int off = vec_off(a, t, chunk, p0 + k * PPP, v, live, center);
+            r0[k] = buf_load16(t.r0, off);
+            if constexpr (GATED) r1[k] = buf_load16(t.r1, off);
         }
     }
 
     // Combine (CALayer gate + skip), optionally materialise, and write the tile to LDS.
     template <bool GATED>
-    __device__ static __forceinline__ void commit_tile(const ConvArgs& a, size_t img_base, int y0, int x0, int chunk,
-                                                       int tid, const uint4 (&r0)[NI], const uint4 (&r1)[GATED ? NI : 1],
-                                                       const float (&gv)[GATED ? UNIT : 1], char* s_in, T* in_store) {
+    __device__ static __forceinline__ void commit_tile(const ConvArgs& a, const TileSrc& t, int chunk, int tid,
+                                                       const uint4 (&r0)[NI], const uint4 (&r1)[GATED ? NI : 1],
+                                                       const float (&gv)[GATED ? UNIT : 1], char* s_in) {
         const int v = tid % VPP, p0 = tid / VPP;
         const bool live = tid < ACTIVE;
+        char* dst = s_in + p0 * SPIX + v * 16;
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int pix = p0 + k * PPP;
-            if (live && pix < NPIX) {
-                uint4 raw = r0[k];
-                if constexpr (GATED) {
-                    bool center;
-                    const long off = tile_vec_offset(a, img_base, y0, x0, chunk, pix, v, live, center);
-                    if (off >= 0) {
-                        float f0[UNIT], f1[UNIT];
-                        Vec16<T>::unpack(r0[k], f0);
-                        Vec16<T>::unpack(r1[k], f1);
+            uint4 raw = r0[k];
+            if constexpr (GATED) {
+                float f0[UNIT], f1[UNIT];
+                Vec16<T>::unpack(r0[k], f0);
+                Vec16<T>::unpack(r1[k], f1);
 #pragma unroll
-                        for (int e = 0; e < UNIT; ++e) f0[e] = f0[e] * gv[e] + f1[e];
-                        raw = Vec16<T>::pack(f0);
-                        if (in_store != nullptr && center) *reinterpret_cast<uint4*>(in_store + off) = raw;
-                    }
-                }
-                *reinterpret_cast<uint4*>(s_in + pix * SPIX + v * 16) = raw;
+                for (int e = 0; e < UNIT; ++e) f0[e] = f0[e] * gv[e] + f1[e];   // zero-filled lanes stay 0*g+0 = 0
+                raw = Vec16<T>::pack(f0);
+                bool center;
+                const int off = vec_off(a, t, chunk, pix, v, live, center);
+                buf_store16(t.rst, center ? off : kOOB, raw);                      // rst has 0 records if in_store == NULL
             }
+            if (live && pix < NPIX) *reinterpret_cast<uint4*>(dst + k * PPP * SPIX) = raw;
         }
     }
 
-    // tiny / odd Cin (head 4->C, lens-shading 2->C): element loads straight to LDS
-    __device__ static __forceinline__ void stage_tile_scalar(const ConvArgs& a, size_t img_base, int b, int y0, int x0,
-                                                             int chunk, int tid, char* s_in, T* in_store) {
+    // tiny / odd Cin (head 4->C, lens-shading 2->C): element loads straight to LDS (never gated in practice,
+    // but the gate is honoured for completeness)
+    __device__ static __forceinline__ void stage_tile_scalar(const ConvArgs& a, int b, int y0, int x0, int chunk, int tid,
+                                                             char* s_in, T* in_store) {
         const T* in0 = static_cast<const T*>(a.in0);
         const T* in1 = static_cast<const T*>(a.in1);
-        for (int i = tid; i < TOTAL; i += kThreads) {
+        const size_t img_base = (size_t)b * a.H * a.W;
+        for (int i = tid; i < NPIX * VPP; i += kThreads) {
             const int pix = i / VPP, v = i - pix * VPP;
-            bool center;
-            const long off = tile_vec_offset(a, img_base, y0, x0, chunk, pix, v, true, center);
+            const int py = pix / TWH, px = pix - py * TWH;
+            const int gy = y0 + py - HALO, gx = x0 + px - HALO;
             const int c0 = chunk * CK + v * UNIT;
+            const bool center = py >= HALO && py < HALO + kTH && px >= HALO && px < HALO + kTW;
             uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-            if (off >= 0) {
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c0 < a.cin) {
+                const size_t off = (img_base + (size_t)gy * a.W + gx) * a.cin + c0;
                 float f0[UNIT];
 #pragma unroll
                 for (int e = 0; e < UNIT; ++e) {
@@ -270,119 +368,151 @@ struct ConvDev {
                                              (__attribute__((address_space(3))) void*)(dst + kb * 1024), 16, 0, 0);
     }
 
-    // MFMA steps [S0, S0+COUNT) of a chunk; weights for step s live at s_w + (s - W0)*NT KiB.
+    // ---- MFMA steps [S0, S0+COUNT) of a chunk; weights of step s live at s_w + (s - W0)*NT KiB ------
+    // Operand fragments are double-buffered in registers: step s+1's LDS reads are issued before step s's
+    // MFMAs so LDS latency hides under the matrix pipe.
+    __device__ static __forceinline__ void load_frags(int s, int w0, const char* s_in, const char* s_w, int lane_x,
+                                                      int lane_w, int q, const LaneOff& lo, uint4 (&wf)[NT], uint4 (&xf)[4]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            wf[nt] = *reinterpret_cast<const uint4*>(s_w + ((s - w0) * NT + nt) * 1024 + lane_w);
+        const char* xp = s_in + lane_x + step_off(s, lo);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+            xf[pt] = *reinterpret_cast<const uint4*>(xp + ((pt >> 1) * TWH + (pt & 1) * 16) * SPIX);
+        if (step_has_pad(s)) {                 // compile-time after unrolling
+            if (lane_is_pad(s, q)) {
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) xf[pt] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    }
+    __device__ static __forceinline__ void mma_frags(const uint4 (&wf)[NT], const uint4 (&xf)[4], f32x4 (&acc)[4][NT]) {
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(wf[nt], xf[pt], acc[pt][nt]);
+    }
     template <int S0, int COUNT, int W0>
     __device__ static __forceinline__ void mma_steps(const char* s_in, const char* s_w, int lane_x, int lane_w, int q,
-                                                     const int (&uoff)[STEPS], f32x4 (&acc)[4][NT]) {
+                                                     const LaneOff& lo, f32x4 (&acc)[4][NT]) {
+        constexpr int END = (S0 + COUNT) < STEPS ? (S0 + COUNT) : STEPS;
+        if constexpr (S0 < END) {
+            uint4 wfa[NT], xfa[4], wfb[NT], xfb[4];
+            load_frags(S0, W0, s_in, s_w, lane_x, lane_w, q, lo, wfa, xfa);
 #pragma unroll
-        for (int sl = 0; sl < COUNT; ++sl) {
-            const int s = S0 + sl;
-            if (s < STEPS) {
-                uint4 wf[NT], xf[4];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    wf[nt] = *reinterpret_cast<const uint4*>(s_w + ((s - W0) * NT + nt) * 1024 + lane_w);
-                const char* xp = s_in + lane_x + uoff[s];
-#pragma unroll
-                for (int pt = 0; pt < 4; ++pt)
-                    xf[pt] = *reinterpret_cast<const uint4*>(xp + ((pt >> 1) * TWH + (pt & 1) * 16) * SPIX);
-                if constexpr (NU % 4 != 0) {
-                    if (s == STEPS - 1 && 4 * s + q >= NU) {
-#pragma unroll
-                        for (int pt = 0; pt < 4; ++pt) xf[pt] = make_uint4(0u, 0u, 0u, 0u);
-                    }
-                }
-#pragma unroll
-                for (int pt = 0; pt < 4; ++pt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) Mma<T>::run(wf[nt], xf[pt], acc[pt][nt]);
+            for (int s = S0; s < END; s += 2) {
+                if (s + 1 < END) load_frags(s + 1, W0, s_in, s_w, lane_x, lane_w, q, lo, wfb, xfb);
+                mma_frags(wfa, xfa, acc);
+                if (s + 2 < END) load_frags(s + 2, W0, s_in, s_w, lane_x, lane_w, q, lo, wfa, xfa);
+                if (s + 1 < END) mma_frags(wfb, xfb, acc);
             }
         }
     }
 
-    // Epilogue operands that can be fetched before the MFMA loop (so their latency hides under it).
-    struct EpiPre {
-        float bias_v[NV];
-    };
-    __device__ static __forceinline__ void epilogue_prefetch(const ConvArgs& a, int b, int jbase, EpiPre& e) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) e.bias_v[i] = a.bias ? a.bias[jbase + i] : 0.f;
-    }
-
+    // ---- epilogue ---------------------------------------------------------------------------------------
     // lane (q, n) holds, per pixel tile pt, packed couts jbase .. jbase+NV-1 of pixel (row, col0+n).
-    // red: LDS scratch of 4*16*NT floats, not aliased with anything still being read.
+    // bias_v: this lane's NV bias values.  red: LDS scratch of 4*16*NT floats not aliased with live data.
     __device__ static __forceinline__ void epilogue(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
-                                                    const EpiPre& pre, f32x4 (&acc)[4][NT], float* red) {
+                                                    const float (&bias_v)[NV], f32x4 (&acc)[4][NT], float* red) {
         const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
         const int jbase = ct * Cfg::COUT_TILE + q * NV;
-        const size_t img_base = (size_t)b * a.H * a.W;
+        float fs[NV], ft[NV];
+        const bool film = a.film_scale != nullptr;
+        if (film) {                               // Res_GFM: (B,cout) vectors, L2-resident
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+                const bool in = jbase + e < a.cout;
+                fs[e] = in ? a.film_scale[(size_t)b * a.cout + jbase + e] : 0.f;
+                ft[e] = in ? a.film_shift[(size_t)b * a.cout + jbase + e] : 0.f;
+            }
+        }
+        const int gy_w = y0 + 2 * wave, gx_l = x0 + n;
         float csum[NV];
 #pragma unroll
         for (int e = 0; e < NV; ++e) csum[e] = 0.f;
 
+        const size_t img_out = (size_t)a.H * a.W * a.cout;    // NHWC output / residual / mul image (elements)
+        const unsigned img_bytes_out = (unsigned)(img_out * ES);
+        const __amdgpu_buffer_rsrc_t r_res = make_rsrc(a.residual ? static_cast<const T*>(a.residual) + (size_t)b * img_out : nullptr,
+                                                       a.residual ? img_bytes_out : 0u);
+        const __amdgpu_buffer_rsrc_t r_mul = make_rsrc(a.mul_plus1 ? static_cast<const T*>(a.mul_plus1) + (size_t)b * img_out : nullptr,
+                                                       a.mul_plus1 ? img_bytes_out : 0u);
+        __amdgpu_buffer_rsrc_t r_out;
+        if (a.out_mode == RC_OUT_NCHW) {
+            const size_t plane = (size_t)a.out_h * a.out_w;
+            const int osz = a.out_dtype == RC_F32 ? 4 : 2;
+            r_out = make_rsrc(static_cast<char*>(a.out) + (size_t)b * a.cout * plane * osz, (unsigned)(a.cout * plane * osz));
+        } else {  // NHWC (H,W,cout) or pixel-shuffled (2H,2W,cout/4): same bytes per image
+            r_out = make_rsrc(static_cast<T*>(a.out) + (size_t)b * img_out, img_bytes_out);
+        }
+        const bool full = a.cout == a.cout_packed;
+
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
-            const int gy = y0 + 2 * wave + (pt >> 1);
-            const int gx = x0 + (pt & 1) * 16 + n;
+            const int gy = gy_w + (pt >> 1);
+            const int gx = gx_l + (pt & 1) * 16;
             const bool valid = gy < a.H && gx < a.W;
             float v[NV];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[pt][nt][r] + pre.bias_v[nt * 4 + r];
-            if (a.film_scale != nullptr) {  // Res_GFM: (B,cout) vectors, L2-resident
+                for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[pt][nt][r] + bias_v[nt * 4 + r];
+            if (film) {
 #pragma unroll
-                for (int e = 0; e < NV; ++e) {
-                    if (jbase + e < a.cout) {
-                        const float fs = a.film_scale[(size_t)b * a.cout + jbase + e];
-                        const float ft = a.film_shift[(size_t)b * a.cout + jbase + e];
-                        v[e] = v[e] * fs + ft + v[e];
-                    }
-                }
+                for (int e = 0; e < NV; ++e) v[e] = v[e] * fs[e] + ft[e] + v[e];
             }
+            if (a.act == RC_ACT_RELU) {
 #pragma unroll
-            for (int e = 0; e < NV; ++e) v[e] = apply_act(v[e], a.act, a.act_slope);
-            if (!valid) continue;
-            const size_t pix = img_base + (size_t)gy * a.W + gx;
+                for (int e = 0; e < NV; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (a.act == RC_ACT_LEAKY) {
+#pragma unroll
+                for (int e = 0; e < NV; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.act_slope;
+            }
+            const int pix_off = valid ? ((gy * a.W + gx) * a.cout + jbase) * ES : kOOB;   // NHWC-shaped operands
             if (a.mul_plus1 != nullptr) {
                 float m[NV];
-                load_row<T, NV>(static_cast<const T*>(a.mul_plus1) + pix * a.cout + jbase, m);
+                buf_load_row<T, NV>(r_mul, pix_off, m);
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] = v[e] * (m[e] + 1.f);
             }
             if (a.residual != nullptr) {
                 float m[NV];
-                load_row<T, NV>(static_cast<const T*>(a.residual) + pix * a.cout + jbase, m);
+                buf_load_row<T, NV>(r_res, pix_off, m);
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] += m[e];
             }
+            if (a.chan_sums != nullptr) {
 #pragma unroll
-            for (int e = 0; e < NV; ++e) csum[e] += v[e];
+                for (int e = 0; e < NV; ++e) csum[e] += valid ? v[e] : 0.f;
+            }
 
             if (a.out_mode == RC_OUT_NHWC) {
-                if (jbase + NV <= a.cout) {
-                    store_row<T, NV>(static_cast<T*>(a.out) + pix * a.cout + jbase, v);
-                } else {
+                if (full) {
+                    buf_store_row<T, NV>(r_out, pix_off, v);
+                } else {  // ragged cout (test sizes): element stores
 #pragma unroll
-                    for (int e = 0; e < NV; ++e)
-                        if (jbase + e < a.cout) static_cast<T*>(a.out)[pix * a.cout + jbase + e] = from_f32<T>(v[e]);
+                    for (int e = 0; e < NV; ++e) {
+                        const int o = (valid && jbase + e < a.cout) ? pix_off + e * ES : kOOB;
+                        if constexpr (ES == 4) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[e]), r_out, o, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b16((unsigned short)Vec16<bf16_t>::rne(v[e]), r_out, o, 0, 0);
+                    }
                 }
             } else if (a.out_mode == RC_OUT_PIXEL_SHUFFLE2) {
                 // packed cout tile `ct` holds out channels ct*NV .. ct*NV+NV-1 for sub-pixel q
                 const int cps = a.cout >> 2;
-                const size_t opix = ((size_t)b * (2 * a.H) + (2 * gy + (q >> 1))) * (2 * a.W) + (2 * gx + (q & 1));
-                store_row<T, NV>(static_cast<T*>(a.out) + opix * cps + ct * NV, v);
+                const int o = valid ? (((2 * gy + (q >> 1)) * (2 * a.W) + (2 * gx + (q & 1))) * cps + ct * NV) * ES : kOOB;
+                buf_store_row<T, NV>(r_out, o, v);
             } else {  // RC_OUT_NCHW, cropped
-                if (gy < a.out_h && gx < a.out_w) {
+                const bool inside = gy < a.out_h && gx < a.out_w;
 #pragma unroll
-                    for (int e = 0; e < NV; ++e) {
-                        const int co = jbase + e;
-                        if (co < a.cout) {
-                            const size_t o = (((size_t)b * a.cout + co) * a.out_h + gy) * a.out_w + gx;
-                            if (a.out_dtype == RC_F32) static_cast<float*>(a.out)[o] = v[e];
-                            else static_cast<bf16_t*>(a.out)[o] = from_f32<bf16_t>(v[e]);
-                        }
-                    }
+                for (int e = 0; e < NV; ++e) {
+                    const int co = jbase + e;
+                    const int idx = (co * a.out_h + gy) * a.out_w + gx;
+                    if (a.out_dtype == RC_F32)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[e]), r_out, (inside && co < a.cout) ? idx * 4 : kOOB, 0, 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)Vec16<bf16_t>::rne(v[e]), r_out, (inside && co < a.cout) ? idx * 2 : kOOB, 0, 0);
                 }
             }
         }
@@ -432,9 +562,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a
     const int b = blockIdx.y;
     const int y0 = ty * kTH, x0 = tx * kTW;
 
-    int uoff[STEPS];
-    D::unit_offsets(q, uoff);
-    const int lane_x = ((2 * wave) * D::TWH + n) * D::SPIX;  // + pixel-tile immediates in mma_steps
+    typename D::LaneOff lo;
+    D::lane_offsets(q, lo);
+    const int lane_x = ((2 * wave) * D::TWH + n) * D::SPIX;  // + pixel-tile immediates in load_frags
     const int lane_w = lane * 16;
 
     f32x4 acc[4][NT];
@@ -443,12 +573,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[pt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    T* in_store = (ct == 0) ? static_cast<T*>(a.in_store) : nullptr;
-    const size_t img_base = (size_t)b * a.H * a.W;
+    ConvArgs aa = a;
+    if (ct != 0) aa.in_store = nullptr;       // only one cout tile materialises the gated input
+    const typename D::TileSrc ts = D::tile_src(aa, b, y0, x0);
     const char* wbase = static_cast<const char*>(a.wpacked) + (size_t)ct * a.n_chunks * Cfg::CHUNK_W_BYTES;
-
-    typename D::EpiPre pre;
-    D::epilogue_prefetch(a, b, ct * Cfg::COUT_TILE + q * NV, pre);
 
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
         if (chunk > 0) __syncthreads();  // all waves done reading s_in / s_w of the previous chunk
@@ -457,53 +585,56 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a
         if (a.cin_vec_ok) {
             uint4 r0[D::NI], r1[GATED ? D::NI : 1];
             float gv[GATED ? D::UNIT : 1];
-            D::template load_tile<GATED>(a, img_base, b, y0, x0, chunk, tid, r0, r1, gv);
-            D::template commit_tile<GATED>(a, img_base, y0, x0, chunk, tid, r0, r1, gv, s_in, in_store);
+            D::template load_tile<GATED>(aa, ts, b, chunk, tid, r0, r1, gv);
+            D::template commit_tile<GATED>(aa, ts, chunk, tid, r0, r1, gv, s_in);
         } else {
-            D::stage_tile_scalar(a, img_base, b, y0, x0, chunk, tid, s_in, in_store);
+            D::stage_tile_scalar(aa, b, y0, x0, chunk, tid, s_in, static_cast<T*>(aa.in_store));
         }
         __syncthreads();
-        D::template mma_steps<0, G, 0>(s_in, s_w, lane_x, lane_w, q, uoff, acc);
+        D::template mma_steps<0, G, 0>(s_in, s_w, lane_x, lane_w, q, lo, acc);
         if constexpr (NSUB > 1) {
             __syncthreads();
             D::dma_weights(wchunk + (size_t)G * NT * 1024, s_w, ((STEPS - G) < G ? (STEPS - G) : G) * NT, wave, lane_w);
             __syncthreads();
-            D::template mma_steps<G, G, G>(s_in, s_w, lane_x, lane_w, q, uoff, acc);
+            D::template mma_steps<G, G, G>(s_in, s_w, lane_x, lane_w, q, lo, acc);
         }
         if constexpr (NSUB > 2) {
             __syncthreads();
             D::dma_weights(wchunk + (size_t)2 * G * NT * 1024, s_w, ((STEPS - 2 * G) < G ? (STEPS - 2 * G) : G) * NT, wave, lane_w);
             __syncthreads();
-            D::template mma_steps<2 * G, G, 2 * G>(s_in, s_w, lane_x, lane_w, q, uoff, acc);
+            D::template mma_steps<2 * G, G, 2 * G>(s_in, s_w, lane_x, lane_w, q, lo, acc);
         }
         static_assert(NSUB <= 3, "add another weight sub-stage");
     }
+    float bias_v[NV];
+#pragma unroll
+    for (int e = 0; e < NV; ++e) bias_v[e] = a.bias ? a.bias[ct * Cfg::COUT_TILE + q * NV + e] : 0.f;
     if (a.chan_sums != nullptr) __syncthreads();  // s_w (reused as reduction scratch) no longer read
-    D::epilogue(a, b, y0, x0, sp, ct, tid, pre, acc, reinterpret_cast<float*>(s_w));
+    D::epilogue(a, b, y0, x0, sp, ct, tid, bias_v, acc, reinterpret_cast<float*>(s_w));
 }
 
 // ==================================================================================================
 // Kernel 2: persistent form for single-chunk, single-cout-tile layers (Cin == CK, Cout <= 16*NT) -- the
-// 48->48 convolutions that dominate the flagship net.  The whole packed weight matrix stays in LDS for
-// the block's lifetime; the block walks a strided list of tiles and issues the NEXT tile's halo loads
-// into registers before the MFMA loop, so HBM latency hides under compute.  Two such blocks share a CU
-// and drift out of phase (one in MFMA while the other stores / stages).
+// 48->48 convolutions that dominate the flagship net.  The whole packed weight matrix (and the bias)
+// stays in LDS for the block's lifetime; the block walks a strided list of tiles and issues the NEXT
+// tile's halo loads into registers before the MFMA loop, so HBM latency hides under compute.  Two such
+// blocks share a CU and drift out of phase (one in MFMA while the other stores / stages).
 // ==================================================================================================
 template <class Cfg, bool GATED>
 __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const ConvArgs a) {
     using D = ConvDev<Cfg>;
-    using T = typename Cfg::elem;
     constexpr int NT = Cfg::NT, STEPS = Cfg::STEPS, NV = 4 * NT;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_in = smem;
     char* s_w = smem + Cfg::IN_BYTES;
     float* s_red = reinterpret_cast<float*>(smem + Cfg::IN_BYTES + Cfg::CHUNK_W_BYTES);
+    float* s_bias = s_red + 4 * Cfg::COUT_TILE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, n = lane & 15;
-    int uoff[STEPS];
-    D::unit_offsets(q, uoff);
+    typename D::LaneOff lo;
+    D::lane_offsets(q, lo);
     const int lane_x = ((2 * wave) * D::TWH + n) * D::SPIX;
     const int lane_w = lane * 16;
 
@@ -512,39 +643,40 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
     // Tile order: at step k the grid covers the window [k*G, (k+1)*G) of consecutive tiles (same image
     // neighbourhood -> addresses spread over all HBM channels); inside the window XCD x (blocks with
     // blockIdx % 8 == x, observed placement -- speed only) takes a run of G/8 consecutive tiles, so
-    // x-neighbouring halos are served by one L2.  (Giving each XCD its own image instead put all eight
-    // XCDs exactly one image stride apart and serialised them on the same HBM channels: 1.5x slower.)
+    // x-neighbouring halos are served by one L2.
     const int slots = gridDim.x >> 3;                  // gridDim.x is a multiple of 8
     const int pos = (blockIdx.x & 7) * slots + (blockIdx.x >> 3);
-    auto tile_of = [&](int k) -> int {                 // k-th tile of this block, or -1
-        const int t = k * (int)gridDim.x + pos;
-        return t < n_tiles ? t : -1;
-    };
 
     D::dma_weights(static_cast<const char*>(a.wpacked), s_w, STEPS * NT, wave, lane_w);
+    if (tid < Cfg::COUT_TILE) s_bias[tid] = a.bias ? a.bias[tid] : 0.f;
 
-    T* in_store = static_cast<T*>(a.in_store);
     uint4 r0[D::NI], r1[GATED ? D::NI : 1];
     float gv[GATED ? D::UNIT : 1];
-    int k = 0;
-    int tile = tile_of(0);
-    if (tile >= 0 && a.cin_vec_ok) {
-        const int b = tile / sp_total, sp = tile - b * sp_total;
-        D::template load_tile<GATED>(a, (size_t)b * a.H * a.W, b, (sp / a.tiles_x) * kTH, (sp % a.tiles_x) * kTW, 0, tid, r0, r1, gv);
+    int tile = pos < n_tiles ? pos : -1;
+    int b = 0, sp = 0, y0 = 0, x0 = 0;
+    typename D::TileSrc ts;
+    if (tile >= 0) {
+        b = fast_div(tile, sp_total, a.inv_sp_total); sp = tile - b * sp_total;
+        const int ty = fast_div(sp, a.tiles_x, a.inv_tiles_x);
+        y0 = ty * kTH; x0 = (sp - ty * a.tiles_x) * kTW;
+        ts = D::tile_src(a, b, y0, x0);
+        if (a.cin_vec_ok) D::template load_tile<GATED>(a, ts, b, 0, tid, r0, r1, gv);
     }
     while (tile >= 0) {
-        const int b = tile / sp_total, sp = tile - b * sp_total;
-        const int y0 = (sp / a.tiles_x) * kTH, x0 = (sp % a.tiles_x) * kTW;
-        const size_t img_base = (size_t)b * a.H * a.W;
         __syncthreads();                               // every wave finished reading s_in (previous tile)
-        if (a.cin_vec_ok) D::template commit_tile<GATED>(a, img_base, y0, x0, 0, tid, r0, r1, gv, s_in, in_store);
-        else D::stage_tile_scalar(a, img_base, b, y0, x0, 0, tid, s_in, in_store);
-        __syncthreads();                               // tile (and, first time, the weights) visible
+        if (a.cin_vec_ok) D::template commit_tile<GATED>(a, ts, 0, tid, r0, r1, gv, s_in);
+        else D::stage_tile_scalar(a, b, y0, x0, 0, tid, s_in, static_cast<typename Cfg::elem*>(a.in_store));
+        __syncthreads();                               // tile (and, first time, weights + bias) visible
 
-        const int next = tile_of(++k);
-        if (next >= 0 && a.cin_vec_ok) {               // prefetch: in flight during the MFMA loop
-            const int nb = next / sp_total, nsp = next - nb * sp_total;
-            D::template load_tile<GATED>(a, (size_t)nb * a.H * a.W, nb, (nsp / a.tiles_x) * kTH, (nsp % a.tiles_x) * kTW, 0, tid, r0, r1, gv);
+        const int cb = b, csp = sp, cy0 = y0, cx0 = x0;
+        const int next = tile + (int)gridDim.x;
+        tile = next < n_tiles ? next : -1;
+        if (tile >= 0) {                               // prefetch: in flight during the MFMA loop
+            b = fast_div(tile, sp_total, a.inv_sp_total); sp = tile - b * sp_total;
+            const int ty = fast_div(sp, a.tiles_x, a.inv_tiles_x);
+            y0 = ty * kTH; x0 = (sp - ty * a.tiles_x) * kTW;
+            ts = D::tile_src(a, b, y0, x0);
+            if (a.cin_vec_ok) D::template load_tile<GATED>(a, ts, b, 0, tid, r0, r1, gv);
         }
 
         f32x4 acc[4][NT];
@@ -552,36 +684,41 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
         for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[pt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        D::template mma_steps<0, STEPS, 0>(s_in, s_w, lane_x, lane_w, q, uoff, acc);
-        typename D::EpiPre pre;                        // bias: 48 floats, L1/L2-resident; not worth 12 VGPRs across the loop
-        D::epilogue_prefetch(a, b, q * NV, pre);
-        D::epilogue(a, b, y0, x0, sp, 0, tid, pre, acc, s_red);
-        tile = next;
+        D::template mma_steps<0, STEPS, 0>(s_in, s_w, lane_x, lane_w, q, lo, acc);
+        float bias_v[NV];
+#pragma unroll
+        for (int e = 0; e < NV; e += 4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(s_bias + q * NV + e);
+            bias_v[e] = t4.x; bias_v[e + 1] = t4.y; bias_v[e + 2] = t4.z; bias_v[e + 3] = t4.w;
+        }
+        D::epilogue(a, cb, cy0, cx0, csp, 0, tid, bias_v, acc, s_red);
     }
 }
 
 // ---- host side: per-instantiation launcher ----------------------------------------------------------
 template <class Cfg>
-constexpr int persist_lds_bytes() { return Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + Cfg::RED_BYTES; }
+constexpr int persist_lds_bytes() { return Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + Cfg::RED_BYTES + Cfg::COUT_TILE * 4; }
 
 template <class Cfg, bool GATED>
 int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
     constexpr int P_LDS = persist_lds_bytes<Cfg>();
     constexpr bool P_OK = P_LDS <= 80 * 1024;          // two persistent blocks per CU
-    if (P_OK && a.n_chunks == 1 && a.n_ct == 1 && a.persist_ok) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_persist_kernel<Cfg, GATED>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
-            attr_set = true;
+    const int n_tiles = a.tiles_x * a.tiles_y * a.batch;
+    if constexpr (P_OK) {
+        if (a.n_chunks == 1 && a.n_ct == 1 && a.persist_ok && n_tiles < (1 << 24)) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_persist_kernel<Cfg, GATED>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
+                attr_set = true;
+            }
+            int grid = 2 * a.num_cus;
+            if (grid > n_tiles) grid = n_tiles;
+            grid = (grid + 7) / 8 * 8;
+            hipLaunchKernelGGL((conv_mfma_persist_kernel<Cfg, GATED>), dim3((unsigned)grid), dim3(kThreads), P_LDS, stream, a);
+            RC_HIP_CHECK(hipGetLastError());
+            return RC_OK;
         }
-        const int n_tiles = a.tiles_x * a.tiles_y * a.batch;
-        int grid = 2 * a.num_cus;
-        if (grid > n_tiles) grid = n_tiles;
-        grid = (grid + 7) / 8 * 8;
-        hipLaunchKernelGGL((conv_mfma_persist_kernel<Cfg, GATED>), dim3((unsigned)grid), dim3(kThreads), P_LDS, stream, a);
-        RC_HIP_CHECK(hipGetLastError());
-        return RC_OK;
     }
     static bool attr_set = false;
     if (!attr_set) {

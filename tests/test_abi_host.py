@@ -48,6 +48,17 @@ def _plan(cin, cout, dtype):
     return unit, ck, nt
 
 
+def _unit_map(upt, taps, s, q):
+    """Python mirror of unit_map() in realcamnet_amd/csrc/conv_kernel.hpp: (live, tap, channel-unit)."""
+    if upt == 6:
+        if s < taps:
+            return True, s, q
+        tap = 2 * (s - taps) + (q >> 1)
+        return tap < taps, tap, 4 + (q & 1)
+    u = 4 * s + q
+    return u < taps * upt, u // upt, u % upt
+
+
 def _bf16_to_f32(u16):
     return (u16.astype(np.uint32) << 16).view(np.float32)
 
@@ -59,8 +70,8 @@ def _emulate(w, x, dtype, out_mode, ks=3):
     cout, cin = w.shape[:2]
     unit, ck, nt = _plan(cin, cout, dtype)
     upt = ck // unit
-    nu = ks * ks * upt
-    steps = (nu + 3) // 4
+    taps = ks * ks
+    steps = taps + (taps + 1) // 2 if upt == 6 else (taps * upt + 3) // 4
     n_chunks = -(-cin // ck)
     n_ct = -(-cout // (16 * nt))
     nbytes = lib.rc_conv_packed_bytes(cin, cout, ks, dtype, out_mode)
@@ -89,9 +100,8 @@ def _emulate(w, x, dtype, out_mode, ks=3):
                             A = np.zeros((16, 4, unit)); B = np.zeros((4, unit, 16))
                             for lane in range(64):
                                 A[m_of[lane], q_of[lane]] = pk[ct, chunk, s, t, lane]
-                                u = 4 * s + q_of[lane]
-                                if u < nu:
-                                    tap, cu = divmod(u, upt)
+                                live, tap, cu = _unit_map(upt, taps, s, q_of[lane])
+                                if live:
                                     dy, dx = divmod(tap, ks)
                                     c0 = chunk * ck + cu * unit
                                     B[q_of[lane], :, n_of[lane]] = xp[c0:c0 + unit, row + dy, col0 + n_of[lane] + dx]

@@ -277,3 +277,28 @@ def test_dwt_with_arbitrary_per_channel_taps(hip, dt):
     assert rel_err(yf.float().cpu(), ref_f) <= t
     yi = run(inv.to(DEV, dt).eval(), ref_f, dt=dt)
     assert rel_err(yi.float().cpu(), ref_i) <= t
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("persist", [1, 0])
+@pytest.mark.parametrize("shape", [(48, 48, 16, 40, 3), (48, 48, 9, 33, 3), (48, 3, 8, 32, 3), (4, 48, 24, 70, 3),
+                                   (64, 64, 8, 40, 3), (96, 48, 8, 32, 3), (48, 48, 8, 32, 1), (2, 48, 10, 34, 1)])
+def test_conv_exact_on_small_integer_data(hip, dt, persist, shape):
+    """Small-integer weights/inputs make every product and partial sum exactly representable, so the HIP conv
+    must equal F.conv2d BIT FOR BIT in bf16 and fp32, on ragged multi-tile images too.  (Regression: an
+    out-of-bounds sentinel that wrapped back into the image corrupted pixel (0,0) on ragged tiles.)"""
+    cin, cout, h, w, ksz = shape
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    c = N.Conv2d(cin, cout, ksz, 1, ksz // 2)
+    with torch.no_grad():
+        c.weight.copy_(torch.randint(-2, 3, c.weight.shape, generator=g).float() / 2)
+        c.bias.copy_(torch.randint(-2, 3, c.bias.shape, generator=g).float())
+    x = torch.randint(-2, 3, (2, cin, h, w), generator=g).float() / 2
+    ref = F.conv2d(x, c.weight.detach(), c.bias.detach(), padding=ksz // 2)
+    assert hip.rc_debug_set(b"persist", persist) == 0
+    try:
+        with torch.no_grad():
+            y = c.to(DEV, dt)(x.to(DEV, dt)).float().cpu()
+    finally:
+        hip.rc_debug_set(b"persist", 1)
+    assert torch.equal(y, ref)
