@@ -24,10 +24,21 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
     } else {
         p->ck = cin <= 4 ? 4 : 16;
     }
-    if (cout % 64 == 0) p->nt = 4;
+    // cout tile: 64 or 48 channels per block.  48 -> 4x48 (the tail conv) stays on 48-wide tiles so the
+    // persistent kernel's LDS footprint (input tile + one cout tile of weights) lets two blocks share a CU.
+    if (out_mode == RC_OUT_PIXEL_SHUFFLE2) {
+        // a cout tile = one sub-pixel x 16*NT consecutive OUT channels, so stores write whole pixel records
+        if (cout % 4 != 0) return false;
+        const int cps = cout / 4;
+        if (cps % 64 == 0 && !(cps % 48 == 0 && dtype == RC_BF16 && cin == 48)) p->nt = 4;
+        else if (cps % 48 == 0) p->nt = 3;
+        else if (cps % 64 == 0) p->nt = 4;
+        else if (cps % 16 == 0) p->nt = 1;
+        else return false;
+    } else if (cout % 48 == 0 && dtype == RC_BF16 && cin == 48) p->nt = 3;
+    else if (cout % 64 == 0) p->nt = 4;
     else if (cout % 48 == 0) p->nt = 3;
     else p->nt = 1;
-    if (out_mode == RC_OUT_PIXEL_SHUFFLE2 && (cout % (16 * p->nt) != 0)) return false;
     p->upt = p->ck / p->unit;
     p->nu = ksize * ksize * p->upt;
     p->steps = unit_map_steps(p->upt, ksize * ksize);
@@ -40,9 +51,11 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
 // packed cout index j -> conv output channel (or -1 for padding rows)
 static int packed_to_cout(const ConvPlan& p, int cout, int out_mode, int j) {
     if (out_mode == RC_OUT_PIXEL_SHUFFLE2) {
-        const int nv = 4 * p.nt;
-        const int t = j / (16 * p.nt), qq = (j / nv) % 4, e = j % nv;
-        return 4 * (t * nv + e) + qq;  // out channel t*nv+e, sub-pixel qq = 2i+j
+        // cout tile ct = cb*4 + sub-pixel; inside it packed index = out channel offset within block cb
+        const int tile = 16 * p.nt;
+        const int ct = j / tile, within = j % tile;
+        const int cb = ct >> 2, sub = ct & 3;            // sub = 2i + j of nn.PixelShuffle(2)
+        return 4 * (cb * tile + within) + sub;            // conv channel 4c + sub
     }
     return j < cout ? j : -1;
 }
@@ -167,12 +180,12 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     const size_t es = dtype_size(d->dtype);
     if (d->out_mode == RC_OUT_NHWC) {
         RC_REQUIRE(d->out_dtype == d->dtype, "rc_conv2d: out_dtype must equal dtype for RC_OUT_NHWC");
-        RC_REQUIRE((d->cout * es) % 8 == 0, "rc_conv2d: cout*elem_size must be a multiple of 8 bytes for RC_OUT_NHWC");
+        RC_REQUIRE(!full_tiles || (d->cout * es) % 8 == 0, "rc_conv2d: cout*elem_size must be a multiple of 8 bytes for RC_OUT_NHWC");
         RC_REQUIRE(reinterpret_cast<uintptr_t>(d->out) % 16 == 0, "rc_conv2d: out must be 16-byte aligned");
         if (p.nt == 4 && d->dtype == RC_BF16) RC_REQUIRE(d->cout % 8 == 0, "rc_conv2d: cout % 8");
     } else if (d->out_mode == RC_OUT_PIXEL_SHUFFLE2) {
         RC_REQUIRE(d->out_dtype == d->dtype, "rc_conv2d: out_dtype must equal dtype for RC_OUT_PIXEL_SHUFFLE2");
-        RC_REQUIRE(full_tiles && ((d->cout / 4) * es) % 16 == 0, "rc_conv2d: pixel-shuffle store needs (cout/4)*elem_size % 16 == 0");
+        RC_REQUIRE(full_tiles && ((d->cout / 4) * es) % 8 == 0, "rc_conv2d: pixel-shuffle store needs (cout/4)*elem_size % 8 == 0");
         RC_REQUIRE(!d->film_scale, "rc_conv2d: film not supported with pixel-shuffle store");
         RC_REQUIRE(reinterpret_cast<uintptr_t>(d->out) % 16 == 0, "rc_conv2d: out must be 16-byte aligned");
     } else {

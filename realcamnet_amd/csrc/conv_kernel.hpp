@@ -393,11 +393,18 @@ struct ConvDev {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) Mma<T>::run(wf[nt], xf[pt], acc[pt][nt]);
     }
-    template <int S0, int COUNT, int W0>
+    template <int S0, int COUNT, int W0, bool DBUF = true>
     __device__ static __forceinline__ void mma_steps(const char* s_in, const char* s_w, int lane_x, int lane_w, int q,
                                                      const LaneOff& lo, f32x4 (&acc)[4][NT]) {
         constexpr int END = (S0 + COUNT) < STEPS ? (S0 + COUNT) : STEPS;
-        if constexpr (S0 < END) {
+        if constexpr (S0 < END && !DBUF) {     // register-starved variants: one fragment set, compiler-scheduled
+#pragma unroll
+            for (int s = S0; s < END; ++s) {
+                uint4 wf[NT], xf[4];
+                load_frags(s, W0, s_in, s_w, lane_x, lane_w, q, lo, wf, xf);
+                mma_frags(wf, xf, acc);
+            }
+        } else if constexpr (S0 < END) {
             uint4 wfa[NT], xfa[4], wfb[NT], xfb[4];
             load_frags(S0, W0, s_in, s_w, lane_x, lane_w, q, lo, wfa, xfa);
 #pragma unroll
@@ -412,9 +419,10 @@ struct ConvDev {
 
     // ---- epilogue ---------------------------------------------------------------------------------------
     // lane (q, n) holds, per pixel tile pt, packed couts jbase .. jbase+NV-1 of pixel (row, col0+n).
-    // bias_v: this lane's NV bias values.  red: LDS scratch of 4*16*NT floats not aliased with live data.
+    // The accumulators already contain the bias (it is the MFMA chain's initial C operand).
+    // red: LDS scratch of 4*16*NT floats not aliased with live data.
     __device__ static __forceinline__ void epilogue(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
-                                                    const float (&bias_v)[NV], f32x4 (&acc)[4][NT], float* red) {
+                                                    f32x4 (&acc)[4][NT], float* red) {
         const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
         const int jbase = ct * Cfg::COUT_TILE + q * NV;
         float fs[NV], ft[NV];
@@ -434,10 +442,6 @@ struct ConvDev {
 
         const size_t img_out = (size_t)a.H * a.W * a.cout;    // NHWC output / residual / mul image (elements)
         const unsigned img_bytes_out = (unsigned)(img_out * ES);
-        const __amdgpu_buffer_rsrc_t r_res = make_rsrc(a.residual ? static_cast<const T*>(a.residual) + (size_t)b * img_out : nullptr,
-                                                       a.residual ? img_bytes_out : 0u);
-        const __amdgpu_buffer_rsrc_t r_mul = make_rsrc(a.mul_plus1 ? static_cast<const T*>(a.mul_plus1) + (size_t)b * img_out : nullptr,
-                                                       a.mul_plus1 ? img_bytes_out : 0u);
         __amdgpu_buffer_rsrc_t r_out;
         if (a.out_mode == RC_OUT_NCHW) {
             const size_t plane = (size_t)a.out_h * a.out_w;
@@ -457,7 +461,7 @@ struct ConvDev {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[pt][nt][r] + bias_v[nt * 4 + r];
+                for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[pt][nt][r];
             if (film) {
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] = v[e] * fs[e] + ft[e] + v[e];
@@ -472,12 +476,14 @@ struct ConvDev {
             const int pix_off = valid ? ((gy * a.W + gx) * a.cout + jbase) * ES : kOOB;   // NHWC-shaped operands
             if (a.mul_plus1 != nullptr) {
                 float m[NV];
+                const __amdgpu_buffer_rsrc_t r_mul = make_rsrc(static_cast<const T*>(a.mul_plus1) + (size_t)b * img_out, img_bytes_out);
                 buf_load_row<T, NV>(r_mul, pix_off, m);
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] = v[e] * (m[e] + 1.f);
             }
             if (a.residual != nullptr) {
                 float m[NV];
+                const __amdgpu_buffer_rsrc_t r_res = make_rsrc(static_cast<const T*>(a.residual) + (size_t)b * img_out, img_bytes_out);
                 buf_load_row<T, NV>(r_res, pix_off, m);
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] += m[e];
@@ -499,9 +505,10 @@ struct ConvDev {
                     }
                 }
             } else if (a.out_mode == RC_OUT_PIXEL_SHUFFLE2) {
-                // packed cout tile `ct` holds out channels ct*NV .. ct*NV+NV-1 for sub-pixel q
-                const int cps = a.cout >> 2;
-                const int o = valid ? (((2 * gy + (q >> 1)) * (2 * a.W) + (2 * gx + (q & 1))) * cps + ct * NV) * ES : kOOB;
+                // cout tile ct = (out-channel block ct>>2, sub-pixel ct&3): this lane's NV values are consecutive
+                // OUT channels of one output pixel -> the 4 lane groups write one contiguous 16*NT-channel run
+                const int cps = a.cout >> 2, sub = ct & 3;
+                const int o = valid ? (((2 * gy + (sub >> 1)) * (2 * a.W) + (2 * gx + (sub & 1))) * cps + (ct >> 2) * Cfg::COUT_TILE + q * NV) * ES : kOOB;
                 buf_store_row<T, NV>(r_out, o, v);
             } else {  // RC_OUT_NCHW, cropped
                 const bool inside = gy < a.out_h && gx < a.out_w;
@@ -567,11 +574,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a
     const int lane_x = ((2 * wave) * D::TWH + n) * D::SPIX;  // + pixel-tile immediates in load_frags
     const int lane_w = lane * 16;
 
-    f32x4 acc[4][NT];
+    f32x4 acc[4][NT];                         // initial C operand = bias (packed order, padded to cout_packed)
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt)
+    for (int nt = 0; nt < NT; ++nt) {
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+            const float4 t4 = *reinterpret_cast<const float4*>(a.bias + ct * Cfg::COUT_TILE + q * NV + nt * 4);
+            bv = f32x4{t4.x, t4.y, t4.z, t4.w};
+        }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[pt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = bv;
+    }
 
     ConvArgs aa = a;
     if (ct != 0) aa.in_store = nullptr;       // only one cout tile materialises the gated input
@@ -606,20 +619,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a
         }
         static_assert(NSUB <= 3, "add another weight sub-stage");
     }
-    float bias_v[NV];
-#pragma unroll
-    for (int e = 0; e < NV; ++e) bias_v[e] = a.bias ? a.bias[ct * Cfg::COUT_TILE + q * NV + e] : 0.f;
     if (a.chan_sums != nullptr) __syncthreads();  // s_w (reused as reduction scratch) no longer read
-    D::epilogue(a, b, y0, x0, sp, ct, tid, bias_v, acc, reinterpret_cast<float*>(s_w));
+    D::epilogue(a, b, y0, x0, sp, ct, tid, acc, reinterpret_cast<float*>(s_w));
 }
 
 // ==================================================================================================
-// Kernel 2: persistent form for single-chunk, single-cout-tile layers (Cin == CK, Cout <= 16*NT) -- the
-// 48->48 convolutions that dominate the flagship net.  The whole packed weight matrix (and the bias)
-// stays in LDS for the block's lifetime; the block walks a strided list of tiles and issues the NEXT
-// tile's halo loads into registers before the MFMA loop, so HBM latency hides under compute.  Two such
-// blocks share a CU and drift out of phase (one in MFMA while the other stores / stages).
+// Kernel 2: persistent form for single-chunk layers (Cin == CK): the 48->48 convolutions that dominate
+// the flagship net, and 48->192 (+PixelShuffle).  A block walks a strided list of tiles; the NEXT tile's
+// halo loads are issued into registers before the last MFMA loop of the current tile, so HBM latency hides
+// under compute.  With one cout tile the whole packed weight matrix stays in LDS for the block's lifetime;
+// with several, the input tile stays resident and the weights of each cout tile are DMA'd in turn.
+// Two such blocks share a CU and drift out of phase (one in MFMA while the other stores / stages).
 // ==================================================================================================
+constexpr int kPersistMaxCout = 256;   // bias slots kept in LDS
+
 template <class Cfg, bool GATED>
 __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const ConvArgs a) {
     using D = ConvDev<Cfg>;
@@ -640,6 +653,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
 
     const int sp_total = a.tiles_x * a.tiles_y;
     const int n_tiles = sp_total * a.batch;
+    const int n_ct = a.n_ct;
     // Tile order: at step k the grid covers the window [k*G, (k+1)*G) of consecutive tiles (same image
     // neighbourhood -> addresses spread over all HBM channels); inside the window XCD x (blocks with
     // blockIdx % 8 == x, observed placement -- speed only) takes a run of G/8 consecutive tiles, so
@@ -647,8 +661,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
     const int slots = gridDim.x >> 3;                  // gridDim.x is a multiple of 8
     const int pos = (blockIdx.x & 7) * slots + (blockIdx.x >> 3);
 
-    D::dma_weights(static_cast<const char*>(a.wpacked), s_w, STEPS * NT, wave, lane_w);
-    if (tid < Cfg::COUT_TILE) s_bias[tid] = a.bias ? a.bias[tid] : 0.f;
+    if (n_ct == 1) D::dma_weights(static_cast<const char*>(a.wpacked), s_w, STEPS * NT, wave, lane_w);
+    for (int i = tid; i < a.cout_packed; i += kThreads) s_bias[i] = a.bias ? a.bias[i] : 0.f;
 
     uint4 r0[D::NI], r1[GATED ? D::NI : 1];
     float gv[GATED ? D::UNIT : 1];
@@ -663,41 +677,42 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
         if (a.cin_vec_ok) D::template load_tile<GATED>(a, ts, b, 0, tid, r0, r1, gv);
     }
     while (tile >= 0) {
-        __syncthreads();                               // every wave finished reading s_in (previous tile)
+        __syncthreads();                               // every wave finished reading s_in / s_w (previous tile)
         if (a.cin_vec_ok) D::template commit_tile<GATED>(a, ts, 0, tid, r0, r1, gv, s_in);
         else D::stage_tile_scalar(a, b, y0, x0, 0, tid, s_in, static_cast<typename Cfg::elem*>(a.in_store));
-        __syncthreads();                               // tile (and, first time, weights + bias) visible
-
         const int cb = b, csp = sp, cy0 = y0, cx0 = x0;
         const int next = tile + (int)gridDim.x;
         tile = next < n_tiles ? next : -1;
-        if (tile >= 0) {                               // prefetch: in flight during the MFMA loop
-            b = fast_div(tile, sp_total, a.inv_sp_total); sp = tile - b * sp_total;
-            const int ty = fast_div(sp, a.tiles_x, a.inv_tiles_x);
-            y0 = ty * kTH; x0 = (sp - ty * a.tiles_x) * kTW;
-            ts = D::tile_src(a, b, y0, x0);
-            if (a.cin_vec_ok) D::template load_tile<GATED>(a, ts, b, 0, tid, r0, r1, gv);
-        }
 
-        f32x4 acc[4][NT];
+        for (int ct = 0; ct < n_ct; ++ct) {
+            if (n_ct > 1) {
+                if (ct > 0) __syncthreads();           // previous cout tile's weights fully consumed
+                D::dma_weights(static_cast<const char*>(a.wpacked) + (size_t)ct * Cfg::CHUNK_W_BYTES, s_w, STEPS * NT, wave, lane_w);
+            }
+            __syncthreads();                           // input tile, weights (+ first time: bias) visible
+            if (ct == n_ct - 1 && tile >= 0) {         // prefetch the next tile: in flight during the MFMA loop
+                b = fast_div(tile, sp_total, a.inv_sp_total); sp = tile - b * sp_total;
+                const int ty = fast_div(sp, a.tiles_x, a.inv_tiles_x);
+                y0 = ty * kTH; x0 = (sp - ty * a.tiles_x) * kTW;
+                ts = D::tile_src(a, b, y0, x0);
+                if (a.cin_vec_ok) D::template load_tile<GATED>(a, ts, b, 0, tid, r0, r1, gv);
+            }
+            f32x4 acc[4][NT];                          // initial C operand = bias
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt)
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 t4 = *reinterpret_cast<const float4*>(s_bias + ct * Cfg::COUT_TILE + q * NV + nt * 4);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[pt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        D::template mma_steps<0, STEPS, 0>(s_in, s_w, lane_x, lane_w, q, lo, acc);
-        float bias_v[NV];
-#pragma unroll
-        for (int e = 0; e < NV; e += 4) {
-            const float4 t4 = *reinterpret_cast<const float4*>(s_bias + q * NV + e);
-            bias_v[e] = t4.x; bias_v[e + 1] = t4.y; bias_v[e + 2] = t4.z; bias_v[e + 3] = t4.w;
+                for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
+            }
+            D::template mma_steps<0, STEPS, 0, !GATED>(s_in, s_w, lane_x, lane_w, q, lo, acc);
+            D::epilogue(a, cb, cy0, cx0, csp, ct, tid, acc, s_red);
         }
-        D::epilogue(a, cb, cy0, cx0, csp, 0, tid, bias_v, acc, s_red);
     }
 }
 
 // ---- host side: per-instantiation launcher ----------------------------------------------------------
 template <class Cfg>
-constexpr int persist_lds_bytes() { return Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + Cfg::RED_BYTES + Cfg::COUT_TILE * 4; }
+constexpr int persist_lds_bytes() { return Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + Cfg::RED_BYTES + kPersistMaxCout * 4; }
 
 template <class Cfg, bool GATED>
 int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
@@ -705,7 +720,7 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
     constexpr bool P_OK = P_LDS <= 80 * 1024;          // two persistent blocks per CU
     const int n_tiles = a.tiles_x * a.tiles_y * a.batch;
     if constexpr (P_OK) {
-        if (a.n_chunks == 1 && a.n_ct == 1 && a.persist_ok && n_tiles < (1 << 24)) {
+        if (a.n_chunks == 1 && a.cout_packed <= kPersistMaxCout && a.persist_ok && n_tiles < (1 << 24)) {
             static bool attr_set = false;
             if (!attr_set) {
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_persist_kernel<Cfg, GATED>),

@@ -44,7 +44,7 @@ def _plan(cin, cout, dtype):
         ck = 8 if cin <= 8 else 64 if cin % 64 == 0 else 48 if cin % 48 == 0 else 16
     else:
         ck = 4 if cin <= 4 else 16
-    nt = 4 if cout % 64 == 0 else 3 if cout % 48 == 0 else 1
+    nt = 3 if (cout % 48 == 0 and dtype == RC_BF16 and cin == 48) else 4 if cout % 64 == 0 else 3 if cout % 48 == 0 else 1
     return unit, ck, nt
 
 
@@ -69,6 +69,9 @@ def _emulate(w, x, dtype, out_mode, ks=3):
     lib = _lib.load()
     cout, cin = w.shape[:2]
     unit, ck, nt = _plan(cin, cout, dtype)
+    if out_mode == RC_OUT_PIXEL_SHUFFLE2:
+        cps = cout // 4
+        nt = 3 if (cps % 48 == 0 and (cps % 64 != 0 or (dtype == RC_BF16 and cin == 48))) else 4 if cps % 64 == 0 else 1
     upt = ck // unit
     taps = ks * ks
     steps = taps + (taps + 1) // 2 if upt == 6 else (taps * upt + 3) // 4
@@ -132,16 +135,18 @@ def test_pixel_shuffle_packing_permutation():
     w = rng.integers(-4, 5, size=(cout, cin, 3, 3)).astype(np.float32) / 4
     x = rng.integers(-4, 5, size=(cin, 8, 32)).astype(np.float32) / 4
     out, nt = _emulate(w, x, RC_F32, RC_OUT_PIXEL_SHUFFLE2)
-    nv = 4 * nt
+    assert nt == 1                    # cout/4 = 16 out channels -> 16-wide tiles, one per sub-pixel
+    tile = 16 * nt
     ref = F.pixel_shuffle(F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), padding=1), 2)[0].numpy()
     got = np.zeros_like(ref)
-    for j in range(cout):            # kernel epilogue: packed j -> (out channel, sub-pixel)
-        t, q, e = j // (16 * nt), (j // nv) % 4, j % nv
-        got[t * nv + e, (q >> 1)::2, (q & 1)::2] = out[j]
+    for j in range(cout):            # kernel epilogue: packed j -> (cout tile ct = cb*4 + sub-pixel, out channel)
+        ct, within = divmod(j, tile)
+        cb, sub = ct >> 2, ct & 3
+        got[cb * tile + within, (sub >> 1)::2, (sub & 1)::2] = out[j]
     np.testing.assert_allclose(got, ref, atol=1e-4)
     bias = np.arange(cout, dtype=np.float32)
     dst = np.zeros(lib.rc_conv_packed_cout(cin, cout, 3, RC_F32, RC_OUT_PIXEL_SHUFFLE2), np.float32)
     assert lib.rc_conv_pack_bias(bias.ctypes.data, cin, cout, 3, RC_F32, RC_OUT_PIXEL_SHUFFLE2, dst.ctypes.data) == 0
     for j in range(cout):
-        t, q, e = j // (16 * nt), (j // nv) % 4, j % nv
-        assert dst[j] == 4 * (t * nv + e) + q
+        ct, within = divmod(j, tile)
+        assert dst[j] == 4 * ((ct >> 2) * tile + within) + (ct & 3)
