@@ -38,7 +38,8 @@ typedef enum rc_status {
 
 typedef enum rc_dtype { RC_F32 = 0, RC_BF16 = 1 } rc_dtype;
 
-typedef enum rc_act { RC_ACT_NONE = 0, RC_ACT_RELU = 1, RC_ACT_LEAKY = 2 /* slope in act_slope */ } rc_act;
+typedef enum rc_act { RC_ACT_NONE = 0, RC_ACT_RELU = 1, RC_ACT_LEAKY = 2 /* slope in act_slope */,
+                      RC_ACT_GELU = 3 /* exact erf GELU: nn.GELU() in groupmix.Mlp */ } rc_act;
 
 typedef enum rc_out_mode {
     RC_OUT_NHWC = 0,           /* out[b][y][x][cout]                                             */
@@ -181,6 +182,37 @@ int rc_color_head(const float* d_x, float* d_vec, int batch, int cin, int cout, 
 int rc_gfm_vector(const float* d_vec, int batch, int cond_c, int nf, int c,
                   const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,
                   float* d_out, void* stream);
+
+/* ---- a14-a16: GroupMix attention (GMA_Block) ---------------------------------------------------
+ * Replaces the non-GEMM parts of models/groupmix.py:159-299 (identical copy models/raw2bit.py:98-142); the
+ * four nn.Linear layers run through rc_conv2d as 1x1 convolutions (tokens (B,N,C) == NHWC pixels).
+ *
+ * rc_dwconv2d: depth-wise KxK (3/5/7), stride 1, 'same' zero padding, on channel sub-ranges of NHWC tensors:
+ *   y[b,p, y_c0 + r*y_rep_stride + c] = bias[r*w_rep_stride + c] + sum_t wT[t][r*w_rep_stride + c] *
+ *                                       x[b,p+t, x_c0 + r*x_rep_stride + c]  (+ x[b,p,..] if add_identity)
+ *   for r < n_rep, c < n_ch.  wT: device fp32, TAP-MAJOR (K*K, n_w).  Replaces ConvPosEnc.proj
+ *   (groupmix.py:206,215), SeparableConv2d.conv1 (:244) and ConvRelPosEnc.conv_list (:127-133).
+ * rc_layernorm: nn.LayerNorm over C of (tokens, C) (groupmix.py:280,285).
+ * rc_gma_pointwise: Aggregator tail (groupmix.py:92-100) with BatchNorm(eval) folded to scale/shift:
+ *   qkv (B,N,3C), dw (B,N,3,3seg) = depth-wise outputs of groups 1..3, dwl (B,N,3seg) = local depth-wise output
+ *   -> qkvp (B,N,3,4seg) [q|k|v, channel = head*Ch + i], loc (B,N,seg).
+ * rc_gma_kv: softmax over the N tokens fused with k^T v (groupmix.py:187-188), one streaming pass + fixed-order
+ *   merge: ktv (B,heads,Ch,Ch) fp32 = scale * softmax_N(k)^T v.  d_scratch: rc_gma_kv_scratch_bytes().
+ * rc_gma_apply: out (B,N,C) = [ q.ktv + q*convv | loc ]  (groupmix.py:189-194). */
+int rc_dwconv2d(const void* d_x, int x_stride_c, int x_c0, void* d_y, int y_stride_c, int y_c0, int dtype,
+                int batch, int H, int W, int n_ch, int ksize, const float* d_wT, int n_w, const float* d_bias,
+                int n_rep, int x_rep_stride, int y_rep_stride, int w_rep_stride, int add_identity, void* stream);
+int rc_layernorm(const void* d_x, void* d_y, int dtype, long long tokens, int c, const float* d_gamma,
+                 const float* d_beta, float eps, void* stream);
+int rc_gma_pointwise(const void* d_qkv, const void* d_dw, const void* d_dwl, void* d_qkvp, void* d_loc, int dtype,
+                     long long tokens, int c, const float* d_pw, const float* d_bn_scale, const float* d_bn_shift,
+                     const float* d_pwl, const float* d_ln_g, const float* d_ln_b, void* stream);
+int rc_gma_kv_blocks(int n_tok);
+size_t rc_gma_kv_scratch_bytes(int batch, int n_tok, int heads, int ch);
+int rc_gma_kv(const void* d_qkvp, int dtype, int batch, int n_tok, int heads, int ch, float scale, float* d_scratch,
+              float* d_ktv, void* stream);
+int rc_gma_apply(const void* d_qkvp, const void* d_convv, const void* d_loc, const float* d_ktv, void* d_out, int dtype,
+                 int batch, int n_tok, int heads, int ch, int seg, void* stream);
 
 /* ---- measurement helpers (bench.py): HIP-event timing of every rc_conv2d launch on its stream -
  * rc_prof_enable(1) brackets each subsequent rc_conv2d with hipEventRecord on the launch stream;

@@ -15,7 +15,7 @@ LIB_PATH = PKG / "librealcam_hip.so"
 HEADER = PKG.parent / "include" / "realcam_hip.h"
 
 RC_F32, RC_BF16 = 0, 1
-RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY = 0, 1, 2
+RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY, RC_ACT_GELU = 0, 1, 2, 3
 RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW = 0, 1, 2
 ABI_VERSION = 1
 
@@ -68,6 +68,13 @@ _SIGS = {
     "rc_instance_stats": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "rc_color_head": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "rc_gfm_vector": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "rc_dwconv2d": (C.c_int, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "rc_layernorm": (C.c_int, [_P, _P, _I, C.c_longlong, _I, _P, _P, _F, _P]),
+    "rc_gma_pointwise": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_longlong, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "rc_gma_kv_blocks": (C.c_int, [_I]),
+    "rc_gma_kv_scratch_bytes": (_SZ, [_I, _I, _I, _I]),
+    "rc_gma_kv": (C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "rc_gma_apply": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rc_debug_set": (C.c_int, [C.c_char_p, _I]),
     "rc_prof_enable": (C.c_int, [_I]),
     "rc_prof_collect": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -170,12 +170,12 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     RC_REQUIRE(d->batch <= 65535, "rc_conv2d: batch > 65535");
     RC_REQUIRE(d->in0 && d->wpacked && d->out, "rc_conv2d: null in0/wpacked/out");
     RC_REQUIRE(d->out_mode >= RC_OUT_NHWC && d->out_mode <= RC_OUT_NCHW, "rc_conv2d: bad out_mode");
-    RC_REQUIRE(d->act >= RC_ACT_NONE && d->act <= RC_ACT_LEAKY, "rc_conv2d: bad act");
+    RC_REQUIRE(d->act >= RC_ACT_NONE && d->act <= RC_ACT_GELU, "rc_conv2d: bad act");
     if (d->in_gate) RC_REQUIRE(d->in1 != nullptr, "rc_conv2d: in_gate needs in1 (the skip tensor)");
     RC_REQUIRE((d->film_scale == nullptr) == (d->film_shift == nullptr), "rc_conv2d: film_scale/film_shift must come together");
     const bool full_tiles = d->cout == p.cout_packed;
-    if (d->mul_plus1 || d->residual)
-        RC_REQUIRE(full_tiles && d->out_mode == RC_OUT_NHWC, "rc_conv2d: mul_plus1/residual need cout % (16*NT) == 0 and RC_OUT_NHWC");
+    if (d->mul_plus1 || d->residual)   // a lane's 4-channel group must be wholly inside or outside [0, cout)
+        RC_REQUIRE((full_tiles || d->cout % 4 == 0) && d->out_mode == RC_OUT_NHWC, "rc_conv2d: mul_plus1/residual need cout % 4 == 0 and RC_OUT_NHWC");
     if (d->chan_sums) RC_REQUIRE(d->out_mode == RC_OUT_NHWC, "rc_conv2d: chan_sums needs RC_OUT_NHWC");
     const size_t es = dtype_size(d->dtype);
     if (d->out_mode == RC_OUT_NHWC) {
@@ -223,7 +223,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
         }
         a.num_cus = num_cus;
         a.persist_ok = g_persist_on ? 1 : 0;
-        a.inv_tiles_x = 1.0f / (float)a.tiles_x;
+        a.inv_band = 1.0f / (float)(kBandRows * a.tiles_x);
         a.inv_sp_total = 1.0f / (float)(a.tiles_x * a.tiles_y);
     }
 

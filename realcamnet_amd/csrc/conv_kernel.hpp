@@ -39,7 +39,7 @@ struct ConvArgs {
     void* out; int out_mode; int out_dtype; int out_h, out_w;
     float* chan_sums; int cout_packed;
     int num_cus; int persist_ok;
-    float inv_tiles_x, inv_sp_total;   // reciprocals for the persistent kernel's tile decode
+    float inv_band, inv_sp_total;      // reciprocals for the persistent kernel's tile decode
 };
 
 constexpr int kTH = 8, kTW = 32, kThreads = 256;
@@ -179,6 +179,22 @@ __device__ __forceinline__ int fast_div(int t, int d, float inv_d) {
     if (r < 0) { --q; r += d; }
     if (r >= d) ++q;
     return q;
+}
+
+// Persistent-kernel tile enumeration inside one image: bands of kBandRows tile rows, column-major inside a
+// band.  A run of 64 consecutive indices is then an 8x8 block of tiles, so the run each XCD takes from the
+// current window shares its horizontal AND vertical halos through that XCD's L2 (row-major order left the
+// vertical halos on different XCDs: measured FETCH_SIZE 1.27x the algorithmic input bytes).
+constexpr int kBandRows = 8;
+__device__ __forceinline__ void band_decode(int idx, int tiles_x, int tiles_y, float inv_band, int& ty, int& tx) {
+    const int band_size = kBandRows * tiles_x;
+    const int band = fast_div(idx, band_size, inv_band);
+    const int rem = idx - band * band_size;
+    const int rows_left = tiles_y - band * kBandRows;
+    const int rows = rows_left < kBandRows ? rows_left : kBandRows;
+    const int col = fast_div(rem, rows, 1.0f / (float)rows);
+    ty = band * kBandRows + (rem - col * rows);
+    tx = col;
 }
 
 // ==================================================================================================
@@ -472,6 +488,9 @@ struct ConvDev {
             } else if (a.act == RC_ACT_LEAKY) {
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.act_slope;
+            } else if (a.act == RC_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < NV; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
             }
             const int pix_off = valid ? ((gy * a.W + gx) * a.cout + jbase) * ES : kOOB;   // NHWC-shaped operands
             if (a.mul_plus1 != nullptr) {
@@ -654,10 +673,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
     const int sp_total = a.tiles_x * a.tiles_y;
     const int n_tiles = sp_total * a.batch;
     const int n_ct = a.n_ct;
-    // Tile order: at step k the grid covers the window [k*G, (k+1)*G) of consecutive tiles (same image
-    // neighbourhood -> addresses spread over all HBM channels); inside the window XCD x (blocks with
-    // blockIdx % 8 == x, observed placement -- speed only) takes a run of G/8 consecutive tiles, so
-    // x-neighbouring halos are served by one L2.
+    // Tile order: at step k the grid covers the window [k*G, (k+1)*G) of consecutive (band-major) tile
+    // indices (same image neighbourhood -> addresses spread over all HBM channels); inside the window XCD x
+    // (blocks with blockIdx % 8 == x, observed placement -- speed only) takes a run of G/8 = 64 consecutive
+    // indices = an 8x8 block of tiles, so its halos are served by one L2.
     const int slots = gridDim.x >> 3;                  // gridDim.x is a multiple of 8
     const int pos = (blockIdx.x & 7) * slots + (blockIdx.x >> 3);
 
@@ -670,9 +689,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
     int b = 0, sp = 0, y0 = 0, x0 = 0;
     typename D::TileSrc ts;
     if (tile >= 0) {
-        b = fast_div(tile, sp_total, a.inv_sp_total); sp = tile - b * sp_total;
-        const int ty = fast_div(sp, a.tiles_x, a.inv_tiles_x);
-        y0 = ty * kTH; x0 = (sp - ty * a.tiles_x) * kTW;
+        b = fast_div(tile, sp_total, a.inv_sp_total);
+        int ty, tx;
+        band_decode(tile - b * sp_total, a.tiles_x, a.tiles_y, a.inv_band, ty, tx);
+        sp = ty * a.tiles_x + tx; y0 = ty * kTH; x0 = tx * kTW;
         ts = D::tile_src(a, b, y0, x0);
         if (a.cin_vec_ok) D::template load_tile<GATED>(a, ts, b, 0, tid, r0, r1, gv);
     }
@@ -691,9 +711,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
             }
             __syncthreads();                           // input tile, weights (+ first time: bias) visible
             if (ct == n_ct - 1 && tile >= 0) {         // prefetch the next tile: in flight during the MFMA loop
-                b = fast_div(tile, sp_total, a.inv_sp_total); sp = tile - b * sp_total;
-                const int ty = fast_div(sp, a.tiles_x, a.inv_tiles_x);
-                y0 = ty * kTH; x0 = (sp - ty * a.tiles_x) * kTW;
+                b = fast_div(tile, sp_total, a.inv_sp_total);
+                int ty, tx;
+                band_decode(tile - b * sp_total, a.tiles_x, a.tiles_y, a.inv_band, ty, tx);
+                sp = ty * a.tiles_x + tx; y0 = ty * kTH; x0 = tx * kTW;
                 ts = D::tile_src(a, b, y0, x0);
                 if (a.cin_vec_ok) D::template load_tile<GATED>(a, ts, b, 0, tid, r0, r1, gv);
             }

@@ -1,0 +1,257 @@
+"""HIP-backed mirror of the GroupMix attention block (upstream models/groupmix.py:21-299; the identical copy in
+models/raw2bit.py:98-142 is what RealCamNet imports).  Same class names, constructor signatures and attribute
+names, so reference state_dicts load unchanged; forward(x (B,N,C), size=(H,W)) keeps the reference signature.
+
+Only the classes on the path are built (Mlp, Agg_0, Aggregator, ConvRelPosEnc, EfficientAtt, ConvPosEnc,
+SeparableConv2d, GMA_Block); the ImageNet classifier around them (ConvStem, PatchEmbedLayer, GMA_Stage,
+GroupMixFormer) is out of scope.  Inference only: BatchNorm uses running statistics,
+Dropout / DropPath are identities.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import check, lib
+
+
+class Mlp(nn.Module):
+    """fc1 -> GELU -> fc2 (upstream groupmix.py:21-38); both Linears run as MFMA 1x1 convs."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        if act_layer is not nn.GELU:
+            raise NotImplementedError("Mlp: only nn.GELU is on the hot path")
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def _nhwc(self, a, residual=None):
+        h = ops.conv2d(a, self.fc1, act="gelu")
+        return ops.conv2d(h, self.fc2, residual=residual)
+
+    def forward(self, x):
+        return self._nhwc(_as_nhwc(x, None)).reshape(x.shape[0], -1, self.fc2.out_features)
+
+
+class SeparableConv2d(nn.Module):
+    """Depth-wise kxk + point-wise 1x1, both without bias (upstream groupmix.py:240-249).  Parameter holder:
+    executed fused inside Aggregator."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=0, dilation=1, bias=False):
+        super().__init__()
+        if stride != 1 or dilation != 1 or bias or padding != kernel_size // 2:
+            raise NotImplementedError("SeparableConv2d: stride 1, 'same' padding, no bias only")
+        self.conv1 = nn.Conv2d(in_channels, in_channels, kernel_size, stride, padding, dilation, groups=in_channels, bias=bias)
+        self.pointwise_conv = nn.Conv2d(in_channels, out_channels, 1, 1, 0, 1, 1, bias=bias)
+
+
+class Agg_0(nn.Module):
+    """Local branch: sep-conv(3seg -> seg) -> LayerNorm(seg) -> Hardswish (upstream groupmix.py:41-53)."""
+
+    def __init__(self, seg_dim):
+        super().__init__()
+        self.conv = SeparableConv2d(seg_dim * 3, seg_dim, 3, 1, 1)
+        self.norm = nn.LayerNorm(seg_dim)
+        self.act = nn.Hardswish()
+
+
+class Aggregator(nn.Module):
+    """Multi-scale depth-wise aggregators over 5 channel groups (upstream groupmix.py:56-105)."""
+
+    def __init__(self, dim, seg=4):
+        super().__init__()
+        self.dim = dim
+        self.seg = seg
+        seg_dim = self.dim // self.seg
+        self.norm0 = nn.SyncBatchNorm(seg_dim)
+        self.act0 = nn.Hardswish()
+        self.agg1 = SeparableConv2d(seg_dim, seg_dim, 3, 1, 1)
+        self.norm1 = nn.SyncBatchNorm(seg_dim)
+        self.act1 = nn.Hardswish()
+        self.agg2 = SeparableConv2d(seg_dim, seg_dim, 5, 1, 2)
+        self.norm2 = nn.SyncBatchNorm(seg_dim)
+        self.act2 = nn.Hardswish()
+        self.agg3 = SeparableConv2d(seg_dim, seg_dim, 7, 1, 3)
+        self.norm3 = nn.SyncBatchNorm(seg_dim)
+        self.act3 = nn.Hardswish()
+        self.agg0 = Agg_0(seg_dim)
+
+    def _run(self, qkv):
+        """qkv NHWC (B,H,W,3C) -> qkvp (B,H,W,3,4seg) [q|k|v, channel = head*Ch + i], loc (B,H,W,seg)."""
+        if self.seg != 5:
+            raise NotImplementedError("Aggregator: seg=5 only (as EfficientAtt builds it)")
+        b, H, W, c3 = qkv.shape
+        c, seg = c3 // 3, c3 // 15
+        dev, dt = qkv.device, qkv.dtype
+        dw = torch.empty((b, H, W, 3, 3 * seg), dtype=dt, device=dev)
+        dwl = torch.empty((b, H, W, 3 * seg), dtype=dt, device=dev)
+        for g, (agg, k) in enumerate(((self.agg1, 3), (self.agg2, 5), (self.agg3, 7)), start=1):
+            (wT,) = ops.host_cached(agg, "taps", [agg.conv1.weight], lambda w: ops.dw_taps(w))
+            ops.dwconv2d(qkv, g * seg, dw, (g - 1) * seg, seg, k, wT, n_rep=3, x_rep=c, y_rep=3 * seg, w_rep=0)
+        (wl,) = ops.host_cached(self.agg0, "taps", [self.agg0.conv.conv1.weight], lambda w: ops.dw_taps(w))
+        ops.dwconv2d(qkv, 4 * seg, dwl, 0, seg, 3, wl, n_rep=3, x_rep=c, y_rep=seg, w_rep=seg)
+
+        def fold(*p):   # BatchNorm(eval) -> per-channel scale / shift; point-wise weights as dense matrices
+            bn = [p[4 * i:4 * i + 4] for i in range(4)]
+            scale = torch.stack([w / torch.sqrt(v + 1e-5) for (w, _, _, v) in bn])
+            shift = torch.stack([bb - m * (w / torch.sqrt(v + 1e-5)) for (w, bb, m, v) in bn])
+            pw = torch.stack([q[:, :, 0, 0] for q in p[16:19]])
+            return scale, shift, pw, p[19][:, :, 0, 0]
+
+        norms = (self.norm0, self.norm1, self.norm2, self.norm3)
+        params = [t for n in norms for t in (n.weight, n.bias, n.running_mean, n.running_var)]
+        params += [self.agg1.pointwise_conv.weight, self.agg2.pointwise_conv.weight, self.agg3.pointwise_conv.weight,
+                   self.agg0.conv.pointwise_conv.weight]
+        for n in norms:
+            if abs(n.eps - 1e-5) > 0:
+                raise NotImplementedError("Aggregator: BatchNorm eps must be the default 1e-5")
+        scale, shift, pw, pwl = ops.host_cached(self, "fold", params, fold)
+        qkvp = torch.empty((b, H, W, 3, 4 * seg), dtype=dt, device=dev)
+        loc = torch.empty((b, H, W, seg), dtype=dt, device=dev)
+        ln = self.agg0.norm
+        check(lib().rc_gma_pointwise(qkv.data_ptr(), dw.data_ptr(), dwl.data_ptr(), qkvp.data_ptr(), loc.data_ptr(), ops._dt(qkv),
+                                     b * H * W, c, pw.data_ptr(), scale.data_ptr(), shift.data_ptr(), pwl.data_ptr(),
+                                     ops.f32_param(ln, "weight").data_ptr(), ops.f32_param(ln, "bias").data_ptr(), ops._stream()),
+              "rc_gma_pointwise")
+        return qkvp, loc
+
+
+class ConvRelPosEnc(nn.Module):
+    """q * depth-wise conv(v) with per-head-group windows (upstream groupmix.py:108-156)."""
+
+    def __init__(self, Ch, h, window):
+        super().__init__()
+        if isinstance(window, int):
+            window = {window: h}
+        elif not isinstance(window, dict):
+            raise ValueError()
+        self.window = window
+        self.conv_list = nn.ModuleList()
+        self.head_splits = []
+        for cur_window, cur_head_split in window.items():
+            padding_size = cur_window // 2
+            self.conv_list.append(nn.Conv2d(cur_head_split * Ch, cur_head_split * Ch, kernel_size=(cur_window, cur_window),
+                                            padding=(padding_size, padding_size), dilation=(1, 1), groups=cur_head_split * Ch))
+            self.head_splits.append(cur_head_split)
+        self.channel_splits = [x * Ch for x in self.head_splits]
+
+    def _conv_v(self, qkvp):
+        """depth-wise conv of v (channels 2ct..3ct of qkvp) with every window zero-padded to a centred 7x7."""
+        b, H, W, _, ct = qkvp.shape
+        kmax = max(self.window.keys())
+        if kmax > 7 or any(k % 2 == 0 for k in self.window):
+            raise NotImplementedError("ConvRelPosEnc: odd windows up to 7")
+        params = [t for cv in self.conv_list for t in (cv.weight, cv.bias)]
+
+        def build(*p):
+            return (torch.cat([ops.dw_taps(p[2 * i], pad_to=7) for i in range(len(self.conv_list))], dim=1),
+                    torch.cat([p[2 * i + 1] for i in range(len(self.conv_list))]))
+
+        wT, bias = ops.host_cached(self, "taps7", params, build)
+        convv = torch.empty((b, H, W, ct), dtype=qkvp.dtype, device=qkvp.device)
+        ops.dwconv2d(qkvp, 2 * ct, convv, 0, ct, 7, wT, bias=bias)
+        return convv
+
+
+class EfficientAtt(nn.Module):
+    """Linear attention with multi-scale aggregators (upstream groupmix.py:159-200)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.aggregator = Aggregator(dim=dim, seg=5)
+        trans_dim = dim // 5 * 4
+        self.crpe = ConvRelPosEnc(Ch=trans_dim // num_heads, h=num_heads, window={3: 2, 5: 3, 7: 3})
+
+    def _nhwc(self, a, residual=None):
+        b, H, W, c = a.shape
+        heads = self.num_heads
+        if c % 5 or (c // 5 * 4) % heads or sum(self.crpe.head_splits) != heads:
+            raise ValueError(f"EfficientAtt: dim {c} / heads {heads} do not tile (upstream needs dim % 10 == 0, heads == 8)")
+        seg, ct = c // 5, c // 5 * 4
+        ch = ct // heads
+        qkv = ops.conv2d(a, self.qkv)                                   # (B,H,W,3C), channel = which*C + c
+        qkvp, loc = self.aggregator._run(qkv)
+        convv = self.crpe._conv_v(qkvp)
+        n = H * W
+        L = lib()
+        scratch = torch.empty(L.rc_gma_kv_scratch_bytes(b, n, heads, ch) // 4, dtype=torch.float32, device=a.device)
+        ktv = torch.empty((b, heads, ch, ch), dtype=torch.float32, device=a.device)
+        check(L.rc_gma_kv(qkvp.data_ptr(), ops._dt(qkvp), b, n, heads, ch, float(self.scale), scratch.data_ptr(), ktv.data_ptr(),
+                          ops._stream()), "rc_gma_kv")
+        y = torch.empty((b, H, W, c), dtype=a.dtype, device=a.device)
+        check(L.rc_gma_apply(qkvp.data_ptr(), convv.data_ptr(), loc.data_ptr(), ktv.data_ptr(), y.data_ptr(), ops._dt(a), b, n, heads,
+                             ch, seg, ops._stream()), "rc_gma_apply")
+        return ops.conv2d(y, self.proj, residual=residual)
+
+    def forward(self, x, size):
+        return self._nhwc(_as_nhwc(x, size)).reshape(x.shape)
+
+
+class ConvPosEnc(nn.Module):
+    """Depth-wise 3x3 conv + identity (upstream groupmix.py:203-217)."""
+
+    def __init__(self, dim, k=3):
+        super().__init__()
+        self.proj = nn.Conv2d(dim, dim, k, 1, k // 2, groups=dim)
+
+    def _nhwc(self, a):
+        k = self.proj.kernel_size[0]
+        (wT,) = ops.host_cached(self, "taps", [self.proj.weight], lambda w: ops.dw_taps(w))
+        y = torch.empty_like(a)
+        return ops.dwconv2d(a, 0, y, 0, a.shape[-1], k, wT, bias=ops.f32_param(self.proj, "bias"), add_identity=True)
+
+    def forward(self, x, size):
+        return self._nhwc(_as_nhwc(x, size)).reshape(x.shape)
+
+
+class GMA_Block(nn.Module):
+    """cpe -> LN -> EfficientAtt -> + ; LN -> Mlp -> +   (upstream groupmix.py:274-299)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path_rate=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        if drop_path_rate > 0.:
+            raise NotImplementedError("GMA_Block: inference path, drop_path_rate must be 0 (identity upstream too)")
+        self.cpe = ConvPosEnc(dim=dim, k=3)
+        self.norm1 = norm_layer(dim)
+        self.att = EfficientAtt(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path_rate = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        mlp_hidden_dim = int(dim * mlp_ratio)
+        self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
+
+    def _nhwc(self, a):
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        x = self.cpe._nhwc(a)
+        x = self.att._nhwc(ops.layernorm(x, self.norm1), residual=x)
+        return self.mlp._nhwc(ops.layernorm(x, self.norm2), residual=x)
+
+    def forward(self, x_input, size):
+        return self._nhwc(_as_nhwc(x_input, size)).reshape(x_input.shape)
+
+
+def _as_nhwc(x, size):
+    """(B,N,C) tokens -> the same memory viewed as NHWC (B,H,W,C)."""
+    x = ops._req(x, "tokens")
+    b, n, c = x.shape
+    if size is None:
+        return x.reshape(b, 1, n, c)
+    H, W = size
+    if H * W != n:
+        raise ValueError(f"size {size} does not match {n} tokens")
+    return x.reshape(b, H, W, c)

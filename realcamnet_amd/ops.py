@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (RC_ACT_LEAKY, RC_ACT_NONE, RC_ACT_RELU, RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC,
+from ._lib import (RC_ACT_GELU, RC_ACT_LEAKY, RC_ACT_NONE, RC_ACT_RELU, RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC,
                    RC_OUT_PIXEL_SHUFFLE2, ConvDesc, check)
 
 _DT = {torch.float32: RC_F32, torch.bfloat16: RC_BF16}
@@ -96,7 +96,11 @@ def packed_conv(mod, act_dtype: torch.dtype, out_mode: int) -> PackedConv:
         return hit[1]
     if not w.is_cuda:
         raise RuntimeError("conv weights are not on a HIP device; move the module with .cuda() first")
-    cout, cin, kh, kw = w.shape
+    if w.dim() == 2:                       # nn.Linear over tokens == 1x1 convolution over NHWC pixels
+        cout, cin = w.shape
+        kh = kw = 1
+    else:
+        cout, cin, kh, kw = w.shape
     if kh != kw or kh not in (1, 3):
         raise NotImplementedError(f"HIP conv supports 1x1 and 3x3 kernels, got {kh}x{kw}")
     L = lib()
@@ -176,7 +180,7 @@ def bayer_unshuffle(mosaic: torch.Tensor, dtype: Optional[torch.dtype] = None, p
 # --------------------------------------------------------------------------------------------------
 # convolution and friends
 # --------------------------------------------------------------------------------------------------
-_ACT = {None: RC_ACT_NONE, "relu": RC_ACT_RELU, "leaky": RC_ACT_LEAKY}
+_ACT = {None: RC_ACT_NONE, "relu": RC_ACT_RELU, "leaky": RC_ACT_LEAKY, "gelu": RC_ACT_GELU}
 
 
 def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.0,
@@ -191,7 +195,8 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
     combined tensor is also materialised and returned.
     Returns out, or a tuple (out, [stored_input], [chan_sums]) when extras are requested.
     """
-    check_conv_module(mod)
+    if mod.weight.dim() == 4:
+        check_conv_module(mod)
     x = _req(x, "conv input")
     b, H, W, cin = x.shape
     pc = packed_conv(mod, x.dtype, out_mode)
@@ -370,3 +375,55 @@ def prof_collect():
     n, ms, fl = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
     check(lib().rc_prof_collect(C.byref(n), C.byref(ms), C.byref(fl)), "rc_prof_collect")
     return n.value, ms.value, fl.value
+
+
+# --------------------------------------------------------------------------------------------------
+# GroupMix attention pieces (upstream models/groupmix.py)
+# --------------------------------------------------------------------------------------------------
+def host_cached(mod, key: str, params, build):
+    """Small derived fp32 tensors (folded BatchNorm, tap-major depth-wise weights ...) built on the host from
+    module parameters once per parameter version and kept on the parameters' device."""
+    c = _cache(mod)
+    k = ("derived", key)
+    ver = _key(*params)
+    hit = c.get(k)
+    if hit is None or hit[0] != ver:
+        dev = params[0].device
+        with torch.no_grad():
+            vals = build(*[p.detach().float().cpu() for p in params])
+        if isinstance(vals, torch.Tensor):
+            vals = (vals,)
+        hit = (ver, tuple(v.contiguous().to(dev) for v in vals))
+        c[k] = hit
+    return hit[1]
+
+
+def dw_taps(weight: torch.Tensor, pad_to: Optional[int] = None) -> torch.Tensor:
+    """(n,1,k,k) depth-wise weights -> tap-major (K*K, n) fp32, optionally zero-padded to a centred KxK."""
+    n, _, k, _ = weight.shape
+    if pad_to is not None and pad_to != k:
+        r = (pad_to - k) // 2
+        weight = torch.nn.functional.pad(weight, (r, r, r, r))
+        k = pad_to
+    return weight.reshape(n, k * k).t().contiguous()
+
+
+def dwconv2d(x: torch.Tensor, x_c0: int, y: torch.Tensor, y_c0: int, n_ch: int, ksize: int, wT: torch.Tensor,
+             bias: Optional[torch.Tensor] = None, n_rep: int = 1, x_rep: int = 0, y_rep: int = 0, w_rep: int = 0,
+             add_identity: bool = False) -> torch.Tensor:
+    x = _req(x, "dwconv input")
+    b, H, W = x.shape[:3]
+    xs = int(np.prod(x.shape[3:]))
+    ys = int(np.prod(y.shape[3:]))
+    check(lib().rc_dwconv2d(x.data_ptr(), xs, x_c0, y.data_ptr(), ys, y_c0, _dt(x), b, H, W, n_ch, ksize, wT.data_ptr(),
+                            wT.shape[1], _ptr(bias), n_rep, x_rep, y_rep, w_rep, 1 if add_identity else 0, _stream()), "rc_dwconv2d")
+    return y
+
+
+def layernorm(x: torch.Tensor, norm) -> torch.Tensor:
+    x = _req(x, "layernorm input")
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib().rc_layernorm(x.data_ptr(), y.data_ptr(), _dt(x), x.numel() // c, c, f32_param(norm, "weight").data_ptr(),
+                             f32_param(norm, "bias").data_ptr(), float(norm.eps), _stream()), "rc_layernorm")
+    return y
