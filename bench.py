@@ -86,7 +86,8 @@ def main():
     ap.add_argument("--height", type=int, default=2160, help="mosaic height")
     ap.add_argument("--width", type=int, default=3840, help="mosaic width")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
-    ap.add_argument("--model", default="LiteISPNet_GFM_LSC", choices=["LiteISPNet_GFM_LSC", "LiteISPNet"])
+    ap.add_argument("--model", default="LiteISPNet_GFM_LSC_GMA", choices=["LiteISPNet_GFM_LSC_GMA", "LiteISPNet_GFM_LSC", "LiteISPNet"],
+                    help="default = cfg3: the flagship net plus one GroupMix GMA_Block(80,8) at H/2 (build-defined placement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -153,7 +154,7 @@ def main():
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (uniform[0,1) mosaics, seed-0 random-init weights)",
         "config": {"workload": f"cfg3: {W2}x{H2} Bayer mosaic -> unshuffle+pad16 -> {args.model} -> sRGB {W2}x{H2}, "
-                               f"{B} frames/GPU, {args.dtype} storage / fp32 accumulate (GroupMix block not yet attached)",
+                               f"{B} frames/GPU, {args.dtype} storage / fp32 accumulate",
                    "frames_per_gpu": B, "global_frames": total_frames, "parallelism": f"frame-shard x{world}"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": None,

@@ -196,12 +196,14 @@ int rc_gfm_vector(const float* d_vec, int batch, int cond_c, int nf, int c,
  * rc_gma_pointwise: Aggregator tail (groupmix.py:92-100) with BatchNorm(eval) folded to scale/shift:
  *   qkv (B,N,3C), dw (B,N,3,3seg) = depth-wise outputs of groups 1..3, dwl (B,N,3seg) = local depth-wise output
  *   -> qkvp (B,N,3,4seg) [q|k|v, channel = head*Ch + i], loc (B,N,seg).
- * rc_gma_kv: softmax over the N tokens fused with k^T v (groupmix.py:187-188), one streaming pass + fixed-order
- *   merge: ktv (B,heads,Ch,Ch) fp32 = scale * softmax_N(k)^T v.  d_scratch: rc_gma_kv_scratch_bytes().
+ * rc_gma_kv: softmax over the N tokens fused with k^T v (groupmix.py:187-188): per-channel max pass, exp-sum +
+ *   k^T v pass, fixed-order merge: ktv (B,heads,Ch,Ch) fp32 = scale * softmax_N(k)^T v.  d_scratch: rc_gma_kv_scratch_bytes().
  * rc_gma_apply: out (B,N,C) = [ q.ktv + q*convv | loc ]  (groupmix.py:189-194). */
 int rc_dwconv2d(const void* d_x, int x_stride_c, int x_c0, void* d_y, int y_stride_c, int y_c0, int dtype,
                 int batch, int H, int W, int n_ch, int ksize, const float* d_wT, int n_w, const float* d_bias,
-                int n_rep, int x_rep_stride, int y_rep_stride, int w_rep_stride, int add_identity, void* stream);
+                int n_rep, int x_rep_stride, int y_rep_stride, int w_rep_stride, int add_identity,
+                const int* d_kvec /* optional: true window per 16-byte weight vector when taps are zero-padded to K */,
+                void* stream);
 int rc_layernorm(const void* d_x, void* d_y, int dtype, long long tokens, int c, const float* d_gamma,
                  const float* d_beta, float eps, void* stream);
 int rc_gma_pointwise(const void* d_qkv, const void* d_dw, const void* d_dwl, void* d_qkvp, void* d_loc, int dtype,

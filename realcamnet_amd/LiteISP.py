@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from . import networks as N
 from . import ops
+from .groupmix import GMA_Block
 from ._lib import RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2
 
 
@@ -134,6 +135,9 @@ class _DwtUNet(nn.Module):
     def _act_dtype(self) -> torch.dtype:
         return self.head.weight.dtype
 
+    def _refine_d1(self, d1):
+        return d1
+
     def _check(self, raw):
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
@@ -146,7 +150,7 @@ class _DwtUNet(nn.Module):
     def _trunk(self, h, vec, crop_hw=None):
         mod = (lambda i, t: getattr(self, f"encoder_modulation{i}")._nhwc((t, vec))[0]) if vec is not None else (lambda i, t: t)
         h = mod(1, h)
-        d1 = self.down1._nhwc(h)
+        d1 = self._refine_d1(self.down1._nhwc(h))
         d2 = self.down2._nhwc(mod(2, d1))
         d3 = self.down3._nhwc(mod(3, d2))
         m = self.middle._nhwc(mod(4, d3), residual=d3)
@@ -257,3 +261,26 @@ class LiteISPNet_GFM_LSC(_DwtUNet):
         co = ops.to_nhwc(coord, dtype=dt, pad_hw=(hp, wp))
         h, vec = self._front(a, cond, co)
         return self._trunk(h, vec, crop_hw=(mosaic.shape[-2], mosaic.shape[-1]))
+
+
+class LiteISPNet_GFM_LSC_GMA(LiteISPNet_GFM_LSC):
+    """BUILD-DEFINED composition for BASELINE.json config 3 ("4K RAW->sRGB with GroupMix attention").
+
+    Upstream defines GMA_Block (models/groupmix.py:274-299, copy at models/raw2bit.py:117-142) but wires it into
+    no full model -- only the smoke test `test_gma` (models/raw2bit.py:4361-4367) instantiates it.  This class
+    attaches one GMA_Block(dim=80, heads=8) as a residual refinement of the H/2-level feature d1 (192 ch):
+        d1 <- d1 + gma_out( GMA_Block( gma_in(d1) ) ),   gma_in: Conv1x1 192->80, gma_out: Conv1x1 80->192
+    i.e. N = (H/2)(W/2) tokens (522 240 at 4K), the placement SURVEY.md section 8d names.  Everything else is
+    LiteISPNet_GFM_LSC unchanged (the extra modules are constructed last, so the base parameters keep the
+    reference's seed-0 values).  oracle/liteisp_oracle.py restates the same composition for parity."""
+
+    def __init__(self, gma_dim: int = 80, gma_heads: int = 8):
+        super().__init__()
+        c1 = self.down1[3].weight.shape[0]            # 4 * ch_1 = 192
+        self.gma_in = N.Conv2d(c1, gma_dim, 1, 1, 0)
+        self.gma = GMA_Block(gma_dim, gma_heads)
+        self.gma_out = N.Conv2d(gma_dim, c1, 1, 1, 0)
+
+    def _refine_d1(self, d1):
+        t = self.gma._nhwc(self.gma_in._nhwc(d1))
+        return self.gma_out._nhwc(t, residual=d1)

@@ -18,6 +18,7 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
     p->unit = dtype == RC_F32 ? 4 : 8;
     if (dtype == RC_BF16) {
         if (cin <= 8) p->ck = 8;
+        else if (ksize == 1 && cin % 80 == 0 && cin % 64 != 0) p->ck = 80;   // GroupMix dims (80, 240, 320 -> 64)
         else if (cin % 64 == 0) p->ck = 64;
         else if (cin % 48 == 0) p->ck = 48;
         else p->ck = 16;
@@ -36,6 +37,7 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
         else if (cps % 16 == 0) p->nt = 1;
         else return false;
     } else if (cout % 48 == 0 && dtype == RC_BF16 && cin == 48) p->nt = 3;
+    else if (ksize == 1 && cout % 80 == 0) p->nt = 5;          // 80-wide cout tiles for the GroupMix Linears
     else if (cout % 64 == 0) p->nt = 4;
     else if (cout % 48 == 0) p->nt = 3;
     else p->nt = 1;

@@ -650,7 +650,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a
 // with several, the input tile stays resident and the weights of each cout tile are DMA'd in turn.
 // Two such blocks share a CU and drift out of phase (one in MFMA while the other stores / stages).
 // ==================================================================================================
-constexpr int kPersistMaxCout = 256;   // bias slots kept in LDS
+constexpr int kPersistMaxCout = 512;   // bias slots kept in LDS
 
 template <class Cfg, bool GATED>
 __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const ConvArgs a) {

@@ -7,8 +7,8 @@
 //   layernorm       per-token LayerNorm over C
 //   gma_pointwise   aggregator tail: per-group seg x seg point-wise conv + BatchNorm(eval) + Hardswish, and
 //                   the local branch (3seg -> seg point-wise, LayerNorm(seg), Hardswish)
-//   gma_kv_reduce   ONE streaming pass over k and v: softmax over the N tokens (online max/sum) fused with the
-//                   k^T v contraction -> per-block partials;  gma_kv_merge folds them in fixed order
+//   gma_kmax / gma_kvsum / gma_kv_merge   softmax over the N tokens fused with the k^T v contraction: per-channel
+//                   max, then exp-sums and k^T v partials per block, folded in fixed order (no (N x C) softmax tensor)
 //   gma_apply       out = scale * q (softmax(k)^T v) + q * dwconv(v), concatenated with the local branch
 // All arithmetic is fp32 on bf16/fp32 storage; reductions have a fixed order (bitwise reproducible).
 #include "common.hpp"
@@ -25,42 +25,81 @@ __device__ __forceinline__ float hardswish(float x) {
 // ---- depth-wise KxK conv on channel sub-ranges of NHWC tensors ---------------------------------------
 // y[b,p, y_c0 + r*y_rep + c] = bias[r*w_rep + c] + sum_t wT[t][r*w_rep + c] * x[b, p+t, x_c0 + r*x_rep + c] (+ x[..] itself)
 // wT is tap-major (K*K, n_w) so a thread's UNIT weights per tap are one contiguous load.
-template <typename T>
-__global__ void dwconv2d_kernel(const T* __restrict__ x, int xs, int x_c0, T* __restrict__ y, int ys, int y_c0,
-                                int batch, int H, int W, int n_ch, int K, const float* __restrict__ wT, int n_w,
-                                const float* __restrict__ bias, int n_rep, int x_rep, int y_rep, int w_rep,
-                                int add_identity) {
-    constexpr int U = Vec16<T>::N;
-    const int vpc = n_ch / U, R = K / 2;
-    const size_t total = (size_t)batch * H * W * n_rep * vpc;
+// Each thread produces DW_PX consecutive output pixels of one 16-byte channel vector.  Per kernel row the
+// K + DW_PX - 1 input vectors are loaded once into registers and reused by all taps and outputs; the tap-major
+// weights live in LDS (read as 16-byte vectors), so the inner loop is pure FMA.  kvec (optional, one int per
+// weight vector) gives the true window of that vector when taps are zero-padded to a common K (ConvRelPosEnc
+// mixes 3/5/7 windows): padded taps are skipped, never multiplied.
+constexpr int DW_PX = 4;
+template <typename T, int K>
+__global__ __launch_bounds__(kGThreads) void dwconv2d_kernel(const T* __restrict__ x, int xs, int x_c0, T* __restrict__ y, int ys,
+                                                            int y_c0, int batch, int H, int W, int n_ch,
+                                                            const float* __restrict__ wT, int n_w, const float* __restrict__ bias,
+                                                            int n_rep, int x_rep, int y_rep, int w_rep, int add_identity,
+                                                            const int* __restrict__ kvec) {
+    constexpr int U = Vec16<T>::N, R = K / 2, NCOL = K + DW_PX - 1;
+    extern __shared__ float s_w[];                       // [K*K][n_w]
+    for (int i = threadIdx.x; i < K * K * n_w; i += blockDim.x) s_w[i] = wT[i];
+    __syncthreads();
+    const int vpc = n_ch / U;
+    const int wq = (W + DW_PX - 1) / DW_PX;
+    const size_t total = (size_t)batch * H * wq * n_rep * vpc;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int v = (int)(i % vpc);
         const int r = (int)((i / vpc) % n_rep);
         const size_t p = i / ((size_t)vpc * n_rep);
-        const int px = (int)(p % W), py = (int)((p / W) % H), b = (int)(p / ((size_t)W * H));
+        const int qx = (int)(p % wq), py = (int)((p / wq) % H), b = (int)(p / ((size_t)wq * H));
+        const int px0 = qx * DW_PX;
         const int cw = r * w_rep + v * U;
-        float acc[U];
+        const int Rv = kvec ? kvec[cw / U] / 2 : R;      // this vector's true half-window
+        float acc[DW_PX][U];
 #pragma unroll
-        for (int e = 0; e < U; ++e) acc[e] = bias ? bias[cw + e] : 0.f;
+        for (int o = 0; o < DW_PX; ++o)
+#pragma unroll
+            for (int e = 0; e < U; ++e) acc[o][e] = bias ? bias[cw + e] : 0.f;
         const int xc = x_c0 + r * x_rep + v * U;
+#pragma unroll
         for (int dy = 0; dy < K; ++dy) {
             const int gy = py + dy - R;
-            if (gy < 0 || gy >= H) continue;
-            for (int dx = 0; dx < K; ++dx) {
-                const int gx = px + dx - R;
-                if (gx < 0 || gx >= W) continue;
-                float f[U];
-                Vec16<T>::unpack(*reinterpret_cast<const uint4*>(x + (((size_t)b * H + gy) * W + gx) * xs + xc), f);
-                const float* wp = wT + (size_t)(dy * K + dx) * n_w + cw;
+            const bool row_ok = gy >= 0 && gy < H && dy >= R - Rv && dy <= R + Rv;
+            const T* row = x + (((size_t)b * H + (row_ok ? gy : 0)) * W) * xs + xc;
+            float f[NCOL][U];
 #pragma unroll
-                for (int e = 0; e < U; ++e) acc[e] += wp[e] * f[e];
-                if (add_identity && dy == R && dx == R) {
+            for (int cidx = 0; cidx < NCOL; ++cidx) {
+                const int gx = px0 + cidx - R;
+                uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+                if (row_ok && gx >= 0 && gx < W) raw = *reinterpret_cast<const uint4*>(row + (size_t)gx * xs);
+                Vec16<T>::unpack(raw, f[cidx]);
+            }
+            if (row_ok) {
 #pragma unroll
-                    for (int e = 0; e < U; ++e) acc[e] += f[e];
+                for (int dx = 0; dx < K; ++dx) {
+                    if (dx >= R - Rv && dx <= R + Rv) {
+                        float wv[U];
+                        const float* wp = s_w + (dy * K + dx) * n_w + cw;
+#pragma unroll
+                        for (int e = 0; e < U; e += 4) {
+                            const float4 t4 = *reinterpret_cast<const float4*>(wp + e);
+                            wv[e] = t4.x; wv[e + 1] = t4.y; wv[e + 2] = t4.z; wv[e + 3] = t4.w;
+                        }
+#pragma unroll
+                        for (int o = 0; o < DW_PX; ++o)
+#pragma unroll
+                            for (int e = 0; e < U; ++e) acc[o][e] += wv[e] * f[o + dx][e];
+                    }
+                }
+                if (add_identity && dy == R) {
+#pragma unroll
+                    for (int o = 0; o < DW_PX; ++o)
+#pragma unroll
+                        for (int e = 0; e < U; ++e) acc[o][e] += f[o + R][e];
                 }
             }
         }
-        *reinterpret_cast<uint4*>(y + p * ys + y_c0 + r * y_rep + v * U) = Vec16<T>::pack(acc);
+#pragma unroll
+        for (int o = 0; o < DW_PX; ++o)
+            if (px0 + o < W)
+                *reinterpret_cast<uint4*>(y + (((size_t)b * H + py) * W + px0 + o) * ys + y_c0 + r * y_rep + v * U) = Vec16<T>::pack(acc[o]);
     }
 }
 
@@ -115,169 +154,210 @@ __global__ void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, con
 // job = which*4 + g (g = 0..3): in = (g == 0 ? qkv[.., which*C + 0..seg) : dw[.., which, (g-1)*seg ..]);
 //   out qkvp[.., which, g*seg + s] = hardswish(bn_scale[g][s] * (g == 0 ? in[s] : sum_j pw[g-1][s][j] in[j]) + bn_shift[g][s])
 // job = 12: local: in = dwl[.., 0..3seg); t[s] = sum_j pwl[s][j] in[j]; out loc[.., s] = hardswish(LN_seg(t)[s])
-template <typename T, int SEG>   // SEG > 0: compile-time segment width (arrays stay in registers); 0: runtime (<= 48)
-__global__ void gma_pointwise_kernel(const T* __restrict__ qkv, const T* __restrict__ dw, const T* __restrict__ dwl,
-                                     T* __restrict__ qkvp, T* __restrict__ loc, size_t tokens, int c, int seg_rt,
+// One job type per block (blockIdx.y = job): no divergence inside a wave; tokens run along blockIdx.x.
+template <typename T, int SEG>   // compile-time segment width: per-thread arrays stay in registers
+__global__ __launch_bounds__(kGThreads) void gma_pointwise_kernel(const T* __restrict__ qkv, const T* __restrict__ dw, const T* __restrict__ dwl,
+                                     T* __restrict__ qkvp, T* __restrict__ loc, size_t tokens, int c,
                                      const float* __restrict__ pw /*3,seg,seg*/, const float* __restrict__ bn_scale /*4,seg*/,
                                      const float* __restrict__ bn_shift, const float* __restrict__ pwl /*seg,3seg*/,
                                      const float* __restrict__ ln_g, const float* __restrict__ ln_b) {
-    const int seg = SEG > 0 ? SEG : seg_rt;
-    extern __shared__ float sw[];   // pw | pwl
-    float* s_pw = sw;
-    float* s_pwl = sw + 3 * seg * seg;
-    for (int i = threadIdx.x; i < 3 * seg * seg; i += blockDim.x) s_pw[i] = pw[i];
-    for (int i = threadIdx.x; i < 3 * seg * seg; i += blockDim.x) s_pwl[i] = pwl[i];
-    __syncthreads();
-    constexpr int MAXSEG = SEG > 0 ? SEG : 48;
-    const size_t total = tokens * 13;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int job = (int)(i % 13);
-        const size_t t = i / 13;
-        float out[MAXSEG];
+    constexpr int U = Vec16<T>::N, NV = SEG / U;
+    static_assert(SEG % U == 0, "segment must be whole 16-byte vectors");
+    // the job's weight matrix is wave-uniform read-only data: indexed straight from global memory it is fetched
+    // through the scalar cache into SGPRs (an LDS copy would cost one ds_read per FMA)
+    const int job = blockIdx.y;
+    const int which = job >> 2, g = job & 3;
+    const float* __restrict__ sw = job == 12 ? pwl : pw + (g > 0 ? (g - 1) * SEG * SEG : 0);
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < tokens; t += (size_t)gridDim.x * blockDim.x) {
+        float out[SEG];
         if (job < 12) {
-            const int which = job >> 2, g = job & 3;
+            float in[SEG];
+            const T* src = g == 0 ? qkv + t * 3 * c + (size_t)which * c : dw + (t * 3 + which) * 3 * SEG + (g - 1) * SEG;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) Vec16<T>::unpack(reinterpret_cast<const uint4*>(src)[v], in + v * U);
             if (g == 0) {
-                const T* src = qkv + t * 3 * c + (size_t)which * c;
 #pragma unroll
-                for (int s = 0; s < seg; ++s) out[s] = to_f32(src[s]);
+                for (int s = 0; s < SEG; ++s) out[s] = in[s];
             } else {
-                const T* src = dw + (t * 3 + which) * 3 * seg + (g - 1) * seg;
-                float in[MAXSEG];
 #pragma unroll
-                for (int s = 0; s < seg; ++s) in[s] = to_f32(src[s]);
-                const float* wm = s_pw + (g - 1) * seg * seg;
-#pragma unroll
-                for (int s = 0; s < seg; ++s) {
+                for (int s = 0; s < SEG; ++s) {
                     float a = 0.f;
 #pragma unroll
-                    for (int j = 0; j < seg; ++j) a += wm[s * seg + j] * in[j];
+                    for (int j = 0; j < SEG; ++j) a += sw[s * SEG + j] * in[j];
                     out[s] = a;
                 }
             }
-            T* dst = qkvp + (t * 3 + which) * 4 * seg + g * seg;
 #pragma unroll
-            for (int s = 0; s < seg; ++s)
-                dst[s] = from_f32<T>(hardswish(out[s] * bn_scale[g * seg + s] + bn_shift[g * seg + s]));
+            for (int s = 0; s < SEG; ++s) out[s] = hardswish(out[s] * bn_scale[g * SEG + s] + bn_shift[g * SEG + s]);
+            T* dst = qkvp + (t * 3 + which) * 4 * SEG + g * SEG;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) reinterpret_cast<uint4*>(dst)[v] = Vec16<T>::pack(out + v * U);
         } else {
-            const T* src = dwl + t * 3 * seg;
+            float lin[3 * SEG];
+            const T* src = dwl + t * 3 * SEG;
+#pragma unroll
+            for (int v = 0; v < 3 * NV; ++v) Vec16<T>::unpack(reinterpret_cast<const uint4*>(src)[v], lin + v * U);
             float mean = 0.f;
-            float lin[3 * MAXSEG];
 #pragma unroll
-            for (int j = 0; j < 3 * seg; ++j) lin[j] = to_f32(src[j]);
-#pragma unroll
-            for (int s = 0; s < seg; ++s) {
+            for (int s = 0; s < SEG; ++s) {
                 float a = 0.f;
 #pragma unroll
-                for (int j = 0; j < 3 * seg; ++j) a += s_pwl[s * 3 * seg + j] * lin[j];
+                for (int j = 0; j < 3 * SEG; ++j) a += sw[s * 3 * SEG + j] * lin[j];
                 out[s] = a; mean += a;
             }
-            mean /= (float)seg;
+            mean /= (float)SEG;
             float var = 0.f;
 #pragma unroll
-            for (int s = 0; s < seg; ++s) { const float d = out[s] - mean; var += d * d; }
-            const float rstd = 1.f / sqrtf(var / (float)seg + 1e-5f);
-            T* dst = loc + t * seg;
+            for (int s = 0; s < SEG; ++s) { const float d = out[s] - mean; var += d * d; }
+            const float rstd = 1.f / sqrtf(var / (float)SEG + 1e-5f);
 #pragma unroll
-            for (int s = 0; s < seg; ++s) dst[s] = from_f32<T>(hardswish((out[s] - mean) * rstd * ln_g[s] + ln_b[s]));
+            for (int s = 0; s < SEG; ++s) out[s] = hardswish((out[s] - mean) * rstd * ln_g[s] + ln_b[s]);
+            T* dst = loc + t * SEG;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) reinterpret_cast<uint4*>(dst)[v] = Vec16<T>::pack(out + v * U);
         }
     }
 }
 
-// ---- softmax over N fused with k^T v: one streaming pass with online rescaling ------------------------
-// qkvp (B,N,3,ct): k = [..,1,:], v = [..,2,:]; ct = heads*ch.  Block (blk, b) folds tokens [blk*L, (blk+1)*L) in
-// tiles of TT tokens: running per-channel max M and sum Z, and KTV[h][i][j] = sum_n exp(k[n][h,i]-M[h,i]) v[n][h,j].
-// Partials: part[(b*nblk + blk)] = { M[ct], Z[ct], KTV[heads*ch*ch] }.
-constexpr int kKvTile = 32;
+// ---- softmax over N fused with k^T v (no (N x C) softmax tensor is ever written) ---------------------------
+// qkvp (B,N,3,ct): k = [..,1,:], v = [..,2,:]; ct = heads*ch.
+//  pass A  gma_kmax:  per-block partial max of k per channel              -> pmax[b][blkA][ct]
+//  pass B  gma_kvsum: M = max over pmax (block prologue), then per tile p = exp(k - M):
+//                     Z[c] += p,  KTV[h][i][j] += p[h,i] * v[h,j]         -> part[b][blkB] = { Z[ct], KTV[nacc] }
+//  merge              fixed-order sum over blocks, ktv = scale * KTV / Z
 template <typename T>
-__global__ __launch_bounds__(kGThreads) void gma_kv_reduce_kernel(const T* __restrict__ qkvp, float* __restrict__ part,
-                                                                  int n_tok, int L, int heads, int ch) {
-    const int ct = heads * ch, nacc = heads * ch * ch;
-    extern __shared__ float sm[];
-    float* s_k = sm;                          // [TT][ct] -> exp(k - M) in place
-    float* s_v = s_k + kKvTile * ct;          // [TT][ct]
-    float* s_m = s_v + kKvTile * ct;          // [ct] running max
-    float* s_f = s_m + ct;                    // [ct] rescale factor of this tile
-    float* s_z = s_f + ct;                    // [ct] running sum
+__global__ __launch_bounds__(kGThreads) void gma_kmax_kernel(const T* __restrict__ qkvp, float* __restrict__ pmax, int n_tok, int L, int ct) {
+    constexpr int U = Vec16<T>::N;
+    extern __shared__ float sm[];             // [groups][ct]
+    const int vpt = ct / U, groups = kGThreads / vpt;
     const int tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
-    constexpr int MAXA = 16;                  // accumulators per thread: nacc <= 256*16
+    const int v = tid % vpt, grp = tid / vpt;
+    const int t0 = blk * L, t1 = (t0 + L) < n_tok ? (t0 + L) : n_tok;
+    const T* base = qkvp + (size_t)b * n_tok * 3 * ct + ct + v * U;
+    float m[U];
+#pragma unroll
+    for (int e = 0; e < U; ++e) m[e] = -INFINITY;
+    if (grp < groups) {
+        for (int t = t0 + grp; t < t1; t += groups) {
+            float f[U];
+            Vec16<T>::unpack(*reinterpret_cast<const uint4*>(base + (size_t)t * 3 * ct), f);
+#pragma unroll
+            for (int e = 0; e < U; ++e) m[e] = fmaxf(m[e], f[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < U; ++e) sm[grp * ct + v * U + e] = m[e];
+    }
+    __syncthreads();
+    for (int c = tid; c < ct; c += kGThreads) {
+        float r = -INFINITY;
+        for (int g = 0; g < groups; ++g) r = fmaxf(r, sm[g * ct + c]);
+        pmax[((size_t)b * gridDim.x + blk) * ct + c] = r;
+    }
+}
+
+template <typename T, int MAXA>   // MAXA = accumulators per thread >= ceil(heads*ch*ch / 256)
+__global__ __launch_bounds__(kGThreads, 2) void gma_kvsum_kernel(const T* __restrict__ qkvp, const float* __restrict__ pmax, int nblk_a,
+                                                              float* __restrict__ part, int n_tok, int L, int heads, int ch, int tile) {
+    constexpr int U = Vec16<T>::N;
+    const int ct = heads * ch, nacc = heads * ch * ch, vpt = ct / U;
+    extern __shared__ float sm[];
+    float* s_p = sm;                          // [tile][ct]  exp(k - M)
+    float* s_v = s_p + tile * ct;             // [tile][ct]
+    float* s_m = s_v + tile * ct;             // [ct]
+    const int tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
+    {   // M[c] = max over pass A's partial maxima: all 256 threads, (channel, part) split, combined through LDS
+        const int parts = kGThreads / ct > 0 ? kGThreads / ct : 1;
+        for (int c0 = 0; c0 < ct; c0 += kGThreads) {
+            const int c = c0 + tid % (ct < kGThreads ? ct : kGThreads), part = tid / (ct < kGThreads ? ct : kGThreads);
+            float r = -INFINITY;
+            if (c < ct && part < parts)
+                for (int k = part; k < nblk_a; k += parts) r = fmaxf(r, pmax[((size_t)b * nblk_a + k) * ct + c]);
+            s_p[tid] = r;
+            __syncthreads();
+            if (tid < ct - c0 && tid < kGThreads) {
+                float m = -INFINITY;
+                for (int q2 = 0; q2 < parts; ++q2) m = fmaxf(m, s_p[q2 * (ct < kGThreads ? ct : kGThreads) + tid]);
+                s_m[c0 + tid] = m;
+            }
+            __syncthreads();
+        }
+    }
     float acc[MAXA];
 #pragma unroll
     for (int a = 0; a < MAXA; ++a) acc[a] = 0.f;
-    for (int c = tid; c < ct; c += kGThreads) { s_m[c] = -INFINITY; s_z[c] = 0.f; }
+    float z = 0.f;                            // thread c < ct owns Z[c]
     __syncthreads();
     const int t0 = blk * L, t1 = (t0 + L) < n_tok ? (t0 + L) : n_tok;
     const T* base = qkvp + (size_t)b * n_tok * 3 * ct;
-    for (int tt = t0; tt < t1; tt += kKvTile) {
-        const int nt = (t1 - tt) < kKvTile ? (t1 - tt) : kKvTile;
-        for (int i = tid; i < kKvTile * ct; i += kGThreads) {
-            const int t = i / ct, c = i - t * ct;
-            float kv = -INFINITY, vv = 0.f;
+    const int nvec_tile = tile * vpt;
+    for (int tt = t0; tt < t1; tt += tile) {
+        const int nt = (t1 - tt) < tile ? (t1 - tt) : tile;
+        for (int i = tid; i < nvec_tile; i += kGThreads) {
+            const int t = i / vpt, v = i - t * vpt;
+            float fk[U], fv[U];
             if (t < nt) {
                 const T* tok = base + (size_t)(tt + t) * 3 * ct;
-                kv = to_f32(tok[ct + c]); vv = to_f32(tok[2 * ct + c]);
+                Vec16<T>::unpack(*reinterpret_cast<const uint4*>(tok + ct + v * U), fk);
+                Vec16<T>::unpack(*reinterpret_cast<const uint4*>(tok + 2 * ct + v * U), fv);
+#pragma unroll
+                for (int e = 0; e < U; ++e) fk[e] = expf(fk[e] - s_m[v * U + e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < U; ++e) { fk[e] = 0.f; fv[e] = 0.f; }
             }
-            s_k[i] = kv; s_v[i] = vv;
+#pragma unroll
+            for (int e = 0; e < U; e += 4) {
+                *reinterpret_cast<float4*>(s_p + t * ct + v * U + e) = make_float4(fk[e], fk[e + 1], fk[e + 2], fk[e + 3]);
+                *reinterpret_cast<float4*>(s_v + t * ct + v * U + e) = make_float4(fv[e], fv[e + 1], fv[e + 2], fv[e + 3]);
+            }
         }
         __syncthreads();
-        for (int c = tid; c < ct; c += kGThreads) {           // new running max + rescale factor
-            float m = s_m[c];
-            const float m_old = m;
-            for (int t = 0; t < nt; ++t) m = fmaxf(m, s_k[t * ct + c]);
-            s_f[c] = (m_old == -INFINITY) ? 0.f : expf(m_old - m);
-            s_m[c] = m;
-        }
-        __syncthreads();
-        for (int i = tid; i < kKvTile * ct; i += kGThreads) { // p = exp(k - M)  (padding tokens: exp(-inf) = 0)
-            const int c = i % ct;
-            s_k[i] = expf(s_k[i] - s_m[c]);
-        }
-        __syncthreads();
-        for (int c = tid; c < ct; c += kGThreads) {
-            float z = s_z[c] * s_f[c];
-            for (int t = 0; t < nt; ++t) z += s_k[t * ct + c];
-            s_z[c] = z;
+        if (tid < ct) {
+            for (int t = 0; t < tile; ++t) z += s_p[t * ct + tid];
         }
 #pragma unroll
         for (int a = 0; a < MAXA; ++a) {
             const int o = tid + a * kGThreads;                // o = (h*ch + i)*ch + j
             if (o < nacc) {
                 const int j = o % ch, hi = o / ch, h = hi / ch;
-                float s = acc[a] * s_f[hi];
-                const float* pk = s_k + hi;
+                float sacc = acc[a];
+                const float* pk = s_p + hi;
                 const float* pv = s_v + h * ch + j;
-                for (int t = 0; t < nt; ++t) s += pk[t * ct] * pv[t * ct];
-                acc[a] = s;
+                for (int t = 0; t < tile; ++t) sacc += pk[t * ct] * pv[t * ct];
+                acc[a] = sacc;
             }
         }
         __syncthreads();
     }
-    float* out = part + ((size_t)b * gridDim.x + blk) * (2 * ct + nacc);
-    for (int c = tid; c < ct; c += kGThreads) { out[c] = s_m[c]; out[ct + c] = s_z[c]; }
+    float* out = part + ((size_t)b * gridDim.x + blk) * (ct + nacc);
+    if (tid < ct) out[tid] = z;
 #pragma unroll
     for (int a = 0; a < MAXA; ++a) {
         const int o = tid + a * kGThreads;
-        if (o < nacc) out[2 * ct + o] = acc[a];
+        if (o < nacc) out[ct + o] = acc[a];
     }
 }
 
-// merge partials in fixed order; ktv[b][h][i][j] = scale * softmax-normalised k^T v
+// fixed-order sum of the partials; ktv[b][h][i][j] = scale * softmax-normalised k^T v.
+// Block (chunk, b): 64 outputs x 4 parts; each part sums every 4th block, parts are combined in a fixed order.
 __global__ __launch_bounds__(kGThreads) void gma_kv_merge_kernel(const float* __restrict__ part, float* __restrict__ ktv,
                                                                  int nblk, int heads, int ch, float scale) {
-    const int ct = heads * ch, nacc = heads * ch * ch, rec = 2 * ct + nacc;
-    const int b = blockIdx.x;
+    __shared__ float s_s[kGThreads], s_z[kGThreads];
+    const int ct = heads * ch, nacc = heads * ch * ch, rec = ct + nacc;
+    const int b = blockIdx.y, o = blockIdx.x * 64 + (threadIdx.x & 63), prt = threadIdx.x >> 6;
     const float* p = part + (size_t)b * nblk * rec;
-    for (int o = threadIdx.x; o < nacc; o += kGThreads) {
+    float z = 0.f, sacc = 0.f;
+    if (o < nacc) {
         const int hi = o / ch;
-        float m = -INFINITY;
-        for (int k = 0; k < nblk; ++k) m = fmaxf(m, p[(size_t)k * rec + hi]);
-        float z = 0.f, s = 0.f;
-        for (int k = 0; k < nblk; ++k) {
-            const float mk = p[(size_t)k * rec + hi];
-            const float f = (mk == -INFINITY) ? 0.f : expf(mk - m);
-            z += p[(size_t)k * rec + ct + hi] * f;
-            s += p[(size_t)k * rec + 2 * ct + o] * f;
-        }
-        ktv[(size_t)b * nacc + o] = scale * s / z;
+        for (int k = prt; k < nblk; k += 4) { z += p[(size_t)k * rec + hi]; sacc += p[(size_t)k * rec + ct + o]; }
+    }
+    s_s[threadIdx.x] = sacc; s_z[threadIdx.x] = z;
+    __syncthreads();
+    if (prt == 0 && o < nacc) {
+        const int l = threadIdx.x;
+        const float zt = ((s_z[l] + s_z[l + 64]) + s_z[l + 128]) + s_z[l + 192];
+        const float st = ((s_s[l] + s_s[l + 64]) + s_s[l + 128]) + s_s[l + 192];
+        ktv[(size_t)b * nacc + o] = scale * st / zt;
     }
 }
 
@@ -330,7 +410,8 @@ extern "C" {
 
 int rc_dwconv2d(const void* d_x, int x_stride_c, int x_c0, void* d_y, int y_stride_c, int y_c0, int dtype,
                 int batch, int H, int W, int n_ch, int ksize, const float* d_wT, int n_w, const float* d_bias,
-                int n_rep, int x_rep_stride, int y_rep_stride, int w_rep_stride, int add_identity, void* stream) {
+                int n_rep, int x_rep_stride, int y_rep_stride, int w_rep_stride, int add_identity, const int* d_kvec,
+                void* stream) {
     RC_REQUIRE(d_x && d_y && d_wT, "rc_dwconv2d: null pointer");
     RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_dwconv2d: bad dtype");
     const int U = dtype == RC_F32 ? 4 : 8;
@@ -341,15 +422,17 @@ int rc_dwconv2d(const void* d_x, int x_stride_c, int x_c0, void* d_y, int y_stri
                "rc_dwconv2d: channel counts/offsets must be multiples of 16 bytes");
     RC_REQUIRE(x_c0 + (n_rep - 1) * x_rep_stride + n_ch <= x_stride_c && y_c0 + (n_rep - 1) * y_rep_stride + n_ch <= y_stride_c &&
                (n_rep - 1) * w_rep_stride + n_ch <= n_w, "rc_dwconv2d: channel range exceeds tensor");
-    const size_t total = (size_t)batch * H * W * n_rep * (n_ch / U);
-    if (dtype == RC_F32)
-        hipLaunchKernelGGL(dwconv2d_kernel<float>, dim3(pw_grid(total)), dim3(kGThreads), 0, as_stream(stream),
-                           static_cast<const float*>(d_x), x_stride_c, x_c0, static_cast<float*>(d_y), y_stride_c, y_c0, batch, H, W,
-                           n_ch, ksize, d_wT, n_w, d_bias, n_rep, x_rep_stride, y_rep_stride, w_rep_stride, add_identity);
-    else
-        hipLaunchKernelGGL(dwconv2d_kernel<bf16_t>, dim3(pw_grid(total)), dim3(kGThreads), 0, as_stream(stream),
-                           static_cast<const bf16_t*>(d_x), x_stride_c, x_c0, static_cast<bf16_t*>(d_y), y_stride_c, y_c0, batch, H, W,
-                           n_ch, ksize, d_wT, n_w, d_bias, n_rep, x_rep_stride, y_rep_stride, w_rep_stride, add_identity);
+    const size_t total = (size_t)batch * H * ((W + DW_PX - 1) / DW_PX) * n_rep * (n_ch / U);
+    const size_t lds = (size_t)ksize * ksize * n_w * sizeof(float);
+    RC_REQUIRE(lds <= 64 * 1024 && n_w % 4 == 0, "rc_dwconv2d: weight table too large for LDS");
+#define RC_DW_LAUNCH(TT, KK)                                                                                              \
+    hipLaunchKernelGGL((dwconv2d_kernel<TT, KK>), dim3(pw_grid(total)), dim3(kGThreads), lds, as_stream(stream),           \
+                       static_cast<const TT*>(d_x), x_stride_c, x_c0, static_cast<TT*>(d_y), y_stride_c, y_c0, batch, H, W, \
+                       n_ch, d_wT, n_w, d_bias, n_rep, x_rep_stride, y_rep_stride, w_rep_stride, add_identity, d_kvec)
+#define RC_DW_K(TT) if (ksize == 3) RC_DW_LAUNCH(TT, 3); else if (ksize == 5) RC_DW_LAUNCH(TT, 5); else RC_DW_LAUNCH(TT, 7);
+    if (dtype == RC_F32) { RC_DW_K(float) } else { RC_DW_K(bf16_t) }
+#undef RC_DW_K
+#undef RC_DW_LAUNCH
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
@@ -377,33 +460,36 @@ int rc_gma_pointwise(const void* d_qkv, const void* d_dw, const void* d_dwl, voi
     RC_REQUIRE(d_qkv && d_dw && d_dwl && d_qkvp && d_loc && d_pw && d_bn_scale && d_bn_shift && d_pwl && d_ln_g && d_ln_b,
                "rc_gma_pointwise: null pointer");
     RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_gma_pointwise: bad dtype");
-    RC_REQUIRE(tokens >= 1 && c >= 10 && c % 5 == 0 && c / 5 <= 48, "rc_gma_pointwise: C must be a multiple of 5 with C/5 <= 48");
+    RC_REQUIRE(tokens >= 1 && c >= 10 && c % 5 == 0, "rc_gma_pointwise: C must be a multiple of 5");
     const int seg = c / 5;
-    const size_t lds = (size_t)6 * seg * seg * sizeof(float);
-    const size_t total = (size_t)tokens * 13;
-#define RC_PW_LAUNCH(TT, SG)                                                                                          \
-    hipLaunchKernelGGL((gma_pointwise_kernel<TT, SG>), dim3(pw_grid(total)), dim3(kGThreads), lds, as_stream(stream), \
-                       static_cast<const TT*>(d_qkv), static_cast<const TT*>(d_dw), static_cast<const TT*>(d_dwl),    \
-                       static_cast<TT*>(d_qkvp), static_cast<TT*>(d_loc), (size_t)tokens, c, seg, d_pw, d_bn_scale,    \
+    RC_REQUIRE(seg == 16 || seg == 40 || seg == 8 || seg == 24 || seg == 32, "rc_gma_pointwise: C/5 must be one of 8, 16, 24, 32, 40 (dims 40..200)");
+    const size_t lds = 0;
+    size_t gx = ((size_t)tokens + kGThreads - 1) / kGThreads;
+    if (gx > 2048) gx = 2048;
+#define RC_PW_LAUNCH(TT, SG)                                                                                            \
+    hipLaunchKernelGGL((gma_pointwise_kernel<TT, SG>), dim3((unsigned)gx, 13), dim3(kGThreads), lds, as_stream(stream), \
+                       static_cast<const TT*>(d_qkv), static_cast<const TT*>(d_dw), static_cast<const TT*>(d_dwl),      \
+                       static_cast<TT*>(d_qkvp), static_cast<TT*>(d_loc), (size_t)tokens, c, d_pw, d_bn_scale,          \
                        d_bn_shift, d_pwl, d_ln_g, d_ln_b)
-    if (dtype == RC_F32) {
-        if (seg == 16) RC_PW_LAUNCH(float, 16); else if (seg == 40) RC_PW_LAUNCH(float, 40); else RC_PW_LAUNCH(float, 0);
-    } else {
-        if (seg == 16) RC_PW_LAUNCH(bf16_t, 16); else if (seg == 40) RC_PW_LAUNCH(bf16_t, 40); else RC_PW_LAUNCH(bf16_t, 0);
-    }
+#define RC_PW_SEG(TT)                                                                                                   \
+    switch (seg) { case 8: RC_PW_LAUNCH(TT, 8); break; case 16: RC_PW_LAUNCH(TT, 16); break; case 24: RC_PW_LAUNCH(TT, 24); break; \
+                   case 32: RC_PW_LAUNCH(TT, 32); break; default: RC_PW_LAUNCH(TT, 40); break; }
+    if (dtype == RC_F32) { RC_PW_SEG(float) } else { RC_PW_SEG(bf16_t) }
+#undef RC_PW_SEG
 #undef RC_PW_LAUNCH
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
 
 int rc_gma_kv_blocks(int n_tok) {
-    int nblk = (n_tok + 4095) / 4096;          // >= 4096 tokens per block, at most 256 blocks per image
+    int nblk = (n_tok + 1023) / 1024;          // >= 1024 tokens per block, at most 256 blocks per image
     if (nblk > 256) nblk = 256;
     if (nblk < 1) nblk = 1;
     return nblk;
 }
 
 size_t rc_gma_kv_scratch_bytes(int batch, int n_tok, int heads, int ch) {
+    // [ partial maxima: nblk x ct ] [ partial sums: nblk x (ct + heads*ch*ch) ] per image
     return (size_t)batch * rc_gma_kv_blocks(n_tok) * (2 * heads * ch + heads * ch * ch) * sizeof(float);
 }
 
@@ -411,20 +497,35 @@ int rc_gma_kv(const void* d_qkvp, int dtype, int batch, int n_tok, int heads, in
               float* d_ktv, void* stream) {
     RC_REQUIRE(d_qkvp && d_scratch && d_ktv, "rc_gma_kv: null pointer");
     RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_gma_kv: bad dtype");
-    RC_REQUIRE(batch >= 1 && batch <= 65535 && n_tok >= 1 && heads >= 1 && ch >= 1 && ch <= 32 && heads * ch * ch <= 256 * 16,
-               "rc_gma_kv: unsupported head geometry");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    RC_REQUIRE(batch >= 1 && batch <= 65535 && n_tok >= 1 && heads >= 1 && ch >= 1 && ch <= 32 && heads * ch * ch <= 256 * 16 &&
+               (heads * ch) % U == 0 && (heads * ch) / U <= kGThreads, "rc_gma_kv: unsupported head geometry");
     const int ct = heads * ch;
     const int nblk = rc_gma_kv_blocks(n_tok);
     const int L = (n_tok + nblk - 1) / nblk;
-    const size_t lds = ((size_t)2 * kKvTile * ct + 3 * ct) * sizeof(float);
-    RC_REQUIRE(lds <= 64 * 1024, "rc_gma_kv: too many attention channels");
-    if (dtype == RC_F32)
-        hipLaunchKernelGGL(gma_kv_reduce_kernel<float>, dim3(nblk, batch), dim3(kGThreads), lds, as_stream(stream),
-                           static_cast<const float*>(d_qkvp), d_scratch, n_tok, L, heads, ch);
-    else
-        hipLaunchKernelGGL(gma_kv_reduce_kernel<bf16_t>, dim3(nblk, batch), dim3(kGThreads), lds, as_stream(stream),
-                           static_cast<const bf16_t*>(d_qkvp), d_scratch, n_tok, L, heads, ch);
-    hipLaunchKernelGGL(gma_kv_merge_kernel, dim3(batch), dim3(kGThreads), 0, as_stream(stream), d_scratch, d_ktv, nblk, heads, ch, scale);
+    const int nblk_a = nblk < 32 ? nblk : 32;     // the max pass is light: few blocks keep pass B's prologue short
+    const int L_a = (n_tok + nblk_a - 1) / nblk_a;
+    float* pmax = d_scratch;
+    float* part = d_scratch + (size_t)batch * nblk * ct;
+    int tile = 6144 / ct;                      // two fp32 tiles of `tile` tokens in <= 48 KiB of LDS
+    tile = tile > 64 ? 64 : tile / 8 * 8;
+    RC_REQUIRE(tile >= 8, "rc_gma_kv: too many attention channels");
+    const size_t lds_a = (size_t)(kGThreads / (ct / U)) * ct * sizeof(float);
+    const size_t lds_b = ((size_t)2 * tile * ct + ct) * sizeof(float);
+    RC_REQUIRE(lds_a <= 64 * 1024 && lds_b <= 64 * 1024, "rc_gma_kv: too many attention channels");
+    const int nacc = heads * ch * ch;
+#define RC_KV_LAUNCH(TT, MA)                                                                                              \
+    hipLaunchKernelGGL((gma_kvsum_kernel<TT, MA>), dim3(nblk, batch), dim3(kGThreads), lds_b, as_stream(stream),          \
+                       static_cast<const TT*>(d_qkvp), pmax, nblk_a, part, n_tok, L, heads, ch, tile)
+#define RC_KV_BOTH(TT)                                                                                                    \
+    hipLaunchKernelGGL(gma_kmax_kernel<TT>, dim3(nblk_a, batch), dim3(kGThreads), lds_a, as_stream(stream),                \
+                       static_cast<const TT*>(d_qkvp), pmax, n_tok, L_a, ct);                                             \
+    if (nacc <= 2 * kGThreads) RC_KV_LAUNCH(TT, 2); else if (nacc <= 4 * kGThreads) RC_KV_LAUNCH(TT, 4); else RC_KV_LAUNCH(TT, 16);
+    if (dtype == RC_F32) { RC_KV_BOTH(float) } else { RC_KV_BOTH(bf16_t) }
+#undef RC_KV_BOTH
+#undef RC_KV_LAUNCH
+    hipLaunchKernelGGL(gma_kv_merge_kernel, dim3((heads * ch * ch + 63) / 64, batch), dim3(kGThreads), 0, as_stream(stream), part, d_ktv, nblk, heads,
+                       ch, scale);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

@@ -150,13 +150,18 @@ class ConvRelPosEnc(nn.Module):
             raise NotImplementedError("ConvRelPosEnc: odd windows up to 7")
         params = [t for cv in self.conv_list for t in (cv.weight, cv.bias)]
 
-        def build(*p):
-            return (torch.cat([ops.dw_taps(p[2 * i], pad_to=7) for i in range(len(self.conv_list))], dim=1),
-                    torch.cat([p[2 * i + 1] for i in range(len(self.conv_list))]))
+        unit = 8 if qkvp.dtype == torch.bfloat16 else 4
+        wins = list(self.window.keys())
 
-        wT, bias = ops.host_cached(self, "taps7", params, build)
+        def build(*p):
+            taps = torch.cat([ops.dw_taps(p[2 * i], pad_to=7) for i in range(len(self.conv_list))], dim=1)
+            kch = torch.cat([torch.full((p[2 * i].shape[0],), float(wins[i])) for i in range(len(self.conv_list))])
+            kvec = kch.reshape(-1, unit).max(dim=1).values      # a vector spanning two head groups takes the larger window
+            return taps, torch.cat([p[2 * i + 1] for i in range(len(self.conv_list))]), kvec.to(torch.int32)
+
+        wT, bias, kvec = ops.host_cached(self, f"taps7_{unit}", params, build)
         convv = torch.empty((b, H, W, ct), dtype=qkvp.dtype, device=qkvp.device)
-        ops.dwconv2d(qkvp, 2 * ct, convv, 0, ct, 7, wT, bias=bias)
+        ops.dwconv2d(qkvp, 2 * ct, convv, 0, ct, 7, wT, bias=bias, kvec=kvec)
         return convv
 
 

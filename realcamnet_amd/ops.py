@@ -410,13 +410,13 @@ def dw_taps(weight: torch.Tensor, pad_to: Optional[int] = None) -> torch.Tensor:
 
 def dwconv2d(x: torch.Tensor, x_c0: int, y: torch.Tensor, y_c0: int, n_ch: int, ksize: int, wT: torch.Tensor,
              bias: Optional[torch.Tensor] = None, n_rep: int = 1, x_rep: int = 0, y_rep: int = 0, w_rep: int = 0,
-             add_identity: bool = False) -> torch.Tensor:
+             add_identity: bool = False, kvec: Optional[torch.Tensor] = None) -> torch.Tensor:
     x = _req(x, "dwconv input")
     b, H, W = x.shape[:3]
     xs = int(np.prod(x.shape[3:]))
     ys = int(np.prod(y.shape[3:]))
     check(lib().rc_dwconv2d(x.data_ptr(), xs, x_c0, y.data_ptr(), ys, y_c0, _dt(x), b, H, W, n_ch, ksize, wT.data_ptr(),
-                            wT.shape[1], _ptr(bias), n_rep, x_rep, y_rep, w_rep, 1 if add_identity else 0, _stream()), "rc_dwconv2d")
+                            wT.shape[1], _ptr(bias), n_rep, x_rep, y_rep, w_rep, 1 if add_identity else 0, _ptr(kvec), _stream()), "rc_dwconv2d")
     return y
 
 

@@ -72,3 +72,33 @@ def test_gma_long_sequence_matches_oracle(hip):
         ref = GO.gma_block(g["sd"], x, hw, 8)
         y = blk.to("cuda").eval()(x.to("cuda"), hw)
     assert rel_err(y.cpu(), ref) <= 5e-5
+
+
+def test_gma_model_keeps_reference_base_parameters():
+    """The cfg3 composition adds modules AFTER the reference's: its base parameters are the reference's seed-0 values."""
+    from conftest import seed0_state_dict
+    torch.manual_seed(0)
+    net = M.LiteISPNet_GFM_LSC_GMA().eval()
+    base = seed0_state_dict("LiteISPNet_GFM_LSC")
+    sd = net.state_dict()
+    assert all(torch.equal(sd[k], v) for k, v in base.items())
+    extra = [k for k in sd if k not in base]
+    assert extra and all(k.startswith(("gma_in.", "gma.", "gma_out.")) for k in extra)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,floor", [(torch.float32, 95.0), (torch.bfloat16, 48.0)])
+def test_gma_model_vs_oracle(hip, dt, floor):
+    torch.manual_seed(0)
+    net = M.LiteISPNet_GFM_LSC_GMA().eval()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(21)
+    h, w = 44, 70
+    mosaic = torch.rand(2, 1, 2 * h, 2 * w, generator=g)
+    cond = torch.rand(2, 4, 32, 48, generator=g)
+    coord = O.make_coord(2, h, w)
+    with torch.no_grad():
+        ref = O.run_padded("LiteISPNet_GFM_LSC_GMA", sd, O.bayer_unshuffle(mosaic), cond, coord)
+        y = net.to("cuda", dt).forward_mosaic(mosaic.to("cuda", dt), cond.to("cuda", dt), coord.to("cuda", dt))
+    assert y.shape == ref.shape
+    assert O.psnr(y.float().cpu(), ref) >= floor
