@@ -8,7 +8,41 @@ import sqlite3
 import sys
 
 
+import shutil
+import subprocess
+
+_FILT = shutil.which("llvm-cxxfilt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+_DT = {"DF16b": "bf16", "f": "f32"}
+
+
+def demangle(name: str) -> str:
+    if not name.startswith("_Z"):
+        return name
+    m = re.match(r"_ZN2rc(\d+)(conv_mfma(?:_persist)?_kernel)INS_7ConvCfgI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EEELb([01])E", name)
+    if m:
+        return f"rc::{m.group(2)}<{_DT[m.group(3)]},CK={m.group(4)},NT={m.group(5)},K={m.group(6)},gated={m.group(7)}>"
+    m = re.match(r"_ZN2rc(\d+)", name)          # generic rc::<kernel><dtype, ints...> (c++filt cannot parse DF16b)
+    if m:
+        n = int(m.group(1)); start = m.end()
+        base, rest = name[start:start + n], name[start + n:]
+        args = []
+        if rest.startswith("I"):
+            rest = rest[1:]
+            while rest and not rest.startswith("E"):
+                for pat, fn in ((r"DF16b", lambda g: "bf16"), (r"f(?![a-z])", lambda g: "f32"), (r"Li(\d+)E", lambda g: g.group(1)),
+                                (r"Lb([01])E", lambda g: g.group(1))):
+                    mm = re.match(pat, rest)
+                    if mm:
+                        args.append(fn(mm)); rest = rest[mm.end():]
+                        break
+                else:
+                    break
+        return f"rc::{base}<{','.join(args)}>" if args else f"rc::{base}"
+    return name
+
+
 def short(name: str) -> str:
+    name = demangle(name)
     name = re.sub(r"^void\s+", "", name)
     m = re.search(r"conv_mfma_kernel<rc::ConvCfg<([^>]*)>", name)
     if m:
