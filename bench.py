@@ -24,7 +24,7 @@ import torch
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(name, sd, budget_s=20.0):
+def cpu_baseline(name, sd, frame_hw=(2160, 3840), budget_s=20.0):
     """Time the CPU oracle (kind 'port': oracle/liteisp_oracle.py, fp32) on the host's cores on a bounded
     sample of the same workload; returns (dict, (mosaic, cond, coord, ref_out)) for the PSNR leg.
     The thread count is probed (oneDNN collapses when a 256-thread pool is thrown at small convs)."""
@@ -62,12 +62,13 @@ def cpu_baseline(name, sd, budget_s=20.0):
     torch.set_num_threads(threads)
     rate = 256 * 256 / best_t                             # output pixels / s at small size
     # largest 16:9 crop of a 4K frame that fits the budget (big images run somewhat slower per pixel)
-    frac = min(1.0, (rate * budget_s * 0.5) / (2160 * 3840))
+    fh, fw = frame_hw
+    frac = min(1.0, (rate * budget_s * 0.5) / (fh * fw))
     scale = frac ** 0.5
-    h2 = max(256, int(2160 * scale) // 32 * 32)
-    w2 = max(256, int(3840 * scale) // 32 * 32)
+    h2 = max(256, int(fh * scale) // 32 * 32)
+    w2 = max(256, int(fw * scale) // 32 * 32)
     if scale >= 1.0:
-        h2, w2 = 2160, 3840
+        h2, w2 = fh, fw
     mosaic, cond, coord = sample(h2, w2)
     t, out = run(mosaic, cond, coord)
     mp = h2 * w2 / 1e6
@@ -144,16 +145,19 @@ def main():
 
     if rank != 0:
         return
+    cfg_name = ("cfg3" if world == 1 else "cfg4") if (args.model.endswith("GMA") and (H2, W2) == (2160, 3840)) else "custom"
+    if args.model == "LiteISPNet" and args.dtype == "f32" and (H2, W2, B) == (1080, 1920, 1):
+        cfg_name = "cfg2"
     mp_per_step = total_frames * H2 * W2 / 1e6
     value = mp_per_step * args.steps / elapsed
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     peak = PEAK_TFLOPS[args.dtype]
     res = {
-        "metric": "megapixels/sec RAW->sRGB at 4K", "value": round(value, 2), "unit": "MP/s",
+        "metric": "megapixels/sec RAW->sRGB at 4K" if (H2, W2) == (2160, 3840) else f"megapixels/sec RAW->sRGB at {W2}x{H2}", "value": round(value, 2), "unit": "MP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (uniform[0,1) mosaics, seed-0 random-init weights)",
-        "config": {"workload": f"cfg3: {W2}x{H2} Bayer mosaic -> unshuffle+pad16 -> {args.model} -> sRGB {W2}x{H2}, "
+        "config": {"workload": f"{cfg_name}: {W2}x{H2} Bayer mosaic -> unshuffle+pad16 -> {args.model} -> sRGB {W2}x{H2}, "
                                f"{B} frames/GPU, {args.dtype} storage / fp32 accumulate",
                    "frames_per_gpu": B, "global_frames": total_frames, "parallelism": f"frame-shard x{world}"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -162,7 +166,7 @@ def main():
                      "kernel_ms_per_step": round(conv_ms, 3), "flops_per_step": conv_flops},
     }
     if world == 1 and not args.no_cpu_baseline:
-        info, (m_c, c_c, co_c, ref) = cpu_baseline(args.model, sd_cpu)
+        info, (m_c, c_c, co_c, ref) = cpu_baseline(args.model, sd_cpu, (H2, W2))
         with torch.no_grad():
             y = net.forward_mosaic(m_c.to(dev, dt), c_c.to(dev, dt), co_c.to(dev, dt))
         torch.cuda.synchronize()
