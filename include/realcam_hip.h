@@ -127,7 +127,7 @@ int rc_conv_pack_weights(const float* w_oihw_host, int cin, int cout, int ksize,
 int rc_conv_packed_cout(int cin, int cout, int ksize, int dtype, int out_mode);
 int rc_conv_pack_bias(const float* bias_host, int cin, int cout, int ksize, int dtype, int out_mode,
                       float* dst_host);
-/* Number of spatial tiles per image the conv kernel uses for chan_sums (depends only on H,W). */
+/* Number of partial-sum slots per image the conv kernel writes to chan_sums (4 waves per 8x32 tile; depends only on H,W). */
 int rc_conv_sum_tiles(int height, int width);
 int rc_conv2d(const rc_conv_desc* desc, void* stream);
 /* sizeof(rc_conv_desc) as compiled into the library: lets an FFI binding verify its struct mirror. */
@@ -220,9 +220,12 @@ int rc_gma_apply(const void* d_qkvp, const void* d_convv, const void* d_loc, con
  * rc_prof_enable(1) brackets each subsequent rc_conv2d with hipEventRecord on the launch stream;
  * rc_prof_collect() synchronises the events and returns launches / total ms / total algorithmic
  * FLOPs (2*MAC at the padded size) since the last rc_prof_enable(1). */
-/* A/B switches for tests and benches.  "persist": 0 routes every conv through the general kernel
- * instead of the persistent weights-resident variant (results must be identical). */
+/* A/B switches for tests and benches.  "persist": 0 = general kernel only, 1 (default) = + persistent weights-resident
+ * kernel, 2 = + producer/consumer wave-specialised kernel (same speed on MI355X; kept as a measured alternative).  Results must be identical in all modes. */
 int rc_debug_set(const char* key, int value);
+/* "conv_phase_timing": device buffer of >= 512 int64; the producer/consumer conv kernel then records s_memtime
+ * cycle counts per tile phase for one compute wave and one loader wave (NULL switches it off). */
+int rc_debug_set_ptr(const char* key, void* d_ptr);
 int rc_prof_enable(int on);
 int rc_prof_collect(int64_t* n_launches, double* total_ms, double* total_flops);
 

@@ -16,6 +16,7 @@ LIB = PKG / "librealcam_hip.so"
 SOURCES = ["lib.hip", "conv.hip", "conv_inst_bf16_k3.hip", "conv_inst_bf16_k1.hip", "conv_inst_f32_k3.hip",
            "conv_inst_f32_k1.hip", "pointwise.hip", "cond.hip", "gma.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("RC_EXTRA_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DRC_EXPERIMENT_LEAN_ONLY)
 
 
 def _hipcc() -> str:

@@ -62,7 +62,9 @@ static int packed_to_cout(const ConvPlan& p, int cout, int out_mode, int j) {
     return j < cout ? j : -1;
 }
 
-static bool g_persist_on = true;   // rc_debug_set("persist", 0) forces the general kernel (A/B checks)
+static int g_persist_on = 1;       // rc_debug_set("persist", v): 0 general kernel only, 1 + persistent (default), 2 + producer/consumer
+static int g_dbg_flags = 0;
+static long long* g_dbg_ptr = nullptr;   // rc_debug_set_ptr("conv_phase_timing", device buffer of >= 512 int64)
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 struct ProfRec { hipEvent_t e0, e1; double flops; };
@@ -133,12 +135,19 @@ int rc_conv_pack_bias(const float* bias, int cin, int cout, int ksize, int dtype
 
 size_t rc_conv_desc_size(void) { return sizeof(rc_conv_desc); }
 
-int rc_conv_sum_tiles(int height, int width) { return ceil_div(height, kTH) * ceil_div(width, kTW); }
+int rc_conv_sum_tiles(int height, int width) { return 4 * ceil_div(height, kTH) * ceil_div(width, kTW); }  // one slot per wave
 
 int rc_debug_set(const char* key, int value) {
     RC_REQUIRE(key != nullptr, "rc_debug_set: null key");
-    if (std::string(key) == "persist") { g_persist_on = value != 0; return RC_OK; }
+    if (std::string(key) == "persist") { g_persist_on = value < 0 ? 0 : (value > 2 ? 2 : value); return RC_OK; }
+    if (std::string(key) == "conv_flags") { g_dbg_flags = value; return RC_OK; }
     return fail(RC_ERR_INVALID, std::string("rc_debug_set: unknown key ") + key);
+}
+
+int rc_debug_set_ptr(const char* key, void* p) {
+    RC_REQUIRE(key != nullptr, "rc_debug_set_ptr: null key");
+    if (std::string(key) == "conv_phase_timing") { g_dbg_ptr = static_cast<long long*>(p); return RC_OK; }
+    return fail(RC_ERR_INVALID, std::string("rc_debug_set_ptr: unknown key ") + key);
 }
 
 int rc_prof_enable(int on) {
@@ -224,7 +233,9 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
             RC_HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
         }
         a.num_cus = num_cus;
-        a.persist_ok = g_persist_on ? 1 : 0;
+        a.persist_ok = g_persist_on;
+        a.dbg = g_dbg_ptr;
+        a.dbg_flags = g_dbg_flags;
         a.inv_band = 1.0f / (float)(kBandRows * a.tiles_x);
         a.inv_sp_total = 1.0f / (float)(a.tiles_x * a.tiles_y);
     }

@@ -40,6 +40,8 @@ struct ConvArgs {
     float* chan_sums; int cout_packed;
     int num_cus; int persist_ok;
     float inv_band, inv_sp_total;      // reciprocals for the persistent kernel's tile decode
+    long long* dbg;                    // optional phase-timing buffer (rc_debug_set_ptr), normally NULL
+    int dbg_flags;                     // knock-out experiments (rc_debug_set "conv_flags"): 1 no stores, 2 no MFMA, 4 no tile loads
 };
 
 constexpr int kTH = 8, kTW = 32, kThreads = 256;
@@ -90,8 +92,7 @@ struct ConvCfg {
     static constexpr int G = (STEPS + NSUB - 1) / NSUB;  // steps of weights resident in LDS (general kernel)
     static constexpr int W_BYTES = G * NT * 1024;
     static constexpr int COUT_TILE = 16 * NT;
-    static constexpr int RED_BYTES = 4 * COUT_TILE * 4;   // per-wave channel partial sums
-    static constexpr int LDS_BYTES = IN_BYTES + (W_BYTES > RED_BYTES ? W_BYTES : RED_BYTES);
+    static constexpr int LDS_BYTES = IN_BYTES + W_BYTES;
     static constexpr size_t CHUNK_W_BYTES = (size_t)STEPS * NT * 1024;  // packed weights per (ct, chunk)
 };
 
@@ -436,13 +437,32 @@ struct ConvDev {
     // ---- epilogue ---------------------------------------------------------------------------------------
     // lane (q, n) holds, per pixel tile pt, packed couts jbase .. jbase+NV-1 of pixel (row, col0+n).
     // The accumulators already contain the bias (it is the MFMA chain's initial C operand).
-    // red: LDS scratch of 4*16*NT floats not aliased with live data.
+    // stage: this WAVE's private LDS area of STAGE_WAVE_BYTES, or nullptr.  With it, the wave's 64-pixel x 16*NT
+    // channel result is transposed through LDS and written as whole 16-byte-per-lane row segments (1 KiB per
+    // store instruction) instead of 8/16-byte pieces scattered over 64 pixels -- the direct form is
+    // store-issue-bound (measured: the epilogue took as long as the 168-MFMA loop).
+    static constexpr int STAGE_WAVE_BYTES = 64 * Cfg::COUT_TILE * ES;
+    // Two compiled forms.  LEAN covers what the big layers use (NHWC / pixel-shuffle store of full cout tiles,
+    // none/ReLU/LeakyReLU, optional residual / (x+1) multiplier / channel sums) in a few hundred instructions.
+    // The generic form adds FiLM, GELU, ragged cout and the planar NCHW store; it is ~10x the code.  Keeping the
+    // two apart matters: with everything in one body the per-tile epilogue walked a >30 KB instruction footprint
+    // and ran ~4500 cycles on instruction fetch alone (knock-out experiment: no stores, no MFMA, no loads).
+    template <bool STAGED>
     __device__ static __forceinline__ void epilogue(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
-                                                    f32x4 (&acc)[4][NT], float* red) {
+                                                    f32x4 (&acc)[4][NT], char* stage) {
+        const bool lean = a.film_scale == nullptr && a.act != RC_ACT_GELU && a.out_mode != RC_OUT_NCHW && a.cout == a.cout_packed;
+        if (lean) epilogue_impl<true, STAGED>(a, b, y0, x0, sp, ct, tid, acc, stage);
+#ifndef RC_EXPERIMENT_LEAN_ONLY
+        else epilogue_impl<false, false>(a, b, y0, x0, sp, ct, tid, acc, nullptr);
+#endif
+    }
+    template <bool LEAN, bool STAGED>
+    __device__ static __forceinline__ void epilogue_impl(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
+                                                         f32x4 (&acc)[4][NT], char* stage) {
         const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
         const int jbase = ct * Cfg::COUT_TILE + q * NV;
         float fs[NV], ft[NV];
-        const bool film = a.film_scale != nullptr;
+        const bool film = !LEAN && a.film_scale != nullptr;
         if (film) {                               // Res_GFM: (B,cout) vectors, L2-resident
 #pragma unroll
             for (int e = 0; e < NV; ++e) {
@@ -466,7 +486,8 @@ struct ConvDev {
         } else {  // NHWC (H,W,cout) or pixel-shuffled (2H,2W,cout/4): same bytes per image
             r_out = make_rsrc(static_cast<T*>(a.out) + (size_t)b * img_out, img_bytes_out);
         }
-        const bool full = a.cout == a.cout_packed;
+        const bool full = LEAN || a.cout == a.cout_packed;
+        constexpr bool staged = LEAN && STAGED;
 
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
@@ -482,13 +503,19 @@ struct ConvDev {
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] = v[e] * fs[e] + ft[e] + v[e];
             }
+            // bf16 + staged store without post-activation operands: ReLU is applied to the packed bf16 pairs
+            // (signed 16-bit max with 0 == max(x, +0) on bf16 bit patterns), one VALU op per two values
+            constexpr bool PK_RELU = LEAN && STAGED && ES == 2;
+            const bool relu_packed = PK_RELU && a.act == RC_ACT_RELU && a.mul_plus1 == nullptr && a.residual == nullptr && a.chan_sums == nullptr;
             if (a.act == RC_ACT_RELU) {
+                if (!relu_packed) {
 #pragma unroll
-                for (int e = 0; e < NV; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < NV; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
             } else if (a.act == RC_ACT_LEAKY) {
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.act_slope;
-            } else if (a.act == RC_ACT_GELU) {
+            } else if (!LEAN && a.act == RC_ACT_GELU) {
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
             }
@@ -512,10 +539,28 @@ struct ConvDev {
                 for (int e = 0; e < NV; ++e) csum[e] += valid ? v[e] : 0.f;
             }
 
-            if (a.out_mode == RC_OUT_NHWC) {
+            if constexpr (staged) {
+                T* sp_ = reinterpret_cast<T*>(stage + (((pt >> 1) * 32 + (pt & 1) * 16 + n) * Cfg::COUT_TILE + q * NV) * ES);
+                if constexpr (ES == 4) {
+#pragma unroll
+                    for (int e = 0; e < NV; e += 4) *reinterpret_cast<float4*>(sp_ + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < NV; e += 4) {
+                        unsigned p0 = pack_bf16x2(v[e], v[e + 1]), p1 = pack_bf16x2(v[e + 2], v[e + 3]);
+                        if (relu_packed) {
+                            typedef short s16x2 __attribute__((ext_vector_type(2)));
+                            const s16x2 z = {0, 0};
+                            p0 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p0), z));
+                            p1 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p1), z));
+                        }
+                        *reinterpret_cast<uint2*>(sp_ + e) = make_uint2(p0, p1);
+                    }
+                }
+            } else if (a.out_mode == RC_OUT_NHWC) {
                 if (full) {
                     buf_store_row<T, NV>(r_out, pix_off, v);
-                } else {  // ragged cout (test sizes): element stores
+                } else if constexpr (!LEAN) {  // ragged cout (test sizes): element stores
 #pragma unroll
                     for (int e = 0; e < NV; ++e) {
                         const int o = (valid && jbase + e < a.cout) ? pix_off + e * ES : kOOB;
@@ -529,7 +574,7 @@ struct ConvDev {
                 const int cps = a.cout >> 2, sub = ct & 3;
                 const int o = valid ? (((2 * gy + (sub >> 1)) * (2 * a.W) + (2 * gx + (sub & 1))) * cps + (ct >> 2) * Cfg::COUT_TILE + q * NV) * ES : kOOB;
                 buf_store_row<T, NV>(r_out, o, v);
-            } else {  // RC_OUT_NCHW, cropped
+            } else if constexpr (!LEAN) {  // RC_OUT_NCHW, cropped
                 const bool inside = gy < a.out_h && gx < a.out_w;
 #pragma unroll
                 for (int e = 0; e < NV; ++e) {
@@ -543,8 +588,29 @@ struct ConvDev {
             }
         }
 
+        if constexpr (staged) {
+            // the wave wrote its own area and reads it back itself: LDS ops of one wave complete in order
+            __builtin_amdgcn_wave_barrier();
+            constexpr int CPP = Cfg::COUT_TILE * ES / 16;          // 16-byte chunks per pixel inside this cout tile
+            const int cps = a.cout >> 2, sub = ct & 3;
+#pragma unroll
+            for (int i = 0; i < CPP; ++i) {
+                const int chunk = i * 64 + lane;                   // linear over [row 0: 32 px][row 1: 32 px] x CPP
+                const int pixel = chunk / CPP, piece = chunk - pixel * CPP;
+                const int gy = gy_w + (pixel >> 5), gx = x0 + (pixel & 31);
+                int off;
+                if (a.out_mode == RC_OUT_NHWC)
+                    off = ((gy * a.W + gx) * a.cout + ct * Cfg::COUT_TILE) * ES + piece * 16;
+                else
+                    off = (((2 * gy + (sub >> 1)) * (2 * a.W) + (2 * gx + (sub & 1))) * cps + (ct >> 2) * Cfg::COUT_TILE) * ES + piece * 16;
+                const uint4 val = *reinterpret_cast<const uint4*>(stage + chunk * 16);
+                buf_store16(r_out, (gy < a.H && gx < a.W && !(a.dbg_flags & 1)) ? off : kOOB, val);
+            }
+        }
+
         if (a.chan_sums != nullptr) {  // uniform branch
-            // reduce over the 16 pixels of the lane group (lanes sharing q), then over the 4 waves
+            // reduce over the 16 pixels of the lane group (lanes sharing q); every wave writes its own partial
+            // (slot = 4*tile + wave), rc_ca_gate folds them in fixed order -> no block barrier in the epilogue
 #pragma unroll
             for (int e = 0; e < NV; ++e) {
                 float s = csum[e];
@@ -552,15 +618,10 @@ struct ConvDev {
                 csum[e] = s;
             }
             if (n == 0) {
+                float* dst = a.chan_sums + (((size_t)b * (a.tiles_x * a.tiles_y) + sp) * 4 + wave) * a.cout;
 #pragma unroll
-                for (int e = 0; e < NV; ++e) red[wave * Cfg::COUT_TILE + q * NV + e] = csum[e];
-            }
-            __syncthreads();
-            if (tid < Cfg::COUT_TILE) {
-                const float s = ((red[tid] + red[Cfg::COUT_TILE + tid]) + red[2 * Cfg::COUT_TILE + tid]) + red[3 * Cfg::COUT_TILE + tid];
-                const int co = ct * Cfg::COUT_TILE + tid;
-                if (co < a.cout)
-                    a.chan_sums[((size_t)b * (a.tiles_x * a.tiles_y) + sp) * a.cout + co] = s;
+                for (int e = 0; e < NV; ++e)
+                    if (jbase + e < a.cout) dst[jbase + e] = csum[e];
             }
         }
     }
@@ -638,8 +699,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a
         }
         static_assert(NSUB <= 3, "add another weight sub-stage");
     }
-    if (a.chan_sums != nullptr) __syncthreads();  // s_w (reused as reduction scratch) no longer read
-    D::epilogue(a, b, y0, x0, sp, ct, tid, acc, reinterpret_cast<float*>(s_w));
+    if constexpr (4 * D::STAGE_WAVE_BYTES <= Cfg::IN_BYTES) {
+        __syncthreads();                           // every wave is done reading the input tile: reuse it as store staging
+        D::template epilogue<true>(a, b, y0, x0, sp, ct, tid, acc, s_in + wave * D::STAGE_WAVE_BYTES);
+    } else {
+        D::template epilogue<false>(a, b, y0, x0, sp, ct, tid, acc, nullptr);
+    }
 }
 
 // ==================================================================================================
@@ -660,8 +725,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_in = smem;
     char* s_w = smem + Cfg::IN_BYTES;
-    float* s_red = reinterpret_cast<float*>(smem + Cfg::IN_BYTES + Cfg::CHUNK_W_BYTES);
-    float* s_bias = s_red + 4 * Cfg::COUT_TILE;
+    float* s_bias = reinterpret_cast<float*>(smem + Cfg::IN_BYTES + Cfg::CHUNK_W_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, n = lane & 15;
@@ -726,20 +790,161 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
                 for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
             }
             D::template mma_steps<0, STEPS, 0, !GATED>(s_in, s_w, lane_x, lane_w, q, lo, acc);
-            D::epilogue(a, cb, cy0, cx0, csp, ct, tid, acc, s_red);
+            if constexpr (4 * D::STAGE_WAVE_BYTES <= Cfg::IN_BYTES) {
+                if (n_ct == 1) {                       // last use of this input tile: reuse it as store staging
+                    __syncthreads();
+                    D::template epilogue<true>(a, cb, cy0, cx0, csp, ct, tid, acc, s_in + wave * D::STAGE_WAVE_BYTES);
+                } else {
+                    D::template epilogue<false>(a, cb, cy0, cx0, csp, ct, tid, acc, nullptr);
+                }
+            } else {
+                D::template epilogue<false>(a, cb, cy0, cx0, csp, ct, tid, acc, nullptr);
+            }
         }
     }
 }
 
+// ==================================================================================================
+// Kernel 3: producer/consumer ("wave-specialised") persistent form for single-chunk, single-cout-tile
+// layers.  One block of 8 waves per CU: waves 0-3 compute (MFMA loop + epilogue, nothing else), waves 4-7
+// load (halo-tile loads two tiles ahead into registers, CALayer gate + skip combine, skip-tensor store, LDS
+// writes).  The LDS input tile is double-buffered, the packed weights and bias stay resident, and the two
+// roles meet at exactly ONE workgroup barrier per tile:
+//     barrier k:   loaders have written tile k+1 into buf[(k+1)&1];  computers have finished tile k (buf[k&1])
+// so staging VALU work, HBM latency and LDS writes all sit beside the matrix pipe instead of in front of it.
+// Each SIMD hosts one compute wave and one loader wave.
+// ==================================================================================================
+constexpr int kWsThreads = 512;
+
+template <class Cfg, bool GATED>
+__global__ __launch_bounds__(kWsThreads) void conv_mfma_ws_kernel(const ConvArgs a) {
+    using D = ConvDev<Cfg>;
+    constexpr int NT = Cfg::NT, STEPS = Cfg::STEPS, NV = 4 * NT;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_buf0 = smem;
+    char* s_buf1 = smem + Cfg::IN_BYTES;
+    char* s_w = smem + 2 * Cfg::IN_BYTES;
+    float* s_bias = reinterpret_cast<float*>(smem + 2 * Cfg::IN_BYTES + Cfg::CHUNK_W_BYTES);
+    char* s_stage = smem + 2 * Cfg::IN_BYTES + Cfg::CHUNK_W_BYTES + 16 * Cfg::NT * 4;   // 4 x STAGE_WAVE_BYTES
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform
+    const bool loader = wave8 >= 4;
+    const int rtid = tid & 255, wave = wave8 & 3;                    // thread / wave index inside the role
+    const int q = lane >> 4, n = lane & 15;
+
+    const int sp_total = a.tiles_x * a.tiles_y;
+    const int n_tiles = sp_total * a.batch;
+    const int slots = gridDim.x >> 3;                                // gridDim.x is a multiple of 8
+    const int pos = (blockIdx.x & 7) * slots + (blockIdx.x >> 3);
+    const int stride = (int)gridDim.x;
+    const int my_tiles = pos < n_tiles ? (n_tiles - pos + stride - 1) / stride : 0;
+
+    // weights + bias: every wave helps (1 KiB per wave-instruction); drained by the first barrier
+    for (int kb = wave8; kb < STEPS * NT; kb += kWsThreads / 64)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.wpacked) + kb * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(s_w + kb * 1024), 16, 0, 0);
+    for (int i = tid; i < a.cout_packed; i += kWsThreads) s_bias[i] = a.bias ? a.bias[i] : 0.f;
+
+    auto decode = [&](int tile, int& b, int& sp, int& y0, int& x0) {
+        b = fast_div(tile, sp_total, a.inv_sp_total);
+        int ty, tx;
+        band_decode(tile - b * sp_total, a.tiles_x, a.tiles_y, a.inv_band, ty, tx);
+        sp = ty * a.tiles_x + tx; y0 = ty * kTH; x0 = tx * kTW;
+    };
+
+    if (loader) {
+        // ---------------------------------------------------------------- producer waves
+        uint4 r0[D::NI], r1[GATED ? D::NI : 1];
+        float gv[GATED ? D::UNIT : 1];
+        typename D::TileSrc ts;
+        int b, sp, y0, x0;
+        if (my_tiles > 0) {                              // tile 0 -> buf0 (synchronously), then tile 1's loads in flight
+            decode(pos, b, sp, y0, x0);
+            ts = D::tile_src(a, b, y0, x0);
+            D::template load_tile<GATED>(a, ts, b, 0, rtid, r0, r1, gv);
+            D::template commit_tile<GATED>(a, ts, 0, rtid, r0, r1, gv, s_buf0);
+        }
+        if (my_tiles > 1) {
+            decode(pos + stride, b, sp, y0, x0);
+            ts = D::tile_src(a, b, y0, x0);
+            D::template load_tile<GATED>(a, ts, b, 0, rtid, r0, r1, gv);
+        }
+        __syncthreads();                                 // barrier 0: weights, bias, tile 0 visible
+        const bool rec = a.dbg != nullptr && blockIdx.x == 8 && wave8 == 4 && lane == 0;
+        for (int k = 0; k < my_tiles; ++k) {
+            const long long tl0 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            if (k + 1 < my_tiles) {                      // registers hold tile k+1 -> the buffer the computers are NOT reading
+                D::template commit_tile<GATED>(a, ts, 0, rtid, r0, r1, gv, ((k + 1) & 1) ? s_buf1 : s_buf0);
+                if (k + 2 < my_tiles) {                  // ... and immediately put tile k+2's loads in flight
+                    decode(pos + (k + 2) * stride, b, sp, y0, x0);
+                    ts = D::tile_src(a, b, y0, x0);
+                    if (!(a.dbg_flags & 4)) D::template load_tile<GATED>(a, ts, b, 0, rtid, r0, r1, gv);
+                }
+            }
+            const long long tl1 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            __syncthreads();                             // barrier k+1
+            if (rec && k < 64) { a.dbg[256 + 2 * k] = tl1 - tl0; a.dbg[256 + 2 * k + 1] = (long long)__builtin_amdgcn_s_memtime() - tl1; }
+        }
+    } else {
+        // ---------------------------------------------------------------- consumer waves
+        typename D::LaneOff lo;
+        D::lane_offsets(q, lo);
+        const int lane_x = ((2 * wave) * D::TWH + n) * D::SPIX;
+        const int lane_w = lane * 16;
+        __syncthreads();                                 // barrier 0
+        const bool rec = a.dbg != nullptr && blockIdx.x == 8 && wave8 == 0 && lane == 0;
+        for (int k = 0; k < my_tiles; ++k) {
+            const long long tc0 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            int b, sp, y0, x0;
+            decode(pos + k * stride, b, sp, y0, x0);
+            f32x4 acc[4][NT];                            // initial C operand = bias
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 t4 = *reinterpret_cast<const float4*>(s_bias + q * NV + nt * 4);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
+            }
+            if (!(a.dbg_flags & 2)) D::template mma_steps<0, STEPS, 0>((k & 1) ? s_buf1 : s_buf0, s_w, lane_x, lane_w, q, lo, acc);
+            const long long tc1 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            D::template epilogue<true>(a, b, y0, x0, sp, 0, rtid, acc, s_stage + wave * D::STAGE_WAVE_BYTES);
+            const long long tc2 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            __syncthreads();                             // barrier k+1
+            if (rec && k < 64) { a.dbg[4 * k] = tc1 - tc0; a.dbg[4 * k + 1] = tc2 - tc1; a.dbg[4 * k + 2] = (long long)__builtin_amdgcn_s_memtime() - tc2; }
+        }
+    }
+}
+
+template <class Cfg>
+constexpr int ws_lds_bytes() { return 2 * Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + 16 * Cfg::NT * 4 + 4 * 64 * Cfg::COUT_TILE * (int)sizeof(typename Cfg::elem); }
+
 // ---- host side: per-instantiation launcher ----------------------------------------------------------
 template <class Cfg>
-constexpr int persist_lds_bytes() { return Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + Cfg::RED_BYTES + kPersistMaxCout * 4; }
+constexpr int persist_lds_bytes() { return Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + kPersistMaxCout * 4; }
 
 template <class Cfg, bool GATED>
 int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
     constexpr int P_LDS = persist_lds_bytes<Cfg>();
     constexpr bool P_OK = P_LDS <= 80 * 1024;          // two persistent blocks per CU
     const int n_tiles = a.tiles_x * a.tiles_y * a.batch;
+    constexpr int WS_LDS = ws_lds_bytes<Cfg>();
+    if constexpr (WS_LDS <= 150 * 1024) {              // one 8-wave producer/consumer block per CU
+        if (a.n_chunks == 1 && a.n_ct == 1 && a.cin_vec_ok && a.persist_ok == 2 && n_tiles < (1 << 24)) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_ws_kernel<Cfg, GATED>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
+                attr_set = true;
+            }
+            int grid = a.num_cus;
+            if (grid > n_tiles) grid = n_tiles;
+            grid = (grid + 7) / 8 * 8;
+            hipLaunchKernelGGL((conv_mfma_ws_kernel<Cfg, GATED>), dim3((unsigned)grid), dim3(kWsThreads), WS_LDS, stream, a);
+            RC_HIP_CHECK(hipGetLastError());
+            return RC_OK;
+        }
+    }
     if constexpr (P_OK) {
         if (a.n_chunks == 1 && a.cout_packed <= kPersistMaxCout && a.persist_ok && n_tiles < (1 << 24)) {
             static bool attr_set = false;

@@ -154,68 +154,111 @@ __global__ void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, con
 // job = which*4 + g (g = 0..3): in = (g == 0 ? qkv[.., which*C + 0..seg) : dw[.., which, (g-1)*seg ..]);
 //   out qkvp[.., which, g*seg + s] = hardswish(bn_scale[g][s] * (g == 0 ? in[s] : sum_j pw[g-1][s][j] in[j]) + bn_shift[g][s])
 // job = 12: local: in = dwl[.., 0..3seg); t[s] = sum_j pwl[s][j] in[j]; out loc[.., s] = hardswish(LN_seg(t)[s])
-// One job type per block (blockIdx.y = job): no divergence inside a wave; tokens run along blockIdx.x.
-template <typename T, int SEG>   // compile-time segment width: per-thread arrays stay in registers
-__global__ __launch_bounds__(kGThreads) void gma_pointwise_kernel(const T* __restrict__ qkv, const T* __restrict__ dw, const T* __restrict__ dwl,
-                                     T* __restrict__ qkvp, T* __restrict__ loc, size_t tokens, int c,
-                                     const float* __restrict__ pw /*3,seg,seg*/, const float* __restrict__ bn_scale /*4,seg*/,
-                                     const float* __restrict__ bn_shift, const float* __restrict__ pwl /*seg,3seg*/,
-                                     const float* __restrict__ ln_g, const float* __restrict__ ln_b) {
-    constexpr int U = Vec16<T>::N, NV = SEG / U;
+// Block = 13 waves (832 threads): wave j runs job j for a tile of TOK tokens (lane = token), so a wave never
+// diverges.  The tile's input slices (g0 of q,k,v from qkv; dw; dwl = 15 segments per token) are staged into LDS
+// with coalesced 16-byte loads, results (qkvp rows + loc = 13 segments per token) are assembled in LDS and written
+// back coalesced.  LDS rows are padded to an odd number of 16-byte slots -> conflict-free per-lane ds_read_b128.
+// The job's weight matrix is wave-uniform read-only data: indexed straight from global it goes through the scalar
+// cache into SGPRs (an LDS copy would cost one ds_read per FMA).
+constexpr int kPwWaves = 13;
+template <typename T, int SEG, int TOK>
+__global__ __launch_bounds__(kPwWaves * 64) void gma_pointwise_kernel(
+    const T* __restrict__ qkv, const T* __restrict__ dw, const T* __restrict__ dwl, T* __restrict__ qkvp, T* __restrict__ loc,
+    size_t tokens, int c, const float* __restrict__ pw /*3,seg,seg*/, const float* __restrict__ bn_scale /*4,seg*/,
+    const float* __restrict__ bn_shift, const float* __restrict__ pwl /*seg,3seg*/, const float* __restrict__ ln_g,
+    const float* __restrict__ ln_b) {
+    constexpr int U = Vec16<T>::N, NV = SEG / U;           // vectors per segment
     static_assert(SEG % U == 0, "segment must be whole 16-byte vectors");
-    // the job's weight matrix is wave-uniform read-only data: indexed straight from global memory it is fetched
-    // through the scalar cache into SGPRs (an LDS copy would cost one ds_read per FMA)
-    const int job = blockIdx.y;
+    constexpr int IN_V = 15 * NV, OUT_V = 13 * NV;          // vectors per token: staged inputs / outputs
+    constexpr int IN_S = IN_V | 1, OUT_S = OUT_V | 1;       // row strides in 16-byte slots (odd)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    uint4* s_in = reinterpret_cast<uint4*>(lds);            // [TOK][IN_S]
+    uint4* s_out = s_in + TOK * IN_S;                       // [TOK][OUT_S]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int job = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar weight loads
     const int which = job >> 2, g = job & 3;
     const float* __restrict__ sw = job == 12 ? pwl : pw + (g > 0 ? (g - 1) * SEG * SEG : 0);
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < tokens; t += (size_t)gridDim.x * blockDim.x) {
-        float out[SEG];
-        if (job < 12) {
-            float in[SEG];
-            const T* src = g == 0 ? qkv + t * 3 * c + (size_t)which * c : dw + (t * 3 + which) * 3 * SEG + (g - 1) * SEG;
+    const size_t n_tiles = (tokens + TOK - 1) / TOK;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t t0 = tile * TOK;
+        const int nt = (int)((tokens - t0) < (size_t)TOK ? (tokens - t0) : (size_t)TOK);
+        // ---- stage in: slot layout per token = [q.g0 | k.g0 | v.g0 | dw (9 seg) | dwl (3 seg)] -----------------
+        for (int i = tid; i < TOK * IN_V; i += kPwWaves * 64) {
+            const int t = i / IN_V, v = i - t * IN_V;
+            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+            if (t < nt) {
+                const size_t tok = t0 + t;
+                const int sg = v / NV, vv = v - sg * NV;     // segment index 0..14
+                const T* src = sg < 3 ? qkv + tok * 3 * c + (size_t)sg * c + vv * U
+                             : sg < 12 ? dw + tok * 9 * SEG + (sg - 3) * SEG + vv * U
+                                       : dwl + tok * 3 * SEG + (sg - 12) * SEG + vv * U;
+                raw = *reinterpret_cast<const uint4*>(src);
+            }
+            s_in[t * IN_S + v] = raw;
+        }
+        __syncthreads();
+        // ---- compute: wave = job, lane = token ------------------------------------------------------------------
+        if (lane < TOK) {
+            float out[SEG];
+            const uint4* row = s_in + lane * IN_S;
+            if (job < 12) {
+                float in[SEG];
+                const int sg = g == 0 ? which : 3 + which * 3 + (g - 1);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) Vec16<T>::unpack(reinterpret_cast<const uint4*>(src)[v], in + v * U);
-            if (g == 0) {
+                for (int v = 0; v < NV; ++v) Vec16<T>::unpack(row[sg * NV + v], in + v * U);
+                if (g == 0) {
 #pragma unroll
-                for (int s = 0; s < SEG; ++s) out[s] = in[s];
+                    for (int s2 = 0; s2 < SEG; ++s2) out[s2] = in[s2];
+                } else {
+#pragma unroll
+                    for (int s2 = 0; s2 < SEG; ++s2) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int j = 0; j < SEG; ++j) a += sw[s2 * SEG + j] * in[j];
+                        out[s2] = a;
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < SEG; ++s2) out[s2] = hardswish(out[s2] * bn_scale[g * SEG + s2] + bn_shift[g * SEG + s2]);
+                uint4* dst = s_out + lane * OUT_S + (which * 4 + g) * NV;      // qkvp row: [which][g][seg]
+#pragma unroll
+                for (int v = 0; v < NV; ++v) dst[v] = Vec16<T>::pack(out + v * U);
             } else {
+                float lin[3 * SEG];
 #pragma unroll
-                for (int s = 0; s < SEG; ++s) {
+                for (int v = 0; v < 3 * NV; ++v) Vec16<T>::unpack(row[12 * NV + v], lin + v * U);
+                float mean = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < SEG; ++s2) {
                     float a = 0.f;
 #pragma unroll
-                    for (int j = 0; j < SEG; ++j) a += sw[s * SEG + j] * in[j];
-                    out[s] = a;
+                    for (int j = 0; j < 3 * SEG; ++j) a += sw[s2 * 3 * SEG + j] * lin[j];
+                    out[s2] = a; mean += a;
                 }
+                mean /= (float)SEG;
+                float var = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < SEG; ++s2) { const float d = out[s2] - mean; var += d * d; }
+                const float rstd = 1.f / sqrtf(var / (float)SEG + 1e-5f);
+#pragma unroll
+                for (int s2 = 0; s2 < SEG; ++s2) out[s2] = hardswish((out[s2] - mean) * rstd * ln_g[s2] + ln_b[s2]);
+                uint4* dst = s_out + lane * OUT_S + 12 * NV;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) dst[v] = Vec16<T>::pack(out + v * U);
             }
-#pragma unroll
-            for (int s = 0; s < SEG; ++s) out[s] = hardswish(out[s] * bn_scale[g * SEG + s] + bn_shift[g * SEG + s]);
-            T* dst = qkvp + (t * 3 + which) * 4 * SEG + g * SEG;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) reinterpret_cast<uint4*>(dst)[v] = Vec16<T>::pack(out + v * U);
-        } else {
-            float lin[3 * SEG];
-            const T* src = dwl + t * 3 * SEG;
-#pragma unroll
-            for (int v = 0; v < 3 * NV; ++v) Vec16<T>::unpack(reinterpret_cast<const uint4*>(src)[v], lin + v * U);
-            float mean = 0.f;
-#pragma unroll
-            for (int s = 0; s < SEG; ++s) {
-                float a = 0.f;
-#pragma unroll
-                for (int j = 0; j < 3 * SEG; ++j) a += sw[s * 3 * SEG + j] * lin[j];
-                out[s] = a; mean += a;
-            }
-            mean /= (float)SEG;
-            float var = 0.f;
-#pragma unroll
-            for (int s = 0; s < SEG; ++s) { const float d = out[s] - mean; var += d * d; }
-            const float rstd = 1.f / sqrtf(var / (float)SEG + 1e-5f);
-#pragma unroll
-            for (int s = 0; s < SEG; ++s) out[s] = hardswish((out[s] - mean) * rstd * ln_g[s] + ln_b[s]);
-            T* dst = loc + t * SEG;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) reinterpret_cast<uint4*>(dst)[v] = Vec16<T>::pack(out + v * U);
         }
+        __syncthreads();
+        // ---- stage out: qkvp rows are 12 segments contiguous per token, loc 1 segment ---------------------------
+        for (int i = tid; i < TOK * OUT_V; i += kPwWaves * 64) {
+            const int t = i / OUT_V, v = i - t * OUT_V;
+            if (t < nt) {
+                const size_t tok = t0 + t;
+                T* dst = v < 12 * NV ? qkvp + tok * 12 * SEG + v * U : loc + tok * SEG + (v - 12 * NV) * U;
+                *reinterpret_cast<uint4*>(dst) = s_out[t * OUT_S + v];
+            }
+        }
+        // no barrier needed here: the next iteration's stage-in only writes s_in, which every wave finished reading
+        // before the barrier above; s_out is rewritten only after the next iteration's first barrier.
     }
 }
 
@@ -463,19 +506,33 @@ int rc_gma_pointwise(const void* d_qkv, const void* d_dw, const void* d_dwl, voi
     RC_REQUIRE(tokens >= 1 && c >= 10 && c % 5 == 0, "rc_gma_pointwise: C must be a multiple of 5");
     const int seg = c / 5;
     RC_REQUIRE(seg == 16 || seg == 40 || seg == 8 || seg == 24 || seg == 32, "rc_gma_pointwise: C/5 must be one of 8, 16, 24, 32, 40 (dims 40..200)");
-    const size_t lds = 0;
-    size_t gx = ((size_t)tokens + kGThreads - 1) / kGThreads;
-    if (gx > 2048) gx = 2048;
-#define RC_PW_LAUNCH(TT, SG)                                                                                            \
-    hipLaunchKernelGGL((gma_pointwise_kernel<TT, SG>), dim3((unsigned)gx, 13), dim3(kGThreads), lds, as_stream(stream), \
-                       static_cast<const TT*>(d_qkv), static_cast<const TT*>(d_dw), static_cast<const TT*>(d_dwl),      \
-                       static_cast<TT*>(d_qkvp), static_cast<TT*>(d_loc), (size_t)tokens, c, d_pw, d_bn_scale,          \
-                       d_bn_shift, d_pwl, d_ln_g, d_ln_b)
+    const int U = dtype == RC_F32 ? 4 : 8;
+    const int nv = seg / U;
+    const int tok = ((15 * nv | 1) + (13 * nv | 1)) * 16 * 64 <= 150 * 1024 ? 64 : 32;   // tokens per tile that fit LDS
+    const size_t lds = (size_t)((15 * nv | 1) + (13 * nv | 1)) * 16 * tok;
+    RC_REQUIRE(lds <= 160 * 1024, "rc_gma_pointwise: tile does not fit LDS");
+    size_t n_tiles = ((size_t)tokens + tok - 1) / tok;
+    const unsigned gx = (unsigned)(n_tiles < 1024 ? n_tiles : 1024);
+#define RC_PW_LAUNCH(TT, SG, TK)                                                                                        \
+    do {                                                                                                                \
+        static bool attr = false;                                                                                       \
+        if (!attr) {                                                                                                    \
+            RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gma_pointwise_kernel<TT, SG, TK>),          \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                  \
+            attr = true;                                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL((gma_pointwise_kernel<TT, SG, TK>), dim3(gx), dim3(kPwWaves * 64), lds, as_stream(stream),   \
+                           static_cast<const TT*>(d_qkv), static_cast<const TT*>(d_dw), static_cast<const TT*>(d_dwl),  \
+                           static_cast<TT*>(d_qkvp), static_cast<TT*>(d_loc), (size_t)tokens, c, d_pw, d_bn_scale,      \
+                           d_bn_shift, d_pwl, d_ln_g, d_ln_b);                                                          \
+    } while (0)
+#define RC_PW_TOK(TT, SG) do { if (tok == 64) RC_PW_LAUNCH(TT, SG, 64); else RC_PW_LAUNCH(TT, SG, 32); } while (0)
 #define RC_PW_SEG(TT)                                                                                                   \
-    switch (seg) { case 8: RC_PW_LAUNCH(TT, 8); break; case 16: RC_PW_LAUNCH(TT, 16); break; case 24: RC_PW_LAUNCH(TT, 24); break; \
-                   case 32: RC_PW_LAUNCH(TT, 32); break; default: RC_PW_LAUNCH(TT, 40); break; }
-    if (dtype == RC_F32) { RC_PW_SEG(float) } else { RC_PW_SEG(bf16_t) }
+    switch (seg) { case 8: RC_PW_TOK(TT, 8); break; case 16: RC_PW_TOK(TT, 16); break; case 24: RC_PW_TOK(TT, 24); break; \
+                   case 32: RC_PW_TOK(TT, 32); break; default: RC_PW_TOK(TT, 40); break; }
+    if (dtype == RC_F32) { RC_PW_SEG(float); } else { RC_PW_SEG(bf16_t); }
 #undef RC_PW_SEG
+#undef RC_PW_TOK
 #undef RC_PW_LAUNCH
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;

@@ -35,7 +35,7 @@ def test_bad_arguments_are_reported_not_fixed():
     assert lib.rc_bayer_unshuffle(None, RC_F32, None, RC_F32, 1, 4, 4, 4, 4, None) < 0
     assert b"null" in lib.rc_last_error()
     assert lib.rc_dwt_forward(1, 1, 1, 1, RC_F32, 1, 5, 4, 8, None) < 0              # odd height
-    assert lib.rc_conv_sum_tiles(1088, 1920) == 136 * 60
+    assert lib.rc_conv_sum_tiles(1088, 1920) == 4 * 136 * 60
 
 
 def _plan(cin, cout, dtype):
