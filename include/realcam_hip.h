@@ -220,8 +220,9 @@ int rc_gma_apply(const void* d_qkvp, const void* d_convv, const void* d_loc, con
  * rc_prof_enable(1) brackets each subsequent rc_conv2d with hipEventRecord on the launch stream;
  * rc_prof_collect() synchronises the events and returns launches / total ms / total algorithmic
  * FLOPs (2*MAC at the padded size) since the last rc_prof_enable(1). */
-/* A/B switches for tests and benches.  "persist": 0 = general kernel only, 1 (default) = + persistent weights-resident
- * kernel, 2 = + producer/consumer wave-specialised kernel (same speed on MI355X; kept as a measured alternative).  Results must be identical in all modes. */
+/* A/B switches for tests and benches.  "persist": 0 = general kernel only, 1 (default) = automatic choice between the
+ * persistent weights-resident kernel and its producer/consumer (wave-specialised) form, 2 = producer/consumer
+ * wherever eligible, 3 = persistent only.  Results must be identical in all modes. */
 int rc_debug_set(const char* key, int value);
 /* "conv_phase_timing": device buffer of >= 512 int64; the producer/consumer conv kernel then records s_memtime
  * cycle counts per tile phase for one compute wave and one loader wave (NULL switches it off). */

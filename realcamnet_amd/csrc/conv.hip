@@ -62,7 +62,7 @@ static int packed_to_cout(const ConvPlan& p, int cout, int out_mode, int j) {
     return j < cout ? j : -1;
 }
 
-static int g_persist_on = 1;       // rc_debug_set("persist", v): 0 general kernel only, 1 + persistent (default), 2 + producer/consumer
+static int g_persist_on = 1;       // rc_debug_set("persist", v): 0 general kernel only, 1 automatic (default), 2 producer/consumer wherever eligible, 3 persistent only
 static int g_dbg_flags = 0;
 static long long* g_dbg_ptr = nullptr;   // rc_debug_set_ptr("conv_phase_timing", device buffer of >= 512 int64)
 static std::mutex g_prof_mu;
@@ -139,7 +139,7 @@ int rc_conv_sum_tiles(int height, int width) { return 4 * ceil_div(height, kTH) 
 
 int rc_debug_set(const char* key, int value) {
     RC_REQUIRE(key != nullptr, "rc_debug_set: null key");
-    if (std::string(key) == "persist") { g_persist_on = value < 0 ? 0 : (value > 2 ? 2 : value); return RC_OK; }
+    if (std::string(key) == "persist") { g_persist_on = value < 0 ? 0 : (value > 3 ? 3 : value); return RC_OK; }
     if (std::string(key) == "conv_flags") { g_dbg_flags = value; return RC_OK; }
     return fail(RC_ERR_INVALID, std::string("rc_debug_set: unknown key ") + key);
 }

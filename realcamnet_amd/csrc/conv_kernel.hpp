@@ -699,12 +699,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a
         }
         static_assert(NSUB <= 3, "add another weight sub-stage");
     }
-    if constexpr (4 * D::STAGE_WAVE_BYTES <= Cfg::IN_BYTES) {
-        __syncthreads();                           // every wave is done reading the input tile: reuse it as store staging
-        D::template epilogue<true>(a, b, y0, x0, sp, ct, tid, acc, s_in + wave * D::STAGE_WAVE_BYTES);
-    } else {
-        D::template epilogue<false>(a, b, y0, x0, sp, ct, tid, acc, nullptr);
-    }
+    D::template epilogue<false>(a, b, y0, x0, sp, ct, tid, acc, nullptr);
 }
 
 // ==================================================================================================
@@ -789,17 +784,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
             }
-            D::template mma_steps<0, STEPS, 0, !GATED>(s_in, s_w, lane_x, lane_w, q, lo, acc);
-            if constexpr (4 * D::STAGE_WAVE_BYTES <= Cfg::IN_BYTES) {
-                if (n_ct == 1) {                       // last use of this input tile: reuse it as store staging
-                    __syncthreads();
-                    D::template epilogue<true>(a, cb, cy0, cx0, csp, ct, tid, acc, s_in + wave * D::STAGE_WAVE_BYTES);
-                } else {
-                    D::template epilogue<false>(a, cb, cy0, cx0, csp, ct, tid, acc, nullptr);
-                }
-            } else {
-                D::template epilogue<false>(a, cb, cy0, cx0, csp, ct, tid, acc, nullptr);
-            }
+            D::template mma_steps<0, STEPS, 0, (!GATED && NT < 5)>(s_in, s_w, lane_x, lane_w, q, lo, acc);
+            D::template epilogue<false>(a, cb, cy0, cx0, csp, ct, tid, acc, nullptr);
         }
     }
 }
@@ -906,7 +892,7 @@ __global__ __launch_bounds__(kWsThreads) void conv_mfma_ws_kernel(const ConvArgs
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
             }
-            if (!(a.dbg_flags & 2)) D::template mma_steps<0, STEPS, 0>((k & 1) ? s_buf1 : s_buf0, s_w, lane_x, lane_w, q, lo, acc);
+            if (!(a.dbg_flags & 2)) D::template mma_steps<0, STEPS, 0, (NT < 5)>((k & 1) ? s_buf1 : s_buf0, s_w, lane_x, lane_w, q, lo, acc);
             const long long tc1 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
             D::template epilogue<true>(a, b, y0, x0, sp, 0, rtid, acc, s_stage + wave * D::STAGE_WAVE_BYTES);
             const long long tc2 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -930,7 +916,10 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
     const int n_tiles = a.tiles_x * a.tiles_y * a.batch;
     constexpr int WS_LDS = ws_lds_bytes<Cfg>();
     if constexpr (WS_LDS <= 150 * 1024) {              // one 8-wave producer/consumer block per CU
-        if (a.n_chunks == 1 && a.n_ct == 1 && a.cin_vec_ok && a.persist_ok == 2 && n_tiles < (1 << 24)) {
+        // persist_ok: 1 = automatic (producer/consumer form for the register-starved variants: gated input or 80-wide
+        // cout tiles, whose prefetch registers would otherwise spill), 2 = wherever eligible, 3 = never
+        const bool ws_auto = GATED || Cfg::NT == 5 || Cfg::CK == 80;
+        if (a.n_chunks == 1 && a.n_ct == 1 && a.cin_vec_ok && (a.persist_ok == 2 || (a.persist_ok == 1 && ws_auto)) && n_tiles < (1 << 24)) {
             static bool attr_set = false;
             if (!attr_set) {
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_ws_kernel<Cfg, GATED>),

@@ -248,7 +248,7 @@ def test_persistent_kernel_equals_general_kernel(hip):
             skip = torch.randn(3, hw[0], hw[1], cin, generator=g).to(DEV, dt)
             gate = torch.rand(3, cin, generator=g).to(DEV)
             outs = []
-            for persist in (2, 1, 0):
+            for persist in (1, 2, 3, 0):
                 assert hip.rc_debug_set(b"persist", persist) == 0
                 if cout == 3:
                     r = (ops.conv2d(x, c, out_mode=ops.RC_OUT_NCHW, crop_hw=(hw[0] - 3, hw[1] - 5)),)
@@ -281,7 +281,7 @@ def test_dwt_with_arbitrary_per_channel_taps(hip, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("persist", [2, 1, 0])
+@pytest.mark.parametrize("persist", [1, 2, 3, 0])
 @pytest.mark.parametrize("shape", [(48, 48, 16, 40, 3), (48, 48, 9, 33, 3), (48, 3, 8, 32, 3), (4, 48, 24, 70, 3),
                                    (64, 64, 8, 40, 3), (96, 48, 8, 32, 3), (48, 48, 8, 32, 1), (2, 48, 10, 34, 1)])
 def test_conv_exact_on_small_integer_data(hip, dt, persist, shape):
