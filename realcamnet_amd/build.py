@@ -13,10 +13,9 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 OBJ = PKG / "_build"
 LIB = PKG / "librealcam_hip.so"
-SOURCES = ["lib.hip", "conv.hip", "conv_inst_bf16_k3.hip", "conv_inst_bf16_k1.hip", "conv_inst_f32_k3.hip",
-           "conv_inst_f32_k1.hip", "pointwise.hip", "cond.hip", "gma.hip"]
+SOURCES = ["lib.hip", "conv.hip", "conv_dispatch.hip", "pointwise.hip", "cond.hip", "gma.hip"] + sorted(p.name for p in CSRC.glob("conv_inst_*.hip"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
-FLAGS += os.environ.get("RC_EXTRA_HIPCC_FLAGS", "").split()   # experiments only (e.g. -DRC_EXPERIMENT_LEAN_ONLY)
+FLAGS += os.environ.get("RC_EXTRA_HIPCC_FLAGS", "").split()   # experiments only
 
 
 def _hipcc() -> str:
@@ -54,7 +53,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
             sys.stderr.write(r.stderr)
         return obj
 
-    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(os.cpu_count() or 8, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
     r = subprocess.run(cmd, capture_output=True, text=True)

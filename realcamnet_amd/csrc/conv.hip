@@ -218,6 +218,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     auto aligned16 = [](const void* q) { return q == nullptr || reinterpret_cast<uintptr_t>(q) % 16 == 0; };
     a.cin_vec_ok = (d->cin % p.unit == 0) && aligned16(d->in0) && aligned16(d->in1) && aligned16(d->in_store) &&
                    (d->in_gate == nullptr || reinterpret_cast<uintptr_t>(d->in_gate) % 4 == 0);
+    a.cin_chunk_ok = d->cin % p.ck == 0;
     a.in0 = d->in0; a.in1 = d->in1; a.in_gate = d->in_gate; a.in_store = d->in_store;
     a.wpacked = d->wpacked; a.bias = d->bias;
     a.film_scale = d->film_scale; a.film_shift = d->film_shift;
@@ -225,6 +226,16 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     a.mul_plus1 = d->mul_plus1; a.residual = d->residual;
     a.out = d->out; a.out_mode = d->out_mode; a.out_dtype = d->out_dtype; a.out_h = d->out_h; a.out_w = d->out_w;
     a.chan_sums = d->chan_sums; a.cout_packed = p.cout_packed;
+    {   // epilogue feature mask (ConvDev::EP_*); anything outside the compiled set takes the generic epilogue
+        int key = (d->act == RC_ACT_RELU ? 1 : 0) | (d->act == RC_ACT_LEAKY ? 2 : 0) | (d->film_scale ? 4 : 0) |
+                  (d->mul_plus1 ? 8 : 0) | (d->residual ? 16 : 0) | (d->chan_sums ? 32 : 0);
+        bool fast = full_tiles && d->out_mode != RC_OUT_NCHW && d->act != RC_ACT_GELU;
+        if (d->act == RC_ACT_LEAKY) fast = fast && d->act_slope >= 0.f && d->act_slope <= 1.f;
+        if (d->film_scale)
+            fast = fast && d->cout % 4 == 0 && reinterpret_cast<uintptr_t>(d->film_scale) % 16 == 0 && reinterpret_cast<uintptr_t>(d->film_shift) % 16 == 0;
+        switch (key) { case 0: case 1: case 2: case 16: case 32: case 8: case 6: break; default: fast = false; }
+        a.ep_key = fast ? key : -1;
+    }
     {
         static int num_cus = 0;
         if (num_cus == 0) {
@@ -251,10 +262,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
         RC_HIP_CHECK(hipEventRecord(rec.e0, stream));
     }
     int rcode;
-    if (d->dtype == RC_BF16)
-        rcode = d->ksize == 3 ? dispatch_conv_bf16_k3(p.ck, p.nt, a, stream) : dispatch_conv_bf16_k1(p.ck, p.nt, a, stream);
-    else
-        rcode = d->ksize == 3 ? dispatch_conv_f32_k3(p.ck, p.nt, a, stream) : dispatch_conv_f32_k1(p.ck, p.nt, a, stream);
+    rcode = dispatch_conv(d->dtype == RC_BF16, d->ksize, p.ck, p.nt, a, stream);
     if (prof) {
         RC_HIP_CHECK(hipEventRecord(rec.e1, stream));
         std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -31,6 +31,7 @@ struct ConvArgs {
     int batch, H, W, cin, cout;
     int n_chunks, n_ct, tiles_x, tiles_y;
     int cin_vec_ok;  // cin % UNIT == 0 and base pointers 16-B aligned -> vector staging
+    int cin_chunk_ok;  // cin is a whole number of CK-channel chunks (no ragged last chunk)
     const void* in0; const void* in1; const float* in_gate; void* in_store;
     const void* wpacked; const float* bias;
     const float* film_scale; const float* film_shift;
@@ -39,6 +40,7 @@ struct ConvArgs {
     void* out; int out_mode; int out_dtype; int out_h, out_w;
     float* chan_sums; int cout_packed;
     int num_cus; int persist_ok;
+    int ep_key;                        // epilogue_fast feature mask, or -1 for the generic epilogue (ep_key_for)
     float inv_band, inv_sp_total;      // reciprocals for the persistent kernel's tile decode
     long long* dbg;                    // optional phase-timing buffer (rc_debug_set_ptr), normally NULL
     int dbg_flags;                     // knock-out experiments (rc_debug_set "conv_flags"): 1 no stores, 2 no MFMA, 4 no tile loads
@@ -106,12 +108,12 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
-__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, int voff, const uint4& v) {
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, r, voff, 0, 0);
+__device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t r, int voff, int soff, const uint4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, r, voff, soff, 0);
 }
 
 // ---- MFMA wrappers -------------------------------------------------------------------------------
@@ -135,23 +137,34 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 }
 
 // Store / load NV consecutive elements of type TT at byte offset voff of a buffer (OOB -> dropped / 0).
-template <typename TT, int NV>
+// bf16: values are converted in pairs (v_cvt_pk_bf16_f32) and written with the widest pieces that fit
+// (24 bytes = 16 + 8).  PK_RELU applies max(x, 0) to the packed pairs: signed 16-bit max with 0 equals
+// max(x, +0) on bf16 bit patterns, one VALU op per two values.
+template <typename TT, int NV, bool PK_RELU>
 __device__ __forceinline__ void buf_store_row(__amdgpu_buffer_rsrc_t r, int voff, const float* v) {
     if constexpr (sizeof(TT) == 4) {
+        static_assert(!PK_RELU, "packed ReLU is a bf16 form");
 #pragma unroll
         for (int i = 0; i < NV; i += 4)
             __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v[i]), __float_as_uint(v[i + 1]), __float_as_uint(v[i + 2]), __float_as_uint(v[i + 3])},
                                                    r, voff + 4 * i, 0, 0);
-    } else if constexpr ((NV * 2) % 16 == 0) {
+    } else {
+        unsigned w[NV / 2];
 #pragma unroll
-        for (int i = 0; i < NV; i += 8)
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{pack_bf16x2(v[i], v[i + 1]), pack_bf16x2(v[i + 2], v[i + 3]),
-                                                           pack_bf16x2(v[i + 4], v[i + 5]), pack_bf16x2(v[i + 6], v[i + 7])},
-                                                   r, voff + 2 * i, 0, 0);
-    } else {  // 8-byte pieces (bf16 with NT = 3 or 1: 24 / 8 bytes per lane)
+        for (int i = 0; i < NV / 2; ++i) {
+            w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+            if constexpr (PK_RELU) {
+                typedef short s16x2 __attribute__((ext_vector_type(2)));
+                const s16x2 z = {0, 0};
+                w[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w[i]), z));
+            }
+        }
+        constexpr int NQ = NV / 8;               // whole 16-byte pieces
 #pragma unroll
-        for (int i = 0; i < NV; i += 4)
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{pack_bf16x2(v[i], v[i + 1]), pack_bf16x2(v[i + 2], v[i + 3])}, r, voff + 2 * i, 0, 0);
+        for (int i = 0; i < NQ; ++i)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]}, r, voff + 16 * i, 0, 0);
+        if constexpr (NV % 8 != 0)
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{w[4 * NQ], w[4 * NQ + 1]}, r, voff + 16 * NQ, 0, 0);
     }
 }
 
@@ -193,7 +206,7 @@ __device__ __forceinline__ void band_decode(int idx, int tiles_x, int tiles_y, f
     const int rem = idx - band * band_size;
     const int rows_left = tiles_y - band * kBandRows;
     const int rows = rows_left < kBandRows ? rows_left : kBandRows;
-    const int col = fast_div(rem, rows, 1.0f / (float)rows);
+    const int col = rows == kBandRows ? rem >> 3 : fast_div(rem, rows, __builtin_amdgcn_rcpf((float)rows));
     ty = band * kBandRows + (rem - col * rows);
     tx = col;
 }
@@ -269,6 +282,8 @@ struct ConvDev {
     struct TileSrc {
         __amdgpu_buffer_rsrc_t r0, r1, rst;   // in0 / in1 (skip) / in_store, one image each
         int gy0, gx0;                         // global coords of halo pixel (0,0)
+        int soff;                             // byte offset of halo pixel (0,0), channel 0 (interior tiles)
+        bool interior;                        // whole halo tile inside the image and Cin a multiple of CK (uniform)
     };
     __device__ static __forceinline__ TileSrc tile_src(const ConvArgs& a, int b, int y0, int x0) {
         const size_t img = (size_t)a.H * a.W * a.cin;
@@ -278,7 +293,26 @@ struct ConvDev {
         t.r1 = make_rsrc(a.in1 ? static_cast<const T*>(a.in1) + (size_t)b * img : nullptr, a.in1 ? bytes : 0u);
         t.rst = make_rsrc(a.in_store ? static_cast<T*>(a.in_store) + (size_t)b * img : nullptr, a.in_store ? bytes : 0u);
         t.gy0 = y0 - HALO; t.gx0 = x0 - HALO;
+        t.soff = (t.gy0 * a.W + t.gx0) * a.cin * ES;
+        t.interior = t.gy0 >= 0 && t.gx0 >= 0 && t.gy0 + THH <= a.H && t.gx0 + TWH <= a.W && a.cin_chunk_ok;
         return t;
+    }
+    // Per-thread, per-launch constants: byte offset of (halo pixel k of this thread, its channel group) relative
+    // to halo pixel (0,0), or kOOB for slots past the tile.  For interior tiles (95 % at 4K) a load address is
+    // this constant + a scalar tile offset carried in the buffer instruction's soffset: no per-tile VALU at all.
+    // ctr has the same offsets for the tile's centre pixels only (the ones a gated conv materialises).
+    struct TileOffs { int o[NI]; int ctr[NI]; };
+    __device__ static __forceinline__ void tile_offsets(const ConvArgs& a, int tid, TileOffs& t) {
+        const int v = tid % VPP, p0 = tid / VPP;
+        const bool live = tid < ACTIVE;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int pix = p0 + k * PPP;
+            const int py = pix / TWH, px = pix - py * TWH;
+            const bool center = py >= HALO && py < HALO + kTH && px >= HALO && px < HALO + kTW;
+            t.o[k] = (live && pix < NPIX) ? ((py * a.W + px) * a.cin + v * UNIT) * ES : kOOB;
+            t.ctr[k] = center ? t.o[k] : kOOB;
+        }
     }
     // byte offset of (halo pixel pix, channel group v) inside the image, or kOOB (-> zero fill / dropped)
     __device__ static __forceinline__ int vec_off(const ConvArgs& a, const TileSrc& t, int chunk, int pix, int v,
@@ -293,28 +327,48 @@ struct ConvDev {
 
     // Issue every global load of one halo tile back-to-back into registers (vector path only).
     template <bool GATED>
-    __device__ static __forceinline__ void load_tile(const ConvArgs& a, const TileSrc& t, int b, int chunk, int tid,
+    __device__ static __forceinline__ void load_tile(const ConvArgs& a, const TileSrc& t, const TileOffs& to, int b, int chunk, int tid,
                                                      uint4 (&r0)[NI], uint4 (&r1)[GATED ? NI : 1],
                                                      float (&gv)[GATED ? UNIT : 1]) {
+        load_gate<GATED>(a, b, chunk, tid, gv);
+        if (t.interior) load_tile_interior<GATED>(t, to, chunk, r0, r1);
+        else load_tile_border<GATED>(a, t, chunk, tid, r0, r1);
+    }
+    template <bool GATED>
+    __device__ static __forceinline__ void load_gate(const ConvArgs& a, int b, int chunk, int tid, float (&gv)[GATED ? UNIT : 1]) {
+        if constexpr (GATED) {
+            const int c0 = chunk * CK + (tid % VPP) * UNIT;
+#pragma unroll
+            for (int e = 0; e < UNIT; ++e) gv[e] = (tid < ACTIVE && c0 + e < a.cin) ? a.in_gate[(size_t)b * a.cin + c0 + e] : 0.f;
+        }
+    }
+    template <bool GATED>
+    __device__ static __forceinline__ void load_tile_interior(const TileSrc& t, const TileOffs& to, int chunk,
+                                                              uint4 (&r0)[NI], uint4 (&r1)[GATED ? NI : 1]) {
+        const int soff = t.soff + chunk * CK * ES;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            r0[k] = buf_load16(t.r0, to.o[k], soff);
+            if constexpr (GATED) r1[k] = buf_load16(t.r1, to.o[k], soff);
+        }
+    }
+    template <bool GATED>
+    __device__ static __forceinline__ void load_tile_border(const ConvArgs& a, const TileSrc& t, int chunk, int tid,
+                                                            uint4 (&r0)[NI], uint4 (&r1)[GATED ? NI : 1]) {
         const int v = tid % VPP, p0 = tid / VPP;
         const bool live = tid < ACTIVE;
-        if constexpr (GATED) {
-            const int c0 = chunk * CK + v * UNIT;
-#pragma unroll
-            for (int e = 0; e < UNIT; ++e) gv[e] = (live && c0 + e < a.cin) ? a.in_gate[(size_t)b * a.cin + c0 + e] : 0.f;
-        }
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             bool center;
             const int off = vec_off(a, t, chunk, p0 + k * PPP, v, live, center);
-            r0[k] = buf_load16(t.r0, off);
-            if constexpr (GATED) r1[k] = buf_load16(t.r1, off);
+            r0[k] = buf_load16(t.r0, off, 0);
+            if constexpr (GATED) r1[k] = buf_load16(t.r1, off, 0);
         }
     }
 
     // Combine (CALayer gate + skip), optionally materialise, and write the tile to LDS.
     template <bool GATED>
-    __device__ static __forceinline__ void commit_tile(const ConvArgs& a, const TileSrc& t, int chunk, int tid,
+    __device__ static __forceinline__ void commit_tile(const ConvArgs& a, const TileSrc& t, const TileOffs& to, int chunk, int tid,
                                                        const uint4 (&r0)[NI], const uint4 (&r1)[GATED ? NI : 1],
                                                        const float (&gv)[GATED ? UNIT : 1], char* s_in) {
         const int v = tid % VPP, p0 = tid / VPP;
@@ -331,9 +385,13 @@ struct ConvDev {
 #pragma unroll
                 for (int e = 0; e < UNIT; ++e) f0[e] = f0[e] * gv[e] + f1[e];   // zero-filled lanes stay 0*g+0 = 0
                 raw = Vec16<T>::pack(f0);
-                bool center;
-                const int off = vec_off(a, t, chunk, pix, v, live, center);
-                buf_store16(t.rst, center ? off : kOOB, raw);                      // rst has 0 records if in_store == NULL
+                if (t.interior) {                                                  // rst has 0 records if in_store == NULL
+                    buf_store16(t.rst, to.ctr[k], t.soff + chunk * CK * ES, raw);
+                } else {
+                    bool center;
+                    const int off = vec_off(a, t, chunk, pix, v, live, center);
+                    buf_store16(t.rst, center ? off : kOOB, 0, raw);
+                }
             }
             if (live && pix < NPIX) *reinterpret_cast<uint4*>(dst + k * PPP * SPIX) = raw;
         }
@@ -386,8 +444,31 @@ struct ConvDev {
     }
 
     // ---- MFMA steps [S0, S0+COUNT) of a chunk; weights of step s live at s_w + (s - W0)*NT KiB ------
-    // Operand fragments are double-buffered in registers: step s+1's LDS reads are issued before step s's
-    // MFMAs so LDS latency hides under the matrix pipe.
+    // Operand fragments are double-buffered in registers and the issue order is fixed by hand: while step s's
+    // 4*NT MFMA items run, step s+1's NT+4 LDS fragment reads are issued one at a time between them, each fenced
+    // with sched_barrier(0).  Left to itself the machine scheduler sinks every read to just before its first use
+    // (to save registers) and the wave then sits out the LDS latency several times per step: measured 25 cycles
+    // per MFMA instead of 16.
+    static constexpr int FR = NT + 4;          // fragment reads per step: NT weight + 4 pixel-tile fragments
+    static constexpr int FM = 4 * NT;          // MFMA items per step (an item = 1 bf16 MFMA or 4 fp32 MFMAs)
+    template <int I>
+    __device__ static __forceinline__ void load_frag_item(int s, int w0, const char* s_in, const char* s_w, int lane_x,
+                                                          int lane_w, const LaneOff& lo, uint4 (&wf)[NT], uint4 (&xf)[4]) {
+        if constexpr (I < NT) {
+            wf[I] = *reinterpret_cast<const uint4*>(s_w + ((s - w0) * NT + I) * 1024 + lane_w);
+        } else {
+            constexpr int pt = I - NT;
+            xf[pt] = *reinterpret_cast<const uint4*>(s_in + lane_x + step_off(s, lo) + ((pt >> 1) * TWH + (pt & 1) * 16) * SPIX);
+        }
+    }
+    __device__ static __forceinline__ void zero_pad_frags(int s, int q, uint4 (&xf)[4]) {
+        if (step_has_pad(s)) {                 // compile-time after unrolling
+            if (lane_is_pad(s, q)) {
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) xf[pt] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    }
     __device__ static __forceinline__ void load_frags(int s, int w0, const char* s_in, const char* s_w, int lane_x,
                                                       int lane_w, int q, const LaneOff& lo, uint4 (&wf)[NT], uint4 (&xf)[4]) {
 #pragma unroll
@@ -397,18 +478,27 @@ struct ConvDev {
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt)
             xf[pt] = *reinterpret_cast<const uint4*>(xp + ((pt >> 1) * TWH + (pt & 1) * 16) * SPIX);
-        if (step_has_pad(s)) {                 // compile-time after unrolling
-            if (lane_is_pad(s, q)) {
-#pragma unroll
-                for (int pt = 0; pt < 4; ++pt) xf[pt] = make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
+        zero_pad_frags(s, q, xf);
     }
     __device__ static __forceinline__ void mma_frags(const uint4 (&wf)[NT], const uint4 (&xf)[4], f32x4 (&acc)[4][NT]) {
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) Mma<T>::run(wf[nt], xf[pt], acc[pt][nt]);
+    }
+    // one step with the next step's reads interleaved (I = read index; recursion keeps every index a constant)
+    template <int I, bool NEXT>
+    __device__ static __forceinline__ void step_interleaved(int s, int w0, const char* s_in, const char* s_w, int lane_x, int lane_w,
+                                                            const LaneOff& lo, const uint4 (&wf)[NT], const uint4 (&xf)[4],
+                                                            uint4 (&wfn)[NT], uint4 (&xfn)[4], f32x4 (&acc)[4][NT]) {
+        if constexpr (I < FR) {
+            if constexpr (NEXT) load_frag_item<I>(s + 1, w0, s_in, s_w, lane_x, lane_w, lo, wfn, xfn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = (I * FM) / FR; j < ((I + 1) * FM) / FR; ++j) Mma<T>::run(wf[j % NT], xf[j / NT], acc[j / NT][j % NT]);
+            __builtin_amdgcn_sched_barrier(0);
+            step_interleaved<I + 1, NEXT>(s, w0, s_in, s_w, lane_x, lane_w, lo, wf, xf, wfn, xfn, acc);
+        }
     }
     template <int S0, int COUNT, int W0, bool DBUF = true>
     __device__ static __forceinline__ void mma_steps(const char* s_in, const char* s_w, int lane_x, int lane_w, int q,
@@ -426,10 +516,14 @@ struct ConvDev {
             load_frags(S0, W0, s_in, s_w, lane_x, lane_w, q, lo, wfa, xfa);
 #pragma unroll
             for (int s = S0; s < END; s += 2) {
-                if (s + 1 < END) load_frags(s + 1, W0, s_in, s_w, lane_x, lane_w, q, lo, wfb, xfb);
-                mma_frags(wfa, xfa, acc);
-                if (s + 2 < END) load_frags(s + 2, W0, s_in, s_w, lane_x, lane_w, q, lo, wfa, xfa);
-                if (s + 1 < END) mma_frags(wfb, xfb, acc);
+                if (s + 1 < END) step_interleaved<0, true>(s, W0, s_in, s_w, lane_x, lane_w, lo, wfa, xfa, wfb, xfb, acc);
+                else step_interleaved<0, false>(s, W0, s_in, s_w, lane_x, lane_w, lo, wfa, xfa, wfb, xfb, acc);
+                if (s + 1 < END) {
+                    zero_pad_frags(s + 1, q, xfb);
+                    if (s + 2 < END) step_interleaved<0, true>(s + 1, W0, s_in, s_w, lane_x, lane_w, lo, wfb, xfb, wfa, xfa, acc);
+                    else step_interleaved<0, false>(s + 1, W0, s_in, s_w, lane_x, lane_w, lo, wfb, xfb, wfa, xfa, acc);
+                    if (s + 2 < END) zero_pad_frags(s + 2, q, xfa);
+                }
             }
         }
     }
@@ -437,33 +531,152 @@ struct ConvDev {
     // ---- epilogue ---------------------------------------------------------------------------------------
     // lane (q, n) holds, per pixel tile pt, packed couts jbase .. jbase+NV-1 of pixel (row, col0+n).
     // The accumulators already contain the bias (it is the MFMA chain's initial C operand).
-    // stage: this WAVE's private LDS area of STAGE_WAVE_BYTES, or nullptr.  With it, the wave's 64-pixel x 16*NT
-    // channel result is transposed through LDS and written as whole 16-byte-per-lane row segments (1 KiB per
-    // store instruction) instead of 8/16-byte pieces scattered over 64 pixels -- the direct form is
-    // store-issue-bound (measured: the epilogue took as long as the 168-MFMA loop).
-    static constexpr int STAGE_WAVE_BYTES = 64 * Cfg::COUT_TILE * ES;
-    // Two compiled forms.  LEAN covers what the big layers use (NHWC / pixel-shuffle store of full cout tiles,
-    // none/ReLU/LeakyReLU, optional residual / (x+1) multiplier / channel sums) in a few hundred instructions.
-    // The generic form adds FiLM, GELU, ragged cout and the planar NCHW store; it is ~10x the code.  Keeping the
-    // two apart matters: with everything in one body the per-tile epilogue walked a >30 KB instruction footprint
-    // and ran ~4500 cycles on instruction fetch alone (knock-out experiment: no stores, no MFMA, no loads).
-    template <bool STAGED>
+    //
+    // Two forms.  epilogue_fast<F> is compiled once per feature mask F that the big layers use (NHWC or
+    // pixel-shuffle store of full cout tiles): every optional operand is a compile-time decision, so a tile's
+    // epilogue is ~100 VALU instead of ~370 (a lone wave issues about one instruction per 4 cycles -- the
+    // epilogue's instruction COUNT was costing as much time as the 168-MFMA loop).  epilogue_generic handles
+    // everything (GELU, ragged cout, planar NCHW store, any operand mix) with run-time branches.
+    enum : int { EP_RELU = 1, EP_LEAKY = 2, EP_FILM = 4, EP_MUL = 8, EP_RES = 16, EP_SUMS = 32 };
+
+    template <bool FAST>
     __device__ static __forceinline__ void epilogue(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
-                                                    f32x4 (&acc)[4][NT], char* stage) {
-        const bool lean = a.film_scale == nullptr && a.act != RC_ACT_GELU && a.out_mode != RC_OUT_NCHW && a.cout == a.cout_packed;
-        if (lean) epilogue_impl<true, STAGED>(a, b, y0, x0, sp, ct, tid, acc, stage);
-#ifndef RC_EXPERIMENT_LEAN_ONLY
-        else epilogue_impl<false, false>(a, b, y0, x0, sp, ct, tid, acc, nullptr);
-#endif
+                                                    f32x4 (&acc)[4][NT]) {
+        if constexpr (!FAST) return epilogue_generic(a, b, y0, x0, sp, ct, tid, acc);
+        else switch (a.ep_key) {                  // uniform; set by the host, >= 0 in FAST kernels
+            case 0: return epilogue_fast<0>(a, b, y0, x0, sp, ct, tid, acc);
+            case EP_RELU: return epilogue_fast<EP_RELU>(a, b, y0, x0, sp, ct, tid, acc);
+            case EP_LEAKY: return epilogue_fast<EP_LEAKY>(a, b, y0, x0, sp, ct, tid, acc);
+            case EP_RES: return epilogue_fast<EP_RES>(a, b, y0, x0, sp, ct, tid, acc);
+            case EP_SUMS: return epilogue_fast<EP_SUMS>(a, b, y0, x0, sp, ct, tid, acc);
+            case EP_MUL: return epilogue_fast<EP_MUL>(a, b, y0, x0, sp, ct, tid, acc);
+            case EP_FILM | EP_LEAKY: return epilogue_fast<EP_FILM | EP_LEAKY>(a, b, y0, x0, sp, ct, tid, acc);
+            default: return;                      // unreachable: the host launches the !FAST kernel for other masks
+        }
     }
-    template <bool LEAN, bool STAGED>
-    __device__ static __forceinline__ void epilogue_impl(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
-                                                         f32x4 (&acc)[4][NT], char* stage) {
+
+    template <int CTRL>
+    __device__ static __forceinline__ float dpp_add(float s) {   // s + (s of the lane CTRL selects inside the 16-lane row)
+        return s + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), CTRL, 0xf, 0xf, false));
+    }
+    // sum over the 16 lanes of a row; every lane ends with the total (pairs, quads, halves, row: the same
+    // tree as an xor butterfly, so the result does not depend on the lane)
+    __device__ static __forceinline__ float row_sum16(float s) {
+        s = dpp_add<0xB1>(s);    // quad_perm [1,0,3,2]
+        s = dpp_add<0x4E>(s);    // quad_perm [2,3,0,1]
+        s = dpp_add<0x141>(s);   // row_half_mirror
+        s = dpp_add<0x140>(s);   // row_mirror
+        return s;
+    }
+    __device__ static __forceinline__ void write_chan_sums(const ConvArgs& a, int b, int sp, int wave, int n, int jbase,
+                                                           float (&csum)[NV], bool ragged) {
+        // every wave writes its own partial (slot = 4*tile + wave); rc_ca_gate folds them in fixed order
+#pragma unroll
+        for (int e = 0; e < NV; ++e) csum[e] = row_sum16(csum[e]);
+        if (n == 0) {
+            float* dst = a.chan_sums + (((size_t)b * (a.tiles_x * a.tiles_y) + sp) * 4 + wave) * a.cout;
+#pragma unroll
+            for (int e = 0; e < NV; ++e)
+                if (!ragged || jbase + e < a.cout) dst[jbase + e] = csum[e];
+        }
+    }
+
+    template <int F>
+    __device__ static __forceinline__ void epilogue_fast(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
+                                                         f32x4 (&acc)[4][NT]) {
+        const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
+        const int jbase = ct * Cfg::COUT_TILE + q * NV;
+        const size_t img_out = (size_t)a.H * a.W * a.cout;    // output / residual / mul image (elements)
+        const unsigned img_bytes = (unsigned)(img_out * ES);
+        const __amdgpu_buffer_rsrc_t r_out = make_rsrc(static_cast<T*>(a.out) + (size_t)b * img_out, img_bytes);
+        const int gy = y0 + 2 * wave, gx = x0 + n;
+        // NHWC-shaped byte offsets: pixel tile pt adds (pt>>1) rows and (pt&1)*16 columns
+        const int row_b = a.W * a.cout * ES, col_b = 16 * a.cout * ES;
+        const int off0 = ((gy * a.W + gx) * a.cout + jbase) * ES;
+        int o_off0 = off0, o_row = row_b, o_col = col_b;
+        if (a.out_mode == RC_OUT_PIXEL_SHUFFLE2) {
+            // cout tile ct = (out-channel block ct>>2, sub-pixel ct&3): this lane's NV values are consecutive
+            // OUT channels of one output pixel -> the 4 lane groups write one contiguous 16*NT-channel run
+            const int cps = a.cout >> 2, sub = ct & 3;
+            o_off0 = (((2 * gy + (sub >> 1)) * (2 * a.W) + (2 * gx + (sub & 1))) * cps + (ct >> 2) * Cfg::COUT_TILE + q * NV) * ES;
+            o_row = 4 * a.W * cps * ES; o_col = 32 * cps * ES;
+        }
+        const bool full = y0 + kTH <= a.H && x0 + kTW <= a.W;     // uniform
+        float fs[NV], ft[NV];
+        if constexpr ((F & EP_FILM) != 0) {                      // Res_GFM: (B,cout) vectors, L2-resident
+#pragma unroll
+            for (int e = 0; e < NV; e += 4) {
+                const float4 s4 = *reinterpret_cast<const float4*>(a.film_scale + (size_t)b * a.cout + jbase + e);
+                const float4 t4 = *reinterpret_cast<const float4*>(a.film_shift + (size_t)b * a.cout + jbase + e);
+                fs[e] = s4.x; fs[e + 1] = s4.y; fs[e + 2] = s4.z; fs[e + 3] = s4.w;
+                ft[e] = t4.x; ft[e + 1] = t4.y; ft[e + 2] = t4.z; ft[e + 3] = t4.w;
+            }
+        }
+        float csum[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) csum[e] = 0.f;
+        const float inf = __builtin_inff();
+
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const int dy = pt >> 1, dx = pt & 1;
+            const bool valid = gy + dy < a.H && gx + 16 * dx < a.W;
+            float v[NV];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[pt][nt][r];
+            if constexpr ((F & EP_FILM) != 0) {
+#pragma unroll
+                for (int e = 0; e < NV; ++e) v[e] = v[e] * fs[e] + ft[e] + v[e];
+            }
+            // ReLU with nothing after it on bf16: applied to the packed pairs below (one op per two values)
+            constexpr bool PK_RELU = F == EP_RELU && ES == 2;
+            if constexpr ((F & EP_RELU) != 0 && !PK_RELU) {
+#pragma unroll
+                for (int e = 0; e < NV; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.f, inf);
+            }
+            if constexpr ((F & EP_LEAKY) != 0) {                 // 0 <= slope <= 1 (host): leaky(v) = med3(v, slope*v, +inf)
+#pragma unroll
+                for (int e = 0; e < NV; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], v[e] * a.act_slope, inf);
+            }
+            if constexpr ((F & (EP_MUL | EP_RES)) != 0) {
+                const int po = valid ? off0 + dy * row_b + dx * col_b : kOOB;
+                if constexpr ((F & EP_MUL) != 0) {
+                    float m[NV];
+                    buf_load_row<T, NV>(make_rsrc(static_cast<const T*>(a.mul_plus1) + (size_t)b * img_out, img_bytes), po, m);
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) v[e] = v[e] * (m[e] + 1.f);
+                }
+                if constexpr ((F & EP_RES) != 0) {
+                    float m[NV];
+                    buf_load_row<T, NV>(make_rsrc(static_cast<const T*>(a.residual) + (size_t)b * img_out, img_bytes), po, m);
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) v[e] += m[e];
+                }
+            }
+            if constexpr ((F & EP_SUMS) != 0) {
+                if (full) {
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) csum[e] += v[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) csum[e] += valid ? v[e] : 0.f;
+                }
+            }
+            const int oo = (valid && !(a.dbg_flags & 1)) ? o_off0 + dy * o_row + dx * o_col : kOOB;
+            buf_store_row<T, NV, PK_RELU>(r_out, oo, v);
+        }
+        if constexpr ((F & EP_SUMS) != 0) write_chan_sums(a, b, sp, wave, n, jbase, csum, false);
+    }
+
+    __device__ static __forceinline__ void epilogue_generic(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
+                                                            f32x4 (&acc)[4][NT]) {
         const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
         const int jbase = ct * Cfg::COUT_TILE + q * NV;
         float fs[NV], ft[NV];
-        const bool film = !LEAN && a.film_scale != nullptr;
-        if (film) {                               // Res_GFM: (B,cout) vectors, L2-resident
+        const bool film = a.film_scale != nullptr;
+        if (film) {
 #pragma unroll
             for (int e = 0; e < NV; ++e) {
                 const bool in = jbase + e < a.cout;
@@ -486,8 +699,7 @@ struct ConvDev {
         } else {  // NHWC (H,W,cout) or pixel-shuffled (2H,2W,cout/4): same bytes per image
             r_out = make_rsrc(static_cast<T*>(a.out) + (size_t)b * img_out, img_bytes_out);
         }
-        const bool full = LEAN || a.cout == a.cout_packed;
-        constexpr bool staged = LEAN && STAGED;
+        const bool full = a.cout == a.cout_packed;
 
 #pragma unroll
         for (int pt = 0; pt < 4; ++pt) {
@@ -503,19 +715,13 @@ struct ConvDev {
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] = v[e] * fs[e] + ft[e] + v[e];
             }
-            // bf16 + staged store without post-activation operands: ReLU is applied to the packed bf16 pairs
-            // (signed 16-bit max with 0 == max(x, +0) on bf16 bit patterns), one VALU op per two values
-            constexpr bool PK_RELU = LEAN && STAGED && ES == 2;
-            const bool relu_packed = PK_RELU && a.act == RC_ACT_RELU && a.mul_plus1 == nullptr && a.residual == nullptr && a.chan_sums == nullptr;
             if (a.act == RC_ACT_RELU) {
-                if (!relu_packed) {
 #pragma unroll
-                    for (int e = 0; e < NV; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
+                for (int e = 0; e < NV; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.f, __builtin_inff());
             } else if (a.act == RC_ACT_LEAKY) {
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.act_slope;
-            } else if (!LEAN && a.act == RC_ACT_GELU) {
+            } else if (a.act == RC_ACT_GELU) {
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
             }
@@ -539,28 +745,10 @@ struct ConvDev {
                 for (int e = 0; e < NV; ++e) csum[e] += valid ? v[e] : 0.f;
             }
 
-            if constexpr (staged) {
-                T* sp_ = reinterpret_cast<T*>(stage + (((pt >> 1) * 32 + (pt & 1) * 16 + n) * Cfg::COUT_TILE + q * NV) * ES);
-                if constexpr (ES == 4) {
-#pragma unroll
-                    for (int e = 0; e < NV; e += 4) *reinterpret_cast<float4*>(sp_ + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < NV; e += 4) {
-                        unsigned p0 = pack_bf16x2(v[e], v[e + 1]), p1 = pack_bf16x2(v[e + 2], v[e + 3]);
-                        if (relu_packed) {
-                            typedef short s16x2 __attribute__((ext_vector_type(2)));
-                            const s16x2 z = {0, 0};
-                            p0 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p0), z));
-                            p1 = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p1), z));
-                        }
-                        *reinterpret_cast<uint2*>(sp_ + e) = make_uint2(p0, p1);
-                    }
-                }
-            } else if (a.out_mode == RC_OUT_NHWC) {
+            if (a.out_mode == RC_OUT_NHWC) {
                 if (full) {
-                    buf_store_row<T, NV>(r_out, pix_off, v);
-                } else if constexpr (!LEAN) {  // ragged cout (test sizes): element stores
+                    buf_store_row<T, NV, false>(r_out, pix_off, v);
+                } else {  // ragged cout (test sizes): element stores
 #pragma unroll
                     for (int e = 0; e < NV; ++e) {
                         const int o = (valid && jbase + e < a.cout) ? pix_off + e * ES : kOOB;
@@ -569,12 +757,10 @@ struct ConvDev {
                     }
                 }
             } else if (a.out_mode == RC_OUT_PIXEL_SHUFFLE2) {
-                // cout tile ct = (out-channel block ct>>2, sub-pixel ct&3): this lane's NV values are consecutive
-                // OUT channels of one output pixel -> the 4 lane groups write one contiguous 16*NT-channel run
                 const int cps = a.cout >> 2, sub = ct & 3;
                 const int o = valid ? (((2 * gy + (sub >> 1)) * (2 * a.W) + (2 * gx + (sub & 1))) * cps + (ct >> 2) * Cfg::COUT_TILE + q * NV) * ES : kOOB;
-                buf_store_row<T, NV>(r_out, o, v);
-            } else if constexpr (!LEAN) {  // RC_OUT_NCHW, cropped
+                buf_store_row<T, NV, false>(r_out, o, v);
+            } else {  // RC_OUT_NCHW, cropped
                 const bool inside = gy < a.out_h && gx < a.out_w;
 #pragma unroll
                 for (int e = 0; e < NV; ++e) {
@@ -587,43 +773,7 @@ struct ConvDev {
                 }
             }
         }
-
-        if constexpr (staged) {
-            // the wave wrote its own area and reads it back itself: LDS ops of one wave complete in order
-            __builtin_amdgcn_wave_barrier();
-            constexpr int CPP = Cfg::COUT_TILE * ES / 16;          // 16-byte chunks per pixel inside this cout tile
-            const int cps = a.cout >> 2, sub = ct & 3;
-#pragma unroll
-            for (int i = 0; i < CPP; ++i) {
-                const int chunk = i * 64 + lane;                   // linear over [row 0: 32 px][row 1: 32 px] x CPP
-                const int pixel = chunk / CPP, piece = chunk - pixel * CPP;
-                const int gy = gy_w + (pixel >> 5), gx = x0 + (pixel & 31);
-                int off;
-                if (a.out_mode == RC_OUT_NHWC)
-                    off = ((gy * a.W + gx) * a.cout + ct * Cfg::COUT_TILE) * ES + piece * 16;
-                else
-                    off = (((2 * gy + (sub >> 1)) * (2 * a.W) + (2 * gx + (sub & 1))) * cps + (ct >> 2) * Cfg::COUT_TILE) * ES + piece * 16;
-                const uint4 val = *reinterpret_cast<const uint4*>(stage + chunk * 16);
-                buf_store16(r_out, (gy < a.H && gx < a.W && !(a.dbg_flags & 1)) ? off : kOOB, val);
-            }
-        }
-
-        if (a.chan_sums != nullptr) {  // uniform branch
-            // reduce over the 16 pixels of the lane group (lanes sharing q); every wave writes its own partial
-            // (slot = 4*tile + wave), rc_ca_gate folds them in fixed order -> no block barrier in the epilogue
-#pragma unroll
-            for (int e = 0; e < NV; ++e) {
-                float s = csum[e];
-                s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-                csum[e] = s;
-            }
-            if (n == 0) {
-                float* dst = a.chan_sums + (((size_t)b * (a.tiles_x * a.tiles_y) + sp) * 4 + wave) * a.cout;
-#pragma unroll
-                for (int e = 0; e < NV; ++e)
-                    if (jbase + e < a.cout) dst[jbase + e] = csum[e];
-            }
-        }
+        if (a.chan_sums != nullptr) write_chan_sums(a, b, sp, wave, n, jbase, csum, true);
     }
 };
 
@@ -631,15 +781,15 @@ struct ConvDev {
 // Kernel 1: general form.  One block = one (spatial tile, cout tile, image); loops over Cin chunks,
 // streaming packed weights through LDS G steps at a time.
 // ==================================================================================================
-template <class Cfg, bool GATED>
+template <class Cfg, bool GATED, bool FAST>
 __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a) {
     using D = ConvDev<Cfg>;
     using T = typename Cfg::elem;
     constexpr int NT = Cfg::NT, STEPS = Cfg::STEPS, G = Cfg::G, NSUB = Cfg::NSUB, NV = 4 * NT;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_in = smem;
-    char* s_w = smem + Cfg::IN_BYTES;
+    char* s_w = smem;                                  // weights first: their ds_read immediates stay below 64 KiB
+    char* s_in = smem + Cfg::W_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, n = lane & 15;
@@ -669,6 +819,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a
     ConvArgs aa = a;
     if (ct != 0) aa.in_store = nullptr;       // only one cout tile materialises the gated input
     const typename D::TileSrc ts = D::tile_src(aa, b, y0, x0);
+    typename D::TileOffs to;
+    D::tile_offsets(aa, tid, to);
     const char* wbase = static_cast<const char*>(a.wpacked) + (size_t)ct * a.n_chunks * Cfg::CHUNK_W_BYTES;
 
     for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
@@ -678,8 +830,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a
         if (a.cin_vec_ok) {
             uint4 r0[D::NI], r1[GATED ? D::NI : 1];
             float gv[GATED ? D::UNIT : 1];
-            D::template load_tile<GATED>(aa, ts, b, chunk, tid, r0, r1, gv);
-            D::template commit_tile<GATED>(aa, ts, chunk, tid, r0, r1, gv, s_in);
+            D::template load_tile<GATED>(aa, ts, to, b, chunk, tid, r0, r1, gv);
+            D::template commit_tile<GATED>(aa, ts, to, chunk, tid, r0, r1, gv, s_in);
         } else {
             D::stage_tile_scalar(aa, b, y0, x0, chunk, tid, s_in, static_cast<T*>(aa.in_store));
         }
@@ -699,7 +851,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a
         }
         static_assert(NSUB <= 3, "add another weight sub-stage");
     }
-    D::template epilogue<false>(a, b, y0, x0, sp, ct, tid, acc, nullptr);
+    D::template epilogue<FAST>(a, b, y0, x0, sp, ct, tid, acc);
 }
 
 // ==================================================================================================
@@ -712,15 +864,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a
 // ==================================================================================================
 constexpr int kPersistMaxCout = 512;   // bias slots kept in LDS
 
-template <class Cfg, bool GATED>
+template <class Cfg, bool GATED, bool FAST>
 __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const ConvArgs a) {
     using D = ConvDev<Cfg>;
     constexpr int NT = Cfg::NT, STEPS = Cfg::STEPS, NV = 4 * NT;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_in = smem;
-    char* s_w = smem + Cfg::IN_BYTES;
-    float* s_bias = reinterpret_cast<float*>(smem + Cfg::IN_BYTES + Cfg::CHUNK_W_BYTES);
+    char* s_w = smem;                                  // weights first: their ds_read immediates stay below 64 KiB
+    float* s_bias = reinterpret_cast<float*>(smem + Cfg::CHUNK_W_BYTES);
+    char* s_in = smem + Cfg::CHUNK_W_BYTES + kPersistMaxCout * 4;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, n = lane & 15;
@@ -744,6 +896,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
 
     uint4 r0[D::NI], r1[GATED ? D::NI : 1];
     float gv[GATED ? D::UNIT : 1];
+    typename D::TileOffs to;
+    D::tile_offsets(a, tid, to);
     int tile = pos < n_tiles ? pos : -1;
     int b = 0, sp = 0, y0 = 0, x0 = 0;
     typename D::TileSrc ts;
@@ -753,11 +907,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
         band_decode(tile - b * sp_total, a.tiles_x, a.tiles_y, a.inv_band, ty, tx);
         sp = ty * a.tiles_x + tx; y0 = ty * kTH; x0 = tx * kTW;
         ts = D::tile_src(a, b, y0, x0);
-        if (a.cin_vec_ok) D::template load_tile<GATED>(a, ts, b, 0, tid, r0, r1, gv);
+        if (a.cin_vec_ok) {
+            D::template load_gate<GATED>(a, b, 0, tid, gv);
+            if (ts.interior) D::template load_tile_interior<GATED>(ts, to, 0, r0, r1);
+        }
     }
     while (tile >= 0) {
         __syncthreads();                               // every wave finished reading s_in / s_w (previous tile)
-        if (a.cin_vec_ok) D::template commit_tile<GATED>(a, ts, 0, tid, r0, r1, gv, s_in);
+        // border tiles (5 % at 4K) were not prefetched: their bounds-checked addressing would otherwise sit,
+        // as live masks and offsets, across the MFMA loop of every tile
+        if (a.cin_vec_ok && !ts.interior) D::template load_tile_border<GATED>(a, ts, 0, tid, r0, r1);
+        if (a.cin_vec_ok) D::template commit_tile<GATED>(a, ts, to, 0, tid, r0, r1, gv, s_in);
         else D::stage_tile_scalar(a, b, y0, x0, 0, tid, s_in, static_cast<typename Cfg::elem*>(a.in_store));
         const int cb = b, csp = sp, cy0 = y0, cx0 = x0;
         const int next = tile + (int)gridDim.x;
@@ -775,7 +935,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
                 band_decode(tile - b * sp_total, a.tiles_x, a.tiles_y, a.inv_band, ty, tx);
                 sp = ty * a.tiles_x + tx; y0 = ty * kTH; x0 = tx * kTW;
                 ts = D::tile_src(a, b, y0, x0);
-                if (a.cin_vec_ok) D::template load_tile<GATED>(a, ts, b, 0, tid, r0, r1, gv);
+                if (a.cin_vec_ok) {
+                    D::template load_gate<GATED>(a, b, 0, tid, gv);
+                    if (ts.interior) D::template load_tile_interior<GATED>(ts, to, 0, r0, r1);
+                }
             }
             f32x4 acc[4][NT];                          // initial C operand = bias
 #pragma unroll
@@ -785,7 +948,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
                 for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
             }
             D::template mma_steps<0, STEPS, 0, (!GATED && NT < 5)>(s_in, s_w, lane_x, lane_w, q, lo, acc);
-            D::template epilogue<false>(a, cb, cy0, cx0, csp, ct, tid, acc, nullptr);
+            D::template epilogue<FAST>(a, cb, cy0, cx0, csp, ct, tid, acc);
         }
     }
 }
@@ -802,17 +965,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const Co
 // ==================================================================================================
 constexpr int kWsThreads = 512;
 
-template <class Cfg, bool GATED>
+template <class Cfg, bool GATED, bool FAST>
 __global__ __launch_bounds__(kWsThreads) void conv_mfma_ws_kernel(const ConvArgs a) {
     using D = ConvDev<Cfg>;
     constexpr int NT = Cfg::NT, STEPS = Cfg::STEPS, NV = 4 * NT;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_buf0 = smem;
-    char* s_buf1 = smem + Cfg::IN_BYTES;
-    char* s_w = smem + 2 * Cfg::IN_BYTES;
-    float* s_bias = reinterpret_cast<float*>(smem + 2 * Cfg::IN_BYTES + Cfg::CHUNK_W_BYTES);
-    char* s_stage = smem + 2 * Cfg::IN_BYTES + Cfg::CHUNK_W_BYTES + 16 * Cfg::NT * 4;   // 4 x STAGE_WAVE_BYTES
+    char* s_w = smem;                                  // weights first: their ds_read immediates stay below 64 KiB
+    float* s_bias = reinterpret_cast<float*>(smem + Cfg::CHUNK_W_BYTES);
+    char* s_buf0 = smem + Cfg::CHUNK_W_BYTES + 16 * Cfg::NT * 4;
+    char* s_buf1 = s_buf0 + Cfg::IN_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform
@@ -845,28 +1007,30 @@ __global__ __launch_bounds__(kWsThreads) void conv_mfma_ws_kernel(const ConvArgs
         uint4 r0[D::NI], r1[GATED ? D::NI : 1];
         float gv[GATED ? D::UNIT : 1];
         typename D::TileSrc ts;
+        typename D::TileOffs to;
+        D::tile_offsets(a, rtid, to);
         int b, sp, y0, x0;
         if (my_tiles > 0) {                              // tile 0 -> buf0 (synchronously), then tile 1's loads in flight
             decode(pos, b, sp, y0, x0);
             ts = D::tile_src(a, b, y0, x0);
-            D::template load_tile<GATED>(a, ts, b, 0, rtid, r0, r1, gv);
-            D::template commit_tile<GATED>(a, ts, 0, rtid, r0, r1, gv, s_buf0);
+            D::template load_tile<GATED>(a, ts, to, b, 0, rtid, r0, r1, gv);
+            D::template commit_tile<GATED>(a, ts, to, 0, rtid, r0, r1, gv, s_buf0);
         }
         if (my_tiles > 1) {
             decode(pos + stride, b, sp, y0, x0);
             ts = D::tile_src(a, b, y0, x0);
-            D::template load_tile<GATED>(a, ts, b, 0, rtid, r0, r1, gv);
+            D::template load_tile<GATED>(a, ts, to, b, 0, rtid, r0, r1, gv);
         }
         __syncthreads();                                 // barrier 0: weights, bias, tile 0 visible
         const bool rec = a.dbg != nullptr && blockIdx.x == 8 && wave8 == 4 && lane == 0;
         for (int k = 0; k < my_tiles; ++k) {
             const long long tl0 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
             if (k + 1 < my_tiles) {                      // registers hold tile k+1 -> the buffer the computers are NOT reading
-                D::template commit_tile<GATED>(a, ts, 0, rtid, r0, r1, gv, ((k + 1) & 1) ? s_buf1 : s_buf0);
+                D::template commit_tile<GATED>(a, ts, to, 0, rtid, r0, r1, gv, ((k + 1) & 1) ? s_buf1 : s_buf0);
                 if (k + 2 < my_tiles) {                  // ... and immediately put tile k+2's loads in flight
                     decode(pos + (k + 2) * stride, b, sp, y0, x0);
                     ts = D::tile_src(a, b, y0, x0);
-                    if (!(a.dbg_flags & 4)) D::template load_tile<GATED>(a, ts, b, 0, rtid, r0, r1, gv);
+                    if (!(a.dbg_flags & 4)) D::template load_tile<GATED>(a, ts, to, b, 0, rtid, r0, r1, gv);
                 }
             }
             const long long tl1 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -894,7 +1058,7 @@ __global__ __launch_bounds__(kWsThreads) void conv_mfma_ws_kernel(const ConvArgs
             }
             if (!(a.dbg_flags & 2)) D::template mma_steps<0, STEPS, 0, (NT < 5)>((k & 1) ? s_buf1 : s_buf0, s_w, lane_x, lane_w, q, lo, acc);
             const long long tc1 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
-            D::template epilogue<true>(a, b, y0, x0, sp, 0, rtid, acc, s_stage + wave * D::STAGE_WAVE_BYTES);
+            D::template epilogue<FAST>(a, b, y0, x0, sp, 0, rtid, acc);
             const long long tc2 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
             __syncthreads();                             // barrier k+1
             if (rec && k < 64) { a.dbg[4 * k] = tc1 - tc0; a.dbg[4 * k + 1] = tc2 - tc1; a.dbg[4 * k + 2] = (long long)__builtin_amdgcn_s_memtime() - tc2; }
@@ -903,13 +1067,13 @@ __global__ __launch_bounds__(kWsThreads) void conv_mfma_ws_kernel(const ConvArgs
 }
 
 template <class Cfg>
-constexpr int ws_lds_bytes() { return 2 * Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + 16 * Cfg::NT * 4 + 4 * 64 * Cfg::COUT_TILE * (int)sizeof(typename Cfg::elem); }
+constexpr int ws_lds_bytes() { return 2 * Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + 16 * Cfg::NT * 4; }
 
 // ---- host side: per-instantiation launcher ----------------------------------------------------------
 template <class Cfg>
 constexpr int persist_lds_bytes() { return Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + kPersistMaxCout * 4; }
 
-template <class Cfg, bool GATED>
+template <class Cfg, bool GATED, bool FAST>
 int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
     constexpr int P_LDS = persist_lds_bytes<Cfg>();
     constexpr bool P_OK = P_LDS <= 80 * 1024;          // two persistent blocks per CU
@@ -922,14 +1086,14 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
         if (a.n_chunks == 1 && a.n_ct == 1 && a.cin_vec_ok && (a.persist_ok == 2 || (a.persist_ok == 1 && ws_auto)) && n_tiles < (1 << 24)) {
             static bool attr_set = false;
             if (!attr_set) {
-                RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_ws_kernel<Cfg, GATED>),
+                RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_ws_kernel<Cfg, GATED, FAST>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
                 attr_set = true;
             }
             int grid = a.num_cus;
             if (grid > n_tiles) grid = n_tiles;
             grid = (grid + 7) / 8 * 8;
-            hipLaunchKernelGGL((conv_mfma_ws_kernel<Cfg, GATED>), dim3((unsigned)grid), dim3(kWsThreads), WS_LDS, stream, a);
+            hipLaunchKernelGGL((conv_mfma_ws_kernel<Cfg, GATED, FAST>), dim3((unsigned)grid), dim3(kWsThreads), WS_LDS, stream, a);
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }
@@ -938,26 +1102,26 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
         if (a.n_chunks == 1 && a.cout_packed <= kPersistMaxCout && a.persist_ok && n_tiles < (1 << 24)) {
             static bool attr_set = false;
             if (!attr_set) {
-                RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_persist_kernel<Cfg, GATED>),
+                RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_persist_kernel<Cfg, GATED, FAST>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
                 attr_set = true;
             }
             int grid = 2 * a.num_cus;
             if (grid > n_tiles) grid = n_tiles;
             grid = (grid + 7) / 8 * 8;
-            hipLaunchKernelGGL((conv_mfma_persist_kernel<Cfg, GATED>), dim3((unsigned)grid), dim3(kThreads), P_LDS, stream, a);
+            hipLaunchKernelGGL((conv_mfma_persist_kernel<Cfg, GATED, FAST>), dim3((unsigned)grid), dim3(kThreads), P_LDS, stream, a);
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }
     }
     static bool attr_set = false;
     if (!attr_set) {
-        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<Cfg, GATED>),
+        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<Cfg, GATED, FAST>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
         attr_set = true;
     }
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.n_ct), (unsigned)a.batch, 1);
-    hipLaunchKernelGGL((conv_mfma_kernel<Cfg, GATED>), grid, dim3(kThreads), Cfg::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<Cfg, GATED, FAST>), grid, dim3(kThreads), Cfg::LDS_BYTES, stream, a);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
@@ -965,14 +1129,12 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
 template <class Cfg>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
     // the gated form (x = in0*gate + in1) only occurs on vectorisable layers inside RCAGroups
-    if (a.in_gate != nullptr && a.cin_vec_ok) return launch_conv_g<Cfg, true>(a, stream);
-    return launch_conv_g<Cfg, false>(a, stream);
+    const bool gated = a.in_gate != nullptr && a.cin_vec_ok;
+    if (a.ep_key >= 0) return gated ? launch_conv_g<Cfg, true, true>(a, stream) : launch_conv_g<Cfg, false, true>(a, stream);
+    return gated ? launch_conv_g<Cfg, true, false>(a, stream) : launch_conv_g<Cfg, false, false>(a, stream);
 }
 
-// One dispatcher per (dtype, ksize) translation unit; defined in conv_inst_*.hip
-int dispatch_conv_bf16_k3(int ck, int nt, const ConvArgs& a, hipStream_t s);
-int dispatch_conv_bf16_k1(int ck, int nt, const ConvArgs& a, hipStream_t s);
-int dispatch_conv_f32_k3(int ck, int nt, const ConvArgs& a, hipStream_t s);
-int dispatch_conv_f32_k1(int ck, int nt, const ConvArgs& a, hipStream_t s);
+// defined in conv_dispatch.hip; the instantiations live in conv_inst_*.hip
+int dispatch_conv(bool bf16, int ksize, int ck, int nt, const ConvArgs& a, hipStream_t s);
 
 }  // namespace rc
