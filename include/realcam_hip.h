@@ -133,6 +133,38 @@ int rc_conv2d(const rc_conv_desc* desc, void* stream);
 /* sizeof(rc_conv_desc) as compiled into the library: lets an FFI binding verify its struct mirror. */
 size_t rc_conv_desc_size(void);
 
+/* ---- a5+a6 fused: two 3x3 convolutions with the intermediate kept on chip ------------------------
+ * Replaces, for 48-channel bf16 feature maps (the flagship width):
+ *   RCABlock.res      conv -> ReLU -> conv                 (models/networks.py:296-311; + CALayer sums)
+ *   Res_GFM           conv0 -> x*scale+shift+x -> LeakyReLU -> conv1 -> + x     (models/LiteISP.py:553-558)
+ * i.e. exactly two rc_conv2d calls whose intermediate NHWC map never goes to HBM (the 48->48 layers run at
+ * the HBM copy rate, so this halves their traffic).  Same operands as rc_conv_desc where they apply:
+ * in1/in_gate/in_store feed conv1's input staging (x = in0*gate + in1), act1 is RC_ACT_RELU, or
+ * RC_ACT_LEAKY together with film_scale/film_shift; residual is added to conv2's result (FiLM form only);
+ * chan_sums receives rc_conv_pair_sum_slots() partials per image (ReLU form only) for rc_ca_gate.
+ * w1/w2: rc_conv_pack_weights(48,48,3,RC_BF16,RC_OUT_NHWC); b1/b2: rc_conv_pack_bias or NULL.
+ * Other widths / fp32 return RC_ERR_UNSUPPORTED-style errors: callers issue two rc_conv2d calls instead. */
+typedef struct rc_conv_pair_desc {
+    int32_t batch, height, width, channels;
+    int32_t dtype;                  /* RC_BF16                                                    */
+    const void* in0;                /* NHWC (B,H,W,48)                                            */
+    const void* in1;                /* optional skip tensor (with in_gate)                        */
+    const float* in_gate;           /* optional (B,48) fp32 CALayer gate                          */
+    void* in_store;                 /* optional: materialised in0*gate + in1                      */
+    const void* w1; const float* b1;
+    const float* film_scale;        /* (B,48) fp32, FiLM form                                     */
+    const float* film_shift;
+    int32_t act1;                   /* RC_ACT_RELU | RC_ACT_LEAKY                                 */
+    float act1_slope;
+    const void* w2; const float* b2;
+    const void* residual;           /* optional NHWC (B,H,W,48), added to conv2's result          */
+    void* out;                      /* NHWC (B,H,W,48)                                            */
+    float* chan_sums;               /* optional fp32 (B, rc_conv_pair_sum_slots(), 48)            */
+} rc_conv_pair_desc;
+int rc_conv_pair(const rc_conv_pair_desc* desc, void* stream);
+int rc_conv_pair_sum_slots(int height, int width);
+size_t rc_conv_pair_desc_size(void);
+
 /* ---- a8: CALayer gate -------------------------------------------------------------------------
  * Replaces: AdaptiveAvgPool2d(1) -> Conv1x1(C,C/r) -> ReLU -> Conv1x1(C/r,C) -> Sigmoid
  * (models/networks.py:259-269).  d_sums: (B, n_tiles, C) partials from rc_conv2d; w0 (Cr,C), b0 (Cr),

@@ -119,7 +119,10 @@ class Res_GFM(nn.Module):
         a, vec = x
         scale = ops.gfm_vector(vec, self.GFM_scale_conv0, self.GFM_scale_conv1)
         shift = ops.gfm_vector(vec, self.GFM_shift_conv0, self.GFM_shift_conv1)
-        f = self.conv0._nhwc(a, film=(scale, shift), act="leaky", slope=float(self.act.negative_slope))
+        slope = float(self.act.negative_slope)
+        if 0.0 <= slope <= 1.0 and ops.conv_pair_ok(a, self.conv0, self.conv1):
+            return ops.conv_pair(a, self.conv0, self.conv1, act="leaky", slope=slope, film=(scale, shift), residual=a), vec
+        f = self.conv0._nhwc(a, film=(scale, shift), act="leaky", slope=slope)
         return self.conv1._nhwc(f, residual=a), vec
 
     def forward(self, x):

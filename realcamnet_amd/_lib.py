@@ -37,6 +37,20 @@ class ConvDesc(C.Structure):
     ]
 
 
+class ConvPairDesc(C.Structure):
+    """Mirror of `struct rc_conv_pair_desc`."""
+    _fields_ = [
+        ("batch", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32),
+        ("dtype", C.c_int32),
+        ("in0", C.c_void_p), ("in1", C.c_void_p), ("in_gate", C.c_void_p), ("in_store", C.c_void_p),
+        ("w1", C.c_void_p), ("b1", C.c_void_p),
+        ("film_scale", C.c_void_p), ("film_shift", C.c_void_p),
+        ("act1", C.c_int32), ("act1_slope", C.c_float),
+        ("w2", C.c_void_p), ("b2", C.c_void_p),
+        ("residual", C.c_void_p), ("out", C.c_void_p), ("chan_sums", C.c_void_p),
+    ]
+
+
 def declared_symbols() -> list[str]:
     """Every function the public header declares (used by the CPU-side ABI test)."""
     text = HEADER.read_text()
@@ -60,6 +74,9 @@ _SIGS = {
     "rc_conv_sum_tiles": (C.c_int, [_I, _I]),
     "rc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "rc_conv_desc_size": (_SZ, []),
+    "rc_conv_pair": (C.c_int, [C.POINTER(ConvPairDesc), _P]),
+    "rc_conv_pair_sum_slots": (C.c_int, [_I, _I]),
+    "rc_conv_pair_desc_size": (_SZ, []),
     "rc_ca_gate": (C.c_int, [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "rc_gate_residual": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rc_dwt_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -70,6 +70,27 @@ static bool g_prof_on = false;
 struct ProfRec { hipEvent_t e0, e1; double flops; };
 static std::vector<ProfRec> g_prof;
 
+long long* conv_dbg_ptr() { return g_dbg_ptr; }
+
+// HIP-event bracket around one conv launch on its own stream (rc_prof_enable); shared with conv_pair.hip
+void conv_prof_begin(double flops, hipStream_t stream, void** token) {
+    *token = nullptr;
+    { std::lock_guard<std::mutex> lk(g_prof_mu); if (!g_prof_on) return; }
+    ProfRec* rec = new ProfRec{};
+    rec->flops = flops;
+    if (hipEventCreate(&rec->e0) != hipSuccess || hipEventCreate(&rec->e1) != hipSuccess) { delete rec; return; }
+    (void)hipEventRecord(rec->e0, stream);
+    *token = rec;
+}
+void conv_prof_end(void* token, hipStream_t stream) {
+    if (!token) return;
+    ProfRec* rec = static_cast<ProfRec*>(token);
+    (void)hipEventRecord(rec->e1, stream);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(*rec);
+    delete rec;
+}
+
 }  // namespace rc
 
 using namespace rc;
@@ -252,22 +273,10 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     }
 
     hipStream_t stream = as_stream(stream_);
-    bool prof;
-    { std::lock_guard<std::mutex> lk(g_prof_mu); prof = g_prof_on; }
-    ProfRec rec{};
-    if (prof) {
-        RC_HIP_CHECK(hipEventCreate(&rec.e0));
-        RC_HIP_CHECK(hipEventCreate(&rec.e1));
-        rec.flops = 2.0 * d->batch * d->height * d->width * (double)d->cin * d->cout * d->ksize * d->ksize;
-        RC_HIP_CHECK(hipEventRecord(rec.e0, stream));
-    }
-    int rcode;
-    rcode = dispatch_conv(d->dtype == RC_BF16, d->ksize, p.ck, p.nt, a, stream);
-    if (prof) {
-        RC_HIP_CHECK(hipEventRecord(rec.e1, stream));
-        std::lock_guard<std::mutex> lk(g_prof_mu);
-        g_prof.push_back(rec);
-    }
+    void* tok = nullptr;
+    conv_prof_begin(2.0 * d->batch * d->height * d->width * (double)d->cin * d->cout * d->ksize * d->ksize, stream, &tok);
+    const int rcode = dispatch_conv(d->dtype == RC_BF16, d->ksize, p.ck, p.nt, a, stream);
+    conv_prof_end(tok, stream);
     return rcode;
 }
 

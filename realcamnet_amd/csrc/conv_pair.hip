@@ -1,0 +1,552 @@
+// Fused pair of 3x3 convolutions, 48 -> 48 -> 48 channels, bf16 storage / fp32 accumulate (gfx950).
+//
+//     mid = act1(conv1(x))            act1 = ReLU (RCAB, networks.py:296-311) or FiLM + LeakyReLU (Res_GFM, LiteISP.py:537-559)
+//     out = conv2(mid) [+ residual]   (+ per-wave channel sums for CALayer's global mean)
+//
+// Unfused, `mid` costs one HBM write and one HBM read of a full-resolution 48-channel map, and the 48->48 layers
+// of the flagship net already run AT the measured HBM copy rate, so the only way to make
+// them faster is to move fewer bytes.  Here a block keeps `mid` for its tile in LDS:
+//
+//   input halo tile 12 x 36 px  --conv1 (MFMA)-->  mid tile 10 x 34 px (LDS, bf16)  --conv2 (MFMA)-->  8 x 32 px out
+//
+// conv1 is recomputed on the 1-pixel ring (340 instead of 256 pixels: 22 instead of 16 MFMA pixel tiles), i.e. the
+// pair costs 1.19x the MFMA work of the two separate layers and ~half their HBM traffic.  mid pixels outside the
+// image are forced to zero (conv2 zero-pads ITS input, it does not see conv1 of the padding).
+//
+// One 512-thread block per CU (LDS: both packed weight matrices 84 KB + input tile 40.5 KB + mid tile 32 KB),
+// persistent over a band-major XCD-aware tile list like the single-layer kernels.  Per tile:
+//   phase 1  all 8 waves: conv1 on 22 linear 16-pixel tiles of the mid grid (3,3,3,3,3,3,2,2 per wave) -> LDS
+//   barrier  (mid complete, input tile free)
+//   stage    registers holding tile k+1's input (loaded one tile earlier) -> LDS; issue tile k+2's loads
+//   phase 2  all 8 waves: conv2, wave w = output row w (2 pixel tiles) -> epilogue -> HBM
+//   barrier  (input tile k+1 visible, mid free)
+// The MFMA / LDS-read interleave, weight fragment layout (rc_conv_pack_weights, CK = 48, NT = 3) and unit map are
+// those of conv_kernel.hpp.
+#include "conv_kernel.hpp"
+
+#include <mutex>
+#include <string>
+
+namespace rc {
+namespace pair {
+
+constexpr int C = 48, NT = 3, NV = 12, SPIX = 96, STEPS = 14, ES = 2;
+constexpr int OTH = 8, OTW = 32;                  // output tile
+constexpr int MH = OTH + 2, MW = OTW + 2;         // mid tile (conv2's halo tile)
+constexpr int IH = OTH + 4, IW = OTW + 4;         // input tile (conv1's halo tile of the mid tile)
+constexpr int NMID = MH * MW, NIN = IH * IW;      // 340, 432 pixels
+constexpr int N_MID_TILES = (NMID + 15) / 16;     // 22 MFMA pixel tiles
+constexpr int W_BYTES = STEPS * NT * 1024;        // one packed 48x(9*48) weight matrix
+constexpr int OFF_W1 = 0, OFF_W2 = W_BYTES, OFF_BIAS = 2 * W_BYTES, OFF_IN = OFF_BIAS + 2 * C * 4;
+constexpr int OFF_MID = OFF_IN + NIN * SPIX, LDS_BYTES = OFF_MID + NMID * SPIX;
+static_assert(LDS_BYTES <= 160 * 1024, "pair kernel LDS budget");
+constexpr int THREADS = 512, WAVES = 8;
+constexpr int VPP = 6, PPP = THREADS / VPP, ACTIVE = PPP * VPP, NI = (NIN + PPP - 1) / PPP;   // staging map, as ConvDev
+
+enum { E1_RELU = 0, E1_FILM_LEAKY = 1 };
+enum { E2_PLAIN = 0, E2_SUMS = 1, E2_RES = 2 };
+
+struct PairArgs {
+    int batch, H, W;
+    const bf16_t* in0; const bf16_t* in1; const float* in_gate; bf16_t* in_store;
+    const void* w1; const float* b1; const float* film_scale; const float* film_shift; float slope;
+    const void* w2; const float* b2;
+    const bf16_t* residual; bf16_t* out; float* chan_sums;
+    int tiles_x, tiles_y;
+    float inv_band, inv_sp_total;
+    long long* dbg;                // optional phase-timing buffer (rc_debug_set_ptr("conv_phase_timing")), normally NULL
+};
+
+// ---- MFMA over one 3x3x48 chunk for NPT pixel tiles whose LDS pixel rows are P pixels apart ------------
+template <int P, int NPT>
+struct PairMma {
+    static constexpr int FR = NT + NPT, FM = NT * NPT;
+    struct Lane { int a, b, c; };
+    __device__ static __forceinline__ Lane lane_consts(int q) {
+        Lane l;
+        l.a = q * 16;
+        l.b = (q >> 1) * SPIX + (4 + (q & 1)) * 16;
+        l.c = (q >> 1) * (P - 2) * SPIX + (4 + (q & 1)) * 16;
+        return l;
+    }
+    __device__ static constexpr int tap_off(int tap) { return ((tap / 3) * P + (tap % 3)) * SPIX; }
+    __device__ static __forceinline__ int step_off(int s, const Lane& l) {   // s is a constant after inlining
+        if (s < 9) return l.a + tap_off(s);
+        const int t0 = 2 * (s - 9);
+        const bool wrap = (t0 + 1 < 9) && ((t0 + 1) % 3 == 0);
+        return (wrap ? l.c : l.b) + tap_off(t0);
+    }
+    template <int I>
+    __device__ static __forceinline__ void load_item(int s, const char* smem, const int (&xb)[NPT], int wb, const Lane& l,
+                                                     uint4 (&wf)[NT], uint4 (&xf)[NPT]) {
+        if constexpr (I < NT) wf[I] = *reinterpret_cast<const uint4*>(smem + wb + (s * NT + I) * 1024);
+        else xf[I - NT] = *reinterpret_cast<const uint4*>(smem + xb[I - NT] + step_off(s, l));
+    }
+    template <int I>
+    __device__ static __forceinline__ void load_all(int s, const char* smem, const int (&xb)[NPT], int wb, const Lane& l,
+                                                    uint4 (&wf)[NT], uint4 (&xf)[NPT]) {
+        if constexpr (I < FR) {
+            load_item<I>(s, smem, xb, wb, l, wf, xf);
+            load_all<I + 1>(s, smem, xb, wb, l, wf, xf);
+        }
+    }
+    __device__ static __forceinline__ void zero_pad(int s, int q, uint4 (&xf)[NPT]) {
+        if (s == STEPS - 1) {                    // last paired step: tap 9 does not exist
+            if (q >= 2) {
+#pragma unroll
+                for (int i = 0; i < NPT; ++i) xf[i] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    }
+    template <int I, bool NEXT>
+    __device__ static __forceinline__ void step(int s, const char* smem, const int (&xb)[NPT], int wb, const Lane& l,
+                                                const uint4 (&wf)[NT], const uint4 (&xf)[NPT], uint4 (&wfn)[NT], uint4 (&xfn)[NPT],
+                                                f32x4 (&acc)[NPT][NT]) {
+        if constexpr (I < FR) {
+            if constexpr (NEXT) load_item<I>(s + 1, smem, xb, wb, l, wfn, xfn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = (I * FM) / FR; j < ((I + 1) * FM) / FR; ++j) Mma<bf16_t>::run(wf[j % NT], xf[j / NT], acc[j / NT][j % NT]);
+            __builtin_amdgcn_sched_barrier(0);
+            step<I + 1, NEXT>(s, smem, xb, wb, l, wf, xf, wfn, xfn, acc);
+        }
+    }
+    __device__ static __forceinline__ void run(const char* smem, const int (&xb)[NPT], int wb, int q, f32x4 (&acc)[NPT][NT]) {
+        const Lane l = lane_consts(q);
+        uint4 wfa[NT], xfa[NPT], wfb[NT], xfb[NPT];
+        load_all<0>(0, smem, xb, wb, l, wfa, xfa);
+#pragma unroll
+        for (int s = 0; s < STEPS; s += 2) {     // STEPS is even
+            step<0, true>(s, smem, xb, wb, l, wfa, xfa, wfb, xfb, acc);
+            zero_pad(s + 1, q, xfb);
+            if (s + 2 < STEPS) {
+                step<0, true>(s + 1, smem, xb, wb, l, wfb, xfb, wfa, xfa, acc);
+                zero_pad(s + 2, q, xfa);
+            } else {
+                step<0, false>(s + 1, smem, xb, wb, l, wfb, xfb, wfa, xfa, acc);
+            }
+        }
+    }
+};
+
+// ---- input staging (the ConvDev scheme with a 12 x 36 halo tile and 512 threads) -----------------------
+struct TileSrc {
+    __amdgpu_buffer_rsrc_t r0, r1, rst;
+    int gy0, gx0, soff;
+    bool interior;
+};
+__device__ __forceinline__ TileSrc tile_src(const PairArgs& a, int b, int y0, int x0) {
+    const size_t img = (size_t)a.H * a.W * C;
+    const unsigned bytes = (unsigned)(img * ES);
+    TileSrc t;
+    t.r0 = make_rsrc(a.in0 + (size_t)b * img, bytes);
+    t.r1 = make_rsrc(a.in1 ? a.in1 + (size_t)b * img : nullptr, a.in1 ? bytes : 0u);
+    t.rst = make_rsrc(a.in_store ? a.in_store + (size_t)b * img : nullptr, a.in_store ? bytes : 0u);
+    t.gy0 = y0 - 2; t.gx0 = x0 - 2;
+    t.soff = (t.gy0 * a.W + t.gx0) * C * ES;
+    t.interior = t.gy0 >= 0 && t.gx0 >= 0 && t.gy0 + IH <= a.H && t.gx0 + IW <= a.W;
+    return t;
+}
+struct TileOffs { int o[NI]; int ctr[NI]; };
+__device__ __forceinline__ void tile_offsets(const PairArgs& a, int tid, TileOffs& t) {
+    const int v = tid % VPP, p0 = tid / VPP;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int pix = p0 + k * PPP;
+        const int py = pix / IW, px = pix - py * IW;
+        const bool center = py >= 2 && py < 2 + OTH && px >= 2 && px < 2 + OTW;
+        t.o[k] = (tid < ACTIVE && pix < NIN) ? ((py * a.W + px) * C + v * 8) * ES : kOOB;
+        t.ctr[k] = center ? t.o[k] : kOOB;
+    }
+}
+__device__ __forceinline__ int border_off(const PairArgs& a, const TileSrc& t, int tid, int k, bool& center) {
+    const int v = tid % VPP, pix = tid / VPP + k * PPP;
+    const int py = pix / IW, px = pix - py * IW;
+    const int gy = t.gy0 + py, gx = t.gx0 + px;
+    center = py >= 2 && py < 2 + OTH && px >= 2 && px < 2 + OTW;
+    const bool ok = tid < ACTIVE && pix < NIN && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    return ok ? ((gy * a.W + gx) * C + v * 8) * ES : kOOB;
+}
+template <bool GATED>
+__device__ __forceinline__ void load_interior(const TileSrc& t, const TileOffs& to, uint4 (&r0)[NI], uint4 (&r1)[GATED ? NI : 1]) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        r0[k] = buf_load16(t.r0, to.o[k], t.soff);
+        if constexpr (GATED) r1[k] = buf_load16(t.r1, to.o[k], t.soff);
+    }
+}
+template <bool GATED>
+__device__ __forceinline__ void load_border(const PairArgs& a, const TileSrc& t, int tid, uint4 (&r0)[NI], uint4 (&r1)[GATED ? NI : 1]) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        bool center;
+        const int off = border_off(a, t, tid, k, center);
+        r0[k] = buf_load16(t.r0, off, 0);
+        if constexpr (GATED) r1[k] = buf_load16(t.r1, off, 0);
+    }
+}
+template <bool GATED>
+__device__ __forceinline__ void load_gate(const PairArgs& a, int b, int tid, float (&gv)[GATED ? 8 : 1]) {
+    if constexpr (GATED) {
+        const int c0 = (tid % VPP) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = tid < ACTIVE ? a.in_gate[(size_t)b * C + c0 + e] : 0.f;
+    }
+}
+template <bool GATED>
+__device__ __forceinline__ void commit(const PairArgs& a, const TileSrc& t, const TileOffs& to, int tid, const uint4 (&r0)[NI],
+                                       const uint4 (&r1)[GATED ? NI : 1], const float (&gv)[GATED ? 8 : 1], char* smem) {
+    const int v = tid % VPP, p0 = tid / VPP;
+    char* dst = smem + OFF_IN + p0 * SPIX + v * 16;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int pix = p0 + k * PPP;
+        uint4 raw = r0[k];
+        if constexpr (GATED) {
+            float f0[8], f1[8];
+            Vec16<bf16_t>::unpack(r0[k], f0);
+            Vec16<bf16_t>::unpack(r1[k], f1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f0[e] = f0[e] * gv[e] + f1[e];       // zero-filled lanes stay 0
+            raw = Vec16<bf16_t>::pack(f0);
+            if (t.interior) {
+                buf_store16(t.rst, to.ctr[k], t.soff, raw);                   // rst has 0 records if in_store == NULL
+            } else {
+                bool center;
+                const int off = border_off(a, t, tid, k, center);
+                buf_store16(t.rst, center ? off : kOOB, 0, raw);
+            }
+        }
+        if (tid < ACTIVE && pix < NIN) *reinterpret_cast<uint4*>(dst + k * PPP * SPIX) = raw;
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float s) {
+    return s + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_sum16(float s) {
+    s = dpp_add<0xB1>(s); s = dpp_add<0x4E>(s); s = dpp_add<0x141>(s); s = dpp_add<0x140>(s);
+    return s;
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------------
+template <bool GATED, int E1, int E2>
+__global__ __launch_bounds__(THREADS) void conv_pair_kernel(const PairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_bias = reinterpret_cast<float*>(smem + OFF_BIAS);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, n = lane & 15;
+
+    // both weight matrices + biases, once per block (1 KiB per wave-instruction by LDS-DMA)
+    for (int kb = w; kb < 2 * STEPS * NT; kb += WAVES) {
+        const char* src = kb < STEPS * NT ? static_cast<const char*>(a.w1) + kb * 1024 : static_cast<const char*>(a.w2) + (kb - STEPS * NT) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(smem + kb * 1024), 16, 0, 0);
+    }
+    if (tid < 2 * C) s_bias[tid] = tid < C ? (a.b1 ? a.b1[tid] : 0.f) : (a.b2 ? a.b2[tid - C] : 0.f);
+
+    // phase-1 geometry: this wave's mid pixel tiles t = w, w+8, w+16 (linear 16-pixel runs of the 10 x 34 grid)
+    const int npt1 = w + 16 < N_MID_TILES ? 3 : 2;                 // wave-uniform
+    int xb1[3], mid_dst[3], my[3], mx[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = 16 * (w + 8 * i) + n;
+        const int jc = j < NMID ? j : NMID - 1;                    // dummy lanes read a valid pixel, write nothing
+        my[i] = jc / MW; mx[i] = jc - my[i] * MW;
+        xb1[i] = OFF_IN + (my[i] * IW + mx[i]) * SPIX;
+        mid_dst[i] = j < NMID ? OFF_MID + j * SPIX + q * (NV * ES) : -1;
+    }
+    int xb2[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) xb2[h] = OFF_MID + (w * MW + 16 * h + n) * SPIX;
+    const int wb1 = OFF_W1 + lane * 16, wb2 = OFF_W2 + lane * 16;
+
+    TileOffs to;
+    tile_offsets(a, tid, to);
+
+    const int sp_total = a.tiles_x * a.tiles_y;
+    const int n_tiles = sp_total * a.batch;
+    const int slots = gridDim.x >> 3;                              // gridDim.x is a multiple of 8
+    const int pos = (blockIdx.x & 7) * slots + (blockIdx.x >> 3);  // XCD x takes a run of consecutive (band-major) tiles
+    const int stride = (int)gridDim.x;
+    const int my_tiles = pos < n_tiles ? (n_tiles - pos + stride - 1) / stride : 0;
+
+    auto decode = [&](int tile, int& b, int& sp, int& y0, int& x0) {
+        b = fast_div(tile, sp_total, a.inv_sp_total);
+        int ty, tx;
+        band_decode(tile - b * sp_total, a.tiles_x, a.tiles_y, a.inv_band, ty, tx);
+        sp = ty * a.tiles_x + tx; y0 = ty * OTH; x0 = tx * OTW;
+    };
+
+    uint4 r0[NI], r1[GATED ? NI : 1];
+    float gv[GATED ? 8 : 1];
+    TileSrc ts;
+    int nb = 0, nsp = 0, ny0 = 0, nx0 = 0;                         // the tile whose input is in registers / in flight
+    if (my_tiles > 0) {                                            // tile 0 straight into LDS
+        decode(pos, nb, nsp, ny0, nx0);
+        ts = tile_src(a, nb, ny0, nx0);
+        load_gate<GATED>(a, nb, tid, gv);
+        if (ts.interior) load_interior<GATED>(ts, to, r0, r1); else load_border<GATED>(a, ts, tid, r0, r1);
+        commit<GATED>(a, ts, to, tid, r0, r1, gv, smem);
+    }
+    int cb = nb, csp = nsp, cy0 = ny0, cx0 = nx0;                  // the tile being computed
+    if (my_tiles > 1) {
+        decode(pos + stride, nb, nsp, ny0, nx0);
+        ts = tile_src(a, nb, ny0, nx0);
+        load_gate<GATED>(a, nb, tid, gv);
+        if (ts.interior) load_interior<GATED>(ts, to, r0, r1);
+    }
+    __syncthreads();                                               // weights, biases, tile 0 visible
+
+    const float inf = __builtin_inff();
+    const bool rec = a.dbg != nullptr && blockIdx.x == 8 && w == 0 && lane == 0;
+    for (int k = 0; k < my_tiles; ++k) {
+        const long long t0 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        long long t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+        // ------------------------------------------------ phase 1: mid = act1(conv1(x)) on the 10 x 34 ring tile
+        {
+            f32x4 acc[3][NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 t4 = *reinterpret_cast<const float4*>(s_bias + q * NV + nt * 4);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc[i][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
+            }
+            if (npt1 == 3) {
+                PairMma<IW, 3>::run(smem, xb1, wb1, q, acc);
+            } else {
+                int xb[2] = {xb1[0], xb1[1]};
+                f32x4 acc2[2][NT];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc2[i][nt] = acc[i][nt];
+                PairMma<IW, 2>::run(smem, xb, wb1, q, acc2);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[i][nt] = acc2[i][nt];
+            }
+            t1 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            float fs[NV], ft[NV];
+            if constexpr (E1 == E1_FILM_LEAKY) {
+#pragma unroll
+                for (int e = 0; e < NV; e += 4) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(a.film_scale + (size_t)cb * C + q * NV + e);
+                    const float4 t4 = *reinterpret_cast<const float4*>(a.film_shift + (size_t)cb * C + q * NV + e);
+                    fs[e] = s4.x; fs[e + 1] = s4.y; fs[e + 2] = s4.z; fs[e + 3] = s4.w;
+                    ft[e] = t4.x; ft[e + 1] = t4.y; ft[e + 2] = t4.z; ft[e + 3] = t4.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (i < npt1) {                                    // wave-uniform
+                    float v[NV];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[i][nt][r];
+                    if constexpr (E1 == E1_FILM_LEAKY) {
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) {
+                            v[e] = v[e] * fs[e] + ft[e] + v[e];
+                            v[e] = __builtin_amdgcn_fmed3f(v[e], v[e] * a.slope, inf);   // 0 <= slope <= 1 (host)
+                        }
+                    }
+                    // conv2 zero-pads its input: mid pixels outside the image are 0, not conv1 of the padding
+                    const int gy = cy0 - 1 + my[i], gx = cx0 - 1 + mx[i];
+                    const bool inside = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                    unsigned wd[NV / 2];
+#pragma unroll
+                    for (int e = 0; e < NV / 2; ++e) {
+                        wd[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                        if constexpr (E1 == E1_RELU) {
+                            typedef short s16x2 __attribute__((ext_vector_type(2)));
+                            const s16x2 z = {0, 0};
+                            wd[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, wd[e]), z));
+                        }
+                        wd[e] = inside ? wd[e] : 0u;
+                    }
+                    if (mid_dst[i] >= 0) {
+#pragma unroll
+                        for (int e = 0; e < NV / 2; e += 2) *reinterpret_cast<uint2*>(smem + mid_dst[i] + 4 * e) = make_uint2(wd[e], wd[e + 1]);
+                    }
+                }
+            }
+        }
+        t2 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        __syncthreads();                                           // A: mid tile complete; the input tile is free
+        t3 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+
+        // ------------------------------------------------ stage tile k+1's input, then phase 2
+        // (staggering the two halves of the block -- lower waves stage first, upper waves last -- measured 6 % SLOWER)
+        const int pb = nb, psp = nsp, py0 = ny0, px0 = nx0;        // tile k+1 (valid if k+1 < my_tiles)
+        auto stage = [&]() {
+        if (k + 1 < my_tiles) {
+                if (!ts.interior) load_border<GATED>(a, ts, tid, r0, r1);              // border tiles are not prefetched
+                commit<GATED>(a, ts, to, tid, r0, r1, gv, smem);
+                if (k + 2 < my_tiles) {
+                    decode(pos + (k + 2) * stride, nb, nsp, ny0, nx0);
+                    ts = tile_src(a, nb, ny0, nx0);
+                    load_gate<GATED>(a, nb, tid, gv);
+                    if (ts.interior) load_interior<GATED>(ts, to, r0, r1);
+                }
+            }
+
+        };
+        auto phase2 = [&]() {
+        // ------------------------------------------------ phase 2: out = conv2(mid) (+ residual, + channel sums)
+            {
+                f32x4 acc[2][NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(s_bias + C + q * NV + nt * 4);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) acc[h][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
+                }
+                PairMma<MW, 2>::run(smem, xb2, wb2, q, acc);
+                t5 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+
+                const size_t img = (size_t)a.H * a.W * C;
+                const unsigned img_bytes = (unsigned)(img * ES);
+                const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out + (size_t)cb * img, img_bytes);
+                const int gy = cy0 + w;
+                float csum[NV];
+#pragma unroll
+                for (int e = 0; e < NV; ++e) csum[e] = 0.f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int gx = cx0 + 16 * h + n;
+                    const bool valid = gy < a.H && gx < a.W;
+                    const int off = valid ? ((gy * a.W + gx) * C + q * NV) * ES : kOOB;
+                    float v[NV];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[h][nt][r];
+                    if constexpr (E2 == E2_RES) {
+                        float m[NV];
+                        buf_load_row<bf16_t, NV>(make_rsrc(a.residual + (size_t)cb * img, img_bytes), off, m);
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) v[e] += m[e];
+                    }
+                    if constexpr (E2 == E2_SUMS) {
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) csum[e] += valid ? v[e] : 0.f;
+                    }
+                    buf_store_row<bf16_t, NV, false>(r_out, off, v);
+                }
+                if constexpr (E2 == E2_SUMS) {
+                    // one partial per wave (slot = 8*tile + wave); rc_ca_gate folds them in fixed order
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) csum[e] = row_sum16(csum[e]);
+                    if (n == 0) {
+                        float* dst = a.chan_sums + (((size_t)cb * sp_total + csp) * WAVES + w) * C + q * NV;
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) dst[e] = csum[e];
+                    }
+                }
+            }
+        };
+        t4 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        stage();
+        phase2();
+        cb = pb; csp = psp; cy0 = py0; cx0 = px0;
+        t6 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        __syncthreads();                                           // B: input tile k+1 visible; mid tile free
+        if (rec && k < 60) {
+            long long* d = a.dbg + 8 * k;
+            d[0] = t1 - t0; d[1] = t2 - t1; d[2] = t3 - t2; d[3] = t4 - t3; d[4] = t5 - t4; d[5] = t6 - t5;
+            d[6] = (long long)__builtin_amdgcn_s_memtime() - t6;
+        }
+    }
+}
+
+template <bool GATED, int E1, int E2>
+int launch(const PairArgs& a, int num_cus, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<GATED, E1, E2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_set = true;
+    }
+    const int n_tiles = a.tiles_x * a.tiles_y * a.batch;
+    int grid = num_cus < n_tiles ? num_cus : n_tiles;
+    grid = (grid + 7) / 8 * 8;
+    hipLaunchKernelGGL((conv_pair_kernel<GATED, E1, E2>), dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, stream, a);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+}  // namespace pair
+long long* conv_dbg_ptr();
+void conv_prof_begin(double flops, hipStream_t stream, void** token);
+void conv_prof_end(void* token, hipStream_t stream);
+}  // namespace rc
+
+using namespace rc;
+
+extern "C" {
+
+size_t rc_conv_pair_desc_size(void) { return sizeof(rc_conv_pair_desc); }
+
+int rc_conv_pair_sum_slots(int height, int width) { return pair::WAVES * ceil_div(height, pair::OTH) * ceil_div(width, pair::OTW); }
+
+int rc_conv_pair(const rc_conv_pair_desc* d, void* stream_) {
+    RC_REQUIRE(d != nullptr, "rc_conv_pair: null desc");
+    RC_REQUIRE(d->channels == pair::C && d->dtype == RC_BF16, "rc_conv_pair: built for 48 channels, bf16 (use two rc_conv2d calls otherwise)");
+    RC_REQUIRE(d->batch >= 1 && d->height >= 1 && d->width >= 1, "rc_conv_pair: empty tensor");
+    RC_REQUIRE(d->in0 && d->w1 && d->w2 && d->out, "rc_conv_pair: null in0/w1/w2/out");
+    RC_REQUIRE(d->act1 == RC_ACT_RELU || d->act1 == RC_ACT_LEAKY, "rc_conv_pair: act1 must be ReLU, or LeakyReLU with FiLM");
+    if (d->act1 == RC_ACT_LEAKY) {
+        RC_REQUIRE(d->film_scale && d->film_shift, "rc_conv_pair: LeakyReLU form needs film_scale/film_shift (Res_GFM)");
+        RC_REQUIRE(d->act1_slope >= 0.f && d->act1_slope <= 1.f, "rc_conv_pair: slope must be in [0, 1]");
+        RC_REQUIRE(d->in_gate == nullptr && d->chan_sums == nullptr, "rc_conv_pair: FiLM form takes no gate / sums");
+    } else {
+        RC_REQUIRE(!d->film_scale && !d->film_shift, "rc_conv_pair: FiLM needs act1 = LeakyReLU");
+        RC_REQUIRE(d->residual == nullptr, "rc_conv_pair: the ReLU form takes no residual");
+    }
+    if (d->in_gate) RC_REQUIRE(d->in1 != nullptr, "rc_conv_pair: in_gate needs in1 (the skip tensor)");
+    auto aligned16 = [](const void* q) { return q == nullptr || reinterpret_cast<uintptr_t>(q) % 16 == 0; };
+    RC_REQUIRE(aligned16(d->in0) && aligned16(d->in1) && aligned16(d->in_store) && aligned16(d->out) && aligned16(d->residual) &&
+               aligned16(d->film_scale) && aligned16(d->film_shift), "rc_conv_pair: tensors must be 16-byte aligned");
+    RC_REQUIRE((double)d->height * d->width * pair::C * 4.0 < 2147483647.0, "rc_conv_pair: one image must be < 2 GiB");
+    RC_REQUIRE(d->batch * (double)ceil_div(d->height, pair::OTH) * ceil_div(d->width, pair::OTW) < (double)(1 << 24), "rc_conv_pair: too many tiles");
+
+    pair::PairArgs a{};
+    a.batch = d->batch; a.H = d->height; a.W = d->width;
+    a.in0 = static_cast<const bf16_t*>(d->in0); a.in1 = static_cast<const bf16_t*>(d->in1);
+    a.in_gate = d->in_gate; a.in_store = static_cast<bf16_t*>(d->in_store);
+    a.w1 = d->w1; a.b1 = d->b1; a.film_scale = d->film_scale; a.film_shift = d->film_shift; a.slope = d->act1_slope;
+    a.w2 = d->w2; a.b2 = d->b2;
+    a.residual = static_cast<const bf16_t*>(d->residual); a.out = static_cast<bf16_t*>(d->out); a.chan_sums = d->chan_sums;
+    a.tiles_x = ceil_div(d->width, pair::OTW); a.tiles_y = ceil_div(d->height, pair::OTH);
+    a.inv_band = 1.0f / (float)(kBandRows * a.tiles_x);
+    a.inv_sp_total = 1.0f / (float)(a.tiles_x * a.tiles_y);
+    a.dbg = conv_dbg_ptr();
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int dev = 0;
+        RC_HIP_CHECK(hipGetDevice(&dev));
+        RC_HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    hipStream_t stream = as_stream(stream_);
+    void* tok = nullptr;
+    conv_prof_begin(2.0 * 2.0 * d->batch * d->height * d->width * 9.0 * pair::C * pair::C, stream, &tok);
+    int rcode;
+    const bool gated = d->in_gate != nullptr;
+    if (d->act1 == RC_ACT_LEAKY)
+        rcode = d->residual ? pair::launch<false, pair::E1_FILM_LEAKY, pair::E2_RES>(a, num_cus, stream)
+                            : pair::launch<false, pair::E1_FILM_LEAKY, pair::E2_PLAIN>(a, num_cus, stream);
+    else if (d->chan_sums)
+        rcode = gated ? pair::launch<true, pair::E1_RELU, pair::E2_SUMS>(a, num_cus, stream) : pair::launch<false, pair::E1_RELU, pair::E2_SUMS>(a, num_cus, stream);
+    else
+        rcode = gated ? pair::launch<true, pair::E1_RELU, pair::E2_PLAIN>(a, num_cus, stream) : pair::launch<false, pair::E1_RELU, pair::E2_PLAIN>(a, num_cus, stream);
+    conv_prof_end(tok, stream);
+    return rcode;
+}
+
+}  // extern "C"

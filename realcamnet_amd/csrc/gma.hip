@@ -24,83 +24,106 @@ __device__ __forceinline__ float hardswish(float x) {
 
 // ---- depth-wise KxK conv on channel sub-ranges of NHWC tensors ---------------------------------------
 // y[b,p, y_c0 + r*y_rep + c] = bias[r*w_rep + c] + sum_t wT[t][r*w_rep + c] * x[b, p+t, x_c0 + r*x_rep + c] (+ x[..] itself)
-// wT is tap-major (K*K, n_w) so a thread's UNIT weights per tap are one contiguous load.
-// Each thread produces DW_PX consecutive output pixels of one 16-byte channel vector.  Per kernel row the
-// K + DW_PX - 1 input vectors are loaded once into registers and reused by all taps and outputs; the tap-major
-// weights live in LDS (read as 16-byte vectors), so the inner loop is pure FMA.  kvec (optional, one int per
-// weight vector) gives the true window of that vector when taps are zero-padded to a common K (ConvRelPosEnc
-// mixes 3/5/7 windows): padded taps are skipped, never multiplied.
-constexpr int DW_PX = 4;
+// wT is tap-major (K*K, n_w).  kvec (optional, one int per weight vector) gives the true window of that vector when
+// taps are zero-padded to a common K (ConvRelPosEnc mixes 3/5/7 windows): padded taps are skipped, never multiplied.
+//
+// LDS-tiled: a block owns a 16 x 32 pixel tile of VB consecutive 16-byte channel vectors (one "slot group"); the
+// halo tile is staged once (every input vector is fetched from L2/HBM once per tile instead of ~K times per
+// output through the vector L1), each wave owns ONE channel vector (so the kvec window test is wave-uniform),
+// each lane a 2-row x 4-column output patch: an input row's K+3 vectors are unpacked once and feed both output
+// rows and all taps.  The loop is FMA-bound (K*K*UNIT fused multiply-adds per output vector).
+constexpr int DW_TH = 16, DW_TW = 32, DW_PX = 4, DW_PY = 2;
 template <typename T, int K>
-__global__ __launch_bounds__(kGThreads) void dwconv2d_kernel(const T* __restrict__ x, int xs, int x_c0, T* __restrict__ y, int ys,
-                                                            int y_c0, int batch, int H, int W, int n_ch,
-                                                            const float* __restrict__ wT, int n_w, const float* __restrict__ bias,
-                                                            int n_rep, int x_rep, int y_rep, int w_rep, int add_identity,
-                                                            const int* __restrict__ kvec) {
-    constexpr int U = Vec16<T>::N, R = K / 2, NCOL = K + DW_PX - 1;
-    extern __shared__ float s_w[];                       // [K*K][n_w]
-    for (int i = threadIdx.x; i < K * K * n_w; i += blockDim.x) s_w[i] = wT[i];
+__global__ __launch_bounds__(64 * 5) void dwconv2d_kernel(const T* __restrict__ x, int xs, int x_c0, T* __restrict__ y, int ys,
+                                                          int y_c0, int batch, int H, int W, int n_ch,
+                                                          const float* __restrict__ wT, int n_w, const float* __restrict__ bias,
+                                                          int n_rep, int x_rep, int y_rep, int w_rep, int add_identity,
+                                                          const int* __restrict__ kvec, int vb, int tiles_x, int tiles_y) {
+    constexpr int U = Vec16<T>::N, R = K / 2, NCOL = K + DW_PX - 1, THH = DW_TH + 2 * R, TWH = DW_TW + 2 * R;
+    extern __shared__ __attribute__((aligned(16))) char dw_smem[];
+    const int ps = (vb | 1) * 16;                        // pixel stride: an odd number of 16-byte slots
+    float* s_w = reinterpret_cast<float*>(dw_smem);      // [K*K][vb*U]
+    char* s_x = dw_smem + K * K * vb * U * 4;            // [THH*TWH][ps]
+
+    const int vpc = n_ch / U, groups = n_rep * vpc / vb;
+    int blk = blockIdx.x;
+    const int g = blk % groups; blk /= groups;
+    const int tx = blk % tiles_x; blk /= tiles_x;
+    const int ty = blk % tiles_y;
+    const int b = blk / tiles_y;
+    const int r = (g * vb) / vpc, v0 = (g * vb) % vpc;   // vb divides vpc: a group never straddles two reps
+    const int y0 = ty * DW_TH, x0 = tx * DW_TW;
+    const int xc = x_c0 + r * x_rep + v0 * U, cw0 = r * w_rep + v0 * U;
+
+    for (int i = threadIdx.x; i < K * K * vb * U; i += blockDim.x) s_w[i] = wT[(i / (vb * U)) * n_w + cw0 + i % (vb * U)];
+    for (int i = threadIdx.x; i < THH * TWH * vb; i += blockDim.x) {
+        const int pix = i / vb, vv = i - pix * vb;
+        const int py = pix / TWH, px = pix - py * TWH;
+        const int gy = y0 + py - R, gx = x0 + px - R;
+        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+            raw = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + gy) * W + gx) * xs + xc + vv * U);
+        *reinterpret_cast<uint4*>(s_x + pix * ps + vv * 16) = raw;
+    }
     __syncthreads();
-    const int vpc = n_ch / U;
-    const int wq = (W + DW_PX - 1) / DW_PX;
-    const size_t total = (size_t)batch * H * wq * n_rep * vpc;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int v = (int)(i % vpc);
-        const int r = (int)((i / vpc) % n_rep);
-        const size_t p = i / ((size_t)vpc * n_rep);
-        const int qx = (int)(p % wq), py = (int)((p / wq) % H), b = (int)(p / ((size_t)wq * H));
-        const int px0 = qx * DW_PX;
-        const int cw = r * w_rep + v * U;
-        const int Rv = kvec ? kvec[cw / U] / 2 : R;      // this vector's true half-window
-        float acc[DW_PX][U];
+
+    const int vv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave = channel vector
+    const int lane = threadIdx.x & 63, rp = lane >> 3, cq = lane & 7;
+    const int cw = cw0 + vv * U;
+    const int Rv = kvec ? kvec[cw / U] / 2 : R;          // this vector's true half-window (wave-uniform)
+    float acc[DW_PY][DW_PX][U];
 #pragma unroll
-        for (int o = 0; o < DW_PX; ++o)
+    for (int e = 0; e < U; ++e) {
+        const float bv = bias ? bias[cw + e] : 0.f;
 #pragma unroll
-            for (int e = 0; e < U; ++e) acc[o][e] = bias ? bias[cw + e] : 0.f;
-        const int xc = x_c0 + r * x_rep + v * U;
+        for (int o = 0; o < DW_PY; ++o)
 #pragma unroll
-        for (int dy = 0; dy < K; ++dy) {
-            const int gy = py + dy - R;
-            const bool row_ok = gy >= 0 && gy < H && dy >= R - Rv && dy <= R + Rv;
-            const T* row = x + (((size_t)b * H + (row_ok ? gy : 0)) * W) * xs + xc;
-            float f[NCOL][U];
+            for (int c = 0; c < DW_PX; ++c) acc[o][c][e] = bv;
+    }
+    const char* base = s_x + ((DW_PY * rp) * TWH + DW_PX * cq) * ps + vv * 16;
+    const float* wbase = s_w + vv * U;
 #pragma unroll
-            for (int cidx = 0; cidx < NCOL; ++cidx) {
-                const int gx = px0 + cidx - R;
-                uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-                if (row_ok && gx >= 0 && gx < W) raw = *reinterpret_cast<const uint4*>(row + (size_t)gx * xs);
-                Vec16<T>::unpack(raw, f[cidx]);
+    for (int iy = 0; iy < K + DW_PY - 1; ++iy) {         // input row iy of this lane's patch feeds output row o with dy = iy - o
+        if (iy + 1 < R - Rv || iy > R + Rv + DW_PY - 1) continue;          // outside every output row's window (uniform)
+        float f[NCOL][U];
+#pragma unroll
+        for (int c = 0; c < NCOL; ++c) Vec16<T>::unpack(*reinterpret_cast<const uint4*>(base + (iy * TWH + c) * ps), f[c]);
+#pragma unroll
+        for (int o = 0; o < DW_PY; ++o) {
+            const int dy = iy - o;
+            if (dy < 0 || dy >= K) continue;                               // compile-time after unrolling
+            if (dy < R - Rv || dy > R + Rv) continue;                      // uniform
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+                if (dx < R - Rv || dx > R + Rv) continue;                  // uniform
+                float wv[U];
+                const float* wp = wbase + (dy * K + dx) * vb * U;
+#pragma unroll
+                for (int e = 0; e < U; e += 4) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(wp + e);
+                    wv[e] = t4.x; wv[e + 1] = t4.y; wv[e + 2] = t4.z; wv[e + 3] = t4.w;
+                }
+#pragma unroll
+                for (int c = 0; c < DW_PX; ++c)
+#pragma unroll
+                    for (int e = 0; e < U; ++e) acc[o][c][e] = __builtin_fmaf(wv[e], f[c + dx][e], acc[o][c][e]);
             }
-            if (row_ok) {
+            if (add_identity && dy == R) {
 #pragma unroll
-                for (int dx = 0; dx < K; ++dx) {
-                    if (dx >= R - Rv && dx <= R + Rv) {
-                        float wv[U];
-                        const float* wp = s_w + (dy * K + dx) * n_w + cw;
+                for (int c = 0; c < DW_PX; ++c)
 #pragma unroll
-                        for (int e = 0; e < U; e += 4) {
-                            const float4 t4 = *reinterpret_cast<const float4*>(wp + e);
-                            wv[e] = t4.x; wv[e + 1] = t4.y; wv[e + 2] = t4.z; wv[e + 3] = t4.w;
-                        }
-#pragma unroll
-                        for (int o = 0; o < DW_PX; ++o)
-#pragma unroll
-                            for (int e = 0; e < U; ++e) acc[o][e] += wv[e] * f[o + dx][e];
-                    }
-                }
-                if (add_identity && dy == R) {
-#pragma unroll
-                    for (int o = 0; o < DW_PX; ++o)
-#pragma unroll
-                        for (int e = 0; e < U; ++e) acc[o][e] += f[o + R][e];
-                }
+                    for (int e = 0; e < U; ++e) acc[o][c][e] += f[c + R][e];
             }
         }
-#pragma unroll
-        for (int o = 0; o < DW_PX; ++o)
-            if (px0 + o < W)
-                *reinterpret_cast<uint4*>(y + (((size_t)b * H + py) * W + px0 + o) * ys + y_c0 + r * y_rep + v * U) = Vec16<T>::pack(acc[o]);
     }
+#pragma unroll
+    for (int o = 0; o < DW_PY; ++o)
+#pragma unroll
+        for (int c = 0; c < DW_PX; ++c) {
+            const int gy = y0 + DW_PY * rp + o, gx = x0 + DW_PX * cq + c;
+            if (gy < H && gx < W)
+                *reinterpret_cast<uint4*>(y + (((size_t)b * H + gy) * W + gx) * ys + y_c0 + r * y_rep + (v0 + vv) * U) = Vec16<T>::pack(acc[o][c]);
+        }
 }
 
 // ---- LayerNorm over the channel dim of (tokens, C); 16 lanes per token -------------------------------
@@ -465,13 +488,28 @@ int rc_dwconv2d(const void* d_x, int x_stride_c, int x_c0, void* d_y, int y_stri
                "rc_dwconv2d: channel counts/offsets must be multiples of 16 bytes");
     RC_REQUIRE(x_c0 + (n_rep - 1) * x_rep_stride + n_ch <= x_stride_c && y_c0 + (n_rep - 1) * y_rep_stride + n_ch <= y_stride_c &&
                (n_rep - 1) * w_rep_stride + n_ch <= n_w, "rc_dwconv2d: channel range exceeds tensor");
-    const size_t total = (size_t)batch * H * ((W + DW_PX - 1) / DW_PX) * n_rep * (n_ch / U);
-    const size_t lds = (size_t)ksize * ksize * n_w * sizeof(float);
-    RC_REQUIRE(lds <= 64 * 1024 && n_w % 4 == 0, "rc_dwconv2d: weight table too large for LDS");
+    const int vpc = n_ch / U;
+    int vb = 1;                                           // channel vectors (= waves) per block: largest divisor of vpc <= 5
+    for (int c = 5; c >= 1; --c) if (vpc % c == 0) { vb = c; break; }
+    const int tiles_x = ceil_div(W, DW_TW), tiles_y = ceil_div(H, DW_TH);
+    const int R = ksize / 2;
+    const size_t lds = (size_t)ksize * ksize * vb * U * 4 + (size_t)(DW_TH + 2 * R) * (DW_TW + 2 * R) * (vb | 1) * 16;
+    const size_t blocks = (size_t)tiles_x * tiles_y * batch * (n_rep * vpc / vb);
+    RC_REQUIRE(blocks < (1ull << 31), "rc_dwconv2d: too many tiles");
+    RC_REQUIRE(n_w % 4 == 0, "rc_dwconv2d: n_w must be a multiple of 4");
 #define RC_DW_LAUNCH(TT, KK)                                                                                              \
-    hipLaunchKernelGGL((dwconv2d_kernel<TT, KK>), dim3(pw_grid(total)), dim3(kGThreads), lds, as_stream(stream),           \
-                       static_cast<const TT*>(d_x), x_stride_c, x_c0, static_cast<TT*>(d_y), y_stride_c, y_c0, batch, H, W, \
-                       n_ch, d_wT, n_w, d_bias, n_rep, x_rep_stride, y_rep_stride, w_rep_stride, add_identity, d_kvec)
+    do {                                                                                                                  \
+        static bool attr_set = false;                                                                                     \
+        if (!attr_set) {                                                                                                  \
+            RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv2d_kernel<TT, KK>),                     \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                    \
+            attr_set = true;                                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL((dwconv2d_kernel<TT, KK>), dim3((unsigned)blocks), dim3(64 * vb), lds, as_stream(stream),      \
+                           static_cast<const TT*>(d_x), x_stride_c, x_c0, static_cast<TT*>(d_y), y_stride_c, y_c0, batch, \
+                           H, W, n_ch, d_wT, n_w, d_bias, n_rep, x_rep_stride, y_rep_stride, w_rep_stride, add_identity,  \
+                           d_kvec, vb, tiles_x, tiles_y);                                                                 \
+    } while (0)
 #define RC_DW_K(TT) if (ksize == 3) RC_DW_LAUNCH(TT, 3); else if (ksize == 5) RC_DW_LAUNCH(TT, 5); else RC_DW_LAUNCH(TT, 7);
     if (dtype == RC_F32) { RC_DW_K(float) } else { RC_DW_K(bf16_t) }
 #undef RC_DW_K

@@ -227,11 +227,17 @@ class RCABlock(HipModule):
         mods = list(self.res)
         if not (len(mods) == 3 and isinstance(mods[0], Conv2d) and _is_act(mods[1]) and isinstance(mods[2], Conv2d)):
             raise NotImplementedError("RCABlock: only mode 'CRC'/'CLC' is on the hot path")
-        t = mods[0]._nhwc(a, **_act_args(mods[1]), **first_conv_kw)
-        stored = None
-        if isinstance(t, tuple):
-            t, stored = t
-        r, sums = mods[2]._nhwc(t, want_sums=True)
+        if isinstance(mods[1], nn.ReLU) and ops.conv_pair_ok(a, mods[0], mods[2]):
+            # both convs in one launch, the ReLU'd intermediate never leaves LDS
+            res = ops.conv_pair(a, mods[0], mods[2], act="relu", want_sums=True, **first_conv_kw)
+            stored = res[1] if len(res) == 3 else None
+            r, sums = res[0], res[-1]
+        else:
+            t = mods[0]._nhwc(a, **_act_args(mods[1]), **first_conv_kw)
+            stored = None
+            if isinstance(t, tuple):
+                t, stored = t
+            r, sums = mods[2]._nhwc(t, want_sums=True)
         gate = ops.ca_gate(sums, a.shape[1] * a.shape[2], self.ca)
         return r, gate, stored
 

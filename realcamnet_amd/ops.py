@@ -14,7 +14,7 @@ import torch
 
 from . import _lib
 from ._lib import (RC_ACT_GELU, RC_ACT_LEAKY, RC_ACT_NONE, RC_ACT_RELU, RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC,
-                   RC_OUT_PIXEL_SHUFFLE2, ConvDesc, check)
+                   RC_OUT_PIXEL_SHUFFLE2, ConvDesc, ConvPairDesc, check)
 
 _DT = {torch.float32: RC_F32, torch.bfloat16: RC_BF16}
 
@@ -251,6 +251,67 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
         sums = torch.empty((b, nt, pc.cout), dtype=torch.float32, device=dev)
         d.chan_sums = sums.data_ptr()
     check(lib().rc_conv2d(C.byref(d), _stream()), "rc_conv2d")
+    extras = [t for t in (stored, sums) if t is not None]
+    return (out, *extras) if extras else out
+
+
+# conv -> act -> conv pairs (RCABlock.res, Res_GFM) as ONE launch with the intermediate in LDS (rc_conv_pair).
+# Off by default: bit-identical to two launches and half their HBM traffic, but measured slower on MI355X in round 1
+# (1.62 vs 1.52 ms per 4K x8 pair; gated 2.34 vs 2.06): its phases serialise on two block-wide barriers per tile and
+# the MFMA pipe sits at 55 %.  DESIGN.md section 4.3 has the phase breakdown and what a pipelined version needs.
+FUSE_PAIR = False
+
+
+def conv_pair_ok(x: torch.Tensor, m1, m2) -> bool:
+    """rc_conv_pair is built for the flagship shape: two 3x3 48->48 convolutions on bf16 NHWC maps."""
+    return (FUSE_PAIR and x.dtype == torch.bfloat16 and x.shape[-1] == 48 and
+            all(m.weight.dim() == 4 and tuple(m.weight.shape) == (48, 48, 3, 3) for m in (m1, m2)))
+
+
+def conv_pair(x: torch.Tensor, m1, m2, *, act: str = "relu", slope: float = 0.0,
+              film: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+              gate: Optional[torch.Tensor] = None, skip: Optional[torch.Tensor] = None, store_input: bool = False,
+              residual: Optional[torch.Tensor] = None, want_sums: bool = False):
+    """out = conv(m2)(act(conv(m1)(x)))  (+ residual, + channel partial sums) in one launch; operands as conv2d.
+    Returns out, or (out, [stored_input], [chan_sums])."""
+    for m in (m1, m2):
+        check_conv_module(m)
+    x = _req(x, "conv_pair input")
+    b, H, W, c = x.shape
+    p1, p2 = packed_conv(m1, x.dtype, RC_OUT_NHWC), packed_conv(m2, x.dtype, RC_OUT_NHWC)
+    d = ConvPairDesc()
+    d.batch, d.height, d.width, d.channels, d.dtype = b, H, W, c, p1.dtype
+    d.in0 = x.data_ptr()
+    stored = None
+    if gate is not None:
+        if skip is None:
+            raise ValueError("gate needs skip")
+        skip, gate = _req(skip, "skip"), _req(gate, "gate")
+        if skip.shape != x.shape or skip.dtype != x.dtype or gate.shape != (b, c) or gate.dtype != torch.float32:
+            raise ValueError("gate/skip shape or dtype mismatch")
+        d.in1, d.in_gate = skip.data_ptr(), gate.data_ptr()
+        if store_input:
+            stored = torch.empty_like(x)
+            d.in_store = stored.data_ptr()
+    d.w1, d.b1, d.w2, d.b2 = p1.wpacked.data_ptr(), _ptr(p1.bias), p2.wpacked.data_ptr(), _ptr(p2.bias)
+    if film is not None:
+        fs, ft = (_req(t, "film") for t in film)
+        if fs.shape != (b, c) or ft.shape != (b, c) or fs.dtype != torch.float32 or ft.dtype != torch.float32:
+            raise ValueError("film tensors must be fp32 (B, C)")
+        d.film_scale, d.film_shift = fs.data_ptr(), ft.data_ptr()
+    d.act1, d.act1_slope = _ACT[act], float(slope)
+    if residual is not None:
+        residual = _req(residual, "residual")
+        if residual.shape != x.shape or residual.dtype != x.dtype:
+            raise ValueError("residual must match the input tensor")
+        d.residual = residual.data_ptr()
+    out = torch.empty_like(x)
+    d.out = out.data_ptr()
+    sums = None
+    if want_sums:
+        sums = torch.empty((b, lib().rc_conv_pair_sum_slots(H, W), c), dtype=torch.float32, device=x.device)
+        d.chan_sums = sums.data_ptr()
+    check(lib().rc_conv_pair(C.byref(d), _stream()), "rc_conv_pair")
     extras = [t for t in (stored, sums) if t is not None]
     return (out, *extras) if extras else out
 

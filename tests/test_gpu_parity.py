@@ -303,3 +303,94 @@ def test_conv_exact_on_small_integer_data(hip, dt, persist, shape):
     finally:
         hip.rc_debug_set(b"persist", 1)
     assert torch.equal(y, ref)
+
+
+def _pair_case(hip, H, W, b, mode, seed):
+    """Run conv -> act -> conv fused (rc_conv_pair) and as two rc_conv2d launches on the same data."""
+    g = torch.Generator().manual_seed(seed)
+    dt = torch.bfloat16
+    c1, c2 = N.Conv2d(48, 48, 3, 1, 1), N.Conv2d(48, 48, 3, 1, 1)
+    for c in (c1, c2):
+        c.weight.data = torch.randn(c.weight.shape, generator=g) * 0.05
+        c.bias.data = torch.randn(48, generator=g) * 0.1
+        c.to(DEV, dt).eval()
+    x = (torch.randn(b, H, W, 48, generator=g)).to(DEV, dt)
+    kw1, kw2 = {}, {}
+    if mode == "gated":
+        kw1 = dict(gate=torch.rand(b, 48, generator=g).to(DEV), skip=torch.randn(b, H, W, 48, generator=g).to(DEV, dt), store_input=True)
+    if mode == "film":
+        film = (torch.randn(b, 48, generator=g).to(DEV) * 0.5, torch.randn(b, 48, generator=g).to(DEV) * 0.5)
+        fused = ops.conv_pair(x, c1, c2, act="leaky", slope=0.01, film=film, residual=x)
+        t = ops.conv2d(x, c1, act="leaky", slope=0.01, film=film)
+        return (fused,), (ops.conv2d(t, c2, residual=x),)
+    sums = mode != "plain"
+    fused = ops.conv_pair(x, c1, c2, act="relu", want_sums=sums, **kw1)
+    t = ops.conv2d(x, c1, act="relu", **kw1)
+    stored = None
+    if isinstance(t, tuple):
+        t, stored = t
+    ref = ops.conv2d(t, c2, want_sums=sums)
+    fused = fused if isinstance(fused, tuple) else (fused,)
+    ref = ref if isinstance(ref, tuple) else (ref,)
+    if stored is not None:
+        ref = (ref[0], stored, *ref[1:])
+    return fused, ref
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["plain", "sums", "gated", "film"])
+@pytest.mark.parametrize("shape", [(5, 7, 1), (37, 70, 2), (64, 96, 1), (8, 32, 3), (90, 200, 1)])
+def test_conv_pair_equals_two_convs(hip, mode, shape):
+    """The fused pair keeps the bf16 intermediate in LDS: same unit map, same accumulation order, same rounding
+    points as two rc_conv2d launches, so the feature maps are bit-identical (ragged, multi-tile, border and
+    interior tiles); the channel partial sums differ only in how they are split, so their totals agree."""
+    H, W, b = shape
+    fused, ref = _pair_case(hip, H, W, b, mode, seed=H * 131 + W)
+    assert torch.equal(fused[0], ref[0])
+    if mode == "gated":
+        assert torch.equal(fused[1], ref[1])
+    if mode in ("sums", "gated"):
+        fs, rs = fused[-1].double().sum(1), ref[-1].double().sum(1)
+        assert torch.allclose(fs, rs, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_conv_pair_vs_fp32_reference(hip):
+    """Against plain fp32 PyTorch on the CPU (bf16 tolerance 3e-2 of max|ref|, as for the single layers)."""
+    g = torch.Generator().manual_seed(7)
+    c1, c2 = N.Conv2d(48, 48, 3, 1, 1), N.Conv2d(48, 48, 3, 1, 1)
+    x = torch.randn(2, 48, 40, 72, generator=g)
+    with torch.no_grad():
+        ref = F.conv2d(F.relu(F.conv2d(x, c1.weight, c1.bias, padding=1)), c2.weight, c2.bias, padding=1)
+    c1.to(DEV, torch.bfloat16); c2.to(DEV, torch.bfloat16)
+    out = ops.conv_pair(ops.to_nhwc(x.to(DEV, torch.bfloat16)), c1, c2, act="relu")
+    assert rel_err(ops.to_nchw(out).float().cpu(), ref) < 3e-2
+
+
+@pytest.mark.gpu
+def test_conv_pair_rejects_other_shapes(hip):
+    c = N.Conv2d(64, 64, 3, 1, 1).to(DEV, torch.bfloat16)
+    x = torch.zeros(1, 8, 32, 64, device=DEV, dtype=torch.bfloat16)
+    old, ops.FUSE_PAIR = ops.FUSE_PAIR, True
+    try:
+        assert not ops.conv_pair_ok(x, c, c)
+    finally:
+        ops.FUSE_PAIR = old
+    with pytest.raises(RuntimeError, match="48 channels"):
+        ops.conv_pair(x, c, c)
+
+
+def test_end_to_end_with_fused_pairs_vs_reference_golden(hip):
+    """The optional rc_conv_pair path (ops.FUSE_PAIR) through the whole flagship net: same golden, same bar."""
+    fixture = [f for f in golden_names("e2e_") if "GFM_LSC" in f][0]
+    g = load_golden(fixture)
+    net = net_on_gpu("LiteISPNet_GFM_LSC", torch.bfloat16)
+    dt = torch.bfloat16
+    old, ops.FUSE_PAIR = ops.FUSE_PAIR, True
+    try:
+        with torch.no_grad():
+            y = net([g["raw"].to(DEV, dt), g["cond"].to(DEV, dt), g["coord"].to(DEV, dt)])
+        torch.cuda.synchronize()
+    finally:
+        ops.FUSE_PAIR = old
+    assert O.psnr(y.float().cpu(), g["y"]) >= 50.0

@@ -5,7 +5,7 @@ import re, sys
 path, key = sys.argv[1], sys.argv[2]
 minn = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 lines = open(path).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and l.rstrip().split(":")[0].endswith("E") and ":" in l)
+start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and ":" in l and not l.startswith("_ZN2rc.*\$"))
 end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
 def cat(op):
     if "mfma" in op: return "mfma"
