@@ -259,6 +259,9 @@ int rc_debug_set(const char* key, int value);
 /* "conv_phase_timing": device buffer of >= 512 int64; the producer/consumer conv kernel then records s_memtime
  * cycle counts per tile phase for one compute wave and one loader wave (NULL switches it off). */
 int rc_debug_set_ptr(const char* key, void* d_ptr);
+/* Calibration: sustained rate of back-to-back v_mfma_f32_16x16x32_bf16 on every SIMD (1 or 2 waves per SIMD),
+ * and s_memtime ticks per MFMA per SIMD: what this part's clocks allow, to read MFMA utilisation against. */
+int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma);
 int rc_prof_enable(int on);
 int rc_prof_collect(int64_t* n_launches, double* total_ms, double* total_flops);
 

@@ -74,6 +74,7 @@ _SIGS = {
     "rc_conv_sum_tiles": (C.c_int, [_I, _I]),
     "rc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "rc_conv_desc_size": (_SZ, []),
+    "rc_debug_mfma_peak": (C.c_int, [_I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rc_conv_pair": (C.c_int, [C.POINTER(ConvPairDesc), _P]),
     "rc_conv_pair_sum_slots": (C.c_int, [_I, _I]),
     "rc_conv_pair_desc_size": (_SZ, []),

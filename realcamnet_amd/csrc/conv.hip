@@ -19,6 +19,8 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
     if (dtype == RC_BF16) {
         if (cin <= 8) p->ck = 8;
         else if (ksize == 1 && cin % 80 == 0 && cin % 64 != 0) p->ck = 80;   // GroupMix dims (80, 240, 320 -> 64)
+        else if (ksize == 3 && cin % 64 == 0 && cin > 64) p->ck = 32;         // multi-chunk layers: 32-channel chunks so two
+                                                                               // input + two weight buffers fit one CU's LDS
         else if (cin % 64 == 0) p->ck = 64;
         else if (cin % 48 == 0) p->ck = 48;
         else p->ck = 16;
@@ -270,6 +272,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
         a.dbg_flags = g_dbg_flags;
         a.inv_band = 1.0f / (float)(kBandRows * a.tiles_x);
         a.inv_sp_total = 1.0f / (float)(a.tiles_x * a.tiles_y);
+        a.inv_n_ct = 1.0f / (float)a.n_ct;
     }
 
     hipStream_t stream = as_stream(stream_);

@@ -3,6 +3,7 @@
 namespace rc {
 int conv_bf16_k3_ck8(int nt, const ConvArgs& a, hipStream_t s);
 int conv_bf16_k3_ck16(int nt, const ConvArgs& a, hipStream_t s);
+int conv_bf16_k3_ck32(int nt, const ConvArgs& a, hipStream_t s);
 int conv_bf16_k3_ck48(int nt, const ConvArgs& a, hipStream_t s);
 int conv_bf16_k3_ck64(int nt, const ConvArgs& a, hipStream_t s);
 int conv_bf16_k1_ck8(int nt, const ConvArgs& a, hipStream_t s);
@@ -18,6 +19,7 @@ int conv_f32_k1_ck16(int nt, const ConvArgs& a, hipStream_t s);
 int dispatch_conv(bool bf16, int ksize, int ck, int nt, const ConvArgs& a, hipStream_t s) {
     if (bf16 && ksize == 3 && ck == 8) return conv_bf16_k3_ck8(nt, a, s);
     if (bf16 && ksize == 3 && ck == 16) return conv_bf16_k3_ck16(nt, a, s);
+    if (bf16 && ksize == 3 && ck == 32) return conv_bf16_k3_ck32(nt, a, s);
     if (bf16 && ksize == 3 && ck == 48) return conv_bf16_k3_ck48(nt, a, s);
     if (bf16 && ksize == 3 && ck == 64) return conv_bf16_k3_ck64(nt, a, s);
     if (bf16 && ksize == 1 && ck == 8) return conv_bf16_k1_ck8(nt, a, s);

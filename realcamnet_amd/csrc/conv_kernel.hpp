@@ -41,7 +41,7 @@ struct ConvArgs {
     float* chan_sums; int cout_packed;
     int num_cus; int persist_ok;
     int ep_key;                        // epilogue_fast feature mask, or -1 for the generic epilogue (ep_key_for)
-    float inv_band, inv_sp_total;      // reciprocals for the persistent kernel's tile decode
+    float inv_band, inv_sp_total, inv_n_ct;   // reciprocals for the persistent kernels' tile decode
     long long* dbg;                    // optional phase-timing buffer (rc_debug_set_ptr), normally NULL
     int dbg_flags;                     // knock-out experiments (rc_debug_set "conv_flags"): 1 no stores, 2 no MFMA, 4 no tile loads
 };
@@ -75,17 +75,17 @@ __host__ __device__ constexpr bool unit_map(int upt, int taps, int s, int q, int
     return u < taps * upt;
 }
 
-template <typename T, int CK_, int NT_, int KS_>
+template <typename T, int CK_, int NT_, int KS_, int TH_ = kTH>
 struct ConvCfg {
     using elem = T;
-    static constexpr int CK = CK_, NT = NT_, KS = KS_;
+    static constexpr int CK = CK_, NT = NT_, KS = KS_, TH = TH_;   // TH: pixel-tile rows staged per block (2 per compute wave)
     static constexpr int UNIT = 16 / (int)sizeof(T);
     static_assert(CK % UNIT == 0, "CK must be a whole number of 16-byte units");
     static constexpr int UPT = CK / UNIT;         // units per tap
     static constexpr int TAPS = KS * KS;
     static constexpr int STEPS = unit_map_steps(UPT, TAPS);  // MFMA steps per Cin chunk
     static constexpr int HALO = KS / 2;
-    static constexpr int THH = kTH + 2 * HALO, TWH = kTW + 2 * HALO;
+    static constexpr int THH = TH + 2 * HALO, TWH = kTW + 2 * HALO;
     static constexpr int SPIX = pix_stride_bytes(CK * (int)sizeof(T));
     static constexpr int IN_BYTES = THH * TWH * SPIX;
     static constexpr int G_RAW = (80 * 1024 - IN_BYTES) / (NT * 1024);
@@ -309,7 +309,7 @@ struct ConvDev {
         for (int k = 0; k < NI; ++k) {
             const int pix = p0 + k * PPP;
             const int py = pix / TWH, px = pix - py * TWH;
-            const bool center = py >= HALO && py < HALO + kTH && px >= HALO && px < HALO + kTW;
+            const bool center = py >= HALO && py < HALO + Cfg::TH && px >= HALO && px < HALO + kTW;
             t.o[k] = (live && pix < NPIX) ? ((py * a.W + px) * a.cin + v * UNIT) * ES : kOOB;
             t.ctr[k] = center ? t.o[k] : kOOB;
         }
@@ -320,7 +320,7 @@ struct ConvDev {
         const int py = pix / TWH, px = pix - py * TWH;
         const int gy = t.gy0 + py, gx = t.gx0 + px;
         const int c0 = chunk * CK + v * UNIT;
-        center = py >= HALO && py < HALO + kTH && px >= HALO && px < HALO + kTW;
+        center = py >= HALO && py < HALO + Cfg::TH && px >= HALO && px < HALO + kTW;
         const bool ok = live && pix < NPIX && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && c0 < a.cin;
         return ok ? ((gy * a.W + gx) * a.cin + c0) * ES : kOOB;
     }
@@ -409,7 +409,7 @@ struct ConvDev {
             const int py = pix / TWH, px = pix - py * TWH;
             const int gy = y0 + py - HALO, gx = x0 + px - HALO;
             const int c0 = chunk * CK + v * UNIT;
-            const bool center = py >= HALO && py < HALO + kTH && px >= HALO && px < HALO + kTW;
+            const bool center = py >= HALO && py < HALO + Cfg::TH && px >= HALO && px < HALO + kTW;
             uint4 raw = make_uint4(0u, 0u, 0u, 0u);
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && c0 < a.cin) {
                 const size_t off = (img_base + (size_t)gy * a.W + gx) * a.cin + c0;
@@ -1066,6 +1066,167 @@ __global__ __launch_bounds__(kWsThreads) void conv_mfma_ws_kernel(const ConvArgs
     }
 }
 
+// ==================================================================================================
+// Kernel 4: producer/consumer form for MULTI-chunk layers (Cin = several CK-channel chunks: the 128/192/512-channel
+// levels of the U-Net).  Calibration (rc_debug_mfma_peak): ONE wave per SIMD issuing nothing but independent
+// MFMAs sustains 59 % of the matrix peak, two waves 91 % -- so this kernel runs 8 compute waves (two per SIMD) on
+// a 16 x 32 pixel tile beside 4 loader waves, 12 waves = 768 threads, one block per CU.  The block walks a flat
+// list of stages = (tile, cout tile, Cin chunk); every stage has two halves separated by a barrier:
+//
+//            compute waves 0-7                          loader waves 8-11
+//   half a   MFMA steps [0, SA) of stage g   (Wa, in[g&1])     issue loads Wa(g+1), tile(g+1);  Wb(g) registers -> LDS
+//   barrier
+//   half b   MFMA steps [SA, STEPS)          (Wb, in[g&1])     issue loads Wb(g+1);  Wa(g+1), tile(g+1) -> LDS in[(g+1)&1]
+//            (+ epilogue on an item's last chunk)
+//   barrier
+//
+// so the packed weights are single-buffered BY HALVES (each half is rewritten while the other is being read) and
+// only the input tile is double-buffered: 36 + 2 x 57 KB of LDS.  Everything the loaders fetch is a plain buffer load
+// issued one half-stage before it is needed (with an LDS-DMA in flight hipcc's barrier would wait vmcnt(0) and drain
+// the prefetch; plain loads survive a __syncthreads()).  The general kernel (one block per (tile, cout tile), loads
+// in front of the MFMAs, weights by LDS-DMA in sub-stages) left the matrix pipe at ~50 % on these layers.
+// For the epilogue each half of the block is an ordinary 8 x 32 tile: same code, same CALayer partial-sum slots.
+// ==================================================================================================
+constexpr int kWsmThreads = 768, kWsmTH = 16, kWsmCompute = 512;
+template <class Cfg>
+using WsmCfg = ConvCfg<typename Cfg::elem, Cfg::CK, Cfg::NT, Cfg::KS, kWsmTH>;
+template <class Cfg>
+constexpr int wsm_lds_bytes() { return (int)Cfg::CHUNK_W_BYTES + kPersistMaxCout * 4 + 2 * WsmCfg<Cfg>::IN_BYTES; }
+
+template <class Cfg8, bool GATED, bool FAST>
+__global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvArgs a) {
+    using Cfg = WsmCfg<Cfg8>;
+    using D = ConvDev<Cfg>;                                          // staging + MFMA pieces on the 16-row tile
+    using D8 = ConvDev<Cfg8>;                                        // epilogue: each half is an 8-row tile
+    constexpr int NT = Cfg::NT, STEPS = Cfg::STEPS, NV = 4 * NT;
+    constexpr int SA = (STEPS + 1) / 2;                              // steps in half a
+    constexpr int WA = SA * NT * 1024, WB = (STEPS - SA) * NT * 1024, WALL = (int)Cfg::CHUNK_W_BYTES;
+    constexpr int NWA = (WA / 16 + kThreads - 1) / kThreads, NWB = (WB / 16 + kThreads - 1) / kThreads;
+    static_assert(STEPS >= 2 && WA + WB == WALL, "weight halves");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_w = smem;                                                // weights first: ds_read immediates < 64 KiB
+    float* s_bias = reinterpret_cast<float*>(smem + WALL);
+    char* s_in0 = smem + WALL + kPersistMaxCout * 4;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave12 >= 8;
+    const int q = lane >> 4, n = lane & 15;
+
+    const int tiles_y = (a.H + kWsmTH - 1) / kWsmTH;                 // 16-row tiles (a.tiles_y counts 8-row tiles)
+    const int sp_total = a.tiles_x * tiles_y;
+    const int n_items = sp_total * a.batch * a.n_ct;                // item = (tile, cout tile); ct fastest: the
+    const int slots = gridDim.x >> 3;                               // n_ct items of a tile reuse its input through L2
+    const int pos = (blockIdx.x & 7) * slots + (blockIdx.x >> 3);
+    const int stride = (int)gridDim.x;
+    const int my_items = pos < n_items ? (n_items - pos + stride - 1) / stride : 0;
+    const int n_chunks = a.n_chunks;
+    const int my_stages = my_items * n_chunks;
+    const float inv_sp_total = 1.0f / (float)sp_total;
+
+    for (int i = tid; i < a.cout_packed; i += kWsmThreads) s_bias[i] = a.bias ? a.bias[i] : 0.f;
+
+    auto decode = [&](int item, int& b, int& ty, int& tx, int& ct) {
+        const int tile = fast_div(item, a.n_ct, a.inv_n_ct);
+        ct = item - tile * a.n_ct;
+        b = fast_div(tile, sp_total, inv_sp_total);
+        band_decode(tile - b * sp_total, a.tiles_x, tiles_y, a.inv_band, ty, tx);
+    };
+
+    if (loader) {
+        // ---------------------------------------------------------------- producer waves
+        const int rtid = tid - kWsmCompute;                          // 0..255
+        uint4 r0[D::NI], r1[GATED ? D::NI : 1], wra[NWA], wrb[NWB];
+        float gv[GATED ? D::UNIT : 1];
+        typename D::TileSrc ts;
+        typename D::TileOffs to;
+        D::tile_offsets(a, rtid, to);
+        int woa[NWA], wob[NWB];                                      // this thread's 16-byte pieces of the two weight halves
+#pragma unroll
+        for (int k = 0; k < NWA; ++k) woa[k] = (k * kThreads + rtid) * 16 < WA ? (k * kThreads + rtid) * 16 : kOOB;
+#pragma unroll
+        for (int k = 0; k < NWB; ++k) wob[k] = (k * kThreads + rtid) * 16 < WB ? WA + (k * kThreads + rtid) * 16 : kOOB;
+        const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpacked, (unsigned)((size_t)a.n_ct * n_chunks * WALL));
+        ConvArgs aa = a;                                             // per-item view: only ct == 0 materialises a gated input
+
+        int item_k = 0, chunk = 0;                                   // stage whose Wa / tile loads are issued next
+        int b = 0, ty = 0, tx = 0, ct = 0;
+        int wsoff = 0, c_chunk = 0;                                  // weight offset / chunk of the stage in registers
+        auto issue_a = [&]() {                                       // Wa + input tile of stage (item_k, chunk) -> registers
+            if (chunk == 0) {
+                decode(pos + item_k * stride, b, ty, tx, ct);
+                aa.in_store = ct == 0 ? a.in_store : nullptr;
+                ts = D::tile_src(aa, b, ty * kWsmTH, tx * kTW);
+            }
+            D::template load_tile<GATED>(aa, ts, to, b, chunk, rtid, r0, r1, gv);
+            wsoff = (ct * n_chunks + chunk) * WALL;
+#pragma unroll
+            for (int k = 0; k < NWA; ++k) wra[k] = buf_load16(r_w, woa[k], wsoff);
+            c_chunk = chunk;
+            if (++chunk == n_chunks) { chunk = 0; ++item_k; }
+        };
+        auto issue_b = [&]() {                                       // Wb of the stage issue_a fetched last
+#pragma unroll
+            for (int k = 0; k < NWB; ++k) wrb[k] = buf_load16(r_w, wob[k], wsoff);
+        };
+        auto commit_a = [&](int buf) {
+            D::template commit_tile<GATED>(aa, ts, to, c_chunk, rtid, r0, r1, gv, s_in0 + buf * Cfg::IN_BYTES);
+#pragma unroll
+            for (int k = 0; k < NWA; ++k)
+                if (woa[k] != kOOB) *reinterpret_cast<uint4*>(s_w + woa[k]) = wra[k];
+        };
+        auto commit_b = [&]() {
+#pragma unroll
+            for (int k = 0; k < NWB; ++k)
+                if (wob[k] != kOOB) *reinterpret_cast<uint4*>(s_w + wob[k]) = wrb[k];
+        };
+
+        if (my_stages > 0) { issue_a(); commit_a(0); issue_b(); }
+        __syncthreads();                                             // barrier 0: bias, Wa(0), tile(0) visible
+        for (int g = 0; g < my_stages; ++g) {
+            // every load is issued at the START of a half and consumed one half later: a whole half of latency budget
+            if (g + 1 < my_stages) issue_a();                        // half a: fetch Wa(g+1), tile(g+1) ...
+            commit_b();                                              //         ... and write Wb(g); the computers read Wa(g)
+            __syncthreads();
+            if (g + 1 < my_stages) { issue_b(); commit_a((g + 1) & 1); }   // half b: fetch Wb(g+1); write Wa(g+1), tile(g+1)
+            __syncthreads();
+        }
+    } else {
+        // ---------------------------------------------------------------- consumer waves (two per SIMD)
+        const int wave = wave12;                                     // 0..7: rows 2*wave, 2*wave+1 of the 16-row tile
+        typename D::LaneOff lo;
+        D::lane_offsets(q, lo);
+        const int lane_x = ((2 * wave) * D::TWH + n) * D::SPIX;
+        const int lane_w = lane * 16;
+        __syncthreads();                                             // barrier 0
+        int g = 0;
+        for (int k = 0; k < my_items; ++k) {
+            int b, ty, tx, ct;
+            decode(pos + k * stride, b, ty, tx, ct);
+            f32x4 acc[4][NT];                                        // initial C operand = bias
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 t4 = *reinterpret_cast<const float4*>(s_bias + ct * Cfg::COUT_TILE + q * NV + nt * 4);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
+            }
+            for (int c = 0; c < n_chunks; ++c, ++g) {
+                const char* s_in = s_in0 + (g & 1) * Cfg::IN_BYTES;
+                D::template mma_steps<0, SA, 0, true>(s_in, s_w, lane_x, lane_w, q, lo, acc);
+                __syncthreads();
+                D::template mma_steps<SA, STEPS - SA, 0, true>(s_in, s_w, lane_x, lane_w, q, lo, acc);
+                if (c + 1 < n_chunks) __syncthreads();
+            }
+            // each half of the block (waves 0-3 / 4-7) stores as an ordinary 8 x 32 tile
+            const int ty8 = 2 * ty + (wave >> 2);
+            if (ty8 < a.tiles_y)
+                D8::template epilogue<FAST>(a, b, ty8 * kTH, tx * kTW, ty8 * a.tiles_x + tx, ct, tid & 255, acc);
+            __syncthreads();
+        }
+    }
+}
+
 template <class Cfg>
 constexpr int ws_lds_bytes() { return 2 * Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + 16 * Cfg::NT * 4; }
 
@@ -1094,6 +1255,26 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
             if (grid > n_tiles) grid = n_tiles;
             grid = (grid + 7) / 8 * 8;
             hipLaunchKernelGGL((conv_mfma_ws_kernel<Cfg, GATED, FAST>), dim3((unsigned)grid), dim3(kWsThreads), WS_LDS, stream, a);
+            RC_HIP_CHECK(hipGetLastError());
+            return RC_OK;
+        }
+    }
+    constexpr int WSM_LDS = wsm_lds_bytes<Cfg>();
+    // multi-chunk producer/consumer form (not for gated inputs: its loader would need > 168 VGPRs at 12 waves per CU)
+    if constexpr (WSM_LDS <= 160 * 1024 && Cfg::KS == 3 && Cfg::STEPS >= 2 && !GATED) {
+        if (a.n_chunks > 1 && a.cin_vec_ok && a.cin_chunk_ok && a.persist_ok && a.cout_packed <= kPersistMaxCout &&
+            (double)n_tiles * a.n_ct < (double)(1 << 24)) {
+            const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch * a.n_ct;
+            static bool attr_set = false;
+            if (!attr_set) {
+                RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_wsm_kernel<Cfg, GATED, FAST>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, WSM_LDS));
+                attr_set = true;
+            }
+            int grid = a.num_cus;
+            if (grid > n_items) grid = n_items;
+            grid = (grid + 7) / 8 * 8;
+            hipLaunchKernelGGL((conv_mfma_wsm_kernel<Cfg, GATED, FAST>), dim3((unsigned)grid), dim3(kWsmThreads), WSM_LDS, stream, a);
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }

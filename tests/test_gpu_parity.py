@@ -394,3 +394,42 @@ def test_end_to_end_with_fused_pairs_vs_reference_golden(hip):
     finally:
         ops.FUSE_PAIR = old
     assert O.psnr(y.float().cpu(), g["y"]) >= 50.0
+
+
+@pytest.mark.parametrize("persist", [1, 0])
+@pytest.mark.parametrize("gated", [False, True])
+@pytest.mark.parametrize("shape", [(128, 64, 16, 40), (192, 192, 9, 33), (512, 128, 8, 32), (192, 48, 24, 70), (128, 128, 37, 100)])
+def test_multichunk_conv_exact_on_integer_data(hip, persist, gated, shape):
+    """Cin = several 32-channel chunks (the 128/192/512-channel U-Net levels): the producer/consumer kernel that
+    streams input and weight chunks through double-buffered LDS (persist=1) and the general kernel (persist=0) must
+    both equal F.conv2d bit for bit on integer data (all sums < 256: exact in bf16), with and without the fused
+    CALayer gate + skip input, on ragged multi-tile images."""
+    cin, cout, h, w = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    c = N.Conv2d(cin, cout, 3, 1, 1)
+    with torch.no_grad():
+        sparse = (torch.rand(c.weight.shape, generator=g) < 96.0 / cin).float()     # keeps every sum below 256
+        c.weight.copy_(torch.randint(-1, 2, c.weight.shape, generator=g).float() * sparse)
+        c.bias.copy_(torch.randint(-2, 3, c.bias.shape, generator=g).float())
+    x = torch.randint(-1, 2, (2, cin, h, w), generator=g).float()
+    kw, xin = {}, x
+    if gated:   # x = r * gate + skip with gate in {0, 1, 2}: still small integers
+        r = torch.randint(-1, 2, (2, cin, h, w), generator=g).float()
+        gate = torch.randint(0, 2, (2, cin), generator=g).float()
+        xin = r * gate[:, :, None, None] + x
+    ref = F.conv2d(xin, c.weight.detach(), c.bias.detach(), padding=1)
+    assert ref.abs().max() <= 256
+    assert hip.rc_debug_set(b"persist", persist) == 0
+    try:
+        c = c.to(DEV, torch.bfloat16)
+        with torch.no_grad():
+            if gated:
+                y, stored = ops.conv2d(ops.to_nhwc(r.to(DEV, torch.bfloat16)), c, gate=gate.to(DEV),
+                                       skip=ops.to_nhwc(x.to(DEV, torch.bfloat16)), store_input=True)
+                assert torch.equal(ops.to_nchw(stored).float().cpu(), xin)
+            else:
+                y = ops.conv2d(ops.to_nhwc(x.to(DEV, torch.bfloat16)), c)
+            y = ops.to_nchw(y).float().cpu()
+    finally:
+        hip.rc_debug_set(b"persist", 1)
+    assert torch.equal(y, ref)

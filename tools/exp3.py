@@ -2,9 +2,9 @@ import os, sys, time, subprocess, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from realcamnet_amd import networks as N, ops
-c = N.Conv2d(48, 48, 3, 1, 1).to("cuda", torch.bfloat16)
-x = torch.rand(8, 1088, 1920, 48, device="cuda").to(torch.bfloat16)
-ops.lib().rc_debug_set(b"persist", 3)
+CIN, H, W = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (48, 1088, 1920)))
+c = N.Conv2d(CIN, CIN, 3, 1, 1).to("cuda", torch.bfloat16)
+x = torch.rand(8, H, W, CIN, device="cuda").to(torch.bfloat16)
 for _ in range(2): ops.conv2d(x, c, act="relu")
 torch.cuda.synchronize()
 def smi(tag):
@@ -16,11 +16,11 @@ time.sleep(2)
 evs = [torch.cuda.Event(enable_timing=True) for _ in range(13)]
 evs[0].record()
 for i in range(12):
-    for _ in range(50): ops.conv2d(x, c, act="relu")
+    for _ in range(25): ops.conv2d(x, c, act="relu")
     evs[i + 1].record()
 th = threading.Thread(target=lambda: smi("load")); th.start()
 torch.cuda.synchronize(); th.join()
-print("ms/iter per block of 50:", [round(evs[i].elapsed_time(evs[i + 1]) / 50, 3) for i in range(12)])
+print("ms/iter per block of 25:", [round(evs[i].elapsed_time(evs[i + 1]) / 25, 3) for i in range(12)])
 time.sleep(3)
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
 e0.record(); ops.conv2d(x, c, act="relu"); e1.record(); torch.cuda.synchronize()
