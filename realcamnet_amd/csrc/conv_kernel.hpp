@@ -1067,11 +1067,12 @@ __global__ __launch_bounds__(kWsThreads) void conv_mfma_ws_kernel(const ConvArgs
 }
 
 // ==================================================================================================
-// Kernel 4: producer/consumer form for MULTI-chunk layers (Cin = several CK-channel chunks: the 128/192/512-channel
-// levels of the U-Net).  Calibration (rc_debug_mfma_peak): ONE wave per SIMD issuing nothing but independent
+// Kernel 4: producer/consumer form for layers whose weights do not fit LDS at once: several Cin chunks (the
+// 128/192/512-channel levels of the U-Net) and/or several cout tiles (48 -> 192 + PixelShuffle).  Calibration (rc_debug_mfma_peak): ONE wave per SIMD issuing nothing but independent
 // MFMAs sustains 59 % of the matrix peak, two waves 91 % -- so this kernel runs 8 compute waves (two per SIMD) on
 // a 16 x 32 pixel tile beside 4 loader waves, 12 waves = 768 threads, one block per CU.  The block walks a flat
-// list of stages = (tile, cout tile, Cin chunk); every stage has two halves separated by a barrier:
+// list of stages = (tile, cout tile, Cin chunk) -- a tile's cout tiles and chunks back to back, so its input comes
+// from this XCD's L2 after the first touch; every stage has two halves separated by a barrier:
 //
 //            compute waves 0-7                          loader waves 8-11
 //   half a   MFMA steps [0, SA) of stage g   (Wa, in[g&1])     issue loads Wa(g+1), tile(g+1);  Wb(g) registers -> LDS
@@ -1116,20 +1117,27 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
 
     const int tiles_y = (a.H + kWsmTH - 1) / kWsmTH;                 // 16-row tiles (a.tiles_y counts 8-row tiles)
     const int sp_total = a.tiles_x * tiles_y;
-    const int n_items = sp_total * a.batch * a.n_ct;                // item = (tile, cout tile); ct fastest: the
-    const int slots = gridDim.x >> 3;                               // n_ct items of a tile reuse its input through L2
+    const int n_tiles = sp_total * a.batch;
+    const int n_chunks = a.n_chunks, n_ct = a.n_ct;
+    // Work units.  One Cin chunk: unit = tile, staged once and reused by all its cout tiles.  Several chunks: every
+    // stage stages a fresh chunk anyway, so unit = (tile, cout tile), cout tile fastest -- finer grains balance the
+    // small deep levels (72 tiles per image at 136 x 240) and the run of units one XCD takes shares tiles through L2.
+    const bool one_chunk = n_chunks == 1;
+    const int n_units = one_chunk ? n_tiles : n_tiles * n_ct;
+    const int cts_per_unit = one_chunk ? n_ct : 1;
+    const int slots = gridDim.x >> 3;                               // XCD x takes a run of consecutive units
     const int pos = (blockIdx.x & 7) * slots + (blockIdx.x >> 3);
     const int stride = (int)gridDim.x;
-    const int my_items = pos < n_items ? (n_items - pos + stride - 1) / stride : 0;
-    const int n_chunks = a.n_chunks;
-    const int my_stages = my_items * n_chunks;
+    const int my_units = pos < n_units ? (n_units - pos + stride - 1) / stride : 0;
+    const int my_stages = my_units * cts_per_unit * n_chunks;
     const float inv_sp_total = 1.0f / (float)sp_total;
 
     for (int i = tid; i < a.cout_packed; i += kWsmThreads) s_bias[i] = a.bias ? a.bias[i] : 0.f;
 
-    auto decode = [&](int item, int& b, int& ty, int& tx, int& ct) {
-        const int tile = fast_div(item, a.n_ct, a.inv_n_ct);
-        ct = item - tile * a.n_ct;
+    auto decode = [&](int unit, int& b, int& ty, int& tx, int& ct0) {
+        int tile = unit;
+        ct0 = 0;
+        if (!one_chunk) { tile = fast_div(unit, n_ct, a.inv_n_ct); ct0 = unit - tile * n_ct; }
         b = fast_div(tile, sp_total, inv_sp_total);
         band_decode(tile - b * sp_total, a.tiles_x, tiles_y, a.inv_band, ty, tx);
     };
@@ -1147,31 +1155,36 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
         for (int k = 0; k < NWA; ++k) woa[k] = (k * kThreads + rtid) * 16 < WA ? (k * kThreads + rtid) * 16 : kOOB;
 #pragma unroll
         for (int k = 0; k < NWB; ++k) wob[k] = (k * kThreads + rtid) * 16 < WB ? WA + (k * kThreads + rtid) * 16 : kOOB;
-        const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpacked, (unsigned)((size_t)a.n_ct * n_chunks * WALL));
+        const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpacked, (unsigned)((size_t)n_ct * n_chunks * WALL));
         ConvArgs aa = a;                                             // per-item view: only ct == 0 materialises a gated input
 
-        int item_k = 0, chunk = 0;                                   // stage whose Wa / tile loads are issued next
-        int b = 0, ty = 0, tx = 0, ct = 0;
-        int wsoff = 0, c_chunk = 0;                                  // weight offset / chunk of the stage in registers
-        auto issue_a = [&]() {                                       // Wa + input tile of stage (item_k, chunk) -> registers
+        int k_unit = 0, cti = 0, ct = 0, chunk = 0, gi = 0;          // the stage whose Wa / tile loads are issued next
+        int b = 0, ty = 0, tx = 0, ct0 = 0;
+        int wsoff = 0, c_chunk = 0, c_buf = 0;                       // of the stage held in registers
+        bool c_tile = false;
+        auto issue_a = [&]() {                                       // Wa (+ input tile) of the next stage -> registers
             if (chunk == 0) {
-                decode(pos + item_k * stride, b, ty, tx, ct);
+                if (cti == 0) decode(pos + k_unit * stride, b, ty, tx, ct0);
+                ct = ct0 + cti;
                 aa.in_store = ct == 0 ? a.in_store : nullptr;
                 ts = D::tile_src(aa, b, ty * kWsmTH, tx * kTW);
             }
-            D::template load_tile<GATED>(aa, ts, to, b, chunk, rtid, r0, r1, gv);
+            c_tile = !one_chunk || cti == 0;
+            c_buf = one_chunk ? (k_unit & 1) : (gi & 1);
+            c_chunk = chunk;
+            if (c_tile) D::template load_tile<GATED>(aa, ts, to, b, chunk, rtid, r0, r1, gv);
             wsoff = (ct * n_chunks + chunk) * WALL;
 #pragma unroll
             for (int k = 0; k < NWA; ++k) wra[k] = buf_load16(r_w, woa[k], wsoff);
-            c_chunk = chunk;
-            if (++chunk == n_chunks) { chunk = 0; ++item_k; }
+            ++gi;
+            if (++chunk == n_chunks) { chunk = 0; if (++cti == cts_per_unit) { cti = 0; ++k_unit; } }
         };
         auto issue_b = [&]() {                                       // Wb of the stage issue_a fetched last
 #pragma unroll
             for (int k = 0; k < NWB; ++k) wrb[k] = buf_load16(r_w, wob[k], wsoff);
         };
-        auto commit_a = [&](int buf) {
-            D::template commit_tile<GATED>(aa, ts, to, c_chunk, rtid, r0, r1, gv, s_in0 + buf * Cfg::IN_BYTES);
+        auto commit_a = [&]() {
+            if (c_tile) D::template commit_tile<GATED>(aa, ts, to, c_chunk, rtid, r0, r1, gv, s_in0 + c_buf * Cfg::IN_BYTES);
 #pragma unroll
             for (int k = 0; k < NWA; ++k)
                 if (woa[k] != kOOB) *reinterpret_cast<uint4*>(s_w + woa[k]) = wra[k];
@@ -1182,14 +1195,14 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
                 if (wob[k] != kOOB) *reinterpret_cast<uint4*>(s_w + wob[k]) = wrb[k];
         };
 
-        if (my_stages > 0) { issue_a(); commit_a(0); issue_b(); }
+        if (my_stages > 0) { issue_a(); commit_a(); issue_b(); }
         __syncthreads();                                             // barrier 0: bias, Wa(0), tile(0) visible
         for (int g = 0; g < my_stages; ++g) {
             // every load is issued at the START of a half and consumed one half later: a whole half of latency budget
-            if (g + 1 < my_stages) issue_a();                        // half a: fetch Wa(g+1), tile(g+1) ...
+            if (g + 1 < my_stages) issue_a();                        // half a: fetch Wa(g+1) (+ tile) ...
             commit_b();                                              //         ... and write Wb(g); the computers read Wa(g)
             __syncthreads();
-            if (g + 1 < my_stages) { issue_b(); commit_a((g + 1) & 1); }   // half b: fetch Wb(g+1); write Wa(g+1), tile(g+1)
+            if (g + 1 < my_stages) { issue_b(); commit_a(); }        // half b: fetch Wb(g+1); write Wa(g+1) (+ tile)
             __syncthreads();
         }
     } else {
@@ -1201,28 +1214,29 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
         const int lane_w = lane * 16;
         __syncthreads();                                             // barrier 0
         int g = 0;
-        for (int k = 0; k < my_items; ++k) {
-            int b, ty, tx, ct;
-            decode(pos + k * stride, b, ty, tx, ct);
-            f32x4 acc[4][NT];                                        // initial C operand = bias
+        for (int k = 0; k < my_units; ++k) {
+            int b, ty, tx, ct0;
+            decode(pos + k * stride, b, ty, tx, ct0);
+            const int ty8 = 2 * ty + (wave >> 2);                    // each half of the block stores as an ordinary 8 x 32 tile
+            for (int ct = ct0; ct < ct0 + cts_per_unit; ++ct) {
+                f32x4 acc[4][NT];                                    // initial C operand = bias
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float4 t4 = *reinterpret_cast<const float4*>(s_bias + ct * Cfg::COUT_TILE + q * NV + nt * 4);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(s_bias + ct * Cfg::COUT_TILE + q * NV + nt * 4);
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
-            }
-            for (int c = 0; c < n_chunks; ++c, ++g) {
-                const char* s_in = s_in0 + (g & 1) * Cfg::IN_BYTES;
-                D::template mma_steps<0, SA, 0, true>(s_in, s_w, lane_x, lane_w, q, lo, acc);
+                    for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
+                }
+                for (int c = 0; c < n_chunks; ++c, ++g) {
+                    const char* s_in = s_in0 + (one_chunk ? (k & 1) : (g & 1)) * Cfg::IN_BYTES;
+                    D::template mma_steps<0, SA, 0, true>(s_in, s_w, lane_x, lane_w, q, lo, acc);
+                    __syncthreads();
+                    D::template mma_steps<SA, STEPS - SA, 0, true>(s_in, s_w, lane_x, lane_w, q, lo, acc);
+                    if (c + 1 < n_chunks) __syncthreads();
+                }
+                if (ty8 < a.tiles_y)
+                    D8::template epilogue<FAST>(a, b, ty8 * kTH, tx * kTW, ty8 * a.tiles_x + tx, ct, tid & 255, acc);
                 __syncthreads();
-                D::template mma_steps<SA, STEPS - SA, 0, true>(s_in, s_w, lane_x, lane_w, q, lo, acc);
-                if (c + 1 < n_chunks) __syncthreads();
             }
-            // each half of the block (waves 0-3 / 4-7) stores as an ordinary 8 x 32 tile
-            const int ty8 = 2 * ty + (wave >> 2);
-            if (ty8 < a.tiles_y)
-                D8::template epilogue<FAST>(a, b, ty8 * kTH, tx * kTW, ty8 * a.tiles_x + tx, ct, tid & 255, acc);
-            __syncthreads();
         }
     }
 }
@@ -1262,9 +1276,9 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
     constexpr int WSM_LDS = wsm_lds_bytes<Cfg>();
     // multi-chunk producer/consumer form (not for gated inputs: its loader would need > 168 VGPRs at 12 waves per CU)
     if constexpr (WSM_LDS <= 160 * 1024 && Cfg::KS == 3 && Cfg::STEPS >= 2 && !GATED) {
-        if (a.n_chunks > 1 && a.cin_vec_ok && a.cin_chunk_ok && a.persist_ok && a.cout_packed <= kPersistMaxCout &&
-            (double)n_tiles * a.n_ct < (double)(1 << 24)) {
-            const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch * a.n_ct;
+        if ((a.n_chunks > 1 || a.n_ct > 1) && a.cin_vec_ok && a.cin_chunk_ok && a.persist_ok && a.cout_packed <= kPersistMaxCout &&
+            n_tiles < (1 << 24)) {
+            const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch * (a.n_chunks > 1 ? a.n_ct : 1);
             static bool attr_set = false;
             if (!attr_set) {
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_wsm_kernel<Cfg, GATED, FAST>),
