@@ -97,6 +97,13 @@ class Lens_Shading_Correction(N.HipModule):
         )
 
     def _nhwc(self, a):
+        mods = list(self.model)
+        convs, acts = mods[0::2], mods[1::2]
+        if (all(isinstance(m, N.Conv2d) for m in convs) and all(isinstance(m, nn.LeakyReLU) for m in acts) and
+                len(mods) == 2 * len(convs) - 1):
+            slopes = [float(m.negative_slope) for m in acts]
+            if ops.pointwise_chain_ok(a, convs, slopes):       # all four layers in one launch
+                return ops.pointwise_chain(a, convs, slopes[0])
         return self.model._nhwc(a)
 
 

@@ -316,6 +316,34 @@ def conv_pair(x: torch.Tensor, m1, m2, *, act: str = "relu", slope: float = 0.0,
     return (out, *extras) if extras else out
 
 
+FUSE_CHAIN = True   # Lens_Shading_Correction's four 1x1 convolutions as one launch (rc_pointwise_chain48)
+
+
+def pointwise_chain_ok(x: torch.Tensor, convs, slopes) -> bool:
+    if not (FUSE_CHAIN and x.dtype == torch.bfloat16 and 2 <= len(convs) <= 5 and x.shape[-1] <= 4):
+        return False
+    ok = all(tuple(m.weight.shape[2:]) == (1, 1) and m.weight.shape[0] == 48 for m in convs)
+    ok = ok and convs[0].weight.shape[1] == x.shape[-1] and all(m.weight.shape[1] == 48 for m in convs[1:])
+    return ok and len(set(slopes)) == 1 and 0.0 <= slopes[0] <= 1.0 and len(slopes) == len(convs) - 1
+
+
+def pointwise_chain(x: torch.Tensor, convs, slope: float) -> torch.Tensor:
+    """convs[0] (cin0 -> 48), LeakyReLU(slope), convs[1:] (48 -> 48) with LeakyReLU between, none after the last."""
+    x = _req(x, "chain input")
+    b, H, W, cin0 = x.shape
+    first, mids = convs[0], convs[1:]
+    w0 = f32_param(first, "weight").reshape(48, cin0)
+    packs = [packed_conv(m, x.dtype, RC_OUT_NHWC) for m in mids]
+    n = len(mids)
+    wp = (C.c_void_p * n)(*[p.wpacked.data_ptr() for p in packs])
+    bp = (C.c_void_p * n)(*[_ptr(p.bias) for p in packs])
+    out = torch.empty((b, H, W, 48), dtype=x.dtype, device=x.device)
+    b0 = f32_param(first, "bias").data_ptr() if first.bias is not None else None
+    check(lib().rc_pointwise_chain48(x.data_ptr(), cin0, w0.data_ptr(), b0, wp, bp, n, float(slope), out.data_ptr(), _dt(x),
+                                     b * H * W, _stream()), "rc_pointwise_chain48")
+    return out
+
+
 def ca_gate(sums: torch.Tensor, hw: int, ca) -> torch.Tensor:
     """CALayer gate (B,C) from the conv's channel partial sums.  models/networks.py:259-269."""
     b, nt, c = sums.shape

@@ -433,3 +433,30 @@ def test_multichunk_conv_exact_on_integer_data(hip, persist, gated, shape):
     finally:
         hip.rc_debug_set(b"persist", 1)
     assert torch.equal(y, ref)
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 7), (2, 37, 70), (1, 64, 96)])
+def test_lens_shading_chain_equals_layer_by_layer(hip, shape):
+    """rc_pointwise_chain48 (all four 1x1 layers in one launch, activations in LDS) against the same module run as
+    four rc_conv2d launches: same bf16 rounding points; layer 0 is plain FMAs instead of an MFMA, so allow 1 bf16
+    ulp-scale differences (2e-2 of max|ref|), and check both against the fp32 CPU reference."""
+    b, H, W = shape
+    g = torch.Generator().manual_seed(H * 17 + W)
+    lsc = M.LiteISP.Lens_Shading_Correction(in_channels=2, out_c=48, nf=48)
+    x = torch.rand(b, 2, H, W, generator=g) * 2 - 1
+    with torch.no_grad():
+        ref = x
+        for i, m in enumerate(lsc.model):
+            ref = F.conv2d(ref, m.weight, m.bias) if isinstance(m, torch.nn.Conv2d) else F.leaky_relu(ref, m.negative_slope)
+    lsc = lsc.to(DEV, torch.bfloat16).eval()
+    xin = ops.to_nhwc(x.to(DEV, torch.bfloat16))
+    outs = {}
+    for fuse in (True, False):
+        old, ops.FUSE_CHAIN = ops.FUSE_CHAIN, fuse
+        try:
+            with torch.no_grad():
+                outs[fuse] = ops.to_nchw(lsc._nhwc(xin)).float().cpu()
+        finally:
+            ops.FUSE_CHAIN = old
+    assert rel_err(outs[True], outs[False]) < 2e-2
+    assert rel_err(outs[True], ref) < 3e-2 and rel_err(outs[False], ref) < 3e-2

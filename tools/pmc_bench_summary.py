@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-kernel-family HBM traffic (FETCH_SIZE x2 per the gfx950 correction for 16-B/lane streaming reads, WRITE_SIZE as is;
+both in KiB) from two rocprofv3 --pmc passes of the bench command.  Prints JSON.
+usage: pmc_bench_summary.py <FETCH_SIZE db> <WRITE_SIZE db>"""
+import collections, json, os, sqlite3, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rocpd_summary import demangle
+
+def per_kernel(path, counter):
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
+    ix = {c: i for i, c in enumerate(cols)}
+    kcol = "kernel_name" if "kernel_name" in ix else "name"
+    tot, seen = collections.defaultdict(float), collections.defaultdict(set)
+    for r in db.execute("select * from counters_collection"):
+        if r[ix["counter_name"]] != counter:
+            continue
+        k = demangle(r[ix[kcol]])
+        tot[k] += r[ix["value"]]
+        seen[k].add(r[ix["dispatch_id"]])
+    return {k: (v, len(seen[k])) for k, v in tot.items()}
+
+f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+out = {"units": "bytes", "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950: wide coalesced reads are tallied at half), WRITE_SIZE KiB x 1024",
+       "command": "python bench.py --steps 1 --warmup 1 --no-cpu-baseline (3 forwards: warm-up, timed, HIP-event pass)", "kernels": {}}
+conv = {"fetch": 0.0, "write": 0.0, "dispatches": 0}
+for k in sorted(set(f) | set(w)):
+    fv, fn = f.get(k, (0.0, 0)); wv, wn = w.get(k, (0.0, 0))
+    n = max(fn, wn)
+    if n == 0:
+        continue
+    e = {"dispatches": n, "fetch_bytes_per_dispatch": fv * 2048.0 / n, "write_bytes_per_dispatch": wv * 1024.0 / n}
+    out["kernels"][k] = e
+    if "conv_mfma" in k or "conv_pair" in k:
+        conv["fetch"] += fv * 2048.0; conv["write"] += wv * 1024.0; conv["dispatches"] += n
+out["conv_kernels_all"] = {"dispatches": conv["dispatches"],
+                           "hbm_bytes_per_dispatch": (conv["fetch"] + conv["write"]) / max(conv["dispatches"], 1),
+                           "fetch_bytes_total": conv["fetch"], "write_bytes_total": conv["write"]}
+tot_f = sum(v[0] for v in f.values()) * 2048.0; tot_w = sum(v[0] for v in w.values()) * 1024.0
+out["all_kernels_total_bytes"] = {"fetch": tot_f, "write": tot_w}
+print(json.dumps(out, indent=1))

@@ -18,7 +18,7 @@ _DT = {"DF16b": "bf16", "f": "f32"}
 def demangle(name: str) -> str:
     if not name.startswith("_Z"):
         return name
-    m = re.match(r"_ZN2rc(\d+)(conv_mfma(?:_persist|_ws)?_kernel)INS_7ConvCfgI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EEELb([01])E", name)
+    m = re.match(r"_ZN2rc(\d+)(conv_mfma(?:_persist|_wsm|_ws)?_kernel)INS_7ConvCfgI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)E(?:Li\d+E)?EELb([01])E", name)
     if m:
         return f"rc::{m.group(2)}<{_DT[m.group(3)]},CK={m.group(4)},NT={m.group(5)},K={m.group(6)},gated={m.group(7)}>"
     m = re.match(r"_ZN2rc(\d+)", name)          # generic rc::<kernel><dtype, ints...> (c++filt cannot parse DF16b)
