@@ -165,6 +165,18 @@ def main():
                      "kernel": "conv_mfma_kernel (all instantiations)", "launches_per_step": int(n_launch),
                      "kernel_ms_per_step": round(conv_ms, 3), "flops_per_step": conv_flops},
     }
+    # HBM traffic comes from PMC counters, which cannot be read inside a timed run: tools/pmc_bench.sh collects them in
+    # separate rocprofv3 --pmc passes of this same default command and commits the summary under profiles/
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_bench.json")
+    if cfg_name == "cfg3" and args.dtype == "bf16" and B == 8 and os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        res["roofline"]["traffic"] = round(pmc["conv_kernels_all"]["hbm_bytes_per_dispatch"])
+        res["roofline"]["traffic_note"] = ("HBM bytes per conv launch (mean over the step's conv launches), FETCH_SIZE x2 + WRITE_SIZE "
+                                           "from profiles/r01_pmc_bench.json")
+        step_bytes = (pmc["all_kernels_total_bytes"]["fetch"] + pmc["all_kernels_total_bytes"]["write"]) / pmc.get("forwards", 3)
+        res["hbm_whole_step"] = {"bytes_per_step": round(step_bytes), "achieved_TBps": round(step_bytes / (elapsed / args.steps) / 1e12, 2),
+                                 "copy_rate_TBps": pmc.get("copy_rate_TBps", 4.7), "peak_TBps": 8.0}
     if world == 1 and not args.no_cpu_baseline:
         info, (m_c, c_c, co_c, ref) = cpu_baseline(args.model, sd_cpu, (H2, W2))
         with torch.no_grad():

@@ -75,38 +75,59 @@ __global__ __launch_bounds__(256) void ca_gate_kernel(const float* __restrict__ 
 
 // ---- color_block: conv1x1 -> avgpool(3, s2, p1, count_include_pad) -> LeakyReLU(0.2) -------------
 // x NCHW (B,cin,h,w), optionally instance-normalised on load; y fp32 NCHW (B,cout,ho,wo).
+// Both stages are linear, so the pool runs FIRST, on the cin input channels (9x fewer multiply-adds than pooling
+// cout conv outputs, and each input value is fetched once per block instead of once per output channel):
+//   y = lrelu( W . (sum_valid x) / 9 + bias * n_valid / 9 )       (padded taps contribute 0, bias included)
+// A block owns 64 output pixels of one image: the pooled (cin x 64) panel is built in LDS by all 256 threads, then
+// thread (pixel, quarter) produces a quarter of the output channels.
+constexpr int CB_PX = 64;
 template <typename TI>
-__global__ void color_block_kernel(const TI* __restrict__ x, float* __restrict__ y, int batch, int cin, int cout,
-                                   int h, int w, int ho, int wo, const float* __restrict__ wgt,
-                                   const float* __restrict__ bias, const float* __restrict__ in_mean,
-                                   const float* __restrict__ in_rstd, const float* __restrict__ in_gamma,
-                                   const float* __restrict__ in_beta) {
-    const size_t total = (size_t)batch * cout * ho * wo;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ox = (int)(i % wo), oy = (int)((i / wo) % ho);
-        const int co = (int)((i / ((size_t)wo * ho)) % cout);
-        const int b = (int)(i / ((size_t)wo * ho * cout));
-        float pooled = 0.f;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = 2 * oy + dy;
-            if (yy < 0 || yy >= h) continue;
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int xx = 2 * ox + dx;
-                if (xx < 0 || xx >= w) continue;
-                float acc = bias[co];
-                for (int ci = 0; ci < cin; ++ci) {
-                    float v = to_f32(x[(((size_t)b * cin + ci) * h + yy) * w + xx]);
-                    if (in_mean != nullptr) {
-                        const size_t k = (size_t)b * cin + ci;
-                        v = (v - in_mean[k]) * in_rstd[k] * in_gamma[ci] + in_beta[ci];
-                    }
-                    acc += wgt[(size_t)co * cin + ci] * v;
+__global__ __launch_bounds__(256) void color_block_kernel(const TI* __restrict__ x, float* __restrict__ y, int batch, int cin, int cout,
+                                                          int h, int w, int ho, int wo, const float* __restrict__ wgt,
+                                                          const float* __restrict__ bias, const float* __restrict__ in_mean,
+                                                          const float* __restrict__ in_rstd, const float* __restrict__ in_gamma,
+                                                          const float* __restrict__ in_beta) {
+    extern __shared__ float cb_pooled[];                 // [cin][CB_PX] sums over the valid taps, then [CB_PX] tap counts
+    float* s_cnt = cb_pooled + (size_t)cin * CB_PX;
+    const int npx = ho * wo;
+    const int tiles = (npx + CB_PX - 1) / CB_PX;
+    const int b = blockIdx.x / tiles, p0 = (blockIdx.x % tiles) * CB_PX;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < cin * CB_PX; i += 256) {
+        const int ci = i / CB_PX, px = i - ci * CB_PX, p = p0 + px;
+        float sum = 0.f; int cnt = 0;
+        if (p < npx) {
+            const int oy = p / wo, ox = p - oy * wo;
+            float sc = 1.f, sh = 0.f;
+            if (in_mean != nullptr) {                    // InstanceNorm(affine) of the previous block, applied on load
+                const size_t k = (size_t)b * cin + ci;
+                sc = in_rstd[k] * in_gamma[ci]; sh = in_beta[ci] - in_mean[k] * sc;
+            }
+            const TI* plane = x + ((size_t)b * cin + ci) * h * w;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = 2 * oy + dy;
+                if (yy < 0 || yy >= h) continue;
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = 2 * ox + dx;
+                    if (xx < 0 || xx >= w) continue;
+                    sum += to_f32(plane[(size_t)yy * w + xx]) * sc + sh;
+                    ++cnt;
                 }
-                pooled += acc;
             }
         }
-        pooled *= (1.f / 9.f);  // count_include_pad=True: padded positions contribute 0, divisor stays 9
-        y[i] = pooled > 0.f ? pooled : 0.2f * pooled;
+        cb_pooled[i] = sum;
+        if (ci == 0) s_cnt[px] = (float)cnt;
+    }
+    __syncthreads();
+    const int px = tid & (CB_PX - 1), quarter = tid / CB_PX, p = p0 + px;
+    if (p >= npx) return;
+    const float cnt = s_cnt[px];
+    for (int co = quarter; co < cout; co += 256 / CB_PX) {
+        const float* wr = wgt + (size_t)co * cin;        // uniform over the wave: scalar loads
+        float acc = 0.f;
+        for (int ci = 0; ci < cin; ++ci) acc += wr[ci] * cb_pooled[ci * CB_PX + px];
+        const float pooled = (acc + bias[co] * cnt) * (1.f / 9.f);
+        y[((size_t)b * cout + co) * npx + p] = pooled > 0.f ? pooled : 0.2f * pooled;
     }
 }
 
@@ -211,14 +232,16 @@ int rc_color_block(const void* d_x, int x_dtype, float* d_y, int batch, int cin,
     RC_REQUIRE(x_dtype == RC_F32 || x_dtype == RC_BF16, "rc_color_block: bad dtype");
     if (d_in_mean) RC_REQUIRE(d_in_rstd && d_in_gamma && d_in_beta, "rc_color_block: incomplete InstanceNorm arguments");
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
-    const size_t total = (size_t)batch * cout * ho * wo;
-    size_t g = (total + 255) / 256; if (g > 65535) g = 65535;
+    const size_t lds = ((size_t)cin + 1) * CB_PX * sizeof(float);
+    RC_REQUIRE(lds <= 64 * 1024, "rc_color_block: cin too large");
+    const size_t g = (size_t)batch * (((size_t)ho * wo + CB_PX - 1) / CB_PX);
+    RC_REQUIRE(g < (1ull << 31), "rc_color_block: too many tiles");
     if (x_dtype == RC_F32)
-        hipLaunchKernelGGL(color_block_kernel<float>, dim3((unsigned)g), dim3(256), 0, as_stream(stream),
+        hipLaunchKernelGGL(color_block_kernel<float>, dim3((unsigned)g), dim3(256), lds, as_stream(stream),
                            static_cast<const float*>(d_x), d_y, batch, cin, cout, h, w, ho, wo, d_w, d_b,
                            d_in_mean, d_in_rstd, d_in_gamma, d_in_beta);
     else
-        hipLaunchKernelGGL(color_block_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, as_stream(stream),
+        hipLaunchKernelGGL(color_block_kernel<bf16_t>, dim3((unsigned)g), dim3(256), lds, as_stream(stream),
                            static_cast<const bf16_t*>(d_x), d_y, batch, cin, cout, h, w, ho, wo, d_w, d_b,
                            d_in_mean, d_in_rstd, d_in_gamma, d_in_beta);
     RC_HIP_CHECK(hipGetLastError());

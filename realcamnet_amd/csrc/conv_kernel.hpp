@@ -863,9 +863,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a
 // Two such blocks share a CU and drift out of phase (one in MFMA while the other stores / stages).
 // ==================================================================================================
 constexpr int kPersistMaxCout = 512;   // bias slots kept in LDS
+template <class Cfg>
+constexpr int persist_lds_bytes_c() { return Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + kPersistMaxCout * 4; }
+
+// blocks per CU: layers with one 16-wide cout tile (the 48 -> 3 output conv) do almost no math per byte, so what
+// matters is bytes in flight: three blocks (their accumulators are small enough for 168 VGPRs)
+template <class Cfg>
+constexpr int persist_blocks_per_cu() { return Cfg::NT == 1 && persist_lds_bytes_c<Cfg>() * 3 <= 160 * 1024 ? 3 : 2; }
 
 template <class Cfg, bool GATED, bool FAST>
-__global__ __launch_bounds__(kThreads, 2) void conv_mfma_persist_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_mfma_persist_kernel(const ConvArgs a) {
     using D = ConvDev<Cfg>;
     constexpr int NT = Cfg::NT, STEPS = Cfg::STEPS, NV = 4 * NT;
 
@@ -1301,7 +1308,7 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
                 attr_set = true;
             }
-            int grid = 2 * a.num_cus;
+            int grid = persist_blocks_per_cu<Cfg>() * a.num_cus;
             if (grid > n_tiles) grid = n_tiles;
             grid = (grid + 7) / 8 * 8;
             hipLaunchKernelGGL((conv_mfma_persist_kernel<Cfg, GATED, FAST>), dim3((unsigned)grid), dim3(kThreads), P_LDS, stream, a);
