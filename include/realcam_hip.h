@@ -239,7 +239,9 @@ int rc_gfm_vector(const float* d_vec, int batch, int cond_c, int nf, int c,
  *   (groupmix.py:206,215), SeparableConv2d.conv1 (:244) and ConvRelPosEnc.conv_list (:127-133).
  * rc_layernorm: nn.LayerNorm over C of (tokens, C) (groupmix.py:280,285).
  * rc_gma_pointwise: Aggregator tail (groupmix.py:92-100) with BatchNorm(eval) folded to scale/shift:
- *   qkv (B,N,3C), dw (B,N,3,3seg) = depth-wise outputs of groups 1..3, dwl (B,N,3seg) = local depth-wise output
+ *   qkv (B,N,3C), dw = depth-wise outputs of groups 1..3 (token t, rep r, group g at dw + t*dw_tok_stride +
+ *   r*dw_rep_stride + (g-1)*seg), dwl = local depth-wise output (dwl + t*dwl_tok_stride + r*dwl_rep_stride); both may
+ *   live in one (B,N,3,4seg) tensor written by a single rc_dwconv2d launch (strides 12seg / 4seg, dwl = dw + 3seg)
  *   -> qkvp (B,N,3,4seg) [q|k|v, channel = head*Ch + i], loc (B,N,seg).
  * rc_gma_kv: softmax over the N tokens fused with k^T v (groupmix.py:187-188): per-channel max pass, exp-sum +
  *   k^T v pass, fixed-order merge: ktv (B,heads,Ch,Ch) fp32 = scale * softmax_N(k)^T v.  d_scratch: rc_gma_kv_scratch_bytes().
@@ -251,9 +253,10 @@ int rc_dwconv2d(const void* d_x, int x_stride_c, int x_c0, void* d_y, int y_stri
                 void* stream);
 int rc_layernorm(const void* d_x, void* d_y, int dtype, long long tokens, int c, const float* d_gamma,
                  const float* d_beta, float eps, void* stream);
-int rc_gma_pointwise(const void* d_qkv, const void* d_dw, const void* d_dwl, void* d_qkvp, void* d_loc, int dtype,
-                     long long tokens, int c, const float* d_pw, const float* d_bn_scale, const float* d_bn_shift,
-                     const float* d_pwl, const float* d_ln_g, const float* d_ln_b, void* stream);
+int rc_gma_pointwise(const void* d_qkv, const void* d_dw, const void* d_dwl, int dw_tok_stride, int dw_rep_stride,
+                     int dwl_tok_stride, int dwl_rep_stride, void* d_qkvp, void* d_loc, int dtype, long long tokens, int c,
+                     const float* d_pw, const float* d_bn_scale, const float* d_bn_shift, const float* d_pwl,
+                     const float* d_ln_g, const float* d_ln_b, void* stream);
 int rc_gma_kv_blocks(int n_tok);
 size_t rc_gma_kv_scratch_bytes(int batch, int n_tok, int heads, int ch);
 int rc_gma_kv(const void* d_qkvp, int dtype, int batch, int n_tok, int heads, int ch, float scale, float* d_scratch,

@@ -186,7 +186,8 @@ __global__ void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, con
 constexpr int kPwWaves = 13;
 template <typename T, int SEG, int TOK>
 __global__ __launch_bounds__(kPwWaves * 64) void gma_pointwise_kernel(
-    const T* __restrict__ qkv, const T* __restrict__ dw, const T* __restrict__ dwl, T* __restrict__ qkvp, T* __restrict__ loc,
+    const T* __restrict__ qkv, const T* __restrict__ dw, const T* __restrict__ dwl, int dw_ts, int dw_rs, int dwl_ts, int dwl_rs,
+    T* __restrict__ qkvp, T* __restrict__ loc,
     size_t tokens, int c, const float* __restrict__ pw /*3,seg,seg*/, const float* __restrict__ bn_scale /*4,seg*/,
     const float* __restrict__ bn_shift, const float* __restrict__ pwl /*seg,3seg*/, const float* __restrict__ ln_g,
     const float* __restrict__ ln_b) {
@@ -213,8 +214,8 @@ __global__ __launch_bounds__(kPwWaves * 64) void gma_pointwise_kernel(
                 const size_t tok = t0 + t;
                 const int sg = v / NV, vv = v - sg * NV;     // segment index 0..14
                 const T* src = sg < 3 ? qkv + tok * 3 * c + (size_t)sg * c + vv * U
-                             : sg < 12 ? dw + tok * 9 * SEG + (sg - 3) * SEG + vv * U
-                                       : dwl + tok * 3 * SEG + (sg - 12) * SEG + vv * U;
+                             : sg < 12 ? dw + tok * dw_ts + ((sg - 3) / 3) * dw_rs + ((sg - 3) % 3) * SEG + vv * U
+                                       : dwl + tok * dwl_ts + (sg - 12) * dwl_rs + vv * U;
                 raw = *reinterpret_cast<const uint4*>(src);
             }
             s_in[t * IN_S + v] = raw;
@@ -490,7 +491,8 @@ int rc_dwconv2d(const void* d_x, int x_stride_c, int x_c0, void* d_y, int y_stri
                (n_rep - 1) * w_rep_stride + n_ch <= n_w, "rc_dwconv2d: channel range exceeds tensor");
     const int vpc = n_ch / U;
     int vb = 1;                                           // channel vectors (= waves) per block: largest divisor of vpc <= 5
-    for (int c = 5; c >= 1; --c) if (vpc % c == 0) { vb = c; break; }
+    for (int c = 5; c >= 1; --c) if (vpc % c == 0) { vb = c; break; }   // (narrower blocks for mixed kvec windows measured slower:
+                                                                         //  32-byte pixel pieces fetch badly)
     const int tiles_x = ceil_div(W, DW_TW), tiles_y = ceil_div(H, DW_TH);
     const int R = ksize / 2;
     const size_t lds = (size_t)ksize * ksize * vb * U * 4 + (size_t)(DW_TH + 2 * R) * (DW_TW + 2 * R) * (vb | 1) * 16;
@@ -535,9 +537,9 @@ int rc_layernorm(const void* d_x, void* d_y, int dtype, long long tokens, int c,
     return RC_OK;
 }
 
-int rc_gma_pointwise(const void* d_qkv, const void* d_dw, const void* d_dwl, void* d_qkvp, void* d_loc, int dtype,
-                     long long tokens, int c, const float* d_pw, const float* d_bn_scale, const float* d_bn_shift,
-                     const float* d_pwl, const float* d_ln_g, const float* d_ln_b, void* stream) {
+int rc_gma_pointwise(const void* d_qkv, const void* d_dw, const void* d_dwl, int dw_tok_stride, int dw_rep_stride,
+                     int dwl_tok_stride, int dwl_rep_stride, void* d_qkvp, void* d_loc, int dtype, long long tokens, int c,
+                     const float* d_pw, const float* d_bn_scale, const float* d_bn_shift, const float* d_pwl, const float* d_ln_g, const float* d_ln_b, void* stream) {
     RC_REQUIRE(d_qkv && d_dw && d_dwl && d_qkvp && d_loc && d_pw && d_bn_scale && d_bn_shift && d_pwl && d_ln_g && d_ln_b,
                "rc_gma_pointwise: null pointer");
     RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_gma_pointwise: bad dtype");
@@ -545,6 +547,9 @@ int rc_gma_pointwise(const void* d_qkv, const void* d_dw, const void* d_dwl, voi
     const int seg = c / 5;
     RC_REQUIRE(seg == 16 || seg == 40 || seg == 8 || seg == 24 || seg == 32, "rc_gma_pointwise: C/5 must be one of 8, 16, 24, 32, 40 (dims 40..200)");
     const int U = dtype == RC_F32 ? 4 : 8;
+    RC_REQUIRE(dw_tok_stride >= 9 * seg && dw_rep_stride >= 3 * seg && dwl_tok_stride >= 3 * seg && dwl_rep_stride >= seg &&
+               dw_tok_stride % U == 0 && dw_rep_stride % U == 0 && dwl_tok_stride % U == 0 && dwl_rep_stride % U == 0,
+               "rc_gma_pointwise: bad dw/dwl strides");
     const int nv = seg / U;
     const int tok = ((15 * nv | 1) + (13 * nv | 1)) * 16 * 64 <= 150 * 1024 ? 64 : 32;   // tokens per tile that fit LDS
     const size_t lds = (size_t)((15 * nv | 1) + (13 * nv | 1)) * 16 * tok;
@@ -561,7 +566,7 @@ int rc_gma_pointwise(const void* d_qkv, const void* d_dw, const void* d_dwl, voi
         }                                                                                                               \
         hipLaunchKernelGGL((gma_pointwise_kernel<TT, SG, TK>), dim3(gx), dim3(kPwWaves * 64), lds, as_stream(stream),   \
                            static_cast<const TT*>(d_qkv), static_cast<const TT*>(d_dw), static_cast<const TT*>(d_dwl),  \
-                           static_cast<TT*>(d_qkvp), static_cast<TT*>(d_loc), (size_t)tokens, c, d_pw, d_bn_scale,      \
+                           dw_tok_stride, dw_rep_stride, dwl_tok_stride, dwl_rep_stride, static_cast<TT*>(d_qkvp), static_cast<TT*>(d_loc), (size_t)tokens, c, d_pw, d_bn_scale,      \
                            d_bn_shift, d_pwl, d_ln_g, d_ln_b);                                                          \
     } while (0)
 #define RC_PW_TOK(TT, SG) do { if (tok == 64) RC_PW_LAUNCH(TT, SG, 64); else RC_PW_LAUNCH(TT, SG, 32); } while (0)

@@ -43,6 +43,20 @@ __global__ void bayer_unshuffle_kernel(const TI* __restrict__ mosaic, TO* __rest
     }
 }
 
+// ---- NCHW -> NHWC for C <= 4 (the coordinate map, packed RAW): one thread per output pixel, plane reads and the
+// pixel-record writes are both coalesced; the 32x32 transpose tile below would launch a block per 32 pixels
+template <typename TI, typename TO>
+__global__ void nchw_to_nhwc_small_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int batch, int c, int h, int w,
+                                          int hp, int wp) {
+    const size_t total = (size_t)batch * hp * wp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % wp), y = (int)((i / wp) % hp), b = (int)(i / ((size_t)wp * hp));
+        const bool in = y < h && x < w;
+        for (int ch = 0; ch < c; ++ch)
+            dst[i * c + ch] = from_f32<TO>(in ? to_f32(src[(((size_t)b * c + ch) * h + y) * w + x]) : 0.f);
+    }
+}
+
 // ---- NCHW <-> NHWC through an LDS transpose tile (32 pixels x 32 channels) -------------------------
 template <typename TI, typename TO>
 __global__ void nchw_to_nhwc_kernel(const TI* __restrict__ src, TO* __restrict__ dst,
@@ -233,6 +247,16 @@ int rc_nchw_to_nhwc(const void* d_src, int src_dtype, void* d_dst, int dst_dtype
     RC_REQUIRE(d_src && d_dst, "rc_nchw_to_nhwc: null pointer");
     RC_REQUIRE(batch >= 1 && c >= 1 && h >= 1 && w >= 1 && hp >= h && wp >= w, "rc_nchw_to_nhwc: bad shape");
     RC_REQUIRE(hp <= 65535 && batch <= 65535, "rc_nchw_to_nhwc: dimension too large");
+    if (c <= 4) {
+        const size_t total = (size_t)batch * hp * wp;
+#define CALL(TI, TO)                                                                                                  \
+    hipLaunchKernelGGL((nchw_to_nhwc_small_kernel<TI, TO>), dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream), \
+                       static_cast<const TI*>(d_src), static_cast<TO*>(d_dst), batch, c, h, w, hp, wp)
+        RC_DISPATCH_2(src_dtype, dst_dtype, CALL);
+#undef CALL
+        RC_HIP_CHECK(hipGetLastError());
+        return RC_OK;
+    }
     dim3 grid(ceil_div(wp, 32), hp, batch);
 #define CALL(TI, TO)                                                                               \
     hipLaunchKernelGGL((nchw_to_nhwc_kernel<TI, TO>), grid, dim3(256), 0, as_stream(stream),       \

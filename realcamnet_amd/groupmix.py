@@ -90,13 +90,20 @@ class Aggregator(nn.Module):
         b, H, W, c3 = qkv.shape
         c, seg = c3 // 3, c3 // 15
         dev, dt = qkv.device, qkv.dtype
-        dw = torch.empty((b, H, W, 3, 3 * seg), dtype=dt, device=dev)
-        dwl = torch.empty((b, H, W, 3 * seg), dtype=dt, device=dev)
-        for g, (agg, k) in enumerate(((self.agg1, 3), (self.agg2, 5), (self.agg3, 7)), start=1):
-            (wT,) = ops.host_cached(agg, "taps", [agg.conv1.weight], lambda w: ops.dw_taps(w))
-            ops.dwconv2d(qkv, g * seg, dw, (g - 1) * seg, seg, k, wT, n_rep=3, x_rep=c, y_rep=3 * seg, w_rep=0)
-        (wl,) = ops.host_cached(self.agg0, "taps", [self.agg0.conv.conv1.weight], lambda w: ops.dw_taps(w))
-        ops.dwconv2d(qkv, 4 * seg, dwl, 0, seg, 3, wl, n_rep=3, x_rep=c, y_rep=seg, w_rep=seg)
+        # all four depth-wise stages (groups 1..3: k = 3, 5, 7 shared by q/k/v; group 4: the local branch's own 3x3 per
+        # q/k/v) in ONE launch: taps zero-padded to 7x7, the true window per weight vector in kvec (padded taps are
+        # skipped, never multiplied), output (B,H,W,3,4seg) = [rep][g1 | g2 | g3 | g4] -- qkv is read once, not 4 times
+        def taps(w1, w2, w3, w0):
+            cols = []
+            for r in range(3):
+                cols += [ops.dw_taps(w1, 7), ops.dw_taps(w2, 7), ops.dw_taps(w3, 7), ops.dw_taps(w0[r * seg:(r + 1) * seg], 7)]
+            unit = 8 if dt == torch.bfloat16 else 4
+            kv = torch.tensor(([3] * (seg // unit) + [5] * (seg // unit) + [7] * (seg // unit) + [3] * (seg // unit)) * 3, dtype=torch.int32)
+            return torch.cat(cols, dim=1).contiguous(), kv
+        wT, kvec = ops.host_cached(self, f"taps7_{dt}", [self.agg1.conv1.weight, self.agg2.conv1.weight, self.agg3.conv1.weight,
+                                                       self.agg0.conv.conv1.weight], taps)
+        dwc = torch.empty((b, H, W, 3, 4 * seg), dtype=dt, device=dev)
+        ops.dwconv2d(qkv, seg, dwc, 0, 4 * seg, 7, wT, n_rep=3, x_rep=c, y_rep=4 * seg, w_rep=4 * seg, kvec=kvec)
 
         def fold(*p):   # BatchNorm(eval) -> per-channel scale / shift; point-wise weights as dense matrices
             bn = [p[4 * i:4 * i + 4] for i in range(4)]
@@ -116,7 +123,9 @@ class Aggregator(nn.Module):
         qkvp = torch.empty((b, H, W, 3, 4 * seg), dtype=dt, device=dev)
         loc = torch.empty((b, H, W, seg), dtype=dt, device=dev)
         ln = self.agg0.norm
-        check(lib().rc_gma_pointwise(qkv.data_ptr(), dw.data_ptr(), dwl.data_ptr(), qkvp.data_ptr(), loc.data_ptr(), ops._dt(qkv),
+        es = qkv.element_size()
+        check(lib().rc_gma_pointwise(qkv.data_ptr(), dwc.data_ptr(), dwc.data_ptr() + 3 * seg * es, 12 * seg, 4 * seg, 12 * seg, 4 * seg,
+                                     qkvp.data_ptr(), loc.data_ptr(), ops._dt(qkv),
                                      b * H * W, c, pw.data_ptr(), scale.data_ptr(), shift.data_ptr(), pwl.data_ptr(),
                                      ops.f32_param(ln, "weight").data_ptr(), ops.f32_param(ln, "bias").data_ptr(), ops._stream()),
               "rc_gma_pointwise")
