@@ -235,7 +235,51 @@ def liteispnet_gfm_lsc_gma(sd: SD, x: Sequence[torch.Tensor], heads: int = 8) ->
     return _unet_trunk(sd, h, v, refine)
 
 
-FORWARDS = {"LiteISPNet": liteispnet, "LiteISPNet_GFM_LSC": liteispnet_gfm_lsc, "LiteISPNet_GFM_LSC_GMA": liteispnet_gfm_lsc_gma}
+def ispunet_gfm_lsc(sd: SD, x: Sequence[torch.Tensor]) -> torch.Tensor:
+    """ISPUNet_GFM_LSC.forward.  models/LiteISP.py:1340-1380; constructor :1229-1338:
+    Conv2d(c, 2c, 2, 2) down-samplers (:1253), Conv1x1(c, 2c, bias=False) + PixelShuffle(2) up-samplers (:1292-1295),
+    m_blocks Res_GFM per level (the count is read off the state_dict), RCAGroups of 2 blocks (middle: 4)."""
+    raw, cond, coord = x
+    v = color_condition_gfm(sd, "classifier", cond)
+
+    def gfm(p, t):
+        if f"{p}.conv0.weight" in sd:                    # N.seq of ONE module is that module (models/networks.py:117-121)
+            return res_gfm(sd, p, t, v)
+        i = 0
+        while f"{p}.{i}.conv0.weight" in sd:
+            t = res_gfm(sd, f"{p}.{i}", t, v)
+            i += 1
+        return t
+
+    def down(p, t):                                      # kernel 2, stride 2, no padding
+        return F.conv2d(t, sd[p + ".weight"], sd.get(p + ".bias"), stride=2)
+
+    def up(p, t):
+        return pixel_shuffle2(F.conv2d(t, sd[p + ".0.weight"]))
+
+    def enc(p, t, lead_conv):
+        i = 0
+        if lead_conv:
+            t = conv(sd, f"{p}.0", t); i = 1
+        t = rcag(sd, f"{p}.{i}", t, nb=2)
+        return F.leaky_relu(conv(sd, f"{p}.{i + 1}", t), 0.1)
+
+    intro = conv(sd, "intro", raw) * (lens_shading(sd, "lsc", coord) + 1)
+    d1 = down("down1", enc("encoder1", gfm("encoder_modulation1", intro), False))
+    d2 = down("down2", enc("encoder2", gfm("encoder_modulation2", d1), False))
+    d3 = down("down3", enc("encoder3", gfm("encoder_modulation3", d2), True))
+    m = gfm("middle_modulation", d3)
+    m = conv(sd, "middle.2", rcag(sd, "middle.1", conv(sd, "middle.0", m), nb=4)) + d3
+
+    def dec(i, t, skip):
+        t = conv(sd, f"decoder{i}.1", rcag(sd, f"decoder{i}.0", up(f"up{i}", t), nb=2))
+        return gfm(f"decoder_modulation{i}", t) + skip
+
+    u = dec(1, dec(2, dec(3, m, d2), d1), intro)
+    return conv(sd, "tail.2", pixel_shuffle2(conv(sd, "tail.0", u)))
+
+
+FORWARDS = {"ISPUNet_GFM_LSC": ispunet_gfm_lsc, "LiteISPNet": liteispnet, "LiteISPNet_GFM_LSC": liteispnet_gfm_lsc, "LiteISPNet_GFM_LSC_GMA": liteispnet_gfm_lsc_gma}
 
 
 # ----------------------------------------------------------------------------------------------

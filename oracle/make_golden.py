@@ -102,7 +102,7 @@ def main():
         save("block_pad16", x_shape=np.array([1, 4, 21, 35]), y=raw, hw=np.array(hw))
 
         # ---- end-to-end fixtures (weights reproduced from seed 0; digest stored) -------------------
-        for name in ("LiteISPNet", "LiteISPNet_GFM_LSC"):
+        for name in ("LiteISPNet", "LiteISPNet_GFM_LSC", "ISPUNet_GFM_LSC"):
             torch.manual_seed(0)
             net = getattr(L, name)().eval()
             dig = sd_digest(net.state_dict())

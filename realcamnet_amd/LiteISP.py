@@ -273,6 +273,102 @@ class LiteISPNet_GFM_LSC(_DwtUNet):
         return self._trunk(h, vec, crop_hw=(mosaic.shape[-2], mosaic.shape[-1]))
 
 
+class ISPUNet_GFM_LSC(nn.Module):
+    """upstream LiteISP.py:1228-1380: the strided U-Net sibling of LiteISPNet_GFM_LSC -- widths
+    chan, 2chan, 4chan, 8chan; Conv2d(c, 2c, 2, 2) down-samplers; Conv1x1(c, 2c, bias=False) + PixelShuffle(2)
+    up-samplers; m_blocks Res_GFM per level on the way down AND up; RCAGroups of 2 (middle: 4) blocks.
+    Same constructor signature, attribute names and construction order as upstream, so the seed-0 parameters and the
+    state_dict keys are identical."""
+
+    output_dtype: Optional[torch.dtype] = None
+
+    def __init__(self, cond_c=32, chan=32, m_blocks=2):
+        super().__init__()
+        self.classifier = Color_Condition_GFM(in_channels=4, out_c=cond_c)
+        n_blocks = 2
+
+        def gfm(c):
+            return N.seq(*[Res_GFM(in_nc=c, chan=c, cond_c=cond_c, out_nc=c, nf=c * 2) for _ in range(m_blocks)])
+
+        def lrelu():
+            return nn.LeakyReLU(negative_slope=1e-1, inplace=True)
+
+        self.intro = N.seq(N.Conv2d(4, chan, 3, 1, 1))
+        self.lsc = Lens_Shading_Correction(in_channels=2, out_c=chan, nf=chan)
+        self.encoder_modulation1 = gfm(chan)
+        self.encoder1 = N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.Conv2d(chan, chan, 3, 1, 1), lrelu())
+        self.down1 = N.Conv2d(chan, chan * 2, 2, 2)
+        chan = chan * 2
+        self.encoder_modulation2 = gfm(chan)
+        self.encoder2 = N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.Conv2d(chan, chan, 3, 1, 1), lrelu())
+        self.down2 = N.Conv2d(chan, chan * 2, 2, 2)
+        chan = chan * 2
+        self.encoder_modulation3 = gfm(chan)
+        self.encoder3 = N.seq(N.Conv2d(chan, chan, 3, 1, 1), N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks),
+                              N.Conv2d(chan, chan, 3, 1, 1), lrelu())
+        self.down3 = N.Conv2d(chan, chan * 2, 2, 2)
+        chan = chan * 2
+        self.middle_modulation = gfm(chan)
+        self.middle = N.seq(N.Conv2d(chan, chan, 3, 1, 1), N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks * 2),
+                            N.Conv2d(chan, chan, 3, 1, 1))
+        self.up3 = N.seq(N.Conv2d(chan, chan * 2, 1, bias=False), nn.PixelShuffle(2))
+        chan = chan // 2
+        self.decoder_modulation3 = gfm(chan)
+        self.decoder3 = N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.conv(chan, chan, mode='C'))
+        self.up2 = N.seq(N.Conv2d(chan, chan * 2, 1, bias=False), nn.PixelShuffle(2))
+        chan = chan // 2
+        self.decoder_modulation2 = gfm(chan)
+        self.decoder2 = N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.conv(chan, chan, mode='C'))
+        self.up1 = N.seq(N.Conv2d(chan, chan * 2, 1, bias=False), nn.PixelShuffle(2))
+        chan = chan // 2
+        self.decoder_modulation1 = gfm(chan)
+        self.decoder1 = N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.conv(chan, chan, mode='C'))
+        self.tail = N.seq(N.conv(chan, chan * 4, mode='C'), nn.PixelShuffle(upscale_factor=2), N.conv(chan, 3, mode='C'))
+
+    def _act_dtype(self) -> torch.dtype:
+        return self.intro.weight.dtype
+
+    def _run(self, a, cond, coord_nhwc, crop_hw=None):
+        lsc = self.lsc._nhwc(coord_nhwc)
+        intro = self.intro._nhwc(a, mul_plus1=lsc)                       # intro(raw) * (lsc + 1)
+        vec = self.classifier._vec(ops._req(cond, "cond"))
+
+        def gfm(seq_, t):
+            return seq_._nhwc((t, vec))[0]
+
+        d1 = self.down1._nhwc(self.encoder1._nhwc(gfm(self.encoder_modulation1, intro)))
+        d2 = self.down2._nhwc(self.encoder2._nhwc(gfm(self.encoder_modulation2, d1)))
+        d3 = self.down3._nhwc(self.encoder3._nhwc(gfm(self.encoder_modulation3, d2)))
+        m = self.middle._nhwc(gfm(self.middle_modulation, d3), residual=d3)
+        u3 = ops.add(gfm(self.decoder_modulation3, self.decoder3._nhwc(self.up3._nhwc(m))), d2)
+        u2 = ops.add(gfm(self.decoder_modulation2, self.decoder2._nhwc(self.up2._nhwc(u3))), d1)
+        u1 = ops.add(gfm(self.decoder_modulation1, self.decoder1._nhwc(self.up1._nhwc(u2))), intro)
+        t = self.tail[0]._nhwc(u1, out_mode=RC_OUT_PIXEL_SHUFFLE2)
+        return self.tail[2]._nhwc(t, out_mode=RC_OUT_NCHW, crop_hw=crop_hw, out_dtype=self.output_dtype)
+
+    def forward(self, x: Sequence[torch.Tensor]):
+        raw, cond, coord = x[0], x[1], x[2]
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        if raw.dim() != 4 or raw.shape[1] != 4 or raw.shape[2] % 8 or raw.shape[3] % 8:
+            raise ValueError(f"raw must be (B,4,H,W) with H,W multiples of 8 (three stride-2 levels), got {tuple(raw.shape)}")
+        if coord.shape[0] != raw.shape[0] or coord.shape[1] != 2 or coord.shape[2:] != raw.shape[2:]:
+            raise ValueError(f"coord must be (B,2,H,W) matching raw, got {tuple(coord.shape)}")
+        dt = self._act_dtype()
+        return self._run(ops.to_nhwc(raw, dtype=dt), cond, ops.to_nhwc(coord, dtype=dt))
+
+    def forward_mosaic(self, mosaic, cond, coord, pad_to: int = 16):
+        """Bayer mosaic (B,1,2h,2w), cond, coord (B,2,h,w) -> sRGB (B,3,2h,2w) with the unshuffle / pad16 / crop front end."""
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        dt = self._act_dtype()
+        a = ops.bayer_unshuffle(mosaic, dtype=dt, pad_to=pad_to)
+        b, hp, wp, _ = a.shape
+        if coord.shape[-2:] != (mosaic.shape[-2] // 2, mosaic.shape[-1] // 2):
+            raise ValueError("coord must be at packed resolution (h, w)")
+        return self._run(a, cond, ops.to_nhwc(coord, dtype=dt, pad_hw=(hp, wp)), crop_hw=(mosaic.shape[-2], mosaic.shape[-1]))
+
+
 class LiteISPNet_GFM_LSC_GMA(LiteISPNet_GFM_LSC):
     """BUILD-DEFINED composition for BASELINE.json config 3 ("4K RAW->sRGB with GroupMix attention").
 

@@ -49,6 +49,8 @@ class Conv2d(nn.Conv2d):
         return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
 
     def _nhwc(self, a, **fuse):
+        if ops.is_down2x2(self):                      # ISPUNet family: Conv2d(c, 2c, 2, 2) (upstream LiteISP.py:1253)
+            return ops.conv2x2s2(a, self, **fuse)
         return ops.conv2d(a, self, **fuse)
 
 

@@ -124,7 +124,48 @@ def packed_conv(mod, act_dtype: torch.dtype, out_mode: int) -> PackedConv:
     return pc
 
 
+class _ConvView:
+    """A conv-shaped view (weight, bias) of another module's parameters, with its own pack cache."""
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight, bias
+
+
+def is_down2x2(mod) -> bool:
+    """nn.Conv2d(c, c2, kernel_size=2, stride=2) without padding: the ISPUNet family's down-sampler (LiteISP.py:1253)."""
+    return (tuple(mod.kernel_size) == (2, 2) and tuple(mod.stride) == (2, 2) and tuple(mod.padding) == (0, 0) and
+            tuple(mod.dilation) == (1, 1) and mod.groups == 1)
+
+
+def conv2x2s2(x: torch.Tensor, mod, **fuse):
+    """2x2 stride-2 convolution = space-to-depth (channel 4c + 2i + j <- pixel (2y+i, 2x+j), done by the Haar kernel with
+    one-hot taps: exact) followed by a 1x1 MFMA convolution over the 4c channels.  The OIHW weight flattened over
+    (c, i, j) already has that channel order, so the 1x1 weight is a reshape of the checkpoint tensor."""
+    x = _req(x, "conv2x2s2 input")
+    b, H, W, c = x.shape
+    if H % 2 or W % 2:
+        raise ValueError(f"stride-2 conv needs even H,W; got {H}x{W}")
+    cout, cin = mod.weight.shape[:2]
+    if cin != c:
+        raise ValueError(f"conv expects {cin} input channels, got {c}")
+    cache = _cache(mod)
+    key = _key(mod.weight, mod.bias)
+    hit = cache.get("down2x2")
+    if hit is None or hit[0] != key:
+        taps = torch.zeros((4 * c, 1, 2, 2), dtype=torch.float32)
+        for k in range(4):
+            taps[k::4, 0, k >> 1, k & 1] = 1.0
+        view = _ConvView(mod.weight.detach().reshape(cout, 4 * c, 1, 1), mod.bias.detach() if mod.bias is not None else None)
+        hit = (key, taps.to(x.device), view)
+        cache["down2x2"] = hit
+    _, taps, view = hit
+    y = torch.empty((b, H // 2, W // 2, 4 * c), dtype=x.dtype, device=x.device)
+    check(lib().rc_dwt_forward(x.data_ptr(), y.data_ptr(), taps.data_ptr(), 1, _dt(x), b, H, W, c, _stream()), "rc_dwt_forward")
+    return conv2d(y, view, **fuse)
+
+
 def check_conv_module(mod) -> None:
+    if isinstance(mod, _ConvView):
+        return
     if tuple(mod.stride) != (1, 1) or tuple(mod.dilation) != (1, 1) or mod.groups != 1:
         raise NotImplementedError("HIP conv: stride 1, dilation 1, groups 1 only")
     k = mod.kernel_size[0]
@@ -363,6 +404,22 @@ def gate_residual(r: torch.Tensor, gate: torch.Tensor, x: torch.Tensor) -> torch
     y = torch.empty_like(r)
     check(lib().rc_gate_residual(r.data_ptr(), gate.data_ptr(), x.data_ptr(), y.data_ptr(), _dt(r), b, H * W, c, _stream()), "rc_gate_residual")
     return y
+
+
+_ONES = {}
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a + b on NHWC feature maps (the ISPUNet decoder skips, upstream LiteISP.py:1365-1373): rc_gate_residual with a
+    unit gate."""
+    a, b = _req(a, "a"), _req(b, "b")
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise ValueError("add: shape / dtype mismatch")
+    key = (a.shape[0], a.shape[-1], str(a.device))
+    ones = _ONES.get(key)
+    if ones is None:
+        ones = _ONES[key] = torch.ones((a.shape[0], a.shape[-1]), dtype=torch.float32, device=a.device)
+    return gate_residual(a, ones, b)
 
 
 def _taps_uniform(mod) -> int:

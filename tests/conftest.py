@@ -37,6 +37,14 @@ def golden_names(prefix):
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith(prefix) and f.endswith(".npz"))
 
 
+def net_name_of(fixture: str) -> str:
+    """e2e_<Net>_<size> -> the net's class name."""
+    for name in ("ISPUNet_GFM_LSC", "LiteISPNet_GFM_LSC", "LiteISPNet"):
+        if fixture.startswith("e2e_" + name + "_"):
+            return name
+    raise KeyError(fixture)
+
+
 def sd_digest(sd) -> str:
     import hashlib
     h = hashlib.sha256()

@@ -14,7 +14,7 @@ import liteisp_oracle as O
 import realcamnet_amd as M
 from realcamnet_amd import networks as N
 from realcamnet_amd import ops
-from conftest import golden_names, load_golden, rel_err, seed0_state_dict
+from conftest import net_name_of, golden_names, load_golden, rel_err, seed0_state_dict
 
 pytestmark = pytest.mark.gpu
 
@@ -157,7 +157,7 @@ def net_on_gpu(name, dt):
 @pytest.mark.parametrize("dt", DTYPES)
 def test_end_to_end_vs_reference_golden(hip, fixture, dt):
     g = load_golden(fixture)
-    name = "LiteISPNet_GFM_LSC" if "GFM_LSC" in fixture else "LiteISPNet"
+    name = net_name_of(fixture)
     net = net_on_gpu(name, dt)
     with torch.no_grad():
         y = net([g["raw"].to(DEV, dt), g["cond"].to(DEV, dt), g["coord"].to(DEV, dt)])
@@ -167,7 +167,7 @@ def test_end_to_end_vs_reference_golden(hip, fixture, dt):
     assert p >= (100.0 if dt == torch.float32 else 50.0), p
 
 
-@pytest.mark.parametrize("name", ["LiteISPNet", "LiteISPNet_GFM_LSC"])
+@pytest.mark.parametrize("name", ["LiteISPNet", "LiteISPNet_GFM_LSC", "ISPUNet_GFM_LSC"])
 def test_batch_and_ragged_mosaic_vs_oracle(hip, name):
     """B=3 frames of a 2*(43x61)... mosaic: exercises unshuffle+pad-to-16, partial tiles, batch indexing, crop."""
     g = torch.Generator().manual_seed(7)
@@ -382,7 +382,7 @@ def test_conv_pair_rejects_other_shapes(hip):
 
 def test_end_to_end_with_fused_pairs_vs_reference_golden(hip):
     """The optional rc_conv_pair path (ops.FUSE_PAIR) through the whole flagship net: same golden, same bar."""
-    fixture = [f for f in golden_names("e2e_") if "GFM_LSC" in f][0]
+    fixture = [f for f in golden_names("e2e_LiteISPNet_GFM_LSC")][0]
     g = load_golden(fixture)
     net = net_on_gpu("LiteISPNet_GFM_LSC", torch.bfloat16)
     dt = torch.bfloat16

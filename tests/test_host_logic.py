@@ -13,9 +13,19 @@ from conftest import ROOT, golden_names, load_golden, sd_digest, seed0_state_dic
 
 
 def test_seed0_parameters_equal_the_reference():
-    for name in ("LiteISPNet", "LiteISPNet_GFM_LSC"):
+    for name in ("LiteISPNet", "LiteISPNet_GFM_LSC", "ISPUNet_GFM_LSC"):
         g = load_golden(f"e2e_{name}_32x32")
         assert sd_digest(seed0_state_dict(name)) == g["sd_digest"]
+
+
+def test_ispunet_checkpoint_keys():
+    """Row a13: strided U-Net sibling -- down-samplers are (2c, c, 2, 2) convs, up-samplers bias-free 1x1 convs."""
+    sd = seed0_state_dict("ISPUNet_GFM_LSC")
+    for k, shape in {"intro.weight": (32, 4, 3, 3), "down1.weight": (64, 32, 2, 2), "down3.bias": (256,),
+                     "up3.0.weight": (512, 256, 1, 1), "encoder_modulation2.1.GFM_scale_conv0.weight": (128, 32),
+                     "middle.1.rg.4.weight": (256, 256, 3, 3), "decoder1.1.weight": (32, 32, 3, 3), "tail.2.weight": (3, 32, 3, 3)}.items():
+        assert tuple(sd[k].shape) == shape, k
+    assert "up3.0.bias" not in sd
 
 
 def test_checkpoint_keys_and_counts():

@@ -3,7 +3,7 @@ import pytest
 import torch
 
 import liteisp_oracle as O
-from conftest import golden_names, load_golden, sd_digest, seed0_state_dict
+from conftest import net_name_of, golden_names, load_golden, sd_digest, seed0_state_dict
 
 torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
 
@@ -83,7 +83,7 @@ def test_bayer_unshuffle_matches_pixel_unshuffle():
 @pytest.mark.parametrize("fixture", golden_names("e2e_"))
 def test_end_to_end_vs_reference(fixture):
     g = load_golden(fixture)
-    name = "LiteISPNet_GFM_LSC" if "GFM_LSC" in fixture else "LiteISPNet"
+    name = net_name_of(fixture)
     sd = seed0_state_dict(name)
     assert sd_digest(sd) == g["sd_digest"], "mirror module's seed-0 parameters differ from the reference's"
     with torch.no_grad():
