@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160, help="mosaic height")
     ap.add_argument("--width", type=int, default=3840, help="mosaic width")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
-    ap.add_argument("--model", default="LiteISPNet_GFM_LSC_GMA", choices=["LiteISPNet_GFM_LSC_GMA", "LiteISPNet_GFM_LSC", "LiteISPNet"],
+    ap.add_argument("--model", default="LiteISPNet_GFM_LSC_GMA", choices=["LiteISPNet_GFM_LSC_GMA", "LiteISPNet_GFM_LSC", "LiteISPNet", "ISPUNet_GFM_LSC"],
                     help="default = cfg3: the flagship net plus one GroupMix GMA_Block(80,8) at H/2 (build-defined placement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -486,6 +486,21 @@ struct ConvDev {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) Mma<T>::run(wf[nt], xf[pt], acc[pt][nt]);
     }
+    // MFMA slot m of a step.  bf16: slot = item (pt, nt).  fp32: an item is FOUR dependent 16x16x4 MFMAs on one
+    // accumulator, so the slots run k-slice-major (all items' slice 0, then slice 1, ...): 4*NT independent MFMAs
+    // sit between two that touch the same accumulator (item-major order stalled every MFMA on its predecessor and
+    // cost the fp32 path a factor 2.3).
+    static constexpr int SLOTS = FM * (ES == 4 ? 4 : 1);
+    __device__ static __forceinline__ void mma_slot(int m, const uint4 (&wf)[NT], const uint4 (&xf)[4], f32x4 (&acc)[4][NT]) {
+        if constexpr (ES == 4) {
+            const int e = m / FM, j = m % FM, pt = j / NT, nt = j % NT;
+            const unsigned w = e == 0 ? wf[nt].x : e == 1 ? wf[nt].y : e == 2 ? wf[nt].z : wf[nt].w;
+            const unsigned x = e == 0 ? xf[pt].x : e == 1 ? xf[pt].y : e == 2 ? xf[pt].z : xf[pt].w;
+            acc[pt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w), __uint_as_float(x), acc[pt][nt], 0, 0, 0);
+        } else {
+            Mma<T>::run(wf[m % NT], xf[m / NT], acc[m / NT][m % NT]);
+        }
+    }
     // one step with the next step's reads interleaved (I = read index; recursion keeps every index a constant)
     template <int I, bool NEXT>
     __device__ static __forceinline__ void step_interleaved(int s, int w0, const char* s_in, const char* s_w, int lane_x, int lane_w,
@@ -493,10 +508,10 @@ struct ConvDev {
                                                             uint4 (&wfn)[NT], uint4 (&xfn)[4], f32x4 (&acc)[4][NT]) {
         if constexpr (I < FR) {
             if constexpr (NEXT) load_frag_item<I>(s + 1, w0, s_in, s_w, lane_x, lane_w, lo, wfn, xfn);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ES == 2) __builtin_amdgcn_sched_barrier(0);   // fp32: 64 MFMAs per step give hipcc room; it schedules better unfenced
 #pragma unroll
-            for (int j = (I * FM) / FR; j < ((I + 1) * FM) / FR; ++j) Mma<T>::run(wf[j % NT], xf[j / NT], acc[j / NT][j % NT]);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int m = (I * SLOTS) / FR; m < ((I + 1) * SLOTS) / FR; ++m) mma_slot(m, wf, xf, acc);
+            if constexpr (ES == 2) __builtin_amdgcn_sched_barrier(0);
             step_interleaved<I + 1, NEXT>(s, w0, s_in, s_w, lane_x, lane_w, lo, wf, xf, wfn, xfn, acc);
         }
     }
@@ -510,6 +525,18 @@ struct ConvDev {
                 uint4 wf[NT], xf[4];
                 load_frags(s, W0, s_in, s_w, lane_x, lane_w, q, lo, wf, xf);
                 mma_frags(wf, xf, acc);
+            }
+        } else if constexpr (S0 < END && ES == 4) {
+            // fp32: 16*NT MFMAs per step leave hipcc's own scheduler plenty of cover for the LDS reads; every
+            // hand-ordered variant tried (item-major or k-slice-major, fenced or not) measured 20-55 % slower
+            uint4 wfa[NT], xfa[4], wfb[NT], xfb[4];
+            load_frags(S0, W0, s_in, s_w, lane_x, lane_w, q, lo, wfa, xfa);
+#pragma unroll
+            for (int s = S0; s < END; s += 2) {
+                if (s + 1 < END) load_frags(s + 1, W0, s_in, s_w, lane_x, lane_w, q, lo, wfb, xfb);
+                mma_frags(wfa, xfa, acc);
+                if (s + 2 < END) load_frags(s + 2, W0, s_in, s_w, lane_x, lane_w, q, lo, wfa, xfa);
+                if (s + 1 < END) mma_frags(wfb, xfb, acc);
             }
         } else if constexpr (S0 < END) {
             uint4 wfa[NT], xfa[4], wfb[NT], xfb[4];
@@ -542,7 +569,9 @@ struct ConvDev {
     template <bool FAST>
     __device__ static __forceinline__ void epilogue(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
                                                     f32x4 (&acc)[4][NT]) {
-        if constexpr (!FAST) return epilogue_generic(a, b, y0, x0, sp, ct, tid, acc);
+        // fp32 always takes the generic form: with the seven-way switch hipcc keeps the fp32 accumulators in scratch
+        // (224 B/lane, measured 92 -> 74 TF/s), and its MFMA loop is 4x longer per tile anyway
+        if constexpr (!FAST || ES == 4) return epilogue_generic(a, b, y0, x0, sp, ct, tid, acc);
         else switch (a.ep_key) {                  // uniform; set by the host, >= 0 in FAST kernels
             case 0: return epilogue_fast<0>(a, b, y0, x0, sp, ct, tid, acc);
             case EP_RELU: return epilogue_fast<EP_RELU>(a, b, y0, x0, sp, ct, tid, acc);
@@ -1282,7 +1311,9 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
     }
     constexpr int WSM_LDS = wsm_lds_bytes<Cfg>();
     // multi-chunk producer/consumer form (not for gated inputs: its loader would need > 168 VGPRs at 12 waves per CU)
-    if constexpr (WSM_LDS <= 160 * 1024 && Cfg::KS == 3 && Cfg::STEPS >= 2 && !GATED) {
+    // bf16 only: in fp32 the MFMAs are 4x longer, the layers are MFMA-bound either way and the general kernel's many
+    // small blocks balance the B = 1 configurations better (measured 99 vs 88 TF/s on 64 -> 64 at 1080p)
+    if constexpr (WSM_LDS <= 160 * 1024 && Cfg::KS == 3 && Cfg::STEPS >= 2 && !GATED && sizeof(typename Cfg::elem) == 2) {
         if ((a.n_chunks > 1 || a.n_ct > 1) && a.cin_vec_ok && a.cin_chunk_ok && a.persist_ok && a.cout_packed <= kPersistMaxCout &&
             n_tiles < (1 << 24)) {
             const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch * (a.n_chunks > 1 ? a.n_ct : 1);
