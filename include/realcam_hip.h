@@ -264,6 +264,16 @@ int rc_gma_kv(const void* d_qkvp, int dtype, int batch, int n_tok, int heads, in
 int rc_gma_apply(const void* d_qkvp, const void* d_convv, const void* d_loc, const float* d_ktv, void* d_out, int dtype,
                  int batch, int n_tok, int heads, int ch, int seg, void* stream);
 
+/* ---- a17: TCM window attention -------------------------------------------------------------------
+ * Replaces the core of WMSA.forward (models/tcm.py:179-206): per ws x ws window of the cyclically shifted NHWC map
+ * and per head, softmax(q k^T / sqrt(hd) + relpos[h, dy, dx] (+ -inf across the wrap in the last window row/column
+ * when shifted)) v.  d_qkv (B,H,W,3C) = embedding_layer output on the UN-shifted map ([q | k | v], head-major inside
+ * each), d_relpos = relative_position_params (heads, 2ws-1, 2ws-1) fp32, d_out (B,H,W,C) attention output at the
+ * un-shifted pixel positions (ready for `linear`).  shift = 0 for type 'W', ws/2 for 'SW'.  The Linear layers,
+ * LayerNorms and the MLP of tcm.Block (:214-236) are rc_conv2d (1x1) / rc_layernorm. */
+int rc_window_attention(const void* d_qkv, const float* d_relpos, void* d_out, int dtype, int batch, int H, int W, int C,
+                        int head_dim, int window, int shift, void* stream);
+
 /* ---- measurement helpers (bench.py): HIP-event timing of every rc_conv2d launch on its stream -
  * rc_prof_enable(1) brackets each subsequent rc_conv2d with hipEventRecord on the launch stream;
  * rc_prof_collect() synchronises the events and returns launches / total ms / total algorithmic

@@ -59,6 +59,14 @@ def install_stubs():
     _mod("timm")
     _mod("timm.data", IMAGENET_DEFAULT_MEAN=(0.485, 0.456, 0.406), IMAGENET_DEFAULT_STD=(0.229, 0.224, 0.225))
     _mod("timm.models")
+    # CompressAI (PyPI `compressai`, no version pinned upstream) is absent: NAME-ONLY stubs so that models/tcm.py imports
+    # and its own classes (WMSA, Block, SwinBlock ...) can run; anything that instantiates a CompressAI layer raises.
+    _mod("compressai")
+    _mod("compressai.entropy_models", EntropyBottleneck=_raiser("EntropyBottleneck"), GaussianConditional=_raiser("GaussianConditional"))
+    _mod("compressai.ans", BufferedRansEncoder=_raiser("BufferedRansEncoder"), RansDecoder=_raiser("RansDecoder"))
+    _mod("compressai.models", CompressionModel=_raiser("CompressionModel"))
+    _mod("compressai.layers", **{n: _raiser(n) for n in ("AttentionBlock", "ResidualBlock", "ResidualBlockUpsample",
+                                                          "ResidualBlockWithStride", "conv3x3", "subpel_conv3x3")})
     _mod("timm.models.layers", DropPath=_DropPath, to_2tuple=lambda x: (x, x) if not isinstance(x, tuple) else x,
          trunc_normal_=torch.nn.init.trunc_normal_)
 

@@ -1,0 +1,75 @@
+"""Host mirror of the TCM transformer blocks: `WMSA` and `Block` of upstream models/tcm.py:139-236.
+
+Same class names, constructor signatures and attribute names as upstream (`ln1`, `msa.embedding_layer`,
+`msa.relative_position_params` (heads, 2ws-1, 2ws-1), `msa.linear`, `ln2`, `mlp.{0,2}`), so a reference state_dict loads
+with strict=True.  Tensors are NHWC (b, h, w, c) exactly as upstream passes them, which is also the HIP path's layout.
+The two Linear layers of WMSA and the MLP run through rc_conv2d as 1x1 convolutions (a point-wise op commutes with the
+cyclic shift, so they run on the un-shifted map), LayerNorm through rc_layernorm, and the window attention core --
+window partition, shift, relative-position bias, wrap mask, softmax, weighted sum -- is rc_window_attention.
+The rest of models/tcm.py (ConvTransBlock, the codec trunk) depends on CompressAI layers that are not in the upstream
+tree (parity unpinned) and is not built.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import check, lib
+
+
+class WMSA(nn.Module):
+    """Window / shifted-window multi-head self-attention (upstream models/tcm.py:139-212)."""
+
+    def __init__(self, input_dim, output_dim, head_dim, window_size, type):
+        super().__init__()
+        self.input_dim, self.output_dim, self.head_dim = input_dim, output_dim, head_dim
+        self.scale = head_dim ** -0.5
+        self.n_heads = input_dim // head_dim
+        self.window_size = window_size
+        self.type = type
+        self.embedding_layer = nn.Linear(input_dim, 3 * input_dim, bias=True)
+        rel = torch.zeros((2 * window_size - 1) * (2 * window_size - 1), self.n_heads)
+        nn.init.trunc_normal_(rel, std=.02)
+        self.relative_position_params = nn.Parameter(
+            rel.view(2 * window_size - 1, 2 * window_size - 1, self.n_heads).transpose(1, 2).transpose(0, 1).contiguous())
+        self.linear = nn.Linear(input_dim, output_dim)
+
+    def _attend(self, t, residual=None):
+        """t NHWC (b,h,w,c) (already normalised) -> linear(attention(t)) [+ residual]."""
+        t = ops._req(t, "WMSA input")
+        b, h, w, c = t.shape
+        ws = self.window_size
+        if c != self.input_dim or h % ws or w % ws:
+            raise ValueError(f"WMSA: expected (b, h, w, {self.input_dim}) with h, w multiples of {ws}, got {tuple(t.shape)}")
+        qkv = ops.conv2d(t, self.embedding_layer)
+        att = torch.empty_like(t)
+        check(lib().rc_window_attention(qkv.data_ptr(), ops.f32_param(self, "relative_position_params").data_ptr(), att.data_ptr(),
+                                        ops._dt(t), b, h, w, c, self.head_dim, ws, 0 if self.type == 'W' else ws // 2, ops._stream()),
+              "rc_window_attention")
+        return ops.conv2d(att, self.linear, residual=residual)
+
+    def forward(self, x):
+        return self._attend(x)
+
+
+class Block(nn.Module):
+    """x + WMSA(LN(x)); + MLP(LN(.))   (upstream models/tcm.py:214-236; DropPath is the identity in eval / at rate 0)."""
+
+    def __init__(self, input_dim, output_dim, head_dim, window_size, drop_path, type='W', input_resolution=None):
+        super().__init__()
+        assert type in ['W', 'SW']
+        self.input_dim, self.output_dim, self.type = input_dim, output_dim, type
+        self.ln1 = nn.LayerNorm(input_dim)
+        self.msa = WMSA(input_dim, input_dim, head_dim, window_size, self.type)
+        self.drop_path = nn.Identity()
+        self.ln2 = nn.LayerNorm(input_dim)
+        self.mlp = nn.Sequential(nn.Linear(input_dim, 4 * input_dim), nn.GELU(), nn.Linear(4 * input_dim, output_dim))
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        x = ops._req(x, "Block input")
+        x = self.msa._attend(ops.layernorm(x, self.ln1), residual=x)
+        h = ops.conv2d(ops.layernorm(x, self.ln2), self.mlp[0], act="gelu")
+        return ops.conv2d(h, self.mlp[2], residual=x)

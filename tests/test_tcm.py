@@ -1,0 +1,79 @@
+"""TCM transformer block: oracle vs reference fixtures on the CPU, HIP path vs fixtures on the GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import tcm_oracle as TO
+from conftest import golden_names, load_golden, rel_err
+
+FIXTURES = golden_names("tcm_block_")
+
+
+def _sd(g):
+    return g["sd"]
+
+
+def _cfg(g):
+    return int(g["head_dim"]), int(g["window"]), str(g["type"])
+
+
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_oracle_block_equals_reference(fixture):
+    g = load_golden(fixture)
+    hd, ws, typ = _cfg(g)
+    with torch.no_grad():
+        y = TO.block(_sd(g), "", g["x"], hd, ws, typ)
+    assert rel_err(y, g["y"]) < 1e-6
+
+
+def test_fixtures_cover_both_types_and_windows():
+    kinds = {(int(load_golden(f)["window"]), str(load_golden(f)["type"])) for f in FIXTURES}
+    assert kinds == {(8, "W"), (8, "SW"), (4, "W"), (4, "SW")}
+
+
+def test_shift_mask_blocks_exactly_the_wrapped_pairs():
+    m = TO.shift_mask(2, 3, 4, 2)
+    assert m.shape == (6, 16, 16) and not m[0].any() and m[5].any()
+    # last window column, first window row: tokens in columns 0-1 never see columns 2-3, rows unrestricted
+    idx = torch.arange(16)
+    expect = (idx[:, None] % 4 >= 2) != (idx[None, :] % 4 >= 2)
+    assert torch.equal(m[2], expect)
+
+
+def test_mirror_module_state_dict_matches_fixture_keys():
+    import realcamnet_amd as M
+    g = load_golden(FIXTURES[0])
+    hd, ws, typ = _cfg(g)
+    c = g["x"].shape[-1]
+    blk = M.tcm.Block(c, c, hd, ws, 0.0, type=typ)
+    sd = _sd(g)
+    assert list(blk.state_dict().keys()) == list(sd.keys())
+    blk.load_state_dict(sd, strict=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_hip_block_vs_reference(fixture, dt):
+    import realcamnet_amd as M
+    g = load_golden(fixture)
+    hd, ws, typ = _cfg(g)
+    c = g["x"].shape[-1]
+    blk = M.tcm.Block(c, c, hd, ws, 0.0, type=typ)
+    blk.load_state_dict(_sd(g), strict=True)
+    blk = blk.to("cuda", dt).eval()
+    with torch.no_grad():
+        y = blk(g["x"].to("cuda", dt)).float().cpu()
+    assert rel_err(y, g["y"]) < (2e-5 if dt == torch.float32 else 3e-2)
+
+
+@pytest.mark.gpu
+def test_window_attention_rejects_bad_shapes():
+    import realcamnet_amd as M
+    blk = M.tcm.Block(64, 64, 16, 8, 0.0, type="SW").to("cuda").eval()
+    with pytest.raises(ValueError):
+        blk(torch.zeros(1, 12, 16, 64, device="cuda"))
