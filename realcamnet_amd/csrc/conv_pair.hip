@@ -13,12 +13,14 @@
 // pair costs 1.19x the MFMA work of the two separate layers and ~half their HBM traffic.  mid pixels outside the
 // image are forced to zero (conv2 zero-pads ITS input, it does not see conv1 of the padding).
 //
-// One 512-thread block per CU (LDS: both packed weight matrices 84 KB + input tile 40.5 KB + mid tile 32 KB),
-// persistent over a band-major XCD-aware tile list like the single-layer kernels.  Per tile:
-//   phase 1  all 8 waves: conv1 on 22 linear 16-pixel tiles of the mid grid (3,3,3,3,3,3,2,2 per wave) -> LDS
+// One 768-thread block per CU (LDS: both packed weight matrices 84 KB + input tile 40.5 KB + mid tile 32 KB): 8 compute
+// waves (two per SIMD: one wave alone only reaches 59 % of the MFMA rate) + 4 loader waves, persistent over a band-major
+// XCD-aware tile list like the single-layer kernels.  Per tile:
+//   phase 1  compute: conv1 on 22 linear 16-pixel tiles of the mid grid (3,3,3,3,3,3,2,2 per wave) -> LDS
+//            loaders: tile k+1's registers -> r*gate + skip, skip-tensor store
 //   barrier  (mid complete, input tile free)
-//   stage    registers holding tile k+1's input (loaded one tile earlier) -> LDS; issue tile k+2's loads
-//   phase 2  all 8 waves: conv2, wave w = output row w (2 pixel tiles) -> epilogue -> HBM
+//   phase 2  compute: conv2, wave w = output row w (2 pixel tiles) -> epilogue -> HBM
+//            loaders: combined tile k+1 -> LDS; issue tile k+2's loads
 //   barrier  (input tile k+1 visible, mid free)
 // The MFMA / LDS-read interleave, weight fragment layout (rc_conv_pack_weights, CK = 48, NT = 3) and unit map are
 // those of conv_kernel.hpp.
@@ -40,8 +42,8 @@ constexpr int W_BYTES = STEPS * NT * 1024;        // one packed 48x(9*48) weight
 constexpr int OFF_W1 = 0, OFF_W2 = W_BYTES, OFF_BIAS = 2 * W_BYTES, OFF_IN = OFF_BIAS + 2 * C * 4;
 constexpr int OFF_MID = OFF_IN + NIN * SPIX, LDS_BYTES = OFF_MID + NMID * SPIX;
 static_assert(LDS_BYTES <= 160 * 1024, "pair kernel LDS budget");
-constexpr int THREADS = 512, WAVES = 8;
-constexpr int VPP = 6, PPP = THREADS / VPP, ACTIVE = PPP * VPP, NI = (NIN + PPP - 1) / PPP;   // staging map, as ConvDev
+constexpr int WAVES = 8, LOADERS = 256, THREADS = WAVES * 64 + LOADERS;   // 8 compute waves (two per SIMD) + 4 loader waves
+constexpr int VPP = 6, PPP = LOADERS / VPP, ACTIVE = PPP * VPP, NI = (NIN + PPP - 1) / PPP;   // staging map over the loader threads, as ConvDev
 
 enum { E1_RELU = 0, E1_FILM_LEAKY = 1 };
 enum { E2_PLAIN = 0, E2_SUMS = 1, E2_RES = 2 };
@@ -193,32 +195,35 @@ __device__ __forceinline__ void load_gate(const PairArgs& a, int b, int tid, flo
         for (int e = 0; e < 8; ++e) gv[e] = tid < ACTIVE ? a.in_gate[(size_t)b * C + c0 + e] : 0.f;
     }
 }
+// registers -> combined tile (r*gate + skip, materialised for the centre pixels); leaves the 16-byte pieces in r0
 template <bool GATED>
-__device__ __forceinline__ void commit(const PairArgs& a, const TileSrc& t, const TileOffs& to, int tid, const uint4 (&r0)[NI],
-                                       const uint4 (&r1)[GATED ? NI : 1], const float (&gv)[GATED ? 8 : 1], char* smem) {
-    const int v = tid % VPP, p0 = tid / VPP;
-    char* dst = smem + OFF_IN + p0 * SPIX + v * 16;
+__device__ __forceinline__ void combine(const PairArgs& a, const TileSrc& t, const TileOffs& to, int tid, uint4 (&r0)[NI],
+                                        const uint4 (&r1)[GATED ? NI : 1], const float (&gv)[GATED ? 8 : 1]) {
+    if constexpr (GATED) {
 #pragma unroll
-    for (int k = 0; k < NI; ++k) {
-        const int pix = p0 + k * PPP;
-        uint4 raw = r0[k];
-        if constexpr (GATED) {
+        for (int k = 0; k < NI; ++k) {
             float f0[8], f1[8];
             Vec16<bf16_t>::unpack(r0[k], f0);
             Vec16<bf16_t>::unpack(r1[k], f1);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f0[e] = f0[e] * gv[e] + f1[e];       // zero-filled lanes stay 0
-            raw = Vec16<bf16_t>::pack(f0);
+            r0[k] = Vec16<bf16_t>::pack(f0);
             if (t.interior) {
-                buf_store16(t.rst, to.ctr[k], t.soff, raw);                   // rst has 0 records if in_store == NULL
+                buf_store16(t.rst, to.ctr[k], t.soff, r0[k]);                 // rst has 0 records if in_store == NULL
             } else {
                 bool center;
                 const int off = border_off(a, t, tid, k, center);
-                buf_store16(t.rst, center ? off : kOOB, 0, raw);
+                buf_store16(t.rst, center ? off : kOOB, 0, r0[k]);
             }
         }
-        if (tid < ACTIVE && pix < NIN) *reinterpret_cast<uint4*>(dst + k * PPP * SPIX) = raw;
     }
+}
+__device__ __forceinline__ void write_tile(int tid, const uint4 (&r0)[NI], char* smem) {
+    const int v = tid % VPP, p0 = tid / VPP;
+    char* dst = smem + OFF_IN + p0 * SPIX + v * 16;
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+        if (tid < ACTIVE && p0 + k * PPP < NIN) *reinterpret_cast<uint4*>(dst + k * PPP * SPIX) = r0[k];
 }
 
 template <int CTRL>
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(THREADS) void conv_pair_kernel(const PairArgs a) {
     const int q = lane >> 4, n = lane & 15;
 
     // both weight matrices + biases, once per block (1 KiB per wave-instruction by LDS-DMA)
-    for (int kb = w; kb < 2 * STEPS * NT; kb += WAVES) {
+    for (int kb = w; kb < 2 * STEPS * NT; kb += THREADS / 64) {
         const char* src = kb < STEPS * NT ? static_cast<const char*>(a.w1) + kb * 1024 : static_cast<const char*>(a.w2) + (kb - STEPS * NT) * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 16),
                                          (__attribute__((address_space(3))) void*)(smem + kb * 1024), 16, 0, 0);
@@ -264,9 +269,6 @@ __global__ __launch_bounds__(THREADS) void conv_pair_kernel(const PairArgs a) {
     for (int h = 0; h < 2; ++h) xb2[h] = OFF_MID + (w * MW + 16 * h + n) * SPIX;
     const int wb1 = OFF_W1 + lane * 16, wb2 = OFF_W2 + lane * 16;
 
-    TileOffs to;
-    tile_offsets(a, tid, to);
-
     const int sp_total = a.tiles_x * a.tiles_y;
     const int n_tiles = sp_total * a.batch;
     const int slots = gridDim.x >> 3;                              // gridDim.x is a multiple of 8
@@ -281,31 +283,56 @@ __global__ __launch_bounds__(THREADS) void conv_pair_kernel(const PairArgs a) {
         sp = ty * a.tiles_x + tx; y0 = ty * OTH; x0 = tx * OTW;
     };
 
-    uint4 r0[NI], r1[GATED ? NI : 1];
-    float gv[GATED ? 8 : 1];
-    TileSrc ts;
-    int nb = 0, nsp = 0, ny0 = 0, nx0 = 0;                         // the tile whose input is in registers / in flight
-    if (my_tiles > 0) {                                            // tile 0 straight into LDS
-        decode(pos, nb, nsp, ny0, nx0);
-        ts = tile_src(a, nb, ny0, nx0);
-        load_gate<GATED>(a, nb, tid, gv);
-        if (ts.interior) load_interior<GATED>(ts, to, r0, r1); else load_border<GATED>(a, ts, tid, r0, r1);
-        commit<GATED>(a, ts, to, tid, r0, r1, gv, smem);
+    if (w >= WAVES) {
+        // ---------------------------------------------------------------- loader waves 8-11
+        // tile k+1's input sits in registers while tile k is computed: the gate math (r*g + skip) and the skip-tensor store
+        // run beside phase 1, the LDS write and the next tile's loads beside phase 2 -- none of it on the compute waves
+        const int ltid = tid - WAVES * 64;
+        TileOffs to;
+        tile_offsets(a, ltid, to);
+        uint4 r0[NI], r1[GATED ? NI : 1];
+        float gv[GATED ? 8 : 1];
+        TileSrc ts;
+        int b, sp, y0, x0;
+        auto fetch = [&](int tile, bool sync_border) {              // loads of one tile -> registers (border tiles only when asked)
+            decode(tile, b, sp, y0, x0);
+            ts = tile_src(a, b, y0, x0);
+            load_gate<GATED>(a, b, ltid, gv);
+            if (ts.interior) load_interior<GATED>(ts, to, r0, r1);
+            else if (sync_border) load_border<GATED>(a, ts, ltid, r0, r1);
+        };
+        if (my_tiles > 0) {
+            fetch(pos, true);
+            combine<GATED>(a, ts, to, ltid, r0, r1, gv);
+            write_tile(ltid, r0, smem);
+        }
+        if (my_tiles > 1) fetch(pos + stride, false);
+        __syncthreads();                                           // weights, biases, tile 0 visible
+        for (int k = 0; k < my_tiles; ++k) {
+            if (k + 1 < my_tiles) {                                // beside phase 1 of tile k
+                if (!ts.interior) load_border<GATED>(a, ts, ltid, r0, r1);          // border tiles are not prefetched
+                combine<GATED>(a, ts, to, ltid, r0, r1, gv);
+            }
+            __syncthreads();                                       // A: the input tile is free
+            if (k + 1 < my_tiles) {                                // beside phase 2 of tile k
+                write_tile(ltid, r0, smem);
+                if (k + 2 < my_tiles) fetch(pos + (k + 2) * stride, false);
+            }
+            __syncthreads();                                       // B: input tile k+1 visible
+        }
+        return;
     }
-    int cb = nb, csp = nsp, cy0 = ny0, cx0 = nx0;                  // the tile being computed
-    if (my_tiles > 1) {
-        decode(pos + stride, nb, nsp, ny0, nx0);
-        ts = tile_src(a, nb, ny0, nx0);
-        load_gate<GATED>(a, nb, tid, gv);
-        if (ts.interior) load_interior<GATED>(ts, to, r0, r1);
-    }
+
+    // -------------------------------------------------------------------- compute waves 0-7 (two per SIMD)
+    int cb = 0, csp = 0, cy0 = 0, cx0 = 0;                         // the tile being computed
+    if (my_tiles > 0) decode(pos, cb, csp, cy0, cx0);
     __syncthreads();                                               // weights, biases, tile 0 visible
 
     const float inf = __builtin_inff();
     const bool rec = a.dbg != nullptr && blockIdx.x == 8 && w == 0 && lane == 0;
     for (int k = 0; k < my_tiles; ++k) {
         const long long t0 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        long long t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+        long long t1 = 0, t2 = 0, t3 = 0, t5 = 0, t6 = 0;
         // ------------------------------------------------ phase 1: mid = act1(conv1(x)) on the 10 x 34 ring tile
         {
             f32x4 acc[3][NT];
@@ -378,88 +405,66 @@ __global__ __launch_bounds__(THREADS) void conv_pair_kernel(const PairArgs a) {
             }
         }
         t2 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        __syncthreads();                                           // A: mid tile complete; the input tile is free
+        __syncthreads();                                           // A: mid tile complete
         t3 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
-
-        // ------------------------------------------------ stage tile k+1's input, then phase 2
-        // (staggering the two halves of the block -- lower waves stage first, upper waves last -- measured 6 % SLOWER)
-        const int pb = nb, psp = nsp, py0 = ny0, px0 = nx0;        // tile k+1 (valid if k+1 < my_tiles)
-        auto stage = [&]() {
-        if (k + 1 < my_tiles) {
-                if (!ts.interior) load_border<GATED>(a, ts, tid, r0, r1);              // border tiles are not prefetched
-                commit<GATED>(a, ts, to, tid, r0, r1, gv, smem);
-                if (k + 2 < my_tiles) {
-                    decode(pos + (k + 2) * stride, nb, nsp, ny0, nx0);
-                    ts = tile_src(a, nb, ny0, nx0);
-                    load_gate<GATED>(a, nb, tid, gv);
-                    if (ts.interior) load_interior<GATED>(ts, to, r0, r1);
-                }
-            }
-
-        };
-        auto phase2 = [&]() {
         // ------------------------------------------------ phase 2: out = conv2(mid) (+ residual, + channel sums)
-            {
-                f32x4 acc[2][NT];
+        {
+            f32x4 acc[2][NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(s_bias + C + q * NV + nt * 4);
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 t4 = *reinterpret_cast<const float4*>(s_bias + C + q * NV + nt * 4);
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) acc[h][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
-                }
-                PairMma<MW, 2>::run(smem, xb2, wb2, q, acc);
-                t5 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+                for (int h = 0; h < 2; ++h) acc[h][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
+            }
+            PairMma<MW, 2>::run(smem, xb2, wb2, q, acc);
+            t5 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
 
-                const size_t img = (size_t)a.H * a.W * C;
-                const unsigned img_bytes = (unsigned)(img * ES);
-                const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out + (size_t)cb * img, img_bytes);
-                const int gy = cy0 + w;
-                float csum[NV];
+            const size_t img = (size_t)a.H * a.W * C;
+            const unsigned img_bytes = (unsigned)(img * ES);
+            const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out + (size_t)cb * img, img_bytes);
+            const int gy = cy0 + w;
+            float csum[NV];
 #pragma unroll
-                for (int e = 0; e < NV; ++e) csum[e] = 0.f;
+            for (int e = 0; e < NV; ++e) csum[e] = 0.f;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int gx = cx0 + 16 * h + n;
-                    const bool valid = gy < a.H && gx < a.W;
-                    const int off = valid ? ((gy * a.W + gx) * C + q * NV) * ES : kOOB;
-                    float v[NV];
+            for (int h = 0; h < 2; ++h) {
+                const int gx = cx0 + 16 * h + n;
+                const bool valid = gy < a.H && gx < a.W;
+                const int off = valid ? ((gy * a.W + gx) * C + q * NV) * ES : kOOB;
+                float v[NV];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[h][nt][r];
-                    if constexpr (E2 == E2_RES) {
-                        float m[NV];
-                        buf_load_row<bf16_t, NV>(make_rsrc(a.residual + (size_t)cb * img, img_bytes), off, m);
+                    for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[h][nt][r];
+                if constexpr (E2 == E2_RES) {
+                    float m[NV];
+                    buf_load_row<bf16_t, NV>(make_rsrc(a.residual + (size_t)cb * img, img_bytes), off, m);
 #pragma unroll
-                        for (int e = 0; e < NV; ++e) v[e] += m[e];
-                    }
-                    if constexpr (E2 == E2_SUMS) {
-#pragma unroll
-                        for (int e = 0; e < NV; ++e) csum[e] += valid ? v[e] : 0.f;
-                    }
-                    buf_store_row<bf16_t, NV, false>(r_out, off, v);
+                    for (int e = 0; e < NV; ++e) v[e] += m[e];
                 }
                 if constexpr (E2 == E2_SUMS) {
-                    // one partial per wave (slot = 8*tile + wave); rc_ca_gate folds them in fixed order
 #pragma unroll
-                    for (int e = 0; e < NV; ++e) csum[e] = row_sum16(csum[e]);
-                    if (n == 0) {
-                        float* dst = a.chan_sums + (((size_t)cb * sp_total + csp) * WAVES + w) * C + q * NV;
+                    for (int e = 0; e < NV; ++e) csum[e] += valid ? v[e] : 0.f;
+                }
+                buf_store_row<bf16_t, NV, false>(r_out, off, v);
+            }
+            if constexpr (E2 == E2_SUMS) {
+                // one partial per wave (slot = 8*tile + wave); rc_ca_gate folds them in fixed order
 #pragma unroll
-                        for (int e = 0; e < NV; ++e) dst[e] = csum[e];
-                    }
+                for (int e = 0; e < NV; ++e) csum[e] = row_sum16(csum[e]);
+                if (n == 0) {
+                    float* dst = a.chan_sums + (((size_t)cb * sp_total + csp) * WAVES + w) * C + q * NV;
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) dst[e] = csum[e];
                 }
             }
-        };
-        t4 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        stage();
-        phase2();
-        cb = pb; csp = psp; cy0 = py0; cx0 = px0;
+        }
+        if (k + 1 < my_tiles) decode(pos + (k + 1) * stride, cb, csp, cy0, cx0);
         t6 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
         __syncthreads();                                           // B: input tile k+1 visible; mid tile free
         if (rec && k < 60) {
             long long* d = a.dbg + 8 * k;
-            d[0] = t1 - t0; d[1] = t2 - t1; d[2] = t3 - t2; d[3] = t4 - t3; d[4] = t5 - t4; d[5] = t6 - t5;
+            d[0] = t1 - t0; d[1] = t2 - t1; d[2] = t3 - t2; d[3] = 0; d[4] = t5 - t3; d[5] = t6 - t5;
             d[6] = (long long)__builtin_amdgcn_s_memtime() - t6;
         }
     }

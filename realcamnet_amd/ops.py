@@ -298,8 +298,8 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
 
 # conv -> act -> conv pairs (RCABlock.res, Res_GFM) as ONE launch with the intermediate in LDS (rc_conv_pair).
 # Off by default: bit-identical to two launches and half their HBM traffic, but measured slower on MI355X in round 1
-# (1.62 vs 1.52 ms per 4K x8 pair; gated 2.34 vs 2.06): its phases serialise on two block-wide barriers per tile and
-# the MFMA pipe sits at 55 %.  DESIGN.md section 4.3 has the phase breakdown and what a pipelined version needs.
+# (1.63 vs 1.51 ms per 4K x8 pair; gated 2.08 vs 2.03): the MFMA pipe sits at 53 % (phase 2 -- conv2 + stores + sums --
+# takes 2.5x its MFMA time).  DESIGN.md section 4.3 has the phase breakdown.
 FUSE_PAIR = False
 
 
