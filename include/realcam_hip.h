@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 1
+#define RC_ABI_VERSION 2
 
 typedef enum rc_status {
     RC_OK = 0,
