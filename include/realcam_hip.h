@@ -264,6 +264,12 @@ int rc_gma_kv(const void* d_qkvp, int dtype, int batch, int n_tok, int heads, in
 int rc_gma_apply(const void* d_qkvp, const void* d_convv, const void* d_loc, const float* d_ktv, void* d_out, int dtype,
                  int batch, int n_tok, int heads, int ch, int seg, void* stream);
 
+/* ---- a18 plumbing: channel split / concat of NHWC tensors -----------------------------------------
+ * Replaces torch.split / torch.cat along the channel dim in ConvTransBlock.forward (models/tcm.py:261-266):
+ * dst[p, dst_c0 + c] = src[p, src_c0 + c] for c < n_ch, all offsets / counts whole 16-byte vectors. */
+int rc_channel_copy(const void* d_src, int src_stride_c, int src_c0, void* d_dst, int dst_stride_c, int dst_c0, int n_ch,
+                    long long pixels, int dtype, void* stream);
+
 /* ---- a17: TCM window attention -------------------------------------------------------------------
  * Replaces the core of WMSA.forward (models/tcm.py:179-206): per ws x ws window of the cyclically shifted NHWC map
  * and per head, softmax(q k^T / sqrt(hd) + relpos[h, dy, dx] (+ -inf across the wrap in the last window row/column

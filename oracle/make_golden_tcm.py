@@ -53,5 +53,80 @@ def main():
         print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, oracle max |diff| {(y - yo).abs().max().item():.2e}")
 
 
+def swin():
+    torch.set_num_threads(1)
+    (T,) = R.load("tcm")
+    g = torch.Generator().manual_seed(4321)
+    torch.manual_seed(0)
+    c, hd, ws = 64, 16, 8
+    m = T.SwinBlock(c, c, hd, ws, 0.0).eval()
+    with torch.no_grad():
+        for k, v in m.state_dict().items():
+            if k.endswith("bias") or "ln" in k:
+                v.add_(torch.randn(v.shape, generator=g) * 0.1)
+            if k.endswith("relative_position_params"):
+                v.add_(torch.randn(v.shape, generator=g) * 0.5)
+        x = torch.randn(1, c, 16, 24, generator=g)
+        y = m(x)
+        sd = m.state_dict()
+        yo = TO.swin_block(sd, "", x, hd, ws)
+    assert (y - yo).abs().max() <= 1e-5 * y.abs().max()
+    arrays = {"x": x.numpy(), "y": y.numpy(), "head_dim": np.array(hd), "window": np.array(ws),
+              "torch_version": np.array(torch.__version__), "reference": np.array("kepengxu/RealCamNet@2024-10-20")}
+    arrays.update({"sd." + k: v.numpy() for k, v in sd.items()})
+    path = os.path.join(OUT, "tcm_swinblock_ws8_c64_hd16.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"tcm_swinblock_ws8_c64_hd16: {os.path.getsize(path) / 1024:.1f} KiB, oracle max |diff| {(y - yo).abs().max().item():.2e}")
+
+
+class _RestatedResidualBlock(torch.nn.Module):
+    """Stand-in for compressai.layers.ResidualBlock (absent here), written from its published definition; only used to let
+    the reference's ConvTransBlock run.  The fixture it produces pins ConvTransBlock's OWN logic (split, double residual,
+    concat order, 1x1 convs, Block); this layer itself stays unpinned."""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.conv1 = torch.nn.Conv2d(in_ch, out_ch, 3, padding=1)
+        self.leaky_relu = torch.nn.LeakyReLU(inplace=True)
+        self.conv2 = torch.nn.Conv2d(out_ch, out_ch, 3, padding=1)
+        self.skip = torch.nn.Conv2d(in_ch, out_ch, 1) if in_ch != out_ch else None
+
+    def forward(self, x):
+        out = self.leaky_relu(self.conv2(self.leaky_relu(self.conv1(x))))
+        return out + (x if self.skip is None else self.skip(x))
+
+
+def conv_trans():
+    torch.set_num_threads(1)
+    (T,) = R.load("tcm")
+    T.ResidualBlock = _RestatedResidualBlock
+    g = torch.Generator().manual_seed(777)
+    for name, typ in (("tcm_convtrans_W_n64_hd16_ws8", "W"), ("tcm_convtrans_SW_n64_hd16_ws8", "SW")):
+        torch.manual_seed(0)
+        m = T.ConvTransBlock(64, 64, 16, 8, 0.0, type=typ).eval()
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                if k.endswith("bias") or "ln" in k:
+                    v.add_(torch.randn(v.shape, generator=g) * 0.1)
+                if k.endswith("relative_position_params"):
+                    v.add_(torch.randn(v.shape, generator=g) * 0.5)
+            x = torch.randn(1, 128, 16, 24, generator=g)
+            y = m(x)
+            sd = m.state_dict()
+            yo = TO.conv_trans_block(sd, "", x, 64, 64, 16, 8, typ)
+        assert (y - yo).abs().max() <= 1e-5 * y.abs().max(), name
+        arrays = {"x": x.numpy(), "y": y.numpy(), "head_dim": np.array(16), "window": np.array(8), "type": np.array(typ),
+                  "conv_dim": np.array(64), "trans_dim": np.array(64),
+                  "torch_version": np.array(torch.__version__), "reference": np.array("kepengxu/RealCamNet@2024-10-20 (+ restated compressai ResidualBlock)")}
+        arrays.update({"sd." + k: v.numpy() for k, v in sd.items()})
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **arrays)
+        print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, oracle max |diff| {(y - yo).abs().max().item():.2e}")
+
+
 if __name__ == "__main__":
+    if "--swin" in sys.argv:
+        swin(); sys.exit(0)
+    if "--convtrans" in sys.argv:
+        conv_trans(); sys.exit(0)
     main()

@@ -127,6 +127,20 @@ __global__ void gate_residual_kernel(const T* __restrict__ r, const float* __res
     }
 }
 
+// ---- dst[p, dst_c0 + c] = src[p, src_c0 + c], c < n_ch: channel split / concat of NHWC tensors in 16-byte vectors ------
+template <typename T>
+__global__ void channel_copy_kernel(const T* __restrict__ src, int src_stride, int src_c0, T* __restrict__ dst, int dst_stride,
+                                    int dst_c0, int n_ch, size_t pixels) {
+    constexpr int U = Vec16<T>::N;
+    const int vpp = n_ch / U;
+    const size_t total = pixels * vpp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / vpp;
+        const int v = (int)(i - p * vpp);
+        *reinterpret_cast<uint4*>(dst + p * dst_stride + dst_c0 + v * U) = *reinterpret_cast<const uint4*>(src + p * src_stride + src_c0 + v * U);
+    }
+}
+
 // ---- Haar DWT as the reference's frozen grouped conv (taps read from the state_dict tensor) ------
 // forward: x (B,H,W,C) -> y (B,H/2,W/2,4C): y[.., 4c+k] = sum_{i,j} taps[4c+k][i][j] * x[2y+i][2x+j][c]
 // One thread per (output pixel, 16-byte group of input channels).
@@ -295,6 +309,26 @@ int rc_gate_residual(const void* d_r, const float* d_gate, const void* d_x, void
     else
         hipLaunchKernelGGL(gate_residual_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
                            static_cast<const bf16_t*>(d_r), d_gate, static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_y), batch, (size_t)n_pix, c);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_channel_copy(const void* d_src, int src_stride_c, int src_c0, void* d_dst, int dst_stride_c, int dst_c0, int n_ch,
+                    long long pixels, int dtype, void* stream) {
+    RC_REQUIRE(d_src && d_dst, "rc_channel_copy: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_channel_copy: bad dtype");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    RC_REQUIRE(pixels >= 1 && n_ch >= U && n_ch % U == 0 && src_stride_c % U == 0 && dst_stride_c % U == 0 && src_c0 % U == 0 && dst_c0 % U == 0 &&
+               src_c0 >= 0 && dst_c0 >= 0 && src_c0 + n_ch <= src_stride_c && dst_c0 + n_ch <= dst_stride_c,
+               "rc_channel_copy: channel ranges must be whole 16-byte vectors inside both tensors");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_src) % 16 == 0 && reinterpret_cast<uintptr_t>(d_dst) % 16 == 0, "rc_channel_copy: 16-byte alignment");
+    const size_t total = (size_t)pixels * (n_ch / U);
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(channel_copy_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const float*>(d_src), src_stride_c, src_c0, static_cast<float*>(d_dst), dst_stride_c, dst_c0, n_ch, (size_t)pixels);
+    else
+        hipLaunchKernelGGL(channel_copy_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_src), src_stride_c, src_c0, static_cast<bf16_t*>(d_dst), dst_stride_c, dst_c0, n_ch, (size_t)pixels);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

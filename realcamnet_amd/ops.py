@@ -406,6 +406,29 @@ def gate_residual(r: torch.Tensor, gate: torch.Tensor, x: torch.Tensor) -> torch
     return y
 
 
+def channel_slice(x: torch.Tensor, c0: int, n: int) -> torch.Tensor:
+    """x[..., c0:c0+n] of an NHWC tensor as a new dense tensor (torch.split along channels, models/tcm.py:261)."""
+    x = _req(x, "channel_slice input")
+    out = torch.empty((*x.shape[:-1], n), dtype=x.dtype, device=x.device)
+    check(lib().rc_channel_copy(x.data_ptr(), x.shape[-1], c0, out.data_ptr(), n, 0, n, x.numel() // x.shape[-1], _dt(x), _stream()), "rc_channel_copy")
+    return out
+
+
+def channel_concat(parts) -> torch.Tensor:
+    """torch.cat along the channel dim of NHWC tensors (models/tcm.py:265)."""
+    parts = [_req(t, "channel_concat input") for t in parts]
+    ctot = sum(t.shape[-1] for t in parts)
+    out = torch.empty((*parts[0].shape[:-1], ctot), dtype=parts[0].dtype, device=parts[0].device)
+    c0 = 0
+    for t in parts:
+        if t.shape[:-1] != parts[0].shape[:-1] or t.dtype != parts[0].dtype:
+            raise ValueError("channel_concat: shape / dtype mismatch")
+        check(lib().rc_channel_copy(t.data_ptr(), t.shape[-1], 0, out.data_ptr(), ctot, c0, t.shape[-1], t.numel() // t.shape[-1], _dt(t), _stream()),
+              "rc_channel_copy")
+        c0 += t.shape[-1]
+    return out
+
+
 _ONES = {}
 
 

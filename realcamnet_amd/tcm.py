@@ -14,6 +14,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from . import networks as N
 from . import ops
 from .ops import check, lib
 
@@ -73,3 +74,72 @@ class Block(nn.Module):
         x = self.msa._attend(ops.layernorm(x, self.ln1), residual=x)
         h = ops.conv2d(ops.layernorm(x, self.ln2), self.mlp[0], act="gelu")
         return ops.conv2d(h, self.mlp[2], residual=x)
+
+
+class SwinBlock(nn.Module):
+    """Block('W') then Block('SW') on an NCHW map (upstream models/tcm.py:299-312).  NCHW in / NCHW out as upstream; the
+    two blocks run on the NHWC view.  Maps must be larger than the window in both dimensions (upstream's padding branch
+    for smaller maps yields sizes the window partition rejects)."""
+
+    def __init__(self, input_dim, output_dim, head_dim, window_size, drop_path) -> None:
+        super().__init__()
+        self.block_1 = Block(input_dim, output_dim, head_dim, window_size, drop_path, type='W')
+        self.block_2 = Block(input_dim, output_dim, head_dim, window_size, drop_path, type='SW')
+        self.window_size = window_size
+
+    def forward(self, x):
+        if x.size(-1) <= self.window_size or x.size(-2) <= self.window_size:
+            raise ValueError("SwinBlock: the map must be larger than the window")
+        t = self.block_2(self.block_1(ops.to_nhwc(x)))
+        return ops.to_nchw(t)
+
+
+class ResidualBlock(nn.Module):
+    """CompressAI's `ResidualBlock(in_ch, out_ch)` (compressai.layers; PyPI package, NOT in the upstream tree, no version
+    pinned -- SURVEY.md 8c "parity unpinned"), restated from its published definition:
+        out = LeakyReLU(conv3x3(LeakyReLU(conv3x3(x)))) + (conv1x1(x) if in_ch != out_ch else x),   LeakyReLU slope 0.01
+    with attributes conv1, conv2 (and skip) so a CompressAI state_dict loads."""
+
+    def __init__(self, in_ch: int, out_ch: int):
+        super().__init__()
+        self.conv1 = N.Conv2d(in_ch, out_ch, 3, 1, 1)
+        self.leaky_relu = nn.LeakyReLU(inplace=True)
+        self.conv2 = N.Conv2d(out_ch, out_ch, 3, 1, 1)
+        self.skip = N.Conv2d(in_ch, out_ch, 1, 1, 0) if in_ch != out_ch else None
+
+    def _nhwc(self, a):
+        slope = float(self.leaky_relu.negative_slope)
+        identity = a if self.skip is None else self.skip._nhwc(a)
+        t = self.conv1._nhwc(a, act="leaky", slope=slope)
+        return self.conv2._nhwc(t, act="leaky", slope=slope, residual=identity)
+
+    def forward(self, x):
+        return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
+
+
+class ConvTransBlock(nn.Module):
+    """1x1 conv -> split -> [ResidualBlock(conv_x) + conv_x  ||  Block(trans_x)] -> concat -> 1x1 conv -> + x
+    (upstream models/tcm.py:242-268; note the double residual on the conv branch, :262).  NCHW in / NCHW out."""
+
+    def __init__(self, conv_dim, trans_dim, head_dim, window_size, drop_path, type='W'):
+        super().__init__()
+        assert type in ['W', 'SW']
+        self.conv_dim, self.trans_dim, self.head_dim, self.window_size, self.drop_path, self.type = \
+            conv_dim, trans_dim, head_dim, window_size, drop_path, type
+        self.trans_block = Block(trans_dim, trans_dim, head_dim, window_size, drop_path, type)
+        self.conv1_1 = N.Conv2d(conv_dim + trans_dim, conv_dim + trans_dim, 1, 1, 0, bias=True)
+        self.conv1_2 = N.Conv2d(conv_dim + trans_dim, conv_dim + trans_dim, 1, 1, 0, bias=True)
+        self.conv_block = ResidualBlock(conv_dim, conv_dim)
+
+    def _nhwc(self, a):
+        t = self.conv1_1._nhwc(a)
+        conv_x = ops.channel_slice(t, 0, self.conv_dim)
+        trans_x = ops.channel_slice(t, self.conv_dim, self.trans_dim)
+        conv_x = ops.add(self.conv_block._nhwc(conv_x), conv_x)
+        trans_x = self.trans_block(trans_x)
+        return self.conv1_2._nhwc(ops.channel_concat([conv_x, trans_x]), residual=a)
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))

@@ -71,6 +71,55 @@ def test_hip_block_vs_reference(fixture, dt):
     assert rel_err(y, g["y"]) < (2e-5 if dt == torch.float32 else 3e-2)
 
 
+def test_oracle_swinblock_equals_reference():
+    g = load_golden("tcm_swinblock_ws8_c64_hd16")
+    with torch.no_grad():
+        y = TO.swin_block(g["sd"], "", g["x"], int(g["head_dim"]), int(g["window"]))
+    assert rel_err(y, g["y"]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_hip_swinblock_vs_reference(dt):
+    import realcamnet_amd as M
+    g = load_golden("tcm_swinblock_ws8_c64_hd16")
+    c = g["x"].shape[1]
+    m = M.tcm.SwinBlock(c, c, int(g["head_dim"]), int(g["window"]), 0.0)
+    m.load_state_dict(g["sd"], strict=True)
+    m = m.to("cuda", dt).eval()
+    with torch.no_grad():
+        y = m(g["x"].to("cuda", dt)).float().cpu()
+    assert rel_err(y, g["y"]) < (2e-5 if dt == torch.float32 else 4e-2)
+
+
+CONVTRANS = golden_names("tcm_convtrans_")
+
+
+@pytest.mark.parametrize("fixture", CONVTRANS)
+def test_oracle_convtransblock_equals_reference(fixture):
+    """ConvTransBlock's own logic (split, double residual, concat order) against the reference run with a restated
+    CompressAI ResidualBlock (that one layer is not in the upstream tree: parity unpinned for it)."""
+    g = load_golden(fixture)
+    with torch.no_grad():
+        y = TO.conv_trans_block(g["sd"], "", g["x"], int(g["conv_dim"]), int(g["trans_dim"]), int(g["head_dim"]), int(g["window"]), str(g["type"]))
+    assert rel_err(y, g["y"]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fixture", CONVTRANS)
+def test_hip_convtransblock_vs_reference(fixture, dt):
+    import realcamnet_amd as M
+    g = load_golden(fixture)
+    m = M.tcm.ConvTransBlock(int(g["conv_dim"]), int(g["trans_dim"]), int(g["head_dim"]), int(g["window"]), 0.0, type=str(g["type"]))
+    assert list(m.state_dict().keys()) == list(g["sd"].keys())
+    m.load_state_dict(g["sd"], strict=True)
+    m = m.to("cuda", dt).eval()
+    with torch.no_grad():
+        y = m(g["x"].to("cuda", dt)).float().cpu()
+    assert rel_err(y, g["y"]) < (2e-5 if dt == torch.float32 else 4e-2)
+
+
 @pytest.mark.gpu
 def test_window_attention_rejects_bad_shapes():
     import realcamnet_amd as M
