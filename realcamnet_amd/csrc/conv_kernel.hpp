@@ -1181,16 +1181,27 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
     if (loader) {
         // ---------------------------------------------------------------- producer waves
         const int rtid = tid - kWsmCompute;                          // 0..255
-        uint4 r0[D::NI], r1[GATED ? D::NI : 1], wra[NWA], wrb[NWB];
+        // gated inputs: two tile operands already fill the loader's 168 VGPRs, so the weight halves go by LDS-DMA instead
+        // of through registers -- issued at the start of the half in which their LDS region is free, landed by the barrier
+        // that ends it (the barrier's vmcnt(0) also waits for this half's tile loads; they had the same half to arrive)
+        constexpr bool WDMA = GATED;
+        uint4 r0[D::NI], r1[GATED ? D::NI : 1], wra[WDMA ? 1 : NWA], wrb[WDMA ? 1 : NWB];
         float gv[GATED ? D::UNIT : 1];
         typename D::TileSrc ts;
         typename D::TileOffs to;
         D::tile_offsets(a, rtid, to);
-        int woa[NWA], wob[NWB];                                      // this thread's 16-byte pieces of the two weight halves
+        int woa[WDMA ? 1 : NWA], wob[WDMA ? 1 : NWB];                // this thread's 16-byte pieces of the two weight halves
+        if constexpr (!WDMA) {
 #pragma unroll
-        for (int k = 0; k < NWA; ++k) woa[k] = (k * kThreads + rtid) * 16 < WA ? (k * kThreads + rtid) * 16 : kOOB;
+            for (int k = 0; k < NWA; ++k) woa[k] = (k * kThreads + rtid) * 16 < WA ? (k * kThreads + rtid) * 16 : kOOB;
 #pragma unroll
-        for (int k = 0; k < NWB; ++k) wob[k] = (k * kThreads + rtid) * 16 < WB ? WA + (k * kThreads + rtid) * 16 : kOOB;
+            for (int k = 0; k < NWB; ++k) wob[k] = (k * kThreads + rtid) * 16 < WB ? WA + (k * kThreads + rtid) * 16 : kOOB;
+        }
+        auto dma = [&](int lds_off, int bytes, int goff) {           // packed weights, global -> LDS, 1 KiB per wave-instruction
+            for (int kb = wave12 - 8; kb < bytes / 1024; kb += 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.wpacked) + goff + lds_off + kb * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(s_w + lds_off + kb * 1024), 16, 0, 0);
+        };
         const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpacked, (unsigned)((size_t)n_ct * n_chunks * WALL));
         ConvArgs aa = a;                                             // per-item view: only ct == 0 materialises a gated input
 
@@ -1210,35 +1221,51 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
             c_chunk = chunk;
             if (c_tile) D::template load_tile<GATED>(aa, ts, to, b, chunk, rtid, r0, r1, gv);
             wsoff = (ct * n_chunks + chunk) * WALL;
+            if constexpr (!WDMA) {
 #pragma unroll
-            for (int k = 0; k < NWA; ++k) wra[k] = buf_load16(r_w, woa[k], wsoff);
+                for (int k = 0; k < NWA; ++k) wra[k] = buf_load16(r_w, woa[k], wsoff);
+            }
             ++gi;
             if (++chunk == n_chunks) { chunk = 0; if (++cti == cts_per_unit) { cti = 0; ++k_unit; } }
         };
         auto issue_b = [&]() {                                       // Wb of the stage issue_a fetched last
+            if constexpr (!WDMA) {
 #pragma unroll
-            for (int k = 0; k < NWB; ++k) wrb[k] = buf_load16(r_w, wob[k], wsoff);
+                for (int k = 0; k < NWB; ++k) wrb[k] = buf_load16(r_w, wob[k], wsoff);
+            }
         };
         auto commit_a = [&]() {
             if (c_tile) D::template commit_tile<GATED>(aa, ts, to, c_chunk, rtid, r0, r1, gv, s_in0 + c_buf * Cfg::IN_BYTES);
+            if constexpr (!WDMA) {
 #pragma unroll
-            for (int k = 0; k < NWA; ++k)
-                if (woa[k] != kOOB) *reinterpret_cast<uint4*>(s_w + woa[k]) = wra[k];
+                for (int k = 0; k < NWA; ++k)
+                    if (woa[k] != kOOB) *reinterpret_cast<uint4*>(s_w + woa[k]) = wra[k];
+            }
         };
         auto commit_b = [&]() {
+            if constexpr (!WDMA) {
 #pragma unroll
-            for (int k = 0; k < NWB; ++k)
-                if (wob[k] != kOOB) *reinterpret_cast<uint4*>(s_w + wob[k]) = wrb[k];
+                for (int k = 0; k < NWB; ++k)
+                    if (wob[k] != kOOB) *reinterpret_cast<uint4*>(s_w + wob[k]) = wrb[k];
+            }
         };
 
-        if (my_stages > 0) { issue_a(); commit_a(); issue_b(); }
+        if (my_stages > 0) {
+            issue_a(); commit_a(); issue_b();
+            if constexpr (WDMA) dma(0, WA, wsoff);                   // Wa(0)
+        }
         __syncthreads();                                             // barrier 0: bias, Wa(0), tile(0) visible
         for (int g = 0; g < my_stages; ++g) {
             // every load is issued at the START of a half and consumed one half later: a whole half of latency budget
-            if (g + 1 < my_stages) issue_a();                        // half a: fetch Wa(g+1) (+ tile) ...
+            const int wsoff_g = wsoff;                               // stage g's weights (issue_a moves wsoff on to g+1)
+            if constexpr (WDMA) dma(WA, WB, wsoff_g);                // half a: Wb(g) straight into its (free) LDS half
+            if (g + 1 < my_stages) issue_a();                        //         fetch Wa(g+1) (+ tile) ...
             commit_b();                                              //         ... and write Wb(g); the computers read Wa(g)
             __syncthreads();
-            if (g + 1 < my_stages) { issue_b(); commit_a(); }        // half b: fetch Wb(g+1); write Wa(g+1) (+ tile)
+            if (g + 1 < my_stages) {                                 // half b: fetch Wb(g+1); write Wa(g+1) (+ tile)
+                if constexpr (WDMA) dma(0, WA, wsoff);
+                issue_b(); commit_a();
+            }
             __syncthreads();
         }
     } else {
@@ -1310,10 +1337,10 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
         }
     }
     constexpr int WSM_LDS = wsm_lds_bytes<Cfg>();
-    // multi-chunk producer/consumer form (not for gated inputs: its loader would need > 168 VGPRs at 12 waves per CU)
+    // multi-chunk producer/consumer form
     // bf16 only: in fp32 the MFMAs are 4x longer, the layers are MFMA-bound either way and the general kernel's many
     // small blocks balance the B = 1 configurations better (measured 99 vs 88 TF/s on 64 -> 64 at 1080p)
-    if constexpr (WSM_LDS <= 160 * 1024 && Cfg::KS == 3 && Cfg::STEPS >= 2 && !GATED && sizeof(typename Cfg::elem) == 2) {
+    if constexpr (WSM_LDS <= 160 * 1024 && Cfg::KS == 3 && Cfg::STEPS >= 2 && sizeof(typename Cfg::elem) == 2) {
         if ((a.n_chunks > 1 || a.n_ct > 1) && a.cin_vec_ok && a.cin_chunk_ok && a.persist_ok && a.cout_packed <= kPersistMaxCout &&
             n_tiles < (1 << 24)) {
             const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch * (a.n_chunks > 1 ? a.n_ct : 1);
