@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Turn the outputs of tools/final_profiles.sh TAG (under gpurun_out/) into the committed evidence under profiles/.
+usage: python tools/write_profiles.py TAG"""
+import json, os, shutil, subprocess, sys
+tag = sys.argv[1]
+G = "gpurun_out"
+last = lambda p: open(p).read().strip().splitlines()[-1]
+shutil.copy(f"{G}/pmc_{tag}.json", "profiles/r01_pmc_bench.json")
+trace, default = last(f"{G}/bench_trace_{tag}.json"), last(f"{G}/bench_default_{tag}.json")
+summ = subprocess.run([sys.executable, "tools/rocpd_summary.py", f"{G}/prof_{tag}/trace_results.db"], capture_output=True, text=True).stdout
+open("profiles/r01_bench_kernel_stats.md", "w").write(f"""# r01 — kernel trace of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline` (cfg3, 1x MI355X)
+
+Command: `rocprofv3 --kernel-trace --stats -d gpurun_out/prof_{tag} -o trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline`
+(5 forwards in the trace: 1 warm-up + 3 timed + 1 HIP-event profiling pass). Summarised from the rocpd database with
+`tools/rocpd_summary.py`. The conv kernels (`conv_mfma_*`) sum to the `kernel_ms_per_step` that `bench.py` measures live with
+HIP events on the launch stream.
+
+```
+{trace}
+```
+
+{summ}
+""")
+open("profiles/r01_bench_default.md", "w").write(f"""# r01 — default `python bench.py` (steps 5, warm-up 2, CPU baseline leg on), 1x MI355X
+
+```json
+{default}
+```
+
+Other rows of BASELINE.md section 4, same box, same build (`tools/final_profiles.sh`):
+
+```
+no attention block (LiteISPNet_GFM_LSC, 4K, B=8, bf16):
+{last(f'{G}/bench_nogma_{tag}.json')}
+cfg2 (LiteISPNet, 1080p, B=1, fp32):
+{last(f'{G}/bench_cfg2_{tag}.json')}
+ISPUNet_GFM_LSC (row a13; 4K, B=8, bf16):
+{last(f'{G}/bench_ispunet_{tag}.json')}
+driver launch form, `python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 ... bench.py --gpus 1` (RCCL, world size 1):
+{last(f'{G}/bench_torchrun_{tag}.json')}
+```
+
+Matrix-pipe calibration (`tools/mfma_peak.py`, `rc_debug_mfma_peak`: nothing but independent `v_mfma_f32_16x16x32_bf16`):
+
+```
+{open(f'{G}/mfma_peak_{tag}.txt').read().strip()}
+```
+""")
+d = json.load(open("profiles/r01_pmc_bench.json"))
+dj = json.loads(default)
+rows = sorted(d["kernels"].items(), key=lambda kv: -(kv[1]["fetch_bytes_per_dispatch"] + kv[1]["write_bytes_per_dispatch"]) * kv[1]["dispatches"])
+tb = "\n".join(f"| `{k[:90]}` | {e['dispatches']} | {e['fetch_bytes_per_dispatch'] / 1e9:.3f} | {e['write_bytes_per_dispatch'] / 1e9:.3f} | "
+               f"{(e['fetch_bytes_per_dispatch'] + e['write_bytes_per_dispatch']) * e['dispatches'] / 3 / 1e9:.1f} |" for k, e in rows[:24])
+tot = (d["all_kernels_total_bytes"]["fetch"] + d["all_kernels_total_bytes"]["write"]) / 3 / 1e9
+rate = tot / dj["ms_per_step"]
+open("profiles/r01_pmc_bench.md", "w").write(f"""# r01 — HBM traffic of the bench command from PMC counters (cfg3, 1x MI355X)
+
+`tools/pmc_bench.sh`: two passes of `rocprofv3 --pmc <counter> --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline`
+(FETCH_SIZE and WRITE_SIZE do not fit one pass; no other trace domains), 3 forwards per pass, summarised per kernel by
+`tools/pmc_bench_summary.py` into `profiles/r01_pmc_bench.json` (which `bench.py` reads for `roofline.traffic` and
+`hbm_whole_step`). Units: FETCH_SIZE KiB x 1024 x 2 (gfx950: a 16-byte-per-lane streaming read is tallied at half, MI355X guide
+section HBM), WRITE_SIZE KiB x 1024 (calibrated earlier on the 48->48 layer: equals the output bytes exactly).
+
+**Whole step: {tot:.0f} GB of HBM traffic per forward** ({d['all_kernels_total_bytes']['fetch'] / 3 / 1e9:.0f} GB read + {d['all_kernels_total_bytes']['write'] / 3 / 1e9:.0f} GB written) = {rate:.2f} TB/s at {dj['ms_per_step']:.1f} ms per step:
+{rate / 4.7 * 100:.0f} % of this part's measured copy rate (4.7 TB/s, 1.6 GB -> 1.6 GB bf16 copy, `tools/clock_probe.py`), {rate / 8 * 100:.0f} % of the 8 TB/s spec.
+Conv kernels: {d['conv_kernels_all']['dispatches']} dispatches, {d['conv_kernels_all']['hbm_bytes_per_dispatch'] / 1e9:.2f} GB per dispatch on average.
+
+| kernel | dispatches (3 forwards) | fetch GB / dispatch | write GB / dispatch | GB per forward |
+|---|---|---|---|---|
+{tb}
+""")
+c2, ng, iu = (json.loads(last(f"{G}/bench_{n}_{tag}.json")) for n in ("cfg2", "nogma", "ispunet"))
+print(json.dumps({"cfg3": [dj["value"], dj["ms_per_step"], dj["roofline"]["achieved"], dj["roofline"]["frac"], dj["hbm_whole_step"], dj["cpu_baseline"]["value"], dj["psnr_db_vs_cpu_fp32"]],
+                  "cfg2": [c2["value"], c2["ms_per_step"], c2["roofline"]["achieved"], c2["roofline"]["frac"], c2["cpu_baseline"]["value"], c2["psnr_db_vs_cpu_fp32"]],
+                  "nogma": [ng["value"], ng["ms_per_step"], ng["roofline"]["achieved"], ng["roofline"]["frac"]],
+                  "ispunet": [iu["value"], iu["ms_per_step"], iu["roofline"]["achieved"]]}, indent=1))
