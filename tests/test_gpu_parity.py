@@ -5,6 +5,9 @@ vectors.  Tolerances (stated here, reported as PSNR in bench.py):
   bf16: bf16 storage / fp32 accumulate vs the fp32 CPU oracle: per block <= 3e-2 * max|ref|,
         end-to-end PSNR >= 50 dB (CPU bf16-vs-fp32 of the same net is ~61 dB)
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -460,3 +463,24 @@ def test_lens_shading_chain_equals_layer_by_layer(hip, shape):
             ops.FUSE_CHAIN = old
     assert rel_err(outs[True], outs[False]) < 2e-2
     assert rel_err(outs[True], ref) < 3e-2 and rel_err(outs[False], ref) < 3e-2
+
+
+def test_bench_prints_one_contract_json_line(hip):
+    """bench.py on a tiny workload: exactly one JSON line on stdout with the driver's contract keys, the roofline object
+    and (with the CPU leg on) the cpu_baseline object."""
+    import json, subprocess
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "1", "--height", "128", "--width", "192",
+                        "--steps", "2", "--warmup", "1", "--model", "LiteISPNet_GFM_LSC"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "MP/s" and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and "workload" in d["config"] and d["value"] > 0
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    assert d["psnr_db_vs_cpu_fp32"] >= 50.0
