@@ -170,11 +170,12 @@ size_t rc_conv_pair_desc_size(void);
  * -> Conv1x1(48,48) (models/LiteISP.py:363-378) when the width is 48 and the tensors are bf16: a 1x1 conv has no
  * halo, so each wave carries its 64 pixels through all layers in LDS and HBM sees only the coordinates in and the
  * final map out (layer by layer, every intermediate 48-channel map is written and re-read).
- * d_x NHWC (pixels, cin0 <= 4) bf16; d_w0 (48,cin0) / d_b0 (48) fp32 device; d_wpacked[m] =
- * rc_conv_pack_weights(48,48,1,RC_BF16,RC_OUT_NHWC) device buffers, d_bias[m] packed fp32 (or NULL), 1 <= n_mid <= 4
+ * d_x NHWC (pixels, cin0 <= 8) bf16; d_w0packed = rc_conv_pack_weights(cin0,48,1,RC_BF16,RC_OUT_NHWC) (one zero-padded MFMA
+ * step), d_b0 its packed bias (or NULL); d_wpacked[m] = rc_conv_pack_weights(48,48,1,RC_BF16,RC_OUT_NHWC) device buffers,
+ * d_bias[m] packed fp32 (or NULL), 1 <= n_mid <= 4
  * (host arrays of device pointers); slope in [0,1]; d_out NHWC (pixels, 48) bf16.  fp32 / other widths: error,
  * callers run the layers through rc_conv2d. */
-int rc_pointwise_chain48(const void* d_x, int cin0, const float* d_w0, const float* d_b0, const void* const* d_wpacked,
+int rc_pointwise_chain48(const void* d_x, int cin0, const void* d_w0packed, const float* d_b0, const void* const* d_wpacked,
                          const float* const* d_bias, int n_mid, float slope, void* d_out, int dtype, long long pixels,
                          void* stream);
 

@@ -361,7 +361,7 @@ FUSE_CHAIN = True   # Lens_Shading_Correction's four 1x1 convolutions as one lau
 
 
 def pointwise_chain_ok(x: torch.Tensor, convs, slopes) -> bool:
-    if not (FUSE_CHAIN and x.dtype == torch.bfloat16 and 2 <= len(convs) <= 5 and x.shape[-1] <= 4):
+    if not (FUSE_CHAIN and x.dtype == torch.bfloat16 and 2 <= len(convs) <= 5 and x.shape[-1] <= 8):
         return False
     ok = all(tuple(m.weight.shape[2:]) == (1, 1) and m.weight.shape[0] == 48 for m in convs)
     ok = ok and convs[0].weight.shape[1] == x.shape[-1] and all(m.weight.shape[1] == 48 for m in convs[1:])
@@ -373,14 +373,13 @@ def pointwise_chain(x: torch.Tensor, convs, slope: float) -> torch.Tensor:
     x = _req(x, "chain input")
     b, H, W, cin0 = x.shape
     first, mids = convs[0], convs[1:]
-    w0 = f32_param(first, "weight").reshape(48, cin0)
+    p0 = packed_conv(first, x.dtype, RC_OUT_NHWC)
     packs = [packed_conv(m, x.dtype, RC_OUT_NHWC) for m in mids]
     n = len(mids)
     wp = (C.c_void_p * n)(*[p.wpacked.data_ptr() for p in packs])
     bp = (C.c_void_p * n)(*[_ptr(p.bias) for p in packs])
     out = torch.empty((b, H, W, 48), dtype=x.dtype, device=x.device)
-    b0 = f32_param(first, "bias").data_ptr() if first.bias is not None else None
-    check(lib().rc_pointwise_chain48(x.data_ptr(), cin0, w0.data_ptr(), b0, wp, bp, n, float(slope), out.data_ptr(), _dt(x),
+    check(lib().rc_pointwise_chain48(x.data_ptr(), cin0, p0.wpacked.data_ptr(), _ptr(p0.bias), wp, bp, n, float(slope), out.data_ptr(), _dt(x),
                                      b * H * W, _stream()), "rc_pointwise_chain48")
     return out
 
