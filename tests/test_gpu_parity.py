@@ -484,3 +484,31 @@ def test_bench_prints_one_contract_json_line(hip):
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert d["psnr_db_vs_cpu_fp32"] >= 50.0
+
+
+def test_forward_is_hip_graph_capturable(hip):
+    """Every op launches on the current stream, allocates through the caching allocator and never syncs with the host, so a
+    whole forward can be captured in a HIP graph; the replay is bit-identical to the eager run."""
+    net = net_on_gpu("LiteISPNet_GFM_LSC", torch.bfloat16)
+    g = torch.Generator().manual_seed(5)
+    mosaic = torch.rand(2, 1, 96, 160, generator=g).to(DEV, torch.bfloat16)
+    cond = torch.rand(2, 4, 32, 32, generator=g).to(DEV, torch.bfloat16)
+    coord = O.make_coord(2, 48, 80).to(DEV, torch.bfloat16)
+
+    def fwd():
+        with torch.no_grad():
+            return net.forward_mosaic(mosaic, cond, coord)
+    for _ in range(2):
+        y_eager = fwd()                                            # warm-up: packs weights, sets launch attributes
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fwd()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        y_graph = fwd()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y_graph, y_eager)
