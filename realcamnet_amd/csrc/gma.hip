@@ -56,14 +56,25 @@ __global__ __launch_bounds__(64 * 5) void dwconv2d_kernel(const T* __restrict__ 
     const int xc = x_c0 + r * x_rep + v0 * U, cw0 = r * w_rep + v0 * U;
 
     for (int i = threadIdx.x; i < K * K * vb * U; i += blockDim.x) s_w[i] = wT[(i / (vb * U)) * n_w + cw0 + i % (vb * U)];
-    for (int i = threadIdx.x; i < THH * TWH * vb; i += blockDim.x) {
-        const int pix = i / vb, vv = i - pix * vb;
-        const int py = pix / TWH, px = pix - py * TWH;
-        const int gy = y0 + py - R, gx = x0 + px - R;
-        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-            raw = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + gy) * W + gx) * xs + xc + vv * U);
-        *reinterpret_cast<uint4*>(s_x + pix * ps + vv * 16) = raw;
+    {   // halo tile: every thread owns channel vector tid % vb of pixels tid / vb + 64 k; all its loads are issued before the
+        // first LDS write (a load -> write loop pays the memory latency once per pixel: 14 round trips per 7 x 7 tile)
+        constexpr int NLD = (THH * TWH + 63) / 64;
+        const int sv = threadIdx.x % vb, sp0 = threadIdx.x / vb;
+        uint4 raw[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int pix = sp0 + 64 * k;
+            const int py = pix / TWH, px = pix - py * TWH;
+            const int gy = y0 + py - R, gx = x0 + px - R;
+            raw[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (pix < THH * TWH && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                raw[k] = *reinterpret_cast<const uint4*>(x + (((size_t)b * H + gy) * W + gx) * xs + xc + sv * U);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int pix = sp0 + 64 * k;
+            if (pix < THH * TWH) *reinterpret_cast<uint4*>(s_x + pix * ps + sv * 16) = raw[k];
+        }
     }
     __syncthreads();
 
