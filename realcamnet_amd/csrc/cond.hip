@@ -212,8 +212,8 @@ int rc_ca_gate(float* d_sums, int batch, int n_tiles, int c, int cr, float inv_h
     RC_REQUIRE(lds <= 64 * 1024, "rc_ca_gate: too many channels");
     RC_REQUIRE(batch <= 65535, "rc_ca_gate: batch > 65535");
     int slots = n_tiles, stride = 1;
-    if (n_tiles > 128) {  // two-stage: ~64 slices per image folded in place first
-        const int L = ceil_div(n_tiles, 64);
+    if (n_tiles > 128) {  // two-stage: ~256 slices per image folded in place first (short serial chains in both stages)
+        const int L = ceil_div(n_tiles, 256);
         slots = ceil_div(n_tiles, L);
         stride = L;
         hipLaunchKernelGGL(ca_reduce_kernel, dim3(slots, batch), dim3(256), 0, as_stream(stream), d_sums, n_tiles, c, L);
