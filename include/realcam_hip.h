@@ -294,6 +294,9 @@ int rc_debug_set(const char* key, int value);
 int rc_debug_set_ptr(const char* key, void* d_ptr);
 /* Calibration: sustained rate of back-to-back v_mfma_f32_16x16x32_bf16 on every SIMD (1 or 2 waves per SIMD),
  * and s_memtime ticks per MFMA per SIMD: what this part's clocks allow, to read MFMA utilisation against. */
+/* Experiment: a HIP stream confined to half of the chip's CUs (hipExtStreamCreateWithCUMask); kind 0/1 = lower / upper 128
+ * mask bits, 2/3 = lower / upper 16 bits of every 32-bit word.  Never destroyed (debug only). */
+int rc_debug_stream_create_masked(int kind, void** stream_out);
 int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma);
 int rc_prof_enable(int on);
 int rc_prof_collect(int64_t* n_launches, double* total_ms, double* total_flops);

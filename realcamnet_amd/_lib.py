@@ -74,6 +74,7 @@ _SIGS = {
     "rc_conv_sum_tiles": (C.c_int, [_I, _I]),
     "rc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "rc_conv_desc_size": (_SZ, []),
+    "rc_debug_stream_create_masked": (C.c_int, [_I, C.POINTER(C.c_void_p)]),
     "rc_debug_mfma_peak": (C.c_int, [_I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rc_pointwise_chain48": (C.c_int, [_P, _I, _P, _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _F, _P, _I, C.c_longlong, _P]),
     "rc_channel_copy": (C.c_int, [_P, _I, _I, _P, _I, _I, _I, C.c_longlong, _I, _P]),

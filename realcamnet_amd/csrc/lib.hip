@@ -64,6 +64,19 @@ int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* me
     return RC_OK;
 }
 
+int rc_debug_stream_create_masked(int kind, void** stream_out) {
+    RC_REQUIRE(stream_out != nullptr && kind >= 0 && kind <= 3, "rc_debug_stream_create_masked: kind 0..3");
+    // experiment: a stream confined to half of the chip's CUs.  kind 0/1: lower / upper 128 mask bits; kind 2/3: lower /
+    // upper 16 bits of every 32-bit word
+    uint32_t mask[8];
+    for (int i = 0; i < 8; ++i)
+        mask[i] = kind == 0 ? (i < 4 ? 0xffffffffu : 0u) : kind == 1 ? (i < 4 ? 0u : 0xffffffffu) : kind == 2 ? 0x0000ffffu : 0xffff0000u;
+    hipStream_t st = nullptr;
+    RC_HIP_CHECK(hipExtStreamCreateWithCUMask(&st, 8, mask));
+    *stream_out = st;
+    return RC_OK;
+}
+
 int rc_abi_version(void) { return RC_ABI_VERSION; }
 
 const char* rc_last_error(void) { return rc::g_err.c_str(); }
