@@ -297,6 +297,10 @@ int rc_debug_set_ptr(const char* key, void* d_ptr);
 /* Experiment: a HIP stream confined to half of the chip's CUs (hipExtStreamCreateWithCUMask); kind 0/1 = lower / upper 128
  * mask bits, 2/3 = lower / upper 16 bits of every 32-bit word.  Never destroyed (debug only). */
 int rc_debug_stream_create_masked(int kind, void** stream_out);
+/* HBM streaming probe on the default stream: mode 0 copy / 1 read / 2 write of `bytes`; nt = non-temporal accesses;
+ * contiguous = one range per block (else grid-stride); blocks = 0 -> one-shot grid (4 x 16 B per thread). */
+int rc_debug_hbm_probe(const void* src, void* dst, size_t bytes, int mode, int nt, int contiguous, int blocks, int iters,
+                       double* ms_per_iter);
 int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma);
 int rc_prof_enable(int on);
 int rc_prof_collect(int64_t* n_launches, double* total_ms, double* total_flops);

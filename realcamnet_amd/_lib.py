@@ -11,7 +11,7 @@ import re
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "librealcam_hip.so"
+LIB_PATH = Path(os.environ["RC_HIP_LIB"]) if os.environ.get("RC_HIP_LIB") else PKG / "librealcam_hip.so"   # override: kernel experiments only
 HEADER = PKG.parent / "include" / "realcam_hip.h"
 
 RC_F32, RC_BF16 = 0, 1
@@ -75,6 +75,7 @@ _SIGS = {
     "rc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "rc_conv_desc_size": (_SZ, []),
     "rc_debug_stream_create_masked": (C.c_int, [_I, C.POINTER(C.c_void_p)]),
+    "rc_debug_hbm_probe": (C.c_int, [_P, _P, C.c_size_t, _I, _I, _I, _I, _I, C.POINTER(C.c_double)]),
     "rc_debug_mfma_peak": (C.c_int, [_I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rc_pointwise_chain48": (C.c_int, [_P, _I, _P, _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _F, _P, _I, C.c_longlong, _P]),
     "rc_channel_copy": (C.c_int, [_P, _I, _I, _P, _I, _I, _I, C.c_longlong, _I, _P]),

@@ -66,10 +66,18 @@ template <> struct Vec16<bf16_t> {
     __device__ static __forceinline__ uint32_t rne(float v) {  // fp32 -> bf16 bits, round-nearest-even
         return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, static_cast<bf16_t>(v)));
     }
+    // two values per v_cvt_pk_bf16_f32 (round-nearest-even, the same instruction the scalar cast selects): converting them one
+    // at a time costs two conversions and a v_perm per pair.  Written as an instruction because the vector-typed
+    // __builtin_convertvector form keeps the callers' unrolled value arrays from being promoted to registers (scratch).
+    __device__ static __forceinline__ uint32_t rne2(float lo, float hi) {
+        uint32_t r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+        return r;
+    }
     __device__ static __forceinline__ uint4 pack(const float* f) {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = rne(f[2 * i]) | (rne(f[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = rne2(f[2 * i], f[2 * i + 1]);
         return make_uint4(w[0], w[1], w[2], w[3]);
     }
 };

@@ -133,7 +133,7 @@ template <> struct Mma<float> {
 };
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    return Vec16<bf16_t>::rne(lo) | (Vec16<bf16_t>::rne(hi) << 16);
+    return Vec16<bf16_t>::rne2(lo, hi);
 }
 
 // Store / load NV consecutive elements of type TT at byte offset voff of a buffer (OOB -> dropped / 0).

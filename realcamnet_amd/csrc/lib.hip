@@ -36,6 +36,45 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* sink, int iters, 
 }
 }  // namespace rc
 
+
+namespace rc {
+// HBM probe kernels (tools/hbm_probe.py): what does this part sustain for a streaming copy, read or write?
+typedef float f4_t __attribute__((ext_vector_type(4)));
+template <int MODE, int NT>    // MODE 0 copy, 1 read-only, 2 write-only;  NT: non-temporal accesses
+__global__ void __launch_bounds__(256) hbm_probe_kernel(const f4_t* __restrict__ src, f4_t* __restrict__ dst, size_t n16,
+                                                         int contiguous, float* sink) {
+    const size_t nthreads = (size_t)gridDim.x * 256;
+    size_t i, step, end;
+    if (contiguous) {                   // each block owns one contiguous range
+        const size_t per = (n16 + gridDim.x - 1) / gridDim.x;
+        i = blockIdx.x * per + threadIdx.x; step = 256; end = (blockIdx.x + 1) * per < n16 ? (blockIdx.x + 1) * per : n16;
+    } else { i = (size_t)blockIdx.x * 256 + threadIdx.x; step = nthreads; end = n16; }
+    f4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (; i + 3 * step < end; i += 4 * step) {
+        f4_t v[4];
+        if (MODE != 2) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = NT ? __builtin_nontemporal_load(src + i + u * step) : src[i + u * step];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = f4_t{1.f, 2.f, 3.f, (float)u};
+        }
+        if (MODE != 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { if (NT) __builtin_nontemporal_store(v[u], dst + i + u * step); else dst[i + u * step] = v[u]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u];
+        }
+    }
+    for (; i < end; i += step) {
+        f4_t v = MODE != 2 ? src[i] : f4_t{1.f, 2.f, 3.f, 4.f};
+        if (MODE != 1) dst[i] = v; else acc += v;
+    }
+    if (MODE == 1 && acc.x + acc.y + acc.z + acc.w == 12345.678f) *sink = acc.x;
+}
+}  // namespace rc
+
 extern "C" {
 
 int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma) {
@@ -61,6 +100,35 @@ int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* me
     *tflops = (double)grid * 4 * iters * 16 * 16384.0 / (ms * 1e-3) / 1e12;
     if (memtime_ticks_per_mfma) *memtime_ticks_per_mfma = (double)h / ((double)iters * 16 * waves_per_simd);
     (void)hipFree(sink); (void)hipFree(cyc); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return RC_OK;
+}
+
+int rc_debug_hbm_probe(const void* src, void* dst, size_t bytes, int mode, int nt, int contiguous, int blocks, int iters,
+                       double* ms_per_iter) {
+    RC_REQUIRE(src && dst && ms_per_iter && bytes % 16 == 0 && mode >= 0 && mode <= 2 && iters >= 1 && blocks >= 0,
+               "rc_debug_hbm_probe: bad arguments");
+    const size_t n16 = bytes / 16;
+    const int grid = blocks > 0 ? blocks : (int)((n16 + 1023) / 1024);
+    float* sink = nullptr;
+    RC_HIP_CHECK(hipMalloc(&sink, 4));
+    hipEvent_t e0, e1;
+    RC_HIP_CHECK(hipEventCreate(&e0)); RC_HIP_CHECK(hipEventCreate(&e1));
+    auto go = [&]() {
+#define RC_PROBE(M, N) hipLaunchKernelGGL((rc::hbm_probe_kernel<M, N>), dim3(grid), dim3(256), 0, nullptr, (const rc::f4_t*)src, (rc::f4_t*)dst, n16, contiguous, sink)
+        if (mode == 0) { if (nt) RC_PROBE(0, 1); else RC_PROBE(0, 0); }
+        else if (mode == 1) { if (nt) RC_PROBE(1, 1); else RC_PROBE(1, 0); }
+        else { if (nt) RC_PROBE(2, 1); else RC_PROBE(2, 0); }
+#undef RC_PROBE
+    };
+    for (int w = 0; w < 20; ++w) go();
+    RC_HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int w = 0; w < iters; ++w) go();
+    RC_HIP_CHECK(hipEventRecord(e1, nullptr));
+    RC_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    RC_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_iter = ms / iters;
+    (void)hipFree(sink); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return RC_OK;
 }
 

@@ -36,8 +36,8 @@ __global__ void bayer_unshuffle_kernel(const TI* __restrict__ mosaic, TO* __rest
             *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
             uint2 p;
-            p.x = Vec16<bf16_t>::rne(v[0]) | (Vec16<bf16_t>::rne(v[1]) << 16);
-            p.y = Vec16<bf16_t>::rne(v[2]) | (Vec16<bf16_t>::rne(v[3]) << 16);
+            p.x = Vec16<bf16_t>::rne2(v[0], v[1]);
+            p.y = Vec16<bf16_t>::rne2(v[2], v[3]);
             *reinterpret_cast<uint2*>(o) = p;
         }
     }
