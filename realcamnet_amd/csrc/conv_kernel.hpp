@@ -613,6 +613,16 @@ struct ConvDev {
     template <int F>
     __device__ static __forceinline__ void epilogue_fast(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
                                                          f32x4 (&acc)[4][NT]) {
+        float none[NV];
+        epilogue_fast_impl<F, false>(a, b, y0, x0, sp, ct, tid, acc, none, true);
+    }
+    // RUN (CALayer sums in a persistent kernel): `run` carries this lane's channel sums from tile to tile; only when
+    // `flush` is set (the block's next tile belongs to another image, or there is none) are they reduced over the 16-lane
+    // rows and written, to the current tile's slot -- the other tiles' slots get zeros, so rc_ca_gate's fixed-order fold
+    // over all slots is unchanged.  Per tile this leaves NV adds per pixel tile instead of a 4-step DPP reduction of NV values.
+    template <int F, bool RUN>
+    __device__ static __forceinline__ void epilogue_fast_impl(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
+                                                              f32x4 (&acc)[4][NT], float (&run)[NV], bool flush) {
         const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
         const int jbase = ct * Cfg::COUT_TILE + q * NV;
         const size_t img_out = (size_t)a.H * a.W * a.cout;    // output / residual / mul image (elements)
@@ -643,7 +653,7 @@ struct ConvDev {
         }
         float csum[NV];
 #pragma unroll
-        for (int e = 0; e < NV; ++e) csum[e] = 0.f;
+        for (int e = 0; e < NV; ++e) csum[e] = RUN ? run[e] : 0.f;
         const float inf = __builtin_inff();
 
 #pragma unroll
@@ -696,7 +706,23 @@ struct ConvDev {
             const int oo = (valid && !(a.dbg_flags & 1)) ? o_off0 + dy * o_row + dx * o_col : kOOB;
             buf_store_row<T, NV, PK_RELU>(r_out, oo, v);
         }
-        if constexpr ((F & EP_SUMS) != 0) write_chan_sums(a, b, sp, wave, n, jbase, csum, false);
+        if constexpr ((F & EP_SUMS) != 0) {
+            if (!RUN || flush) {
+                write_chan_sums(a, b, sp, wave, n, jbase, csum, false);
+                if constexpr (RUN) {
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) run[e] = 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < NV; ++e) run[e] = csum[e];
+                if (n == 0) {
+                    float* dst = a.chan_sums + (((size_t)b * (a.tiles_x * a.tiles_y) + sp) * 4 + wave) * a.cout;
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) dst[jbase + e] = 0.f;
+                }
+            }
+        }
     }
 
     __device__ static __forceinline__ void epilogue_generic(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
@@ -948,6 +974,9 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
             if (ts.interior) D::template load_tile_interior<GATED>(ts, to, 0, r0, r1);
         }
     }
+    float run[NV];                                     // CALayer channel sums carried across this block's tiles
+#pragma unroll
+    for (int e = 0; e < NV; ++e) run[e] = 0.f;
     while (tile >= 0) {
         __syncthreads();                               // every wave finished reading s_in / s_w (previous tile)
         // border tiles (5 % at 4K) were not prefetched: their bounds-checked addressing would otherwise sit,
@@ -984,7 +1013,11 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
                 for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
             }
             D::template mma_steps<0, STEPS, 0, (!GATED && NT < 5)>(s_in, s_w, lane_x, lane_w, q, lo, acc);
-            D::template epilogue<FAST>(a, cb, cy0, cx0, csp, ct, tid, acc);
+            if constexpr (FAST && sizeof(typename Cfg::elem) == 2) {
+                if (a.ep_key == D::EP_SUMS && n_ct == 1)    // uniform
+                    D::template epilogue_fast_impl<D::EP_SUMS, true>(a, cb, cy0, cx0, csp, ct, tid, acc, run, tile < 0 || b != cb);
+                else D::template epilogue<FAST>(a, cb, cy0, cx0, csp, ct, tid, acc);
+            } else D::template epilogue<FAST>(a, cb, cy0, cx0, csp, ct, tid, acc);
         }
     }
 }

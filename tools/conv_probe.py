@@ -13,13 +13,13 @@ ap.add_argument("--b", type=int, default=8); ap.add_argument("--k", type=int, de
 ap.add_argument("--dtype", default="bf16"); ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--gated", action="store_true"); ap.add_argument("--residual", action="store_true")
 ap.add_argument("--sums", action="store_true"); ap.add_argument("--ps", action="store_true")
-ap.add_argument("--persist", type=int, default=1); ap.add_argument("--flags", type=int, default=0)
+ap.add_argument("--persist", type=int, default=1); ap.add_argument("--flags", type=int, default=0); ap.add_argument("--act", default="relu")
 a = ap.parse_args()
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 dev = "cuda"
 c = N.Conv2d(a.cin, a.cout, a.k, 1, a.k // 2).to(dev, dt)
 x = torch.rand(a.b, a.h, a.w, a.cin, device=dev).to(dt)
-kw = {}
+kw = {} if a.act == "none" else dict(act=a.act)
 if a.gated:
     kw.update(gate=torch.rand(a.b, a.cin, device=dev), skip=torch.rand_like(x), store_input=True)
 if a.residual:
@@ -30,13 +30,13 @@ if a.ps:
     kw.update(out_mode=ops.RC_OUT_PIXEL_SHUFFLE2)
 ops.lib().rc_debug_set(b"persist", a.persist); ops.lib().rc_debug_set(b"conv_flags", a.flags)
 for _ in range(60):   # the GPU idles at low clocks: reach steady state before timing
-    ops.conv2d(x, c, act="relu", **kw)
+    ops.conv2d(x, c, **kw)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(a.iters):
-    ops.conv2d(x, c, act="relu", **kw)
+    ops.conv2d(x, c, **kw)
 torch.cuda.synchronize()
 t = (time.perf_counter() - t0) / a.iters
 fl = 2.0 * a.b * a.h * a.w * a.cin * a.cout * a.k * a.k
-print(f"conv {a.cin}->{a.cout} k{a.k} {a.b}x{a.h}x{a.w} {a.dtype} gated={a.gated} res={a.residual} sums={a.sums} persist={a.persist} flags={a.flags}: "
+print(f"conv {a.cin}->{a.cout} k{a.k} {a.b}x{a.h}x{a.w} {a.dtype} gated={a.gated} res={a.residual} sums={a.sums} persist={a.persist} flags={a.flags} act={a.act}: "
       f"{t*1e3:.3f} ms  {fl/t/1e12:.1f} TF/s")
