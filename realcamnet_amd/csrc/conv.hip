@@ -270,9 +270,9 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
         a.persist_ok = g_persist_on;
         a.dbg = g_dbg_ptr;
         a.dbg_flags = g_dbg_flags;
-        a.inv_band = 1.0f / (float)(kBandRows * a.tiles_x);
-        a.inv_sp_total = 1.0f / (float)(a.tiles_x * a.tiles_y);
-        a.inv_n_ct = 1.0f / (float)a.n_ct;
+        a.td = make_tile_decode(a.tiles_x, a.tiles_y, kBandRows);
+        a.td_wsm = make_tile_decode(a.tiles_x, (a.H + kWsmTH - 1) / kWsmTH, kBandRows);
+        a.div_n_ct = make_magic(a.n_ct);
     }
 
     hipStream_t stream = as_stream(stream_);

@@ -27,6 +27,25 @@
 
 namespace rc {
 
+// Unsigned division by a launch constant as multiply-high + shift: scalar-ALU only.  (The float-reciprocal form it
+// replaces went SGPR -> VALU convert/multiply/convert -> readfirstlane three times per tile decode.)
+// Exact for 0 <= n < 2^24 and 1 <= d < 2^24: m = ceil(2^(31+L) / d), L = floor(log2 d), q = mulhi(n, m) >> (L - 1).
+struct MagicDiv { unsigned m, sh; };
+inline MagicDiv make_magic(int d) {
+    if (d <= 1) return MagicDiv{0u, 0u};
+    int L = 0;
+    while ((2 << L) <= d) ++L;
+    const unsigned long long m = ((1ull << (31 + L)) + (unsigned long long)d - 1) / (unsigned long long)d;
+    return MagicDiv{(unsigned)m, (unsigned)(L - 1)};
+}
+__device__ __forceinline__ int magic_div(int n, const MagicDiv& d) {
+    return d.m ? (int)(__umulhi((unsigned)n, d.m) >> d.sh) : n;
+}
+struct TileDecode { MagicDiv sp_total, band, last_rows; };
+inline TileDecode make_tile_decode(int tiles_x, int tiles_y, int band_rows) {
+    return TileDecode{make_magic(tiles_x * tiles_y), make_magic(band_rows * tiles_x), make_magic(tiles_y % band_rows ? tiles_y % band_rows : 1)};
+}
+
 struct ConvArgs {
     int batch, H, W, cin, cout;
     int n_chunks, n_ct, tiles_x, tiles_y;
@@ -41,7 +60,8 @@ struct ConvArgs {
     float* chan_sums; int cout_packed;
     int num_cus; int persist_ok;
     int ep_key;                        // epilogue_fast feature mask, or -1 for the generic epilogue (ep_key_for)
-    float inv_band, inv_sp_total, inv_n_ct;   // reciprocals for the persistent kernels' tile decode
+    TileDecode td, td_wsm;             // division constants of the persistent kernels' tile decode (8- and 16-row tiles)
+    MagicDiv div_n_ct;
     long long* dbg;                    // optional phase-timing buffer (rc_debug_set_ptr), normally NULL
     int dbg_flags;                     // knock-out experiments (rc_debug_set "conv_flags"): 1 no stores, 2 no MFMA, 4 no tile loads
 };
@@ -186,28 +206,18 @@ __device__ __forceinline__ void buf_load_row(__amdgpu_buffer_rsrc_t r, int voff,
     }
 }
 
-// exact t / d for 0 <= t < 2^24 using a float reciprocal (+-1 correction); no integer division.
-__device__ __forceinline__ int fast_div(int t, int d, float inv_d) {
-    int q = (int)((float)t * inv_d);
-    int r = t - q * d;
-    if (r < 0) { --q; r += d; }
-    if (r >= d) ++q;
-    return q;
-}
-
 // Persistent-kernel tile enumeration inside one image: bands of kBandRows tile rows, column-major inside a
 // band.  A run of 64 consecutive indices is then an 8x8 block of tiles, so the run each XCD takes from the
 // current window shares its horizontal AND vertical halos through that XCD's L2 (row-major order left the
 // vertical halos on different XCDs: measured FETCH_SIZE 1.27x the algorithmic input bytes).
 constexpr int kBandRows = 8;
-__device__ __forceinline__ void band_decode(int idx, int tiles_x, int tiles_y, float inv_band, int& ty, int& tx) {
-    const int band_size = kBandRows * tiles_x;
-    const int band = fast_div(idx, band_size, inv_band);
-    const int rem = idx - band * band_size;
+__device__ __forceinline__ void band_decode(int idx, int tiles_x, int tiles_y, const TileDecode& td, int& ty, int& tx) {
+    const int band = magic_div(idx, td.band);
+    const int rem = idx - band * (kBandRows * tiles_x);
     const int rows_left = tiles_y - band * kBandRows;
-    const int rows = rows_left < kBandRows ? rows_left : kBandRows;
-    const int col = rows == kBandRows ? rem >> 3 : fast_div(rem, rows, __builtin_amdgcn_rcpf((float)rows));
-    ty = band * kBandRows + (rem - col * rows);
+    const bool whole = rows_left >= kBandRows;         // only the image's last band can be shorter
+    const int col = whole ? rem >> 3 : magic_div(rem, td.last_rows);
+    ty = band * kBandRows + (rem - col * (whole ? kBandRows : rows_left));
     tx = col;
 }
 
@@ -964,9 +974,9 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
     int b = 0, sp = 0, y0 = 0, x0 = 0;
     typename D::TileSrc ts;
     if (tile >= 0) {
-        b = fast_div(tile, sp_total, a.inv_sp_total);
+        b = magic_div(tile, a.td.sp_total);
         int ty, tx;
-        band_decode(tile - b * sp_total, a.tiles_x, a.tiles_y, a.inv_band, ty, tx);
+        band_decode(tile - b * sp_total, a.tiles_x, a.tiles_y, a.td, ty, tx);
         sp = ty * a.tiles_x + tx; y0 = ty * kTH; x0 = tx * kTW;
         ts = D::tile_src(a, b, y0, x0);
         if (a.cin_vec_ok) {
@@ -995,9 +1005,9 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
             }
             __syncthreads();                           // input tile, weights (+ first time: bias) visible
             if (ct == n_ct - 1 && tile >= 0) {         // prefetch the next tile: in flight during the MFMA loop
-                b = fast_div(tile, sp_total, a.inv_sp_total);
+                b = magic_div(tile, a.td.sp_total);
                 int ty, tx;
-                band_decode(tile - b * sp_total, a.tiles_x, a.tiles_y, a.inv_band, ty, tx);
+                band_decode(tile - b * sp_total, a.tiles_x, a.tiles_y, a.td, ty, tx);
                 sp = ty * a.tiles_x + tx; y0 = ty * kTH; x0 = tx * kTW;
                 ts = D::tile_src(a, b, y0, x0);
                 if (a.cin_vec_ok) {
@@ -1065,9 +1075,9 @@ __global__ __launch_bounds__(kWsThreads) void conv_mfma_ws_kernel(const ConvArgs
     for (int i = tid; i < a.cout_packed; i += kWsThreads) s_bias[i] = a.bias ? a.bias[i] : 0.f;
 
     auto decode = [&](int tile, int& b, int& sp, int& y0, int& x0) {
-        b = fast_div(tile, sp_total, a.inv_sp_total);
+        b = magic_div(tile, a.td.sp_total);
         int ty, tx;
-        band_decode(tile - b * sp_total, a.tiles_x, a.tiles_y, a.inv_band, ty, tx);
+        band_decode(tile - b * sp_total, a.tiles_x, a.tiles_y, a.td, ty, tx);
         sp = ty * a.tiles_x + tx; y0 = ty * kTH; x0 = tx * kTW;
     };
 
@@ -1199,16 +1209,15 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
     const int stride = (int)gridDim.x;
     const int my_units = pos < n_units ? (n_units - pos + stride - 1) / stride : 0;
     const int my_stages = my_units * cts_per_unit * n_chunks;
-    const float inv_sp_total = 1.0f / (float)sp_total;
 
     for (int i = tid; i < a.cout_packed; i += kWsmThreads) s_bias[i] = a.bias ? a.bias[i] : 0.f;
 
     auto decode = [&](int unit, int& b, int& ty, int& tx, int& ct0) {
         int tile = unit;
         ct0 = 0;
-        if (!one_chunk) { tile = fast_div(unit, n_ct, a.inv_n_ct); ct0 = unit - tile * n_ct; }
-        b = fast_div(tile, sp_total, inv_sp_total);
-        band_decode(tile - b * sp_total, a.tiles_x, tiles_y, a.inv_band, ty, tx);
+        if (!one_chunk) { tile = magic_div(unit, a.div_n_ct); ct0 = unit - tile * n_ct; }
+        b = magic_div(tile, a.td_wsm.sp_total);
+        band_decode(tile - b * sp_total, a.tiles_x, tiles_y, a.td_wsm, ty, tx);
     };
 
     if (loader) {

@@ -55,7 +55,7 @@ struct PairArgs {
     const void* w2; const float* b2;
     const bf16_t* residual; bf16_t* out; float* chan_sums;
     int tiles_x, tiles_y;
-    float inv_band, inv_sp_total;
+    TileDecode td;
     long long* dbg;                // optional phase-timing buffer (rc_debug_set_ptr("conv_phase_timing")), normally NULL
 };
 
@@ -277,9 +277,9 @@ __global__ __launch_bounds__(THREADS) void conv_pair_kernel(const PairArgs a) {
     const int my_tiles = pos < n_tiles ? (n_tiles - pos + stride - 1) / stride : 0;
 
     auto decode = [&](int tile, int& b, int& sp, int& y0, int& x0) {
-        b = fast_div(tile, sp_total, a.inv_sp_total);
+        b = magic_div(tile, a.td.sp_total);
         int ty, tx;
-        band_decode(tile - b * sp_total, a.tiles_x, a.tiles_y, a.inv_band, ty, tx);
+        band_decode(tile - b * sp_total, a.tiles_x, a.tiles_y, a.td, ty, tx);
         sp = ty * a.tiles_x + tx; y0 = ty * OTH; x0 = tx * OTW;
     };
 
@@ -529,8 +529,7 @@ int rc_conv_pair(const rc_conv_pair_desc* d, void* stream_) {
     a.w2 = d->w2; a.b2 = d->b2;
     a.residual = static_cast<const bf16_t*>(d->residual); a.out = static_cast<bf16_t*>(d->out); a.chan_sums = d->chan_sums;
     a.tiles_x = ceil_div(d->width, pair::OTW); a.tiles_y = ceil_div(d->height, pair::OTH);
-    a.inv_band = 1.0f / (float)(kBandRows * a.tiles_x);
-    a.inv_sp_total = 1.0f / (float)(a.tiles_x * a.tiles_y);
+    a.td = make_tile_decode(a.tiles_x, a.tiles_y, kBandRows);
     a.dbg = conv_dbg_ptr();
     static int num_cus = 0;
     if (num_cus == 0) {

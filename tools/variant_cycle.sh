@@ -1,4 +1,6 @@
-timeout 120 python tools/conv_probe.py --act none 2>&1 | grep "^conv"
-timeout 120 python tools/conv_probe.py --sums --act none 2>&1 | grep "^conv"
-timeout 120 python tools/conv_probe.py --sums --act none --flags 16 2>&1 | grep "^conv"
-timeout 120 python tools/conv_probe.py --sums --act none --flags 17 2>&1 | grep "^conv"
+for r in 1 2; do
+for v in old new; do
+  if [ $v = old ]; then export RC_HIP_LIB=$PWD/realcamnet_amd/_variants/lib_old.so; else unset RC_HIP_LIB; fi
+  echo "$v $(timeout 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>&1 | grep -o '"ms_per_step": [0-9.]*')"
+done
+done
