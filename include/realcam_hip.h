@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 2
+#define RC_ABI_VERSION 3
 
 typedef enum rc_status {
     RC_OK = 0,
@@ -39,7 +39,9 @@ typedef enum rc_status {
 typedef enum rc_dtype { RC_F32 = 0, RC_BF16 = 1 } rc_dtype;
 
 typedef enum rc_act { RC_ACT_NONE = 0, RC_ACT_RELU = 1, RC_ACT_LEAKY = 2 /* slope in act_slope */,
-                      RC_ACT_GELU = 3 /* exact erf GELU: nn.GELU() in groupmix.Mlp */ } rc_act;
+                      RC_ACT_GELU = 3 /* exact erf GELU: nn.GELU() in groupmix.Mlp */,
+                      RC_ACT_RELU_POST = 4 /* ReLU applied LAST, after the residual add: relu(conv(x) + residual), the
+                                              ResidualUnit of CompressAI's AttentionBlock (models/tcm.py:270 SWAtten) */ } rc_act;
 
 typedef enum rc_out_mode {
     RC_OUT_NHWC = 0,           /* out[b][y][x][cout]                                             */
@@ -192,6 +194,11 @@ int rc_ca_gate(float* d_sums, int batch, int n_tiles, int c, int cr, float inv_h
  * gated tensor is not consumed by a conv.  NHWC, n_pix = H*W per image. */
 int rc_gate_residual(const void* d_r, const float* d_gate, const void* d_x, void* d_y, int dtype,
                      int batch, int n_pix, int c, void* stream);
+
+/* ---- a19 (SWAtten, models/tcm.py:284-289): y = a * sigmoid(b) + identity, element-wise on NHWC maps of n_elems
+ * elements (a multiple of 16 bytes); y may alias a. */
+int rc_sigmoid_gate_add(const void* d_a, const void* d_b, const void* d_identity, void* d_y, int dtype, long long n_elems,
+                        void* stream);
 
 /* ---- a10: Haar DWT / IDWT as the reference's frozen grouped conv -----------------------------
  * Replaces: DWTForward (models/networks.py:224-235) / DWTInverse (:238-249).  taps: device fp32

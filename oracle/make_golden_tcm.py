@@ -124,7 +124,100 @@ def conv_trans():
         print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, oracle max |diff| {(y - yo).abs().max().item():.2e}")
 
 
+class _RestatedAttentionBlock(torch.nn.Module):
+    """Stand-in for compressai.layers.AttentionBlock (absent here), written from its published definition; installed as the
+    base class of the reference's SWAtten so that class can be constructed and run.  The fixture pins SWAtten's OWN logic
+    (in_conv / out_conv, SwinBlock placement, which branch sees z, the sigmoid gate and identity); conv_a / conv_b stay
+    unpinned."""
+
+    def __init__(self, N):
+        super().__init__()
+        nn = torch.nn
+
+        class ResidualUnit(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.conv = nn.Sequential(nn.Conv2d(N, N // 2, 1), nn.ReLU(inplace=True), nn.Conv2d(N // 2, N // 2, 3, padding=1),
+                                          nn.ReLU(inplace=True), nn.Conv2d(N // 2, N, 1))
+                self.relu = nn.ReLU(inplace=True)
+
+            def forward(self, x):
+                identity = x
+                out = self.conv(x)
+                out += identity
+                return self.relu(out)
+
+        self.conv_a = nn.Sequential(ResidualUnit(), ResidualUnit(), ResidualUnit())
+        self.conv_b = nn.Sequential(ResidualUnit(), ResidualUnit(), ResidualUnit(), nn.Conv2d(N, N, 1))
+
+    def forward(self, x):
+        return self.conv_a(x) * torch.sigmoid(self.conv_b(x)) + x
+
+
+def _perturb(m, g):
+    for k, v in m.state_dict().items():
+        if k.endswith("bias") or "ln" in k:
+            v.add_(torch.randn(v.shape, generator=g) * 0.1)
+        if k.endswith("relative_position_params"):
+            v.add_(torch.randn(v.shape, generator=g) * 0.5)
+
+
+def swatten():
+    import importlib
+    torch.set_num_threads(1)
+    R.install_stubs()
+    sys.modules["compressai.layers"].AttentionBlock = _RestatedAttentionBlock     # before models.tcm creates `class SWAtten(AttentionBlock)`
+    sys.modules.pop("models.tcm", None)
+    T = importlib.import_module("models.tcm")
+    g = torch.Generator().manual_seed(2468)
+    torch.manual_seed(0)
+    cin, cout, inter, hd, ws = 96, 96, 64, 16, 4
+    m = T.SWAtten(cin, cout, hd, ws, 0, inter_dim=inter).eval()
+    with torch.no_grad():
+        _perturb(m, g)
+        x = torch.randn(1, cin, 8, 12, generator=g)
+        y = m(x)
+        sd = m.state_dict()
+        yo = TO.swatten(sd, "", x, hd, ws)
+    assert (y - yo).abs().max() <= 1e-5 * y.abs().max()
+    arrays = {"x": x.numpy(), "y": y.numpy(), "head_dim": np.array(hd), "window": np.array(ws), "inter_dim": np.array(inter),
+              "torch_version": np.array(torch.__version__),
+              "reference": np.array("kepengxu/RealCamNet@2024-10-20 (+ restated compressai AttentionBlock as base class)")}
+    arrays.update({"sd." + k: v.numpy() for k, v in sd.items()})
+    path = os.path.join(OUT, "tcm_swatten_c96_i64_hd16_ws4.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"tcm_swatten: {os.path.getsize(path) / 1024:.1f} KiB, oracle max |diff| {(y - yo).abs().max().item():.2e}")
+
+
+def slice_transforms():
+    """cc_mean_transforms[1]-shaped stack, built exactly as TCM.__init__ builds it (models/tcm.py:398-405) from the reference's
+    own `conv` helper and nn.GELU; TCM itself cannot be constructed here (CompressionModel is a CompressAI class).  Channel
+    counts are scaled down (40 -> 28 -> 16 -> 8 instead of 384 -> 224 -> 128 -> 64) to keep the fixture small."""
+    torch.set_num_threads(1)
+    (T,) = R.load("tcm")
+    nn = torch.nn
+    g = torch.Generator().manual_seed(1357)
+    torch.manual_seed(0)
+    m = nn.Sequential(T.conv(40, 28, stride=1, kernel_size=3), nn.GELU(), T.conv(28, 16, stride=1, kernel_size=3), nn.GELU(),
+                      T.conv(16, 8, stride=1, kernel_size=3)).eval()
+    with torch.no_grad():
+        x = torch.randn(2, 40, 9, 13, generator=g)
+        y = m(x)
+        sd = m.state_dict()
+        yo = TO.slice_transform(sd, "", x)
+    assert torch.equal(y, yo)
+    arrays = {"x": x.numpy(), "y": y.numpy(), "torch_version": np.array(torch.__version__), "reference": np.array("kepengxu/RealCamNet@2024-10-20")}
+    arrays.update({"sd." + k: v.numpy() for k, v in sd.items()})
+    path = os.path.join(OUT, "tcm_slice_transform_40_28_16_8.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"tcm_slice_transform: {os.path.getsize(path) / 1024:.1f} KiB, bitwise equal to the oracle")
+
+
 if __name__ == "__main__":
+    if "--swatten" in sys.argv:
+        swatten(); sys.exit(0)
+    if "--slice" in sys.argv:
+        slice_transforms(); sys.exit(0)
     if "--swin" in sys.argv:
         swin(); sys.exit(0)
     if "--convtrans" in sys.argv:

@@ -15,9 +15,9 @@ LIB_PATH = Path(os.environ["RC_HIP_LIB"]) if os.environ.get("RC_HIP_LIB") else P
 HEADER = PKG.parent / "include" / "realcam_hip.h"
 
 RC_F32, RC_BF16 = 0, 1
-RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY, RC_ACT_GELU = 0, 1, 2, 3
+RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY, RC_ACT_GELU, RC_ACT_RELU_POST = 0, 1, 2, 3, 4
 RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ConvDesc(C.Structure):
@@ -78,6 +78,7 @@ _SIGS = {
     "rc_debug_hbm_probe": (C.c_int, [_P, _P, C.c_size_t, _I, _I, _I, _I, _I, C.POINTER(C.c_double)]),
     "rc_debug_mfma_peak": (C.c_int, [_I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rc_pointwise_chain48": (C.c_int, [_P, _I, _P, _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _F, _P, _I, C.c_longlong, _P]),
+    "rc_sigmoid_gate_add": (C.c_int, [_P, _P, _P, _P, _I, C.c_longlong, _P]),
     "rc_channel_copy": (C.c_int, [_P, _I, _I, _P, _I, _I, _I, C.c_longlong, _I, _P]),
     "rc_window_attention": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "rc_conv_pair": (C.c_int, [C.POINTER(ConvPairDesc), _P]),

@@ -204,7 +204,9 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     RC_REQUIRE(d->batch <= 65535, "rc_conv2d: batch > 65535");
     RC_REQUIRE(d->in0 && d->wpacked && d->out, "rc_conv2d: null in0/wpacked/out");
     RC_REQUIRE(d->out_mode >= RC_OUT_NHWC && d->out_mode <= RC_OUT_NCHW, "rc_conv2d: bad out_mode");
-    RC_REQUIRE(d->act >= RC_ACT_NONE && d->act <= RC_ACT_GELU, "rc_conv2d: bad act");
+    RC_REQUIRE(d->act >= RC_ACT_NONE && d->act <= RC_ACT_RELU_POST, "rc_conv2d: bad act");
+    RC_REQUIRE(d->act != RC_ACT_RELU_POST || (d->residual != nullptr && d->mul_plus1 == nullptr && d->film_scale == nullptr && d->chan_sums == nullptr),
+               "rc_conv2d: RC_ACT_RELU_POST is relu(conv + residual): needs residual, excludes film / mul_plus1 / chan_sums");
     if (d->in_gate) RC_REQUIRE(d->in1 != nullptr, "rc_conv2d: in_gate needs in1 (the skip tensor)");
     RC_REQUIRE((d->film_scale == nullptr) == (d->film_shift == nullptr), "rc_conv2d: film_scale/film_shift must come together");
     const bool full_tiles = d->cout == p.cout_packed;
@@ -252,7 +254,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     {   // epilogue feature mask (ConvDev::EP_*); anything outside the compiled set takes the generic epilogue
         int key = (d->act == RC_ACT_RELU ? 1 : 0) | (d->act == RC_ACT_LEAKY ? 2 : 0) | (d->film_scale ? 4 : 0) |
                   (d->mul_plus1 ? 8 : 0) | (d->residual ? 16 : 0) | (d->chan_sums ? 32 : 0);
-        bool fast = full_tiles && d->out_mode != RC_OUT_NCHW && d->act != RC_ACT_GELU;
+        bool fast = full_tiles && d->out_mode != RC_OUT_NCHW && d->act != RC_ACT_GELU && d->act != RC_ACT_RELU_POST;
         if (d->act == RC_ACT_LEAKY) fast = fast && d->act_slope >= 0.f && d->act_slope <= 1.f;
         if (d->film_scale)
             fast = fast && d->cout % 4 == 0 && reinterpret_cast<uintptr_t>(d->film_scale) % 16 == 0 && reinterpret_cast<uintptr_t>(d->film_shift) % 16 == 0;

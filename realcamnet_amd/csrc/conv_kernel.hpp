@@ -804,6 +804,10 @@ struct ConvDev {
                 buf_load_row<T, NV>(r_res, pix_off, m);
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] += m[e];
+                if (a.act == RC_ACT_RELU_POST) {           // relu(conv + residual): CompressAI ResidualUnit
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.f, __builtin_inff());
+                }
             }
             if (a.chan_sums != nullptr) {
 #pragma unroll

@@ -127,6 +127,22 @@ __global__ void gate_residual_kernel(const T* __restrict__ r, const float* __res
     }
 }
 
+// ---- y = a * sigmoid(b) + identity ----------------------------------------------------------------------
+template <typename T>
+__global__ void sigmoid_gate_add_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ idn, T* __restrict__ y,
+                                        size_t total) {
+    constexpr int U = Vec16<T>::N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float fa[U], fb[U], fi[U];
+        Vec16<T>::unpack(reinterpret_cast<const uint4*>(a)[i], fa);
+        Vec16<T>::unpack(reinterpret_cast<const uint4*>(b)[i], fb);
+        Vec16<T>::unpack(reinterpret_cast<const uint4*>(idn)[i], fi);
+#pragma unroll
+        for (int e = 0; e < U; ++e) fa[e] = fa[e] * (1.f / (1.f + expf(-fb[e]))) + fi[e];
+        reinterpret_cast<uint4*>(y)[i] = Vec16<T>::pack(fa);
+    }
+}
+
 // ---- dst[p, dst_c0 + c] = src[p, src_c0 + c], c < n_ch: channel split / concat of NHWC tensors in 16-byte vectors ------
 template <typename T>
 __global__ void channel_copy_kernel(const T* __restrict__ src, int src_stride, int src_c0, T* __restrict__ dst, int dst_stride,
@@ -309,6 +325,25 @@ int rc_gate_residual(const void* d_r, const float* d_gate, const void* d_x, void
     else
         hipLaunchKernelGGL(gate_residual_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
                            static_cast<const bf16_t*>(d_r), d_gate, static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_y), batch, (size_t)n_pix, c);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_sigmoid_gate_add(const void* d_a, const void* d_b, const void* d_identity, void* d_y, int dtype, long long n_elems,
+                        void* stream) {
+    RC_REQUIRE(d_a && d_b && d_identity && d_y, "rc_sigmoid_gate_add: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_sigmoid_gate_add: bad dtype");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    RC_REQUIRE(n_elems >= U && n_elems % U == 0, "rc_sigmoid_gate_add: element count must be a whole number of 16-byte vectors");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_a) % 16 == 0 && reinterpret_cast<uintptr_t>(d_b) % 16 == 0 &&
+               reinterpret_cast<uintptr_t>(d_identity) % 16 == 0 && reinterpret_cast<uintptr_t>(d_y) % 16 == 0, "rc_sigmoid_gate_add: 16-byte alignment");
+    const size_t total = (size_t)n_elems / U;
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(sigmoid_gate_add_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const float*>(d_a), static_cast<const float*>(d_b), static_cast<const float*>(d_identity), static_cast<float*>(d_y), total);
+    else
+        hipLaunchKernelGGL(sigmoid_gate_add_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_a), static_cast<const bf16_t*>(d_b), static_cast<const bf16_t*>(d_identity), static_cast<bf16_t*>(d_y), total);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

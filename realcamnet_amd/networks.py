@@ -21,12 +21,14 @@ from ._lib import RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2
 
 
 def _is_act(m) -> bool:
-    return isinstance(m, (nn.ReLU, nn.LeakyReLU))
+    return isinstance(m, (nn.ReLU, nn.LeakyReLU)) or (isinstance(m, nn.GELU) and m.approximate == "none")
 
 
 def _act_args(m):
     if isinstance(m, nn.ReLU):
         return dict(act="relu")
+    if isinstance(m, nn.GELU):          # the codec's slice transforms (upstream models/tcm.py:398-425)
+        return dict(act="gelu")
     return dict(act="leaky", slope=float(m.negative_slope))
 
 

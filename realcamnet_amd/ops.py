@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (RC_ACT_GELU, RC_ACT_LEAKY, RC_ACT_NONE, RC_ACT_RELU, RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC,
+from ._lib import (RC_ACT_GELU, RC_ACT_LEAKY, RC_ACT_NONE, RC_ACT_RELU, RC_ACT_RELU_POST, RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC,
                    RC_OUT_PIXEL_SHUFFLE2, ConvDesc, ConvPairDesc, check)
 
 _DT = {torch.float32: RC_F32, torch.bfloat16: RC_BF16}
@@ -221,7 +221,8 @@ def bayer_unshuffle(mosaic: torch.Tensor, dtype: Optional[torch.dtype] = None, p
 # --------------------------------------------------------------------------------------------------
 # convolution and friends
 # --------------------------------------------------------------------------------------------------
-_ACT = {None: RC_ACT_NONE, "relu": RC_ACT_RELU, "leaky": RC_ACT_LEAKY, "gelu": RC_ACT_GELU}
+# "relu_post": ReLU applied after the residual add, relu(conv(x) + residual) (CompressAI ResidualUnit)
+_ACT = {None: RC_ACT_NONE, "relu": RC_ACT_RELU, "leaky": RC_ACT_LEAKY, "gelu": RC_ACT_GELU, "relu_post": RC_ACT_RELU_POST}
 
 
 def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.0,
@@ -402,6 +403,17 @@ def gate_residual(r: torch.Tensor, gate: torch.Tensor, x: torch.Tensor) -> torch
     b, H, W, c = r.shape
     y = torch.empty_like(r)
     check(lib().rc_gate_residual(r.data_ptr(), gate.data_ptr(), x.data_ptr(), y.data_ptr(), _dt(r), b, H * W, c, _stream()), "rc_gate_residual")
+    return y
+
+
+def sigmoid_gate_add(a: torch.Tensor, b: torch.Tensor, identity: torch.Tensor) -> torch.Tensor:
+    """a * sigmoid(b) + identity, element-wise (SWAtten / AttentionBlock, upstream models/tcm.py:287-288)."""
+    a, b, identity = _req(a, "a"), _req(b, "b"), _req(identity, "identity")
+    if a.shape != b.shape or a.shape != identity.shape or a.dtype != b.dtype or a.dtype != identity.dtype:
+        raise ValueError("sigmoid_gate_add: shape / dtype mismatch")
+    y = torch.empty_like(a)
+    check(lib().rc_sigmoid_gate_add(a.data_ptr(), b.data_ptr(), identity.data_ptr(), y.data_ptr(), _dt(a), a.numel(), _stream()),
+          "rc_sigmoid_gate_add")
     return y
 
 

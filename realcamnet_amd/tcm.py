@@ -6,8 +6,9 @@ with strict=True.  Tensors are NHWC (b, h, w, c) exactly as upstream passes them
 The two Linear layers of WMSA and the MLP run through rc_conv2d as 1x1 convolutions (a point-wise op commutes with the
 cyclic shift, so they run on the un-shifted map), LayerNorm through rc_layernorm, and the window attention core --
 window partition, shift, relative-position bias, wrap mask, softmax, weighted sum -- is rc_window_attention.
-The rest of models/tcm.py (ConvTransBlock, the codec trunk) depends on CompressAI layers that are not in the upstream
-tree (parity unpinned) and is not built.
+ConvTransBlock, SWAtten and the slice transforms of the codec trunk (rows a18/a19) follow below; the CompressAI layers
+they lean on (`ResidualBlock`, `AttentionBlock`) are not in the upstream tree and are restated from their published
+definitions (parity unpinned for those layers).  The rest of the trunk (GDN stages, entropy models) is not built.
 """
 from __future__ import annotations
 
@@ -138,6 +139,111 @@ class ConvTransBlock(nn.Module):
         conv_x = ops.add(self.conv_block._nhwc(conv_x), conv_x)
         trans_x = self.trans_block(trans_x)
         return self.conv1_2._nhwc(ops.channel_concat([conv_x, trans_x]), residual=a)
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
+
+
+def conv1x1(in_ch: int, out_ch: int, stride: int = 1) -> nn.Module:
+    """upstream models/tcm.py:29-31"""
+    if stride != 1:
+        raise NotImplementedError("conv1x1: only stride 1 is on this path")
+    return N.Conv2d(in_ch, out_ch, kernel_size=1, stride=1)
+
+
+def conv3x3(in_ch: int, out_ch: int, stride: int = 1) -> nn.Module:
+    """compressai.layers.conv3x3 (3x3, padding 1)"""
+    if stride != 1:
+        raise NotImplementedError("conv3x3: only stride 1 is on this path")
+    return N.Conv2d(in_ch, out_ch, kernel_size=3, stride=1, padding=1)
+
+
+def conv(in_channels, out_channels, kernel_size=5, stride=2):
+    """upstream models/tcm.py:130-137.  Only the stride-1 3x3 form the slice transforms use has a HIP kernel."""
+    if stride != 1 or kernel_size not in (1, 3):
+        raise NotImplementedError("conv: only kernel_size 1/3, stride 1 is on this path (the strided 5x5 stages of g_a/h_a are not built)")
+    return N.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=1, padding=kernel_size // 2)
+
+
+def slice_transform(in_channels: int, out_channels: int) -> nn.Module:
+    """One entry of TCM.cc_mean_transforms / cc_scale_transforms / lrp_transforms (upstream models/tcm.py:398-425):
+    conv3x3(in, 224) -> GELU -> conv3x3(224, 128) -> GELU -> conv3x3(128, out), stride 1.  Same Sequential indices
+    (0, 2, 4) as upstream, so the matching slice of a TCM state_dict loads.  Each conv + GELU is one rc_conv2d launch."""
+    return N.Sequential(conv(in_channels, 224, stride=1, kernel_size=3), nn.GELU(),
+                        conv(224, 128, stride=1, kernel_size=3), nn.GELU(),
+                        conv(128, out_channels, stride=1, kernel_size=3))
+
+
+class _ResidualUnit(nn.Module):
+    """The residual unit inside CompressAI's AttentionBlock (restated, parity unpinned):
+        relu(conv1x1(relu(conv3x3(relu(conv1x1(x))))) + x)   with N -> N/2 -> N/2 -> N channels."""
+
+    def __init__(self, n: int):
+        super().__init__()
+        self.conv = nn.Sequential(conv1x1(n, n // 2), nn.ReLU(inplace=True), conv3x3(n // 2, n // 2), nn.ReLU(inplace=True),
+                                  conv1x1(n // 2, n))
+        self.relu = nn.ReLU(inplace=True)
+
+    def _nhwc(self, a):
+        t = self.conv[0]._nhwc(a, act="relu")
+        t = self.conv[2]._nhwc(t, act="relu")
+        return self.conv[4]._nhwc(t, act="relu_post", residual=a)
+
+
+class AttentionBlock(nn.Module):
+    """compressai.layers.AttentionBlock(N) (PyPI package, NOT in the upstream tree -- parity unpinned), restated from its
+    published definition: conv_a = 3 residual units, conv_b = 3 residual units + conv1x1; out = a * sigmoid(b) + x.
+    Attribute names (conv_a.{0,1,2}.conv.{0,2,4}, conv_b.{0,1,2}.conv.{0,2,4}, conv_b.3) match CompressAI's state_dict."""
+
+    def __init__(self, N_: int):
+        super().__init__()
+        self.conv_a = nn.Sequential(_ResidualUnit(N_), _ResidualUnit(N_), _ResidualUnit(N_))
+        self.conv_b = nn.Sequential(_ResidualUnit(N_), _ResidualUnit(N_), _ResidualUnit(N_), conv1x1(N_, N_))
+
+    def _branch_a(self, a):
+        for u in self.conv_a:
+            a = u._nhwc(a)
+        return a
+
+    def _branch_b(self, b):
+        for u in list(self.conv_b)[:3]:
+            b = u._nhwc(b)
+        return self.conv_b[3]._nhwc(b)
+
+    def _nhwc(self, a):
+        return ops.sigmoid_gate_add(self._branch_a(a), self._branch_b(a), a)
+
+    def forward(self, x):
+        return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
+
+
+class SWAtten(AttentionBlock):
+    """Window-attention gate of the codec's slice loop (upstream models/tcm.py:270-291): in_conv -> [conv_a(x),
+    conv_b(SwinBlock(x))] -> a * sigmoid(b) + x -> out_conv.  NCHW in / NCHW out."""
+
+    def __init__(self, input_dim, output_dim, head_dim, window_size, drop_path, inter_dim=192) -> None:
+        if inter_dim is not None:
+            super().__init__(inter_dim)
+            self.non_local_block = SwinBlock(inter_dim, inter_dim, head_dim, window_size, drop_path)
+            self.in_conv = conv1x1(input_dim, inter_dim)
+            self.out_conv = conv1x1(inter_dim, output_dim)
+        else:
+            super().__init__(input_dim)
+            self.non_local_block = SwinBlock(input_dim, input_dim, head_dim, window_size, drop_path)
+            self.in_conv = self.out_conv = None
+
+    def _nhwc(self, a):
+        if self.in_conv is None:
+            # upstream's inter_dim=None branch never sets in_conv and fails in forward (tcm.py:284); mirrored as an error
+            raise AttributeError("SWAtten without inter_dim has no in_conv (same as upstream)")
+        x = self.in_conv._nhwc(a)
+        if x.shape[1] <= self.non_local_block.window_size or x.shape[2] <= self.non_local_block.window_size:
+            raise ValueError("SWAtten: the map must be larger than the window")
+        z = self.non_local_block.block_2(self.non_local_block.block_1(x))
+        out = ops.sigmoid_gate_add(self._branch_a(x), self._branch_b(z), x)
+        return self.out_conv._nhwc(out)
 
     def forward(self, x):
         if self.training:

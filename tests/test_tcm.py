@@ -126,3 +126,84 @@ def test_window_attention_rejects_bad_shapes():
     blk = M.tcm.Block(64, 64, 16, 8, 0.0, type="SW").to("cuda").eval()
     with pytest.raises(ValueError):
         blk(torch.zeros(1, 12, 16, 64, device="cuda"))
+
+
+# ---- row a19 (part): SWAtten and the slice transforms of the codec's slice loop ----------------------------------------
+def test_oracle_swatten_equals_reference():
+    """SWAtten's own logic (in/out convs, which branch sees the SwinBlock output, sigmoid gate + identity) against the
+    reference class run on a restated CompressAI AttentionBlock base (conv_a / conv_b stay parity-unpinned)."""
+    g = load_golden("tcm_swatten_c96_i64_hd16_ws4")
+    with torch.no_grad():
+        y = TO.swatten(g["sd"], "", g["x"], int(g["head_dim"]), int(g["window"]))
+    assert rel_err(y, g["y"]) < 1e-6
+
+
+def test_oracle_slice_transform_equals_reference():
+    g = load_golden("tcm_slice_transform_40_28_16_8")
+    with torch.no_grad():
+        y = TO.slice_transform(g["sd"], "", g["x"])
+    assert rel_err(y, g["y"]) < 1e-6
+
+
+def test_swatten_mirror_state_dict_keys():
+    import realcamnet_amd.tcm as T
+    g = load_golden("tcm_swatten_c96_i64_hd16_ws4")
+    m = T.SWAtten(96, 96, int(g["head_dim"]), int(g["window"]), 0, inter_dim=int(g["inter_dim"]))
+    assert list(m.state_dict().keys()) == list(g["sd"].keys())
+    assert [tuple(v.shape) for v in m.state_dict().values()] == [tuple(v.shape) for v in g["sd"].values()]
+    s = T.slice_transform(40, 8)
+    assert list(s.state_dict().keys()) == ["0.weight", "0.bias", "2.weight", "2.bias", "4.weight", "4.bias"]
+    with pytest.raises(NotImplementedError):
+        T.conv(3, 8)                                    # the strided 5x5 default of upstream's helper has no HIP kernel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_hip_swatten_vs_reference(dt):
+    import realcamnet_amd as M
+    g = load_golden("tcm_swatten_c96_i64_hd16_ws4")
+    m = M.tcm.SWAtten(96, 96, int(g["head_dim"]), int(g["window"]), 0, inter_dim=int(g["inter_dim"]))
+    m.load_state_dict(g["sd"], strict=True)
+    m = m.to("cuda", dt).eval()
+    with torch.no_grad():
+        y = m(g["x"].to("cuda", dt)).float().cpu()
+    assert rel_err(y, g["y"]) < (2e-5 if dt == torch.float32 else 4e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_hip_slice_transform_vs_reference(dt):
+    import realcamnet_amd as M
+    g = load_golden("tcm_slice_transform_40_28_16_8")
+    m = M.tcm.slice_transform(40, 8)
+    # the fixture's stack is a scaled-down cc_mean transform: same layout, smaller widths
+    m[0] = M.tcm.conv(40, 28, stride=1, kernel_size=3); m[2] = M.tcm.conv(28, 16, stride=1, kernel_size=3); m[4] = M.tcm.conv(16, 8, stride=1, kernel_size=3)
+    m.load_state_dict(g["sd"], strict=True)
+    m = m.to("cuda", dt).eval()
+    with torch.no_grad():
+        y = m(g["x"].to("cuda", dt)).float().cpu()
+    assert rel_err(y, g["y"]) < (2e-5 if dt == torch.float32 else 4e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_hip_slice_transform_full_width_vs_oracle(dt):
+    """cc_mean_transforms[1] at its real widths (384 -> 224 -> 128 -> 64, models/tcm.py:398-405), seeded weights, vs the oracle."""
+    import realcamnet_amd as M
+    torch.manual_seed(3)
+    m = M.tcm.slice_transform(384, 64).eval()
+    x = torch.randn(1, 384, 17, 24)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        want = TO.slice_transform(sd, "", x)
+        y = m.to("cuda", dt)(x.to("cuda", dt)).float().cpu()
+    assert rel_err(y, want) < (2e-5 if dt == torch.float32 else 4e-2)
+
+
+@pytest.mark.gpu
+def test_relu_post_requires_residual():
+    import realcamnet_amd as M
+    from realcamnet_amd import ops
+    c = M.networks.Conv2d(16, 16, 1).to("cuda").eval()
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 8, 8, 16, device="cuda"), c, act="relu_post")
