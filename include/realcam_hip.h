@@ -200,6 +200,21 @@ int rc_gate_residual(const void* d_r, const float* d_gate, const void* d_x, void
 int rc_sigmoid_gate_add(const void* d_a, const void* d_b, const void* d_identity, void* d_y, int dtype, long long n_elems,
                         void* stream);
 
+/* ---- a20 (CompressAI layers under models/tcm.py:336-357, restated; parity unpinned) -----------------------------------
+ * Stride-2 sampling of an NHWC map: dst (B, ceil(H/2), ceil(W/2), C)[y][x] = src (B,H,W,C)[2y][2x].  A 3x3 stride-2 padding-1
+ * convolution (conv3x3(stride=2) in ResidualBlockWithStride / g_a / h_a) is rc_conv2d followed by this; a 1x1 stride-2
+ * convolution (the block's skip) is this followed by rc_conv2d. */
+int rc_subsample2(const void* d_src, void* d_dst, int dtype, int batch, int H, int W, int c, void* stream);
+/* nn.PixelShuffle(2) on NHWC maps of any width: dst (B,2H,2W,c)[2y+i][2x+j][k] = src (B,H,W,4c)[y][x][4k + 2i + j].  (rc_conv2d's
+ * RC_OUT_PIXEL_SHUFFLE2 store covers c % 16 == 0; this is for the narrow tails, e.g. subpel_conv3x3(2N, 3, 2) of g_s.) */
+int rc_pixel_shuffle2(const void* d_src, void* d_dst, int dtype, int batch, int H, int W, int c_out, void* stream);
+/* GDN / inverse GDN around a 1x1 rc_conv2d:  rc_square gives x^2 (the conv input, weights gamma, bias beta);
+ * rc_gdn_apply gives y = x * rsqrt(norm) (inverse=0) or x * sqrt(norm) (inverse=1), + identity if d_identity != NULL
+ * (the residual add that follows the GDN in both residual blocks). */
+int rc_square(const void* d_x, void* d_y, int dtype, long long n_elems, void* stream);
+int rc_gdn_apply(const void* d_x, const void* d_norm, const void* d_identity, void* d_y, int dtype, int inverse, long long n_elems,
+                 void* stream);
+
 /* ---- a10: Haar DWT / IDWT as the reference's frozen grouped conv -----------------------------
  * Replaces: DWTForward (models/networks.py:224-235) / DWTInverse (:238-249).  taps: device fp32
  * (4C,1,2,2) exactly as stored in the state_dict ("down1.3.weight", "up1.0.weight").

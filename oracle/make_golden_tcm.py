@@ -154,6 +154,129 @@ class _RestatedAttentionBlock(torch.nn.Module):
         return self.conv_a(x) * torch.sigmoid(self.conv_b(x)) + x
 
 
+class _RestatedGDN(torch.nn.Module):
+    """compressai.layers.GDN, restated (see _RestatedAttentionBlock for why)."""
+
+    class _NonNeg(torch.nn.Module):
+        def __init__(self, minimum=0.0, reparam_offset=2 ** -18):
+            super().__init__()
+            pedestal = float(reparam_offset) ** 2
+            self.register_buffer("pedestal", torch.Tensor([pedestal]))
+            self.lower_bound = torch.nn.Module()
+            self.lower_bound.register_buffer("bound", torch.Tensor([(float(minimum) + pedestal) ** 0.5]))
+
+        def init(self, x):
+            return torch.sqrt(torch.max(x + self.pedestal, self.pedestal))
+
+        def forward(self, x):
+            return torch.max(x, self.lower_bound.bound) ** 2 - self.pedestal
+
+    def __init__(self, in_channels, inverse=False, beta_min=1e-6, gamma_init=0.1):
+        super().__init__()
+        self.inverse = bool(inverse)
+        self.beta_reparam = self._NonNeg(minimum=float(beta_min))
+        self.beta = torch.nn.Parameter(self.beta_reparam.init(torch.ones(in_channels)))
+        self.gamma_reparam = self._NonNeg()
+        self.gamma = torch.nn.Parameter(self.gamma_reparam.init(float(gamma_init) * torch.eye(in_channels)))
+
+    def forward(self, x):
+        c = x.shape[1]
+        norm = torch.nn.functional.conv2d(x ** 2, self.gamma_reparam(self.gamma).reshape(c, c, 1, 1), self.beta_reparam(self.beta))
+        return x * (torch.sqrt(norm) if self.inverse else torch.rsqrt(norm))
+
+
+def _restated_conv3x3(in_ch, out_ch, stride=1):
+    return torch.nn.Conv2d(in_ch, out_ch, kernel_size=3, stride=stride, padding=1)
+
+
+def _restated_subpel_conv3x3(in_ch, out_ch, r=1):
+    return torch.nn.Sequential(torch.nn.Conv2d(in_ch, out_ch * r ** 2, kernel_size=3, padding=1), torch.nn.PixelShuffle(r))
+
+
+class _RestatedResidualBlockWithStride(torch.nn.Module):
+    def __init__(self, in_ch, out_ch, stride=2):
+        super().__init__()
+        self.conv1 = _restated_conv3x3(in_ch, out_ch, stride=stride)
+        self.leaky_relu = torch.nn.LeakyReLU(inplace=True)
+        self.conv2 = _restated_conv3x3(out_ch, out_ch)
+        self.gdn = _RestatedGDN(out_ch)
+        self.skip = torch.nn.Conv2d(in_ch, out_ch, kernel_size=1, stride=stride) if (stride != 1 or in_ch != out_ch) else None
+
+    def forward(self, x):
+        out = self.gdn(self.conv2(self.leaky_relu(self.conv1(x))))
+        return out + (x if self.skip is None else self.skip(x))
+
+
+class _RestatedResidualBlockUpsample(torch.nn.Module):
+    def __init__(self, in_ch, out_ch, upsample=2):
+        super().__init__()
+        self.subpel_conv = _restated_subpel_conv3x3(in_ch, out_ch, upsample)
+        self.leaky_relu = torch.nn.LeakyReLU(inplace=True)
+        self.conv = _restated_conv3x3(out_ch, out_ch)
+        self.igdn = _RestatedGDN(out_ch, inverse=True)
+        self.upsample = _restated_subpel_conv3x3(in_ch, out_ch, upsample)
+
+    def forward(self, x):
+        out = self.igdn(self.conv(self.leaky_relu(self.subpel_conv(x))))
+        return out + self.upsample(x)
+
+
+class _Dummy(torch.nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+
+
+def transforms():
+    """g_a / g_s / h_a / h_mean_s of the reference's TCM, built by ITS OWN __init__ (models/tcm.py:321-385: block order, head
+    dims, window sizes, W/SW alternation, channel counts) over restated CompressAI layers; CompressionModel and the entropy
+    models are inert placeholders (not exercised).  Pins the composition; the CompressAI layers themselves stay unpinned."""
+    import importlib
+    torch.set_num_threads(1)
+    R.install_stubs()
+    L = sys.modules["compressai.layers"]
+    L.AttentionBlock, L.ResidualBlock = _RestatedAttentionBlock, _RestatedResidualBlock
+    L.ResidualBlockWithStride, L.ResidualBlockUpsample = _RestatedResidualBlockWithStride, _RestatedResidualBlockUpsample
+    L.conv3x3, L.subpel_conv3x3 = _restated_conv3x3, _restated_subpel_conv3x3
+    sys.modules["compressai.models"].CompressionModel = _Dummy
+    sys.modules["compressai.entropy_models"].EntropyBottleneck = _Dummy
+    sys.modules["compressai.entropy_models"].GaussianConditional = _Dummy
+    sys.modules.pop("models.tcm", None)
+    T = importlib.import_module("models.tcm")
+    g = torch.Generator().manual_seed(97531)
+    torch.manual_seed(0)
+    n, mm = 32, 64                                        # TCM(N=32, M=64): the default layout at half the width (head_dim 32 needs N >= 32)
+    model = T.TCM(config=[2, 2, 2, 2, 2, 2], head_dim=[8, 16, 32, 32, 16, 8], N=n, M=mm, num_slices=2).eval()
+    specs = TO.tcm_transform_specs(N=n)
+    with torch.no_grad():
+        _perturb(model, g)
+        for k, v in model.state_dict().items():            # livelier GDN parameters than the identity-like init
+            if k.endswith(".gamma") or k.endswith(".beta"):
+                v.add_(torch.rand(v.shape, generator=g) * 0.05)
+        for k, v in model.state_dict().items():            # weights made bf16-exact so the fixture can store 16 bits each
+            if v.is_floating_point() and v.numel() > 64:
+                v.copy_(v.bfloat16().float())
+        x = torch.rand(1, 3, 128, 128, generator=g)
+        y = model.g_a(x)
+        xh = model.g_s(y)
+        sd = model.state_dict()
+        pick = lambda pre: {k[len(pre) + 1:]: v for k, v in sd.items() if k.startswith(pre + ".")}
+        arrays = {"x": x.numpy(), "y": y.numpy(), "x_hat": xh.numpy(), "N": np.array(n), "M": np.array(mm),
+                  "torch_version": np.array(torch.__version__),
+                  "reference": np.array("kepengxu/RealCamNet@2024-10-20 TCM.__init__ (+ restated compressai layers)")}
+        for name, inp in (("g_a", x), ("g_s", y)):
+            yo = TO.run_transform(pick(name), "", specs[name], inp)
+            want = y if name == "g_a" else xh
+            assert (want - yo).abs().max() <= 1e-4 * want.abs().max(), (name, (want - yo).abs().max())
+            for k, v in pick(name).items():
+                if v.is_floating_point() and v.numel() > 64:
+                    arrays[f"sd16.{name}.{k}"] = (v.contiguous().view(torch.int32) >> 16).to(torch.int16).numpy().view(np.uint16)
+                else:
+                    arrays[f"sd.{name}.{k}"] = v.numpy()
+    path = os.path.join(OUT, "tcm_transforms_n32_m64.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"tcm_transforms: {os.path.getsize(path) / 1024:.1f} KiB; y {tuple(y.shape)}, x_hat {tuple(xh.shape)}")
+
+
 def _perturb(m, g):
     for k, v in m.state_dict().items():
         if k.endswith("bias") or "ln" in k:
@@ -218,6 +341,8 @@ if __name__ == "__main__":
         swatten(); sys.exit(0)
     if "--slice" in sys.argv:
         slice_transforms(); sys.exit(0)
+    if "--transforms" in sys.argv:
+        transforms(); sys.exit(0)
     if "--swin" in sys.argv:
         swin(); sys.exit(0)
     if "--convtrans" in sys.argv:

@@ -79,6 +79,10 @@ _SIGS = {
     "rc_debug_mfma_peak": (C.c_int, [_I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rc_pointwise_chain48": (C.c_int, [_P, _I, _P, _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _F, _P, _I, C.c_longlong, _P]),
     "rc_sigmoid_gate_add": (C.c_int, [_P, _P, _P, _P, _I, C.c_longlong, _P]),
+    "rc_subsample2": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "rc_pixel_shuffle2": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "rc_square": (C.c_int, [_P, _P, _I, C.c_longlong, _P]),
+    "rc_gdn_apply": (C.c_int, [_P, _P, _P, _P, _I, _I, C.c_longlong, _P]),
     "rc_channel_copy": (C.c_int, [_P, _I, _I, _P, _I, _I, _I, C.c_longlong, _I, _P]),
     "rc_window_attention": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "rc_conv_pair": (C.c_int, [C.POINTER(ConvPairDesc), _P]),

@@ -143,6 +143,66 @@ __global__ void sigmoid_gate_add_kernel(const T* __restrict__ a, const T* __rest
     }
 }
 
+// ---- dst[b][y][x] = src[b][2y][2x] ----------------------------------------------------------------------
+template <typename T>
+__global__ void subsample2_kernel(const T* __restrict__ src, T* __restrict__ dst, int batch, int H, int W, int c) {
+    constexpr int U = Vec16<T>::N;
+    const int vpp = c / U, oh = (H + 1) / 2, ow = (W + 1) / 2;
+    const size_t total = (size_t)batch * oh * ow * vpp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vpp);
+        const size_t p = i / vpp;
+        const int x = (int)(p % ow), y = (int)((p / ow) % oh), b = (int)(p / ((size_t)ow * oh));
+        reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[(((size_t)b * H + 2 * y) * W + 2 * x) * vpp + v];
+    }
+}
+
+// ---- nn.PixelShuffle(2), element-wise (narrow maps) ------------------------------------------------------
+template <typename T>
+__global__ void pixel_shuffle2_kernel(const T* __restrict__ src, T* __restrict__ dst, int batch, int H, int W, int c) {
+    const size_t total = (size_t)batch * 2 * H * 2 * W * c;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % c);
+        size_t p = i / c;
+        const int ox = (int)(p % (2 * W)); p /= (2 * W);
+        const int oy = (int)(p % (2 * H));
+        const int b = (int)(p / (2 * H));
+        dst[i] = src[(((size_t)b * H + (oy >> 1)) * W + (ox >> 1)) * (4 * c) + 4 * k + 2 * (oy & 1) + (ox & 1)];
+    }
+}
+
+// ---- GDN pieces: y = x*x;  y = x * rsqrt(norm) | x * sqrt(norm)  (+ identity) ----------------------------------
+template <typename T>
+__global__ void square_kernel(const T* __restrict__ x, T* __restrict__ y, size_t total) {
+    constexpr int U = Vec16<T>::N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float f[U];
+        Vec16<T>::unpack(reinterpret_cast<const uint4*>(x)[i], f);
+#pragma unroll
+        for (int e = 0; e < U; ++e) f[e] = f[e] * f[e];
+        reinterpret_cast<uint4*>(y)[i] = Vec16<T>::pack(f);
+    }
+}
+template <typename T, bool INVERSE>
+__global__ void gdn_apply_kernel(const T* __restrict__ x, const T* __restrict__ norm, const T* __restrict__ idn, T* __restrict__ y,
+                                 size_t total) {
+    constexpr int U = Vec16<T>::N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float fx[U], fn[U];
+        Vec16<T>::unpack(reinterpret_cast<const uint4*>(x)[i], fx);
+        Vec16<T>::unpack(reinterpret_cast<const uint4*>(norm)[i], fn);
+#pragma unroll
+        for (int e = 0; e < U; ++e) fx[e] = fx[e] * (INVERSE ? sqrtf(fn[e]) : 1.f / sqrtf(fn[e]));
+        if (idn != nullptr) {
+            float fi[U];
+            Vec16<T>::unpack(reinterpret_cast<const uint4*>(idn)[i], fi);
+#pragma unroll
+            for (int e = 0; e < U; ++e) fx[e] += fi[e];
+        }
+        reinterpret_cast<uint4*>(y)[i] = Vec16<T>::pack(fx);
+    }
+}
+
 // ---- dst[p, dst_c0 + c] = src[p, src_c0 + c], c < n_ch: channel split / concat of NHWC tensors in 16-byte vectors ------
 template <typename T>
 __global__ void channel_copy_kernel(const T* __restrict__ src, int src_stride, int src_c0, T* __restrict__ dst, int dst_stride,
@@ -344,6 +404,73 @@ int rc_sigmoid_gate_add(const void* d_a, const void* d_b, const void* d_identity
     else
         hipLaunchKernelGGL(sigmoid_gate_add_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
                            static_cast<const bf16_t*>(d_a), static_cast<const bf16_t*>(d_b), static_cast<const bf16_t*>(d_identity), static_cast<bf16_t*>(d_y), total);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_subsample2(const void* d_src, void* d_dst, int dtype, int batch, int H, int W, int c, void* stream) {
+    RC_REQUIRE(d_src && d_dst, "rc_subsample2: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_subsample2: bad dtype");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    RC_REQUIRE(batch >= 1 && H >= 1 && W >= 1 && c >= U && c % U == 0, "rc_subsample2: channels must be a whole number of 16-byte vectors");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_src) % 16 == 0 && reinterpret_cast<uintptr_t>(d_dst) % 16 == 0, "rc_subsample2: 16-byte alignment");
+    const size_t total = (size_t)batch * ((H + 1) / 2) * ((W + 1) / 2) * (c / U);
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(subsample2_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const float*>(d_src), static_cast<float*>(d_dst), batch, H, W, c);
+    else
+        hipLaunchKernelGGL(subsample2_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_src), static_cast<bf16_t*>(d_dst), batch, H, W, c);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_pixel_shuffle2(const void* d_src, void* d_dst, int dtype, int batch, int H, int W, int c_out, void* stream) {
+    RC_REQUIRE(d_src && d_dst, "rc_pixel_shuffle2: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_pixel_shuffle2: bad dtype");
+    RC_REQUIRE(batch >= 1 && H >= 1 && W >= 1 && c_out >= 1, "rc_pixel_shuffle2: bad shape");
+    const size_t total = (size_t)batch * 4 * H * W * c_out;
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(pixel_shuffle2_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const float*>(d_src), static_cast<float*>(d_dst), batch, H, W, c_out);
+    else
+        hipLaunchKernelGGL(pixel_shuffle2_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_src), static_cast<bf16_t*>(d_dst), batch, H, W, c_out);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_square(const void* d_x, void* d_y, int dtype, long long n_elems, void* stream) {
+    RC_REQUIRE(d_x && d_y, "rc_square: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_square: bad dtype");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    RC_REQUIRE(n_elems >= U && n_elems % U == 0, "rc_square: element count must be a whole number of 16-byte vectors");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_x) % 16 == 0 && reinterpret_cast<uintptr_t>(d_y) % 16 == 0, "rc_square: 16-byte alignment");
+    const size_t total = (size_t)n_elems / U;
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(square_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const float*>(d_x), static_cast<float*>(d_y), total);
+    else
+        hipLaunchKernelGGL(square_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_y), total);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_gdn_apply(const void* d_x, const void* d_norm, const void* d_identity, void* d_y, int dtype, int inverse, long long n_elems,
+                 void* stream) {
+    RC_REQUIRE(d_x && d_norm && d_y, "rc_gdn_apply: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_gdn_apply: bad dtype");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    RC_REQUIRE(n_elems >= U && n_elems % U == 0, "rc_gdn_apply: element count must be a whole number of 16-byte vectors");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_x) % 16 == 0 && reinterpret_cast<uintptr_t>(d_norm) % 16 == 0 &&
+               reinterpret_cast<uintptr_t>(d_identity) % 16 == 0 && reinterpret_cast<uintptr_t>(d_y) % 16 == 0, "rc_gdn_apply: 16-byte alignment");
+    const size_t total = (size_t)n_elems / U;
+#define RC_GDN(T, INV) hipLaunchKernelGGL((gdn_apply_kernel<T, INV>), dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream), \
+        static_cast<const T*>(d_x), static_cast<const T*>(d_norm), static_cast<const T*>(d_identity), static_cast<T*>(d_y), total)
+    if (dtype == RC_F32) { if (inverse) RC_GDN(float, true); else RC_GDN(float, false); }
+    else { if (inverse) RC_GDN(bf16_t, true); else RC_GDN(bf16_t, false); }
+#undef RC_GDN
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

@@ -53,6 +53,8 @@ class Conv2d(nn.Conv2d):
     def _nhwc(self, a, **fuse):
         if ops.is_down2x2(self):                      # ISPUNet family: Conv2d(c, 2c, 2, 2) (upstream LiteISP.py:1253)
             return ops.conv2x2s2(a, self, **fuse)
+        if tuple(self.stride) == (2, 2) and ops.is_stride2(self):   # codec transforms: conv3x3 / conv1x1 with stride 2
+            return ops.conv_stride2(a, self, **fuse)
         return ops.conv2d(a, self, **fuse)
 
 
@@ -78,14 +80,20 @@ class Sequential(nn.Sequential):
                 if j < n and _is_act(mods[j]):
                     kw.update(_act_args(mods[j]))
                     j += 1
+                shuffle_after = False
                 if j < n and isinstance(mods[j], nn.PixelShuffle):
                     if mods[j].upscale_factor != 2:
                         raise NotImplementedError("PixelShuffle: only upscale_factor=2 is on the hot path")
-                    kw["out_mode"] = RC_OUT_PIXEL_SHUFFLE2
+                    if (m.out_channels // 4) % 16 == 0:
+                        kw["out_mode"] = RC_OUT_PIXEL_SHUFFLE2
+                    else:                             # narrow tails (the codec's subpel_conv3x3(2N, 3, 2)): separate shuffle
+                        shuffle_after = True
                     j += 1
-                if j == n and residual is not None and kw.get("out_mode", RC_OUT_NHWC) == RC_OUT_NHWC:
+                if j == n and residual is not None and kw.get("out_mode", RC_OUT_NHWC) == RC_OUT_NHWC and not shuffle_after:
                     kw["residual"], residual = residual, None
                 a = m._nhwc(a, **kw)
+                if shuffle_after:
+                    a = ops.pixel_shuffle2(a)
                 i = j
                 continue
             if isinstance(m, (nn.Dropout, nn.Identity)):

@@ -136,6 +136,73 @@ def is_down2x2(mod) -> bool:
             tuple(mod.dilation) == (1, 1) and mod.groups == 1)
 
 
+def is_stride2(mod) -> bool:
+    """nn.Conv2d(k in {1,3}, stride=2, padding=k//2): CompressAI's conv3x3(stride=2) / conv1x1(stride=2) (models/tcm.py:336-345)."""
+    k = mod.kernel_size[0]
+    return (tuple(mod.kernel_size) in ((1, 1), (3, 3)) and tuple(mod.stride) == (2, 2) and tuple(mod.padding) == (k // 2, k // 2) and
+            tuple(mod.dilation) == (1, 1) and mod.groups == 1 and getattr(mod, "padding_mode", "zeros") == "zeros")
+
+
+def subsample2(x: torch.Tensor) -> torch.Tensor:
+    """x[:, ::2, ::2, :] of an NHWC map as a new dense tensor (rc_subsample2)."""
+    x = _req(x, "subsample2 input")
+    b, H, W, c = x.shape
+    y = torch.empty((b, (H + 1) // 2, (W + 1) // 2, c), dtype=x.dtype, device=x.device)
+    check(lib().rc_subsample2(x.data_ptr(), y.data_ptr(), _dt(x), b, H, W, c, _stream()), "rc_subsample2")
+    return y
+
+
+def conv_stride2(x: torch.Tensor, mod, **fuse):
+    """kxk stride-2 padding-k//2 convolution.  Output pixel (y, x) of the strided conv is output pixel (2y, 2x) of the stride-1
+    conv, so 3x3: rc_conv2d then rc_subsample2 (4x the necessary MACs on these few layers -- a strided input staging is future
+    work); 1x1: sample first (when the channel count is a whole number of 16-byte vectors), then convolve.  Epilogue operands
+    in `fuse` (act only) apply element-wise and commute with the sampling."""
+    x = _req(x, "conv_stride2 input")
+    if any(k not in ("act", "slope") for k in fuse):
+        raise NotImplementedError("conv_stride2: only an activation can be fused")
+    cache = _cache(mod)
+    view = cache.get("stride2_view")
+    if view is None or view.weight is not mod.weight or view.bias is not mod.bias:
+        view = cache["stride2_view"] = _ConvView(mod.weight, mod.bias)
+    unit = 16 // x.element_size()
+    if mod.kernel_size[0] == 1 and x.shape[-1] % unit == 0:
+        return conv2d(subsample2(x), view, **fuse)
+    return subsample2(conv2d(x, view, **fuse))
+
+
+def pixel_shuffle2(x: torch.Tensor) -> torch.Tensor:
+    """nn.PixelShuffle(2) on an NHWC map (B,H,W,4c) -> (B,2H,2W,c), any c (rc_pixel_shuffle2)."""
+    x = _req(x, "pixel_shuffle2 input")
+    b, H, W, c4 = x.shape
+    if c4 % 4:
+        raise ValueError("pixel_shuffle2: channels must be a multiple of 4")
+    y = torch.empty((b, 2 * H, 2 * W, c4 // 4), dtype=x.dtype, device=x.device)
+    check(lib().rc_pixel_shuffle2(x.data_ptr(), y.data_ptr(), _dt(x), b, H, W, c4 // 4, _stream()), "rc_pixel_shuffle2")
+    return y
+
+
+def square(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x, "square input")
+    y = torch.empty_like(x)
+    check(lib().rc_square(x.data_ptr(), y.data_ptr(), _dt(x), x.numel(), _stream()), "rc_square")
+    return y
+
+
+def gdn_apply(x: torch.Tensor, norm: torch.Tensor, inverse: bool, identity: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x * rsqrt(norm) (GDN) or x * sqrt(norm) (inverse GDN), + identity."""
+    x, norm = _req(x, "x"), _req(norm, "norm")
+    if x.shape != norm.shape or x.dtype != norm.dtype:
+        raise ValueError("gdn_apply: shape / dtype mismatch")
+    if identity is not None:
+        identity = _req(identity, "identity")
+        if identity.shape != x.shape or identity.dtype != x.dtype:
+            raise ValueError("gdn_apply: identity shape / dtype mismatch")
+    y = torch.empty_like(x)
+    check(lib().rc_gdn_apply(x.data_ptr(), norm.data_ptr(), _ptr(identity), y.data_ptr(), _dt(x), int(bool(inverse)), x.numel(), _stream()),
+          "rc_gdn_apply")
+    return y
+
+
 def conv2x2s2(x: torch.Tensor, mod, **fuse):
     """2x2 stride-2 convolution = space-to-depth (channel 4c + 2i + j <- pixel (2y+i, 2x+j), done by the Haar kernel with
     one-hot taps: exact) followed by a 1x1 MFMA convolution over the 4c channels.  The OIHW weight flattened over

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import networks as N
+from . import networks as N_mod      # TCM.__init__ keeps upstream's parameter name `N`
 from . import ops
 from .ops import check, lib
 
@@ -148,16 +149,23 @@ class ConvTransBlock(nn.Module):
 
 def conv1x1(in_ch: int, out_ch: int, stride: int = 1) -> nn.Module:
     """upstream models/tcm.py:29-31"""
-    if stride != 1:
-        raise NotImplementedError("conv1x1: only stride 1 is on this path")
-    return N.Conv2d(in_ch, out_ch, kernel_size=1, stride=1)
+    if stride not in (1, 2):
+        raise NotImplementedError("conv1x1: stride 1 or 2")
+    return N.Conv2d(in_ch, out_ch, kernel_size=1, stride=stride)
 
 
 def conv3x3(in_ch: int, out_ch: int, stride: int = 1) -> nn.Module:
     """compressai.layers.conv3x3 (3x3, padding 1)"""
-    if stride != 1:
-        raise NotImplementedError("conv3x3: only stride 1 is on this path")
-    return N.Conv2d(in_ch, out_ch, kernel_size=3, stride=1, padding=1)
+    if stride not in (1, 2):
+        raise NotImplementedError("conv3x3: stride 1 or 2")
+    return N.Conv2d(in_ch, out_ch, kernel_size=3, stride=stride, padding=1)
+
+
+def subpel_conv3x3(in_ch: int, out_ch: int, r: int = 1) -> nn.Module:
+    """compressai.layers.subpel_conv3x3: conv3x3(in, out*r^2) + PixelShuffle(r) (one rc_conv2d launch for r = 2)."""
+    if r != 2:
+        raise NotImplementedError("subpel_conv3x3: only r = 2 is on this path")
+    return N.Sequential(N.Conv2d(in_ch, out_ch * r ** 2, kernel_size=3, padding=1), nn.PixelShuffle(r))
 
 
 def conv(in_channels, out_channels, kernel_size=5, stride=2):
@@ -249,3 +257,147 @@ class SWAtten(AttentionBlock):
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
         return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
+
+
+class _LowerBound(nn.Module):
+    def __init__(self, bound: float):
+        super().__init__()
+        self.register_buffer("bound", torch.Tensor([float(bound)]))
+
+
+class _NonNegativeParametrizer(nn.Module):
+    """compressai.ops.parametrizers.NonNegativeParametrizer (restated): stored p -> max(p, bound)^2 - pedestal."""
+
+    def __init__(self, minimum: float = 0.0, reparam_offset: float = 2 ** -18):
+        super().__init__()
+        pedestal = float(reparam_offset) ** 2
+        self.register_buffer("pedestal", torch.Tensor([pedestal]))
+        self.lower_bound = _LowerBound((float(minimum) + pedestal) ** 0.5)
+
+    def init(self, x):
+        return torch.sqrt(torch.max(x + self.pedestal, self.pedestal))
+
+    def forward(self, x):
+        return torch.max(x, self.lower_bound.bound.to(x.dtype)) ** 2 - self.pedestal.to(x.dtype)
+
+
+class GDN(nn.Module):
+    """compressai.layers.GDN (restated, parity unpinned): y = x * rsqrt(beta + gamma (*) x^2) over channels (a 1x1 convolution
+    of x^2); inverse=True multiplies by sqrt(...) instead.  Parameters `beta` (C), `gamma` (C,C) are stored re-parametrised
+    exactly as CompressAI stores them, with the same buffer names, so its state_dict loads.  Runs as rc_square -> rc_conv2d
+    (1x1, weights = effective gamma, bias = effective beta, re-derived when the parameters change) -> rc_gdn_apply."""
+
+    def __init__(self, in_channels: int, inverse: bool = False, beta_min: float = 1e-6, gamma_init: float = 0.1):
+        super().__init__()
+        self.inverse = bool(inverse)
+        self.beta_reparam = _NonNegativeParametrizer(minimum=float(beta_min))
+        self.beta = nn.Parameter(self.beta_reparam.init(torch.ones(in_channels)))
+        self.gamma_reparam = _NonNegativeParametrizer()
+        self.gamma = nn.Parameter(self.gamma_reparam.init(float(gamma_init) * torch.eye(in_channels)))
+
+    def _effective(self):
+        key = (self.beta._version, self.gamma._version, self.beta.data_ptr(), self.gamma.data_ptr(), self.beta.dtype)
+        hit = getattr(self, "_eff", None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                c = self.beta.numel()
+                view = ops._ConvView(self.gamma_reparam(self.gamma.float()).reshape(c, c, 1, 1).contiguous(),
+                                     self.beta_reparam(self.beta.float()).contiguous())
+            hit = (key, view)
+            object.__setattr__(self, "_eff", hit)
+        return hit[1]
+
+    def _nhwc(self, a, identity=None):
+        norm = ops.conv2d(ops.square(a), self._effective())
+        return ops.gdn_apply(a, norm, self.inverse, identity)
+
+    def forward(self, x):
+        return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
+
+
+class ResidualBlockWithStride(nn.Module):
+    """compressai.layers.ResidualBlockWithStride (restated, parity unpinned; call sites upstream models/tcm.py:336-339,361):
+    GDN(conv3x3(LeakyReLU(conv3x3_s2(x)))) + conv1x1_s2(x)."""
+
+    def __init__(self, in_ch: int, out_ch: int, stride: int = 2):
+        super().__init__()
+        self.conv1 = conv3x3(in_ch, out_ch, stride=stride)
+        self.leaky_relu = nn.LeakyReLU(inplace=True)
+        self.conv2 = conv3x3(out_ch, out_ch)
+        self.gdn = GDN(out_ch)
+        self.skip = conv1x1(in_ch, out_ch, stride=stride) if (stride != 1 or in_ch != out_ch) else None
+
+    def _nhwc(self, a):
+        t = self.conv1._nhwc(a, act="leaky", slope=float(self.leaky_relu.negative_slope))
+        t = self.conv2._nhwc(t)
+        identity = a if self.skip is None else self.skip._nhwc(a)
+        return self.gdn._nhwc(t, identity)
+
+    def forward(self, x):
+        return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
+
+
+class ResidualBlockUpsample(nn.Module):
+    """compressai.layers.ResidualBlockUpsample (restated, parity unpinned; call sites upstream models/tcm.py:347-353,364):
+    IGDN(conv3x3(LeakyReLU(subpel_conv3x3(x)))) + subpel_conv3x3'(x)."""
+
+    def __init__(self, in_ch: int, out_ch: int, upsample: int = 2):
+        super().__init__()
+        self.subpel_conv = subpel_conv3x3(in_ch, out_ch, upsample)
+        self.leaky_relu = nn.LeakyReLU(inplace=True)
+        self.conv = conv3x3(out_ch, out_ch)
+        self.igdn = GDN(out_ch, inverse=True)
+        self.upsample = subpel_conv3x3(in_ch, out_ch, upsample)
+
+    def _nhwc(self, a):
+        # LeakyReLU commutes with the pixel shuffle: fused into the conv's epilogue ahead of the shuffled store
+        slope = float(self.leaky_relu.negative_slope)
+        if (self.subpel_conv[0].out_channels // 4) % 16 == 0:
+            t = self.subpel_conv[0]._nhwc(a, act="leaky", slope=slope, out_mode=N.RC_OUT_PIXEL_SHUFFLE2)
+        else:
+            t = ops.pixel_shuffle2(self.subpel_conv[0]._nhwc(a, act="leaky", slope=slope))
+        t = self.conv._nhwc(t)
+        return self.igdn._nhwc(t, self.upsample._nhwc(a))
+
+    def forward(self, x):
+        return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
+
+
+class TCM(nn.Module):
+    """The transforms of upstream's `TCM` codec (models/tcm.py:320-425), built in the same order under the same attribute
+    names: g_a, g_s, h_a, h_mean_s, h_scale_s, atten_mean, atten_scale, cc_mean_transforms, cc_scale_transforms,
+    lrp_transforms.  The entropy models (`entropy_bottleneck`, `gaussian_conditional`: CompressAI classes) and therefore
+    `forward` / `compress` / `decompress` are NOT built: load a reference checkpoint with strict=False (only those two
+    modules' keys are missing) and call the transforms directly.  All maps NCHW at this boundary, NHWC inside."""
+
+    def __init__(self, config=[2, 2, 2, 2, 2, 2], head_dim=[8, 16, 32, 32, 16, 8], drop_path_rate=0, N=64, M=320, num_slices=5,
+                 max_support_slices=5, **kwargs):
+        super().__init__()
+        if drop_path_rate != 0:
+            raise NotImplementedError("inference path: drop_path_rate must be 0")
+        self.config, self.head_dim, self.window_size = config, head_dim, 8
+        self.num_slices, self.max_support_slices, self.M = num_slices, max_support_slices, M
+        dim = N_ = N
+
+        def stage(n, hd, ws=self.window_size):
+            return [ConvTransBlock(dim, dim, hd, ws, 0, 'W' if not i % 2 else 'SW') for i in range(n)]
+
+        self.g_a = N_mod.Sequential(*[ResidualBlockWithStride(3, 2 * N_, 2)] + stage(config[0], head_dim[0]) + [ResidualBlockWithStride(2 * N_, 2 * N_, stride=2)] +
+                                    stage(config[1], head_dim[1]) + [ResidualBlockWithStride(2 * N_, 2 * N_, stride=2)] +
+                                    stage(config[2], head_dim[2]) + [conv3x3(2 * N_, M, stride=2)])
+        self.g_s = N_mod.Sequential(*[ResidualBlockUpsample(M, 2 * N_, 2)] + stage(config[3], head_dim[3]) + [ResidualBlockUpsample(2 * N_, 2 * N_, 2)] +
+                                    stage(config[4], head_dim[4]) + [ResidualBlockUpsample(2 * N_, 2 * N_, 2)] +
+                                    stage(config[5], head_dim[5]) + [subpel_conv3x3(2 * N_, 3, 2)])
+        self.h_a = N_mod.Sequential(*[ResidualBlockWithStride(320, 2 * N_, 2)] + stage(config[0], 32, 4) + [conv3x3(2 * N_, 192, stride=2)])
+        self.h_mean_s = N_mod.Sequential(*[ResidualBlockUpsample(192, 2 * N_, 2)] + stage(config[3], 32, 4) + [subpel_conv3x3(2 * N_, 320, 2)])
+        self.h_scale_s = N_mod.Sequential(*[ResidualBlockUpsample(192, 2 * N_, 2)] + stage(config[3], 32, 4) + [subpel_conv3x3(2 * N_, 320, 2)])
+        width = lambda i, cap: 320 + (320 // num_slices) * min(i, cap)
+        self.atten_mean = nn.ModuleList(nn.Sequential(SWAtten(width(i, 5), width(i, 5), 16, self.window_size, 0, inter_dim=128)) for i in range(num_slices))
+        self.atten_scale = nn.ModuleList(nn.Sequential(SWAtten(width(i, 5), width(i, 5), 16, self.window_size, 0, inter_dim=128)) for i in range(num_slices))
+        self.cc_mean_transforms = nn.ModuleList(slice_transform(width(i, 5), 320 // num_slices) for i in range(num_slices))
+        self.cc_scale_transforms = nn.ModuleList(slice_transform(width(i, 5), 320 // num_slices) for i in range(num_slices))
+        self.lrp_transforms = nn.ModuleList(slice_transform(width(i + 1, 6), 320 // num_slices) for i in range(num_slices))
+
+    def forward(self, x):
+        raise NotImplementedError("TCM.forward needs CompressAI's EntropyBottleneck / GaussianConditional, which are not built "
+                                  "(SURVEY.md rows a19/a20); call g_a / g_s / h_a / h_mean_s / h_scale_s and the slice modules directly")

@@ -23,7 +23,9 @@ def load_golden(name):
     sd = {}
     for k in z.files:
         v = z[k]
-        if k.startswith("sd."):
+        if k.startswith("sd16."):      # bf16-exact weights stored as their upper 16 bits (halves the fixture)
+            sd[k[5:]] = torch.from_numpy((v.astype(np.uint32) << 16).view(np.float32).copy())
+        elif k.startswith("sd."):
             sd[k[3:]] = torch.from_numpy(v)
         elif v.dtype.kind in "US":
             out[k] = str(v)

@@ -207,3 +207,91 @@ def test_relu_post_requires_residual():
     c = M.networks.Conv2d(16, 16, 1).to("cuda").eval()
     with pytest.raises(RuntimeError):
         ops.conv2d(torch.zeros(1, 8, 8, 16, device="cuda"), c, act="relu_post")
+
+
+# ---- rows a19/a20 (part): the codec's analysis / synthesis transforms over restated CompressAI layers -----------------------
+def _pick(sd, pre):
+    return {k[len(pre) + 1:]: v for k, v in sd.items() if k.startswith(pre + ".")}
+
+
+def test_oracle_transforms_equal_reference_composition():
+    """g_a / g_s as the reference's TCM.__init__ composes them (order, head dims, windows, W/SW alternation, widths), run over
+    restated CompressAI layers (GDN, ResidualBlockWithStride/Upsample, subpel_conv3x3: parity unpinned)."""
+    g = load_golden("tcm_transforms_n32_m64")
+    specs = TO.tcm_transform_specs(N=int(g["N"]))
+    with torch.no_grad():
+        y = TO.run_transform(_pick(g["sd"], "g_a"), "", specs["g_a"], g["x"])
+        xh = TO.run_transform(_pick(g["sd"], "g_s"), "", specs["g_s"], g["y"])
+    assert tuple(y.shape) == (1, int(g["M"]), 8, 8) and tuple(xh.shape) == (1, 3, 128, 128)
+    assert rel_err(y, g["y"]) < 1e-5 and rel_err(xh, g["x_hat"]) < 1e-5
+
+
+def test_tcm_mirror_state_dict_keys():
+    import realcamnet_amd.tcm as T
+    g = load_golden("tcm_transforms_n32_m64")
+    m = T.TCM(N=int(g["N"]), M=int(g["M"]), num_slices=2)
+    for name in ("g_a", "g_s"):
+        want = _pick(g["sd"], name)
+        got = getattr(m, name).state_dict()
+        assert list(got.keys()) == list(want.keys())
+        assert [tuple(v.shape) for v in got.values()] == [tuple(v.shape) for v in want.values()]
+    full = T.TCM()                                           # the reference's default widths: slice modules as in tcm.py:386-425
+    assert len(full.atten_mean) == 5 and full.cc_mean_transforms[4][0].in_channels == 320 + 64 * 4
+    assert full.lrp_transforms[4][0].in_channels == 320 + 64 * 5 and full.h_a[0].conv1.in_channels == 320
+    with pytest.raises(NotImplementedError):
+        full(torch.zeros(1, 3, 64, 64))
+
+
+def test_gdn_init_matches_compressai_definition():
+    """beta -> 1, gamma -> 0.1 * I after the re-parametrisation round trip (GDN's published init)."""
+    import realcamnet_amd.tcm as T
+    gd = T.GDN(6)
+    with torch.no_grad():
+        assert torch.allclose(gd.beta_reparam(gd.beta), torch.ones(6), atol=1e-6)
+        assert torch.allclose(gd.gamma_reparam(gd.gamma), 0.1 * torch.eye(6), atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_hip_transforms_vs_reference_composition(dt):
+    import realcamnet_amd as M
+    g = load_golden("tcm_transforms_n32_m64")
+    m = M.tcm.TCM(N=int(g["N"]), M=int(g["M"]), num_slices=2)
+    m.g_a.load_state_dict(_pick(g["sd"], "g_a"), strict=True)
+    m.g_s.load_state_dict(_pick(g["sd"], "g_s"), strict=True)
+    m = m.to("cuda", dt).eval()
+    with torch.no_grad():
+        y = m.g_a(g["x"].to("cuda", dt)).float().cpu()
+        xh = m.g_s(g["y"].to("cuda", dt)).float().cpu()
+    tol = 5e-5 if dt == torch.float32 else 6e-2
+    assert rel_err(y, g["y"]) < tol and rel_err(xh, g["x_hat"]) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_hip_gdn_vs_oracle(dt, inverse):
+    import realcamnet_amd as M
+    torch.manual_seed(5)
+    gd = M.tcm.GDN(32, inverse=inverse)
+    with torch.no_grad():
+        gd.gamma.add_(torch.rand(32, 32) * 0.05); gd.beta.add_(torch.rand(32) * 0.2)
+    x = torch.randn(2, 32, 9, 11)
+    sd = {"g." + k: v.clone() for k, v in gd.state_dict().items()}
+    with torch.no_grad():
+        want = TO.gdn(sd, "g", x, inverse)
+        y = gd.to("cuda", dt).eval()(x.to("cuda", dt)).float().cpu()
+    assert rel_err(y, want) < (2e-5 if dt == torch.float32 else 3e-2)
+
+
+@pytest.mark.gpu
+def test_hip_stride2_conv_odd_sizes_vs_torch():
+    import realcamnet_amd as M
+    torch.manual_seed(6)
+    for k, cin in ((3, 3), (3, 16), (1, 16), (1, 3)):
+        c = M.tcm.conv3x3(cin, 24, stride=2) if k == 3 else M.tcm.conv1x1(cin, 24, stride=2)
+        x = torch.randn(1, cin, 13, 18)
+        with torch.no_grad():
+            want = torch.nn.functional.conv2d(x, c.weight, c.bias, stride=2, padding=k // 2)
+            y = c.to("cuda").eval()(x.cuda()).cpu()
+        assert y.shape == want.shape and rel_err(y, want) < 2e-5
