@@ -176,7 +176,7 @@ def main():
                                            "from profiles/r01_pmc_bench.json")
         step_bytes = (pmc["all_kernels_total_bytes"]["fetch"] + pmc["all_kernels_total_bytes"]["write"]) / pmc.get("forwards", 3)
         res["hbm_whole_step"] = {"bytes_per_step": round(step_bytes), "achieved_TBps": round(step_bytes / (elapsed / args.steps) / 1e12, 2),
-                                 "copy_rate_TBps": pmc.get("copy_rate_TBps", 4.7), "peak_TBps": 8.0}
+                                 "copy_rate_TBps": pmc.get("copy_rate_TBps", 5.9), "peak_TBps": 8.0}
     if world == 1 and not args.no_cpu_baseline:
         info, (m_c, c_c, co_c, ref) = cpu_baseline(args.model, sd_cpu, (H2, W2))
         with torch.no_grad():

@@ -39,5 +39,5 @@ out["conv_kernels_all"] = {"dispatches": conv["dispatches"],
 tot_f = sum(v[0] for v in f.values()) * 2048.0; tot_w = sum(v[0] for v in w.values()) * 1024.0
 out["all_kernels_total_bytes"] = {"fetch": tot_f, "write": tot_w}
 out["forwards"] = 3
-out["copy_rate_TBps"] = 4.7   # measured: 1.6 GB -> 1.6 GB bf16 tensor copy on this part (tools/clock_probe.py)
+out["copy_rate_TBps"] = 5.9   # measured: 1.6 GB -> 1.6 GB float4 copy, one-shot grid (tools/hbm_probe.py)
 print(json.dumps(out, indent=1))

@@ -62,7 +62,7 @@ open("profiles/r01_pmc_bench.md", "w").write(f"""# r01 — HBM traffic of the be
 section HBM), WRITE_SIZE KiB x 1024 (calibrated earlier on the 48->48 layer: equals the output bytes exactly).
 
 **Whole step: {tot:.0f} GB of HBM traffic per forward** ({d['all_kernels_total_bytes']['fetch'] / 3 / 1e9:.0f} GB read + {d['all_kernels_total_bytes']['write'] / 3 / 1e9:.0f} GB written) = {rate:.2f} TB/s at {dj['ms_per_step']:.1f} ms per step:
-{rate / 4.7 * 100:.0f} % of this part's measured copy rate (4.7 TB/s, 1.6 GB -> 1.6 GB bf16 copy, `tools/clock_probe.py`), {rate / 8 * 100:.0f} % of the 8 TB/s spec.
+{rate / 5.9 * 100:.0f} % of this part's measured copy rate (5.9 TB/s, 1.6 GB -> 1.6 GB one-shot float4 copy, `tools/hbm_probe.py`), {rate / 8 * 100:.0f} % of the 8 TB/s spec.
 Conv kernels: {d['conv_kernels_all']['dispatches']} dispatches, {d['conv_kernels_all']['hbm_bytes_per_dispatch'] / 1e9:.2f} GB per dispatch on average.
 
 | kernel | dispatches (3 forwards) | fetch GB / dispatch | write GB / dispatch | GB per forward |
