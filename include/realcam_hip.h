@@ -215,6 +215,25 @@ int rc_square(const void* d_x, void* d_y, int dtype, long long n_elems, void* st
 int rc_gdn_apply(const void* d_x, const void* d_norm, const void* d_identity, void* d_y, int dtype, int inverse, long long n_elems,
                  void* stream);
 
+/* ---- a19: the likelihood path TCM.forward asks of CompressAI's entropy models (models/tcm.py:441-446, 467-469, 475-477),
+ * restated from their published definitions (parity unpinned); element-wise on NHWC maps, likelihoods always fp32.
+ * rc_entropy_bottleneck: EntropyBottleneck.forward in eval mode + the z_hat of :443-446.
+ *   d_params: (C, 58) fp32 per channel, the 1-3-3-3-3-1 cumulative-logit network with the parameter non-linearities already
+ *   applied on the host: [softplus(_matrix0) 3 | _bias0 3 | tanh(_factor0) 3] then for layers 1..3
+ *   [softplus(_matrix_l) 3x3 row-major (out, in) | _bias_l 3 | tanh(_factor_l) 3], then [softplus(_matrix4) 3 | _bias4 1];
+ *   d_medians: (C) fp32 = quantiles[:, 0, 1].
+ *   likelihood = max(|sigmoid(s*upper) - sigmoid(s*lower)|, bound), s = -sign(lower + upper), evaluated at round(z - med) + med -+ 0.5;
+ *   z_hat = (round(t) - t + t) + med, t = z - med  (ste_round). */
+int rc_entropy_bottleneck(const void* d_z, const float* d_params, const float* d_medians, void* d_z_hat, float* d_likelihood,
+                          int dtype, long long n_pix, int channels, float likelihood_bound, void* stream);
+/* GaussianConditional.forward(y, scales, means) in eval mode + the y_hat of :470:
+ *   likelihood = max(Phi((0.5 - |q|)/s) - Phi((-0.5 - |q|)/s), bound), q = round(y - mu), s = max(scale, scale_bound (0.11)),
+ *   Phi(x) = 0.5 erfc(-x / sqrt 2);  y_hat = ste_round(y - mu) + mu. */
+int rc_gaussian_conditional(const void* d_y, const void* d_scale, const void* d_mu, void* d_y_hat, float* d_likelihood, int dtype,
+                            long long n_elems, float scale_bound, float likelihood_bound, void* stream);
+/* y_hat_slice += 0.5 * tanh(lrp)  (:478-479) */
+int rc_tanh_half_add(const void* d_a, const void* d_lrp, void* d_out, int dtype, long long n_elems, void* stream);
+
 /* ---- a10: Haar DWT / IDWT as the reference's frozen grouped conv -----------------------------
  * Replaces: DWTForward (models/networks.py:224-235) / DWTInverse (:238-249).  taps: device fp32
  * (4C,1,2,2) exactly as stored in the state_dict ("down1.3.weight", "up1.0.weight").

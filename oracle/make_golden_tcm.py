@@ -277,6 +277,104 @@ def transforms():
     print(f"tcm_transforms: {os.path.getsize(path) / 1024:.1f} KiB; y {tuple(y.shape)}, x_hat {tuple(xh.shape)}")
 
 
+class _RestatedEntropyBottleneck(torch.nn.Module):
+    """compressai.entropy_models.EntropyBottleneck, eval-mode likelihood path, restated (see _RestatedAttentionBlock)."""
+
+    def __init__(self, channels, tail_mass=1e-9, init_scale=10, filters=(3, 3, 3, 3)):
+        super().__init__()
+        import math
+        self.channels, self.filters = int(channels), tuple(filters)
+        f = (1,) + self.filters + (1,)
+        scale = float(init_scale) ** (1 / (len(self.filters) + 1))
+        for i in range(len(self.filters) + 1):
+            init = math.log(math.expm1(1 / scale / f[i + 1]))
+            self.register_parameter(f"_matrix{i}", torch.nn.Parameter(torch.full((channels, f[i + 1], f[i]), init)))
+            self.register_parameter(f"_bias{i}", torch.nn.Parameter(torch.empty(channels, f[i + 1], 1).uniform_(-0.5, 0.5)))
+            if i < len(self.filters):
+                self.register_parameter(f"_factor{i}", torch.nn.Parameter(torch.zeros(channels, f[i + 1], 1)))
+        self.quantiles = torch.nn.Parameter(torch.tensor([-float(init_scale), 0.0, float(init_scale)]).repeat(channels, 1, 1))
+        target = math.log(2 / float(tail_mass) - 1)
+        self.register_buffer("target", torch.tensor([-target, 0.0, target]))
+
+    def _get_medians(self):
+        return self.quantiles[:, :, 1:2]
+
+    def _logits_cumulative(self, inputs):
+        logits = inputs
+        for i in range(len(self.filters) + 1):
+            logits = torch.matmul(torch.nn.functional.softplus(getattr(self, f"_matrix{i}")), logits)
+            logits = logits + getattr(self, f"_bias{i}")
+            if i < len(self.filters):
+                logits = logits + torch.tanh(getattr(self, f"_factor{i}")) * torch.tanh(logits)
+        return logits
+
+    def forward(self, x):
+        perm = (1, 0, 2, 3)
+        values = x.permute(*perm).contiguous()
+        shape = values.size()
+        values = values.reshape(x.size(1), 1, -1)
+        med = self._get_medians()
+        outputs = torch.round(values - med) + med
+        lower, upper = self._logits_cumulative(outputs - 0.5), self._logits_cumulative(outputs + 0.5)
+        sign = -torch.sign(lower + upper)
+        likelihood = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower)).clamp_min(1e-9)
+        return outputs.reshape(shape).permute(*perm).contiguous(), likelihood.reshape(shape).permute(*perm).contiguous()
+
+
+class _RestatedGaussianConditional(torch.nn.Module):
+    def __init__(self, scale_table=None, scale_bound=0.11):
+        super().__init__()
+        self.scale_bound = float(scale_bound)
+
+    def forward(self, inputs, scales, means=None):
+        outputs = torch.round(inputs - means) + means
+        values = torch.abs(outputs - means)
+        s = scales.clamp_min(self.scale_bound)
+        phi = lambda t: 0.5 * torch.erfc(-(2 ** -0.5) * t)
+        return outputs, (phi((0.5 - values) / s) - phi((-0.5 - values) / s)).clamp_min(1e-9)
+
+
+def forward_fixture():
+    """TCM.forward of the reference (models/tcm.py:437-486) at N=32 (M is 320 in the slice loop regardless), eval mode, over
+    restated CompressAI classes; parameters come from oracle/det_fill.py (a function of key and shape), so the fixture stores
+    only the input and the outputs.  Pins the forward's composition: slice order, supports, which tensors feed which module."""
+    import importlib
+    from det_fill import det_fill_
+    torch.set_num_threads(8)
+    R.install_stubs()
+    L = sys.modules["compressai.layers"]
+    L.AttentionBlock, L.ResidualBlock = _RestatedAttentionBlock, _RestatedResidualBlock
+    L.ResidualBlockWithStride, L.ResidualBlockUpsample = _RestatedResidualBlockWithStride, _RestatedResidualBlockUpsample
+    L.conv3x3, L.subpel_conv3x3 = _restated_conv3x3, _restated_subpel_conv3x3
+    sys.modules["compressai.models"].CompressionModel = _Dummy
+    sys.modules["compressai.entropy_models"].EntropyBottleneck = _RestatedEntropyBottleneck
+    sys.modules["compressai.entropy_models"].GaussianConditional = _RestatedGaussianConditional
+    sys.modules.pop("models.tcm", None)
+    T = importlib.import_module("models.tcm")
+    torch.manual_seed(0)
+    n, slices = 32, 5
+    model = T.TCM(N=n, M=320, num_slices=slices).eval()
+    sd = model.state_dict()
+    det_fill_(sd)
+    g = torch.Generator().manual_seed(8642)
+    x = torch.rand(1, 3, 256, 256, generator=g)           # latent 16x16: SWAtten's SwinBlock needs a map larger than its 8x8 window
+    with torch.no_grad():
+        out = model(x)
+        ours = TO.tcm_forward(sd, x, N=n, num_slices=slices)
+    flat = lambda o: {"x_hat": o["x_hat"], "lik_y": o["likelihoods"]["y"], "lik_z": o["likelihoods"]["z"], "means": o["para"]["means"],
+                      "scales": o["para"]["scales"], "y": o["para"]["y"]}
+    a, b = flat(out), flat(ours)
+    for k in a:
+        assert (a[k] - b[k]).abs().max() <= 1e-4 * max(a[k].abs().max().item(), 1e-6), (k, (a[k] - b[k]).abs().max())
+    arrays = {"x": x.numpy(), "N": np.array(n), "num_slices": np.array(slices), "n_keys": np.array(len(sd)),
+              "torch_version": np.array(torch.__version__),
+              "reference": np.array("kepengxu/RealCamNet@2024-10-20 TCM.forward (+ restated compressai classes; det_fill parameters)")}
+    arrays.update({"out." + k: v.numpy() for k, v in a.items()})
+    path = os.path.join(OUT, "tcm_forward_n32.npz")
+    np.savez_compressed(path, **arrays)
+    print(f"tcm_forward: {os.path.getsize(path) / 1024:.1f} KiB;", {k: (tuple(v.shape), float(v.abs().mean())) for k, v in a.items()})
+
+
 def _perturb(m, g):
     for k, v in m.state_dict().items():
         if k.endswith("bias") or "ln" in k:
@@ -343,6 +441,8 @@ if __name__ == "__main__":
         slice_transforms(); sys.exit(0)
     if "--transforms" in sys.argv:
         transforms(); sys.exit(0)
+    if "--forward" in sys.argv:
+        forward_fixture(); sys.exit(0)
     if "--swin" in sys.argv:
         swin(); sys.exit(0)
     if "--convtrans" in sys.argv:

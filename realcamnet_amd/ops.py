@@ -170,6 +170,42 @@ def conv_stride2(x: torch.Tensor, mod, **fuse):
     return subsample2(conv2d(x, view, **fuse))
 
 
+def entropy_bottleneck(z: torch.Tensor, params: torch.Tensor, medians: torch.Tensor, bound: float = 1e-9):
+    """EntropyBottleneck likelihood path on an NHWC latent: returns (z_hat, likelihood fp32).  params (C,58) / medians (C) fp32
+    device tensors as rc_entropy_bottleneck documents them."""
+    z, params, medians = _req(z, "z"), _req(params, "params"), _req(medians, "medians")
+    c = z.shape[-1]
+    if tuple(params.shape) != (c, 58) or tuple(medians.shape) != (c,) or params.dtype != torch.float32 or medians.dtype != torch.float32:
+        raise ValueError("entropy_bottleneck: params must be fp32 (C,58), medians fp32 (C)")
+    z_hat = torch.empty_like(z)
+    lik = torch.empty(z.shape, dtype=torch.float32, device=z.device)
+    check(lib().rc_entropy_bottleneck(z.data_ptr(), params.data_ptr(), medians.data_ptr(), z_hat.data_ptr(), lik.data_ptr(), _dt(z),
+                                      z.numel() // c, c, float(bound), _stream()), "rc_entropy_bottleneck")
+    return z_hat, lik
+
+
+def gaussian_conditional(y: torch.Tensor, scale: torch.Tensor, mu: torch.Tensor, scale_bound: float = 0.11, bound: float = 1e-9):
+    """GaussianConditional likelihood path: returns (y_hat = ste_round(y - mu) + mu, likelihood fp32)."""
+    y, scale, mu = _req(y, "y"), _req(scale, "scale"), _req(mu, "mu")
+    if y.shape != scale.shape or y.shape != mu.shape or y.dtype != scale.dtype or y.dtype != mu.dtype:
+        raise ValueError("gaussian_conditional: shape / dtype mismatch")
+    y_hat = torch.empty_like(y)
+    lik = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    check(lib().rc_gaussian_conditional(y.data_ptr(), scale.data_ptr(), mu.data_ptr(), y_hat.data_ptr(), lik.data_ptr(), _dt(y),
+                                        y.numel(), float(scale_bound), float(bound), _stream()), "rc_gaussian_conditional")
+    return y_hat, lik
+
+
+def tanh_half_add(a: torch.Tensor, lrp: torch.Tensor) -> torch.Tensor:
+    """a + 0.5 * tanh(lrp)  (upstream models/tcm.py:478-479)."""
+    a, lrp = _req(a, "a"), _req(lrp, "lrp")
+    if a.shape != lrp.shape or a.dtype != lrp.dtype:
+        raise ValueError("tanh_half_add: shape / dtype mismatch")
+    out = torch.empty_like(a)
+    check(lib().rc_tanh_half_add(a.data_ptr(), lrp.data_ptr(), out.data_ptr(), _dt(a), a.numel(), _stream()), "rc_tanh_half_add")
+    return out
+
+
 def pixel_shuffle2(x: torch.Tensor) -> torch.Tensor:
     """nn.PixelShuffle(2) on an NHWC map (B,H,W,4c) -> (B,2H,2W,c), any c (rc_pixel_shuffle2)."""
     x = _req(x, "pixel_shuffle2 input")

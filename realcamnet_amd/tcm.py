@@ -363,12 +363,89 @@ class ResidualBlockUpsample(nn.Module):
         return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
 
 
+class EntropyBottleneck(nn.Module):
+    """compressai.entropy_models.EntropyBottleneck(channels) -- parameters and the eval-mode likelihood path only (restated from
+    its published definition, parity unpinned; no CDF tables, no coder).  Parameter names `_matrix{i}`, `_bias{i}`, `_factor{i}`,
+    `quantiles` and the `target` buffer follow CompressAI's classic layout."""
+
+    def __init__(self, channels: int, tail_mass: float = 1e-9, init_scale: float = 10, filters=(3, 3, 3, 3), likelihood_bound: float = 1e-9):
+        super().__init__()
+        import math
+        if tuple(filters) != (3, 3, 3, 3):
+            raise NotImplementedError("EntropyBottleneck: the HIP kernel is built for filters=(3,3,3,3)")
+        self.channels, self.filters, self.likelihood_bound = int(channels), (3, 3, 3, 3), float(likelihood_bound)
+        f = (1, 3, 3, 3, 3, 1)
+        scale = float(init_scale) ** (1 / 5)
+        for i in range(5):
+            init = math.log(math.expm1(1 / scale / f[i + 1]))
+            self.register_parameter(f"_matrix{i}", nn.Parameter(torch.full((channels, f[i + 1], f[i]), init)))
+            self.register_parameter(f"_bias{i}", nn.Parameter(torch.empty(channels, f[i + 1], 1).uniform_(-0.5, 0.5)))
+            if i < 4:
+                self.register_parameter(f"_factor{i}", nn.Parameter(torch.zeros(channels, f[i + 1], 1)))
+        self.quantiles = nn.Parameter(torch.tensor([-float(init_scale), 0.0, float(init_scale)]).repeat(channels, 1, 1))
+        target = math.log(2 / float(tail_mass) - 1)
+        self.register_buffer("target", torch.tensor([-target, 0.0, target]))
+
+    def _get_medians(self):
+        return self.quantiles[:, :, 1:2]
+
+    def _packed(self):
+        ps = [getattr(self, f"_matrix{i}") for i in range(5)] + [getattr(self, f"_bias{i}") for i in range(5)] + \
+             [getattr(self, f"_factor{i}") for i in range(4)] + [self.quantiles]
+        key = tuple((p._version, p.data_ptr()) for p in ps)
+        hit = getattr(self, "_pk", None)
+        if hit is None or hit[0] != key:
+            import numpy as np
+            g = lambda n: getattr(self, n).detach().float().cpu().numpy().astype(np.float64)
+            softplus = lambda a: np.logaddexp(a, 0.0)
+            cols = []
+            for i in range(5):
+                cols.append(softplus(g(f"_matrix{i}")).reshape(self.channels, -1))     # (out, in) row-major
+                cols.append(g(f"_bias{i}").reshape(self.channels, -1))
+                if i < 4:
+                    cols.append(np.tanh(g(f"_factor{i}")).reshape(self.channels, -1))
+            packed = np.concatenate(cols, axis=1).astype(np.float32)
+            assert packed.shape == (self.channels, 58)
+            dev = self.quantiles.device
+            hit = (key, torch.from_numpy(packed).to(dev), self.quantiles.detach()[:, 0, 1].float().contiguous())
+            object.__setattr__(self, "_pk", hit)
+        return hit[1], hit[2]
+
+    def _nhwc(self, z):
+        """(z_hat, likelihood fp32) of an NHWC latent."""
+        params, med = self._packed()
+        return ops.entropy_bottleneck(z, params, med, self.likelihood_bound)
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        z_hat, lik = self._nhwc(ops.to_nhwc(x))
+        return ops.to_nchw(z_hat), ops.to_nchw(lik)
+
+
+class GaussianConditional(nn.Module):
+    """compressai.entropy_models.GaussianConditional(None) -- the eval-mode likelihood path only (restated, parity unpinned)."""
+
+    def __init__(self, scale_table=None, scale_bound: float = 0.11, likelihood_bound: float = 1e-9):
+        super().__init__()
+        self.scale_bound, self.likelihood_bound = float(scale_bound), float(likelihood_bound)
+
+    def _nhwc(self, y, scale, mu):
+        return ops.gaussian_conditional(y, scale, mu, self.scale_bound, self.likelihood_bound)
+
+    def forward(self, inputs, scales, means):
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        y_hat, lik = self._nhwc(ops.to_nhwc(inputs), ops.to_nhwc(scales), ops.to_nhwc(means))
+        return ops.to_nchw(y_hat), ops.to_nchw(lik)
+
+
 class TCM(nn.Module):
     """The transforms of upstream's `TCM` codec (models/tcm.py:320-425), built in the same order under the same attribute
     names: g_a, g_s, h_a, h_mean_s, h_scale_s, atten_mean, atten_scale, cc_mean_transforms, cc_scale_transforms,
-    lrp_transforms.  The entropy models (`entropy_bottleneck`, `gaussian_conditional`: CompressAI classes) and therefore
-    `forward` / `compress` / `decompress` are NOT built: load a reference checkpoint with strict=False (only those two
-    modules' keys are missing) and call the transforms directly.  All maps NCHW at this boundary, NHWC inside."""
+    lrp_transforms, entropy_bottleneck, gaussian_conditional, and `forward` (the likelihood path, eval mode).  `compress` /
+    `decompress` (CDF tables, rANS) are NOT built; of the entropy models only the parameters and the likelihood arithmetic exist,
+    so load a reference checkpoint with strict=False (their CDF buffers have no counterpart).  NCHW at this boundary, NHWC inside."""
 
     def __init__(self, config=[2, 2, 2, 2, 2, 2], head_dim=[8, 16, 32, 32, 16, 8], drop_path_rate=0, N=64, M=320, num_slices=5,
                  max_support_slices=5, **kwargs):
@@ -398,6 +475,36 @@ class TCM(nn.Module):
         self.cc_scale_transforms = nn.ModuleList(slice_transform(width(i, 5), 320 // num_slices) for i in range(num_slices))
         self.lrp_transforms = nn.ModuleList(slice_transform(width(i + 1, 6), 320 // num_slices) for i in range(num_slices))
 
+        self.entropy_bottleneck = EntropyBottleneck(192)
+        self.gaussian_conditional = GaussianConditional(None)
+
     def forward(self, x):
-        raise NotImplementedError("TCM.forward needs CompressAI's EntropyBottleneck / GaussianConditional, which are not built "
-                                  "(SURVEY.md rows a19/a20); call g_a / g_s / h_a / h_mean_s / h_scale_s and the slice modules directly")
+        """upstream models/tcm.py:437-486 (eval mode): x (B,3,H,W) -> {"x_hat", "likelihoods": {"y","z"}, "para": {"means","scales","y"}}.
+        Every map stays NHWC between the first and the last line; likelihoods are fp32."""
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        y = self.g_a._nhwc(ops.to_nhwc(x))
+        z = self.h_a._nhwc(y)
+        z_hat, z_lik = self.entropy_bottleneck._nhwc(z)
+        latent_scales = self.h_scale_s._nhwc(z_hat)
+        latent_means = self.h_mean_s._nhwc(z_hat)
+        if latent_means.shape[1:3] != y.shape[1:3]:
+            raise NotImplementedError("TCM.forward: latent size must be a multiple of 4 (input a multiple of 64); upstream crops here (tcm.py:461)")
+        per = y.shape[-1] // self.num_slices
+        y_hat_slices, y_lik, mu_list, scale_list = [], [], [], []
+        for i in range(self.num_slices):
+            y_slice = ops.channel_slice(y, i * per, per)
+            support = y_hat_slices if self.max_support_slices < 0 else y_hat_slices[:self.max_support_slices]
+            mean_support = self.atten_mean[i][0]._nhwc(ops.channel_concat([latent_means] + support))
+            mu = self.cc_mean_transforms[i]._nhwc(mean_support)
+            scale_support = self.atten_scale[i][0]._nhwc(ops.channel_concat([latent_scales] + support))
+            scale = self.cc_scale_transforms[i]._nhwc(scale_support)
+            y_hat_slice, lik = self.gaussian_conditional._nhwc(y_slice, scale, mu)
+            lrp = self.lrp_transforms[i]._nhwc(ops.channel_concat([mean_support, y_hat_slice]))
+            y_hat_slices.append(ops.tanh_half_add(y_hat_slice, lrp))
+            y_lik.append(lik); mu_list.append(mu); scale_list.append(scale)
+        x_hat = self.g_s._nhwc(ops.channel_concat(y_hat_slices))
+        nchw = ops.to_nchw
+        return {"x_hat": nchw(x_hat),
+                "likelihoods": {"y": nchw(ops.channel_concat(y_lik)), "z": nchw(z_lik)},
+                "para": {"means": nchw(ops.channel_concat(mu_list)), "scales": nchw(ops.channel_concat(scale_list)), "y": nchw(y)}}

@@ -238,8 +238,7 @@ def test_tcm_mirror_state_dict_keys():
     full = T.TCM()                                           # the reference's default widths: slice modules as in tcm.py:386-425
     assert len(full.atten_mean) == 5 and full.cc_mean_transforms[4][0].in_channels == 320 + 64 * 4
     assert full.lrp_transforms[4][0].in_channels == 320 + 64 * 5 and full.h_a[0].conv1.in_channels == 320
-    with pytest.raises(NotImplementedError):
-        full(torch.zeros(1, 3, 64, 64))
+    assert full.entropy_bottleneck.quantiles.shape == (192, 1, 3)
 
 
 def test_gdn_init_matches_compressai_definition():
@@ -295,3 +294,95 @@ def test_hip_stride2_conv_odd_sizes_vs_torch():
             want = torch.nn.functional.conv2d(x, c.weight, c.bias, stride=2, padding=k // 2)
             y = c.to("cuda").eval()(x.cuda()).cpu()
         assert y.shape == want.shape and rel_err(y, want) < 2e-5
+
+
+# ---- row a19: TCM.forward, likelihood path ----------------------------------------------------------------------------
+from det_fill import det_fill_  # noqa: E402  (oracle/: key-and-shape-determined parameters shared with the fixture's generator)
+
+
+def _flat(o):
+    return {"x_hat": o["x_hat"], "lik_y": o["likelihoods"]["y"], "lik_z": o["likelihoods"]["z"], "means": o["para"]["means"],
+            "scales": o["para"]["scales"], "y": o["para"]["y"]}
+
+
+def _mirror_with_det_params(g):
+    import realcamnet_amd.tcm as T
+    m = T.TCM(N=int(g["N"]), M=320, num_slices=int(g["num_slices"])).eval()
+    sd = m.state_dict()
+    assert len(sd) == int(g["n_keys"])                     # same tensors as the reference model over restated CompressAI classes
+    det_fill_(sd)
+    return m, sd
+
+
+def test_oracle_tcm_forward_equals_reference():
+    """TCM.forward's composition (slice order, supports, which tensor feeds which module) against the reference's own forward run
+    over restated CompressAI classes; parameters are det_fill's function of key and shape on both sides."""
+    g = load_golden("tcm_forward_n32")
+    _, sd = _mirror_with_det_params(g)
+    with torch.no_grad():
+        out = _flat(TO.tcm_forward(sd, g["x"], N=int(g["N"]), num_slices=int(g["num_slices"])))
+    for k, v in out.items():
+        assert rel_err(v, g["out." + k]) < 1e-4, k
+
+
+def test_ste_round_order_of_operations():
+    x = torch.tensor([0.3, 2.5, -1.49999, 1e7 + 0.5])
+    assert torch.equal(TO.ste_round(x), torch.round(x) - x + x)
+
+
+def _close_fraction(a, b, tol):
+    return ((a - b).abs() <= tol * (1.0 + b.abs())).float().mean().item()
+
+
+@pytest.mark.gpu
+def test_hip_tcm_forward_vs_reference_fp32():
+    g = load_golden("tcm_forward_n32")
+    m, _ = _mirror_with_det_params(g)
+    m = m.to("cuda").eval()
+    with torch.no_grad():
+        out = _flat(m(g["x"].cuda()))
+    out = {k: v.float().cpu() for k, v in out.items()}
+    assert rel_err(out["y"], g["out.y"]) < 5e-5 and rel_err(out["lik_z"], g["out.lik_z"]) < 1e-3
+    # downstream of round(): a value within float noise of a half-integer may round the other way, so a few isolated
+    # elements may differ; everything else must agree closely
+    for k in ("means", "scales", "lik_y", "x_hat"):
+        assert _close_fraction(out[k], g["out." + k], 2e-3) > 0.995, k
+
+
+@pytest.mark.gpu
+def test_hip_tcm_forward_bf16_runs():
+    g = load_golden("tcm_forward_n32")
+    m, _ = _mirror_with_det_params(g)
+    m = m.to("cuda", torch.bfloat16).eval()
+    with torch.no_grad():
+        out = _flat(m(g["x"].to("cuda", torch.bfloat16)))
+    assert rel_err(out["y"].float().cpu(), g["out.y"]) < 6e-2
+    assert out["lik_y"].dtype == torch.float32 and out["lik_z"].dtype == torch.float32
+    for v in out.values():
+        assert torch.isfinite(v.float()).all()
+    assert float(out["lik_y"].min()) >= 0.99e-9 and float(out["lik_y"].max()) <= 1.0 + 1e-6      # the 1e-9 bound in fp32
+
+
+@pytest.mark.gpu
+def test_hip_entropy_kernels_vs_oracle():
+    import realcamnet_amd as M
+    from realcamnet_amd import ops
+    torch.manual_seed(11)
+    eb = M.tcm.EntropyBottleneck(24).eval()
+    sd = eb.state_dict(); det_fill_({"entropy_bottleneck." + k: v for k, v in sd.items()})
+    z = torch.randn(2, 24, 5, 7) * 3
+    z = z + ((z - torch.round(z)).abs() > 0.49).float() * 0.05           # keep clear of the rounding boundary (medians shift it, so only roughly)
+    with torch.no_grad():
+        want_out, want_lik = TO.entropy_bottleneck({"e." + k: v for k, v in sd.items()}, "e", z)
+        z_hat, lik = eb.to("cuda")(z.cuda())
+    med = sd["quantiles"][:, 0, 1].reshape(1, -1, 1, 1)
+    assert _close_fraction(z_hat.cpu(), TO.ste_round(z - med) + med, 1e-5) > 0.99
+    assert _close_fraction(lik.cpu(), want_lik, 1e-4) > 0.99
+    y, mu = torch.randn(2, 16, 6, 6) * 4, torch.randn(2, 16, 6, 6)
+    scale = torch.randn(2, 16, 6, 6).abs() * 2 - 0.2                    # includes values under the 0.11 bound and negatives
+    with torch.no_grad():
+        _, want = TO.gaussian_conditional(y, scale, mu)
+        yh, lk = M.tcm.GaussianConditional(None).eval()(y.cuda(), scale.cuda(), mu.cuda())
+    assert _close_fraction(lk.cpu(), want, 1e-4) > 0.99 and _close_fraction(yh.cpu(), TO.ste_round(y - mu) + mu, 1e-5) > 0.99
+    a, l = torch.randn(1, 4, 4, 8).cuda(), torch.randn(1, 4, 4, 8).cuda()
+    assert torch.allclose(ops.tanh_half_add(a, l).cpu(), (a + 0.5 * torch.tanh(l)).cpu(), atol=1e-6)
