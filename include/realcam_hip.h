@@ -205,6 +205,11 @@ int rc_sigmoid_gate_add(const void* d_a, const void* d_b, const void* d_identity
  * convolution (conv3x3(stride=2) in ResidualBlockWithStride / g_a / h_a) is rc_conv2d followed by this; a 1x1 stride-2
  * convolution (the block's skip) is this followed by rc_conv2d. */
 int rc_subsample2(const void* d_src, void* d_dst, int dtype, int batch, int H, int W, int c, void* stream);
+/* Space-to-depth by 2 on NHWC maps of any width: dst (B, ceil(H/2), ceil(W/2), 4c)[y][x][(2i+j)*c + k] = src (B,H,W,c)[2y+i][2x+j][k], zero
+ * beyond the bottom / right edge.  A 3x3 stride-2 padding-1 convolution is then a 3x3 stride-1 convolution over the 4c-channel map
+ * with the taps re-indexed (row offset -1 <- phase 1 of the previous row pair, 0 <- phases 0 and 1), which rc_conv2d runs at the
+ * OUTPUT resolution. */
+int rc_space_to_depth2(const void* d_src, void* d_dst, int dtype, int batch, int H, int W, int c, void* stream);
 /* nn.PixelShuffle(2) on NHWC maps of any width: dst (B,2H,2W,c)[2y+i][2x+j][k] = src (B,H,W,4c)[y][x][4k + 2i + j].  (rc_conv2d's
  * RC_OUT_PIXEL_SHUFFLE2 store covers c % 16 == 0; this is for the narrow tails, e.g. subpel_conv3x3(2N, 3, 2) of g_s.) */
 int rc_pixel_shuffle2(const void* d_src, void* d_dst, int dtype, int batch, int H, int W, int c_out, void* stream);

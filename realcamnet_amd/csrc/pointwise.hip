@@ -157,6 +157,23 @@ __global__ void subsample2_kernel(const T* __restrict__ src, T* __restrict__ dst
     }
 }
 
+// ---- space-to-depth by 2, element-wise: dst[y][x][(2i+j)*c + k] = src[2y+i][2x+j][k] ----------------------
+template <typename T>
+__global__ void space_to_depth2_kernel(const T* __restrict__ src, T* __restrict__ dst, int batch, int H, int W, int c) {
+    const int oh = (H + 1) / 2, ow = (W + 1) / 2;
+    const size_t total = (size_t)batch * oh * ow * 4 * c;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % c);
+        size_t p = i / c;
+        const int ph = (int)(p % 4); p /= 4;
+        const int x = (int)(p % ow); p /= ow;
+        const int y = (int)(p % oh);
+        const int b = (int)(p / oh);
+        const int sy = 2 * y + (ph >> 1), sx = 2 * x + (ph & 1);
+        dst[i] = (sy < H && sx < W) ? src[(((size_t)b * H + sy) * W + sx) * c + k] : from_f32<T>(0.f);
+    }
+}
+
 // ---- nn.PixelShuffle(2), element-wise (narrow maps) ------------------------------------------------------
 template <typename T>
 __global__ void pixel_shuffle2_kernel(const T* __restrict__ src, T* __restrict__ dst, int batch, int H, int W, int c) {
@@ -420,6 +437,21 @@ int rc_subsample2(const void* d_src, void* d_dst, int dtype, int batch, int H, i
                            static_cast<const float*>(d_src), static_cast<float*>(d_dst), batch, H, W, c);
     else
         hipLaunchKernelGGL(subsample2_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_src), static_cast<bf16_t*>(d_dst), batch, H, W, c);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_space_to_depth2(const void* d_src, void* d_dst, int dtype, int batch, int H, int W, int c, void* stream) {
+    RC_REQUIRE(d_src && d_dst, "rc_space_to_depth2: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_space_to_depth2: bad dtype");
+    RC_REQUIRE(batch >= 1 && H >= 1 && W >= 1 && c >= 1, "rc_space_to_depth2: bad shape");
+    const size_t total = (size_t)batch * ((H + 1) / 2) * ((W + 1) / 2) * 4 * c;
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(space_to_depth2_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const float*>(d_src), static_cast<float*>(d_dst), batch, H, W, c);
+    else
+        hipLaunchKernelGGL(space_to_depth2_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
                            static_cast<const bf16_t*>(d_src), static_cast<bf16_t*>(d_dst), batch, H, W, c);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;

@@ -152,22 +152,54 @@ def subsample2(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def space_to_depth2(x: torch.Tensor) -> torch.Tensor:
+    """(B,H,W,c) -> (B,ceil(H/2),ceil(W/2),4c), channel (2i+j)*c + k <- pixel (2y+i, 2x+j), zero beyond the edge."""
+    x = _req(x, "space_to_depth2 input")
+    b, H, W, c = x.shape
+    y = torch.empty((b, (H + 1) // 2, (W + 1) // 2, 4 * c), dtype=x.dtype, device=x.device)
+    check(lib().rc_space_to_depth2(x.data_ptr(), y.data_ptr(), _dt(x), b, H, W, c, _stream()), "rc_space_to_depth2")
+    return y
+
+
+def _stride2_view(mod) -> "_ConvView":
+    """Weights of a kxk stride-2 conv re-indexed for the space-to-depth map: input pixel offset d in {-1, 0, +1} of the strided
+    conv is (phase 1, offset -1), (phase 0, offset 0), (phase 1, offset 0) of the half-resolution map."""
+    cache = _cache(mod)
+    key = _key(mod.weight, mod.bias)
+    hit = cache.get("stride2_s2d")
+    if hit is None or hit[0] != key:
+        w = mod.weight.detach().float().cpu()
+        cout, c, k, _ = w.shape
+        w3 = torch.zeros(cout, 4 * c, k, k)
+        if k == 3:
+            place = {-1: (1, -1), 0: (0, 0), 1: (1, 0)}
+            for dy, (i, oy) in place.items():
+                for dx, (j, ox) in place.items():
+                    ph = 2 * i + j
+                    w3[:, ph * c:(ph + 1) * c, oy + 1, ox + 1] = w[:, :, dy + 1, dx + 1]
+        else:
+            w3[:, :c, 0, 0] = w[:, :, 0, 0]
+        view = _ConvView(w3.to(mod.weight.device, mod.weight.dtype), mod.bias.detach() if mod.bias is not None else None)
+        hit = (key, view)
+        cache["stride2_s2d"] = hit
+    return hit[1]
+
+
 def conv_stride2(x: torch.Tensor, mod, **fuse):
-    """kxk stride-2 padding-k//2 convolution.  Output pixel (y, x) of the strided conv is output pixel (2y, 2x) of the stride-1
-    conv, so 3x3: rc_conv2d then rc_subsample2 (4x the necessary MACs on these few layers -- a strided input staging is future
-    work); 1x1: sample first (when the channel count is a whole number of 16-byte vectors), then convolve.  Epilogue operands
-    in `fuse` (act only) apply element-wise and commute with the sampling."""
+    """kxk stride-2 padding-k//2 convolution (k in {1, 3}) as a stride-1 rc_conv2d at the OUTPUT resolution over the
+    space-to-depth map (4c channels, re-indexed taps; 16 of the 36 (tap, phase) blocks are structurally zero -- skipping them in
+    the packed weights is future work).  1x1 with a vectorisable channel count: sample (rc_subsample2), then convolve."""
     x = _req(x, "conv_stride2 input")
     if any(k not in ("act", "slope") for k in fuse):
         raise NotImplementedError("conv_stride2: only an activation can be fused")
-    cache = _cache(mod)
-    view = cache.get("stride2_view")
-    if view is None or view.weight is not mod.weight or view.bias is not mod.bias:
-        view = cache["stride2_view"] = _ConvView(mod.weight, mod.bias)
     unit = 16 // x.element_size()
     if mod.kernel_size[0] == 1 and x.shape[-1] % unit == 0:
+        cache = _cache(mod)
+        view = cache.get("stride2_view")
+        if view is None or view.weight is not mod.weight or view.bias is not mod.bias:
+            view = cache["stride2_view"] = _ConvView(mod.weight, mod.bias)
         return conv2d(subsample2(x), view, **fuse)
-    return subsample2(conv2d(x, view, **fuse))
+    return conv2d(space_to_depth2(x), _stride2_view(mod), **fuse)
 
 
 def entropy_bottleneck(z: torch.Tensor, params: torch.Tensor, medians: torch.Tensor, bound: float = 1e-9):
