@@ -205,6 +205,12 @@ int rc_sigmoid_gate_add(const void* d_a, const void* d_b, const void* d_identity
  * convolution (conv3x3(stride=2) in ResidualBlockWithStride / g_a / h_a) is rc_conv2d followed by this; a 1x1 stride-2
  * convolution (the block's skip) is this followed by rc_conv2d. */
 int rc_subsample2(const void* d_src, void* d_dst, int dtype, int batch, int H, int W, int c, void* stream);
+/* ---- a18 (models/raw2bit.py): nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) of HyCondModDecBlock (:790-793) on NHWC maps:
+ * dst (B,2H,2W,c); source coordinate = dst * (H-1)/(2H-1) per axis. */
+int rc_upsample_bilinear2(const void* d_src, void* d_dst, int dtype, int batch, int H, int W, int c, void* stream);
+/* SpatialFeatureTransform (:877-885) + the block's identity (:313): y = x*scale + shift + x (+ identity if d_identity != NULL). */
+int rc_sft_apply(const void* d_x, const void* d_scale, const void* d_shift, const void* d_identity, void* d_y, int dtype,
+                 long long n_elems, void* stream);
 /* Space-to-depth by 2 on NHWC maps of any width: dst (B, ceil(H/2), ceil(W/2), 4c)[y][x][(2i+j)*c + k] = src (B,H,W,c)[2y+i][2x+j][k], zero
  * beyond the bottom / right edge.  A 3x3 stride-2 padding-1 convolution is then a 3x3 stride-1 convolution over the 4c-channel map
  * with the taps re-indexed (row offset -1 <- phase 1 of the previous row pair, 0 <- phases 0 and 1), which rc_conv2d runs at the

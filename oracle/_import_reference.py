@@ -67,6 +67,18 @@ def install_stubs():
     _mod("compressai.models", CompressionModel=_raiser("CompressionModel"))
     _mod("compressai.layers", **{n: _raiser(n) for n in ("AttentionBlock", "ResidualBlock", "ResidualBlockUpsample",
                                                           "ResidualBlockWithStride", "conv3x3", "subpel_conv3x3")})
+    # models/raw2bit.py additionally imports torchvision and more of CompressAI at module level (datasets, zoo, google models,
+    # deconv/conv helpers, GDN, MaskedConv2d): name-only stubs again -- none of them is on the path the oracle restates.
+    _mod("torchvision", transforms=types.ModuleType("torchvision.transforms"), models=types.ModuleType("torchvision.models"))
+    _mod("torchvision.transforms")
+    _mod("torchvision.models")
+    _mod("compressai.datasets", ImageFolder=_raiser("ImageFolder"), Vimeo90kDataset=_raiser("Vimeo90kDataset"))
+    _mod("compressai.zoo", models={})
+    _mod("compressai.models.google", FactorizedPrior=_raiser("FactorizedPrior"), ScaleHyperprior=_raiser("ScaleHyperprior"),
+         MeanScaleHyperprior=_raiser("MeanScaleHyperprior"))
+    _mod("compressai.models.utils", deconv=_raiser("deconv"), conv=_raiser("conv"))
+    for _n in ("GDN", "MaskedConv2d"):
+        setattr(sys.modules["compressai.layers"], _n, _raiser(_n))
     _mod("timm.models.layers", DropPath=_DropPath, to_2tuple=lambda x: (x, x) if not isinstance(x, tuple) else x,
          trunc_normal_=torch.nn.init.trunc_normal_)
 

@@ -7,7 +7,8 @@ from . import networks  # noqa: F401
 from . import LiteISP  # noqa: F401
 from . import groupmix  # noqa: F401
 from . import tcm  # noqa: F401
+from . import raw2bit  # noqa: F401
 from .LiteISP import ISPUNet_GFM_LSC, LiteISPNet, LiteISPNet_GFM_LSC, LiteISPNet_GFM_LSC_GMA  # noqa: F401
 from .groupmix import GMA_Block  # noqa: F401
 
-__all__ = ["networks", "LiteISP", "groupmix", "tcm", "LiteISPNet", "LiteISPNet_GFM_LSC", "LiteISPNet_GFM_LSC_GMA", "ISPUNet_GFM_LSC", "GMA_Block"]
+__all__ = ["networks", "LiteISP", "groupmix", "tcm", "raw2bit", "LiteISPNet", "LiteISPNet_GFM_LSC", "LiteISPNet_GFM_LSC_GMA", "ISPUNet_GFM_LSC", "GMA_Block"]

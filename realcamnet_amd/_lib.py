@@ -83,6 +83,8 @@ _SIGS = {
     "rc_entropy_bottleneck": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_longlong, _I, C.c_float, _P]),
     "rc_gaussian_conditional": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_longlong, C.c_float, C.c_float, _P]),
     "rc_tanh_half_add": (C.c_int, [_P, _P, _P, _I, C.c_longlong, _P]),
+    "rc_upsample_bilinear2": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "rc_sft_apply": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_longlong, _P]),
     "rc_space_to_depth2": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "rc_pixel_shuffle2": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "rc_square": (C.c_int, [_P, _P, _I, C.c_longlong, _P]),

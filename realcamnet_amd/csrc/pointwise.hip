@@ -157,6 +157,56 @@ __global__ void subsample2_kernel(const T* __restrict__ src, T* __restrict__ dst
     }
 }
 
+// ---- bilinear x2 upsampling, align_corners=True (torch's area_pixel_compute_source_index with align_corners) ------------
+template <typename T>
+__global__ void upsample_bilinear2_kernel(const T* __restrict__ src, T* __restrict__ dst, int batch, int H, int W, int c) {
+    constexpr int U = Vec16<T>::N;
+    const int vpp = c / U, oh = 2 * H, ow = 2 * W;
+    const float ry = oh > 1 ? (float)(H - 1) / (float)(oh - 1) : 0.f, rx = ow > 1 ? (float)(W - 1) / (float)(ow - 1) : 0.f;
+    const size_t total = (size_t)batch * oh * ow * vpp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vpp);
+        size_t p = i / vpp;
+        const int x = (int)(p % ow); p /= ow;
+        const int y = (int)(p % oh);
+        const int b = (int)(p / oh);
+        const float fy = ry * (float)y, fx = rx * (float)x;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const uint4* s4 = reinterpret_cast<const uint4*>(src) + (size_t)b * H * W * vpp + v;
+        float a[U], bq[U], cq[U], d[U], o[U];
+        Vec16<T>::unpack(s4[((size_t)y0 * W + x0) * vpp], a);
+        Vec16<T>::unpack(s4[((size_t)y0 * W + x1) * vpp], bq);
+        Vec16<T>::unpack(s4[((size_t)y1 * W + x0) * vpp], cq);
+        Vec16<T>::unpack(s4[((size_t)y1 * W + x1) * vpp], d);
+#pragma unroll
+        for (int e = 0; e < U; ++e) o[e] = hy * (hx * a[e] + lx * bq[e]) + ly * (hx * cq[e] + lx * d[e]);
+        reinterpret_cast<uint4*>(dst)[i] = Vec16<T>::pack(o);
+    }
+}
+
+// ---- y = x*scale + shift + x (+ identity) ----------------------------------------------------------------
+template <typename T>
+__global__ void sft_apply_kernel(const T* __restrict__ x, const T* __restrict__ scale, const T* __restrict__ shift, const T* __restrict__ idn,
+                                 T* __restrict__ y, size_t total) {
+    constexpr int U = Vec16<T>::N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float fx[U], fs[U], ft[U];
+        Vec16<T>::unpack(reinterpret_cast<const uint4*>(x)[i], fx);
+        Vec16<T>::unpack(reinterpret_cast<const uint4*>(scale)[i], fs);
+        Vec16<T>::unpack(reinterpret_cast<const uint4*>(shift)[i], ft);
+#pragma unroll
+        for (int e = 0; e < U; ++e) fs[e] = (fx[e] * fs[e] + ft[e]) + fx[e];
+        if (idn != nullptr) {
+            Vec16<T>::unpack(reinterpret_cast<const uint4*>(idn)[i], ft);
+#pragma unroll
+            for (int e = 0; e < U; ++e) fs[e] += ft[e];
+        }
+        reinterpret_cast<uint4*>(y)[i] = Vec16<T>::pack(fs);
+    }
+}
+
 // ---- space-to-depth by 2, element-wise: dst[y][x][(2i+j)*c + k] = src[2y+i][2x+j][k] ----------------------
 template <typename T>
 __global__ void space_to_depth2_kernel(const T* __restrict__ src, T* __restrict__ dst, int batch, int H, int W, int c) {
@@ -438,6 +488,44 @@ int rc_subsample2(const void* d_src, void* d_dst, int dtype, int batch, int H, i
     else
         hipLaunchKernelGGL(subsample2_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
                            static_cast<const bf16_t*>(d_src), static_cast<bf16_t*>(d_dst), batch, H, W, c);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_upsample_bilinear2(const void* d_src, void* d_dst, int dtype, int batch, int H, int W, int c, void* stream) {
+    RC_REQUIRE(d_src && d_dst, "rc_upsample_bilinear2: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_upsample_bilinear2: bad dtype");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    RC_REQUIRE(batch >= 1 && H >= 1 && W >= 1 && c >= U && c % U == 0, "rc_upsample_bilinear2: channels must be a whole number of 16-byte vectors");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_src) % 16 == 0 && reinterpret_cast<uintptr_t>(d_dst) % 16 == 0, "rc_upsample_bilinear2: 16-byte alignment");
+    const size_t total = (size_t)batch * 4 * H * W * (c / U);
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(upsample_bilinear2_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const float*>(d_src), static_cast<float*>(d_dst), batch, H, W, c);
+    else
+        hipLaunchKernelGGL(upsample_bilinear2_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_src), static_cast<bf16_t*>(d_dst), batch, H, W, c);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_sft_apply(const void* d_x, const void* d_scale, const void* d_shift, const void* d_identity, void* d_y, int dtype,
+                 long long n_elems, void* stream) {
+    RC_REQUIRE(d_x && d_scale && d_shift && d_y, "rc_sft_apply: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_sft_apply: bad dtype");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    RC_REQUIRE(n_elems >= U && n_elems % U == 0, "rc_sft_apply: element count must be a whole number of 16-byte vectors");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_x) % 16 == 0 && reinterpret_cast<uintptr_t>(d_scale) % 16 == 0 && reinterpret_cast<uintptr_t>(d_shift) % 16 == 0 &&
+               reinterpret_cast<uintptr_t>(d_identity) % 16 == 0 && reinterpret_cast<uintptr_t>(d_y) % 16 == 0, "rc_sft_apply: 16-byte alignment");
+    const size_t total = (size_t)n_elems / U;
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(sft_apply_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const float*>(d_x), static_cast<const float*>(d_scale), static_cast<const float*>(d_shift),
+                           static_cast<const float*>(d_identity), static_cast<float*>(d_y), total);
+    else
+        hipLaunchKernelGGL(sft_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_x), static_cast<const bf16_t*>(d_scale), static_cast<const bf16_t*>(d_shift),
+                           static_cast<const bf16_t*>(d_identity), static_cast<bf16_t*>(d_y), total);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

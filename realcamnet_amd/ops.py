@@ -152,6 +152,40 @@ def subsample2(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def upsample_bilinear2(x: torch.Tensor) -> torch.Tensor:
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) on an NHWC map (upstream models/raw2bit.py:790-793)."""
+    x = _req(x, "upsample_bilinear2 input")
+    b, H, W, c = x.shape
+    y = torch.empty((b, 2 * H, 2 * W, c), dtype=x.dtype, device=x.device)
+    check(lib().rc_upsample_bilinear2(x.data_ptr(), y.data_ptr(), _dt(x), b, H, W, c, _stream()), "rc_upsample_bilinear2")
+    return y
+
+
+def sft_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, identity: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x*scale + shift + x (+ identity): SpatialFeatureTransform with residual=True (upstream models/raw2bit.py:877-885)."""
+    x, scale, shift = _req(x, "x"), _req(scale, "scale"), _req(shift, "shift")
+    for t in (scale, shift) + ((identity,) if identity is not None else ()):
+        if t.shape != x.shape or t.dtype != x.dtype:
+            raise ValueError("sft_apply: shape / dtype mismatch")
+    y = torch.empty_like(x)
+    check(lib().rc_sft_apply(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), _ptr(identity), y.data_ptr(), _dt(x), x.numel(), _stream()), "rc_sft_apply")
+    return y
+
+
+def ca_gate_linear(sums: torch.Tensor, hw: int, fc0, fc1) -> torch.Tensor:
+    """CALayer gate from channel partial sums for the bias-free nn.Linear form (upstream models/raw2bit.py:238-254)."""
+    b, nt, c = sums.shape
+    cr = fc0.weight.shape[0]
+    key = ("zeros", c, cr, str(sums.device))
+    z = _ONES.get(key)
+    if z is None:
+        z = _ONES[key] = torch.zeros(max(c, cr), dtype=torch.float32, device=sums.device)
+    gate = torch.empty((b, c), dtype=torch.float32, device=sums.device)
+    check(lib().rc_ca_gate(sums.data_ptr(), b, nt, c, cr, 1.0 / float(hw), f32_param(fc0, "weight").data_ptr(), z.data_ptr(),
+                           f32_param(fc1, "weight").data_ptr(), z.data_ptr(), gate.data_ptr(), _stream()), "rc_ca_gate")
+    return gate
+
+
 def space_to_depth2(x: torch.Tensor) -> torch.Tensor:
     """(B,H,W,c) -> (B,ceil(H/2),ceil(W/2),4c), channel (2i+j)*c + k <- pixel (2y+i, 2x+j), zero beyond the edge."""
     x = _req(x, "space_to_depth2 input")

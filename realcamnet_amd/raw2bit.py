@@ -1,0 +1,308 @@
+"""Host mirror of the RAW codec's own blocks and of `raw_compression_tcm_final` (upstream
+models/raw2bit.py:238-328, 730-886, 1614-1855): same class names, constructor signatures and attribute names, NCHW tensors at
+the module boundary, NHWC inside, every op through librealcam_hip.so.
+
+What is pinned and what is not is the same as in realcamnet_amd/tcm.py: upstream's own composition (these classes' forward
+logic) is checked against fixtures produced by running the reference classes; the CompressAI layers underneath them
+(`ResidualBlockWithStride`, `GDN`, `AttentionBlock`, entropy models ...) are restated and parity-unpinned.  Only the likelihood
+path (`forward`, eval mode) exists: no CDF tables, no `compress` / `decompress`.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import networks as N
+from . import ops
+from .LiteISP import Color_Condition_GFM, Lens_Shading_Correction, Res_GFM
+from .tcm import (Block, ConvTransBlock, EntropyBottleneck, GaussianConditional, ResidualBlock, ResidualBlockUpsample,
+                  ResidualBlockWithStride, SWAtten, conv1x1, conv3x3, slice_transform, subpel_conv3x3)
+
+
+class CALayer(nn.Module):
+    """Channel attention with bias-free Linear layers (upstream models/raw2bit.py:238-254).  Executed fused inside
+    ResidualBlockWithCA: the producing conv emits the channel sums, rc_ca_gate the gate."""
+
+    def __init__(self, channel, reduction=16):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Sequential(nn.Linear(channel, channel // reduction, bias=False), nn.ReLU(inplace=True),
+                                nn.Linear(channel // reduction, channel, bias=False), nn.Sigmoid())
+
+
+class ResidualBlockWithCA(nn.Module):
+    """CA(conv3x3(LeakyReLU(conv3x3(x)))) + skip(x)   (upstream models/raw2bit.py:257-289)."""
+
+    def __init__(self, in_ch: int, out_ch: int, redution=8):
+        super().__init__()
+        self.conv1 = conv3x3(in_ch, out_ch)
+        self.leaky_relu = nn.LeakyReLU(inplace=True)
+        self.conv2 = conv3x3(out_ch, out_ch)
+        self.ca = CALayer(out_ch, redution)
+        self.skip = conv1x1(in_ch, out_ch) if in_ch != out_ch else None
+
+    def _nhwc(self, a):
+        t = self.conv1._nhwc(a, act="leaky", slope=float(self.leaky_relu.negative_slope))
+        r, sums = self.conv2._nhwc(t, want_sums=True)
+        gate = ops.ca_gate_linear(sums, a.shape[1] * a.shape[2], self.ca.fc[0], self.ca.fc[2])
+        identity = a if self.skip is None else self.skip._nhwc(a)
+        return ops.gate_residual(r, gate, identity)
+
+    def forward(self, x):
+        return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
+
+
+class SpatialFeatureTransform(nn.Module):
+    """x * scale(cond) + shift(cond) (+ x)   (upstream models/raw2bit.py:860-885)."""
+
+    def __init__(self, cond_channels=64, n_features=64, ada_method='vanilla', residual=True):
+        super().__init__()
+        if ada_method != 'vanilla' or not residual:
+            raise NotImplementedError("SpatialFeatureTransform: the 'vanilla', residual=True form is the one upstream instantiates")
+        self.cond_scale = nn.Sequential(N.Conv2d(cond_channels, n_features, 3, stride=1, padding=1), nn.ReLU(inplace=True),
+                                        N.Conv2d(n_features, n_features, 3, stride=1, padding=1))
+        self.cond_shift = nn.Sequential(N.Conv2d(cond_channels, n_features, 3, stride=1, padding=1), nn.ReLU(inplace=True),
+                                        N.Conv2d(n_features, n_features, 3, stride=1, padding=1))
+        self.residual = residual
+
+    def _nhwc(self, a, cond, identity=None):
+        scale = self.cond_scale[2]._nhwc(self.cond_scale[0]._nhwc(cond, act="relu"))
+        shift = self.cond_shift[2]._nhwc(self.cond_shift[0]._nhwc(cond, act="relu"))
+        return ops.sft_apply(a, scale, shift, identity)
+
+    def forward(self, x, cond):
+        return ops.to_nchw(self._nhwc(ops.to_nhwc(x), ops.to_nhwc(cond)))
+
+
+class ConvTransBlock_mzj(nn.Module):
+    """ConvTransBlock whose conv branch is ResidualBlockWithCA followed by the spatial feature transform on the local RAW
+    condition (upstream models/raw2bit.py:292-328).  Takes and returns the pair (x, cond) so it chains in nn.Sequential."""
+
+    def __init__(self, conv_dim, trans_dim, head_dim, window_size, drop_path, type='W'):
+        super().__init__()
+        assert type in ['W', 'SW']
+        self.conv_dim, self.trans_dim, self.head_dim, self.window_size, self.drop_path, self.type = \
+            conv_dim, trans_dim, head_dim, window_size, drop_path, type
+        self.num_head = trans_dim // head_dim
+        self.trans_block = Block(trans_dim, trans_dim, head_dim, window_size, drop_path, type)
+        self.conv1_1 = N.Conv2d(conv_dim + trans_dim, conv_dim + trans_dim, 1, 1, 0, bias=True)
+        self.conv1_2 = N.Conv2d(conv_dim + trans_dim, conv_dim + trans_dim, 1, 1, 0, bias=True)
+        self.conv_block = ResidualBlockWithCA(conv_dim, conv_dim, 8)
+        self.spatial_transform = SpatialFeatureTransform(cond_channels=conv_dim, n_features=conv_dim)
+
+    def _nhwc(self, xx):
+        a, cond = xx
+        t = self.conv1_1._nhwc(a)
+        conv_x = ops.channel_slice(t, 0, self.conv_dim)
+        trans_x = ops.channel_slice(t, self.conv_dim, self.trans_dim)
+        conv_x = self.spatial_transform._nhwc(self.conv_block._nhwc(conv_x), cond, identity=conv_x)
+        trans_x = self.trans_block(trans_x)
+        return self.conv1_2._nhwc(ops.channel_concat([conv_x, trans_x]), residual=a), cond
+
+    def forward(self, xx):
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        y, _ = self._nhwc((ops.to_nhwc(xx[0]), ops.to_nhwc(xx[1])))
+        return ops.to_nchw(y), xx[1]
+
+
+class HyCondModConvBlock(nn.Module):
+    """conv + ReLU (upstream models/raw2bit.py:730-744; only the default 'relu' form is instantiated upstream)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, act='relu'):
+        super().__init__()
+        if act != 'relu':
+            raise NotImplementedError("HyCondModConvBlock: act='relu' only")
+        self.conv = N.Conv2d(in_channels, out_channels, kernel_size, stride, padding)
+        self.act = nn.ReLU(inplace=True)
+
+    def _nhwc(self, a):
+        return self.conv._nhwc(a, act="relu")
+
+
+class HyCondModEncBlock(nn.Module):
+    """stride-2 conv block, conv block (upstream models/raw2bit.py:746-767)."""
+
+    def __init__(self, in_channels, out_channels, downscale_method='stride'):
+        super().__init__()
+        if downscale_method != 'stride':
+            raise NotImplementedError("HyCondModEncBlock: 'stride' only")
+        self.down = HyCondModConvBlock(in_channels, out_channels, stride=2)
+        self.conv = HyCondModConvBlock(out_channels, out_channels)
+
+    def _nhwc(self, a):
+        return self.conv._nhwc(self.down._nhwc(a))
+
+
+class HyCondModDecBlock(nn.Module):
+    """bilinear x2 (align_corners) -> conv block; cat([skip, up]) -> conv block (upstream models/raw2bit.py:781-813)."""
+
+    def __init__(self, in_channels, out_channels, upscale_method='bilinear'):
+        super().__init__()
+        if upscale_method != 'bilinear':
+            raise NotImplementedError("HyCondModDecBlock: 'bilinear' only")
+        self.up = nn.Sequential(nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True), HyCondModConvBlock(in_channels, out_channels))
+        self.conv = HyCondModConvBlock(in_channels, out_channels)
+
+    def _nhwc(self, a1, a2):
+        up = self.up[1]._nhwc(ops.upsample_bilinear2(a1))
+        return self.conv._nhwc(ops.channel_concat([a2, up]))
+
+
+class HybridConditionModule(nn.Module):
+    """Small U-Net on the packed RAW giving three local condition maps at 1/2, 1/4, 1/8 (upstream models/raw2bit.py:817-858)."""
+
+    def __init__(self, in_channels=4, out_channels=64, init_mid_channels=16, down_method='stride', up_method='bilinear'):
+        super().__init__()
+        m = init_mid_channels
+        self.in_conv = HyCondModConvBlock(in_channels, m)
+        self.enc_1 = HyCondModEncBlock(m, m * 2, down_method)
+        self.enc_2 = HyCondModEncBlock(m * 2, m * 4, down_method)
+        self.enc_3 = HyCondModEncBlock(m * 4, m * 8, down_method)
+        self.dec_1 = HyCondModDecBlock(m * 8, m * 4, up_method)
+        self.dec_2 = HyCondModDecBlock(m * 4, m * 2, up_method)
+        self.dec_3 = HyCondModDecBlock(m * 2, m, up_method)
+        self.out_conv = HyCondModConvBlock(m, out_channels)
+        c = out_channels
+        self.CondNet1 = nn.Sequential(N.Conv2d(c, c, 3, 2, 1), nn.LeakyReLU(0.1, True), N.Conv2d(c, c, 1))
+        self.CondNet2 = nn.Sequential(N.Conv2d(c, c, 3, 2, 1), nn.LeakyReLU(0.1, True), N.Conv2d(c, c, 3, 2, 1))
+        self.CondNet3 = nn.Sequential(N.Conv2d(c, c, 3, 2, 1), nn.LeakyReLU(0.1, True), N.Conv2d(c, c, 3, 2, 1), nn.LeakyReLU(0.1, True),
+                                      N.Conv2d(c, c, 3, 2, 1))
+
+    @staticmethod
+    def _cond(net, y):
+        mods = list(net)
+        i = 0
+        while i < len(mods):
+            kw = {}
+            if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
+                kw = dict(act="leaky", slope=float(mods[i + 1].negative_slope))
+            y = mods[i]._nhwc(y, **kw)
+            i += 2 if kw else 1
+        return y
+
+    def _nhwc(self, a):
+        x1 = self.in_conv._nhwc(a)
+        x2 = self.enc_1._nhwc(x1)
+        x3 = self.enc_2._nhwc(x2)
+        x4 = self.enc_3._nhwc(x3)
+        y = self.dec_1._nhwc(x4, x3)
+        y = self.dec_2._nhwc(y, x2)
+        y = self.dec_3._nhwc(y, x1)
+        y = self.out_conv._nhwc(y)
+        return [self._cond(self.CondNet1, y), self._cond(self.CondNet2, y), self._cond(self.CondNet3, y)]
+
+    def forward(self, x):
+        if x.shape[-1] % 8 or x.shape[-2] % 8:
+            raise ValueError("HybridConditionModule: H and W must be multiples of 8 (three stride-2 stages with skip concatenation)")
+        return [ops.to_nchw(t) for t in self._nhwc(ops.to_nhwc(x))]
+
+
+class raw_compression_tcm_final(nn.Module):
+    """The RAW codec (upstream models/raw2bit.py:1614-1855), likelihood path: x = [raw (B,4,H,W), cond (B,4,h,w), coord (B,2,H,W)]
+    -> {"x_hat" (B,3,2H,2W), "y", "lft", "lsc", "likelihoods": {"y","z"}, "para": {"means","scales","y"}}.  Same attribute names as
+    upstream; load a reference checkpoint with strict=False (the entropy models' CDF buffers have no counterpart here)."""
+
+    def __init__(self, config=[2, 2, 2, 2, 2, 2, 2], head_dim=[8, 16, 32, 32, 16, 8, 8], drop_path_rate=0, N=64, M=320, num_slices=5,
+                 max_support_slices=5, **kwargs):
+        super().__init__()
+        if drop_path_rate != 0:
+            raise NotImplementedError("inference path: drop_path_rate must be 0")
+        self.config, self.head_dim, self.window_size = config, head_dim, 8
+        self.num_slices, self.max_support_slices, self.M = num_slices, max_support_slices, M
+        dim, ws = N, self.window_size
+        n2 = 2 * N
+        cond_c = 128
+        self.classifier = Color_Condition_GFM(in_channels=4, out_c=cond_c)
+        self.lsc = Lens_Shading_Correction(in_channels=2, out_c=n2, nf=n2)
+        self.local_condition = HybridConditionModule(out_channels=N, init_mid_channels=16)
+        self.conv_first = conv3x3(4, n2)
+        self.conv_down = ResidualBlockWithStride(n2, n2, 2)
+
+        def mzj(n, hd):
+            return nn.Sequential(*[ConvTransBlock_mzj(dim, dim, hd, ws, 0, 'W' if not i % 2 else 'SW') for i in range(n)])
+
+        def ctb(n, hd, w=ws):
+            return [ConvTransBlock(dim, dim, hd, w, 0, 'W' if not i % 2 else 'SW') for i in range(n)]
+
+        self.gfm1 = nn.Sequential(Res_GFM(in_nc=n2, chan=n2, cond_c=cond_c, nf=4 * N))
+        self.m_down1 = mzj(config[0], head_dim[0])
+        self.m_down1_down = ResidualBlockWithStride(n2, n2, stride=2)
+        self.gfm2 = nn.Sequential(Res_GFM(in_nc=n2, chan=n2, cond_c=cond_c, nf=4 * N))
+        self.m_down2 = mzj(config[1], head_dim[1])
+        self.m_down2_down = ResidualBlockWithStride(n2, n2, stride=2)
+        self.gfm3 = nn.Sequential(Res_GFM(in_nc=n2, chan=n2, cond_c=cond_c, nf=4 * N))
+        self.m_down3 = mzj(config[2], head_dim[2])
+        self.m_down3_down = conv3x3(n2, M, stride=2)
+        self.g_s = N_seq(*[ResidualBlockUpsample(M, n2, 2)] + ctb(config[3], head_dim[3]) + [ResidualBlockUpsample(n2, n2, 2)] +
+                         ctb(config[4], head_dim[4]) + [ResidualBlockUpsample(n2, n2, 2)] + ctb(config[5], head_dim[5]) +
+                         [subpel_conv3x3(n2, n2, 2)] + [ResidualBlock(n2, n2), subpel_conv3x3(n2, 3, 2)])
+        self.h_a = N_seq(*[ResidualBlockWithStride(320, n2, 2)] + ctb(config[0], 32, 4) + [conv3x3(n2, 192, stride=2)])
+        self.h_mean_s = N_seq(*[ResidualBlockUpsample(192, n2, 2)] + ctb(config[3], 32, 4) + [subpel_conv3x3(n2, 320, 2)])
+        self.h_scale_s = N_seq(*[ResidualBlockUpsample(192, n2, 2)] + ctb(config[3], 32, 4) + [subpel_conv3x3(n2, 320, 2)])
+        width = lambda i, cap: 320 + (320 // num_slices) * min(i, cap)
+        self.atten_mean = nn.ModuleList(nn.Sequential(SWAtten(width(i, 5), width(i, 5), 16, ws, 0, inter_dim=128)) for i in range(num_slices))
+        self.atten_scale = nn.ModuleList(nn.Sequential(SWAtten(width(i, 5), width(i, 5), 16, ws, 0, inter_dim=128)) for i in range(num_slices))
+        self.cc_mean_transforms = nn.ModuleList(slice_transform(width(i, 5), 320 // num_slices) for i in range(num_slices))
+        self.cc_scale_transforms = nn.ModuleList(slice_transform(width(i, 5), 320 // num_slices) for i in range(num_slices))
+        self.lrp_transforms = nn.ModuleList(slice_transform(width(i + 1, 6), 320 // num_slices) for i in range(num_slices))
+        self.entropy_bottleneck = EntropyBottleneck(192)
+        self.gaussian_conditional = GaussianConditional(None)
+
+    def _act_dtype(self):
+        return self.conv_first.weight.dtype
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        raw, cond, coord = x[0], x[1], x[2]
+        dt = self._act_dtype()
+        a = ops.to_nhwc(raw, dtype=dt)
+        lsc_fea = self.lsc._nhwc(ops.to_nhwc(coord, dtype=dt))
+        vec = self.classifier._vec(ops._req(cond, "cond"))
+        local = self.local_condition._nhwc(a)
+        fea = self.conv_first._nhwc(a, mul_plus1=lsc_fea)                 # conv_first(raw) * (lsc + 1)
+        fea = self.conv_down._nhwc(fea)
+        for gfm, blocks, down, c in ((self.gfm1, self.m_down1, self.m_down1_down, local[0]), (self.gfm2, self.m_down2, self.m_down2_down, local[1]),
+                                     (self.gfm3, self.m_down3, self.m_down3_down, local[2])):
+            fea, _ = gfm[0]._nhwc((fea, vec))
+            for blk in blocks:
+                fea, _ = blk._nhwc((fea, c))
+            fea = down._nhwc(fea)
+        y = fea
+        out = _slice_loop(self, y)
+        nchw = ops.to_nchw
+        out.update({"y": out["para"]["y"], "lft": nchw(local[2]), "lsc": nchw(lsc_fea)})
+        return out
+
+
+def N_seq(*mods):
+    return N.Sequential(*mods)
+
+
+def _slice_loop(m, y):
+    """h_a, entropy bottleneck, hyper-synthesis, the slice loop and g_s: identical in `TCM.forward` (models/tcm.py:439-486) and
+    `raw_compression_tcm_final.forward` (models/raw2bit.py:1791-1846).  y NHWC; returns the NCHW result dict."""
+    z = m.h_a._nhwc(y)
+    z_hat, z_lik = m.entropy_bottleneck._nhwc(z)
+    latent_scales = m.h_scale_s._nhwc(z_hat)
+    latent_means = m.h_mean_s._nhwc(z_hat)
+    if latent_means.shape[1:3] != y.shape[1:3]:
+        raise NotImplementedError("latent size must be a multiple of 4; upstream crops here")
+    per = y.shape[-1] // m.num_slices
+    y_hat_slices, y_lik, mu_list, scale_list = [], [], [], []
+    for i in range(m.num_slices):
+        y_slice = ops.channel_slice(y, i * per, per)
+        support = y_hat_slices if m.max_support_slices < 0 else y_hat_slices[:m.max_support_slices]
+        mean_support = m.atten_mean[i][0]._nhwc(ops.channel_concat([latent_means] + support))
+        mu = m.cc_mean_transforms[i]._nhwc(mean_support)
+        scale_support = m.atten_scale[i][0]._nhwc(ops.channel_concat([latent_scales] + support))
+        scale = m.cc_scale_transforms[i]._nhwc(scale_support)
+        y_hat_slice, lik = m.gaussian_conditional._nhwc(y_slice, scale, mu)
+        lrp = m.lrp_transforms[i]._nhwc(ops.channel_concat([mean_support, y_hat_slice]))
+        y_hat_slices.append(ops.tanh_half_add(y_hat_slice, lrp))
+        y_lik.append(lik); mu_list.append(mu); scale_list.append(scale)
+    x_hat = m.g_s._nhwc(ops.channel_concat(y_hat_slices))
+    nchw = ops.to_nchw
+    return {"x_hat": nchw(x_hat), "likelihoods": {"y": nchw(ops.channel_concat(y_lik)), "z": nchw(z_lik)},
+            "para": {"means": nchw(ops.channel_concat(mu_list)), "scales": nchw(ops.channel_concat(scale_list)), "y": nchw(y)}}

@@ -386,3 +386,124 @@ def test_hip_entropy_kernels_vs_oracle():
     assert _close_fraction(lk.cpu(), want, 1e-4) > 0.99 and _close_fraction(yh.cpu(), TO.ste_round(y - mu) + mu, 1e-5) > 0.99
     a, l = torch.randn(1, 4, 4, 8).cuda(), torch.randn(1, 4, 4, 8).cuda()
     assert torch.allclose(ops.tanh_half_add(a, l).cpu(), (a + 0.5 * torch.tanh(l)).cpu(), atol=1e-6)
+
+
+# ---- rows a18/a19: the RAW codec's own blocks and raw_compression_tcm_final.forward ------------------------------------------
+import liteisp_oracle as LO  # noqa: E402
+import raw2bit_oracle as RO  # noqa: E402
+
+MZJ = golden_names("raw2bit_convtrans_mzj_")
+
+
+@pytest.mark.parametrize("fixture", MZJ)
+def test_oracle_convtrans_mzj_equals_reference(fixture):
+    g = load_golden(fixture)
+    with torch.no_grad():
+        y = RO.conv_trans_block_mzj(g["sd"], "", g["x"], g["cond"], 32, 32, 16, 8, str(g["type"]))
+    assert rel_err(y, g["y"]) < 1e-6
+
+
+def test_oracle_hycond_equals_reference():
+    g = load_golden("raw2bit_hycond_c32")
+    with torch.no_grad():
+        ys = RO.hybrid_condition_module(g["sd"], "", g["x"])
+    for i, y in enumerate(ys):
+        assert rel_err(y, g[f"cond_{i + 1}"]) < 1e-6
+
+
+def _flat_raw(o):
+    d = _flat(o)
+    d.update({"lft": o["lft"], "lsc_s8": o["lsc"][:, :, ::8, ::8]})
+    return d
+
+
+def _raw_inputs(g):
+    return [g["raw"], g["cond"], LO.make_coord(1, g["raw"].shape[2], g["raw"].shape[3])]
+
+
+def _raw_mirror(g):
+    import realcamnet_amd.raw2bit as RB
+    m = RB.raw_compression_tcm_final(N=int(g["N"]), M=320, num_slices=int(g["num_slices"])).eval()
+    sd = m.state_dict()
+    assert len(sd) == int(g["n_keys"])
+    det_fill_(sd)
+    return m, sd
+
+
+def test_oracle_raw_codec_forward_equals_reference():
+    """raw_compression_tcm_final.forward (models/raw2bit.py:1768-1855) against the reference's own forward over restated
+    CompressAI classes; det_fill parameters on both sides."""
+    g = load_golden("raw2bit_final_forward_n32")
+    _, sd = _raw_mirror(g)
+    with torch.no_grad():
+        out = _flat_raw(RO.raw_compression_tcm_final(sd, _raw_inputs(g), N=int(g["N"]), num_slices=int(g["num_slices"])))
+    for k, v in out.items():
+        assert rel_err(v, g["out." + k].float()) < (2e-3 if k == "x_hat" else 1e-4), k
+
+
+def test_raw2bit_mirror_state_dict_keys():
+    import realcamnet_amd.raw2bit as RB
+    for fixture in MZJ[:1]:
+        g = load_golden(fixture)
+        m = RB.ConvTransBlock_mzj(32, 32, 16, 8, 0.0, type=str(g["type"]))
+        assert list(m.state_dict().keys()) == list(g["sd"].keys())
+    g = load_golden("raw2bit_hycond_c32")
+    m = RB.HybridConditionModule(out_channels=32, init_mid_channels=16)
+    assert list(m.state_dict().keys()) == list(g["sd"].keys())
+    assert [tuple(v.shape) for v in m.state_dict().values()] == [tuple(v.shape) for v in g["sd"].values()]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fixture", MZJ)
+def test_hip_convtrans_mzj_vs_reference(fixture, dt):
+    import realcamnet_amd.raw2bit as RB
+    g = load_golden(fixture)
+    m = RB.ConvTransBlock_mzj(32, 32, 16, 8, 0.0, type=str(g["type"]))
+    m.load_state_dict(g["sd"], strict=True)
+    m = m.to("cuda", dt).eval()
+    with torch.no_grad():
+        y, _ = m([g["x"].to("cuda", dt), g["cond"].to("cuda", dt)])
+    assert rel_err(y.float().cpu(), g["y"]) < (2e-5 if dt == torch.float32 else 4e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_hip_hycond_vs_reference(dt):
+    import realcamnet_amd.raw2bit as RB
+    g = load_golden("raw2bit_hycond_c32")
+    m = RB.HybridConditionModule(out_channels=32, init_mid_channels=16)
+    m.load_state_dict(g["sd"], strict=True)
+    m = m.to("cuda", dt).eval()
+    with torch.no_grad():
+        ys = m(g["x"].to("cuda", dt))
+    for i, y in enumerate(ys):
+        assert rel_err(y.float().cpu(), g[f"cond_{i + 1}"]) < (2e-5 if dt == torch.float32 else 4e-2)
+
+
+@pytest.mark.gpu
+def test_hip_raw_codec_forward_vs_reference_fp32():
+    g = load_golden("raw2bit_final_forward_n32")
+    m, _ = _raw_mirror(g)
+    m = m.to("cuda").eval()
+    with torch.no_grad():
+        out = _flat_raw(m([t.cuda() for t in _raw_inputs(g)]))
+    out = {k: v.float().cpu() for k, v in out.items()}
+    for k in ("y", "lft", "lsc_s8"):
+        assert rel_err(out[k], g["out." + k]) < 1e-4, k
+    assert rel_err(out["lik_z"], g["out.lik_z"]) < 1e-3
+    for k in ("means", "scales", "lik_y", "x_hat"):                     # downstream of round(): isolated flips tolerated
+        assert _close_fraction(out[k], g["out." + k].float(), 3e-3) > 0.995, k
+
+
+@pytest.mark.gpu
+def test_hip_raw_codec_forward_bf16_runs():
+    g = load_golden("raw2bit_final_forward_n32")
+    m, _ = _raw_mirror(g)
+    m = m.to("cuda", torch.bfloat16).eval()
+    with torch.no_grad():
+        out = _flat_raw(m([t.cuda() for t in _raw_inputs(g)]))
+    assert rel_err(out["y"].float().cpu(), g["out.y"]) < 8e-2
+    assert tuple(out["x_hat"].shape) == (1, 3, 512, 512)
+    for v in out.values():
+        assert torch.isfinite(v.float()).all()
