@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""TCM.forward (likelihood path) at the cfg5 size: sRGB 3840x2160 padded to 2176 rows, random-init weights, bf16 or fp32.
-   python tools/tcm_bench.py [--frames 1] [--dtype bf16] [--steps 5]      (not the headline bench: see bench.py)"""
+"""Codec forward (likelihood path) at the cfg5 size, random-init weights, bf16 or fp32 (not the headline bench: see bench.py).
+   python tools/tcm_bench.py [--model tcm|raw] [--frames 1] [--dtype bf16] [--steps 5]
+   tcm: TCM.forward on sRGB 3840x2160 padded to 2176 rows;  raw: raw_compression_tcm_final.forward on the packed RAW of a 4K
+   mosaic (4 x 1080 x 1920 padded to 1152 rows) + cond 256x256 + coord, producing the 2304 x 3840 sRGB."""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -9,15 +11,27 @@ from det_fill import det_fill_
 import realcamnet_amd.tcm as T
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--frames", type=int, default=1); ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--frames", type=int, default=1); ap.add_argument("--dtype", default="bf16"); ap.add_argument("--model", default="tcm")
 ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
-ap.add_argument("--height", type=int, default=2176); ap.add_argument("--width", type=int, default=3840)
+ap.add_argument("--height", type=int, default=0); ap.add_argument("--width", type=int, default=0)
 a = ap.parse_args()
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-m = T.TCM().eval()
+g = torch.Generator().manual_seed(1)
+if a.model == "raw":
+    import realcamnet_amd.raw2bit as RB
+    import liteisp_oracle as LO
+    a.height, a.width = a.height or 1152, a.width or 1920
+    m = RB.raw_compression_tcm_final().eval()
+    x = [torch.rand(a.frames, 4, a.height, a.width, generator=g).to("cuda", dt), torch.rand(a.frames, 4, 256, 256, generator=g).to("cuda", dt),
+         LO.make_coord(a.frames, a.height, a.width).to("cuda", dt)]
+    label = "megapixels/sec packed RAW -> raw_compression_tcm_final.forward (likelihood path), per 4K mosaic frame"
+else:
+    a.height, a.width = a.height or 2176, a.width or 3840
+    m = T.TCM().eval()
+    x = torch.rand(a.frames, 3, a.height, a.width, generator=g).to("cuda", dt)
+    label = "megapixels/sec sRGB -> TCM.forward (likelihood path)"
 det_fill_(m.state_dict())
 m = m.to("cuda", dt)
-x = torch.rand(a.frames, 3, a.height, a.width, generator=torch.Generator().manual_seed(1)).to("cuda", dt)
 with torch.no_grad():
     for _ in range(a.warmup):
         out = m(x)
@@ -28,6 +42,6 @@ with torch.no_grad():
     torch.cuda.synchronize()
 t = (time.perf_counter() - t0) / a.steps
 bpp = float((-torch.log2(out["likelihoods"]["y"])).sum() + (-torch.log2(out["likelihoods"]["z"])).sum()) / (a.frames * a.height * a.width)
-print(json.dumps({"metric": "megapixels/sec sRGB -> TCM.forward (likelihood path)", "value": round(a.frames * 3840 * 2160 / 1e6 / t, 2), "unit": "MP/s",
+print(json.dumps({"metric": label, "model": a.model, "value": round(a.frames * 3840 * 2160 / 1e6 / t, 2), "unit": "MP/s",
                   "ms_per_step": round(t * 1e3, 2), "frames": a.frames, "dtype": a.dtype, "padded": [a.height, a.width],
                   "bits_per_pixel_random_weights": round(bpp, 4), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}))
