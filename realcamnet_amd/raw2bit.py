@@ -16,7 +16,7 @@ from . import networks as N
 from . import ops
 from .LiteISP import Color_Condition_GFM, Lens_Shading_Correction, Res_GFM
 from .tcm import (Block, ConvTransBlock, EntropyBottleneck, GaussianConditional, ResidualBlock, ResidualBlockUpsample,
-                  ResidualBlockWithStride, SWAtten, conv1x1, conv3x3, slice_transform, subpel_conv3x3)
+                  ResidualBlockWithStride, SWAtten, _slice_loop, conv1x1, conv3x3, slice_transform, subpel_conv3x3)
 
 
 class CALayer(nn.Module):
@@ -278,31 +278,3 @@ class raw_compression_tcm_final(nn.Module):
 
 def N_seq(*mods):
     return N.Sequential(*mods)
-
-
-def _slice_loop(m, y):
-    """h_a, entropy bottleneck, hyper-synthesis, the slice loop and g_s: identical in `TCM.forward` (models/tcm.py:439-486) and
-    `raw_compression_tcm_final.forward` (models/raw2bit.py:1791-1846).  y NHWC; returns the NCHW result dict."""
-    z = m.h_a._nhwc(y)
-    z_hat, z_lik = m.entropy_bottleneck._nhwc(z)
-    latent_scales = m.h_scale_s._nhwc(z_hat)
-    latent_means = m.h_mean_s._nhwc(z_hat)
-    if latent_means.shape[1:3] != y.shape[1:3]:
-        raise NotImplementedError("latent size must be a multiple of 4; upstream crops here")
-    per = y.shape[-1] // m.num_slices
-    y_hat_slices, y_lik, mu_list, scale_list = [], [], [], []
-    for i in range(m.num_slices):
-        y_slice = ops.channel_slice(y, i * per, per)
-        support = y_hat_slices if m.max_support_slices < 0 else y_hat_slices[:m.max_support_slices]
-        mean_support = m.atten_mean[i][0]._nhwc(ops.channel_concat([latent_means] + support))
-        mu = m.cc_mean_transforms[i]._nhwc(mean_support)
-        scale_support = m.atten_scale[i][0]._nhwc(ops.channel_concat([latent_scales] + support))
-        scale = m.cc_scale_transforms[i]._nhwc(scale_support)
-        y_hat_slice, lik = m.gaussian_conditional._nhwc(y_slice, scale, mu)
-        lrp = m.lrp_transforms[i]._nhwc(ops.channel_concat([mean_support, y_hat_slice]))
-        y_hat_slices.append(ops.tanh_half_add(y_hat_slice, lrp))
-        y_lik.append(lik); mu_list.append(mu); scale_list.append(scale)
-    x_hat = m.g_s._nhwc(ops.channel_concat(y_hat_slices))
-    nchw = ops.to_nchw
-    return {"x_hat": nchw(x_hat), "likelihoods": {"y": nchw(ops.channel_concat(y_lik)), "z": nchw(z_lik)},
-            "para": {"means": nchw(ops.channel_concat(mu_list)), "scales": nchw(ops.channel_concat(scale_list)), "y": nchw(y)}}
