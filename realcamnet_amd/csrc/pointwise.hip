@@ -224,6 +224,25 @@ __global__ void space_to_depth2_kernel(const T* __restrict__ src, T* __restrict_
     }
 }
 
+template <typename T>     // the same in 16-byte vectors, c % (16 / sizeof(T)) == 0
+__global__ void space_to_depth2_vec_kernel(const T* __restrict__ src, T* __restrict__ dst, int batch, int H, int W, int c) {
+    constexpr int U = Vec16<T>::N;
+    const int vpp = c / U, oh = (H + 1) / 2, ow = (W + 1) / 2;
+    const size_t total = (size_t)batch * oh * ow * 4 * vpp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vpp);
+        size_t p = i / vpp;
+        const int ph = (int)(p % 4); p /= 4;
+        const int x = (int)(p % ow); p /= ow;
+        const int y = (int)(p % oh);
+        const int b = (int)(p / oh);
+        const int sy = 2 * y + (ph >> 1), sx = 2 * x + (ph & 1);
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (sy < H && sx < W) val = reinterpret_cast<const uint4*>(src)[(((size_t)b * H + sy) * W + sx) * vpp + v];
+        reinterpret_cast<uint4*>(dst)[i] = val;
+    }
+}
+
 // ---- nn.PixelShuffle(2), element-wise (narrow maps) ------------------------------------------------------
 template <typename T>
 __global__ void pixel_shuffle2_kernel(const T* __restrict__ src, T* __restrict__ dst, int batch, int H, int W, int c) {
@@ -534,6 +553,18 @@ int rc_space_to_depth2(const void* d_src, void* d_dst, int dtype, int batch, int
     RC_REQUIRE(d_src && d_dst, "rc_space_to_depth2: null pointer");
     RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_space_to_depth2: bad dtype");
     RC_REQUIRE(batch >= 1 && H >= 1 && W >= 1 && c >= 1, "rc_space_to_depth2: bad shape");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    if (c % U == 0 && reinterpret_cast<uintptr_t>(d_src) % 16 == 0 && reinterpret_cast<uintptr_t>(d_dst) % 16 == 0) {
+        const size_t tv = (size_t)batch * ((H + 1) / 2) * ((W + 1) / 2) * 4 * (c / U);
+        if (dtype == RC_F32)
+            hipLaunchKernelGGL(space_to_depth2_vec_kernel<float>, dim3(grid_for(tv)), dim3(kPwThreads), 0, as_stream(stream),
+                               static_cast<const float*>(d_src), static_cast<float*>(d_dst), batch, H, W, c);
+        else
+            hipLaunchKernelGGL(space_to_depth2_vec_kernel<bf16_t>, dim3(grid_for(tv)), dim3(kPwThreads), 0, as_stream(stream),
+                               static_cast<const bf16_t*>(d_src), static_cast<bf16_t*>(d_dst), batch, H, W, c);
+        RC_HIP_CHECK(hipGetLastError());
+        return RC_OK;
+    }
     const size_t total = (size_t)batch * ((H + 1) / 2) * ((W + 1) / 2) * 4 * c;
     if (dtype == RC_F32)
         hipLaunchKernelGGL(space_to_depth2_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),

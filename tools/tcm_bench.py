@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=1); ap.add_argument("--dtype", default="bf16"); ap.add_argument("--model", default="tcm")
 ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--height", type=int, default=0); ap.add_argument("--width", type=int, default=0)
+ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU oracle (fp32) on a 512x512-mosaic sample with the same weights")
 a = ap.parse_args()
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 g = torch.Generator().manual_seed(1)
@@ -31,6 +32,23 @@ else:
     x = torch.rand(a.frames, 3, a.height, a.width, generator=g).to("cuda", dt)
     label = "megapixels/sec sRGB -> TCM.forward (likelihood path)"
 det_fill_(m.state_dict())
+cpu = None
+if a.cpu_baseline:                       # oracle on the host cores, bounded sample (the codec's CPU restatement, kind "port")
+    import raw2bit_oracle as RO, tcm_oracle as TO
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        if a.model == "raw":
+            xs = [torch.rand(1, 4, 256, 256, generator=g), torch.rand(1, 4, 256, 256, generator=g), LO.make_coord(1, 256, 256)]
+            f = lambda: RO.raw_compression_tcm_final(sd, xs)
+            px = 512 * 512
+        else:
+            xs = torch.rand(1, 3, 512, 512, generator=g)
+            f = lambda: TO.tcm_forward(sd, xs)
+            px = 512 * 512
+        f(); t0 = time.perf_counter(); f(); tc = time.perf_counter() - t0
+    cpu = {"value": round(px / 1e6 / tc, 4), "unit": "MP/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"1 frame, 512x512 output pixels, fp32, oracle/{'raw2bit' if a.model == 'raw' else 'tcm'}_oracle.py, {tc:.1f} s"}
 m = m.to("cuda", dt)
 with torch.no_grad():
     for _ in range(a.warmup):
@@ -44,4 +62,4 @@ t = (time.perf_counter() - t0) / a.steps
 bpp = float((-torch.log2(out["likelihoods"]["y"])).sum() + (-torch.log2(out["likelihoods"]["z"])).sum()) / (a.frames * a.height * a.width)
 print(json.dumps({"metric": label, "model": a.model, "value": round(a.frames * 3840 * 2160 / 1e6 / t, 2), "unit": "MP/s",
                   "ms_per_step": round(t * 1e3, 2), "frames": a.frames, "dtype": a.dtype, "padded": [a.height, a.width],
-                  "bits_per_pixel_random_weights": round(bpp, 4), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}))
+                  "bits_per_pixel_random_weights": round(bpp, 4), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2), "cpu_baseline": cpu}))
