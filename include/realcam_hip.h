@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 3
+#define RC_ABI_VERSION 4
 
 typedef enum rc_status {
     RC_OK = 0,

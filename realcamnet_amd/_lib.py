@@ -17,7 +17,7 @@ HEADER = PKG.parent / "include" / "realcam_hip.h"
 RC_F32, RC_BF16 = 0, 1
 RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY, RC_ACT_GELU, RC_ACT_RELU_POST = 0, 1, 2, 3, 4
 RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ConvDesc(C.Structure):
