@@ -7,7 +7,6 @@ import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import torch
-from det_fill import det_fill_
 import realcamnet_amd.tcm as T
 
 ap = argparse.ArgumentParser()
@@ -19,23 +18,22 @@ ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU o
 a = ap.parse_args()
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
 g = torch.Generator().manual_seed(1)
+torch.manual_seed(0)
 if a.model == "raw":
     import realcamnet_amd.raw2bit as RB
-    import liteisp_oracle as LO
     a.height, a.width = a.height or 1152, a.width or 1920
     m = RB.raw_compression_tcm_final().eval()
     x = [torch.rand(a.frames, 4, a.height, a.width, generator=g).to("cuda", dt), torch.rand(a.frames, 4, 256, 256, generator=g).to("cuda", dt),
-         LO.make_coord(a.frames, a.height, a.width).to("cuda", dt)]
+         torch.stack(torch.meshgrid(torch.linspace(-1, 1, a.height), torch.linspace(-1, 1, a.width), indexing="ij"))[None].expand(a.frames, -1, -1, -1).contiguous().to("cuda", dt)]
     label = "megapixels/sec packed RAW -> raw_compression_tcm_final.forward (likelihood path), per 4K mosaic frame"
 else:
     a.height, a.width = a.height or 2176, a.width or 3840
     m = T.TCM().eval()
     x = torch.rand(a.frames, 3, a.height, a.width, generator=g).to("cuda", dt)
     label = "megapixels/sec sRGB -> TCM.forward (likelihood path)"
-det_fill_(m.state_dict())
-cpu = None
+cpu = None                               # weights: seed-0 default initialisation of the mirror modules
 if a.cpu_baseline:                       # oracle on the host cores, bounded sample (the codec's CPU restatement, kind "port")
-    import raw2bit_oracle as RO, tcm_oracle as TO
+    import liteisp_oracle as LO, raw2bit_oracle as RO, tcm_oracle as TO   # the oracle is used in this leg only, as in bench.py
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     with torch.no_grad():
