@@ -189,7 +189,8 @@ __global__ void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, con
 //   out qkvp[.., which, g*seg + s] = hardswish(bn_scale[g][s] * (g == 0 ? in[s] : sum_j pw[g-1][s][j] in[j]) + bn_shift[g][s])
 // job = 12: local: in = dwl[.., 0..3seg); t[s] = sum_j pwl[s][j] in[j]; out loc[.., s] = hardswish(LN_seg(t)[s])
 // Block = 13 waves (832 threads): wave j runs job j for a tile of TOK tokens (lane = token), so a wave never
-// diverges.  The tile's input slices (g0 of q,k,v from qkv; dw; dwl = 15 segments per token) are staged into LDS
+// diverges.  The local branch's 16 x 48 product is three times a point-wise job, so it is split by input segment over the
+// three g = 0 waves (whose own job has no product); wave 12 adds the partial sums and applies LayerNorm + Hardswish.  The tile's input slices (g0 of q,k,v from qkv; dw; dwl = 15 segments per token) are staged into LDS
 // with coalesced 16-byte loads, results (qkvp rows + loc = 13 segments per token) are assembled in LDS and written
 // back coalesced.  LDS rows are padded to an odd number of 16-byte slots -> conflict-free per-lane ds_read_b128.
 // The job's weight matrix is wave-uniform read-only data: indexed straight from global it goes through the scalar
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(kPwWaves * 64) void gma_pointwise_kernel(
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint4* s_in = reinterpret_cast<uint4*>(lds);            // [TOK][IN_S]
     uint4* s_out = s_in + TOK * IN_S;                       // [TOK][OUT_S]
+    float* s_part = reinterpret_cast<float*>(s_out + TOK * OUT_S);   // [TOK][3][SEG] partial sums of the local branch
     const int tid = threadIdx.x, lane = tid & 63;
     const int job = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> scalar weight loads
     const int which = job >> 2, g = job & 3;
@@ -258,29 +260,40 @@ __global__ __launch_bounds__(kPwWaves * 64) void gma_pointwise_kernel(
                 uint4* dst = s_out + lane * OUT_S + (which * 4 + g) * NV;      // qkvp row: [which][g][seg]
 #pragma unroll
                 for (int v = 0; v < NV; ++v) dst[v] = Vec16<T>::pack(out + v * U);
-            } else {
-                float lin[3 * SEG];
+                if (g == 0) {
+                    // one third of the local branch's 16 x 48 product (this wave's own job is only BN + Hardswish): the
+                    // `which`-th input segment of dwl against the matching 16 columns of pwl; summed by wave 12 below
+                    float lin[SEG];
 #pragma unroll
-                for (int v = 0; v < 3 * NV; ++v) Vec16<T>::unpack(row[12 * NV + v], lin + v * U);
-                float mean = 0.f;
+                    for (int v = 0; v < NV; ++v) Vec16<T>::unpack(row[(12 + which) * NV + v], lin + v * U);
+                    float* part = s_part + (lane * 3 + which) * SEG;
 #pragma unroll
-                for (int s2 = 0; s2 < SEG; ++s2) {
-                    float a = 0.f;
+                    for (int s2 = 0; s2 < SEG; ++s2) {
+                        float a = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 3 * SEG; ++j) a += sw[s2 * 3 * SEG + j] * lin[j];
-                    out[s2] = a; mean += a;
+                        for (int j = 0; j < SEG; ++j) a += pwl[s2 * 3 * SEG + which * SEG + j] * lin[j];
+                        part[s2] = a;
+                    }
                 }
-                mean /= (float)SEG;
-                float var = 0.f;
-#pragma unroll
-                for (int s2 = 0; s2 < SEG; ++s2) { const float d = out[s2] - mean; var += d * d; }
-                const float rstd = 1.f / sqrtf(var / (float)SEG + 1e-5f);
-#pragma unroll
-                for (int s2 = 0; s2 < SEG; ++s2) out[s2] = hardswish((out[s2] - mean) * rstd * ln_g[s2] + ln_b[s2]);
-                uint4* dst = s_out + lane * OUT_S + 12 * NV;
-#pragma unroll
-                for (int v = 0; v < NV; ++v) dst[v] = Vec16<T>::pack(out + v * U);
             }
+        }
+        __syncthreads();
+        if (job == 12 && lane < TOK) {
+            float out[SEG];
+            const float* part = s_part + lane * 3 * SEG;
+            float mean = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < SEG; ++s2) { out[s2] = (part[s2] + part[SEG + s2]) + part[2 * SEG + s2]; mean += out[s2]; }
+            mean /= (float)SEG;
+            float var = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < SEG; ++s2) { const float d = out[s2] - mean; var += d * d; }
+            const float rstd = 1.f / sqrtf(var / (float)SEG + 1e-5f);
+#pragma unroll
+            for (int s2 = 0; s2 < SEG; ++s2) out[s2] = hardswish((out[s2] - mean) * rstd * ln_g[s2] + ln_b[s2]);
+            uint4* dst = s_out + lane * OUT_S + 12 * NV;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) dst[v] = Vec16<T>::pack(out + v * U);
         }
         __syncthreads();
         // ---- stage out: qkvp rows are 12 segments contiguous per token, loc 1 segment ---------------------------
@@ -562,8 +575,9 @@ int rc_gma_pointwise(const void* d_qkv, const void* d_dw, const void* d_dwl, int
                dw_tok_stride % U == 0 && dw_rep_stride % U == 0 && dwl_tok_stride % U == 0 && dwl_rep_stride % U == 0,
                "rc_gma_pointwise: bad dw/dwl strides");
     const int nv = seg / U;
-    const int tok = ((15 * nv | 1) + (13 * nv | 1)) * 16 * 64 <= 150 * 1024 ? 64 : 32;   // tokens per tile that fit LDS
-    const size_t lds = (size_t)((15 * nv | 1) + (13 * nv | 1)) * 16 * tok;
+    const int per_tok = ((15 * nv | 1) + (13 * nv | 1)) * 16 + 3 * seg * 4;            // staged in + out rows, local-branch partial sums
+    const int tok = per_tok * 64 <= 150 * 1024 ? 64 : 32;                               // tokens per tile that fit LDS
+    const size_t lds = (size_t)per_tok * tok;
     RC_REQUIRE(lds <= 160 * 1024, "rc_gma_pointwise: tile does not fit LDS");
     size_t n_tiles = ((size_t)tokens + tok - 1) / tok;
     const unsigned gx = (unsigned)(n_tiles < 1024 ? n_tiles : 1024);
