@@ -87,8 +87,9 @@ def main():
     ap.add_argument("--height", type=int, default=2160, help="mosaic height")
     ap.add_argument("--width", type=int, default=3840, help="mosaic width")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
-    ap.add_argument("--model", default="LiteISPNet_GFM_LSC_GMA", choices=["LiteISPNet_GFM_LSC_GMA", "LiteISPNet_GFM_LSC", "LiteISPNet", "ISPUNet_GFM_LSC"],
-                    help="default = cfg3: the flagship net plus one GroupMix GMA_Block(80,8) at H/2 (build-defined placement)")
+    ap.add_argument("--model", default="LiteISPNet_GFM_LSC_GMA", choices=["LiteISPNet_GFM_LSC_GMA", "LiteISPNet_GFM_LSC", "LiteISPNet", "ISPUNet_GFM_LSC", "raw_compression_tcm_final"],
+                    help="default = cfg3: the flagship net plus one GroupMix GMA_Block(80,8) at H/2 (build-defined placement); "
+                         "raw_compression_tcm_final = the RAW codec's forward (likelihood path), SURVEY cfg5's codec leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -106,7 +107,8 @@ def main():
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     torch.manual_seed(0)                                   # random-init weights of the named architecture
-    net = getattr(M, args.model)().eval()
+    codec = args.model == "raw_compression_tcm_final"
+    net = (M.raw2bit.raw_compression_tcm_final() if codec else getattr(M, args.model)()).eval()
     sd_cpu = {k: v.clone() for k, v in net.state_dict().items()}
     net = net.to(device=dev, dtype=dt)
 
@@ -122,6 +124,9 @@ def main():
     def step():
         with torch.no_grad():
             return net.forward_mosaic(mosaic, cond, coord)
+
+    if codec:
+        return bench_codec(args, net, sd_cpu, step, (mosaic, cond, coord), rank, world, dev, dt)
 
     for _ in range(args.warmup):
         step()
@@ -184,6 +189,59 @@ def main():
         torch.cuda.synchronize()
         res["cpu_baseline"] = info
         res["psnr_db_vs_cpu_fp32"] = round(O.psnr(y.float().cpu(), ref), 2)
+    print(json.dumps(res), flush=True)
+
+
+def bench_codec(args, net, sd_cpu, step, inputs, rank, world, dev, dt):
+    """--model raw_compression_tcm_final: the RAW codec's forward (models/raw2bit.py:1768-1855, likelihood path; no entropy coder)
+    on 4K mosaics, packed RAW padded to a multiple of 128.  Same timing contract and JSON shape as the headline run."""
+    import liteisp_oracle as O
+    import raw2bit_oracle as RO
+    from realcamnet_amd import ops, shard
+    B, H2, W2 = args.frames, args.height, args.width
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(); shard.barrier(); torch.cuda.synchronize()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dev)
+    ops.prof_enable(True)
+    step()
+    n_launch, conv_ms, conv_flops = ops.prof_collect()
+    ops.prof_enable(False)
+    if rank != 0:
+        return
+    total_frames = B * world
+    value = total_frames * H2 * W2 / 1e6 * args.steps / elapsed
+    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    peak = PEAK_TFLOPS[args.dtype]
+    hp, wp = out["lsc"].shape[-2:]
+    res = {"metric": f"megapixels/sec RAW mosaic {W2}x{H2} -> raw_compression_tcm_final.forward (likelihood path)", "value": round(value, 2), "unit": "MP/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+           "data": "synthetic (uniform[0,1) mosaics, seed-0 random-init weights)",
+           "config": {"workload": f"cfg5 codec leg: {W2}x{H2} Bayer mosaic -> unshuffle + pad128 (packed {wp}x{hp}) -> raw_compression_tcm_final "
+                                  f"(N=64, M=320, 5 slices) -> x_hat {2 * wp}x{2 * hp} + likelihoods, {B} frames/GPU, {args.dtype} storage / fp32 accumulate",
+                      "frames_per_gpu": B, "global_frames": total_frames, "parallelism": f"frame-shard x{world}"},
+           "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                        "traffic": None, "kernel": "conv_mfma_kernel (all instantiations)", "launches_per_step": int(n_launch),
+                        "kernel_ms_per_step": round(conv_ms, 3), "flops_per_step": conv_flops}}
+    if world == 1 and not args.no_cpu_baseline:
+        g = torch.Generator().manual_seed(1234)
+        raw = torch.rand(1, 4, 256, 256, generator=g); cond = torch.rand(1, 4, 256, 256, generator=g); coord = O.make_coord(1, 256, 256)
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        with torch.no_grad():
+            RO.raw_compression_tcm_final(sd_cpu, [raw, cond, coord])
+            t0 = time.perf_counter()
+            ref = RO.raw_compression_tcm_final(sd_cpu, [raw, cond, coord])
+            tc = time.perf_counter() - t0
+            y = net([raw.to(dev, dt), cond.to(dev, dt), coord.to(dev, dt)])
+        res["cpu_baseline"] = {"value": round(512 * 512 / 1e6 / tc, 4), "unit": "MP/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"1 frame, packed RAW 4x256x256 (a 512x512 mosaic) fp32, oracle/raw2bit_oracle.py, {tc:.1f} s"}
+        res["psnr_db_vs_cpu_fp32"] = {"y (latent, before rounding)": round(O.psnr(y["para"]["y"].float().cpu(), ref["para"]["y"]), 2),
+                                      "x_hat": round(O.psnr(y["x_hat"].float().cpu(), ref["x_hat"]), 2)}
     print(json.dumps(res), flush=True)
 
 

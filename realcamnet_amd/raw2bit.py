@@ -257,8 +257,22 @@ class raw_compression_tcm_final(nn.Module):
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
         raw, cond, coord = x[0], x[1], x[2]
         dt = self._act_dtype()
-        a = ops.to_nhwc(raw, dtype=dt)
-        lsc_fea = self.lsc._nhwc(ops.to_nhwc(coord, dtype=dt))
+        return self._forward_nhwc(ops.to_nhwc(raw, dtype=dt), cond, ops.to_nhwc(coord, dtype=dt))
+
+    def forward_mosaic(self, mosaic, cond, coord, pad_to: int = 128):
+        """Bayer mosaic (B,1,2h,2w), cond (B,4,hc,wc), coord (B,2,h,w) -> the same dict as forward().  The packed RAW and coord are
+        zero-padded bottom/right to a multiple of `pad_to` (128: window 4 at 1/32 of the packed size), x_hat
+        is NOT cropped (it is the decoder's output for the padded frame)."""
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        dt = self._act_dtype()
+        a = ops.bayer_unshuffle(mosaic, dtype=dt, pad_to=pad_to)
+        if coord.shape[-2:] != (mosaic.shape[-2] // 2, mosaic.shape[-1] // 2):
+            raise ValueError("coord must be at packed resolution (h, w)")
+        return self._forward_nhwc(a, cond, ops.to_nhwc(coord, dtype=dt, pad_hw=(a.shape[1], a.shape[2])))
+
+    def _forward_nhwc(self, a, cond, coord_nhwc):
+        lsc_fea = self.lsc._nhwc(coord_nhwc)
         vec = self.classifier._vec(ops._req(cond, "cond"))
         local = self.local_condition._nhwc(a)
         fea = self.conv_first._nhwc(a, mul_plus1=lsc_fea)                 # conv_first(raw) * (lsc + 1)
@@ -269,8 +283,7 @@ class raw_compression_tcm_final(nn.Module):
             for blk in blocks:
                 fea, _ = blk._nhwc((fea, c))
             fea = down._nhwc(fea)
-        y = fea
-        out = _slice_loop(self, y)
+        out = _slice_loop(self, fea)
         nchw = ops.to_nchw
         out.update({"y": out["para"]["y"], "lft": nchw(local[2]), "lsc": nchw(lsc_fea)})
         return out
