@@ -221,8 +221,8 @@ def _stride2_view(mod) -> "_ConvView":
 
 def conv_stride2(x: torch.Tensor, mod, **fuse):
     """kxk stride-2 padding-k//2 convolution (k in {1, 3}) as a stride-1 rc_conv2d at the OUTPUT resolution over the
-    space-to-depth map (4c channels, re-indexed taps; 16 of the 36 (tap, phase) blocks are structurally zero -- skipping them in
-    the packed weights is future work).  1x1 with a vectorisable channel count: sample (rc_subsample2), then convolve."""
+    space-to-depth map (4c channels, re-indexed taps; only 9 of the 36 (tap, phase) blocks are non-zero -- skipping the rest in
+    the packed weights, or a strided input staging, is future work).  1x1 with a vectorisable channel count: sample (rc_subsample2), then convolve."""
     x = _req(x, "conv_stride2 input")
     if any(k not in ("act", "slope") for k in fuse):
         raise NotImplementedError("conv_stride2: only an activation can be fused")
