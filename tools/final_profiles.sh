@@ -12,7 +12,8 @@ timeout 900 python bench.py > gpurun_out/bench_default_$TAG.json 2> gpurun_out/b
 timeout 300 python bench.py --model LiteISPNet_GFM_LSC --no-cpu-baseline > gpurun_out/bench_nogma_$TAG.json 2>/dev/null
 timeout 300 python bench.py --model LiteISPNet --dtype f32 --frames 1 --height 1080 --width 1920 --steps 20 --warmup 5 > gpurun_out/bench_cfg2_$TAG.json 2>/dev/null
 timeout 300 python bench.py --model ISPUNet_GFM_LSC --no-cpu-baseline > gpurun_out/bench_ispunet_$TAG.json 2>/dev/null
+timeout 600 python bench.py --model raw_compression_tcm_final --frames 4 > gpurun_out/bench_codec_$TAG.json 2>/dev/null
 timeout 120 python tools/mfma_peak.py > gpurun_out/mfma_peak_$TAG.txt 2>/dev/null
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_torchrun_$TAG.json 2>/dev/null
 
-tail -c 400 gpurun_out/bench_default_$TAG.json; echo; cut -c1-160 gpurun_out/bench_nogma_$TAG.json gpurun_out/bench_cfg2_$TAG.json gpurun_out/bench_ispunet_$TAG.json gpurun_out/bench_torchrun_$TAG.json
+tail -c 400 gpurun_out/bench_default_$TAG.json; echo; cut -c1-160 gpurun_out/bench_nogma_$TAG.json gpurun_out/bench_cfg2_$TAG.json gpurun_out/bench_ispunet_$TAG.json gpurun_out/bench_codec_$TAG.json gpurun_out/bench_torchrun_$TAG.json
