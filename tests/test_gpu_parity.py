@@ -486,6 +486,25 @@ def test_bench_prints_one_contract_json_line(hip):
     assert d["psnr_db_vs_cpu_fp32"] >= 50.0
 
 
+def test_bench_codec_leg_prints_one_contract_json_line(hip):
+    """bench.py --model raw_compression_tcm_final on a 512x512 mosaic: same contract keys; the latent before rounding must agree
+    with the CPU oracle (downstream of round() isolated flips are expected in bf16, so x_hat is only required to be sane)."""
+    import json, subprocess
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "1", "--height", "512", "--width", "512", "--steps", "1",
+                        "--warmup", "1", "--model", "raw_compression_tcm_final"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "MP/s" and d["value"] > 0 and "raw_compression_tcm_final" in d["config"]["workload"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["psnr_db_vs_cpu_fp32"]["y (latent, before rounding)"] >= 45.0
+    assert d["psnr_db_vs_cpu_fp32"]["x_hat"] >= 25.0
+
+
 def test_forward_is_hip_graph_capturable(hip):
     """Every op launches on the current stream, allocates through the caching allocator and never syncs with the host, so a
     whole forward can be captured in a HIP graph; the replay is bit-identical to the eager run."""
