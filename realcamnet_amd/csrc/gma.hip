@@ -457,9 +457,11 @@ template <typename T, int CH>   // CH > 0: compile-time head width; 0: runtime (
 __global__ void gma_apply_kernel(const T* __restrict__ qkvp, const T* __restrict__ convv, const T* __restrict__ loc,
                                  const float* __restrict__ ktv, T* __restrict__ out, int n_tok, int heads, int ch_rt, int seg) {
     const int ch = CH > 0 ? CH : ch_rt;
-    extern __shared__ float s_ktv[];          // this image's [heads][ch][ch]
-    const int ct = heads * ch, c = ct + seg, nacc = heads * ch * ch, b = blockIdx.y;
-    for (int i = threadIdx.x; i < nacc; i += blockDim.x) s_ktv[i] = ktv[(size_t)b * nacc + i];
+    extern __shared__ float s_ktv[];          // this image's [heads][ch*ch + 1]: adjacent lanes work on different heads of one token,
+                                              // and with a head stride of ch*ch = 64 floats they would all hit one LDS bank
+                                              // (PMC: 0.87 conflict cycles per LDS cycle, the kernel was LDS-bound)
+    const int ct = heads * ch, c = ct + seg, nacc = heads * ch * ch, hs = ch * ch + 1, b = blockIdx.y;
+    for (int i = threadIdx.x; i < nacc; i += blockDim.x) s_ktv[(i / (ch * ch)) * hs + i % (ch * ch)] = ktv[(size_t)b * nacc + i];
     __syncthreads();
     const size_t jobs = (size_t)n_tok * (heads + 1);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < jobs; i += (size_t)gridDim.x * blockDim.x) {
@@ -475,7 +477,7 @@ __global__ void gma_apply_kernel(const T* __restrict__ qkvp, const T* __restrict
         const T* qp = qkvp + t * 3 * ct + h * ch;
 #pragma unroll
         for (int k = 0; k < ch; ++k) q[k] = to_f32(qp[k]);
-        const float* m = s_ktv + h * ch * ch;
+        const float* m = s_ktv + h * hs;
 #pragma unroll
         for (int j = 0; j < ch; ++j) {
             float a = q[j] * to_f32(convv[t * ct + h * ch + j]);
@@ -660,7 +662,7 @@ int rc_gma_apply(const void* d_qkvp, const void* d_convv, const void* d_loc, con
     RC_REQUIRE(d_qkvp && d_convv && d_loc && d_ktv && d_out, "rc_gma_apply: null pointer");
     RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_gma_apply: bad dtype");
     RC_REQUIRE(batch >= 1 && batch <= 65535 && n_tok >= 1 && heads >= 1 && ch >= 1 && ch <= 32 && seg >= 1, "rc_gma_apply: bad shape");
-    const size_t lds = (size_t)heads * ch * ch * sizeof(float);
+    const size_t lds = (size_t)heads * (ch * ch + 1) * sizeof(float);
     RC_REQUIRE(lds <= 64 * 1024, "rc_gma_apply: too many attention channels");
     size_t g = ((size_t)n_tok * (heads + 1) + kGThreads - 1) / kGThreads;
     if (g > 4096) g = 4096;
