@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 4
+#define RC_ABI_VERSION 5
 
 typedef enum rc_status {
     RC_OK = 0,
@@ -36,7 +36,7 @@ typedef enum rc_status {
     RC_ERR_UNSUPPORTED = -3  /* valid request, but no kernel instantiation covers it */
 } rc_status;
 
-typedef enum rc_dtype { RC_F32 = 0, RC_BF16 = 1 } rc_dtype;
+typedef enum rc_dtype { RC_F32 = 0, RC_BF16 = 1, RC_U16 = 2 /* sensor counts: rc_raw_ingest's mosaic only */ } rc_dtype;
 
 typedef enum rc_act { RC_ACT_NONE = 0, RC_ACT_RELU = 1, RC_ACT_LEAKY = 2 /* slope in act_slope */,
                       RC_ACT_GELU = 3 /* exact erf GELU: nn.GELU() in groupmix.Mlp */,
@@ -66,6 +66,15 @@ int rc_device_arch(char* buf, size_t buflen);
  * channel k = 2*i + j <- mosaic pixel (2y+i, 2x+j); rows/cols beyond (h,w) are written as zero. */
 int rc_bayer_unshuffle(const void* d_mosaic, int in_dtype, void* d_packed, int out_dtype,
                        int batch, int h, int w, int hp, int wp, void* stream);
+
+/* ---- f4: RAW ingest in front of the path ----------------------------------
+ * The "Unpixel shuffle" and "Resize" boxes of assets/networkarch.png with the sensor normalisation upstream leaves to
+ * the data loader: v' = (v - black_level) / (white_level - black_level); packed as rc_bayer_unshuffle (zero padded to
+ * hp x wp); cond (B,4,cond_h,cond_w) NCHW = bilinear resize of the un-padded normalised packed RAW (h x w) with
+ * torch.nn.functional.interpolate(mode="bilinear", align_corners=False) semantics -- the colour prior's input
+ * (models/LiteISP.py:2016, x[1]).  One launch.  in_dtype may also be RC_U16 (sensor counts, e.g. black 64 / white 1023). */
+int rc_raw_ingest(const void* d_mosaic, int in_dtype, void* d_packed, void* d_cond, int out_dtype, int batch, int h, int w,
+                  int hp, int wp, int cond_h, int cond_w, float black_level, float white_level, void* stream);
 
 /* ---- layout plumbing at the nn.Module boundary (reference tensors are NCHW) ------------------
  * nchw (B,C,h,w) -> nhwc (B,hp,wp,C) with zero padding (hp>=h, wp>=w) and dtype conversion. */
@@ -190,8 +199,15 @@ int rc_ca_gate(float* d_sums, int batch, int n_tiles, int c, int cr, float inv_h
                const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,
                float* d_gate, void* stream);
 
+/* Per-channel partial sums of an NHWC map (B, n_pix, C): the AdaptiveAvgPool2d(1) of a standalone CALayer
+ * (models/networks.py:259,268) when no producing conv emitted them.  d_sums: fp32 (B, rc_channel_sums_slots(n_pix), C),
+ * fixed-order partials in the layout rc_ca_gate folds. */
+int rc_channel_sums_slots(int n_pix);
+int rc_channel_sums(const void* d_x, int dtype, int batch, int n_pix, int c, float* d_sums, void* stream);
+
 /* y = r*gate[b][c] + x  (CALayer scale + RCAB skip, networks.py:270,311) for call sites where the
- * gated tensor is not consumed by a conv.  NHWC, n_pix = H*W per image. */
+ * gated tensor is not consumed by a conv; d_x == NULL: y = r*gate (CALayer alone, networks.py:270).
+ * NHWC, n_pix = H*W per image. */
 int rc_gate_residual(const void* d_r, const float* d_gate, const void* d_x, void* d_y, int dtype,
                      int batch, int n_pix, int c, void* stream);
 

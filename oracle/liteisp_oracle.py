@@ -235,14 +235,19 @@ def liteispnet_gfm_lsc_gma(sd: SD, x: Sequence[torch.Tensor], heads: int = 8) ->
     return _unet_trunk(sd, h, v, refine)
 
 
-def ispunet_gfm_lsc(sd: SD, x: Sequence[torch.Tensor]) -> torch.Tensor:
-    """ISPUNet_GFM_LSC.forward.  models/LiteISP.py:1340-1380; constructor :1229-1338:
-    Conv2d(c, 2c, 2, 2) down-samplers (:1253), Conv1x1(c, 2c, bias=False) + PixelShuffle(2) up-samplers (:1292-1295),
-    m_blocks Res_GFM per level (the count is read off the state_dict), RCAGroups of 2 blocks (middle: 4)."""
-    raw, cond, coord = x
-    v = color_condition_gfm(sd, "classifier", cond)
+def _strided_unet(sd: SD, x: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Shared body of the ISPUNet / ResUNet family: ISPUNet_GFM_LSC (models/LiteISP.py:1340-1380),
+    ISPUNet_GFM (:1076-1110), ISPUNet_LSC (:1196-1225), ResUNet (:2121-2146).  Conv2d(c, 2c, 2, 2) down-samplers (:1253),
+    Conv1x1(c, 2c, bias=False) + PixelShuffle(2) up-samplers (:1292-1295), RCAGroups of 2 blocks (middle: 4).  Which of the
+    optional parts exist (colour prior + Res_GFM modulation, lens shading) is read off the state_dict, like the count of
+    Res_GFM blocks per level."""
+    raw = x[0]
+    has_gfm, has_lsc = "classifier.model.0.weight" in sd, "lsc.model.0.weight" in sd
+    v = color_condition_gfm(sd, "classifier", x[1]) if has_gfm else None
 
     def gfm(p, t):
+        if not has_gfm:
+            return t
         if f"{p}.conv0.weight" in sd:                    # N.seq of ONE module is that module (models/networks.py:117-121)
             return res_gfm(sd, p, t, v)
         i = 0
@@ -264,7 +269,9 @@ def ispunet_gfm_lsc(sd: SD, x: Sequence[torch.Tensor]) -> torch.Tensor:
         t = rcag(sd, f"{p}.{i}", t, nb=2)
         return F.leaky_relu(conv(sd, f"{p}.{i + 1}", t), 0.1)
 
-    intro = conv(sd, "intro", raw) * (lens_shading(sd, "lsc", coord) + 1)
+    intro = conv(sd, "intro", raw)
+    if has_lsc:
+        intro = intro * (lens_shading(sd, "lsc", x[2]) + 1)
     d1 = down("down1", enc("encoder1", gfm("encoder_modulation1", intro), False))
     d2 = down("down2", enc("encoder2", gfm("encoder_modulation2", d1), False))
     d3 = down("down3", enc("encoder3", gfm("encoder_modulation3", d2), True))
@@ -279,7 +286,30 @@ def ispunet_gfm_lsc(sd: SD, x: Sequence[torch.Tensor]) -> torch.Tensor:
     return conv(sd, "tail.2", pixel_shuffle2(conv(sd, "tail.0", u)))
 
 
-FORWARDS = {"ISPUNet_GFM_LSC": ispunet_gfm_lsc, "LiteISPNet": liteispnet, "LiteISPNet_GFM_LSC": liteispnet_gfm_lsc, "LiteISPNet_GFM_LSC_GMA": liteispnet_gfm_lsc_gma}
+ispunet_gfm_lsc = _strided_unet
+
+
+def _dwt_unet(sd: SD, x: Sequence[torch.Tensor], cond_from_raw: bool = False) -> torch.Tensor:
+    """The LiteISPNet family around _unet_trunk: LiteISPNet_LSC (models/LiteISP.py:1787-1805: head * (lsc + 1), no prior),
+    LiteISPNet_GFM (:1894-1920: prior + Res_GFM, no lens shading; 64 channels, cond_c 64), LiteISPNet_GFMresize (:2490-2520: as
+    _GFM but the colour prior reads the packed RAW x[0] itself)."""
+    raw = x[0]
+    h = conv(sd, "head", raw)
+    if "lsc.model.0.weight" in sd:
+        h = h * (lens_shading(sd, "lsc", x[2]) + 1)
+    v = None
+    if "classifier.model.0.weight" in sd:
+        v = color_condition_gfm(sd, "classifier", raw if cond_from_raw else x[1])
+    return _unet_trunk(sd, h, v)
+
+
+def liteispnet_gfmresize(sd: SD, x: Sequence[torch.Tensor]) -> torch.Tensor:
+    return _dwt_unet(sd, x, cond_from_raw=True)
+
+
+FORWARDS = {"ISPUNet_GFM_LSC": ispunet_gfm_lsc, "LiteISPNet": liteispnet, "LiteISPNet_GFM_LSC": liteispnet_gfm_lsc, "LiteISPNet_GFM_LSC_GMA": liteispnet_gfm_lsc_gma,
+            "ISPUNet_GFM": _strided_unet, "ISPUNet_LSC": _strided_unet, "ResUNet": _strided_unet,
+            "LiteISPNet_LSC": _dwt_unet, "LiteISPNet_GFM": _dwt_unet, "LiteISPNet_GFMresize": liteispnet_gfmresize}
 
 
 # ----------------------------------------------------------------------------------------------
@@ -307,9 +337,6 @@ def run_padded(name: str, sd: SD, raw: torch.Tensor, cond=None, coord=None, mult
     """Oracle forward with the reference padding convention (pad packed RAW (+coord) bottom/right
     with zeros to a multiple of `mult`, crop the output to 2x the original size)."""
     rp, hw = pad_to_multiple(raw, mult)
-    if name == "LiteISPNet":
-        out = liteispnet(sd, [rp])
-    else:
-        cp, _ = pad_to_multiple(coord, mult)
-        out = FORWARDS[name](sd, [rp, cond, cp])
+    cp = pad_to_multiple(coord, mult)[0] if coord is not None else None
+    out = FORWARDS[name](sd, [rp, cond, cp])
     return remove_padding(out, hw)

@@ -138,9 +138,44 @@ class Res_GFM(nn.Module):
 
 
 class _DwtUNet(nn.Module):
-    """Shared trunk of LiteISPNet / LiteISPNet_GFM_LSC (upstream LiteISP.py:2019-2032, 2397-2409)."""
+    """Shared trunk of the LiteISPNet family (upstream LiteISP.py:2019-2032, 2397-2409): Haar-DWT U-Net with RCAGroups; optional
+    colour prior + Res_GFM modulation in front of each encoder level, optional lens-shading gain on the head."""
 
     output_dtype: Optional[torch.dtype] = None  # None: same as the parameters (reference semantics)
+    cond_from_raw = False                       # LiteISPNet_GFMresize feeds the packed RAW itself to the colour prior
+
+    def _build(self, ch_1, ch_2, ch_3, cond_c=None, lsc=False, nf=None, n_blocks=4):
+        """Modules in the reference's construction order ([classifier], head, [lsc], [encoder_modulation i], down i, ..., tail),
+        so torch.manual_seed(0) reproduces the reference's seed-0 parameters.  nf: Res_GFM hidden widths per level."""
+        if cond_c is not None:
+            self.classifier = Color_Condition_GFM(in_channels=4, out_c=cond_c)
+        self.head = N.seq(N.conv(4, ch_1, mode='C'))
+        if lsc:
+            self.lsc = Lens_Shading_Correction(in_channels=2, out_c=ch_1, nf=ch_1)
+
+        def gfm(i, c):
+            if cond_c is not None:
+                setattr(self, f"encoder_modulation{i}", N.seq(Res_GFM(in_nc=c, chan=c, cond_c=cond_c, out_nc=c, nf=nf[i - 1])))
+
+        gfm(1, ch_1)
+        self.down1 = N.seq(N.conv(ch_1, ch_1, mode='C'), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
+                           N.conv(ch_1, ch_1, mode='C'), N.DWTForward(ch_1))
+        gfm(2, ch_1 * 4)
+        self.down2 = N.seq(N.conv(ch_1 * 4, ch_1, mode='C'), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
+                           N.DWTForward(ch_1))
+        gfm(3, ch_1 * 4)
+        self.down3 = N.seq(N.conv(ch_1 * 4, ch_2, mode='C'), N.RCAGroup(in_channels=ch_2, out_channels=ch_2, nb=n_blocks),
+                           N.DWTForward(ch_2))
+        gfm(4, ch_2 * 4)
+        self.middle = N.seq(N.conv(ch_2 * 4, ch_3, mode='C'), N.RCAGroup(in_channels=ch_3, out_channels=ch_3, nb=n_blocks),
+                            N.RCAGroup(in_channels=ch_3, out_channels=ch_3, nb=n_blocks), N.conv(ch_3, ch_2 * 4, mode='C'))
+        self.up3 = N.seq(N.DWTInverse(ch_2 * 4), N.RCAGroup(in_channels=ch_2, out_channels=ch_2, nb=n_blocks),
+                         N.conv(ch_2, ch_1 * 4, mode='C'))
+        self.up2 = N.seq(N.DWTInverse(ch_1 * 4), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
+                         N.conv(ch_1, ch_1 * 4, mode='C'))
+        self.up1 = N.seq(N.DWTInverse(ch_1 * 4), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
+                         N.conv(ch_1, ch_1, mode='C'))
+        self.tail = N.seq(N.conv(ch_1, ch_1 * 4, mode='C'), nn.PixelShuffle(upscale_factor=2), N.conv(ch_1, 3, mode='C'))
 
     def _act_dtype(self) -> torch.dtype:
         return self.head.weight.dtype
@@ -157,6 +192,15 @@ class _DwtUNet(nn.Module):
             raise ValueError(f"packed RAW H,W must be multiples of 8 (3 Haar levels), got {raw.shape[2]}x{raw.shape[3]}; "
                              "use forward_mosaic()/pad_to_multiple_of_16 for other sizes")
 
+    def _front(self, a, cond, coord_nhwc):
+        """head(raw) [* (lsc(coord) + 1)] and the colour-prior vector (None without a classifier)."""
+        if hasattr(self, "lsc"):
+            h = self.head._nhwc(a, mul_plus1=self.lsc._nhwc(coord_nhwc))           # h = head(raw) * (lsc + 1)
+        else:
+            h = self.head._nhwc(a)
+        vec = self.classifier._vec(ops._req(cond, "cond")) if hasattr(self, "classifier") else None
+        return h, vec
+
     def _trunk(self, h, vec, crop_hw=None):
         mod = (lambda i, t: getattr(self, f"encoder_modulation{i}")._nhwc((t, vec))[0]) if vec is not None else (lambda i, t: t)
         h = mod(1, h)
@@ -170,94 +214,23 @@ class _DwtUNet(nn.Module):
         t = self.tail[0]._nhwc(u1, out_mode=RC_OUT_PIXEL_SHUFFLE2)
         return self.tail[2]._nhwc(t, out_mode=RC_OUT_NCHW, crop_hw=crop_hw, out_dtype=self.output_dtype)
 
-
-class LiteISPNet(_DwtUNet):
-    """upstream LiteISP.py:2322-2412 (reads only x[0])."""
-
-    def __init__(self):
-        super().__init__()
-        ch_1, ch_2, ch_3, n_blocks = 64, 128, 128, 4
-        self.head = N.seq(N.conv(4, ch_1, mode='C'))
-        self.down1 = N.seq(N.conv(ch_1, ch_1, mode='C'), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
-                           N.conv(ch_1, ch_1, mode='C'), N.DWTForward(ch_1))
-        self.down2 = N.seq(N.conv(ch_1 * 4, ch_1, mode='C'), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
-                           N.DWTForward(ch_1))
-        self.down3 = N.seq(N.conv(ch_1 * 4, ch_2, mode='C'), N.RCAGroup(in_channels=ch_2, out_channels=ch_2, nb=n_blocks),
-                           N.DWTForward(ch_2))
-        self.middle = N.seq(N.conv(ch_2 * 4, ch_3, mode='C'), N.RCAGroup(in_channels=ch_3, out_channels=ch_3, nb=n_blocks),
-                            N.RCAGroup(in_channels=ch_3, out_channels=ch_3, nb=n_blocks), N.conv(ch_3, ch_2 * 4, mode='C'))
-        self.up3 = N.seq(N.DWTInverse(ch_2 * 4), N.RCAGroup(in_channels=ch_2, out_channels=ch_2, nb=n_blocks),
-                         N.conv(ch_2, ch_1 * 4, mode='C'))
-        self.up2 = N.seq(N.DWTInverse(ch_1 * 4), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
-                         N.conv(ch_1, ch_1 * 4, mode='C'))
-        self.up1 = N.seq(N.DWTInverse(ch_1 * 4), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
-                         N.conv(ch_1, ch_1, mode='C'))
-        self.tail = N.seq(N.conv(ch_1, ch_1 * 4, mode='C'), nn.PixelShuffle(upscale_factor=2), N.conv(ch_1, 3, mode='C'))
-
-    def forward(self, x):
+    def forward(self, x: Sequence[torch.Tensor]):
+        """x = [raw (B,4,H,W), cond (B,4,h,w), coord (B,2,H,W)] (nets without a prior / lens shading ignore those entries, as
+        upstream does) -> sRGB (B,3,2H,2W)."""
         raw = x if isinstance(x, torch.Tensor) else x[0]
         self._check(raw)
-        a = ops.to_nhwc(raw, dtype=self._act_dtype())
-        return self._trunk(self.head._nhwc(a), None)
-
-    def forward_mosaic(self, mosaic, cond=None, coord=None, pad_to: int = 16):
-        """Bayer mosaic (B,1,2h,2w) -> sRGB (B,3,2h,2w): unshuffle + zero-pad to `pad_to`, net, crop."""
-        if self.training:
-            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
-        a = ops.bayer_unshuffle(mosaic, dtype=self._act_dtype(), pad_to=pad_to)
-        return self._trunk(self.head._nhwc(a), None, crop_hw=(mosaic.shape[-2], mosaic.shape[-1]))
-
-
-class LiteISPNet_GFM_LSC(_DwtUNet):
-    """upstream LiteISP.py:1924-2035 -- the net the reference's __main__ builds."""
-
-    def __init__(self):
-        super().__init__()
-        ch_1, ch_2, ch_3, n_blocks, cond_c = 48, 128, 128, 4, 32
-        self.classifier = Color_Condition_GFM(in_channels=4, out_c=cond_c)
-        modulation_blocks = 1
-        self.head = N.seq(N.conv(4, ch_1, mode='C'))
-        self.lsc = Lens_Shading_Correction(in_channels=2, out_c=ch_1, nf=ch_1)
-        self.encoder_modulation1 = N.seq(*[Res_GFM(in_nc=ch_1, chan=ch_1, cond_c=cond_c, out_nc=ch_1, nf=ch_1)
-                                           for _ in range(modulation_blocks)])
-        self.down1 = N.seq(N.conv(ch_1, ch_1, mode='C'), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
-                           N.conv(ch_1, ch_1, mode='C'), N.DWTForward(ch_1))
-        self.encoder_modulation2 = N.seq(*[Res_GFM(in_nc=ch_1 * 4, chan=ch_1 * 4, cond_c=cond_c, out_nc=ch_1 * 4, nf=ch_1)
-                                           for _ in range(modulation_blocks)])
-        self.down2 = N.seq(N.conv(ch_1 * 4, ch_1, mode='C'), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
-                           N.DWTForward(ch_1))
-        self.encoder_modulation3 = N.seq(*[Res_GFM(in_nc=ch_1 * 4, chan=ch_1 * 4, cond_c=cond_c, out_nc=ch_1 * 4, nf=ch_1)
-                                           for _ in range(modulation_blocks)])
-        self.down3 = N.seq(N.conv(ch_1 * 4, ch_2, mode='C'), N.RCAGroup(in_channels=ch_2, out_channels=ch_2, nb=n_blocks),
-                           N.DWTForward(ch_2))
-        self.encoder_modulation4 = N.seq(*[Res_GFM(in_nc=ch_2 * 4, chan=ch_2 * 4, cond_c=cond_c, out_nc=ch_2 * 4, nf=ch_2)
-                                           for _ in range(modulation_blocks)])
-        self.middle = N.seq(N.conv(ch_2 * 4, ch_3, mode='C'), N.RCAGroup(in_channels=ch_3, out_channels=ch_3, nb=n_blocks),
-                            N.RCAGroup(in_channels=ch_3, out_channels=ch_3, nb=n_blocks), N.conv(ch_3, ch_2 * 4, mode='C'))
-        self.up3 = N.seq(N.DWTInverse(ch_2 * 4), N.RCAGroup(in_channels=ch_2, out_channels=ch_2, nb=n_blocks),
-                         N.conv(ch_2, ch_1 * 4, mode='C'))
-        self.up2 = N.seq(N.DWTInverse(ch_1 * 4), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
-                         N.conv(ch_1, ch_1 * 4, mode='C'))
-        self.up1 = N.seq(N.DWTInverse(ch_1 * 4), N.RCAGroup(in_channels=ch_1, out_channels=ch_1, nb=n_blocks),
-                         N.conv(ch_1, ch_1, mode='C'))
-        self.tail = N.seq(N.conv(ch_1, ch_1 * 4, mode='C'), nn.PixelShuffle(upscale_factor=2), N.conv(ch_1, 3, mode='C'))
-
-    def _front(self, a, cond, coord_nhwc):
-        lsc = self.lsc._nhwc(coord_nhwc)
-        h = self.head._nhwc(a, mul_plus1=lsc)           # h = head(raw) * (lsc + 1)
-        vec = self.classifier._vec(ops._req(cond, "cond"))
-        return h, vec
-
-    def forward(self, x: Sequence[torch.Tensor]):
-        raw, cond, coord = x[0], x[1], x[2]
-        self._check(raw)
-        if coord.shape[0] != raw.shape[0] or coord.shape[1] != 2 or coord.shape[2:] != raw.shape[2:]:
-            raise ValueError(f"coord must be (B,2,H,W) matching raw, got {tuple(coord.shape)}")
         dt = self._act_dtype()
-        h, vec = self._front(ops.to_nhwc(raw, dtype=dt), cond, ops.to_nhwc(coord, dtype=dt))
+        coord_nhwc = None
+        if hasattr(self, "lsc"):
+            coord = x[2]
+            if coord.shape[0] != raw.shape[0] or coord.shape[1] != 2 or coord.shape[2:] != raw.shape[2:]:
+                raise ValueError(f"coord must be (B,2,H,W) matching raw, got {tuple(coord.shape)}")
+            coord_nhwc = ops.to_nhwc(coord, dtype=dt)
+        cond = (raw if self.cond_from_raw else x[1]) if hasattr(self, "classifier") else None
+        h, vec = self._front(ops.to_nhwc(raw, dtype=dt), cond, coord_nhwc)
         return self._trunk(h, vec)
 
-    def forward_mosaic(self, mosaic, cond, coord, pad_to: int = 16):
+    def forward_mosaic(self, mosaic, cond=None, coord=None, pad_to: int = 16):
         """Bayer mosaic (B,1,2h,2w), cond (B,4,hc,wc), coord (B,2,h,w) -> sRGB (B,3,2h,2w).
         RAW and coord are zero-padded bottom/right to a multiple of `pad_to` (reference convention,
         upstream LiteISP.py:84-105) and the output is cropped back."""
@@ -266,107 +239,194 @@ class LiteISPNet_GFM_LSC(_DwtUNet):
         dt = self._act_dtype()
         a = ops.bayer_unshuffle(mosaic, dtype=dt, pad_to=pad_to)
         b, hp, wp, _ = a.shape
-        if coord.shape[-2:] != (mosaic.shape[-2] // 2, mosaic.shape[-1] // 2):
-            raise ValueError("coord must be at packed resolution (h, w)")
-        co = ops.to_nhwc(coord, dtype=dt, pad_hw=(hp, wp))
+        co = None
+        if hasattr(self, "lsc"):
+            if coord is None or coord.shape[-2:] != (mosaic.shape[-2] // 2, mosaic.shape[-1] // 2):
+                raise ValueError("coord must be at packed resolution (h, w)")
+            co = ops.to_nhwc(coord, dtype=dt, pad_hw=(hp, wp))
+        if hasattr(self, "classifier") and self.cond_from_raw:
+            cond = ops.to_nchw(a)                             # the padded packed RAW, as upstream's x[0]
         h, vec = self._front(a, cond, co)
         return self._trunk(h, vec, crop_hw=(mosaic.shape[-2], mosaic.shape[-1]))
 
 
-class ISPUNet_GFM_LSC(nn.Module):
-    """upstream LiteISP.py:1228-1380: the strided U-Net sibling of LiteISPNet_GFM_LSC -- widths
-    chan, 2chan, 4chan, 8chan; Conv2d(c, 2c, 2, 2) down-samplers; Conv1x1(c, 2c, bias=False) + PixelShuffle(2)
-    up-samplers; m_blocks Res_GFM per level on the way down AND up; RCAGroups of 2 (middle: 4) blocks.
-    Same constructor signature, attribute names and construction order as upstream, so the seed-0 parameters and the
-    state_dict keys are identical."""
+class LiteISPNet(_DwtUNet):
+    """upstream LiteISP.py:2322-2412 (reads only x[0])."""
+
+    def __init__(self):
+        super().__init__()
+        self._build(64, 128, 128)
+
+
+class LiteISPNet_GFM_LSC(_DwtUNet):
+    """upstream LiteISP.py:1924-2035 -- the net the reference's __main__ builds."""
+
+    def __init__(self):
+        super().__init__()
+        self._build(48, 128, 128, cond_c=32, lsc=True, nf=(48, 48, 48, 128))
+
+
+class LiteISPNet_LSC(_DwtUNet):
+    """upstream LiteISP.py:1710-1805: the 48-channel trunk with the lens-shading gain only (x[1] is ignored)."""
+
+    def __init__(self):
+        super().__init__()
+        self._build(48, 128, 128, lsc=True)
+
+
+class LiteISPNet_GFM(_DwtUNet):
+    """upstream LiteISP.py:1809-1920: 64-channel trunk, colour prior (cond_c = 64) + Res_GFM modulation, no lens shading."""
+
+    def __init__(self):
+        super().__init__()
+        self._build(64, 128, 128, cond_c=64, nf=(64, 64, 64, 128))
+
+
+class LiteISPNet_GFMresize(_DwtUNet):
+    """upstream LiteISP.py:2414-2520: as LiteISPNet_GFM with cond_c = 32, wider GFM MLPs, and the colour prior reading the packed
+    RAW x[0] itself (:2496)."""
+    cond_from_raw = True
+
+    def __init__(self):
+        super().__init__()
+        self._build(64, 128, 128, cond_c=32, nf=(128, 256, 256, 512))
+
+
+class _StridedUNet(nn.Module):
+    """Shared body of the ISPUNet / ResUNet family (upstream LiteISP.py:963-1380, 2038-2146): widths chan,
+    2chan, 4chan, 8chan; Conv2d(c, 2c, 2, 2) down-samplers; Conv1x1(c, 2c, bias=False) + PixelShuffle(2) up-samplers; RCAGroups of
+    2 (middle: 4) blocks; optionally m_blocks Res_GFM per level on the way down AND up and the lens-shading gain on the intro.
+    Modules are created in the reference's order ([classifier], intro, [lsc], [encoder_modulation1], encoder1, down1, ...), so the
+    seed-0 parameters and the state_dict keys are identical."""
 
     output_dtype: Optional[torch.dtype] = None
 
-    def __init__(self, cond_c=32, chan=32, m_blocks=2):
-        super().__init__()
-        self.classifier = Color_Condition_GFM(in_channels=4, out_c=cond_c)
+    def _build(self, chan=32, cond_c=None, lsc=False, m_blocks=2):
         n_blocks = 2
+        if cond_c is not None:
+            self.classifier = Color_Condition_GFM(in_channels=4, out_c=cond_c)
 
-        def gfm(c):
-            return N.seq(*[Res_GFM(in_nc=c, chan=c, cond_c=cond_c, out_nc=c, nf=c * 2) for _ in range(m_blocks)])
+        def gfm(name, c):
+            if cond_c is not None:
+                setattr(self, name, N.seq(*[Res_GFM(in_nc=c, chan=c, cond_c=cond_c, out_nc=c, nf=c * 2) for _ in range(m_blocks)]))
 
         def lrelu():
             return nn.LeakyReLU(negative_slope=1e-1, inplace=True)
 
         self.intro = N.seq(N.Conv2d(4, chan, 3, 1, 1))
-        self.lsc = Lens_Shading_Correction(in_channels=2, out_c=chan, nf=chan)
-        self.encoder_modulation1 = gfm(chan)
+        if lsc:
+            self.lsc = Lens_Shading_Correction(in_channels=2, out_c=chan, nf=chan)
+        gfm("encoder_modulation1", chan)
         self.encoder1 = N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.Conv2d(chan, chan, 3, 1, 1), lrelu())
         self.down1 = N.Conv2d(chan, chan * 2, 2, 2)
         chan = chan * 2
-        self.encoder_modulation2 = gfm(chan)
+        gfm("encoder_modulation2", chan)
         self.encoder2 = N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.Conv2d(chan, chan, 3, 1, 1), lrelu())
         self.down2 = N.Conv2d(chan, chan * 2, 2, 2)
         chan = chan * 2
-        self.encoder_modulation3 = gfm(chan)
+        gfm("encoder_modulation3", chan)
         self.encoder3 = N.seq(N.Conv2d(chan, chan, 3, 1, 1), N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks),
                               N.Conv2d(chan, chan, 3, 1, 1), lrelu())
         self.down3 = N.Conv2d(chan, chan * 2, 2, 2)
         chan = chan * 2
-        self.middle_modulation = gfm(chan)
+        gfm("middle_modulation", chan)
         self.middle = N.seq(N.Conv2d(chan, chan, 3, 1, 1), N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks * 2),
                             N.Conv2d(chan, chan, 3, 1, 1))
-        self.up3 = N.seq(N.Conv2d(chan, chan * 2, 1, bias=False), nn.PixelShuffle(2))
-        chan = chan // 2
-        self.decoder_modulation3 = gfm(chan)
-        self.decoder3 = N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.conv(chan, chan, mode='C'))
-        self.up2 = N.seq(N.Conv2d(chan, chan * 2, 1, bias=False), nn.PixelShuffle(2))
-        chan = chan // 2
-        self.decoder_modulation2 = gfm(chan)
-        self.decoder2 = N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.conv(chan, chan, mode='C'))
-        self.up1 = N.seq(N.Conv2d(chan, chan * 2, 1, bias=False), nn.PixelShuffle(2))
-        chan = chan // 2
-        self.decoder_modulation1 = gfm(chan)
-        self.decoder1 = N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.conv(chan, chan, mode='C'))
+        for i in (3, 2, 1):
+            setattr(self, f"up{i}", N.seq(N.Conv2d(chan, chan * 2, 1, bias=False), nn.PixelShuffle(2)))
+            chan = chan // 2
+            gfm(f"decoder_modulation{i}", chan)
+            setattr(self, f"decoder{i}", N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.conv(chan, chan, mode='C')))
         self.tail = N.seq(N.conv(chan, chan * 4, mode='C'), nn.PixelShuffle(upscale_factor=2), N.conv(chan, 3, mode='C'))
 
     def _act_dtype(self) -> torch.dtype:
         return self.intro.weight.dtype
 
     def _run(self, a, cond, coord_nhwc, crop_hw=None):
-        lsc = self.lsc._nhwc(coord_nhwc)
-        intro = self.intro._nhwc(a, mul_plus1=lsc)                       # intro(raw) * (lsc + 1)
-        vec = self.classifier._vec(ops._req(cond, "cond"))
+        if hasattr(self, "lsc"):
+            intro = self.intro._nhwc(a, mul_plus1=self.lsc._nhwc(coord_nhwc))    # intro(raw) * (lsc + 1)
+        else:
+            intro = self.intro._nhwc(a)
+        has_gfm = hasattr(self, "classifier")
+        vec = self.classifier._vec(ops._req(cond, "cond")) if has_gfm else None
 
-        def gfm(seq_, t):
-            return seq_._nhwc((t, vec))[0]
+        def gfm(name, t):
+            return getattr(self, name)._nhwc((t, vec))[0] if has_gfm else t
 
-        d1 = self.down1._nhwc(self.encoder1._nhwc(gfm(self.encoder_modulation1, intro)))
-        d2 = self.down2._nhwc(self.encoder2._nhwc(gfm(self.encoder_modulation2, d1)))
-        d3 = self.down3._nhwc(self.encoder3._nhwc(gfm(self.encoder_modulation3, d2)))
-        m = self.middle._nhwc(gfm(self.middle_modulation, d3), residual=d3)
-        u3 = ops.add(gfm(self.decoder_modulation3, self.decoder3._nhwc(self.up3._nhwc(m))), d2)
-        u2 = ops.add(gfm(self.decoder_modulation2, self.decoder2._nhwc(self.up2._nhwc(u3))), d1)
-        u1 = ops.add(gfm(self.decoder_modulation1, self.decoder1._nhwc(self.up1._nhwc(u2))), intro)
+        def dec(i, t, skip):
+            t = getattr(self, f"up{i}")._nhwc(t)
+            if has_gfm:
+                return ops.add(gfm(f"decoder_modulation{i}", getattr(self, f"decoder{i}")._nhwc(t)), skip)
+            return getattr(self, f"decoder{i}")._nhwc(t, residual=skip)            # decoder's last conv takes the skip add
+
+        d1 = self.down1._nhwc(self.encoder1._nhwc(gfm("encoder_modulation1", intro)))
+        d2 = self.down2._nhwc(self.encoder2._nhwc(gfm("encoder_modulation2", d1)))
+        d3 = self.down3._nhwc(self.encoder3._nhwc(gfm("encoder_modulation3", d2)))
+        m = self.middle._nhwc(gfm("middle_modulation", d3), residual=d3)
+        u1 = dec(1, dec(2, dec(3, m, d2), d1), intro)
         t = self.tail[0]._nhwc(u1, out_mode=RC_OUT_PIXEL_SHUFFLE2)
         return self.tail[2]._nhwc(t, out_mode=RC_OUT_NCHW, crop_hw=crop_hw, out_dtype=self.output_dtype)
 
     def forward(self, x: Sequence[torch.Tensor]):
-        raw, cond, coord = x[0], x[1], x[2]
+        raw = x if isinstance(x, torch.Tensor) else x[0]
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
         if raw.dim() != 4 or raw.shape[1] != 4 or raw.shape[2] % 8 or raw.shape[3] % 8:
             raise ValueError(f"raw must be (B,4,H,W) with H,W multiples of 8 (three stride-2 levels), got {tuple(raw.shape)}")
-        if coord.shape[0] != raw.shape[0] or coord.shape[1] != 2 or coord.shape[2:] != raw.shape[2:]:
-            raise ValueError(f"coord must be (B,2,H,W) matching raw, got {tuple(coord.shape)}")
         dt = self._act_dtype()
-        return self._run(ops.to_nhwc(raw, dtype=dt), cond, ops.to_nhwc(coord, dtype=dt))
+        co = None
+        if hasattr(self, "lsc"):
+            coord = x[2]
+            if coord.shape[0] != raw.shape[0] or coord.shape[1] != 2 or coord.shape[2:] != raw.shape[2:]:
+                raise ValueError(f"coord must be (B,2,H,W) matching raw, got {tuple(coord.shape)}")
+            co = ops.to_nhwc(coord, dtype=dt)
+        return self._run(ops.to_nhwc(raw, dtype=dt), x[1] if hasattr(self, "classifier") else None, co)
 
-    def forward_mosaic(self, mosaic, cond, coord, pad_to: int = 16):
+    def forward_mosaic(self, mosaic, cond=None, coord=None, pad_to: int = 16):
         """Bayer mosaic (B,1,2h,2w), cond, coord (B,2,h,w) -> sRGB (B,3,2h,2w) with the unshuffle / pad16 / crop front end."""
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
         dt = self._act_dtype()
         a = ops.bayer_unshuffle(mosaic, dtype=dt, pad_to=pad_to)
         b, hp, wp, _ = a.shape
-        if coord.shape[-2:] != (mosaic.shape[-2] // 2, mosaic.shape[-1] // 2):
-            raise ValueError("coord must be at packed resolution (h, w)")
-        return self._run(a, cond, ops.to_nhwc(coord, dtype=dt, pad_hw=(hp, wp)), crop_hw=(mosaic.shape[-2], mosaic.shape[-1]))
+        co = None
+        if hasattr(self, "lsc"):
+            if coord is None or coord.shape[-2:] != (mosaic.shape[-2] // 2, mosaic.shape[-1] // 2):
+                raise ValueError("coord must be at packed resolution (h, w)")
+            co = ops.to_nhwc(coord, dtype=dt, pad_hw=(hp, wp))
+        return self._run(a, cond, co, crop_hw=(mosaic.shape[-2], mosaic.shape[-1]))
+
+
+class ISPUNet_GFM_LSC(_StridedUNet):
+    """upstream LiteISP.py:1228-1380: colour prior + Res_GFM on both sides + lens shading."""
+
+    def __init__(self, cond_c=32, chan=32, m_blocks=2):
+        super().__init__()
+        self._build(chan=chan, cond_c=cond_c, lsc=True, m_blocks=m_blocks)
+
+
+class ISPUNet_GFM(_StridedUNet):
+    """upstream LiteISP.py:963-1110: ISPUNet_GFM_LSC without the lens-shading branch (x[2] is ignored)."""
+
+    def __init__(self):
+        super().__init__()
+        self._build(chan=32, cond_c=32, lsc=False, m_blocks=2)
+
+
+class ISPUNet_LSC(_StridedUNet):
+    """upstream LiteISP.py:1113-1225: the strided U-Net with the lens-shading gain only (x[1] is ignored)."""
+
+    def __init__(self):
+        super().__init__()
+        self._build(chan=32, cond_c=None, lsc=True)
+
+
+class ResUNet(_StridedUNet):
+    """upstream LiteISP.py:2038-2146: the bare strided U-Net (reads only x[0])."""
+
+    def __init__(self):
+        super().__init__()
+        self._build(chan=32)
 
 
 class LiteISPNet_GFM_LSC_GMA(LiteISPNet_GFM_LSC):

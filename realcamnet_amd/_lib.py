@@ -14,10 +14,10 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["RC_HIP_LIB"]) if os.environ.get("RC_HIP_LIB") else PKG / "librealcam_hip.so"   # override: kernel experiments only
 HEADER = PKG.parent / "include" / "realcam_hip.h"
 
-RC_F32, RC_BF16 = 0, 1
+RC_F32, RC_BF16, RC_U16 = 0, 1, 2
 RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY, RC_ACT_GELU, RC_ACT_RELU_POST = 0, 1, 2, 3, 4
 RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ConvDesc(C.Structure):
@@ -65,6 +65,7 @@ _SIGS = {
     "rc_build_info": (C.c_char_p, []),
     "rc_device_arch": (C.c_int, [C.c_char_p, _SZ]),
     "rc_bayer_unshuffle": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "rc_raw_ingest": (C.c_int, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "rc_nchw_to_nhwc": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "rc_nhwc_to_nchw": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "rc_conv_packed_bytes": (_SZ, [_I, _I, _I, _I, _I]),
@@ -96,6 +97,8 @@ _SIGS = {
     "rc_conv_pair_desc_size": (_SZ, []),
     "rc_ca_gate": (C.c_int, [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "rc_gate_residual": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "rc_channel_sums_slots": (C.c_int, [_I]),
+    "rc_channel_sums": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
     "rc_dwt_forward": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rc_dwt_inverse": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rc_color_block": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -197,11 +197,70 @@ __global__ __launch_bounds__(256) void gfm_vector_kernel(const float* __restrict
     }
 }
 
+
+// ---- per-channel partial sums of an NHWC map (standalone CALayer / AdaptiveAvgPool2d(1), networks.py:259,268) ----
+// Block (slot, b) folds pixels [slot*L, (slot+1)*L) of image b: thread = (channel vector v, part p), parts are combined
+// through LDS in a fixed order, so the result is run-to-run bitwise stable.  Output (B, n_slots, C) feeds rc_ca_gate.
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sums_kernel(const T* __restrict__ x, float* __restrict__ sums, int n_pix, int c, int L) {
+    constexpr int U = Vec16<T>::N;
+    extern __shared__ float cs_part[];                   // [parts][c]
+    const int vpp = c / U, parts = 256 / vpp;
+    const int slot = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int v = tid % vpp, p = tid / vpp;
+    const int p0 = slot * L, p1 = (p0 + L) < n_pix ? (p0 + L) : n_pix;
+    float acc[U];
+#pragma unroll
+    for (int e = 0; e < U; ++e) acc[e] = 0.f;
+    if (p < parts) {
+        const T* base = x + (size_t)b * n_pix * c + v * U;
+        for (int i = p0 + p; i < p1; i += parts) {
+            float f[U];
+            Vec16<T>::unpack(*reinterpret_cast<const uint4*>(base + (size_t)i * c), f);
+#pragma unroll
+            for (int e = 0; e < U; ++e) acc[e] += f[e];
+        }
+#pragma unroll
+        for (int e = 0; e < U; ++e) cs_part[p * c + v * U + e] = acc[e];
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += 256) {
+        float tot = 0.f;
+        for (int q = 0; q < parts; ++q) tot += cs_part[q * c + ch];
+        sums[((size_t)b * gridDim.x + slot) * c + ch] = tot;
+    }
+}
+
 }  // namespace rc
 
 using namespace rc;
 
 extern "C" {
+
+int rc_channel_sums_slots(int n_pix) {
+    int s = (n_pix + 4095) / 4096;          // >= 4096 pixels per slot, at most 256 slots per image
+    return s < 1 ? 1 : (s > 256 ? 256 : s);
+}
+
+int rc_channel_sums(const void* d_x, int dtype, int batch, int n_pix, int c, float* d_sums, void* stream) {
+    RC_REQUIRE(d_x && d_sums, "rc_channel_sums: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_channel_sums: bad dtype");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    RC_REQUIRE(batch >= 1 && batch <= 65535 && n_pix >= 1 && c >= U && c % U == 0 && c / U <= 256,
+               "rc_channel_sums: C must be a multiple of 16 bytes, at most 256 vectors");
+    const int slots = rc_channel_sums_slots(n_pix);
+    const int L = ceil_div(n_pix, slots);
+    const size_t lds = (size_t)(256 / (c / U)) * c * sizeof(float);
+    RC_REQUIRE(lds <= 64 * 1024, "rc_channel_sums: too many channels");
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(channel_sums_kernel<float>, dim3(slots, batch), dim3(256), lds, as_stream(stream),
+                           static_cast<const float*>(d_x), d_sums, n_pix, c, L);
+    else
+        hipLaunchKernelGGL(channel_sums_kernel<bf16_t>, dim3(slots, batch), dim3(256), lds, as_stream(stream),
+                           static_cast<const bf16_t*>(d_x), d_sums, n_pix, c, L);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
 
 int rc_ca_gate(float* d_sums, int batch, int n_tiles, int c, int cr, float inv_hw,
                const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,

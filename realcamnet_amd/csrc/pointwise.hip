@@ -43,6 +43,64 @@ __global__ void bayer_unshuffle_kernel(const TI* __restrict__ mosaic, TO* __rest
     }
 }
 
+// ---- RAW ingest: black/white-level normalisation + Bayer unshuffle + pad, and the bilinear "Resize" of the packed RAW
+// to the colour-prior's cond image, one launch (the two boxes in front of the net in
+// assets/networkarch.png).  Items [0, B*hp*wp): one packed pixel each (as bayer_unshuffle_kernel);
+// items [B*hp*wp, + B*ch*cw): one cond pixel each, all 4 planes: F.interpolate(mode='bilinear', align_corners=False)
+// semantics (src = scale*(dst+0.5)-0.5 clamped at 0, second tap clamped to the last row/column), read straight from
+// the mosaic (packed channel 2i+j at (y,x) = mosaic (2y+i, 2x+j)) and normalised before interpolation.
+template <typename TI, typename TO>
+__global__ void raw_ingest_kernel(const TI* __restrict__ mosaic, TO* __restrict__ packed, TO* __restrict__ cond,
+                                  int batch, int h, int w, int hp, int wp, int ch, int cw, float black, float inv_range,
+                                  float scale_y, float scale_x) {
+    const size_t n_packed = (size_t)batch * hp * wp, n_cond = (size_t)batch * ch * cw;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_packed + n_cond; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < n_packed) {
+            const int x = (int)(i % wp);
+            const int y = (int)((i / wp) % hp);
+            const int b = (int)(i / ((size_t)wp * hp));
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (y < h && x < w) {
+                const TI* r0 = mosaic + ((size_t)b * 2 * h + 2 * y) * (2 * (size_t)w) + 2 * x;
+                const TI* r1 = r0 + 2 * (size_t)w;
+                v[0] = (to_f32(r0[0]) - black) * inv_range; v[1] = (to_f32(r0[1]) - black) * inv_range;
+                v[2] = (to_f32(r1[0]) - black) * inv_range; v[3] = (to_f32(r1[1]) - black) * inv_range;
+            }
+            TO* o = packed + i * 4;
+            if constexpr (sizeof(TO) == 4) {
+                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 p;
+                p.x = Vec16<bf16_t>::rne2(v[0], v[1]);
+                p.y = Vec16<bf16_t>::rne2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(o) = p;
+            }
+        } else {
+            const size_t j = i - n_packed;
+            const int ox = (int)(j % cw);
+            const int oy = (int)((j / cw) % ch);
+            const int b = (int)(j / ((size_t)cw * ch));
+            float sy = scale_y * ((float)oy + 0.5f) - 0.5f; sy = sy < 0.f ? 0.f : sy;
+            float sx = scale_x * ((float)ox + 0.5f) - 0.5f; sx = sx < 0.f ? 0.f : sx;
+            int y0 = (int)sy, x0 = (int)sx;
+            y0 = y0 < h - 1 ? y0 : h - 1; x0 = x0 < w - 1 ? x0 : w - 1;
+            const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+            const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+            const TI* img = mosaic + (size_t)b * 4 * h * w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int di = k >> 1, dj = k & 1;
+                const float v00 = (to_f32(img[(size_t)(2 * y0 + di) * 2 * w + 2 * x0 + dj]) - black) * inv_range;
+                const float v01 = (to_f32(img[(size_t)(2 * y0 + di) * 2 * w + 2 * x1 + dj]) - black) * inv_range;
+                const float v10 = (to_f32(img[(size_t)(2 * y1 + di) * 2 * w + 2 * x0 + dj]) - black) * inv_range;
+                const float v11 = (to_f32(img[(size_t)(2 * y1 + di) * 2 * w + 2 * x1 + dj]) - black) * inv_range;
+                const float r = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+                cond[(((size_t)b * 4 + k) * ch + oy) * cw + ox] = from_f32<TO>(r);
+            }
+        }
+    }
+}
+
 // ---- NCHW -> NHWC for C <= 4 (the coordinate map, packed RAW): one thread per output pixel, plane reads and the
 // pixel-record writes are both coalesced; the 32x32 transpose tile below would launch a block per 32 pixels
 template <typename TI, typename TO>
@@ -106,7 +164,7 @@ __global__ void nhwc_to_nchw_kernel(const TI* __restrict__ src, TO* __restrict__
     }
 }
 
-// ---- y = r*gate[b][c] + x ---------------------------------------------------------------------------
+// ---- y = r*gate[b][c] + x   (x == NULL: y = r*gate, the standalone CALayer scale) --------------------
 template <typename T>
 __global__ void gate_residual_kernel(const T* __restrict__ r, const float* __restrict__ gate,
                                      const T* __restrict__ x, T* __restrict__ y,
@@ -119,7 +177,12 @@ __global__ void gate_residual_kernel(const T* __restrict__ r, const float* __res
         const int b = (int)(i / ((size_t)vpp * n_pix));
         float fr[U], fx[U];
         Vec16<T>::unpack(reinterpret_cast<const uint4*>(r)[i], fr);
-        Vec16<T>::unpack(reinterpret_cast<const uint4*>(x)[i], fx);
+        if (x) {
+            Vec16<T>::unpack(reinterpret_cast<const uint4*>(x)[i], fx);
+        } else {
+#pragma unroll
+            for (int e = 0; e < U; ++e) fx[e] = 0.f;
+        }
         const float* g = gate + (size_t)b * c + v * U;
 #pragma unroll
         for (int e = 0; e < U; ++e) fr[e] = fr[e] * g[e] + fx[e];
@@ -418,6 +481,29 @@ int rc_bayer_unshuffle(const void* d_mosaic, int in_dtype, void* d_packed, int o
     return RC_OK;
 }
 
+int rc_raw_ingest(const void* d_mosaic, int in_dtype, void* d_packed, void* d_cond, int out_dtype, int batch, int h, int w,
+                  int hp, int wp, int cond_h, int cond_w, float black_level, float white_level, void* stream) {
+    RC_REQUIRE(d_mosaic && d_packed && d_cond, "rc_raw_ingest: null pointer");
+    RC_REQUIRE(batch >= 1 && h >= 1 && w >= 1 && hp >= h && wp >= w && cond_h >= 1 && cond_w >= 1, "rc_raw_ingest: bad shape");
+    RC_REQUIRE(white_level > black_level, "rc_raw_ingest: white_level must exceed black_level");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_packed) % 16 == 0, "rc_raw_ingest: packed must be 16-byte aligned");
+    const size_t total = (size_t)batch * hp * wp + (size_t)batch * cond_h * cond_w;
+    const float inv = 1.f / (white_level - black_level);
+    const float sy = (float)h / (float)cond_h, sx = (float)w / (float)cond_w;
+#define CALL(TI, TO)                                                                                                        \
+    hipLaunchKernelGGL((raw_ingest_kernel<TI, TO>), dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),          \
+                       static_cast<const TI*>(d_mosaic), static_cast<TO*>(d_packed), static_cast<TO*>(d_cond), batch, h, w, \
+                       hp, wp, cond_h, cond_w, black_level, inv, sy, sx)
+    if (in_dtype == RC_U16) {
+        if (out_dtype == RC_F32) { CALL(uint16_t, float); } else if (out_dtype == RC_BF16) { CALL(uint16_t, bf16_t); } else return fail(RC_ERR_INVALID, "bad dtype");
+    } else {
+        RC_DISPATCH_2(in_dtype, out_dtype, CALL);
+    }
+#undef CALL
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
 int rc_nchw_to_nhwc(const void* d_src, int src_dtype, void* d_dst, int dst_dtype,
                     int batch, int c, int h, int w, int hp, int wp, void* stream) {
     RC_REQUIRE(d_src && d_dst, "rc_nchw_to_nhwc: null pointer");
@@ -460,7 +546,7 @@ int rc_nhwc_to_nchw(const void* d_src, int src_dtype, void* d_dst, int dst_dtype
 
 int rc_gate_residual(const void* d_r, const float* d_gate, const void* d_x, void* d_y, int dtype,
                      int batch, int n_pix, int c, void* stream) {
-    RC_REQUIRE(d_r && d_gate && d_x && d_y, "rc_gate_residual: null pointer");
+    RC_REQUIRE(d_r && d_gate && d_y, "rc_gate_residual: null pointer");
     const int U = dtype == RC_F32 ? 4 : 8;
     RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_gate_residual: bad dtype");
     RC_REQUIRE(batch >= 1 && n_pix >= 1 && c >= U && c % U == 0, "rc_gate_residual: c must be a multiple of 16 bytes");

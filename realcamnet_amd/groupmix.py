@@ -9,13 +9,10 @@ Dropout / DropPath are identities.
 """
 from __future__ import annotations
 
-import ctypes as C
-
 import torch
 import torch.nn as nn
 
 from . import ops
-from .ops import check, lib
 
 
 class Mlp(nn.Module):
@@ -102,8 +99,7 @@ class Aggregator(nn.Module):
             return torch.cat(cols, dim=1).contiguous(), kv
         wT, kvec = ops.host_cached(self, f"taps7_{dt}", [self.agg1.conv1.weight, self.agg2.conv1.weight, self.agg3.conv1.weight,
                                                        self.agg0.conv.conv1.weight], taps)
-        dwc = torch.empty((b, H, W, 3, 4 * seg), dtype=dt, device=dev)
-        ops.dwconv2d(qkv, seg, dwc, 0, 4 * seg, 7, wT, n_rep=3, x_rep=c, y_rep=4 * seg, w_rep=4 * seg, kvec=kvec)
+        dwc = ops.dwconv2d(qkv, seg, (3, 4 * seg), 0, 4 * seg, 7, wT, n_rep=3, x_rep=c, y_rep=4 * seg, w_rep=4 * seg, kvec=kvec)
 
         def fold(*p):   # BatchNorm(eval) -> per-channel scale / shift; point-wise weights as dense matrices
             bn = [p[4 * i:4 * i + 4] for i in range(4)]
@@ -120,15 +116,8 @@ class Aggregator(nn.Module):
             if abs(n.eps - 1e-5) > 0:
                 raise NotImplementedError("Aggregator: BatchNorm eps must be the default 1e-5")
         scale, shift, pw, pwl = ops.host_cached(self, "fold", params, fold)
-        qkvp = torch.empty((b, H, W, 3, 4 * seg), dtype=dt, device=dev)
-        loc = torch.empty((b, H, W, seg), dtype=dt, device=dev)
         ln = self.agg0.norm
-        es = qkv.element_size()
-        check(lib().rc_gma_pointwise(qkv.data_ptr(), dwc.data_ptr(), dwc.data_ptr() + 3 * seg * es, 12 * seg, 4 * seg, 12 * seg, 4 * seg,
-                                     qkvp.data_ptr(), loc.data_ptr(), ops._dt(qkv),
-                                     b * H * W, c, pw.data_ptr(), scale.data_ptr(), shift.data_ptr(), pwl.data_ptr(),
-                                     ops.f32_param(ln, "weight").data_ptr(), ops.f32_param(ln, "bias").data_ptr(), ops._stream()),
-              "rc_gma_pointwise")
+        qkvp, loc = torch.ops.realcam.gma_pointwise(qkv, dwc, pw, scale, shift, pwl, ops.f32_param(ln, "weight"), ops.f32_param(ln, "bias"))
         return qkvp, loc
 
 
@@ -169,9 +158,7 @@ class ConvRelPosEnc(nn.Module):
             return taps, torch.cat([p[2 * i + 1] for i in range(len(self.conv_list))]), kvec.to(torch.int32)
 
         wT, bias, kvec = ops.host_cached(self, f"taps7_{unit}", params, build)
-        convv = torch.empty((b, H, W, ct), dtype=qkvp.dtype, device=qkvp.device)
-        ops.dwconv2d(qkvp, 2 * ct, convv, 0, ct, 7, wT, bias=bias, kvec=kvec)
-        return convv
+        return ops.dwconv2d(qkvp, 2 * ct, (ct,), 0, ct, 7, wT, bias=bias, kvec=kvec)
 
 
 class EfficientAtt(nn.Module):
@@ -200,15 +187,8 @@ class EfficientAtt(nn.Module):
         qkv = ops.conv2d(a, self.qkv)                                   # (B,H,W,3C), channel = which*C + c
         qkvp, loc = self.aggregator._run(qkv)
         convv = self.crpe._conv_v(qkvp)
-        n = H * W
-        L = lib()
-        scratch = torch.empty(L.rc_gma_kv_scratch_bytes(b, n, heads, ch) // 4, dtype=torch.float32, device=a.device)
-        ktv = torch.empty((b, heads, ch, ch), dtype=torch.float32, device=a.device)
-        check(L.rc_gma_kv(qkvp.data_ptr(), ops._dt(qkvp), b, n, heads, ch, float(self.scale), scratch.data_ptr(), ktv.data_ptr(),
-                          ops._stream()), "rc_gma_kv")
-        y = torch.empty((b, H, W, c), dtype=a.dtype, device=a.device)
-        check(L.rc_gma_apply(qkvp.data_ptr(), convv.data_ptr(), loc.data_ptr(), ktv.data_ptr(), y.data_ptr(), ops._dt(a), b, n, heads,
-                             ch, seg, ops._stream()), "rc_gma_apply")
+        ktv = torch.ops.realcam.gma_kv(qkvp, heads, ch, float(self.scale))
+        y = torch.ops.realcam.gma_apply(qkvp, convv, loc, ktv, heads, ch, seg)
         return ops.conv2d(y, self.proj, residual=residual)
 
     def forward(self, x, size):
@@ -225,8 +205,7 @@ class ConvPosEnc(nn.Module):
     def _nhwc(self, a):
         k = self.proj.kernel_size[0]
         (wT,) = ops.host_cached(self, "taps", [self.proj.weight], lambda w: ops.dw_taps(w))
-        y = torch.empty_like(a)
-        return ops.dwconv2d(a, 0, y, 0, a.shape[-1], k, wT, bias=ops.f32_param(self.proj, "bias"), add_identity=True)
+        return ops.dwconv2d(a, 0, (a.shape[-1],), 0, a.shape[-1], k, wT, bias=ops.f32_param(self.proj, "bias"), add_identity=True)
 
     def forward(self, x, size):
         return self._nhwc(_as_nhwc(x, size)).reshape(x.shape)

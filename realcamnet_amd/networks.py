@@ -204,8 +204,10 @@ class CALayer(HipModule):
             nn.Sigmoid())
 
     def _nhwc(self, a):
-        raise NotImplementedError("CALayer is executed fused inside RCABlock (global mean + gate); "
-                                  "a standalone CALayer is not on the hot path")
+        """x * sigmoid(conv_du(mean_HW(x))).  Inside RCABlock the producing conv emits the channel sums and the scale is
+        folded into the next conv's staging; this stand-alone form reduces the map itself (rc_channel_sums)."""
+        gate = ops.ca_gate(ops.channel_sums(a), a.shape[1] * a.shape[2], self)
+        return ops.gate_residual(a, gate, None)
 
 
 class ResBlock(HipModule):

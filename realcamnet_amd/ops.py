@@ -13,10 +13,17 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import torch_ops as _T  # noqa: F401  (registers torch.ops.realcam.*)
 from ._lib import (RC_ACT_GELU, RC_ACT_LEAKY, RC_ACT_NONE, RC_ACT_RELU, RC_ACT_RELU_POST, RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC,
                    RC_OUT_PIXEL_SHUFFLE2, ConvDesc, ConvPairDesc, check)
 
 _DT = {torch.float32: RC_F32, torch.bfloat16: RC_BF16}
+_R = torch.ops.realcam          # every launch below goes through the dispatcher op registered in torch_ops.py
+
+
+def _opt(t: torch.Tensor) -> Optional[torch.Tensor]:
+    """An op's 'absent' output (an empty (0,) tensor) back to None."""
+    return t if t.numel() else None
 
 # Fold CALayer's "res*gate + skip" into the next conv's input staging (saves one full HBM pass per
 # RCAB).  The unfused form (rc_gate_residual) is kept for A/B checks.
@@ -55,7 +62,19 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 # parameter caches (never part of the state_dict)
 # --------------------------------------------------------------------------------------------------
 def _key(*params) -> tuple:
-    return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) if p is not None else None for p in params)
+    """Cache key of derived parameters: storage address + version counter + dtype + device.  NOTE: an in-place edit through
+    `.data` (`w.data.copy_()`, EMA swaps) does not bump `_version`; call invalidate_caches(module) after such edits."""
+    from torch._subclasses.fake_tensor import FakeTensor
+    return tuple(((id(p) if isinstance(p, FakeTensor) else p.data_ptr()), p._version, p.dtype, str(p.device)) if p is not None else None
+                 for p in params)
+
+
+def invalidate_caches(module) -> None:
+    """Drop every derived-parameter cache (packed MFMA weights, fp32 views, folded BatchNorm, CDF tables ...) below `module`.
+    load_state_dict / optimizer steps / .to() are detected automatically; edits through `.data` are not."""
+    for m in module.modules():
+        m.__dict__.pop("_rc_cache", None)
+        m.__dict__.pop("_pk", None)
 
 
 def _cache(mod) -> dict:
@@ -86,7 +105,7 @@ class PackedConv:
 
 
 def packed_conv(mod, act_dtype: torch.dtype, out_mode: int) -> PackedConv:
-    """MFMA-fragment-ordered copy of a conv's weights (rc_conv_pack_weights), cached on the module."""
+    """MFMA-fragment-ordered copy of a conv's weights (realcam::conv_pack_weights), cached on the module."""
     w, b = mod.weight, mod.bias
     c = _cache(mod)
     k = ("conv", act_dtype, out_mode)
@@ -103,23 +122,11 @@ def packed_conv(mod, act_dtype: torch.dtype, out_mode: int) -> PackedConv:
         cout, cin, kh, kw = w.shape
     if kh != kw or kh not in (1, 3):
         raise NotImplementedError(f"HIP conv supports 1x1 and 3x3 kernels, got {kh}x{kw}")
-    L = lib()
-    dt = _DT[act_dtype]
-    nbytes = L.rc_conv_packed_bytes(cin, cout, kh, dt, out_mode)
-    if nbytes == 0:
-        raise _lib.HipError(f"rc_conv_packed_bytes: {L.rc_last_error().decode()}")
-    w_host = np.ascontiguousarray(w.detach().float().cpu().numpy())
-    dst = np.empty(nbytes, dtype=np.uint8)
-    check(L.rc_conv_pack_weights(w_host.ctypes.data, cin, cout, kh, dt, out_mode, dst.ctypes.data), "rc_conv_pack_weights")
-    n_packed = L.rc_conv_packed_cout(cin, cout, kh, dt, out_mode)
-    bdst = np.zeros(n_packed, dtype=np.float32)
-    if b is not None:
-        b_host = np.ascontiguousarray(b.detach().float().cpu().numpy())
-        check(L.rc_conv_pack_bias(b_host.ctypes.data, cin, cout, kh, dt, out_mode, bdst.ctypes.data), "rc_conv_pack_bias")
+    wp, bp = _R.conv_pack_weights(w.detach(), b.detach() if b is not None else None, act_dtype, out_mode)
     pc = PackedConv()
-    pc.wpacked = torch.from_numpy(dst).to(w.device)
-    pc.bias = torch.from_numpy(bdst).to(w.device) if b is not None else None
-    pc.cin, pc.cout, pc.ksize, pc.dtype, pc.out_mode = cin, cout, kh, dt, out_mode
+    pc.wpacked = wp
+    pc.bias = bp if b is not None else None
+    pc.cin, pc.cout, pc.ksize, pc.dtype, pc.out_mode = cin, cout, kh, _DT[act_dtype], out_mode
     c[k] = (key, pc)
     return pc
 
@@ -145,54 +152,36 @@ def is_stride2(mod) -> bool:
 
 def subsample2(x: torch.Tensor) -> torch.Tensor:
     """x[:, ::2, ::2, :] of an NHWC map as a new dense tensor (rc_subsample2)."""
-    x = _req(x, "subsample2 input")
-    b, H, W, c = x.shape
-    y = torch.empty((b, (H + 1) // 2, (W + 1) // 2, c), dtype=x.dtype, device=x.device)
-    check(lib().rc_subsample2(x.data_ptr(), y.data_ptr(), _dt(x), b, H, W, c, _stream()), "rc_subsample2")
-    return y
+    return _R.subsample2(_req(x, "subsample2 input"))
 
 
 def upsample_bilinear2(x: torch.Tensor) -> torch.Tensor:
     """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) on an NHWC map (upstream models/raw2bit.py:790-793)."""
-    x = _req(x, "upsample_bilinear2 input")
-    b, H, W, c = x.shape
-    y = torch.empty((b, 2 * H, 2 * W, c), dtype=x.dtype, device=x.device)
-    check(lib().rc_upsample_bilinear2(x.data_ptr(), y.data_ptr(), _dt(x), b, H, W, c, _stream()), "rc_upsample_bilinear2")
-    return y
+    return _R.upsample_bilinear2(_req(x, "upsample_bilinear2 input"))
 
 
 def sft_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, identity: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x*scale + shift + x (+ identity): SpatialFeatureTransform with residual=True (upstream models/raw2bit.py:877-885)."""
     x, scale, shift = _req(x, "x"), _req(scale, "scale"), _req(shift, "shift")
+    if identity is not None:
+        identity = _req(identity, "identity")
     for t in (scale, shift) + ((identity,) if identity is not None else ()):
         if t.shape != x.shape or t.dtype != x.dtype:
             raise ValueError("sft_apply: shape / dtype mismatch")
-    y = torch.empty_like(x)
-    check(lib().rc_sft_apply(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), _ptr(identity), y.data_ptr(), _dt(x), x.numel(), _stream()), "rc_sft_apply")
-    return y
+    return _R.sft_apply(x, scale, shift, identity)
 
 
 def ca_gate_linear(sums: torch.Tensor, hw: int, fc0, fc1) -> torch.Tensor:
     """CALayer gate from channel partial sums for the bias-free nn.Linear form (upstream models/raw2bit.py:238-254)."""
     b, nt, c = sums.shape
     cr = fc0.weight.shape[0]
-    key = ("zeros", c, cr, str(sums.device))
-    z = _ONES.get(key)
-    if z is None:
-        z = _ONES[key] = torch.zeros(max(c, cr), dtype=torch.float32, device=sums.device)
-    gate = torch.empty((b, c), dtype=torch.float32, device=sums.device)
-    check(lib().rc_ca_gate(sums.data_ptr(), b, nt, c, cr, 1.0 / float(hw), f32_param(fc0, "weight").data_ptr(), z.data_ptr(),
-                           f32_param(fc1, "weight").data_ptr(), z.data_ptr(), gate.data_ptr(), _stream()), "rc_ca_gate")
-    return gate
+    z = _const(0.0, (max(c, cr),), sums)
+    return _R.ca_gate(sums, int(hw), f32_param(fc0, "weight"), z, f32_param(fc1, "weight"), z)
 
 
 def space_to_depth2(x: torch.Tensor) -> torch.Tensor:
     """(B,H,W,c) -> (B,ceil(H/2),ceil(W/2),4c), channel (2i+j)*c + k <- pixel (2y+i, 2x+j), zero beyond the edge."""
-    x = _req(x, "space_to_depth2 input")
-    b, H, W, c = x.shape
-    y = torch.empty((b, (H + 1) // 2, (W + 1) // 2, 4 * c), dtype=x.dtype, device=x.device)
-    check(lib().rc_space_to_depth2(x.data_ptr(), y.data_ptr(), _dt(x), b, H, W, c, _stream()), "rc_space_to_depth2")
-    return y
+    return _R.space_to_depth2(_req(x, "space_to_depth2 input"))
 
 
 def _stride2_view(mod) -> "_ConvView":
@@ -243,11 +232,7 @@ def entropy_bottleneck(z: torch.Tensor, params: torch.Tensor, medians: torch.Ten
     c = z.shape[-1]
     if tuple(params.shape) != (c, 58) or tuple(medians.shape) != (c,) or params.dtype != torch.float32 or medians.dtype != torch.float32:
         raise ValueError("entropy_bottleneck: params must be fp32 (C,58), medians fp32 (C)")
-    z_hat = torch.empty_like(z)
-    lik = torch.empty(z.shape, dtype=torch.float32, device=z.device)
-    check(lib().rc_entropy_bottleneck(z.data_ptr(), params.data_ptr(), medians.data_ptr(), z_hat.data_ptr(), lik.data_ptr(), _dt(z),
-                                      z.numel() // c, c, float(bound), _stream()), "rc_entropy_bottleneck")
-    return z_hat, lik
+    return _R.entropy_bottleneck(z, params, medians, float(bound))
 
 
 def gaussian_conditional(y: torch.Tensor, scale: torch.Tensor, mu: torch.Tensor, scale_bound: float = 0.11, bound: float = 1e-9):
@@ -255,11 +240,7 @@ def gaussian_conditional(y: torch.Tensor, scale: torch.Tensor, mu: torch.Tensor,
     y, scale, mu = _req(y, "y"), _req(scale, "scale"), _req(mu, "mu")
     if y.shape != scale.shape or y.shape != mu.shape or y.dtype != scale.dtype or y.dtype != mu.dtype:
         raise ValueError("gaussian_conditional: shape / dtype mismatch")
-    y_hat = torch.empty_like(y)
-    lik = torch.empty(y.shape, dtype=torch.float32, device=y.device)
-    check(lib().rc_gaussian_conditional(y.data_ptr(), scale.data_ptr(), mu.data_ptr(), y_hat.data_ptr(), lik.data_ptr(), _dt(y),
-                                        y.numel(), float(scale_bound), float(bound), _stream()), "rc_gaussian_conditional")
-    return y_hat, lik
+    return _R.gaussian_conditional(y, scale, mu, float(scale_bound), float(bound))
 
 
 def tanh_half_add(a: torch.Tensor, lrp: torch.Tensor) -> torch.Tensor:
@@ -267,27 +248,19 @@ def tanh_half_add(a: torch.Tensor, lrp: torch.Tensor) -> torch.Tensor:
     a, lrp = _req(a, "a"), _req(lrp, "lrp")
     if a.shape != lrp.shape or a.dtype != lrp.dtype:
         raise ValueError("tanh_half_add: shape / dtype mismatch")
-    out = torch.empty_like(a)
-    check(lib().rc_tanh_half_add(a.data_ptr(), lrp.data_ptr(), out.data_ptr(), _dt(a), a.numel(), _stream()), "rc_tanh_half_add")
-    return out
+    return _R.tanh_half_add(a, lrp)
 
 
 def pixel_shuffle2(x: torch.Tensor) -> torch.Tensor:
     """nn.PixelShuffle(2) on an NHWC map (B,H,W,4c) -> (B,2H,2W,c), any c (rc_pixel_shuffle2)."""
     x = _req(x, "pixel_shuffle2 input")
-    b, H, W, c4 = x.shape
-    if c4 % 4:
+    if x.shape[-1] % 4:
         raise ValueError("pixel_shuffle2: channels must be a multiple of 4")
-    y = torch.empty((b, 2 * H, 2 * W, c4 // 4), dtype=x.dtype, device=x.device)
-    check(lib().rc_pixel_shuffle2(x.data_ptr(), y.data_ptr(), _dt(x), b, H, W, c4 // 4, _stream()), "rc_pixel_shuffle2")
-    return y
+    return _R.pixel_shuffle2(x)
 
 
 def square(x: torch.Tensor) -> torch.Tensor:
-    x = _req(x, "square input")
-    y = torch.empty_like(x)
-    check(lib().rc_square(x.data_ptr(), y.data_ptr(), _dt(x), x.numel(), _stream()), "rc_square")
-    return y
+    return _R.square(_req(x, "square input"))
 
 
 def gdn_apply(x: torch.Tensor, norm: torch.Tensor, inverse: bool, identity: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -299,10 +272,7 @@ def gdn_apply(x: torch.Tensor, norm: torch.Tensor, inverse: bool, identity: Opti
         identity = _req(identity, "identity")
         if identity.shape != x.shape or identity.dtype != x.dtype:
             raise ValueError("gdn_apply: identity shape / dtype mismatch")
-    y = torch.empty_like(x)
-    check(lib().rc_gdn_apply(x.data_ptr(), norm.data_ptr(), _ptr(identity), y.data_ptr(), _dt(x), int(bool(inverse)), x.numel(), _stream()),
-          "rc_gdn_apply")
-    return y
+    return _R.gdn_apply(x, norm, bool(inverse), identity)
 
 
 def conv2x2s2(x: torch.Tensor, mod, **fuse):
@@ -327,9 +297,7 @@ def conv2x2s2(x: torch.Tensor, mod, **fuse):
         hit = (key, taps.to(x.device), view)
         cache["down2x2"] = hit
     _, taps, view = hit
-    y = torch.empty((b, H // 2, W // 2, 4 * c), dtype=x.dtype, device=x.device)
-    check(lib().rc_dwt_forward(x.data_ptr(), y.data_ptr(), taps.data_ptr(), 1, _dt(x), b, H, W, c, _stream()), "rc_dwt_forward")
-    return conv2d(y, view, **fuse)
+    return conv2d(_R.haar_dwt(x, taps, False), view, **fuse)     # one-hot 2x2 taps, the same for every channel
 
 
 def check_conv_module(mod) -> None:
@@ -350,41 +318,57 @@ def to_nhwc(x: torch.Tensor, dtype: Optional[torch.dtype] = None, pad_hw: Option
     x = _req(x, "to_nhwc input")
     if x.dim() != 4:
         raise ValueError(f"expected a 4-D NCHW tensor, got shape {tuple(x.shape)}")
-    b, c, h, w = x.shape
-    hp, wp = pad_hw if pad_hw is not None else (h, w)
+    hp, wp = pad_hw if pad_hw is not None else (x.shape[2], x.shape[3])
     dtype = dtype or x.dtype
-    out = torch.empty((b, hp, wp, c), dtype=dtype, device=x.device)
-    check(lib().rc_nchw_to_nhwc(x.data_ptr(), _dt(x), out.data_ptr(), _DT[dtype], b, c, h, w, hp, wp, _stream()), "rc_nchw_to_nhwc")
-    return out
+    _dt(x), _DT[dtype]
+    return _R.nchw_to_nhwc(x, dtype, int(hp), int(wp))
 
 
 def to_nchw(a: torch.Tensor, dtype: Optional[torch.dtype] = None, crop_hw: Optional[Tuple[int, int]] = None) -> torch.Tensor:
     a = _req(a, "to_nchw input")
-    b, H, W, c = a.shape
-    h, w = crop_hw if crop_hw is not None else (H, W)
+    h, w = crop_hw if crop_hw is not None else (a.shape[1], a.shape[2])
     dtype = dtype or a.dtype
-    out = torch.empty((b, c, h, w), dtype=dtype, device=a.device)
-    check(lib().rc_nhwc_to_nchw(a.data_ptr(), _dt(a), out.data_ptr(), _DT[dtype], b, c, H, W, h, w, _stream()), "rc_nhwc_to_nchw")
-    return out
+    _dt(a), _DT[dtype]
+    return _R.nhwc_to_nchw(a, dtype, int(h), int(w))
 
 
-def bayer_unshuffle(mosaic: torch.Tensor, dtype: Optional[torch.dtype] = None, pad_to: int = 1) -> torch.Tensor:
-    """(B,1,2h,2w) or (B,2h,2w) Bayer mosaic -> packed NHWC (B,hp,wp,4), zero padded to a multiple of
-    `pad_to` (README.md:33-38 'Unpixel shuffle' + models/LiteISP.py:84-105)."""
+def _mosaic3(mosaic: torch.Tensor) -> torch.Tensor:
     mosaic = _req(mosaic, "mosaic")
     if mosaic.dim() == 4:
         if mosaic.shape[1] != 1:
             raise ValueError("mosaic must have one channel")
         mosaic = mosaic[:, 0]
-    b, h2, w2 = mosaic.shape
-    if h2 % 2 or w2 % 2:
-        raise ValueError("mosaic height/width must be even")
-    h, w = h2 // 2, w2 // 2
-    hp, wp = -(-h // pad_to) * pad_to, -(-w // pad_to) * pad_to
+    if mosaic.dim() != 3 or mosaic.shape[1] % 2 or mosaic.shape[2] % 2:
+        raise ValueError("mosaic must be (B,[1,]2h,2w) with even height/width")
+    return mosaic
+
+
+def bayer_unshuffle(mosaic: torch.Tensor, dtype: Optional[torch.dtype] = None, pad_to: int = 1) -> torch.Tensor:
+    """(B,1,2h,2w) or (B,2h,2w) Bayer mosaic -> packed NHWC (B,hp,wp,4), zero padded to a multiple of
+    `pad_to` (README.md:33-38 'Unpixel shuffle' + models/LiteISP.py:84-105)."""
+    mosaic = _mosaic3(mosaic)
     dtype = dtype or mosaic.dtype
-    out = torch.empty((b, hp, wp, 4), dtype=dtype, device=mosaic.device)
-    check(lib().rc_bayer_unshuffle(mosaic.data_ptr(), _dt(mosaic), out.data_ptr(), _DT[dtype], b, h, w, hp, wp, _stream()), "rc_bayer_unshuffle")
-    return out
+    _dt(mosaic), _DT[dtype]
+    return _R.bayer_unshuffle(mosaic, dtype, int(pad_to))
+
+
+def raw_ingest(mosaic: torch.Tensor, dtype: Optional[torch.dtype] = None, pad_to: int = 16, black_level: float = 0.0, white_level: float = 1.0,
+               cond_hw: Tuple[int, int] = (256, 256)):
+    """The RAW ingest step in front of the path (the 'Unpixel shuffle' and 'Resize' boxes of
+    assets/networkarch.png), one launch: sensor mosaic (B,[1,]2h,2w) -> normalise (v - black) / (white - black) ->
+    Bayer unshuffle -> zero-pad to `pad_to` -> packed NHWC (B,hp,wp,4); and cond (B,4,ch,cw) NCHW = bilinear resize
+    (align_corners=False, as F.interpolate) of the un-padded normalised packed RAW.  Returns (packed, cond)."""
+    mosaic = _mosaic3(mosaic)
+    if not white_level > black_level:
+        raise ValueError("white_level must exceed black_level")
+    if mosaic.dtype == torch.uint16:
+        if dtype is None:
+            raise ValueError("raw_ingest: give the activation dtype for a uint16 mosaic")
+    else:
+        _dt(mosaic)
+        dtype = dtype or mosaic.dtype
+    _DT[dtype]
+    return _R.raw_ingest(mosaic, dtype, int(pad_to), float(black_level), float(white_level), int(cond_hw[0]), int(cond_hw[1]))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -413,11 +397,6 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
     pc = packed_conv(mod, x.dtype, out_mode)
     if cin != pc.cin:
         raise ValueError(f"conv expects {pc.cin} input channels, got {cin}")
-    dev = x.device
-    d = ConvDesc()
-    d.batch, d.height, d.width, d.cin, d.cout, d.ksize, d.dtype = b, H, W, cin, pc.cout, pc.ksize, pc.dtype
-    d.in0 = x.data_ptr()
-    stored = None
     if gate is not None:
         if skip is None:
             raise ValueError("gate needs skip")
@@ -425,44 +404,25 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
         gate = _req(gate, "gate")
         if skip.shape != x.shape or skip.dtype != x.dtype or gate.shape != (b, cin) or gate.dtype != torch.float32:
             raise ValueError("gate/skip shape or dtype mismatch")
-        d.in1, d.in_gate = skip.data_ptr(), gate.data_ptr()
-        if store_input:
-            stored = torch.empty_like(x)
-            d.in_store = stored.data_ptr()
-    d.wpacked = pc.wpacked.data_ptr()
-    d.bias = _ptr(pc.bias)
+    fs = ft = None
     if film is not None:
         fs, ft = (_req(t, "film") for t in film)
         if fs.shape != (b, pc.cout) or ft.shape != (b, pc.cout) or fs.dtype != torch.float32 or ft.dtype != torch.float32:
             raise ValueError("film tensors must be fp32 (B, cout)")
-        d.film_scale, d.film_shift = fs.data_ptr(), ft.data_ptr()
-    d.act, d.act_slope = _ACT[act], float(slope)
+    if mul_plus1 is not None:
+        mul_plus1 = _req(mul_plus1, "mul_plus1")
+    if residual is not None:
+        residual = _req(residual, "residual")
     for name, t in (("mul_plus1", mul_plus1), ("residual", residual)):
-        if t is not None:
-            t = _req(t, name)
-            if t.shape != (b, H, W, pc.cout) or t.dtype != x.dtype:
-                raise ValueError(f"{name} must be NHWC {(b, H, W, pc.cout)} {x.dtype}, got {tuple(t.shape)} {t.dtype}")
-            setattr(d, name, t.data_ptr())
-    d.out_mode = out_mode
-    if out_mode == RC_OUT_NHWC:
-        out = torch.empty((b, H, W, pc.cout), dtype=x.dtype, device=dev)
-        d.out_dtype = pc.dtype
-    elif out_mode == RC_OUT_PIXEL_SHUFFLE2:
-        out = torch.empty((b, 2 * H, 2 * W, pc.cout // 4), dtype=x.dtype, device=dev)
-        d.out_dtype = pc.dtype
-    else:
-        oh, ow = crop_hw if crop_hw is not None else (H, W)
-        odt = out_dtype or x.dtype
-        out = torch.empty((b, pc.cout, oh, ow), dtype=odt, device=dev)
-        d.out_dtype, d.out_h, d.out_w = _DT[odt], oh, ow
-    d.out = out.data_ptr()
-    sums = None
-    if want_sums:
-        nt = lib().rc_conv_sum_tiles(H, W)
-        sums = torch.empty((b, nt, pc.cout), dtype=torch.float32, device=dev)
-        d.chan_sums = sums.data_ptr()
-    check(lib().rc_conv2d(C.byref(d), _stream()), "rc_conv2d")
-    extras = [t for t in (stored, sums) if t is not None]
+        if t is not None and (t.shape != (b, H, W, pc.cout) or t.dtype != x.dtype):
+            raise ValueError(f"{name} must be NHWC {(b, H, W, pc.cout)} {x.dtype}, got {tuple(t.shape)} {t.dtype}")
+    ch, cw = (crop_hw if crop_hw is not None else (0, 0)) if out_mode == RC_OUT_NCHW else (0, 0)
+    if out_dtype is not None:
+        _DT[out_dtype]
+    out, stored, sums = _R.conv2d(x, pc.wpacked, pc.bias, pc.cout, pc.ksize, _ACT[act], float(slope), residual, mul_plus1, fs, ft, gate, skip,
+                                  bool(store_input), int(out_mode), bool(want_sums), int(ch), int(cw),
+                                  out_dtype if out_mode == RC_OUT_NCHW else None)
+    extras = [t for t in (_opt(stored), _opt(sums)) if t is not None]
     return (out, *extras) if extras else out
 
 
@@ -490,40 +450,24 @@ def conv_pair(x: torch.Tensor, m1, m2, *, act: str = "relu", slope: float = 0.0,
     x = _req(x, "conv_pair input")
     b, H, W, c = x.shape
     p1, p2 = packed_conv(m1, x.dtype, RC_OUT_NHWC), packed_conv(m2, x.dtype, RC_OUT_NHWC)
-    d = ConvPairDesc()
-    d.batch, d.height, d.width, d.channels, d.dtype = b, H, W, c, p1.dtype
-    d.in0 = x.data_ptr()
-    stored = None
     if gate is not None:
         if skip is None:
             raise ValueError("gate needs skip")
         skip, gate = _req(skip, "skip"), _req(gate, "gate")
         if skip.shape != x.shape or skip.dtype != x.dtype or gate.shape != (b, c) or gate.dtype != torch.float32:
             raise ValueError("gate/skip shape or dtype mismatch")
-        d.in1, d.in_gate = skip.data_ptr(), gate.data_ptr()
-        if store_input:
-            stored = torch.empty_like(x)
-            d.in_store = stored.data_ptr()
-    d.w1, d.b1, d.w2, d.b2 = p1.wpacked.data_ptr(), _ptr(p1.bias), p2.wpacked.data_ptr(), _ptr(p2.bias)
+    fs = ft = None
     if film is not None:
         fs, ft = (_req(t, "film") for t in film)
         if fs.shape != (b, c) or ft.shape != (b, c) or fs.dtype != torch.float32 or ft.dtype != torch.float32:
             raise ValueError("film tensors must be fp32 (B, C)")
-        d.film_scale, d.film_shift = fs.data_ptr(), ft.data_ptr()
-    d.act1, d.act1_slope = _ACT[act], float(slope)
     if residual is not None:
         residual = _req(residual, "residual")
         if residual.shape != x.shape or residual.dtype != x.dtype:
             raise ValueError("residual must match the input tensor")
-        d.residual = residual.data_ptr()
-    out = torch.empty_like(x)
-    d.out = out.data_ptr()
-    sums = None
-    if want_sums:
-        sums = torch.empty((b, lib().rc_conv_pair_sum_slots(H, W), c), dtype=torch.float32, device=x.device)
-        d.chan_sums = sums.data_ptr()
-    check(lib().rc_conv_pair(C.byref(d), _stream()), "rc_conv_pair")
-    extras = [t for t in (stored, sums) if t is not None]
+    out, stored, sums = _R.conv_pair(x, p1.wpacked, p1.bias, p2.wpacked, p2.bias, _ACT[act], float(slope), fs, ft, gate, skip, bool(store_input),
+                                     residual, bool(want_sums))
+    extras = [t for t in (_opt(stored), _opt(sums)) if t is not None]
     return (out, *extras) if extras else out
 
 
@@ -541,38 +485,36 @@ def pointwise_chain_ok(x: torch.Tensor, convs, slopes) -> bool:
 def pointwise_chain(x: torch.Tensor, convs, slope: float) -> torch.Tensor:
     """convs[0] (cin0 -> 48), LeakyReLU(slope), convs[1:] (48 -> 48) with LeakyReLU between, none after the last."""
     x = _req(x, "chain input")
-    b, H, W, cin0 = x.shape
-    first, mids = convs[0], convs[1:]
-    p0 = packed_conv(first, x.dtype, RC_OUT_NHWC)
-    packs = [packed_conv(m, x.dtype, RC_OUT_NHWC) for m in mids]
-    n = len(mids)
-    wp = (C.c_void_p * n)(*[p.wpacked.data_ptr() for p in packs])
-    bp = (C.c_void_p * n)(*[_ptr(p.bias) for p in packs])
-    out = torch.empty((b, H, W, 48), dtype=x.dtype, device=x.device)
-    check(lib().rc_pointwise_chain48(x.data_ptr(), cin0, p0.wpacked.data_ptr(), _ptr(p0.bias), wp, bp, n, float(slope), out.data_ptr(), _dt(x),
-                                     b * H * W, _stream()), "rc_pointwise_chain48")
-    return out
+    p0 = packed_conv(convs[0], x.dtype, RC_OUT_NHWC)
+    packs = [packed_conv(m, x.dtype, RC_OUT_NHWC) for m in convs[1:]]
+    return _R.pointwise_chain48(x, p0.wpacked, p0.bias, [p.wpacked for p in packs], [p.bias for p in packs], float(slope))
 
 
 def ca_gate(sums: torch.Tensor, hw: int, ca) -> torch.Tensor:
     """CALayer gate (B,C) from the conv's channel partial sums.  models/networks.py:259-269."""
-    b, nt, c = sums.shape
     c0, c1 = ca.conv_du[0], ca.conv_du[2]
-    cr = c0.weight.shape[0]
-    gate = torch.empty((b, c), dtype=torch.float32, device=sums.device)
-    check(lib().rc_ca_gate(sums.data_ptr(), b, nt, c, cr, 1.0 / float(hw),
-                           f32_param(c0, "weight").data_ptr(), f32_param(c0, "bias").data_ptr(),
-                           f32_param(c1, "weight").data_ptr(), f32_param(c1, "bias").data_ptr(),
-                           gate.data_ptr(), _stream()), "rc_ca_gate")
-    return gate
+    cr, c = c0.weight.shape[0], c0.weight.shape[1]
+    return _R.ca_gate(sums, int(hw), f32_param(c0, "weight").reshape(cr, c), f32_param(c0, "bias"), f32_param(c1, "weight").reshape(c, cr),
+                      f32_param(c1, "bias"))
 
 
-def gate_residual(r: torch.Tensor, gate: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    r, x, gate = _req(r, "r"), _req(x, "x"), _req(gate, "gate")
+def gate_residual(r: torch.Tensor, gate: torch.Tensor, x: Optional[torch.Tensor]) -> torch.Tensor:
+    """r * gate[b, c] + x on NHWC maps; x None: r * gate (CALayer alone, models/networks.py:270)."""
+    r, gate = _req(r, "r"), _req(gate, "gate")
     b, H, W, c = r.shape
-    y = torch.empty_like(r)
-    check(lib().rc_gate_residual(r.data_ptr(), gate.data_ptr(), x.data_ptr(), y.data_ptr(), _dt(r), b, H * W, c, _stream()), "rc_gate_residual")
-    return y
+    if x is not None:
+        x = _req(x, "x")
+        if x.shape != r.shape or x.dtype != r.dtype:
+            raise ValueError("gate_residual: shape / dtype mismatch")
+    if gate.shape != (b, c) or gate.dtype != torch.float32:
+        raise ValueError("gate_residual: gate must be fp32 (B, C)")
+    return _R.gate_residual(r, gate, x)
+
+
+def channel_sums(x: torch.Tensor) -> torch.Tensor:
+    """Per-channel partial sums (B, slots, C) fp32 of an NHWC map, in the layout rc_ca_gate folds (AdaptiveAvgPool2d(1) of a
+    CALayer that is not fed by a conv emitting them, models/networks.py:268)."""
+    return _R.channel_sums(_req(x, "channel_sums input"))
 
 
 def sigmoid_gate_add(a: torch.Tensor, b: torch.Tensor, identity: torch.Tensor) -> torch.Tensor:
@@ -580,36 +522,36 @@ def sigmoid_gate_add(a: torch.Tensor, b: torch.Tensor, identity: torch.Tensor) -
     a, b, identity = _req(a, "a"), _req(b, "b"), _req(identity, "identity")
     if a.shape != b.shape or a.shape != identity.shape or a.dtype != b.dtype or a.dtype != identity.dtype:
         raise ValueError("sigmoid_gate_add: shape / dtype mismatch")
-    y = torch.empty_like(a)
-    check(lib().rc_sigmoid_gate_add(a.data_ptr(), b.data_ptr(), identity.data_ptr(), y.data_ptr(), _dt(a), a.numel(), _stream()),
-          "rc_sigmoid_gate_add")
-    return y
+    return _R.sigmoid_gate_add(a, b, identity)
 
 
 def channel_slice(x: torch.Tensor, c0: int, n: int) -> torch.Tensor:
     """x[..., c0:c0+n] of an NHWC tensor as a new dense tensor (torch.split along channels, models/tcm.py:261)."""
-    x = _req(x, "channel_slice input")
-    out = torch.empty((*x.shape[:-1], n), dtype=x.dtype, device=x.device)
-    check(lib().rc_channel_copy(x.data_ptr(), x.shape[-1], c0, out.data_ptr(), n, 0, n, x.numel() // x.shape[-1], _dt(x), _stream()), "rc_channel_copy")
-    return out
+    return _R.channel_slice(_req(x, "channel_slice input"), int(c0), int(n))
 
 
 def channel_concat(parts) -> torch.Tensor:
     """torch.cat along the channel dim of NHWC tensors (models/tcm.py:265)."""
     parts = [_req(t, "channel_concat input") for t in parts]
-    ctot = sum(t.shape[-1] for t in parts)
-    out = torch.empty((*parts[0].shape[:-1], ctot), dtype=parts[0].dtype, device=parts[0].device)
-    c0 = 0
     for t in parts:
         if t.shape[:-1] != parts[0].shape[:-1] or t.dtype != parts[0].dtype:
             raise ValueError("channel_concat: shape / dtype mismatch")
-        check(lib().rc_channel_copy(t.data_ptr(), t.shape[-1], 0, out.data_ptr(), ctot, c0, t.shape[-1], t.numel() // t.shape[-1], _dt(t), _stream()),
-              "rc_channel_copy")
-        c0 += t.shape[-1]
-    return out
+    return _R.channel_concat(parts)
 
 
 _ONES = {}
+
+
+def _const(value: float, shape, like: torch.Tensor) -> torch.Tensor:
+    """A cached constant fp32 device tensor (never cached for fake tensors: they belong to their FakeTensorMode)."""
+    from torch._subclasses.fake_tensor import FakeTensor
+    if isinstance(like, FakeTensor):
+        return torch.full(shape, value, dtype=torch.float32, device=like.device)
+    key = (value, tuple(shape), str(like.device))
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.full(shape, value, dtype=torch.float32, device=like.device)
+    return t
 
 
 def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -618,24 +560,9 @@ def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     a, b = _req(a, "a"), _req(b, "b")
     if a.shape != b.shape or a.dtype != b.dtype:
         raise ValueError("add: shape / dtype mismatch")
-    key = (a.shape[0], a.shape[-1], str(a.device))
-    ones = _ONES.get(key)
-    if ones is None:
-        ones = _ONES[key] = torch.ones((a.shape[0], a.shape[-1]), dtype=torch.float32, device=a.device)
-    return gate_residual(a, ones, b)
+    return gate_residual(a, _const(1.0, (a.shape[0], a.shape[-1]), a), b)
 
 
-def _taps_uniform(mod) -> int:
-    """1 if every channel of a DWT module carries the same 4x(2x2) taps (the reference's Haar init);
-    checked once per parameter version on the host."""
-    c = _cache(mod)
-    key = _key(mod.weight)
-    hit = c.get("taps_uniform")
-    if hit is None or hit[0] != key:
-        w = mod.weight.detach().float().reshape(-1, 4, 4)
-        hit = (key, int(bool((w == w[:1]).all().item())))
-        c["taps_uniform"] = hit
-    return hit[1]
 
 
 def dwt_forward(x: torch.Tensor, mod) -> torch.Tensor:
@@ -645,19 +572,14 @@ def dwt_forward(x: torch.Tensor, mod) -> torch.Tensor:
         raise ValueError(f"DWTForward needs even H,W; got {H}x{W}")
     if mod.weight.shape[0] != 4 * c:
         raise ValueError("DWTForward channel mismatch")
-    y = torch.empty((b, H // 2, W // 2, 4 * c), dtype=x.dtype, device=x.device)
-    check(lib().rc_dwt_forward(x.data_ptr(), y.data_ptr(), f32_param(mod, "weight").data_ptr(), _taps_uniform(mod), _dt(x), b, H, W, c, _stream()), "rc_dwt_forward")
-    return y
+    return _R.haar_dwt(x, f32_param(mod, "weight"), True)
 
 
 def dwt_inverse(x: torch.Tensor, mod) -> torch.Tensor:
     x = _req(x, "idwt input")
-    b, h, w, c4 = x.shape
-    if mod.weight.shape[0] != c4:
+    if mod.weight.shape[0] != x.shape[3]:
         raise ValueError("DWTInverse channel mismatch")
-    y = torch.empty((b, 2 * h, 2 * w, c4 // 4), dtype=x.dtype, device=x.device)
-    check(lib().rc_dwt_inverse(x.data_ptr(), y.data_ptr(), f32_param(mod, "weight").data_ptr(), _taps_uniform(mod), _dt(x), b, h, w, c4, _stream()), "rc_dwt_inverse")
-    return y
+    return _R.haar_idwt(x, f32_param(mod, "weight"), True)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -667,35 +589,22 @@ def color_block(x: torch.Tensor, conv, prev_norm=None, prev_stats=None) -> torch
     """Conv1x1 -> AvgPool(3,2,1) -> LeakyReLU(0.2) on NCHW x; applies the previous block's InstanceNorm
     (prev_norm affine params, prev_stats=(mean,rstd)) on load.  models/LiteISP.py:23-30."""
     x = _req(x, "color_block input")
-    b, cin, h, w = x.shape
-    cout = conv.weight.shape[0]
-    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    y = torch.empty((b, cout, ho, wo), dtype=torch.float32, device=x.device)
+    _dt(x)
+    cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+    w, bias = f32_param(conv, "weight").reshape(cout, cin), f32_param(conv, "bias")
     if prev_norm is not None:
         mean, rstd = prev_stats
-        args = (mean.data_ptr(), rstd.data_ptr(), f32_param(prev_norm, "weight").data_ptr(), f32_param(prev_norm, "bias").data_ptr())
-    else:
-        args = (None, None, None, None)
-    check(lib().rc_color_block(x.data_ptr(), _dt(x), y.data_ptr(), b, cin, cout, h, w,
-                               f32_param(conv, "weight").data_ptr(), f32_param(conv, "bias").data_ptr(), *args, _stream()), "rc_color_block")
-    return y
+        return _R.color_block(x, w, bias, mean, rstd, f32_param(prev_norm, "weight"), f32_param(prev_norm, "bias"))
+    return _R.color_block(x, w, bias, None, None, None, None)
 
 
 def instance_stats(x: torch.Tensor, eps: float = 1e-5):
-    b, c, h, w = x.shape
-    mean = torch.empty((b, c), dtype=torch.float32, device=x.device)
-    rstd = torch.empty_like(mean)
-    check(lib().rc_instance_stats(x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), b, c, h * w, float(eps), _stream()), "rc_instance_stats")
-    return mean, rstd
+    return _R.instance_stats(x, float(eps))
 
 
 def color_head(x: torch.Tensor, conv) -> torch.Tensor:
-    b, cin, h, w = x.shape
-    cout = conv.weight.shape[0]
-    vec = torch.empty((b, cout), dtype=torch.float32, device=x.device)
-    check(lib().rc_color_head(x.data_ptr(), vec.data_ptr(), b, cin, cout, h * w,
-                              f32_param(conv, "weight").data_ptr(), f32_param(conv, "bias").data_ptr(), _stream()), "rc_color_head")
-    return vec
+    cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+    return _R.color_head(x, f32_param(conv, "weight").reshape(cout, cin), f32_param(conv, "bias"))
 
 
 def gfm_vector(vec: torch.Tensor, lin0, lin1) -> torch.Tensor:
@@ -703,14 +612,7 @@ def gfm_vector(vec: torch.Tensor, lin0, lin1) -> torch.Tensor:
     vec = _req(vec, "gfm vector")
     if vec.dtype != torch.float32:
         vec = vec.float()
-    b, cond_c = vec.shape
-    nf, c = lin0.weight.shape[0], lin1.weight.shape[0]
-    out = torch.empty((b, c), dtype=torch.float32, device=vec.device)
-    check(lib().rc_gfm_vector(vec.data_ptr(), b, cond_c, nf, c,
-                              f32_param(lin0, "weight").data_ptr(), f32_param(lin0, "bias").data_ptr(),
-                              f32_param(lin1, "weight").data_ptr(), f32_param(lin1, "bias").data_ptr(),
-                              out.data_ptr(), _stream()), "rc_gfm_vector")
-    return out
+    return _R.gfm_vector(vec, f32_param(lin0, "weight"), f32_param(lin0, "bias"), f32_param(lin1, "weight"), f32_param(lin1, "bias"))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -757,22 +659,16 @@ def dw_taps(weight: torch.Tensor, pad_to: Optional[int] = None) -> torch.Tensor:
     return weight.reshape(n, k * k).t().contiguous()
 
 
-def dwconv2d(x: torch.Tensor, x_c0: int, y: torch.Tensor, y_c0: int, n_ch: int, ksize: int, wT: torch.Tensor,
+def dwconv2d(x: torch.Tensor, x_c0: int, y_tail, y_c0: int, n_ch: int, ksize: int, wT: torch.Tensor,
              bias: Optional[torch.Tensor] = None, n_rep: int = 1, x_rep: int = 0, y_rep: int = 0, w_rep: int = 0,
              add_identity: bool = False, kvec: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Depth-wise KxK conv over channel sub-ranges (rc_dwconv2d); allocates and returns y of shape (B,H,W,*y_tail), which the call
+    must cover completely."""
     x = _req(x, "dwconv input")
-    b, H, W = x.shape[:3]
-    xs = int(np.prod(x.shape[3:]))
-    ys = int(np.prod(y.shape[3:]))
-    check(lib().rc_dwconv2d(x.data_ptr(), xs, x_c0, y.data_ptr(), ys, y_c0, _dt(x), b, H, W, n_ch, ksize, wT.data_ptr(),
-                            wT.shape[1], _ptr(bias), n_rep, x_rep, y_rep, w_rep, 1 if add_identity else 0, _ptr(kvec), _stream()), "rc_dwconv2d")
-    return y
+    return _R.dwconv2d(x, int(x_c0), [int(v) for v in y_tail], int(y_c0), int(n_ch), int(ksize), wT, bias, int(n_rep), int(x_rep), int(y_rep),
+                       int(w_rep), bool(add_identity), kvec)
 
 
 def layernorm(x: torch.Tensor, norm) -> torch.Tensor:
     x = _req(x, "layernorm input")
-    c = x.shape[-1]
-    y = torch.empty_like(x)
-    check(lib().rc_layernorm(x.data_ptr(), y.data_ptr(), _dt(x), x.numel() // c, c, f32_param(norm, "weight").data_ptr(),
-                             f32_param(norm, "bias").data_ptr(), float(norm.eps), _stream()), "rc_layernorm")
-    return y
+    return _R.layernorm(x, f32_param(norm, "weight"), f32_param(norm, "bias"), float(norm.eps))

@@ -18,7 +18,6 @@ import torch.nn as nn
 from . import networks as N
 from . import networks as N_mod      # TCM.__init__ keeps upstream's parameter name `N`
 from . import ops
-from .ops import check, lib
 
 
 class WMSA(nn.Module):
@@ -46,10 +45,8 @@ class WMSA(nn.Module):
         if c != self.input_dim or h % ws or w % ws:
             raise ValueError(f"WMSA: expected (b, h, w, {self.input_dim}) with h, w multiples of {ws}, got {tuple(t.shape)}")
         qkv = ops.conv2d(t, self.embedding_layer)
-        att = torch.empty_like(t)
-        check(lib().rc_window_attention(qkv.data_ptr(), ops.f32_param(self, "relative_position_params").data_ptr(), att.data_ptr(),
-                                        ops._dt(t), b, h, w, c, self.head_dim, ws, 0 if self.type == 'W' else ws // 2, ops._stream()),
-              "rc_window_attention")
+        att = torch.ops.realcam.window_attention(qkv, ops.f32_param(self, "relative_position_params"), self.head_dim, ws,
+                                                 0 if self.type == 'W' else ws // 2)
         return ops.conv2d(att, self.linear, residual=residual)
 
     def forward(self, x):

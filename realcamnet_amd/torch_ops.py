@@ -1,0 +1,433 @@
+"""PyTorch-ROCm custom ops `torch.ops.realcam.*` over the C ABI (include/realcam_hip.h).
+
+SURVEY.md section 8(b): the drop-in boundary upstream sits behind is `nn.Module.forward`, so the extension exports its kernels
+as dispatcher ops registered by schema.  Every op here is
+    schema  : `realcam::<name>(...)` (TORCH_LIBRARY-style schema string, below)
+    CUDA    : allocate the outputs through the caching allocator, enqueue ONE C-ABI launch (rc_<name>) on the current HIP
+              stream, no host sync (HIP-graph capturable)
+    Meta    : a fake-tensor kernel that only allocates the outputs, so FakeTensorMode / torch.compile tracing see shapes and
+              dtypes without touching the library
+There is no CPU kernel: a CPU tensor reaching one of these ops has no backend and raises (the wrappers in ops.py raise first,
+with a message that names the oracle).  Layout: activations NHWC (B,H,W,C) contiguous, fp32 or bf16.  Absent optional outputs
+are returned as empty (0,) tensors (an op's returns cannot be optional).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, ConvDesc, ConvPairDesc, check
+
+_DT = {torch.float32: RC_F32, torch.bfloat16: RC_BF16}
+_LIB = torch.library.Library("realcam", "DEF")
+SCHEMAS = {}
+
+
+def lib():
+    return _lib.load()
+
+
+def _dt(t: Tensor) -> int:
+    return _DT[t.dtype]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _none(x: Tensor) -> Tensor:
+    return x.new_empty((0,))
+
+
+def define(schema: str, alloc, launch):
+    """Register `realcam::<schema>`: alloc(*args) -> outputs (shared by the CUDA and the fake kernel), launch(outs, *args)
+    enqueues the C-ABI call."""
+    name = schema.split("(")[0]
+    SCHEMAS[name] = schema
+    _LIB.define(schema)
+
+    def cuda_impl(*args):
+        outs = alloc(*args)
+        launch(outs, *args)
+        return outs
+
+    def fake_impl(*args):
+        return alloc(*args)
+
+    _LIB.impl(name, cuda_impl, "CUDA")
+    torch.library.register_fake(f"realcam::{name}", fake_impl, lib=_LIB)
+
+
+# ---- a1/a2: ingest and layout ---------------------------------------------------------------------------------------
+def _bu_alloc(mosaic, dtype, pad_to):
+    b, h2, w2 = mosaic.shape
+    h, w = h2 // 2, w2 // 2
+    return mosaic.new_empty((b, -(-h // pad_to) * pad_to, -(-w // pad_to) * pad_to, 4), dtype=dtype)
+
+
+def _bu_launch(out, mosaic, dtype, pad_to):
+    b, h2, w2 = mosaic.shape
+    check(lib().rc_bayer_unshuffle(mosaic.data_ptr(), _dt(mosaic), out.data_ptr(), _DT[dtype], b, h2 // 2, w2 // 2, out.shape[1], out.shape[2],
+                                   _stream()), "rc_bayer_unshuffle")
+
+
+define("bayer_unshuffle(Tensor mosaic, ScalarType dtype, int pad_to) -> Tensor", _bu_alloc, _bu_launch)
+
+
+def _ingest_alloc(mosaic, dtype, pad_to, black, white, cond_h, cond_w):
+    b, h2, w2 = mosaic.shape
+    h, w = h2 // 2, w2 // 2
+    return (mosaic.new_empty((b, -(-h // pad_to) * pad_to, -(-w // pad_to) * pad_to, 4), dtype=dtype),
+            mosaic.new_empty((b, 4, cond_h, cond_w), dtype=dtype))
+
+
+def _ingest_launch(outs, mosaic, dtype, pad_to, black, white, cond_h, cond_w):
+    packed, cond = outs
+    b, h2, w2 = mosaic.shape
+    in_dt = _lib.RC_U16 if mosaic.dtype == torch.uint16 else _dt(mosaic)
+    check(lib().rc_raw_ingest(mosaic.data_ptr(), in_dt, packed.data_ptr(), cond.data_ptr(), _DT[dtype], b, h2 // 2, w2 // 2,
+                              packed.shape[1], packed.shape[2], cond_h, cond_w, float(black), float(white), _stream()), "rc_raw_ingest")
+
+
+define("raw_ingest(Tensor mosaic, ScalarType dtype, int pad_to, float black, float white, int cond_h, int cond_w) -> (Tensor, Tensor)",
+       _ingest_alloc, _ingest_launch)
+
+
+define("nchw_to_nhwc(Tensor x, ScalarType dtype, int hp, int wp) -> Tensor",
+       lambda x, dtype, hp, wp: x.new_empty((x.shape[0], hp, wp, x.shape[1]), dtype=dtype),
+       lambda out, x, dtype, hp, wp: check(lib().rc_nchw_to_nhwc(x.data_ptr(), _dt(x), out.data_ptr(), _DT[dtype], x.shape[0], x.shape[1],
+                                                                 x.shape[2], x.shape[3], hp, wp, _stream()), "rc_nchw_to_nhwc"))
+
+define("nhwc_to_nchw(Tensor a, ScalarType dtype, int h, int w) -> Tensor",
+       lambda a, dtype, h, w: a.new_empty((a.shape[0], a.shape[3], h, w), dtype=dtype),
+       lambda out, a, dtype, h, w: check(lib().rc_nhwc_to_nchw(a.data_ptr(), _dt(a), out.data_ptr(), _DT[dtype], a.shape[0], a.shape[3],
+                                                               a.shape[1], a.shape[2], h, w, _stream()), "rc_nhwc_to_nchw"))
+
+
+# ---- a3/a4: convolution -------------------------------------------------------------------------------------------------
+def _wshape(weight):
+    if weight.dim() == 2:
+        return weight.shape[0], weight.shape[1], 1
+    return weight.shape[0], weight.shape[1], weight.shape[2]
+
+
+def _pack_alloc(weight, bias, act_dtype, out_mode):
+    cout, cin, k = _wshape(weight)
+    L = lib()
+    dt = _DT[act_dtype]
+    nbytes = L.rc_conv_packed_bytes(cin, cout, k, dt, out_mode)
+    if nbytes == 0:
+        raise _lib.HipError(f"rc_conv_packed_bytes: {L.rc_last_error().decode()}")
+    n_packed = L.rc_conv_packed_cout(cin, cout, k, dt, out_mode)
+    return (weight.new_empty((nbytes,), dtype=torch.uint8),
+            weight.new_empty((n_packed if bias is not None else 0,), dtype=torch.float32))
+
+
+def _pack_launch(outs, weight, bias, act_dtype, out_mode):
+    # one-time host-side re-ordering into MFMA fragment order (rc_conv_pack_weights is a host function)
+    wp, bp = outs
+    cout, cin, k = _wshape(weight)
+    L = lib()
+    dt = _DT[act_dtype]
+    w_host = np.ascontiguousarray(weight.detach().float().cpu().numpy())
+    dst = np.empty(wp.numel(), dtype=np.uint8)
+    check(L.rc_conv_pack_weights(w_host.ctypes.data, cin, cout, k, dt, out_mode, dst.ctypes.data), "rc_conv_pack_weights")
+    wp.copy_(torch.from_numpy(dst))
+    if bias is not None:
+        b_host = np.ascontiguousarray(bias.detach().float().cpu().numpy())
+        bdst = np.zeros(bp.numel(), dtype=np.float32)
+        check(L.rc_conv_pack_bias(b_host.ctypes.data, cin, cout, k, dt, out_mode, bdst.ctypes.data), "rc_conv_pack_bias")
+        bp.copy_(torch.from_numpy(bdst))
+
+
+define("conv_pack_weights(Tensor weight, Tensor? bias, ScalarType act_dtype, int out_mode) -> (Tensor, Tensor)", _pack_alloc, _pack_launch)
+
+
+def _conv_alloc(x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, film_scale, film_shift, gate, skip, store_input, out_mode,
+                want_sums, crop_h, crop_w, out_dtype):
+    b, H, W, _ = x.shape
+    if out_mode == RC_OUT_NHWC:
+        out = x.new_empty((b, H, W, cout))
+    elif out_mode == RC_OUT_PIXEL_SHUFFLE2:
+        out = x.new_empty((b, 2 * H, 2 * W, cout // 4))
+    else:
+        out = x.new_empty((b, cout, crop_h if crop_h > 0 else H, crop_w if crop_w > 0 else W), dtype=out_dtype or x.dtype)
+    stored = torch.empty_like(x) if (store_input and gate is not None) else _none(x)
+    sums = x.new_empty((b, lib().rc_conv_sum_tiles(H, W), cout), dtype=torch.float32) if want_sums else x.new_empty((0,), dtype=torch.float32)
+    return out, stored, sums
+
+
+def _conv_launch(outs, x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, film_scale, film_shift, gate, skip, store_input,
+                 out_mode, want_sums, crop_h, crop_w, out_dtype):
+    out, stored, sums = outs
+    b, H, W, cin = x.shape
+    d = ConvDesc()
+    d.batch, d.height, d.width, d.cin, d.cout, d.ksize, d.dtype = b, H, W, cin, cout, ksize, _dt(x)
+    d.in0 = x.data_ptr()
+    if gate is not None:
+        d.in1, d.in_gate = skip.data_ptr(), gate.data_ptr()
+        if stored.numel():
+            d.in_store = stored.data_ptr()
+    d.wpacked, d.bias = wpacked.data_ptr(), _p(bias)
+    d.film_scale, d.film_shift = _p(film_scale), _p(film_shift)
+    d.act, d.act_slope = act, float(slope)
+    d.mul_plus1, d.residual = _p(mul_plus1), _p(residual)
+    d.out, d.out_mode = out.data_ptr(), out_mode
+    d.out_dtype = _dt(out)
+    if out_mode == RC_OUT_NCHW:
+        d.out_h, d.out_w = out.shape[2], out.shape[3]
+    if want_sums:
+        d.chan_sums = sums.data_ptr()
+    check(lib().rc_conv2d(C.byref(d), _stream()), "rc_conv2d")
+
+
+define("conv2d(Tensor x, Tensor wpacked, Tensor? bias, int cout, int ksize, int act, float slope, Tensor? residual, Tensor? mul_plus1, "
+       "Tensor? film_scale, Tensor? film_shift, Tensor? gate, Tensor? skip, bool store_input, int out_mode, bool want_sums, "
+       "int crop_h, int crop_w, ScalarType? out_dtype) -> (Tensor, Tensor, Tensor)", _conv_alloc, _conv_launch)
+
+
+def _pair_alloc(x, w1, b1, w2, b2, act, slope, film_scale, film_shift, gate, skip, store_input, residual, want_sums):
+    b, H, W, c = x.shape
+    stored = torch.empty_like(x) if (store_input and gate is not None) else _none(x)
+    sums = x.new_empty((b, lib().rc_conv_pair_sum_slots(H, W), c), dtype=torch.float32) if want_sums else x.new_empty((0,), dtype=torch.float32)
+    return torch.empty_like(x), stored, sums
+
+
+def _pair_launch(outs, x, w1, b1, w2, b2, act, slope, film_scale, film_shift, gate, skip, store_input, residual, want_sums):
+    out, stored, sums = outs
+    b, H, W, c = x.shape
+    d = ConvPairDesc()
+    d.batch, d.height, d.width, d.channels, d.dtype = b, H, W, c, _dt(x)
+    d.in0 = x.data_ptr()
+    if gate is not None:
+        d.in1, d.in_gate = skip.data_ptr(), gate.data_ptr()
+        if stored.numel():
+            d.in_store = stored.data_ptr()
+    d.w1, d.b1, d.w2, d.b2 = w1.data_ptr(), _p(b1), w2.data_ptr(), _p(b2)
+    d.film_scale, d.film_shift = _p(film_scale), _p(film_shift)
+    d.act1, d.act1_slope = act, float(slope)
+    d.residual, d.out = _p(residual), out.data_ptr()
+    if want_sums:
+        d.chan_sums = sums.data_ptr()
+    check(lib().rc_conv_pair(C.byref(d), _stream()), "rc_conv_pair")
+
+
+define("conv_pair(Tensor x, Tensor w1, Tensor? b1, Tensor w2, Tensor? b2, int act, float slope, Tensor? film_scale, Tensor? film_shift, "
+       "Tensor? gate, Tensor? skip, bool store_input, Tensor? residual, bool want_sums) -> (Tensor, Tensor, Tensor)", _pair_alloc, _pair_launch)
+
+
+def _chain_launch(out, x, w0, b0, wmid, bmid, slope):
+    n = len(wmid)
+    wp = (C.c_void_p * n)(*[w.data_ptr() for w in wmid])
+    bp = (C.c_void_p * n)(*[_p(b) for b in bmid])
+    check(lib().rc_pointwise_chain48(x.data_ptr(), x.shape[-1], w0.data_ptr(), _p(b0), wp, bp, n, float(slope), out.data_ptr(), _dt(x),
+                                     x.numel() // x.shape[-1], _stream()), "rc_pointwise_chain48")
+
+
+define("pointwise_chain48(Tensor x, Tensor w0, Tensor? b0, Tensor[] wmid, Tensor?[] bmid, float slope) -> Tensor",
+       lambda x, w0, b0, wmid, bmid, slope: x.new_empty((*x.shape[:-1], 48)), _chain_launch)
+
+
+# ---- a8: channel attention ------------------------------------------------------------------------------------------------
+define("ca_gate(Tensor(a!) sums, int hw, Tensor w0, Tensor b0, Tensor w1, Tensor b1) -> Tensor",
+       lambda sums, hw, w0, b0, w1, b1: sums.new_empty((sums.shape[0], sums.shape[2])),
+       lambda out, sums, hw, w0, b0, w1, b1: check(lib().rc_ca_gate(sums.data_ptr(), sums.shape[0], sums.shape[1], sums.shape[2], w0.shape[0],
+                                                                    1.0 / float(hw), w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(),
+                                                                    out.data_ptr(), _stream()), "rc_ca_gate"))
+
+define("gate_residual(Tensor r, Tensor gate, Tensor? x) -> Tensor",
+       lambda r, gate, x: torch.empty_like(r),
+       lambda out, r, gate, x: check(lib().rc_gate_residual(r.data_ptr(), gate.data_ptr(), _p(x), out.data_ptr(), _dt(r), r.shape[0],
+                                                            r.shape[1] * r.shape[2], r.shape[3], _stream()), "rc_gate_residual"))
+
+define("channel_sums(Tensor x) -> Tensor",
+       lambda x: x.new_empty((x.shape[0], lib().rc_channel_sums_slots(x.shape[1] * x.shape[2]), x.shape[3]), dtype=torch.float32),
+       lambda out, x: check(lib().rc_channel_sums(x.data_ptr(), _dt(x), x.shape[0], x.shape[1] * x.shape[2], x.shape[3], out.data_ptr(),
+                                                  _stream()), "rc_channel_sums"))
+
+
+# ---- element-wise / resampling pieces of the codec (rows a18-a20) ----------------------------------------------------------
+def _ew(name, schema_args, call):
+    define(f"{name}({schema_args}) -> Tensor", lambda x, *a: torch.empty_like(x), call)
+
+
+_ew("sigmoid_gate_add", "Tensor a, Tensor b, Tensor identity",
+    lambda out, a, b, i: check(lib().rc_sigmoid_gate_add(a.data_ptr(), b.data_ptr(), i.data_ptr(), out.data_ptr(), _dt(a), a.numel(), _stream()),
+                               "rc_sigmoid_gate_add"))
+_ew("sft_apply", "Tensor x, Tensor scale, Tensor shift, Tensor? identity",
+    lambda out, x, s, t, i: check(lib().rc_sft_apply(x.data_ptr(), s.data_ptr(), t.data_ptr(), _p(i), out.data_ptr(), _dt(x), x.numel(), _stream()),
+                                  "rc_sft_apply"))
+_ew("square", "Tensor x", lambda out, x: check(lib().rc_square(x.data_ptr(), out.data_ptr(), _dt(x), x.numel(), _stream()), "rc_square"))
+_ew("gdn_apply", "Tensor x, Tensor norm, bool inverse, Tensor? identity",
+    lambda out, x, n, inv, i: check(lib().rc_gdn_apply(x.data_ptr(), n.data_ptr(), _p(i), out.data_ptr(), _dt(x), int(bool(inv)), x.numel(),
+                                                       _stream()), "rc_gdn_apply"))
+_ew("tanh_half_add", "Tensor a, Tensor lrp",
+    lambda out, a, l: check(lib().rc_tanh_half_add(a.data_ptr(), l.data_ptr(), out.data_ptr(), _dt(a), a.numel(), _stream()), "rc_tanh_half_add"))
+
+
+def _resample(name, shape_fn, fn_name):
+    def launch(out, x):
+        b, H, W, c = x.shape
+        cc = c // 4 if name == "pixel_shuffle2" else c
+        check(getattr(lib(), fn_name)(x.data_ptr(), out.data_ptr(), _dt(x), b, H, W, cc, _stream()), fn_name)
+    define(f"{name}(Tensor x) -> Tensor", lambda x: x.new_empty(shape_fn(*x.shape)), launch)
+
+
+_resample("subsample2", lambda b, H, W, c: (b, (H + 1) // 2, (W + 1) // 2, c), "rc_subsample2")
+_resample("upsample_bilinear2", lambda b, H, W, c: (b, 2 * H, 2 * W, c), "rc_upsample_bilinear2")
+_resample("space_to_depth2", lambda b, H, W, c: (b, (H + 1) // 2, (W + 1) // 2, 4 * c), "rc_space_to_depth2")
+_resample("pixel_shuffle2", lambda b, H, W, c: (b, 2 * H, 2 * W, c // 4), "rc_pixel_shuffle2")
+
+define("entropy_bottleneck(Tensor z, Tensor params, Tensor medians, float bound) -> (Tensor, Tensor)",
+       lambda z, p, m, bound: (torch.empty_like(z), z.new_empty(z.shape, dtype=torch.float32)),
+       lambda outs, z, p, m, bound: check(lib().rc_entropy_bottleneck(z.data_ptr(), p.data_ptr(), m.data_ptr(), outs[0].data_ptr(),
+                                                                      outs[1].data_ptr(), _dt(z), z.numel() // z.shape[-1], z.shape[-1],
+                                                                      float(bound), _stream()), "rc_entropy_bottleneck"))
+
+define("gaussian_conditional(Tensor y, Tensor scale, Tensor mu, float scale_bound, float bound) -> (Tensor, Tensor)",
+       lambda y, s, m, sb, bound: (torch.empty_like(y), y.new_empty(y.shape, dtype=torch.float32)),
+       lambda outs, y, s, m, sb, bound: check(lib().rc_gaussian_conditional(y.data_ptr(), s.data_ptr(), m.data_ptr(), outs[0].data_ptr(),
+                                                                            outs[1].data_ptr(), _dt(y), y.numel(), float(sb), float(bound),
+                                                                            _stream()), "rc_gaussian_conditional"))
+
+define("channel_slice(Tensor x, int c0, int n) -> Tensor",
+       lambda x, c0, n: x.new_empty((*x.shape[:-1], n)),
+       lambda out, x, c0, n: check(lib().rc_channel_copy(x.data_ptr(), x.shape[-1], c0, out.data_ptr(), n, 0, n, x.numel() // x.shape[-1], _dt(x),
+                                                         _stream()), "rc_channel_copy"))
+
+
+def _concat_launch(out, parts):
+    ctot, c0 = out.shape[-1], 0
+    for t in parts:
+        check(lib().rc_channel_copy(t.data_ptr(), t.shape[-1], 0, out.data_ptr(), ctot, c0, t.shape[-1], t.numel() // t.shape[-1], _dt(t),
+                                    _stream()), "rc_channel_copy")
+        c0 += t.shape[-1]
+
+
+define("channel_concat(Tensor[] parts) -> Tensor",
+       lambda parts: parts[0].new_empty((*parts[0].shape[:-1], sum(t.shape[-1] for t in parts))), _concat_launch)
+
+
+# ---- a10: Haar DWT / inverse (taps live in the state_dict) -------------------------------------------------------------------
+_UNIFORM = {}
+
+
+def _taps_uniform(taps: Tensor) -> int:
+    """1 if every channel carries the same 4 x (2x2) taps (the reference's Haar init): checked once per tensor version on the
+    host, in the CUDA kernel's launcher only (a data-dependent branch has no place in the fake kernel)."""
+    key = (taps.data_ptr(), taps._version)
+    hit = _UNIFORM.get(key)
+    if hit is None:
+        w = taps.detach().float().reshape(-1, 4, 4)
+        hit = int(bool((w == w[:1]).all().item()))
+        if len(_UNIFORM) > 256:
+            _UNIFORM.clear()
+        _UNIFORM[key] = hit
+    return hit
+
+
+define("haar_dwt(Tensor x, Tensor taps, bool check_uniform) -> Tensor",
+       lambda x, taps, cu: x.new_empty((x.shape[0], x.shape[1] // 2, x.shape[2] // 2, 4 * x.shape[3])),
+       lambda out, x, taps, cu: check(lib().rc_dwt_forward(x.data_ptr(), out.data_ptr(), taps.data_ptr(), _taps_uniform(taps) if cu else 1, _dt(x),
+                                                           x.shape[0], x.shape[1], x.shape[2], x.shape[3], _stream()), "rc_dwt_forward"))
+
+define("haar_idwt(Tensor x, Tensor taps, bool check_uniform) -> Tensor",
+       lambda x, taps, cu: x.new_empty((x.shape[0], 2 * x.shape[1], 2 * x.shape[2], x.shape[3] // 4)),
+       lambda out, x, taps, cu: check(lib().rc_dwt_inverse(x.data_ptr(), out.data_ptr(), taps.data_ptr(), _taps_uniform(taps) if cu else 1, _dt(x),
+                                                           x.shape[0], x.shape[1], x.shape[2], x.shape[3], _stream()), "rc_dwt_inverse"))
+
+
+# ---- a5-a7: conditioning ------------------------------------------------------------------------------------------------------
+def _cb_launch(out, x, w, b, mean, rstd, gamma, beta):
+    bt, cin, h, wd = x.shape
+    check(lib().rc_color_block(x.data_ptr(), _dt(x), out.data_ptr(), bt, cin, w.shape[0], h, wd, w.data_ptr(), b.data_ptr(), _p(mean), _p(rstd),
+                               _p(gamma), _p(beta), _stream()), "rc_color_block")
+
+
+define("color_block(Tensor x, Tensor w, Tensor b, Tensor? mean, Tensor? rstd, Tensor? gamma, Tensor? beta) -> Tensor",
+       lambda x, w, b, mean, rstd, gamma, beta: x.new_empty((x.shape[0], w.shape[0], (x.shape[2] - 1) // 2 + 1, (x.shape[3] - 1) // 2 + 1),
+                                                            dtype=torch.float32), _cb_launch)
+
+define("instance_stats(Tensor x, float eps) -> (Tensor, Tensor)",
+       lambda x, eps: (x.new_empty((x.shape[0], x.shape[1])), x.new_empty((x.shape[0], x.shape[1]))),
+       lambda outs, x, eps: check(lib().rc_instance_stats(x.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), x.shape[0], x.shape[1],
+                                                          x.shape[2] * x.shape[3], float(eps), _stream()), "rc_instance_stats"))
+
+define("color_head(Tensor x, Tensor w, Tensor b) -> Tensor",
+       lambda x, w, b: x.new_empty((x.shape[0], w.shape[0])),
+       lambda out, x, w, b: check(lib().rc_color_head(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], w.shape[0], x.shape[2] * x.shape[3],
+                                                      w.data_ptr(), b.data_ptr(), _stream()), "rc_color_head"))
+
+define("gfm_vector(Tensor vec, Tensor w0, Tensor b0, Tensor w1, Tensor b1) -> Tensor",
+       lambda vec, w0, b0, w1, b1: vec.new_empty((vec.shape[0], w1.shape[0])),
+       lambda out, vec, w0, b0, w1, b1: check(lib().rc_gfm_vector(vec.data_ptr(), vec.shape[0], vec.shape[1], w0.shape[0], w1.shape[0],
+                                                                  w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), out.data_ptr(),
+                                                                  _stream()), "rc_gfm_vector"))
+
+
+# ---- a14-a16: GroupMix pieces --------------------------------------------------------------------------------------------------
+def _dw_launch(y, x, x_c0, y_tail, y_c0, n_ch, ksize, wT, bias, n_rep, x_rep, y_rep, w_rep, add_identity, kvec):
+    b, H, W = x.shape[:3]
+    xs = int(np.prod(x.shape[3:]))
+    ys = int(np.prod(y.shape[3:]))
+    check(lib().rc_dwconv2d(x.data_ptr(), xs, x_c0, y.data_ptr(), ys, y_c0, _dt(x), b, H, W, n_ch, ksize, wT.data_ptr(), wT.shape[1], _p(bias),
+                            n_rep, x_rep, y_rep, w_rep, 1 if add_identity else 0, _p(kvec), _stream()), "rc_dwconv2d")
+
+
+define("dwconv2d(Tensor x, int x_c0, int[] y_tail, int y_c0, int n_ch, int ksize, Tensor wT, Tensor? bias, int n_rep, int x_rep, int y_rep, "
+       "int w_rep, bool add_identity, Tensor? kvec) -> Tensor",
+       lambda x, x_c0, y_tail, *a: x.new_empty((*x.shape[:3], *y_tail)), _dw_launch)
+
+define("layernorm(Tensor x, Tensor gamma, Tensor beta, float eps) -> Tensor",
+       lambda x, g, b, eps: torch.empty_like(x),
+       lambda out, x, g, b, eps: check(lib().rc_layernorm(x.data_ptr(), out.data_ptr(), _dt(x), x.numel() // x.shape[-1], x.shape[-1], g.data_ptr(),
+                                                          b.data_ptr(), float(eps), _stream()), "rc_layernorm"))
+
+
+def _gpw_launch(outs, qkv, dwc, pw, scale, shift, pwl, ln_g, ln_b):
+    qkvp, loc = outs
+    b, H, W, c3 = qkv.shape
+    c, seg = c3 // 3, c3 // 15
+    es = qkv.element_size()
+    check(lib().rc_gma_pointwise(qkv.data_ptr(), dwc.data_ptr(), dwc.data_ptr() + 3 * seg * es, 12 * seg, 4 * seg, 12 * seg, 4 * seg,
+                                 qkvp.data_ptr(), loc.data_ptr(), _dt(qkv), b * H * W, c, pw.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                 pwl.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), _stream()), "rc_gma_pointwise")
+
+
+define("gma_pointwise(Tensor qkv, Tensor dwc, Tensor pw, Tensor bn_scale, Tensor bn_shift, Tensor pwl, Tensor ln_g, Tensor ln_b) -> (Tensor, Tensor)",
+       lambda qkv, dwc, *a: (qkv.new_empty((*qkv.shape[:3], 3, 4 * (qkv.shape[3] // 15))), qkv.new_empty((*qkv.shape[:3], qkv.shape[3] // 15))),
+       _gpw_launch)
+
+
+def _gkv_launch(ktv, qkvp, heads, ch, scale):
+    b, H, W = qkvp.shape[:3]
+    n = H * W
+    scratch = torch.empty(lib().rc_gma_kv_scratch_bytes(b, n, heads, ch) // 4, dtype=torch.float32, device=qkvp.device)
+    check(lib().rc_gma_kv(qkvp.data_ptr(), _dt(qkvp), b, n, heads, ch, float(scale), scratch.data_ptr(), ktv.data_ptr(), _stream()), "rc_gma_kv")
+
+
+define("gma_kv(Tensor qkvp, int heads, int ch, float scale) -> Tensor",
+       lambda qkvp, heads, ch, scale: qkvp.new_empty((qkvp.shape[0], heads, ch, ch), dtype=torch.float32), _gkv_launch)
+
+define("gma_apply(Tensor qkvp, Tensor convv, Tensor loc, Tensor ktv, int heads, int ch, int seg) -> Tensor",
+       lambda qkvp, convv, loc, ktv, heads, ch, seg: qkvp.new_empty((*qkvp.shape[:3], heads * ch + seg)),
+       lambda out, qkvp, convv, loc, ktv, heads, ch, seg: check(
+           lib().rc_gma_apply(qkvp.data_ptr(), convv.data_ptr(), loc.data_ptr(), ktv.data_ptr(), out.data_ptr(), _dt(qkvp), qkvp.shape[0],
+                              qkvp.shape[1] * qkvp.shape[2], heads, ch, seg, _stream()), "rc_gma_apply"))
+
+
+# ---- a17: window attention ------------------------------------------------------------------------------------------------------
+define("window_attention(Tensor qkv, Tensor rel_pos, int head_dim, int window, int shift) -> Tensor",
+       lambda qkv, rel, hd, ws, sh: qkv.new_empty((*qkv.shape[:3], qkv.shape[3] // 3)),
+       lambda out, qkv, rel, hd, ws, sh: check(lib().rc_window_attention(qkv.data_ptr(), rel.data_ptr(), out.data_ptr(), _dt(qkv), qkv.shape[0],
+                                                                         qkv.shape[1], qkv.shape[2], qkv.shape[3] // 3, hd, ws, sh, _stream()),
+                                               "rc_window_attention"))

@@ -39,12 +39,17 @@ def golden_names(prefix):
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith(prefix) and f.endswith(".npz"))
 
 
+NET_NAMES = ("LiteISPNet", "LiteISPNet_GFM_LSC", "LiteISPNet_LSC", "LiteISPNet_GFM", "LiteISPNet_GFMresize",
+             "ISPUNet_GFM_LSC", "ISPUNet_GFM", "ISPUNet_LSC", "ResUNet")
+
+
 def net_name_of(fixture: str) -> str:
     """e2e_<Net>_<size> -> the net's class name."""
-    for name in ("ISPUNet_GFM_LSC", "LiteISPNet_GFM_LSC", "LiteISPNet"):
-        if fixture.startswith("e2e_" + name + "_"):
-            return name
-    raise KeyError(fixture)
+    import re
+    m = re.match(r"e2e_([A-Za-z_]+?)_(?:randn_)?\d+x\d+$", fixture)
+    if m is None or m.group(1) not in NET_NAMES:
+        raise KeyError(fixture)
+    return m.group(1)
 
 
 def sd_digest(sd) -> str:

@@ -1,0 +1,107 @@
+"""GPU (-m gpu): BASELINE.json's configurations at their OWN sizes, through size-independent properties (the CPU oracle
+needs minutes per 4K frame, so full-size parity is proven by properties; fixture-size parity by tests/test_gpu_parity.py).
+
+  cfg2  1080p, LiteISPNet, B=1, fp32   : the whole frame against the CPU oracle (PSNR >= 100 dB; ~10 s of CPU work) + conv
+                                         linearity of the 64-channel general kernel at that size
+  cfg3  4K, LiteISPNet_GFM_LSC_GMA, bf16: GMA_Block at N = 544*960 = 522 240 tokens: frame i of a batch == frame i alone (bitwise),
+                                         run-to-run bitwise, finite, shape
+  cfg5  4K, raw_compression_tcm_final, bf16, packed 1152x1920: the same properties for every entry of the result dict
+"""
+import pytest
+import torch
+
+import liteisp_oracle as O
+import realcamnet_amd as M
+from realcamnet_amd import networks as N
+from realcamnet_amd import ops
+from conftest import seed0_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_cfg2_1080p_fp32_whole_frame_vs_cpu_oracle(hip):
+    name = "LiteISPNet"
+    sd = seed0_state_dict(name)
+    g = torch.Generator().manual_seed(1234)
+    mosaic = torch.rand(1, 1, 1080, 1920, generator=g)
+    net = M.LiteISPNet()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        y = net.forward_mosaic(mosaic.to(DEV))
+        y2 = net.forward_mosaic(mosaic.to(DEV))
+    torch.cuda.synchronize()
+    assert y.shape == (1, 3, 1080, 1920) and torch.isfinite(y).all()
+    assert torch.equal(y, y2)                                     # run-to-run bitwise
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    with torch.no_grad():
+        ref = O.run_padded(name, sd, O.bayer_unshuffle(mosaic))   # packed 540x960 -> pad 544x960 -> crop
+    p = O.psnr(y.cpu(), ref)
+    assert p >= 100.0, p
+    # conv linearity in the 64-channel fp32 form at this size: conv(2x) == 2 conv(x) exactly (bias zero)
+    x = torch.rand(1, 544, 960, 64, generator=torch.Generator(device=DEV).manual_seed(5), device=DEV)
+    c = N.conv(64, 64, mode="C").to(DEV)
+    with torch.no_grad():
+        c.bias.zero_()
+        assert torch.equal(c._nhwc(x * 2), c._nhwc(x) * 2)
+
+
+def test_cfg3_4k_with_groupmix_block_batch_invariant(hip):
+    dt = torch.bfloat16
+    torch.manual_seed(0)
+    net = M.LiteISPNet_GFM_LSC_GMA().to(DEV, dt).eval()
+    g = torch.Generator().manual_seed(3)
+    mosaic = torch.rand(2, 1, 2160, 3840, generator=g).to(DEV, dt)
+    cond = torch.rand(2, 4, 256, 256, generator=g).to(DEV, dt)
+    coord = O.make_coord(2, 1080, 1920).to(DEV, dt)
+    with torch.no_grad():
+        y = net.forward_mosaic(mosaic, cond, coord)
+        y_again = net.forward_mosaic(mosaic, cond, coord)
+        y1 = net.forward_mosaic(mosaic[1:2], cond[1:2], coord[1:2])
+    torch.cuda.synchronize()
+    assert y.shape == (2, 3, 2160, 3840) and y.dtype == dt and torch.isfinite(y.float()).all()
+    assert torch.equal(y, y_again)                                # fixed-order reductions at 522 240 tokens
+    assert torch.equal(y1[0], y[1])                               # frames are independent: per-image softmax / k^T v / CALayer sums
+    # the GroupMix block really is in the path: without it the output differs
+    base = M.LiteISPNet_GFM_LSC()
+    base.load_state_dict({k: v for k, v in net.state_dict().items() if not k.startswith(("gma_in.", "gma.", "gma_out."))}, strict=True)
+    with torch.no_grad():
+        y0 = base.to(DEV, dt).eval().forward_mosaic(mosaic[1:2], cond[1:2], coord[1:2])
+    assert not torch.equal(y0, y1)
+
+
+def _flatten(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.update(_flatten(v, prefix + k + "."))
+        else:
+            out[prefix + k] = v
+    return out
+
+
+def test_cfg5_4k_raw_codec_forward_batch_invariant(hip):
+    import realcamnet_amd.raw2bit as RB
+    dt = torch.bfloat16
+    torch.manual_seed(0)
+    m = RB.raw_compression_tcm_final().to(DEV, dt).eval()
+    g = torch.Generator().manual_seed(9)
+    mosaic = torch.rand(2, 1, 2160, 3840, generator=g).to(DEV, dt)
+    cond = torch.rand(2, 4, 256, 256, generator=g).to(DEV, dt)
+    coord = O.make_coord(2, 1080, 1920).to(DEV, dt)
+    with torch.no_grad():
+        out = _flatten(m.forward_mosaic(mosaic, cond, coord))
+        again = _flatten(m.forward_mosaic(mosaic, cond, coord))
+        one = _flatten(m.forward_mosaic(mosaic[1:2], cond[1:2], coord[1:2]))
+    torch.cuda.synchronize()
+    want = {"x_hat": (2, 3, 2304, 3840), "y": (2, 320, 72, 120), "para.y": (2, 320, 72, 120), "para.means": (2, 320, 72, 120),
+            "para.scales": (2, 320, 72, 120), "likelihoods.y": (2, 320, 72, 120), "likelihoods.z": (2, 192, 18, 30),
+            "lft": (2, 64, 144, 240), "lsc": (2, 128, 1152, 1920)}
+    for k, shp in want.items():
+        assert tuple(out[k].shape) == shp, (k, tuple(out[k].shape))
+        assert torch.isfinite(out[k].float()).all(), k
+        assert torch.equal(out[k], again[k]), k                   # run-to-run bitwise
+        assert torch.equal(one[k][0], out[k][1]), k               # frame 1 alone == frame 1 of the batch
+    lik = out["likelihoods.y"]
+    assert lik.dtype == torch.float32 and float(lik.min()) >= 0.99e-9 and float(lik.max()) <= 1.0 + 1e-6

@@ -3,7 +3,7 @@ vectors.  Tolerances (stated here, reported as PSNR in bench.py):
   fp32: max|err| <= 2e-5 * max|ref| per block, end-to-end PSNR >= 100 dB
         (exact-f32 MFMA is an fmaf chain; ATen-CPU sums in another order -> ~1e-6 relative)
   bf16: bf16 storage / fp32 accumulate vs the fp32 CPU oracle: per block <= 3e-2 * max|ref|,
-        end-to-end PSNR >= 50 dB (CPU bf16-vs-fp32 of the same net is ~61 dB)
+        end-to-end PSNR >= 55 dB (CPU bf16-vs-fp32 of the same net is ~61 dB)
 """
 import os
 import sys
@@ -115,6 +115,22 @@ def test_channel_attention_blocks_vs_reference(hip, dt, fuse):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+def test_standalone_calayer_vs_reference(hip, dt):
+    """networks.CALayer.forward on its own (upstream models/networks.py:255-270): rc_channel_sums -> rc_ca_gate -> scale."""
+    g = load_golden("block_calayer_32")
+    mod = put(N.CALayer(32, 16), g["sd"], dt)
+    y = run(mod, g["x"], dt=dt)
+    y2 = run(mod, g["x"], dt=dt)
+    assert torch.equal(y, y2)
+    assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
+    # many slots per image (fixed-order fold), odd pixel count, vs the oracle
+    x = torch.randn(2, 32, 97, 131, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        ref = O.ca_layer({"ca." + k: v for k, v in g["sd"].items()}, "ca", x)
+    assert rel_err(run(mod, x, dt=dt).float().cpu(), ref) <= tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_conditioning_blocks_vs_reference(hip, dt):
     g = load_golden("block_res_gfm_48")
     mod = put(M.LiteISP.Res_GFM(48, 48, 32, 48, 48), g["sd"], dt)
@@ -167,7 +183,7 @@ def test_end_to_end_vs_reference_golden(hip, fixture, dt):
     torch.cuda.synchronize()
     assert y.shape == g["y"].shape and y.dtype == dt
     p = O.psnr(y.float().cpu(), g["y"])
-    assert p >= (100.0 if dt == torch.float32 else 50.0), p
+    assert p >= (100.0 if dt == torch.float32 else 55.0), p        # fp32 >= 100 dB, bf16 >= 55 dB
 
 
 @pytest.mark.parametrize("name", ["LiteISPNet", "LiteISPNet_GFM_LSC", "ISPUNet_GFM_LSC"])

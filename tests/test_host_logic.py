@@ -13,9 +13,13 @@ from conftest import ROOT, golden_names, load_golden, sd_digest, seed0_state_dic
 
 
 def test_seed0_parameters_equal_the_reference():
-    for name in ("LiteISPNet", "LiteISPNet_GFM_LSC", "ISPUNet_GFM_LSC"):
+    from conftest import NET_NAMES
+    for name in NET_NAMES:                                  # the whole ISP family: same construction order => same seed-0 parameters
         g = load_golden(f"e2e_{name}_32x32")
-        assert sd_digest(seed0_state_dict(name)) == g["sd_digest"]
+        sd = seed0_state_dict(name)
+        assert sd_digest(sd) == g["sd_digest"], name
+        if "n_tensors" in g:
+            assert len(sd) == int(g["n_tensors"]), name
 
 
 def test_ispunet_checkpoint_keys():
