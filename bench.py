@@ -4,9 +4,11 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path (Bayer unshuffle + pad -> LiteISPNet_GFM_LSC -> cropped sRGB) over
-one batch of `--frames` synthetic 4K mosaics per GPU (weak scaling: cfg3 at N=1, cfg4 = 64 frames at
-N=8).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+One step = one pass of the hot path (RAW ingest: Bayer unshuffle + pad + bilinear cond resize -> LiteISPNet_GFM_LSC_GMA ->
+cropped sRGB) over one batch of `--frames` synthetic 4K mosaics per GPU (weak scaling: cfg3 at N=1, cfg4 = 64 frames at
+N=8).  Inputs are resident in HBM before the timed region.  At N>1 every rank's sRGB frames are all-gathered to all ranks
+over RCCL/xGMI on a side stream, overlapped with the next step's forward; the last gather is inside the timed
+region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -37,7 +39,7 @@ def cpu_baseline(name, sd, frame_hw=(2160, 3840), budget_s=20.0):
 
     def sample(h2, w2):
         mosaic = torch.rand(1, 1, h2, w2, generator=g)
-        cond = torch.rand(1, 4, 256, 256, generator=g)
+        cond = O.raw_ingest(mosaic)[1]                    # cond = bilinear resize of the packed RAW to 256x256
         coord = O.make_coord(1, h2 // 2, w2 // 2)
         return mosaic, cond, coord
 
@@ -91,9 +93,9 @@ def main():
                     help="default = cfg3: the flagship net plus one GroupMix GMA_Block(80,8) at H/2 (build-defined placement); "
                          "raw_compression_tcm_final = the RAW codec's forward (likelihood path), SURVEY cfg5's codec leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of the output frames (replicas only)")
     args = ap.parse_args()
 
-    import liteisp_oracle as O
     import realcamnet_amd as M
     from realcamnet_amd import ops, shard
 
@@ -118,8 +120,8 @@ def main():
     assert e - s == B
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     mosaic = torch.rand(B, 1, H2, W2, generator=g, device=dev).to(dt)
-    cond = torch.rand(B, 4, 256, 256, generator=g, device=dev).to(dt)
-    coord = O.make_coord(B, H2 // 2, W2 // 2).to(dev, dt)
+    coord = ops.make_coord(B, H2 // 2, W2 // 2, device=dev, dtype=dt)
+    cond = None                                            # forward_mosaic's ingest kernel makes it: the packed RAW resized to 256x256
 
     def step():
         with torch.no_grad():
@@ -128,19 +130,30 @@ def main():
     if codec:
         return bench_codec(args, net, sd_cpu, step, (mosaic, cond, coord), rank, world, dev, dt)
 
+    import torch.distributed as dist
+    gather = shard.OverlappedGather(total_frames) if (dist.is_available() and dist.is_initialized() and not args.no_gather) else None
     for _ in range(args.warmup):
-        step()
+        out = step()
+        if gather is not None:
+            gather.submit(out)
+    if gather is not None:
+        gather.wait()
     torch.cuda.synchronize()
     shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+        if gather is not None:
+            gather.submit(out)                             # side stream: overlaps the next step's forward
+    gathered = gather.wait() if gather is not None else out
     torch.cuda.synchronize()
     shard.barrier()
     torch.cuda.synchronize()
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, dev)
-    assert out.shape == (B, 3, H2, W2)
+    assert out.shape == (B, 3, H2, W2) and gathered.shape == (total_frames if gather is not None else B, 3, H2, W2)
+    if gather is not None:                                 # the gathered payload is this rank's own frames where they belong
+        assert torch.equal(gathered[s:e], out)
 
     # dominant kernel (MFMA conv): HIP-event time of every launch on its stream, one extra step
     ops.prof_enable(True)
@@ -164,7 +177,9 @@ def main():
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (uniform[0,1) mosaics, seed-0 random-init weights)",
         "config": {"workload": f"{cfg_name}: {W2}x{H2} Bayer mosaic -> unshuffle+pad16 -> {args.model} -> sRGB {W2}x{H2}, "
                                f"{B} frames/GPU, {args.dtype} storage / fp32 accumulate",
-                   "frames_per_gpu": B, "global_frames": total_frames, "parallelism": f"frame-shard x{world}"},
+                   "frames_per_gpu": B, "global_frames": total_frames, "parallelism": f"frame-shard x{world}",
+                   "collective": (f"all_gather of the sRGB frames over RCCL, {out.numel() * out.element_size()} bytes per rank per step, on a side "
+                                  "stream overlapped with the next step's forward") if gather is not None else "none"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": None,
                      "kernel": "conv_mfma_kernel (all instantiations)", "launches_per_step": int(n_launch),
@@ -188,6 +203,7 @@ def main():
             y = net.forward_mosaic(m_c.to(dev, dt), c_c.to(dev, dt), co_c.to(dev, dt))
         torch.cuda.synchronize()
         res["cpu_baseline"] = info
+        import liteisp_oracle as O
         res["psnr_db_vs_cpu_fp32"] = round(O.psnr(y.float().cpu(), ref), 2)
     print(json.dumps(res), flush=True)
 
@@ -195,8 +211,6 @@ def main():
 def bench_codec(args, net, sd_cpu, step, inputs, rank, world, dev, dt):
     """--model raw_compression_tcm_final: the RAW codec's forward (models/raw2bit.py:1768-1855, likelihood path; no entropy coder)
     on 4K mosaics, packed RAW padded to a multiple of 128.  Same timing contract and JSON shape as the headline run."""
-    import liteisp_oracle as O
-    import raw2bit_oracle as RO
     from realcamnet_amd import ops, shard
     B, H2, W2 = args.frames, args.height, args.width
     for _ in range(args.warmup):
@@ -229,8 +243,11 @@ def bench_codec(args, net, sd_cpu, step, inputs, rank, world, dev, dt):
                         "traffic": None, "kernel": "conv_mfma_kernel (all instantiations)", "launches_per_step": int(n_launch),
                         "kernel_ms_per_step": round(conv_ms, 3), "flops_per_step": conv_flops}}
     if world == 1 and not args.no_cpu_baseline:
+        import liteisp_oracle as O                      # the oracle: checker and CPU baseline only
+        import raw2bit_oracle as RO
         g = torch.Generator().manual_seed(1234)
-        raw = torch.rand(1, 4, 256, 256, generator=g); cond = torch.rand(1, 4, 256, 256, generator=g); coord = O.make_coord(1, 256, 256)
+        mos = torch.rand(1, 1, 512, 512, generator=g)
+        raw, cond = O.raw_ingest(mos); coord = O.make_coord(1, 256, 256)
         torch.set_num_threads(min(16, os.cpu_count() or 1))
         with torch.no_grad():
             RO.raw_compression_tcm_final(sd_cpu, [raw, cond, coord])

@@ -40,6 +40,15 @@ def bayer_unshuffle(mosaic: torch.Tensor) -> torch.Tensor:
     return torch.stack(planes, dim=1)
 
 
+def raw_ingest(mosaic: torch.Tensor, black_level: float = 0.0, white_level: float = 1.0, cond_hw=(256, 256)):
+    """The ingest step in front of the path ('Unpixel shuffle' + 'Resize' boxes of assets/networkarch.png,
+    unpublished upstream): normalise (v - black) / (white - black), Bayer unshuffle, and cond = bilinear resize of the packed RAW
+    (F.interpolate, align_corners=False) -- SURVEY.md 8d cfg3 'cond = bilinear resize of packed raw to 256x256'.
+    Returns (packed (B,4,h,w), cond (B,4,*cond_hw))."""
+    packed = bayer_unshuffle((mosaic.float() - black_level) * (1.0 / (white_level - black_level)))
+    return packed, F.interpolate(packed, size=tuple(cond_hw), mode="bilinear", align_corners=False)
+
+
 def pad_to_multiple(x: torch.Tensor, mult: int = 16):
     """Zero-pad bottom/right so H,W % mult == 0.  models/LiteISP.py:84-105 (mult=16 upstream)."""
     h, w = x.shape[-2:]

@@ -137,6 +137,15 @@ class Res_GFM(nn.Module):
         return ops.to_nchw(y), vec
 
 
+def _ingest(net, mosaic, cond, dt, pad_to, black_level, white_level, cond_hw):
+    """Front end shared by every forward_mosaic: packed NHWC RAW (+ the cond image when the caller did not bring one)."""
+    need_cond = hasattr(net, "classifier") and cond is None and not getattr(net, "cond_from_raw", False)
+    if need_cond or black_level != 0.0 or white_level != 1.0 or mosaic.dtype == torch.uint16:
+        a, c = ops.raw_ingest(mosaic, dtype=dt, pad_to=pad_to, black_level=black_level, white_level=white_level, cond_hw=cond_hw)
+        return a, (c if need_cond else cond)
+    return ops.bayer_unshuffle(mosaic, dtype=dt, pad_to=pad_to), cond
+
+
 class _DwtUNet(nn.Module):
     """Shared trunk of the LiteISPNet family (upstream LiteISP.py:2019-2032, 2397-2409): Haar-DWT U-Net with RCAGroups; optional
     colour prior + Res_GFM modulation in front of each encoder level, optional lens-shading gain on the head."""
@@ -230,14 +239,16 @@ class _DwtUNet(nn.Module):
         h, vec = self._front(ops.to_nhwc(raw, dtype=dt), cond, coord_nhwc)
         return self._trunk(h, vec)
 
-    def forward_mosaic(self, mosaic, cond=None, coord=None, pad_to: int = 16):
+    def forward_mosaic(self, mosaic, cond=None, coord=None, pad_to: int = 16, black_level: float = 0.0, white_level: float = 1.0,
+                       cond_hw=(256, 256)):
         """Bayer mosaic (B,1,2h,2w), cond (B,4,hc,wc), coord (B,2,h,w) -> sRGB (B,3,2h,2w).
         RAW and coord are zero-padded bottom/right to a multiple of `pad_to` (reference convention,
-        upstream LiteISP.py:84-105) and the output is cropped back."""
+        upstream LiteISP.py:84-105) and the output is cropped back.  cond=None on a net with a colour prior: the fused ingest
+        kernel (ops.raw_ingest) also produces cond = bilinear resize of the normalised packed RAW to `cond_hw`."""
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
         dt = self._act_dtype()
-        a = ops.bayer_unshuffle(mosaic, dtype=dt, pad_to=pad_to)
+        a, cond = _ingest(self, mosaic, cond, dt, pad_to, black_level, white_level, cond_hw)
         b, hp, wp, _ = a.shape
         co = None
         if hasattr(self, "lsc"):
@@ -382,12 +393,14 @@ class _StridedUNet(nn.Module):
             co = ops.to_nhwc(coord, dtype=dt)
         return self._run(ops.to_nhwc(raw, dtype=dt), x[1] if hasattr(self, "classifier") else None, co)
 
-    def forward_mosaic(self, mosaic, cond=None, coord=None, pad_to: int = 16):
-        """Bayer mosaic (B,1,2h,2w), cond, coord (B,2,h,w) -> sRGB (B,3,2h,2w) with the unshuffle / pad16 / crop front end."""
+    def forward_mosaic(self, mosaic, cond=None, coord=None, pad_to: int = 16, black_level: float = 0.0, white_level: float = 1.0,
+                       cond_hw=(256, 256)):
+        """Bayer mosaic (B,1,2h,2w), cond, coord (B,2,h,w) -> sRGB (B,3,2h,2w) with the unshuffle / pad16 / crop front end
+        (cond=None: see _DwtUNet.forward_mosaic)."""
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
         dt = self._act_dtype()
-        a = ops.bayer_unshuffle(mosaic, dtype=dt, pad_to=pad_to)
+        a, cond = _ingest(self, mosaic, cond, dt, pad_to, black_level, white_level, cond_hw)
         b, hp, wp, _ = a.shape
         co = None
         if hasattr(self, "lsc"):

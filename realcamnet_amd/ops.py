@@ -371,6 +371,14 @@ def raw_ingest(mosaic: torch.Tensor, dtype: Optional[torch.dtype] = None, pad_to
     return _R.raw_ingest(mosaic, dtype, int(pad_to), float(black_level), float(white_level), int(cond_hw[0]), int(cond_hw[1]))
 
 
+def make_coord(b: int, h: int, w: int, device=None, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """Normalised pixel-coordinate map (B,2,h,w) in [-1,1], channel 0 = y, channel 1 = x: the lens-shading branch's input x[2]
+    (upstream never published its generator; build convention).  Plain tensor construction, no kernel."""
+    ys = torch.linspace(-1.0, 1.0, h, device=device).view(1, 1, h, 1).expand(b, 1, h, w)
+    xs = torch.linspace(-1.0, 1.0, w, device=device).view(1, 1, 1, w).expand(b, 1, h, w)
+    return torch.cat([ys, xs], dim=1).to(dtype).contiguous()
+
+
 # --------------------------------------------------------------------------------------------------
 # convolution and friends
 # --------------------------------------------------------------------------------------------------

@@ -259,14 +259,15 @@ class raw_compression_tcm_final(nn.Module):
         dt = self._act_dtype()
         return self._forward_nhwc(ops.to_nhwc(raw, dtype=dt), cond, ops.to_nhwc(coord, dtype=dt))
 
-    def forward_mosaic(self, mosaic, cond, coord, pad_to: int = 128):
+    def forward_mosaic(self, mosaic, cond, coord, pad_to: int = 128, black_level: float = 0.0, white_level: float = 1.0, cond_hw=(256, 256)):
         """Bayer mosaic (B,1,2h,2w), cond (B,4,hc,wc), coord (B,2,h,w) -> the same dict as forward().  The packed RAW and coord are
         zero-padded bottom/right to a multiple of `pad_to` (128: window 4 at 1/32 of the packed size), x_hat
         is NOT cropped (it is the decoder's output for the padded frame)."""
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
         dt = self._act_dtype()
-        a = ops.bayer_unshuffle(mosaic, dtype=dt, pad_to=pad_to)
+        from .LiteISP import _ingest
+        a, cond = _ingest(self, mosaic, cond, dt, pad_to, black_level, white_level, cond_hw)    # cond=None: resized packed RAW
         if coord.shape[-2:] != (mosaic.shape[-2] // 2, mosaic.shape[-1] // 2):
             raise ValueError("coord must be at packed resolution (h, w)")
         return self._forward_nhwc(a, cond, ops.to_nhwc(coord, dtype=dt, pad_hw=(a.shape[1], a.shape[2])))

@@ -61,6 +61,36 @@ def test_bayer_unshuffle_bit_exact(hip, dt):
     assert torch.equal(got.float().cpu().permute(0, 3, 1, 2), ref.to(dt).float())   # pure data movement: exact
 
 
+def test_raw_ingest_vs_oracle(hip):
+    """f4 ingest (rc_raw_ingest): black/white level + unshuffle + pad16 + bilinear cond resize in one launch, against the oracle
+    (F.interpolate align_corners=False).  uint16 sensor counts and normalised floats; ragged size; up- and down-scaling cond."""
+    g = torch.Generator().manual_seed(9)
+    counts = torch.randint(60, 1024, (2, 1, 86, 140), generator=g, dtype=torch.int32).to(torch.uint16)
+    want_p, want_c = O.raw_ingest(counts.to(torch.int32).float(), 64.0, 1023.0, cond_hw=(32, 48))
+    want_p, _ = O.pad_to_multiple(want_p, 16)
+    packed, cond = ops.raw_ingest(counts.to(DEV), dtype=torch.float32, pad_to=16, black_level=64.0, white_level=1023.0, cond_hw=(32, 48))
+    torch.cuda.synchronize()
+    assert packed.shape == (2, 48, 80, 4) and cond.shape == (2, 4, 32, 48)
+    assert (packed.cpu().permute(0, 3, 1, 2) - want_p).abs().max() <= 1e-6
+    assert (cond.cpu() - want_c).abs().max() <= 2e-6
+    mosaic = torch.rand(1, 1, 40, 64, generator=g)
+    want_p, want_c = O.raw_ingest(mosaic, cond_hw=(64, 96))            # up-scaling: taps clamp at the last row / column
+    packed, cond = ops.raw_ingest(mosaic.to(DEV), pad_to=1, cond_hw=(64, 96))
+    assert torch.equal(packed.cpu().permute(0, 3, 1, 2), want_p)        # black 0 / white 1: pure data movement
+    assert (cond.cpu() - want_c).abs().max() <= 2e-6
+    pb, cb = ops.raw_ingest(mosaic.to(DEV, torch.bfloat16), pad_to=1, cond_hw=(64, 96))
+    assert pb.dtype == torch.bfloat16 and (cb.float().cpu() - want_c).abs().max() <= 1e-2
+    # forward_mosaic(cond=None) == forward_mosaic(cond = the oracle's resized packed RAW) up to the resize's float noise
+    net = net_on_gpu("LiteISPNet_GFM_LSC", torch.float32)
+    mosaic = torch.rand(1, 1, 96, 128, generator=g)
+    coord = O.make_coord(1, 48, 64)
+    with torch.no_grad():
+        y0 = net.forward_mosaic(mosaic.to(DEV), None, coord.to(DEV), cond_hw=(32, 32))
+        ref = O.run_padded("LiteISPNet_GFM_LSC", seed0_state_dict("LiteISPNet_GFM_LSC"), O.bayer_unshuffle(mosaic),
+                           O.raw_ingest(mosaic, cond_hw=(32, 32))[1], coord)
+    assert O.psnr(y0.cpu(), ref) >= 100.0
+
+
 def test_layout_roundtrip_and_pad(hip):
     x = torch.randn(2, 37, 13, 29)
     a = ops.to_nhwc(x.to(DEV), pad_hw=(16, 32))
@@ -500,6 +530,20 @@ def test_bench_prints_one_contract_json_line(hip):
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert d["psnr_db_vs_cpu_fp32"] >= 50.0
+
+
+def test_bench_under_torchrun_gathers_over_rccl(hip):
+    """One rank under torch.distributed.run: the process group is RCCL ("nccl"), every step's frames go through
+    OverlappedGather (side stream, all_gather_into_tensor) and the gathered payload equals the local output."""
+    import json, subprocess
+    from conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", "2", "--height", "256", "--width", "384",
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
+    assert d["n_gpus"] == 1 and "all_gather" in d["config"]["collective"] and d["value"] > 0
 
 
 def test_bench_codec_leg_prints_one_contract_json_line(hip):

@@ -103,6 +103,14 @@ frames = torch.arange(n, dtype=torch.float32).view(n, 1, 1, 1).expand(n, 3, 4, 6
 local = frames[s:e] * 2.0               # the "forward": independent per frame
 full = shard.gather_frames(local, n)
 assert full.shape == (n, 3, 4, 6) and torch.equal(full, frames * 2.0), (rank, full[:, 0, 0, 0])
+# the bench's overlapped per-step gather (equal shards, one all_gather_into_tensor per step, double-buffered)
+og = shard.OverlappedGather(4)
+for step in range(3):
+    mine = torch.full((2, 3, 4, 6), float(10 * step + rank))
+    og.submit(mine)
+got = og.wait()
+want = torch.cat([torch.full((2, 3, 4, 6), float(20 + r)) for r in range(world)])
+assert got.shape == (4, 3, 4, 6) and torch.equal(got, want), (rank, got[:, 0, 0, 0])
 t = shard.max_over_ranks(1.0 + rank)
 assert t == float(world), t
 shard.barrier()
