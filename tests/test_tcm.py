@@ -369,9 +369,10 @@ def test_hip_tcm_forward_vs_reference_fp32():
 
 @pytest.mark.gpu
 def test_hip_tcm_forward_bf16_vs_reference():
-    """bf16 storage / fp32 accumulate against the fp32 reference fixture (models/tcm.py:481-485's dict).  Floors: the latent y
-    (before any rounding) >= 45 dB; means / scales (downstream of ste_round: isolated half-integer flips move whole latents
-    by 1) >= 30 dB; x_hat >= 30 dB; total rate sum(-log2 lik_y) + sum(-log2 lik_z) within 3 % of the reference's."""
+    """bf16 storage / fp32 accumulate against the fp32 reference fixture (models/tcm.py:481-485's dict).  Floors (measured on
+    MI355X: y 61.5, means 60.9, scales 58.9, x_hat 43.5 dB, rate delta 0.07 %): the latent y (before any rounding) >= 55 dB;
+    means / scales (downstream of ste_round: an isolated half-integer flip moves a latent by 1) >= 50 dB; x_hat >= 38 dB;
+    total rate sum(-log2 lik_y) + sum(-log2 lik_z) within 0.5 % of the reference's."""
     g = load_golden("tcm_forward_n32")
     m, _ = _mirror_with_det_params(g)
     m = m.to("cuda", torch.bfloat16).eval()
@@ -383,8 +384,8 @@ def test_hip_tcm_forward_bf16_vs_reference():
         assert tuple(v.shape) == tuple(g["out." + k].shape), k
     assert float(out["lik_y"].min()) >= 0.99e-9 and float(out["lik_y"].max()) <= 1.0 + 1e-6      # the 1e-9 bound in fp32
     rep = _codec_bf16_report(out, g, ("y", "means", "scales", "x_hat"))
-    assert rep["y"] >= 45.0 and rep["means"] >= 30.0 and rep["scales"] >= 30.0 and rep["x_hat"] >= 30.0, rep
-    assert rep["rate_rel"] <= 0.03, rep
+    assert rep["y"] >= 55.0 and rep["means"] >= 50.0 and rep["scales"] >= 50.0 and rep["x_hat"] >= 38.0, rep
+    assert rep["rate_rel"] <= 0.005, rep
 
 
 @pytest.mark.gpu
@@ -523,7 +524,8 @@ def test_hip_raw_codec_forward_vs_reference_fp32():
 @pytest.mark.gpu
 def test_hip_raw_codec_forward_bf16_vs_reference():
     """cfg5's dtype: bf16 raw_compression_tcm_final.forward against the fp32 reference fixture (models/raw2bit.py:1848-1855's
-    dict) -- same floors as the TCM test, plus the condition maps lft / lsc >= 40 dB."""
+    dict) -- same floors as the TCM test (measured: y 59.3, means 59.1, scales 57.3, x_hat 45.8 dB, rate delta 0.07 %), plus the
+    condition maps lft / lsc >= 55 dB (measured 64 / 66)."""
     g = load_golden("raw2bit_final_forward_n32")
     m, _ = _raw_mirror(g)
     m = m.to("cuda", torch.bfloat16).eval()
@@ -534,6 +536,6 @@ def test_hip_raw_codec_forward_bf16_vs_reference():
         assert torch.isfinite(v.float()).all(), k
         assert tuple(v.shape) == tuple(g["out." + k].shape), k
     rep = _codec_bf16_report(out, g, ("y", "means", "scales", "x_hat", "lft", "lsc_s8"))
-    assert rep["y"] >= 45.0 and rep["means"] >= 30.0 and rep["scales"] >= 30.0 and rep["x_hat"] >= 30.0, rep
-    assert rep["lft"] >= 40.0 and rep["lsc_s8"] >= 40.0, rep
-    assert rep["rate_rel"] <= 0.03, rep
+    assert rep["y"] >= 55.0 and rep["means"] >= 50.0 and rep["scales"] >= 50.0 and rep["x_hat"] >= 38.0, rep
+    assert rep["lft"] >= 55.0 and rep["lsc_s8"] >= 55.0, rep
+    assert rep["rate_rel"] <= 0.005, rep
