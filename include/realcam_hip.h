@@ -315,6 +315,27 @@ int rc_gfm_vector(const float* d_vec, int batch, int cond_c, int nf, int c,
  * rc_gma_kv: softmax over the N tokens fused with k^T v (groupmix.py:187-188): per-channel max pass, exp-sum +
  *   k^T v pass, fixed-order merge: ktv (B,heads,Ch,Ch) fp32 = scale * softmax_N(k)^T v.  d_scratch: rc_gma_kv_scratch_bytes().
  * rc_gma_apply: out (B,N,C) = [ q.ktv + q*convv | loc ]  (groupmix.py:189-194). */
+/* ---- a15/a16 fused per-token stages of GMA_Block for dim 80 (5 x 16, 8 heads), bf16 (csrc/gma_fused.hip) --------------------
+ * Chain weights: an nn.Linear / 1x1 conv weight (cout, cin) fp32 host -> bf16 MFMA fragments whose output rows are ordered so
+ * that a layer's accumulator fragments are the next layer's B fragments (rc_chain_packed_bytes bytes); biases fp32 in the same
+ * row order, zero padded (rc_chain_packed_rows(cout) floats; b NULL: zeros).  Host functions.
+ * rc_gma_ln_qkv: qkv (tokens, 240) = Linear_qkv(LayerNorm1(x (tokens, 80)))                        (groupmix.py:178 after :293)
+ * rc_gma_tail:   y = [ q.ktv + q*convv | loc ] (groupmix.py:189-194); x2 = proj(y) + x (:197, :294); x3 = x2 + fc2(GELU(fc1(LN2(x2))))
+ *                (:296-298); cout == 0: out (tokens, 80) = x3; cout == 192: out (tokens, 192) = Conv1x1(x3) + res (the cfg3 net's
+ *                gma_out + d1, realcamnet_amd/LiteISP.py).  d_ktv (B,8,8,8) fp32 from rc_gma_kv; d_ktv_frags: B * 8 KiB scratch.
+ * Rounding points are those of the layer-by-layer path (bf16 wherever that path stored a tensor), accumulation fp32; GELU's erf is
+ * evaluated to 1.5e-7 absolute (far below the bf16 rounding of its result). */
+size_t rc_chain_packed_bytes(int cin, int cout);
+int rc_chain_packed_rows(int cout);
+int rc_chain_pack_weights(const float* w, int cin, int cout, void* dst);
+int rc_chain_pack_bias(const float* b, int cout, float* dst);
+int rc_gma_ln_qkv(const void* d_x, void* d_qkv, long long tokens, const void* d_wpacked, const float* d_bias_packed,
+                  const float* d_ln_gamma, const float* d_ln_beta, float eps, void* stream);
+int rc_gma_tail(const void* d_qkvp, const void* d_convv, const void* d_loc, const void* d_x, const float* d_ktv, void* d_ktv_frags,
+                int batch, int n_tok, const void* d_w_proj, const float* d_b_proj, const float* d_ln_gamma, const float* d_ln_beta,
+                float eps, const void* d_w_fc1, const float* d_b_fc1, const void* d_w_fc2, const float* d_b_fc2, const void* d_res,
+                const void* d_w_out, const float* d_b_out, int cout, void* d_out, void* stream);
+
 int rc_dwconv2d(const void* d_x, int x_stride_c, int x_c0, void* d_y, int y_stride_c, int y_c0, int dtype,
                 int batch, int H, int W, int n_ch, int ksize, const float* d_wT, int n_w, const float* d_bias,
                 int n_rep, int x_rep_stride, int y_rep_stride, int w_rep_stride, int add_identity,

@@ -69,6 +69,8 @@ template <> struct Vec16<bf16_t> {
     // two values per v_cvt_pk_bf16_f32 (round-nearest-even, the same instruction the scalar cast selects): converting them one
     // at a time costs two conversions and a v_perm per pair.  Written as an instruction because the vector-typed
     // __builtin_convertvector form keeps the callers' unrolled value arrays from being promoted to registers (scratch).
+    // HAZARD: inline asm is opaque to the compiler's hazard recogniser -- never pass an MFMA accumulator straight in (no wait states
+    // are inserted for the MFMA result latency); route it through a real VALU op first (the epilogues' bias add / activation do).
     __device__ static __forceinline__ uint32_t rne2(float lo, float hi) {
         uint32_t r;
         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));

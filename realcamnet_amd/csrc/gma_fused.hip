@@ -1,0 +1,519 @@
+// GroupMix block, fused per-token stages for the cfg3 shape (dim 80 = 5 x 16, 8 heads, bf16) -- upstream models/groupmix.py:159-299.
+//
+// Every stage of GMA_Block that is a per-token map (LayerNorm, the Linear layers, the attention read-out
+// q.(softmax(k)^T v) + q*crpe(v), GELU, residual adds) runs here as ONE pass with the token's activations held in registers:
+//   gma_ln_qkv_kernel : x -> LayerNorm1 -> qkv Linear (80 -> 240)                                   (groupmix.py:178, 293)
+//   gma_tail_kernel   : [q, convv, loc, k^T v] -> attention read-out -> proj + x -> LayerNorm2 -> fc1 -> GELU -> fc2 + .
+//                       [-> Conv1x1 80 -> Cout + residual: the cfg3 net's gma_out]                 (groupmix.py:189-199, 296-298)
+// The layer-by-layer form (rc_gma_apply, rc_layernorm, 1x1 rc_conv2d x4) moved 17 GB per step for these stages (the 320-channel
+// MLP hidden map alone 5.3 GB); fused, each token's bytes cross HBM once: q/convv/loc/x (+ d1) in, the result out.
+//
+// Register-resident chain of MFMA layers.  A wave owns 64 consecutive tokens = 4 column tiles of v_mfma_f32_16x16x32_bf16
+// (B operand = activations: lane (n = lane & 15, g = lane >> 4) holds channels 32 s + 8 g + 0..7 of token n for K-step s;
+// a trailing 16 channels go through v_mfma_f32_16x16x16_bf16: channels C0 + 4 g + 0..3).  A layer's weights are packed so that
+// MFMA row R = 4 g + j of output tile m is channel 32 (m >> 1) + 8 g + 4 (m & 1) + j: the C/D fragments of output tiles
+// (2 p, 2 p + 1) in lane (n, g) are then exactly channels 32 p + 8 g + 0..7 of token n -- the B fragment of the NEXT layer's
+// K-step p after fp32 -> bf16 packing, with no cross-lane movement (an unpaired last tile keeps natural order 16 m + R and feeds
+// the K = 16 form).  HBM loads / stores use the same map: 16 bytes per lane, 64 contiguous bytes per token and K-step.
+// Weights (packed by rc_chain_pack_weights) sit in LDS for the whole launch; each A fragment read (ds_read_b128) feeds 4 MFMAs.
+// Rounding points are those of the layer-by-layer path (every tensor that path stored in bf16 is rounded to bf16 here too);
+// accumulation is fp32.  LayerNorm statistics: per-lane partial sums + two xor-shuffles (the 4 lanes of a token).
+#include "common.hpp"
+
+namespace rc {
+namespace gf {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kNT = 4;                       // column tiles (16 tokens each) per wave
+constexpr int kC = 80, kCT = 64, kSEG = 16, kHID = 320;
+
+__host__ __device__ constexpr int tile_bytes(int cin) { return (cin / 32) * 1024 + ((cin % 32) ? 512 : 0); }
+__host__ __device__ constexpr int n_mtiles(int cout) { return (cout + 15) / 16; }
+__host__ __device__ constexpr int row_channel(int m, int R, int mt) {
+    return (m < (mt & ~1)) ? 32 * (m >> 1) + 8 * (R >> 2) + 4 * (m & 1) + (R & 3) : 16 * m + R;
+}
+
+template <int C> struct Act {                // one token column tile's activations in B-operand layout
+    static constexpr int KS = C / 32;
+    static constexpr bool TAIL = (C % 32) != 0;
+    uint4 f[KS > 0 ? KS : 1];
+    uint2 t;
+};
+
+__device__ __forceinline__ void mma32(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(const uint2& a, const uint2& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+// fp32 pair -> packed bf16: Vec16::rne2, ONE v_cvt_pk_bf16_f32 written as inline asm (the vector-typed __builtin_convertvector form
+// of the same instruction cost this kernel ~120 spilled VGPRs).  HAZARD RULE: an inline-asm instruction is opaque to the compiler's
+// hazard recogniser, so it must never read an MFMA accumulator directly -- the first build of this file did (accumulators seeded
+// with bias + residual, packed straight after the MFMA chain): the conversion issued inside the MFMA's result latency and packed
+// stale register contents (random tokens came out as garbage / NaN, and only for some instruction schedules).  Every pack below
+// therefore takes the result of a real VALU instruction (the bias add is done AFTER the chain, on purpose).
+__device__ __forceinline__ uint32_t pk(float lo, float hi) { return Vec16<bf16_t>::rne2(lo, hi); }
+__device__ __forceinline__ uint4 pack_pair(const f32x4& lo, const f32x4& hi) {
+    return make_uint4(pk(lo[0], lo[1]), pk(lo[2], lo[3]), pk(hi[0], hi[1]), pk(hi[2], hi[3]));
+}
+__device__ __forceinline__ uint2 pack_tail(const f32x4& v) { return make_uint2(pk(v[0], v[1]), pk(v[2], v[3])); }
+// bf16 pairs -> fp32, as vectors (no float arrays: with the vector-typed conversion above they would not be promoted to registers)
+__device__ __forceinline__ f32x4 up_lo(const uint4& r) {
+    return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+__device__ __forceinline__ f32x4 up_hi(const uint4& r) {
+    return f32x4{__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u), __uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)};
+}
+__device__ __forceinline__ f32x4 up_tail(const uint2& r) {
+    return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+}
+__device__ __forceinline__ f32x4 ld4(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    return f32x4{t.x, t.y, t.z, t.w};
+}
+
+// acc[g][nt] += W[tiles m0 .. m0+MG) . in   (weights of a layer with CIN inputs at LDS address w, fragment order)
+template <int CIN, int MG>
+__device__ __forceinline__ void gemm_tiles(const char* w, int m0, int lane, const Act<CIN> (&in)[kNT], f32x4 (&acc)[MG][kNT]) {
+    constexpr int KS = CIN / 32, TB = tile_bytes(CIN);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        uint4 a[MG];
+#pragma unroll
+        for (int g = 0; g < MG; ++g) a[g] = *reinterpret_cast<const uint4*>(w + (m0 + g) * TB + s * 1024 + lane * 16);
+#pragma unroll
+        for (int g = 0; g < MG; ++g)
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) mma32(a[g], in[nt].f[s], acc[g][nt]);
+    }
+    if constexpr ((CIN % 32) != 0) {
+        uint2 a[MG];
+#pragma unroll
+        for (int g = 0; g < MG; ++g) a[g] = *reinterpret_cast<const uint2*>(w + (m0 + g) * TB + KS * 1024 + lane * 8);
+#pragma unroll
+        for (int g = 0; g < MG; ++g)
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) mma16(a[g], in[nt].t, acc[g][nt]);
+    }
+}
+
+template <int MG> __device__ __forceinline__ void zero(f32x4 (&acc)[MG][kNT]) {
+#pragma unroll
+    for (int g = 0; g < MG; ++g)
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) acc[g][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// bias of this lane's 4 rows of output tile m (packed by rc_chain_pack_bias: [tile][row])
+__device__ __forceinline__ f32x4 bias4(const float* b, int m, int g) { return ld4(b + m * 16 + 4 * g); }
+
+// 16-byte loads of a token row in B-operand layout (pointer p = token's first channel)
+template <int C> __device__ __forceinline__ void load_act(const bf16_t* p, int g, Act<C>& a) {
+#pragma unroll
+    for (int s = 0; s < Act<C>::KS; ++s) a.f[s] = *reinterpret_cast<const uint4*>(p + 32 * s + 8 * g);
+    if constexpr (Act<C>::TAIL) a.t = *reinterpret_cast<const uint2*>(p + 32 * Act<C>::KS + 4 * g);
+}
+template <int C> __device__ __forceinline__ void store_act(bf16_t* p, int g, const Act<C>& a) {
+#pragma unroll
+    for (int s = 0; s < Act<C>::KS; ++s) *reinterpret_cast<uint4*>(p + 32 * s + 8 * g) = a.f[s];
+    if constexpr (Act<C>::TAIL) *reinterpret_cast<uint2*>(p + 32 * Act<C>::KS + 4 * g) = a.t;
+}
+
+// nn.LayerNorm over the 80 channels of each token (two-pass like rc_layernorm: mean, then centred second moment);
+// gamma / beta in natural channel order at LDS address gb (gamma[80] | beta[80])
+__device__ __forceinline__ void layernorm80(const Act<kC> (&in)[kNT], Act<kC> (&out)[kNT], const float* gb, int g, float eps) {
+    // this lane's 20 channels: 8 g + 0..7, 32 + 8 g + 0..7, 64 + 4 g + 0..3
+    const f32x4 g0 = ld4(gb + 8 * g), g1 = ld4(gb + 8 * g + 4), g2 = ld4(gb + 32 + 8 * g), g3 = ld4(gb + 32 + 8 * g + 4), g4 = ld4(gb + 64 + 4 * g);
+    const float* bb = gb + kC;
+    const f32x4 e0 = ld4(bb + 8 * g), e1 = ld4(bb + 8 * g + 4), e2 = ld4(bb + 32 + 8 * g), e3 = ld4(bb + 32 + 8 * g + 4), e4 = ld4(bb + 64 + 4 * g);
+#pragma unroll
+    for (int nt = 0; nt < kNT; ++nt) {
+        const f32x4 v0 = up_lo(in[nt].f[0]), v1 = up_hi(in[nt].f[0]), v2 = up_lo(in[nt].f[1]), v3 = up_hi(in[nt].f[1]), v4 = up_tail(in[nt].t);
+        const f32x4 sv = ((v0 + v1) + (v2 + v3)) + v4;
+        float s = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        const float mean = s / (float)kC;
+        const f32x4 d0 = v0 - mean, d1 = v1 - mean, d2 = v2 - mean, d3 = v3 - mean, d4 = v4 - mean;
+        const f32x4 qv = ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + d4 * d4;
+        float q = (qv[0] + qv[1]) + (qv[2] + qv[3]);
+        q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+        const float rstd = 1.f / sqrtf(q / (float)kC + eps);
+        out[nt].f[0] = pack_pair(d0 * rstd * g0 + e0, d1 * rstd * g1 + e1);
+        out[nt].f[1] = pack_pair(d2 * rstd * g2 + e2, d3 * rstd * g3 + e3);
+        out[nt].t = pack_tail(d4 * rstd * g4 + e4);
+    }
+}
+
+// exact-erf GELU to 1.5e-7 absolute in erf (Abramowitz-Stegun 7.1.26), far below the bf16 rounding that follows:
+// 0.5 v (1 + erf(v / sqrt 2)),  erf(z) = sign(z) (1 - (a1 t + .. + a5 t^5) exp(-z^2)),  t = 1 / (1 + p |z|)
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float z = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.f - poly * __expf(-z * z);                        // erf(|z|)
+    return 0.5f * v * (1.f + copysignf(e, v));
+}
+
+// ---- LayerNorm1 + qkv ------------------------------------------------------------------------------------------------------------
+constexpr int kQkvThreads = 256;
+__global__ __launch_bounds__(kQkvThreads) void gma_ln_qkv_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ qkv, size_t tokens,
+                                                                   const void* __restrict__ w_qkv, const float* __restrict__ b_qkv,
+                                                                   const float* __restrict__ ln_g, const float* __restrict__ ln_b, float eps) {
+    constexpr int MT = n_mtiles(3 * kC), TB = tile_bytes(kC);          // 15 tiles of 2560 bytes
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* s_w = lds;
+    float* s_bias = reinterpret_cast<float*>(lds + MT * TB);            // [MT*16]
+    float* s_gb = s_bias + MT * 16;                                     // gamma[80] | beta[80]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < MT * TB / 16; i += kQkvThreads) reinterpret_cast<uint4*>(s_w)[i] = reinterpret_cast<const uint4*>(w_qkv)[i];
+    for (int i = tid; i < MT * 16; i += kQkvThreads) s_bias[i] = b_qkv ? b_qkv[i] : 0.f;
+    for (int i = tid; i < kC; i += kQkvThreads) { s_gb[i] = ln_g[i]; s_gb[kC + i] = ln_b[i]; }
+    __syncthreads();
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const size_t n_tiles = (tokens + 63) / 64, wave = (size_t)blockIdx.x * (kQkvThreads / 64) + (tid >> 6), n_waves = (size_t)gridDim.x * (kQkvThreads / 64);
+    for (size_t tile = wave; tile < n_tiles; tile += n_waves) {
+        Act<kC> xin[kNT], n1[kNT];
+        size_t tok[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            const size_t t = tile * 64 + 16 * nt + n;
+            tok[nt] = t < tokens ? t : tokens - 1;
+            load_act<kC>(x + tok[nt] * kC, g, xin[nt]);
+        }
+        layernorm80(xin, n1, s_gb, g, eps);
+#pragma unroll
+        for (int p = 0; p < MT / 2; ++p) {
+            f32x4 acc[2][kNT];
+            zero<2>(acc);
+            gemm_tiles<kC, 2>(s_w, 2 * p, lane, n1, acc);
+            const f32x4 b0 = bias4(s_bias, 2 * p, g), b1 = bias4(s_bias, 2 * p + 1, g);
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt)
+                if (tile * 64 + 16 * nt + n < tokens)
+                    *reinterpret_cast<uint4*>(qkv + tok[nt] * (3 * kC) + 32 * p + 8 * g) = pack_pair(acc[0][nt] + b0, acc[1][nt] + b1);
+        }
+        if constexpr (MT & 1) {
+            f32x4 acc[1][kNT];
+            zero<1>(acc);
+            gemm_tiles<kC, 1>(s_w, MT - 1, lane, n1, acc);
+            const f32x4 b0 = bias4(s_bias, MT - 1, g);
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt)
+                if (tile * 64 + 16 * nt + n < tokens)
+                    *reinterpret_cast<uint2*>(qkv + tok[nt] * (3 * kC) + 16 * (MT - 1) + 4 * g) = pack_tail(acc[0][nt] + b0);
+        }
+    }
+}
+
+// ---- k^T v as MFMA A fragments: [b][out tile m (4)][K-step s (2)][lane][8 bf16], block-diagonal 64 x 64 --------------------------
+__global__ void gma_ktv_pack_kernel(const float* __restrict__ ktv /* (B, 8, 8, 8) [h][i][j] */, uint4* __restrict__ frags) {
+    const int b = blockIdx.x, frag = threadIdx.x >> 6, lane = threadIdx.x & 63;   // 512 threads: 8 fragments
+    const int m = frag >> 1, s = frag & 1, R = lane & 15, q = lane >> 4;
+    const int jo = row_channel(m, R, 4);                                          // output channel h*8 + j
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ki = 32 * s + 8 * q + i;                                        // input channel h*8 + i
+        v[i] = (ki >> 3) == (jo >> 3) ? ktv[(((size_t)b * 8 + (jo >> 3)) * 8 + (ki & 7)) * 8 + (jo & 7)] : 0.f;
+    }
+    frags[((size_t)b * 8 + frag) * 64 + lane] = make_uint4(pk(v[0], v[1]), pk(v[2], v[3]), pk(v[4], v[5]), pk(v[6], v[7]));
+}
+
+// ---- attention read-out + proj + LN2 + MLP [+ output conv] ---------------------------------------------------------------------------
+struct TailArgs {
+    const bf16_t* qkvp; int q_stride;        // q = qkvp[tok * q_stride + 0..64)
+    const bf16_t* convv; const bf16_t* loc; const bf16_t* x;
+    const bf16_t* res;                        // COUT > 0: residual of the output conv (tokens, COUT)
+    bf16_t* out;                              // (tokens, COUT > 0 ? COUT : 80)
+    const uint4* ktv_frags;
+    const void* w_proj; const void* w_fc1; const void* w_fc2; const void* w_out;
+    const float* b_proj; const float* b_fc1; const float* b_fc2; const float* b_out;
+    const float* ln_g; const float* ln_b; float eps;
+    int n_tok; int batch;
+};
+
+constexpr int kTailWaves = 8, kTailThreads = 64 * kTailWaves;
+template <int COUT>
+__host__ __device__ constexpr int tail_lds_bytes() {
+    return n_mtiles(kC) * tile_bytes(kC) + n_mtiles(kHID) * tile_bytes(kC) + n_mtiles(kC) * tile_bytes(kHID) + n_mtiles(COUT) * tile_bytes(kC) +
+           4 * (n_mtiles(kC) * 16 * 2 + n_mtiles(kHID) * 16 + n_mtiles(COUT) * 16 + 2 * kC);
+}
+
+template <int COUT>
+__global__ __launch_bounds__(kTailThreads, 2) void gma_tail_kernel(TailArgs a) {
+    constexpr int MT80 = n_mtiles(kC), MTH = n_mtiles(kHID), MTO = n_mtiles(COUT);
+    constexpr int TB80 = tile_bytes(kC), TBH = tile_bytes(kHID);
+    static_assert(COUT % 32 == 0, "output width must be a whole number of tile pairs");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* s_proj = lds;
+    char* s_fc1 = s_proj + MT80 * TB80;
+    char* s_fc2 = s_fc1 + MTH * TB80;
+    char* s_out = s_fc2 + MT80 * TBH;
+    float* s_bproj = reinterpret_cast<float*>(s_out + MTO * TB80);
+    float* s_bfc1 = s_bproj + MT80 * 16;
+    float* s_bfc2 = s_bfc1 + MTH * 16;
+    float* s_bout = s_bfc2 + MT80 * 16;
+    float* s_gb = s_bout + MTO * 16;
+    const int tid = threadIdx.x;
+    auto stage = [&](char* dst, const void* src, int bytes) {
+        for (int i = tid; i < bytes / 16; i += kTailThreads) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    };
+    stage(s_proj, a.w_proj, MT80 * TB80); stage(s_fc1, a.w_fc1, MTH * TB80); stage(s_fc2, a.w_fc2, MT80 * TBH);
+    if constexpr (COUT > 0) stage(s_out, a.w_out, MTO * TB80);
+    for (int i = tid; i < MT80 * 16; i += kTailThreads) { s_bproj[i] = a.b_proj[i]; s_bfc2[i] = a.b_fc2[i]; }
+    for (int i = tid; i < MTH * 16; i += kTailThreads) s_bfc1[i] = a.b_fc1[i];
+    if constexpr (COUT > 0) for (int i = tid; i < MTO * 16; i += kTailThreads) s_bout[i] = a.b_out[i];
+    for (int i = tid; i < kC; i += kTailThreads) { s_gb[i] = a.ln_g[i]; s_gb[kC + i] = a.ln_b[i]; }
+    __syncthreads();
+
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int tpi = (a.n_tok + 63) / 64;                                  // wave tiles per image (a tile never straddles images)
+    const int n_tiles = tpi * a.batch;
+    for (int tile = blockIdx.x * kTailWaves + (tid >> 6); tile < n_tiles; tile += gridDim.x * kTailWaves) {
+        const int b = tile / tpi, t0 = (tile - b * tpi) * 64;
+        size_t tok[kNT];
+        bool ok[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            const int t = t0 + 16 * nt + n;
+            ok[nt] = t < a.n_tok;
+            tok[nt] = (size_t)b * a.n_tok + (ok[nt] ? t : a.n_tok - 1);
+        }
+        Act<kC> x2[kNT];                                                  // starts as x, becomes x2 = proj(y) + x (bf16-rounded)
+        Act<kC> y[kNT];
+        {   // ---- attention read-out: y[h*8+j] = sum_i q[h*8+i] ktv[h][i][j] + q[h*8+j] convv[h*8+j]; y[64..80) = loc --------------
+            Act<kCT> q[kNT], cv[kNT];
+            Act<kSEG> lc[kNT];
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                load_act<kCT>(a.qkvp + tok[nt] * a.q_stride, g, q[nt]);
+                load_act<kCT>(a.convv + tok[nt] * kCT, g, cv[nt]);
+                load_act<kSEG>(a.loc + tok[nt] * kSEG, g, lc[nt]);
+                load_act<kC>(a.x + tok[nt] * kC, g, x2[nt]);
+            }
+            f32x4 att[4][kNT];
+            zero<4>(att);
+            const uint4* kf = a.ktv_frags + (size_t)b * 8 * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const uint4 af = kf[(m * 2 + s) * 64];
+#pragma unroll
+                    for (int nt = 0; nt < kNT; ++nt) mma32(af, q[nt].f[s], att[m][nt]);
+                }
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+                    y[nt].f[p] = pack_pair(att[2 * p][nt] + up_lo(q[nt].f[p]) * up_lo(cv[nt].f[p]),
+                                           att[2 * p + 1][nt] + up_hi(q[nt].f[p]) * up_hi(cv[nt].f[p]));
+                y[nt].t = lc[nt].t;
+            }
+        }
+        Act<kC> n2[kNT];
+        f32x4 oa[2][kNT], ob[2][kNT], oc[1][kNT];                         // fc2 accumulators, seeded with the residual x2 below
+        {   // ---- proj + bias + x -> x2 (rounded to bf16 where the layer-by-layer path stored it); accumulators start at the residual x ----
+            f32x4 pa[2][kNT], pb[2][kNT], pc[1][kNT];
+            const f32x4 b0 = bias4(s_bproj, 0, g), b1 = bias4(s_bproj, 1, g), b2 = bias4(s_bproj, 2, g), b3 = bias4(s_bproj, 3, g),
+                        b4 = bias4(s_bproj, 4, g);
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                pa[0][nt] = up_lo(x2[nt].f[0]); pa[1][nt] = up_hi(x2[nt].f[0]); pb[0][nt] = up_lo(x2[nt].f[1]);
+                pb[1][nt] = up_hi(x2[nt].f[1]); pc[0][nt] = up_tail(x2[nt].t);
+            }
+            gemm_tiles<kC, 2>(s_proj, 0, lane, y, pa);
+            gemm_tiles<kC, 2>(s_proj, 2, lane, y, pb);
+            gemm_tiles<kC, 1>(s_proj, 4, lane, y, pc);
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                x2[nt].f[0] = pack_pair(pa[0][nt] + b0, pa[1][nt] + b1); x2[nt].f[1] = pack_pair(pb[0][nt] + b2, pb[1][nt] + b3);
+                x2[nt].t = pack_tail(pc[0][nt] + b4);
+                // the bf16-rounded x2 is what LayerNorm2 and the MLP residual see
+                oa[0][nt] = up_lo(x2[nt].f[0]); oa[1][nt] = up_hi(x2[nt].f[0]); ob[0][nt] = up_lo(x2[nt].f[1]);
+                ob[1][nt] = up_hi(x2[nt].f[1]); oc[0][nt] = up_tail(x2[nt].t);
+            }
+            layernorm80(x2, n2, s_gb, g, a.eps);
+        }
+        // ---- MLP: x2 + fc2(gelu(fc1(n2))) accumulated over 10 chunks of 32 hidden channels (= one fc2 K-step each) ----------------------
+#pragma unroll 1
+        for (int hc = 0; hc < kHID / 32; ++hc) {
+            f32x4 h[2][kNT];
+            const f32x4 c0 = bias4(s_bfc1, 2 * hc, g), c1 = bias4(s_bfc1, 2 * hc + 1, g);
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) { h[0][nt] = c0; h[1][nt] = c1; }
+            gemm_tiles<kC, 2>(s_fc1, 2 * hc, lane, n2, h);
+            uint4 hb[kNT];
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                f32x4 u = h[0][nt], w = h[1][nt];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { u[j] = gelu_erf(u[j]); w[j] = gelu_erf(w[j]); }
+                hb[nt] = pack_pair(u, w);
+            }
+            const char* w2 = s_fc2 + hc * 1024 + lane * 16;
+            const uint4 a0 = *reinterpret_cast<const uint4*>(w2), a1 = *reinterpret_cast<const uint4*>(w2 + TBH),
+                        a2 = *reinterpret_cast<const uint4*>(w2 + 2 * TBH), a3 = *reinterpret_cast<const uint4*>(w2 + 3 * TBH),
+                        a4 = *reinterpret_cast<const uint4*>(w2 + 4 * TBH);
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                mma32(a0, hb[nt], oa[0][nt]); mma32(a1, hb[nt], oa[1][nt]); mma32(a2, hb[nt], ob[0][nt]);
+                mma32(a3, hb[nt], ob[1][nt]); mma32(a4, hb[nt], oc[0][nt]);
+            }
+        }
+        Act<kC> x3[kNT];
+        {
+            const f32x4 c0 = bias4(s_bfc2, 0, g), c1 = bias4(s_bfc2, 1, g), c2 = bias4(s_bfc2, 2, g), c3 = bias4(s_bfc2, 3, g),
+                        c4 = bias4(s_bfc2, 4, g);
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                x3[nt].f[0] = pack_pair(oa[0][nt] + c0, oa[1][nt] + c1); x3[nt].f[1] = pack_pair(ob[0][nt] + c2, ob[1][nt] + c3);
+                x3[nt].t = pack_tail(oc[0][nt] + c4);
+            }
+        }
+        if constexpr (COUT == 0) {
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt)
+                if (ok[nt]) store_act<kC>(a.out + tok[nt] * kC, g, x3[nt]);
+        } else {   // ---- output conv 80 -> COUT + bias + residual, one tile pair (32 channels) at a time; residual loads run one pair ahead
+            uint4 rcur[kNT], rnext[kNT];
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) rcur[nt] = *reinterpret_cast<const uint4*>(a.res + tok[nt] * COUT + 8 * g);
+#pragma unroll
+            for (int p = 0; p < COUT / 32; ++p) {
+                if (p + 1 < COUT / 32) {
+#pragma unroll
+                    for (int nt = 0; nt < kNT; ++nt) rnext[nt] = *reinterpret_cast<const uint4*>(a.res + tok[nt] * COUT + 32 * (p + 1) + 8 * g);
+                }
+                f32x4 o[2][kNT];
+                const f32x4 b0 = bias4(s_bout, 2 * p, g), b1 = bias4(s_bout, 2 * p + 1, g);
+#pragma unroll
+                for (int nt = 0; nt < kNT; ++nt) {
+                    o[0][nt] = up_lo(rcur[nt]); o[1][nt] = up_hi(rcur[nt]);
+                }
+                gemm_tiles<kC, 2>(s_out, 2 * p, lane, x3, o);
+#pragma unroll
+                for (int nt = 0; nt < kNT; ++nt) {
+                    if (ok[nt]) *reinterpret_cast<uint4*>(a.out + tok[nt] * COUT + 32 * p + 8 * g) = pack_pair(o[0][nt] + b0, o[1][nt] + b1);
+                    rcur[nt] = rnext[nt];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace gf
+}  // namespace rc
+
+using namespace rc;
+using namespace rc::gf;
+
+extern "C" {
+
+size_t rc_chain_packed_bytes(int cin, int cout) {
+    if (cin < 16 || cin % 16 || cout < 1) return 0;
+    return (size_t)n_mtiles(cout) * tile_bytes(cin);
+}
+
+int rc_chain_packed_rows(int cout) { return cout >= 1 ? n_mtiles(cout) * 16 : 0; }
+
+int rc_chain_pack_weights(const float* w, int cin, int cout, void* dst) {
+    RC_REQUIRE(w && dst, "rc_chain_pack_weights: null pointer");
+    RC_REQUIRE(cin >= 16 && cin % 16 == 0 && cout >= 1, "rc_chain_pack_weights: cin must be a multiple of 16");
+    const int mt = n_mtiles(cout), ks = cin / 32, tb = tile_bytes(cin);
+    uint16_t* out = static_cast<uint16_t*>(dst);
+    for (int m = 0; m < mt; ++m) {
+        uint16_t* tile = out + (size_t)m * tb / 2;
+        for (int s = 0; s < ks; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int ch = row_channel(m, lane & 15, mt), q = lane >> 4;
+                for (int i = 0; i < 8; ++i)
+                    tile[(s * 64 + lane) * 8 + i] = ch < cout ? host_f32_to_bf16(w[(size_t)ch * cin + 32 * s + 8 * q + i]) : 0;
+            }
+        if (cin % 32)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int ch = row_channel(m, lane & 15, mt), q = lane >> 4;
+                for (int i = 0; i < 4; ++i)
+                    tile[ks * 512 + lane * 4 + i] = ch < cout ? host_f32_to_bf16(w[(size_t)ch * cin + 32 * ks + 4 * q + i]) : 0;
+            }
+    }
+    return RC_OK;
+}
+
+int rc_chain_pack_bias(const float* b, int cout, float* dst) {
+    RC_REQUIRE(dst && cout >= 1, "rc_chain_pack_bias: bad arguments");
+    const int mt = n_mtiles(cout);
+    for (int m = 0; m < mt; ++m)
+        for (int R = 0; R < 16; ++R) {
+            const int ch = row_channel(m, R, mt);
+            dst[m * 16 + R] = (b && ch < cout) ? b[ch] : 0.f;
+        }
+    return RC_OK;
+}
+
+int rc_gma_ln_qkv(const void* d_x, void* d_qkv, long long tokens, const void* d_wpacked, const float* d_bias_packed,
+                  const float* d_ln_gamma, const float* d_ln_beta, float eps, void* stream) {
+    RC_REQUIRE(d_x && d_qkv && d_wpacked && d_ln_gamma && d_ln_beta, "rc_gma_ln_qkv: null pointer");
+    RC_REQUIRE(tokens >= 1, "rc_gma_ln_qkv: no tokens");
+    constexpr int MT = n_mtiles(3 * kC);
+    const size_t lds = (size_t)MT * tile_bytes(kC) + 4 * (MT * 16 + 2 * kC);
+    int dev = 0;
+    RC_HIP_CHECK(hipGetDevice(&dev));
+    static bool attr[64] = {};                                            // function attributes are per device
+    if (dev >= 0 && dev < 64 && !attr[dev]) {
+        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gma_ln_qkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr[dev] = true;
+    }
+    const size_t n_tiles = ((size_t)tokens + 63) / 64;
+    size_t blocks = (n_tiles + 3) / 4;
+    if (blocks > 256 * 3) blocks = 256 * 3;
+    hipLaunchKernelGGL(gma_ln_qkv_kernel, dim3((unsigned)blocks), dim3(kQkvThreads), lds, as_stream(stream), static_cast<const bf16_t*>(d_x),
+                       static_cast<bf16_t*>(d_qkv), (size_t)tokens, d_wpacked, d_bias_packed, d_ln_gamma, d_ln_beta, eps);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_gma_tail(const void* d_qkvp, const void* d_convv, const void* d_loc, const void* d_x, const float* d_ktv, void* d_ktv_frags,
+                int batch, int n_tok, const void* d_w_proj, const float* d_b_proj, const float* d_ln_gamma, const float* d_ln_beta,
+                float eps, const void* d_w_fc1, const float* d_b_fc1, const void* d_w_fc2, const float* d_b_fc2, const void* d_res,
+                const void* d_w_out, const float* d_b_out, int cout, void* d_out, void* stream) {
+    RC_REQUIRE(d_qkvp && d_convv && d_loc && d_x && d_ktv && d_ktv_frags && d_w_proj && d_b_proj && d_ln_gamma && d_ln_beta && d_w_fc1 &&
+               d_b_fc1 && d_w_fc2 && d_b_fc2 && d_out, "rc_gma_tail: null pointer");
+    RC_REQUIRE(batch >= 1 && n_tok >= 1, "rc_gma_tail: bad shape");
+    RC_REQUIRE(cout == 0 || cout == 192, "rc_gma_tail: the output conv is built for 0 (none) or 192 channels");
+    if (cout) RC_REQUIRE(d_res && d_w_out && d_b_out, "rc_gma_tail: output conv needs residual, weights and bias");
+    TailArgs a;
+    a.qkvp = static_cast<const bf16_t*>(d_qkvp); a.q_stride = 3 * kCT;
+    a.convv = static_cast<const bf16_t*>(d_convv); a.loc = static_cast<const bf16_t*>(d_loc); a.x = static_cast<const bf16_t*>(d_x);
+    a.res = static_cast<const bf16_t*>(d_res); a.out = static_cast<bf16_t*>(d_out); a.ktv_frags = static_cast<const uint4*>(d_ktv_frags);
+    a.w_proj = d_w_proj; a.w_fc1 = d_w_fc1; a.w_fc2 = d_w_fc2; a.w_out = d_w_out;
+    a.b_proj = d_b_proj; a.b_fc1 = d_b_fc1; a.b_fc2 = d_b_fc2; a.b_out = d_b_out;
+    a.ln_g = d_ln_gamma; a.ln_b = d_ln_beta; a.eps = eps; a.n_tok = n_tok; a.batch = batch;
+    hipLaunchKernelGGL(gma_ktv_pack_kernel, dim3(batch), dim3(512), 0, as_stream(stream), d_ktv, static_cast<uint4*>(d_ktv_frags));
+    const long long n_tiles = (long long)((n_tok + 63) / 64) * batch;
+    int dev = 0;
+    RC_HIP_CHECK(hipGetDevice(&dev));
+    RC_REQUIRE(dev >= 0 && dev < 64, "rc_gma_tail: device index out of range");
+    static int cus[64] = {};
+    if (!cus[dev]) RC_HIP_CHECK(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    const int num_cus = cus[dev];
+    long long blocks = (n_tiles + kTailWaves - 1) / kTailWaves;
+    if (blocks > num_cus) blocks = num_cus;                               // one 8-wave block per CU (154 KB of LDS), grid-stride over tiles
+#define RC_TAIL_LAUNCH(CO)                                                                                                          \
+    do {                                                                                                                            \
+        static bool attr[64] = {};                                                                                                  \
+        if (!attr[dev]) {                                                                                                           \
+            RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gma_tail_kernel<CO>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                             160 * 1024));                                                                          \
+            attr[dev] = true;                                                                                                       \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((gma_tail_kernel<CO>), dim3((unsigned)blocks), dim3(kTailThreads), tail_lds_bytes<CO>(), as_stream(stream), a); \
+    } while (0)
+    if (cout == 0) RC_TAIL_LAUNCH(0); else RC_TAIL_LAUNCH(192);
+#undef RC_TAIL_LAUNCH
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+}  // extern "C"

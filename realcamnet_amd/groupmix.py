@@ -177,18 +177,25 @@ class EfficientAtt(nn.Module):
         trans_dim = dim // 5 * 4
         self.crpe = ConvRelPosEnc(Ch=trans_dim // num_heads, h=num_heads, window={3: 2, 5: 3, 7: 3})
 
-    def _nhwc(self, a, residual=None):
-        b, H, W, c = a.shape
+    def _geometry(self, c):
         heads = self.num_heads
         if c % 5 or (c // 5 * 4) % heads or sum(self.crpe.head_splits) != heads:
             raise ValueError(f"EfficientAtt: dim {c} / heads {heads} do not tile (upstream needs dim % 10 == 0, heads == 8)")
-        seg, ct = c // 5, c // 5 * 4
-        ch = ct // heads
-        qkv = ops.conv2d(a, self.qkv)                                   # (B,H,W,3C), channel = which*C + c
+        return c // 5, c // 5 * 4, (c // 5 * 4) // heads                # seg, ct, ch
+
+    def _context(self, qkv):
+        """qkv (B,H,W,3C) -> (qkvp, loc, convv, ktv): aggregators, crpe's depth-wise conv of v, softmax_N(k)^T v."""
+        seg, ct, ch = self._geometry(qkv.shape[-1] // 3)
         qkvp, loc = self.aggregator._run(qkv)
         convv = self.crpe._conv_v(qkvp)
-        ktv = torch.ops.realcam.gma_kv(qkvp, heads, ch, float(self.scale))
-        y = torch.ops.realcam.gma_apply(qkvp, convv, loc, ktv, heads, ch, seg)
+        ktv = torch.ops.realcam.gma_kv(qkvp, self.num_heads, ch, float(self.scale))
+        return qkvp, loc, convv, ktv
+
+    def _nhwc(self, a, residual=None):
+        seg, ct, ch = self._geometry(a.shape[-1])
+        qkv = ops.conv2d(a, self.qkv)                                   # (B,H,W,3C), channel = which*C + c
+        qkvp, loc, convv, ktv = self._context(qkv)
+        y = torch.ops.realcam.gma_apply(qkvp, convv, loc, ktv, self.num_heads, ch, seg)
         return ops.conv2d(y, self.proj, residual=residual)
 
     def forward(self, x, size):
@@ -227,12 +234,31 @@ class GMA_Block(nn.Module):
         mlp_hidden_dim = int(dim * mlp_ratio)
         self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
 
-    def _nhwc(self, a):
+    def _fusable(self, a) -> bool:
+        """csrc/gma_fused.hip is built for the cfg3 shape: dim 80 (5 x 16), 8 heads, MLP ratio 4, bf16."""
+        return (ops.FUSE_GMA and a.dtype == torch.bfloat16 and a.shape[-1] == 80 and self.att.num_heads == 8 and
+                self.mlp.fc1.out_features == 320 and self.att.qkv.in_features == 80 and self.norm1.eps == self.norm2.eps)
+
+    def _nhwc(self, a, post=None):
+        """post = (conv1x1 module, residual): fold `conv(block(a)) + residual` into the block's last launch (the cfg3 net's gma_out)."""
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
         x = self.cpe._nhwc(a)
+        if self._fusable(a) and (post is None or post[0].weight.shape[0] == 192):
+            R = torch.ops.realcam
+            f32 = ops.f32_param
+            wq, bq = ops.packed_chain(self.att.qkv)
+            qkv = R.gma_ln_qkv(x, wq, bq, f32(self.norm1, "weight"), f32(self.norm1, "bias"), float(self.norm1.eps))
+            qkvp, loc, convv, ktv = self.att._context(qkv)
+            wp, bp = ops.packed_chain(self.att.proj)
+            w1, b1 = ops.packed_chain(self.mlp.fc1)
+            w2, b2 = ops.packed_chain(self.mlp.fc2)
+            wo, bo, res = (*ops.packed_chain(post[0]), ops._req(post[1], "residual")) if post is not None else (None, None, None)
+            return R.gma_tail(qkvp, convv, loc, x, ktv, wp, bp, f32(self.norm2, "weight"), f32(self.norm2, "bias"), float(self.norm2.eps),
+                              w1, b1, w2, b2, res, wo, bo)
         x = self.att._nhwc(ops.layernorm(x, self.norm1), residual=x)
-        return self.mlp._nhwc(ops.layernorm(x, self.norm2), residual=x)
+        y = self.mlp._nhwc(ops.layernorm(x, self.norm2), residual=x)
+        return y if post is None else ops.conv2d(y, post[0], residual=post[1])
 
     def forward(self, x_input, size):
         return self._nhwc(_as_nhwc(x_input, size)).reshape(x_input.shape)

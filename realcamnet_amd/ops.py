@@ -131,6 +131,29 @@ def packed_conv(mod, act_dtype: torch.dtype, out_mode: int) -> PackedConv:
     return pc
 
 
+def packed_chain(mod):
+    """(packed bf16 MFMA fragments, packed fp32 bias) of an nn.Linear / 1x1 conv for the register-resident layer chains of
+    csrc/gma_fused.hip (realcam::chain_pack_weights), cached on the module."""
+    w, b = mod.weight, mod.bias
+    c = _cache(mod)
+    key = _key(w, b)
+    hit = c.get("chain")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if not w.is_cuda:
+        raise RuntimeError("weights are not on a HIP device; move the module with .cuda() first")
+    if w.dim() == 4 and tuple(w.shape[2:]) != (1, 1):
+        raise NotImplementedError("layer chains take Linear / 1x1 weights")
+    pair = _R.chain_pack_weights(w.detach().reshape(w.shape[0], w.shape[1]), b.detach() if b is not None else None)
+    c["chain"] = (key, pair)
+    return pair
+
+
+# The per-token stages of GMA_Block (LayerNorm1 + qkv; attention read-out + proj + LayerNorm2 + MLP [+ the net's output conv]) as
+# two launches with register-resident activations (csrc/gma_fused.hip) instead of nine layer-by-layer ones.  Built for dim 80, bf16.
+FUSE_GMA = True
+
+
 class _ConvView:
     """A conv-shaped view (weight, bias) of another module's parameters, with its own pack cache."""
     def __init__(self, weight, bias):

@@ -431,3 +431,53 @@ define("window_attention(Tensor qkv, Tensor rel_pos, int head_dim, int window, i
        lambda out, qkv, rel, hd, ws, sh: check(lib().rc_window_attention(qkv.data_ptr(), rel.data_ptr(), out.data_ptr(), _dt(qkv), qkv.shape[0],
                                                                          qkv.shape[1], qkv.shape[2], qkv.shape[3] // 3, hd, ws, sh, _stream()),
                                                "rc_window_attention"))
+
+
+# ---- a15/a16 fused per-token stages of GMA_Block at dim 80 (csrc/gma_fused.hip) ---------------------------------------------------
+def _cpack_alloc(weight, bias):
+    cout, cin = weight.shape[0], weight.shape[1]
+    nbytes = lib().rc_chain_packed_bytes(cin, cout)
+    if nbytes == 0:
+        raise _lib.HipError("rc_chain_packed_bytes: cin must be a multiple of 16")
+    return weight.new_empty((nbytes,), dtype=torch.uint8), weight.new_empty((lib().rc_chain_packed_rows(cout),), dtype=torch.float32)
+
+
+def _cpack_launch(outs, weight, bias):
+    wp, bp = outs
+    cout, cin = weight.shape[0], weight.shape[1]
+    w_host = np.ascontiguousarray(weight.detach().float().reshape(cout, cin).cpu().numpy())
+    dst = np.empty(wp.numel(), dtype=np.uint8)
+    check(lib().rc_chain_pack_weights(w_host.ctypes.data, cin, cout, dst.ctypes.data), "rc_chain_pack_weights")
+    wp.copy_(torch.from_numpy(dst))
+    bdst = np.zeros(bp.numel(), dtype=np.float32)
+    b_host = np.ascontiguousarray(bias.detach().float().cpu().numpy()) if bias is not None else None
+    check(lib().rc_chain_pack_bias(b_host.ctypes.data if b_host is not None else None, cout, bdst.ctypes.data), "rc_chain_pack_bias")
+    bp.copy_(torch.from_numpy(bdst))
+
+
+define("chain_pack_weights(Tensor weight, Tensor? bias) -> (Tensor, Tensor)", _cpack_alloc, _cpack_launch)
+
+define("gma_ln_qkv(Tensor x, Tensor wpacked, Tensor bias_packed, Tensor ln_gamma, Tensor ln_beta, float eps) -> Tensor",
+       lambda x, wp, bp, g, b, eps: x.new_empty((*x.shape[:-1], 3 * x.shape[-1])),
+       lambda out, x, wp, bp, g, b, eps: check(lib().rc_gma_ln_qkv(x.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], wp.data_ptr(),
+                                                                   bp.data_ptr(), g.data_ptr(), b.data_ptr(), float(eps), _stream()),
+                                               "rc_gma_ln_qkv"))
+
+
+def _tail_alloc(qkvp, convv, loc, x, ktv, w_proj, b_proj, ln_g, ln_b, eps, w_fc1, b_fc1, w_fc2, b_fc2, res, w_out, b_out):
+    return x.new_empty(res.shape) if res is not None else torch.empty_like(x)
+
+
+def _tail_launch(out, qkvp, convv, loc, x, ktv, w_proj, b_proj, ln_g, ln_b, eps, w_fc1, b_fc1, w_fc2, b_fc2, res, w_out, b_out):
+    b = x.shape[0]
+    n_tok = x.numel() // (b * x.shape[-1])
+    frags = torch.empty((b, 8 * 1024), dtype=torch.uint8, device=x.device)
+    check(lib().rc_gma_tail(qkvp.data_ptr(), convv.data_ptr(), loc.data_ptr(), x.data_ptr(), ktv.data_ptr(), frags.data_ptr(), b, n_tok,
+                            w_proj.data_ptr(), b_proj.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), float(eps), w_fc1.data_ptr(),
+                            b_fc1.data_ptr(), w_fc2.data_ptr(), b_fc2.data_ptr(), _p(res), _p(w_out), _p(b_out),
+                            res.shape[-1] if res is not None else 0, out.data_ptr(), _stream()), "rc_gma_tail")
+
+
+define("gma_tail(Tensor qkvp, Tensor convv, Tensor loc, Tensor x, Tensor ktv, Tensor w_proj, Tensor b_proj, Tensor ln_gamma, Tensor ln_beta, "
+       "float eps, Tensor w_fc1, Tensor b_fc1, Tensor w_fc2, Tensor b_fc2, Tensor? res, Tensor? w_out, Tensor? b_out) -> Tensor",
+       _tail_alloc, _tail_launch)

@@ -40,7 +40,7 @@ def test_constraints_raise_like_upstream():
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_gma_block_vs_reference_golden(hip, fixture, dt):
     """fp32: <= 5e-5 relative (1x1 convs on exact-f32 MFMA; softmax/k^T v in another summation order than ATen);
-    bf16 storage: PSNR >= 40 dB vs the fp32 reference (5 bf16-rounded intermediates per token)."""
+    bf16 storage: PSNR >= 60 dB vs the fp32 reference (measured on MI355X: 68.2 - 69.5 dB on the three fixtures)."""
     g = load_golden(fixture)
     hw = tuple(int(v) for v in g["hw"])
     blk = M.GMA_Block(g["x"].shape[-1], 8)
@@ -55,7 +55,78 @@ def test_gma_block_vs_reference_golden(hip, fixture, dt):
     if dt == torch.float32:
         assert rel_err(y.float().cpu(), g["y"]) <= 5e-5
     else:
-        assert O.psnr(y.float().cpu(), g["y"]) >= 40.0
+        p = O.psnr(y.float().cpu(), g["y"])
+        _metric(f"gma_block bf16 {fixture}", p)
+        assert p >= 60.0, p
+
+
+def _metric(name, value):
+    import json, os
+    path = os.environ.get("RC_METRICS_OUT")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({name: value}) + "\n")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fixture", [f for f in GMA if "_80_" in f])
+def test_gma_fused_stages_vs_layer_by_layer_and_reference(hip, fixture):
+    """dim 80, bf16: the per-token stages as two launches with register-resident activations (csrc/gma_fused.hip) against the
+    layer-by-layer path (same rounding points; fp32 summation order and the erf evaluation differ) and the fp32 reference."""
+    from realcamnet_amd import ops
+    g = load_golden(fixture)
+    hw = tuple(int(v) for v in g["hw"])
+    blk = M.GMA_Block(80, 8)
+    blk.load_state_dict(g["sd"], strict=True)
+    blk = blk.to("cuda", torch.bfloat16).eval()
+    x = g["x"].to("cuda", torch.bfloat16)
+    old = ops.FUSE_GMA
+    try:
+        with torch.no_grad():
+            ops.FUSE_GMA = True
+            yf = blk(x, hw); yf2 = blk(x, hw)
+            ops.FUSE_GMA = False
+            yl = blk(x, hw)
+    finally:
+        ops.FUSE_GMA = old
+    assert torch.equal(yf, yf2)
+    pf, pl = O.psnr(yf.float().cpu(), g["y"]), O.psnr(yl.float().cpu(), g["y"])
+    pfl = O.psnr(yf.float().cpu(), yl.float().cpu())
+    _metric(f"gma_fused {fixture}", {"fused_vs_ref": pf, "layers_vs_ref": pl, "fused_vs_layers": pfl})
+    assert pf >= 60.0 and pf >= pl - 1.0, (pf, pl)             # measured: 68.2 / 68.9 dB either way
+    assert pfl >= 70.0, pfl                                     # measured: 80.7 / 81.6 dB between the two forms
+
+
+@pytest.mark.gpu
+def test_gma_fused_tail_with_output_conv_and_ragged_token_count(hip):
+    """The cfg3 form: gma_out (80 -> 192) + residual folded into the block's last launch; 3 images of 37 x 29 = 1073 tokens
+    (not a multiple of the 64-token wave tile, so the last tile of every image is partial)."""
+    from realcamnet_amd import networks as N, ops
+    torch.manual_seed(5)
+    blk = M.GMA_Block(80, 8).to("cuda", torch.bfloat16).eval()
+    conv = N.Conv2d(80, 192, 1, 1, 0).to("cuda", torch.bfloat16)
+    gen = torch.Generator().manual_seed(6)
+    a = torch.randn(3, 37, 29, 80, generator=gen).to("cuda", torch.bfloat16)
+    d1 = torch.randn(3, 37, 29, 192, generator=gen).to("cuda", torch.bfloat16)
+    old = ops.FUSE_GMA
+    try:
+        with torch.no_grad():
+            ops.FUSE_GMA = True
+            yf = blk._nhwc(a, post=(conv, d1))
+            y0 = blk._nhwc(a)
+            ops.FUSE_GMA = False
+            yl = blk._nhwc(a, post=(conv, d1))
+            y0l = blk._nhwc(a)
+    finally:
+        ops.FUSE_GMA = old
+    assert yf.shape == (3, 37, 29, 192) and y0.shape == (3, 37, 29, 80)
+    p1, p0 = O.psnr(yf.float().cpu(), yl.float().cpu()), O.psnr(y0.float().cpu(), y0l.float().cpu())
+    _metric("gma_fused ragged", {"with_out_conv": p1, "block_only": p0})
+    assert p1 >= 70.0 and p0 >= 70.0, (p1, p0)                  # measured: 82.5 / 86.7 dB
+    # frames are independent: image 2 alone == image 2 of the batch (bitwise)
+    with torch.no_grad():
+        y2 = blk._nhwc(a[2:3], post=(conv, d1[2:3]))
+    assert torch.equal(y2[0], yf[2])
 
 
 @pytest.mark.gpu
@@ -87,7 +158,7 @@ def test_gma_model_keeps_reference_base_parameters():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dt,floor", [(torch.float32, 95.0), (torch.bfloat16, 48.0)])
+@pytest.mark.parametrize("dt,floor", [(torch.float32, 100.0), (torch.bfloat16, 55.0)])      # measured: 139.0 / 61.8 dB
 def test_gma_model_vs_oracle(hip, dt, floor):
     torch.manual_seed(0)
     net = M.LiteISPNet_GFM_LSC_GMA().eval()
@@ -101,4 +172,6 @@ def test_gma_model_vs_oracle(hip, dt, floor):
         ref = O.run_padded("LiteISPNet_GFM_LSC_GMA", sd, O.bayer_unshuffle(mosaic), cond, coord)
         y = net.to("cuda", dt).forward_mosaic(mosaic.to("cuda", dt), cond.to("cuda", dt), coord.to("cuda", dt))
     assert y.shape == ref.shape
-    assert O.psnr(y.float().cpu(), ref) >= floor
+    p = O.psnr(y.float().cpu(), ref)
+    _metric(f"gma_model {dt}", p)
+    assert p >= floor, p
