@@ -336,6 +336,20 @@ int rc_gma_tail(const void* d_qkvp, const void* d_convv, const void* d_loc, cons
                 float eps, const void* d_w_fc1, const float* d_b_fc1, const void* d_w_fc2, const float* d_b_fc2, const void* d_res,
                 const void* d_w_out, const float* d_b_out, int cout, void* d_out, void* stream);
 
+/* rc_gma_aggregate: the whole Aggregator (groupmix.py:56-105) for dim 80, bf16, one launch: qkv (B,H,W,240) -> qkvp (B,H,W,3,64)
+ * [q|k|v][group 0: BN+Hardswish | groups 1..3: dw 3/5/7 -> pw 16x16 -> BN -> Hardswish] and loc (B,H,W,16) = Hardswish(LN(pw(dw3x3(
+ * [q4|k4|v4])))).  dw3/5/7: tap-major (K*K,16) fp32; dwl (3,9,16); pw (3,16,16) [out][in]; pwl (16,48); bn_scale/shift (4,16)
+ * (BatchNorm(eval) folded); ln (16).  Same values as rc_dwconv2d + rc_gma_pointwise up to the point-wise product's summation order. */
+int rc_gma_aggregate(const void* d_qkv, void* d_qkvp, void* d_loc, int batch, int H, int W, const float* d_dw3, const float* d_dw5,
+                     const float* d_dw7, const float* d_dwl, const float* d_pw, const float* d_pwl, const float* d_bn_scale,
+                     const float* d_bn_shift, const float* d_ln_g, const float* d_ln_b, void* stream);
+
+/* rc_gma_crpe: ConvRelPosEnc's depth-wise conv of v (groupmix.py:127-133,146-150) for dim 80 / 8 heads of 8, bf16: v = qkvp[..,2,:]
+ * (B,H,W,3,64) -> convv (B,H,W,64); four 16-channel segments with windows 3, 5, 7, 7 (tap-major (K*K,16) fp32 each; segment 2 holds
+ * heads of window 5 and 7, its window-5 taps zero-padded to 7x7), bias (64).  Same values as rc_dwconv2d. */
+int rc_gma_crpe(const void* d_qkvp, void* d_convv, int batch, int H, int W, const float* d_taps0, const float* d_taps1,
+                const float* d_taps2, const float* d_taps3, const float* d_bias, void* stream);
+
 int rc_dwconv2d(const void* d_x, int x_stride_c, int x_c0, void* d_y, int y_stride_c, int y_c0, int dtype,
                 int batch, int H, int W, int n_ch, int ksize, const float* d_wT, int n_w, const float* d_bias,
                 int n_rep, int x_rep_stride, int y_rep_stride, int w_rep_stride, int add_identity,

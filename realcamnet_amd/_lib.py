@@ -114,6 +114,8 @@ _SIGS = {
     "rc_chain_pack_bias": (C.c_int, [_P, _I, _P]),
     "rc_gma_ln_qkv": (C.c_int, [_P, _P, C.c_longlong, _P, _P, _P, _P, _F, _P]),
     "rc_gma_tail": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "rc_gma_aggregate": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rc_gma_crpe": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "rc_gma_kv_blocks": (C.c_int, [_I]),
     "rc_gma_kv_scratch_bytes": (_SZ, [_I, _I, _I, _I]),
     "rc_gma_kv": (C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),

@@ -10,7 +10,7 @@
 //
 // Register-resident chain of MFMA layers.  A wave owns 64 consecutive tokens = 4 column tiles of v_mfma_f32_16x16x32_bf16
 // (B operand = activations: lane (n = lane & 15, g = lane >> 4) holds channels 32 s + 8 g + 0..7 of token n for K-step s;
-// a trailing 16 channels go through v_mfma_f32_16x16x16_bf16: channels C0 + 4 g + 0..3).  A layer's weights are packed so that
+// a trailing 16 channels use the lower half of a K-step: channels C0 + 4 g + 0..3, upper half zero).  A layer's weights are packed so that
 // MFMA row R = 4 g + j of output tile m is channel 32 (m >> 1) + 8 g + 4 (m & 1) + j: the C/D fragments of output tiles
 // (2 p, 2 p + 1) in lane (n, g) are then exactly channels 32 p + 8 g + 0..7 of token n -- the B fragment of the NEXT layer's
 // K-step p after fp32 -> bf16 packing, with no cross-lane movement (an unpaired last tile keeps natural order 16 m + R and feeds
@@ -44,8 +44,12 @@ template <int C> struct Act {                // one token column tile's activati
 __device__ __forceinline__ void mma32(const uint4& a, const uint4& b, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// K = 16 step (4 values per lane: k = 4 q + i) as a K = 32 MFMA with the upper 4 k-slots of every lane zero in both operands.
+// NOT v_mfma_f32_16x16x16_bf16: on gfx950 / ROCm 7.2 results of that (legacy) opcode read by the VALU shortly afterwards came out
+// stale for random lanes -- hipcc pads its result latency with `s_nop 4` (a 4-pass model) and that is not enough; the K = 32 opcode's
+// wait states are right (the conv kernels live on them).  Costs nothing here: the chains are HBM / VALU bound.
 __device__ __forceinline__ void mma16(const uint2& a, const uint2& b, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+    mma32(make_uint4(a.x, a.y, 0u, 0u), make_uint4(b.x, b.y, 0u, 0u), c);
 }
 // fp32 pair -> packed bf16: Vec16::rne2, ONE v_cvt_pk_bf16_f32 written as inline asm (the vector-typed __builtin_convertvector form
 // of the same instruction cost this kernel ~120 spilled VGPRs).  HAZARD RULE: an inline-asm instruction is opaque to the compiler's
@@ -517,3 +521,297 @@ int rc_gma_tail(const void* d_qkvp, const void* d_convv, const void* d_loc, cons
 }
 
 }  // extern "C"
+
+// ======================================================================================================================================
+// Aggregator (upstream models/groupmix.py:56-105) as ONE kernel: depth-wise KxK -> point-wise 16x16 (MFMA) -> BatchNorm(eval) ->
+// Hardswish for the three conv groups of q, k and v, the pass-through group, and the local branch (dw 3x3 on 3x16 channels ->
+// 48 -> 16 point-wise -> LayerNorm(16) -> Hardswish).  The layer-by-layer form wrote the depth-wise results (1.6 GB at cfg3) and read
+// them back, staged every channel with a 7x7 halo, and spent 2.0 + 1.6 ms; here a block owns (16 x 32 pixel tile, one of q / k / v /
+// local), stages one 16-channel segment at a time with ITS window's halo, and the depth-wise results never leave registers:
+// lane (n, q) owns channels 4 q .. 4 q + 3 of a 2 x 4 pixel patch, its packed bf16 results are exactly the B fragments of
+// a half-filled K-step (K = the segment's 16 channels), one MFMA per patch pixel, and the C fragment (4 output channels of the
+// same pixel) goes through BN + Hardswish to an 8-byte store.  A lane's 16-byte LDS reads are reused by 4 x K taps.
+// Depth-wise accumulation order (dy, dx ascending, fmaf) and the bf16 rounding point are those of rc_dwconv2d.
+namespace rc {
+namespace gf {
+
+constexpr int AG_TH = 16, AG_TW = 32, AG_THREADS = 256;
+constexpr int AG_PS = 40;                                                  // LDS pixel stride in bytes (32 of data): 4 pixels = 40 dwords,
+                                                                           // so the 8 column groups of a wave hit 8 different bank octets
+constexpr int AG_MAXPIX = (AG_TH + 6) * (AG_TW + 6);
+
+struct AggArgs {
+    const bf16_t* qkv; bf16_t* qkvp; bf16_t* loc;
+    int batch, H, W, tiles_x, tiles_y;
+    const float* dw[3];          // groups 1..3: tap-major [K*K][16], K = 3, 5, 7
+    const float* dwl;            // local branch: [3 (q,k,v)][9][16]
+    const float* pw;             // [3][16 out][16 in]
+    const float* pwl;            // [16 out][48 in]
+    const float* bn_scale; const float* bn_shift;   // [4][16]
+    const float* ln_g; const float* ln_b;           // [16]
+};
+
+__device__ __forceinline__ float hswish(float x) {
+    const float r = fminf(fmaxf(x + 3.f, 0.f), 6.f);
+    return x * r * (1.f / 6.f);
+}
+
+// stage channels [c0, c0 + 16) of the (TH + 2R) x (TW + 2R) halo tile (pixel stride `cs` channels), zero outside the image
+template <int R>
+__device__ __forceinline__ void agg_stage(char* s_x, const bf16_t* img, int cs, int c0, int y0, int x0, int H, int W, int tid) {
+    constexpr int THH = AG_TH + 2 * R, TWH = AG_TW + 2 * R, NPIECE = THH * TWH * 2, NLD = (NPIECE + AG_THREADS - 1) / AG_THREADS;
+    uint4 raw[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + k * AG_THREADS, pix = i >> 1, half = i & 1;
+        const int py = pix / TWH, px = pix - py * TWH;
+        const int gy = y0 + py - R, gx = x0 + px - R;
+        raw[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (i < NPIECE && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            raw[k] = *reinterpret_cast<const uint4*>(img + ((size_t)gy * W + gx) * cs + c0 + 8 * half);
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + k * AG_THREADS;
+        if (i < NPIECE) *reinterpret_cast<uint4*>(s_x + (i >> 1) * AG_PS + (i & 1) * 16) = raw[k];
+    }
+}
+
+// depth-wise KxK of this lane's 2 x 4 patch, channels 4 q .. 4 q + 3: acc[o][c] (fp32, taps in (dy, dx) order)
+template <int K>
+__device__ __forceinline__ void agg_dw(const char* s_x, const float* s_w, int prow, int pcol, int q, f32x4 (&acc)[2][4]) {
+    constexpr int R = K / 2, TWH = AG_TW + 2 * R;
+    const char* base = s_x + (prow * TWH + pcol) * AG_PS + q * 8;
+#pragma unroll 1                                                           // rolled: fully unrolled, all 4 K^2 tap vectors were hoisted (256+ VGPRs)
+    for (int iy = 0; iy < K + 1; ++iy) {
+        f32x4 xin[K + 3];
+#pragma unroll
+        for (int c = 0; c < K + 3; ++c) xin[c] = up_tail(*reinterpret_cast<const uint2*>(base + (iy * TWH + c) * AG_PS));
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int dy = iy - o;
+            if (dy < 0 || dy >= K) continue;
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+                const f32x4 w = ld4(s_w + (dy * K + dx) * 16 + 4 * q);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[o][c][e] = __builtin_fmaf(w[e], xin[c + dx][e], acc[o][c][e]);
+            }
+        }
+    }
+}
+
+// A fragment (16 out x 16 in, lower half of a K-step) of an fp32 row-major matrix with row stride ld, starting at column col0
+__device__ __forceinline__ uint2 agg_afrag(const float* w, int ld, int col0, int lane) {
+    const float* p = w + (lane & 15) * ld + col0 + 4 * (lane >> 4);
+    return make_uint2(pk(p[0] + 0.f, p[1] + 0.f), pk(p[2] + 0.f, p[3] + 0.f));
+}
+
+struct AggGeom { int y0, x0, prow, pcol, q; size_t pix0; };
+
+// one conv group: stage -> depth-wise K x K -> point-wise (MFMA) -> BN + Hardswish -> qkvp[.., which, 16 g + ..]
+template <int K>
+__device__ __forceinline__ void agg_conv_job(const AggArgs& a, char* s_x, float* s_w, const bf16_t* img, const AggGeom& t, int which, int g,
+                                             int tid, int lane) {
+    constexpr int R = K / 2;
+    for (int i = tid; i < K * K * 16; i += AG_THREADS) s_w[i] = a.dw[g - 1][i];
+    agg_stage<R>(s_x, img, 3 * kC, which * kC + 16 * g, t.y0, t.x0, a.H, a.W, tid);
+    const uint2 apw = agg_afrag(a.pw + (g - 1) * 256, 16, 0, lane);
+    const f32x4 sc = ld4(a.bn_scale + 16 * g + 4 * t.q), sh = ld4(a.bn_shift + 16 * g + 4 * t.q);
+    __syncthreads();
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[o][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    agg_dw<K>(s_x, s_w, t.prow, t.pcol, t.q, acc);
+    bf16_t* outp = a.qkvp + which * kCT + 16 * g + 4 * t.q;
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma16(apw, pack_tail(acc[o][c]), d);
+            f32x4 v = d * sc + sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
+            if (t.y0 + t.prow + o < a.H && t.x0 + t.pcol + c < a.W)
+                *reinterpret_cast<uint2*>(outp + (t.pix0 + (size_t)o * a.W + c) * (3 * kCT)) = pack_tail(v);
+        }
+}
+
+// Blocks = tiles x 10 jobs: (which, group 3 / 2 / 1) x 3, the group-1 job also doing the pass-through group 0, and the local branch.
+// One short job per block: with 4 blocks per CU in different phases the staging loads of one hide under the FMAs of another
+// (one block walking all of a tile's groups, barrier to barrier, ran at a sixth of its FMA time).
+__global__ __launch_bounds__(AG_THREADS) void gma_agg_kernel(AggArgs a) {
+    __shared__ __attribute__((aligned(16))) char s_x[AG_MAXPIX * AG_PS];
+    __shared__ __attribute__((aligned(16))) float s_w[49 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15;
+    int blk = blockIdx.x;
+    const int job = blk % 10; blk /= 10;
+    const int tx = blk % a.tiles_x; blk /= a.tiles_x;
+    const int ty = blk % a.tiles_y;
+    const int b = blk / a.tiles_y;
+    AggGeom t;
+    t.y0 = ty * AG_TH; t.x0 = tx * AG_TW; t.q = lane >> 4;
+    t.prow = 4 * wave + 2 * (n >> 3); t.pcol = 4 * (n & 7);               // this lane's patch: 2 rows x 4 columns of the tile
+    t.pix0 = ((size_t)b * a.H + t.y0 + t.prow) * a.W + t.x0 + t.pcol;
+    const bf16_t* img = a.qkv + (size_t)b * a.H * a.W * (3 * kC);
+    const int q = t.q;
+
+    if (job < 9) {
+        const int which = job / 3, g = 3 - job % 3;
+        if (g == 3) agg_conv_job<7>(a, s_x, s_w, img, t, which, g, tid, lane);
+        else if (g == 2) agg_conv_job<5>(a, s_x, s_w, img, t, which, g, tid, lane);
+        else {
+            agg_conv_job<3>(a, s_x, s_w, img, t, which, g, tid, lane);
+            // pass-through group 0: BatchNorm + Hardswish of the segment itself
+            const f32x4 sc = ld4(a.bn_scale + 4 * q), sh = ld4(a.bn_shift + 4 * q);
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (t.y0 + t.prow + o < a.H && t.x0 + t.pcol + c < a.W) {
+                        const size_t p = t.pix0 + (size_t)o * a.W + c;
+                        f32x4 v = up_tail(*reinterpret_cast<const uint2*>(a.qkv + p * (3 * kC) + which * kC + 4 * q)) * sc + sh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
+                        *reinterpret_cast<uint2*>(a.qkvp + p * (3 * kCT) + which * kCT + 4 * q) = pack_tail(v);
+                    }
+        }
+    } else {
+        f32x4 d[2][4];
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[o][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int wh = 0; wh < 3; ++wh) {
+            __syncthreads();
+            for (int i = tid; i < 9 * 16; i += AG_THREADS) s_w[i] = a.dwl[wh * 144 + i];
+            agg_stage<1>(s_x, img, 3 * kC, wh * kC + 4 * kSEG, t.y0, t.x0, a.H, a.W, tid);
+            const uint2 apw = agg_afrag(a.pwl, 48, 16 * wh, lane);
+            __syncthreads();
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[o][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            agg_dw<3>(s_x, s_w, t.prow, t.pcol, q, acc);
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) mma16(apw, pack_tail(acc[o][c]), d[o][c]);
+        }
+        const f32x4 lg = ld4(a.ln_g + 4 * q), lb = ld4(a.ln_b + 4 * q);
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 tt = d[o][c] + 0.f;
+                float s = (tt[0] + tt[1]) + (tt[2] + tt[3]);
+                s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+                const float mean = s / 16.f;
+                const f32x4 dd = tt - mean;
+                const f32x4 d2 = dd * dd;
+                float var = (d2[0] + d2[1]) + (d2[2] + d2[3]);
+                var += __shfl_xor(var, 16); var += __shfl_xor(var, 32);
+                const float rstd = 1.f / sqrtf(var / 16.f + 1e-5f);
+                f32x4 v = dd * rstd * lg + lb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
+                if (t.y0 + t.prow + o < a.H && t.x0 + t.pcol + c < a.W)
+                    *reinterpret_cast<uint2*>(a.loc + (t.pix0 + (size_t)o * a.W + c) * kSEG + 4 * q) = pack_tail(v);
+            }
+    }
+}
+
+// ---- ConvRelPosEnc's depth-wise conv of v (groupmix.py:108-156): 64 channels in four 16-channel segments with windows 3, 5, 7, 7
+// (segment 2 mixes heads of window 5 and 7: its taps are zero-padded to 7 x 7), + bias.  Same tiles, staging and FMA core. ------------
+struct CrpeArgs {
+    const bf16_t* qkvp; bf16_t* convv; int batch, H, W, tiles_x, tiles_y;
+    const float* taps[4];        // tap-major [K*K][16] per segment, K = 3, 5, 7, 7
+    const float* bias;           // [64]
+};
+
+template <int K>
+__device__ __forceinline__ void crpe_job(const CrpeArgs& a, char* s_x, float* s_w, const bf16_t* img, const AggGeom& t, int seg, int tid) {
+    constexpr int R = K / 2;
+    for (int i = tid; i < K * K * 16; i += AG_THREADS) s_w[i] = a.taps[seg][i];
+    agg_stage<R>(s_x, img, 3 * kCT, 2 * kCT + 16 * seg, t.y0, t.x0, a.H, a.W, tid);
+    const f32x4 bv = ld4(a.bias + 16 * seg + 4 * t.q);
+    __syncthreads();
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[o][c] = bv;
+    agg_dw<K>(s_x, s_w, t.prow, t.pcol, t.q, acc);
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (t.y0 + t.prow + o < a.H && t.x0 + t.pcol + c < a.W)
+                *reinterpret_cast<uint2*>(a.convv + (t.pix0 + (size_t)o * a.W + c) * kCT + 16 * seg + 4 * t.q) = pack_tail(acc[o][c] + 0.f);
+}
+
+__global__ __launch_bounds__(AG_THREADS) void gma_crpe_kernel(CrpeArgs a) {
+    __shared__ __attribute__((aligned(16))) char s_x[AG_MAXPIX * AG_PS];
+    __shared__ __attribute__((aligned(16))) float s_w[49 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15;
+    int blk = blockIdx.x;
+    const int seg = 3 - (blk & 3); blk >>= 2;                               // heavy segments first
+    const int tx = blk % a.tiles_x; blk /= a.tiles_x;
+    const int ty = blk % a.tiles_y;
+    const int b = blk / a.tiles_y;
+    AggGeom t;
+    t.y0 = ty * AG_TH; t.x0 = tx * AG_TW; t.q = lane >> 4;
+    t.prow = 4 * wave + 2 * (n >> 3); t.pcol = 4 * (n & 7);
+    t.pix0 = ((size_t)b * a.H + t.y0 + t.prow) * a.W + t.x0 + t.pcol;
+    const bf16_t* img = a.qkvp + (size_t)b * a.H * a.W * (3 * kCT);
+    if (seg == 0) crpe_job<3>(a, s_x, s_w, img, t, seg, tid);
+    else if (seg == 1) crpe_job<5>(a, s_x, s_w, img, t, seg, tid);
+    else crpe_job<7>(a, s_x, s_w, img, t, seg, tid);
+}
+
+}  // namespace gf
+}  // namespace rc
+
+extern "C" int rc_gma_aggregate(const void* d_qkv, void* d_qkvp, void* d_loc, int batch, int H, int W, const float* d_dw3, const float* d_dw5,
+                                const float* d_dw7, const float* d_dwl, const float* d_pw, const float* d_pwl, const float* d_bn_scale,
+                                const float* d_bn_shift, const float* d_ln_g, const float* d_ln_b, void* stream) {
+    using namespace rc;
+    using namespace rc::gf;
+    RC_REQUIRE(d_qkv && d_qkvp && d_loc && d_dw3 && d_dw5 && d_dw7 && d_dwl && d_pw && d_pwl && d_bn_scale && d_bn_shift && d_ln_g && d_ln_b,
+               "rc_gma_aggregate: null pointer");
+    RC_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "rc_gma_aggregate: bad shape");
+    AggArgs a;
+    a.qkv = static_cast<const bf16_t*>(d_qkv); a.qkvp = static_cast<bf16_t*>(d_qkvp); a.loc = static_cast<bf16_t*>(d_loc);
+    a.batch = batch; a.H = H; a.W = W; a.tiles_x = ceil_div(W, AG_TW); a.tiles_y = ceil_div(H, AG_TH);
+    a.dw[0] = d_dw3; a.dw[1] = d_dw5; a.dw[2] = d_dw7; a.dwl = d_dwl; a.pw = d_pw; a.pwl = d_pwl;
+    a.bn_scale = d_bn_scale; a.bn_shift = d_bn_shift; a.ln_g = d_ln_g; a.ln_b = d_ln_b;
+    const size_t blocks = (size_t)a.tiles_x * a.tiles_y * batch * 10;
+    RC_REQUIRE(blocks < (1ull << 31), "rc_gma_aggregate: too many tiles");
+    hipLaunchKernelGGL(gma_agg_kernel, dim3((unsigned)blocks), dim3(AG_THREADS), 0, as_stream(stream), a);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+extern "C" int rc_gma_crpe(const void* d_qkvp, void* d_convv, int batch, int H, int W, const float* d_taps0, const float* d_taps1,
+                           const float* d_taps2, const float* d_taps3, const float* d_bias, void* stream) {
+    using namespace rc;
+    using namespace rc::gf;
+    RC_REQUIRE(d_qkvp && d_convv && d_taps0 && d_taps1 && d_taps2 && d_taps3 && d_bias, "rc_gma_crpe: null pointer");
+    RC_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "rc_gma_crpe: bad shape");
+    CrpeArgs a;
+    a.qkvp = static_cast<const bf16_t*>(d_qkvp); a.convv = static_cast<bf16_t*>(d_convv);
+    a.batch = batch; a.H = H; a.W = W; a.tiles_x = ceil_div(W, AG_TW); a.tiles_y = ceil_div(H, AG_TH);
+    a.taps[0] = d_taps0; a.taps[1] = d_taps1; a.taps[2] = d_taps2; a.taps[3] = d_taps3; a.bias = d_bias;
+    const size_t blocks = (size_t)a.tiles_x * a.tiles_y * batch * 4;
+    RC_REQUIRE(blocks < (1ull << 31), "rc_gma_crpe: too many tiles");
+    hipLaunchKernelGGL(gma_crpe_kernel, dim3((unsigned)blocks), dim3(AG_THREADS), 0, as_stream(stream), a);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}

@@ -87,6 +87,8 @@ class Aggregator(nn.Module):
         b, H, W, c3 = qkv.shape
         c, seg = c3 // 3, c3 // 15
         dev, dt = qkv.device, qkv.dtype
+        if ops.FUSE_GMA and dt == torch.bfloat16 and c == 80:
+            return self._run_fused(qkv)
         # all four depth-wise stages (groups 1..3: k = 3, 5, 7 shared by q/k/v; group 4: the local branch's own 3x3 per
         # q/k/v) in ONE launch: taps zero-padded to 7x7, the true window per weight vector in kvec (padded taps are
         # skipped, never multiplied), output (B,H,W,3,4seg) = [rep][g1 | g2 | g3 | g4] -- qkv is read once, not 4 times
@@ -101,7 +103,15 @@ class Aggregator(nn.Module):
                                                        self.agg0.conv.conv1.weight], taps)
         dwc = ops.dwconv2d(qkv, seg, (3, 4 * seg), 0, 4 * seg, 7, wT, n_rep=3, x_rep=c, y_rep=4 * seg, w_rep=4 * seg, kvec=kvec)
 
-        def fold(*p):   # BatchNorm(eval) -> per-channel scale / shift; point-wise weights as dense matrices
+        scale, shift, pw, pwl = self._folded()
+        ln = self.agg0.norm
+        qkvp, loc = torch.ops.realcam.gma_pointwise(qkv, dwc, pw, scale, shift, pwl, ops.f32_param(ln, "weight"), ops.f32_param(ln, "bias"))
+        return qkvp, loc
+
+
+    def _folded(self):
+        """BatchNorm(eval) -> per-channel scale / shift (4,16); point-wise weights as dense matrices (3,16,16), (16,48)."""
+        def fold(*p):
             bn = [p[4 * i:4 * i + 4] for i in range(4)]
             scale = torch.stack([w / torch.sqrt(v + 1e-5) for (w, _, _, v) in bn])
             shift = torch.stack([bb - m * (w / torch.sqrt(v + 1e-5)) for (w, bb, m, v) in bn])
@@ -115,10 +125,23 @@ class Aggregator(nn.Module):
         for n in norms:
             if abs(n.eps - 1e-5) > 0:
                 raise NotImplementedError("Aggregator: BatchNorm eps must be the default 1e-5")
-        scale, shift, pw, pwl = ops.host_cached(self, "fold", params, fold)
+        return ops.host_cached(self, "fold", params, fold)
+
+    def _run_fused(self, qkv):
+        """dim 80, bf16: depth-wise, point-wise, BatchNorm, Hardswish and the local branch in ONE launch (rc_gma_aggregate)."""
+        seg = 16
+
+        def taps(w1, w2, w3, w0):
+            return (ops.dw_taps(w1), ops.dw_taps(w2), ops.dw_taps(w3),
+                    ops.dw_taps(w0).reshape(9, 3, seg).permute(1, 0, 2).contiguous())      # local: (which, tap, channel)
+        dw3, dw5, dw7, dwl = ops.host_cached(self, "taps_exact", [self.agg1.conv1.weight, self.agg2.conv1.weight, self.agg3.conv1.weight,
+                                                                 self.agg0.conv.conv1.weight], taps)
+        scale, shift, pw, pwl = self._folded()
         ln = self.agg0.norm
-        qkvp, loc = torch.ops.realcam.gma_pointwise(qkv, dwc, pw, scale, shift, pwl, ops.f32_param(ln, "weight"), ops.f32_param(ln, "bias"))
-        return qkvp, loc
+        if abs(ln.eps - 1e-5) > 0:
+            raise NotImplementedError("Aggregator: LayerNorm eps must be the default 1e-5")
+        return torch.ops.realcam.gma_aggregate(qkv, dw3, dw5, dw7, dwl, pw, pwl, scale, shift, ops.f32_param(ln, "weight"),
+                                               ops.f32_param(ln, "bias"))
 
 
 class ConvRelPosEnc(nn.Module):
@@ -147,6 +170,14 @@ class ConvRelPosEnc(nn.Module):
         if kmax > 7 or any(k % 2 == 0 for k in self.window):
             raise NotImplementedError("ConvRelPosEnc: odd windows up to 7")
         params = [t for cv in self.conv_list for t in (cv.weight, cv.bias)]
+        if (ops.FUSE_GMA and qkvp.dtype == torch.bfloat16 and ct == 64 and list(self.window.items()) == [(3, 2), (5, 3), (7, 3)] and
+                self.channel_splits == [16, 24, 24]):
+            def seg_taps(*p):   # 16-channel segments: [conv3 (16)] [conv5 0..16] [conv5 16..24 padded to 7x7 | conv7 0..8] [conv7 8..24]
+                w3, w5, w7 = p[0], p[2], p[4]
+                t2 = torch.cat([ops.dw_taps(w5[16:24], pad_to=7), ops.dw_taps(w7[0:8])], dim=1)
+                return (ops.dw_taps(w3), ops.dw_taps(w5[0:16]), t2.contiguous(), ops.dw_taps(w7[8:24]), torch.cat([p[1], p[3], p[5]]))
+            t0, t1, t2, t3, bias = ops.host_cached(self, "seg_taps", params, seg_taps)
+            return torch.ops.realcam.gma_crpe(qkvp, t0, t1, t2, t3, bias)
 
         unit = 8 if qkvp.dtype == torch.bfloat16 else 4
         wins = list(self.window.keys())

@@ -481,3 +481,18 @@ def _tail_launch(out, qkvp, convv, loc, x, ktv, w_proj, b_proj, ln_g, ln_b, eps,
 define("gma_tail(Tensor qkvp, Tensor convv, Tensor loc, Tensor x, Tensor ktv, Tensor w_proj, Tensor b_proj, Tensor ln_gamma, Tensor ln_beta, "
        "float eps, Tensor w_fc1, Tensor b_fc1, Tensor w_fc2, Tensor b_fc2, Tensor? res, Tensor? w_out, Tensor? b_out) -> Tensor",
        _tail_alloc, _tail_launch)
+
+
+define("gma_aggregate(Tensor qkv, Tensor dw3, Tensor dw5, Tensor dw7, Tensor dwl, Tensor pw, Tensor pwl, Tensor bn_scale, Tensor bn_shift, "
+       "Tensor ln_gamma, Tensor ln_beta) -> (Tensor, Tensor)",
+       lambda qkv, *a: (qkv.new_empty((*qkv.shape[:3], 3, 64)), qkv.new_empty((*qkv.shape[:3], 16))),
+       lambda outs, qkv, dw3, dw5, dw7, dwl, pw, pwl, sc, sh, lg, lb: check(
+           lib().rc_gma_aggregate(qkv.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), qkv.shape[0], qkv.shape[1], qkv.shape[2], dw3.data_ptr(),
+                                  dw5.data_ptr(), dw7.data_ptr(), dwl.data_ptr(), pw.data_ptr(), pwl.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                  lg.data_ptr(), lb.data_ptr(), _stream()), "rc_gma_aggregate"))
+
+define("gma_crpe(Tensor qkvp, Tensor taps0, Tensor taps1, Tensor taps2, Tensor taps3, Tensor bias) -> Tensor",
+       lambda qkvp, *a: qkvp.new_empty((*qkvp.shape[:3], 64)),
+       lambda out, qkvp, t0, t1, t2, t3, bias: check(
+           lib().rc_gma_crpe(qkvp.data_ptr(), out.data_ptr(), qkvp.shape[0], qkvp.shape[1], qkvp.shape[2], t0.data_ptr(), t1.data_ptr(),
+                             t2.data_ptr(), t3.data_ptr(), bias.data_ptr(), _stream()), "rc_gma_crpe"))

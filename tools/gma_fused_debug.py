@@ -95,3 +95,32 @@ print("run-to-run equal:", torch.equal(of, of2))
 d = (of.float() - x.float()).abs().reshape(-1, 80)
 bad = (d > 0).nonzero()
 print("mismatching (token, channel) pairs:", bad[:30].tolist(), "total", bad.shape[0])
+
+# ---- aggregator: one launch vs dwconv2d + gma_pointwise -----------------------------------------------------------------------------
+with torch.no_grad():
+    agg = blk.att.aggregator
+    for n_ in (agg.norm0, agg.norm1, agg.norm2, agg.norm3):
+        n_.running_mean.normal_(0, 0.2); n_.running_var.uniform_(0.5, 1.5)
+    ops.invalidate_caches(blk)
+    for shape in ((2, 24, 40), (1, 37, 29), (1, 16, 32)):
+        qkv_t = torch.randn(*shape, 240, device=dev).to(torch.bfloat16)
+        ops.FUSE_GMA = True
+        qf, lf = agg._run(qkv_t)
+        ops.FUSE_GMA = False
+        ql, ll = agg._run(qkv_t)
+        ops.FUSE_GMA = True
+        cmp(f"aggregate qkvp {shape}", qf, ql)
+        cmp(f"aggregate loc  {shape}", lf, ll)
+        for gidx in range(4):
+            d = (qf.float() - ql.float())[..., 16 * gidx:16 * gidx + 16].abs().max().item()
+            print(f"   group {gidx}: max|diff| {d:.4g}")
+
+with torch.no_grad():
+    for shape in ((2, 24, 40), (1, 37, 29)):
+        qp = torch.randn(*shape, 3, 64, device=dev).to(torch.bfloat16)
+        ops.FUSE_GMA = True
+        cf = blk.att.crpe._conv_v(qp)
+        ops.FUSE_GMA = False
+        cl = blk.att.crpe._conv_v(qp)
+        ops.FUSE_GMA = True
+        cmp(f"crpe {shape}", cf, cl)
