@@ -319,8 +319,10 @@ int rc_gfm_vector(const float* d_vec, int batch, int cond_c, int nf, int c,
  * Chain weights: an nn.Linear / 1x1 conv weight (cout, cin) fp32 host -> bf16 MFMA fragments whose output rows are ordered so
  * that a layer's accumulator fragments are the next layer's B fragments (rc_chain_packed_bytes bytes); biases fp32 in the same
  * row order, zero padded (rc_chain_packed_rows(cout) floats; b NULL: zeros).  Host functions.
- * rc_gma_ln_qkv: qkv (tokens, 240) = Linear_qkv(LayerNorm1(x (tokens, 80)))                        (groupmix.py:178 after :293)
- * rc_gma_tail:   y = [ q.ktv + q*convv | loc ] (groupmix.py:189-194); x2 = proj(y) + x (:197, :294); x3 = x2 + fc2(GELU(fc1(LN2(x2))))
+ * rc_gma_ln_qkv: qkv = Linear_qkv(LayerNorm1(x (tokens, 80))), written PLANAR BY 16-CHANNEL SEGMENT: d_qkv[15][tokens][16], segment
+ *                s = channel / 16 = 5 * {q,k,v} + group -- the layout rc_gma_aggregate reads            (groupmix.py:178 after :293)
+ * rc_gma_tail:   (d_qkvp, d_convv: the segment-planar tensors of rc_gma_aggregate / rc_gma_crpe; d_loc (tokens,16); d_x (tokens,80))
+ *                y = [ q.ktv + q*convv | loc ] (groupmix.py:189-194); x2 = proj(y) + x (:197, :294); x3 = x2 + fc2(GELU(fc1(LN2(x2))))
  *                (:296-298); cout == 0: out (tokens, 80) = x3; cout == 192: out (tokens, 192) = Conv1x1(x3) + res (the cfg3 net's
  *                gma_out + d1, realcamnet_amd/LiteISP.py).  d_ktv (B,8,8,8) fp32 from rc_gma_kv; d_ktv_frags: B * 8 KiB scratch.
  * Rounding points are those of the layer-by-layer path (bf16 wherever that path stored a tensor), accumulation fp32; GELU's erf is
@@ -336,7 +338,8 @@ int rc_gma_tail(const void* d_qkvp, const void* d_convv, const void* d_loc, cons
                 float eps, const void* d_w_fc1, const float* d_b_fc1, const void* d_w_fc2, const float* d_b_fc2, const void* d_res,
                 const void* d_w_out, const float* d_b_out, int cout, void* d_out, void* stream);
 
-/* rc_gma_aggregate: the whole Aggregator (groupmix.py:56-105) for dim 80, bf16, one launch: qkv (B,H,W,240) -> qkvp (B,H,W,3,64)
+/* rc_gma_aggregate: the whole Aggregator (groupmix.py:56-105) for dim 80, bf16, one launch: qkv in rc_gma_ln_qkv's segment-planar
+ * layout [15][B,H,W][16] -> qkvp, segment-planar too: [12 = 4 * {q,k,v} + group][B,H,W][16]
  * [q|k|v][group 0: BN+Hardswish | groups 1..3: dw 3/5/7 -> pw 16x16 -> BN -> Hardswish] and loc (B,H,W,16) = Hardswish(LN(pw(dw3x3(
  * [q4|k4|v4])))).  dw3/5/7: tap-major (K*K,16) fp32; dwl (3,9,16); pw (3,16,16) [out][in]; pwl (16,48); bn_scale/shift (4,16)
  * (BatchNorm(eval) folded); ln (16).  Same values as rc_dwconv2d + rc_gma_pointwise up to the point-wise product's summation order. */
@@ -344,8 +347,8 @@ int rc_gma_aggregate(const void* d_qkv, void* d_qkvp, void* d_loc, int batch, in
                      const float* d_dw7, const float* d_dwl, const float* d_pw, const float* d_pwl, const float* d_bn_scale,
                      const float* d_bn_shift, const float* d_ln_g, const float* d_ln_b, void* stream);
 
-/* rc_gma_crpe: ConvRelPosEnc's depth-wise conv of v (groupmix.py:127-133,146-150) for dim 80 / 8 heads of 8, bf16: v = qkvp[..,2,:]
- * (B,H,W,3,64) -> convv (B,H,W,64); four 16-channel segments with windows 3, 5, 7, 7 (tap-major (K*K,16) fp32 each; segment 2 holds
+/* rc_gma_crpe: ConvRelPosEnc's depth-wise conv of v (groupmix.py:127-133,146-150) for dim 80 / 8 heads of 8, bf16: v = segments 8..11
+ * of rc_gma_aggregate's segment-planar qkvp -> convv, segment-planar [4][B,H,W][16]; four 16-channel segments with windows 3, 5, 7, 7 (tap-major (K*K,16) fp32 each; segment 2 holds
  * heads of window 5 and 7, its window-5 taps zero-padded to 7x7), bias (64).  Same values as rc_dwconv2d. */
 int rc_gma_crpe(const void* d_qkvp, void* d_convv, int batch, int H, int W, const float* d_taps0, const float* d_taps1,
                 const float* d_taps2, const float* d_taps3, const float* d_bias, void* stream);
@@ -365,6 +368,8 @@ int rc_gma_kv_blocks(int n_tok);
 size_t rc_gma_kv_scratch_bytes(int batch, int n_tok, int heads, int ch);
 int rc_gma_kv(const void* d_qkvp, int dtype, int batch, int n_tok, int heads, int ch, float scale, float* d_scratch,
               float* d_ktv, void* stream);
+/* rc_gma_kv on rc_gma_aggregate's segment-planar qkvp ([12][B * n_tok][16], bf16). */
+int rc_gma_kv_planar(const void* d_qkvp, int batch, int n_tok, int heads, int ch, float scale, float* d_scratch, float* d_ktv, void* stream);
 int rc_gma_apply(const void* d_qkvp, const void* d_convv, const void* d_loc, const float* d_ktv, void* d_out, int dtype,
                  int batch, int n_tok, int heads, int ch, int seg, void* stream);
 

@@ -119,6 +119,7 @@ _SIGS = {
     "rc_gma_kv_blocks": (C.c_int, [_I]),
     "rc_gma_kv_scratch_bytes": (_SZ, [_I, _I, _I, _I]),
     "rc_gma_kv": (C.c_int, [_P, _I, _I, _I, _I, _I, _F, _P, _P, _P]),
+    "rc_gma_kv_planar": (C.c_int, [_P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "rc_gma_apply": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rc_debug_set": (C.c_int, [C.c_char_p, _I]),
     "rc_debug_set_ptr": (C.c_int, [C.c_char_p, _P]),

@@ -316,22 +316,32 @@ __global__ __launch_bounds__(kPwWaves * 64) void gma_pointwise_kernel(
 //  pass B  gma_kvsum: M = max over pmax (block prologue), then per tile p = exp(k - M):
 //                     Z[c] += p,  KTV[h][i][j] += p[h,i] * v[h,j]         -> part[b][blkB] = { Z[ct], KTV[nacc] }
 //  merge              fixed-order sum over blocks, ktv = scale * KTV / Z
+// Address of channel vector v (U channels) of q/k/v `which` at token t of image b.  plane == 0: token-major (B,N,3,ct);
+// plane > 0: planar by 16-channel segment, [3 * ct / 16][B * N][16] with `plane` elements per segment (bf16: a vector is half a segment).
 template <typename T>
-__global__ __launch_bounds__(kGThreads) void gma_kmax_kernel(const T* __restrict__ qkvp, float* __restrict__ pmax, int n_tok, int L, int ct) {
+__device__ __forceinline__ const T* qkvp_vec(const T* qkvp, size_t plane, int b, int n_tok, int ct, int which, int t, int v) {
+    constexpr int U = Vec16<T>::N;
+    const size_t tok = (size_t)b * n_tok + t;
+    if (plane == 0) return qkvp + tok * 3 * ct + which * ct + v * U;
+    const int c = v * U;
+    return qkvp + (size_t)(which * (ct / 16) + c / 16) * plane + tok * 16 + (c & 15);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kGThreads) void gma_kmax_kernel(const T* __restrict__ qkvp, size_t plane, float* __restrict__ pmax, int n_tok, int L, int ct) {
     constexpr int U = Vec16<T>::N;
     extern __shared__ float sm[];             // [groups][ct]
     const int vpt = ct / U, groups = kGThreads / vpt;
     const int tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
     const int v = tid % vpt, grp = tid / vpt;
     const int t0 = blk * L, t1 = (t0 + L) < n_tok ? (t0 + L) : n_tok;
-    const T* base = qkvp + (size_t)b * n_tok * 3 * ct + ct + v * U;
     float m[U];
 #pragma unroll
     for (int e = 0; e < U; ++e) m[e] = -INFINITY;
     if (grp < groups) {
         for (int t = t0 + grp; t < t1; t += groups) {
             float f[U];
-            Vec16<T>::unpack(*reinterpret_cast<const uint4*>(base + (size_t)t * 3 * ct), f);
+            Vec16<T>::unpack(*reinterpret_cast<const uint4*>(qkvp_vec(qkvp, plane, b, n_tok, ct, 1, t, v)), f);
 #pragma unroll
             for (int e = 0; e < U; ++e) m[e] = fmaxf(m[e], f[e]);
         }
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(kGThreads) void gma_kmax_kernel(const T* __restrict
 }
 
 template <typename T, int MAXA>   // MAXA = accumulators per thread >= ceil(heads*ch*ch / 256)
-__global__ __launch_bounds__(kGThreads, 2) void gma_kvsum_kernel(const T* __restrict__ qkvp, const float* __restrict__ pmax, int nblk_a,
+__global__ __launch_bounds__(kGThreads, 2) void gma_kvsum_kernel(const T* __restrict__ qkvp, size_t plane, const float* __restrict__ pmax, int nblk_a,
                                                               float* __restrict__ part, int n_tok, int L, int heads, int ch, int tile) {
     constexpr int U = Vec16<T>::N;
     const int ct = heads * ch, nacc = heads * ch * ch, vpt = ct / U;
@@ -379,7 +389,6 @@ __global__ __launch_bounds__(kGThreads, 2) void gma_kvsum_kernel(const T* __rest
     float z = 0.f;                            // thread c < ct owns Z[c]
     __syncthreads();
     const int t0 = blk * L, t1 = (t0 + L) < n_tok ? (t0 + L) : n_tok;
-    const T* base = qkvp + (size_t)b * n_tok * 3 * ct;
     const int nvec_tile = tile * vpt;
     for (int tt = t0; tt < t1; tt += tile) {
         const int nt = (t1 - tt) < tile ? (t1 - tt) : tile;
@@ -387,9 +396,8 @@ __global__ __launch_bounds__(kGThreads, 2) void gma_kvsum_kernel(const T* __rest
             const int t = i / vpt, v = i - t * vpt;
             float fk[U], fv[U];
             if (t < nt) {
-                const T* tok = base + (size_t)(tt + t) * 3 * ct;
-                Vec16<T>::unpack(*reinterpret_cast<const uint4*>(tok + ct + v * U), fk);
-                Vec16<T>::unpack(*reinterpret_cast<const uint4*>(tok + 2 * ct + v * U), fv);
+                Vec16<T>::unpack(*reinterpret_cast<const uint4*>(qkvp_vec(qkvp, plane, b, n_tok, ct, 1, tt + t, v)), fk);
+                Vec16<T>::unpack(*reinterpret_cast<const uint4*>(qkvp_vec(qkvp, plane, b, n_tok, ct, 2, tt + t, v)), fv);
 #pragma unroll
                 for (int e = 0; e < U; ++e) fk[e] = expf(fk[e] - s_m[v * U + e]);
             } else {
@@ -620,9 +628,10 @@ size_t rc_gma_kv_scratch_bytes(int batch, int n_tok, int heads, int ch) {
     return (size_t)batch * rc_gma_kv_blocks(n_tok) * (2 * heads * ch + heads * ch * ch) * sizeof(float);
 }
 
-int rc_gma_kv(const void* d_qkvp, int dtype, int batch, int n_tok, int heads, int ch, float scale, float* d_scratch,
-              float* d_ktv, void* stream) {
+static int gma_kv_impl(const void* d_qkvp, size_t plane, int dtype, int batch, int n_tok, int heads, int ch, float scale, float* d_scratch,
+                       float* d_ktv, void* stream) {
     RC_REQUIRE(d_qkvp && d_scratch && d_ktv, "rc_gma_kv: null pointer");
+    RC_REQUIRE(plane == 0 || (dtype == RC_BF16 && (heads * ch) % 16 == 0), "rc_gma_kv_planar: bf16 with whole 16-channel segments only");
     RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_gma_kv: bad dtype");
     const int U = dtype == RC_F32 ? 4 : 8;
     RC_REQUIRE(batch >= 1 && batch <= 65535 && n_tok >= 1 && heads >= 1 && ch >= 1 && ch <= 32 && heads * ch * ch <= 256 * 16 &&
@@ -643,10 +652,10 @@ int rc_gma_kv(const void* d_qkvp, int dtype, int batch, int n_tok, int heads, in
     const int nacc = heads * ch * ch;
 #define RC_KV_LAUNCH(TT, MA)                                                                                              \
     hipLaunchKernelGGL((gma_kvsum_kernel<TT, MA>), dim3(nblk, batch), dim3(kGThreads), lds_b, as_stream(stream),          \
-                       static_cast<const TT*>(d_qkvp), pmax, nblk_a, part, n_tok, L, heads, ch, tile)
+                       static_cast<const TT*>(d_qkvp), plane, pmax, nblk_a, part, n_tok, L, heads, ch, tile)
 #define RC_KV_BOTH(TT)                                                                                                    \
     hipLaunchKernelGGL(gma_kmax_kernel<TT>, dim3(nblk_a, batch), dim3(kGThreads), lds_a, as_stream(stream),                \
-                       static_cast<const TT*>(d_qkvp), pmax, n_tok, L_a, ct);                                             \
+                       static_cast<const TT*>(d_qkvp), plane, pmax, n_tok, L_a, ct);                                             \
     if (nacc <= 2 * kGThreads) RC_KV_LAUNCH(TT, 2); else if (nacc <= 4 * kGThreads) RC_KV_LAUNCH(TT, 4); else RC_KV_LAUNCH(TT, 16);
     if (dtype == RC_F32) { RC_KV_BOTH(float) } else { RC_KV_BOTH(bf16_t) }
 #undef RC_KV_BOTH
@@ -655,6 +664,15 @@ int rc_gma_kv(const void* d_qkvp, int dtype, int batch, int n_tok, int heads, in
                        ch, scale);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
+}
+
+int rc_gma_kv(const void* d_qkvp, int dtype, int batch, int n_tok, int heads, int ch, float scale, float* d_scratch,
+              float* d_ktv, void* stream) {
+    return gma_kv_impl(d_qkvp, 0, dtype, batch, n_tok, heads, ch, scale, d_scratch, d_ktv, stream);
+}
+
+int rc_gma_kv_planar(const void* d_qkvp, int batch, int n_tok, int heads, int ch, float scale, float* d_scratch, float* d_ktv, void* stream) {
+    return gma_kv_impl(d_qkvp, (size_t)batch * n_tok * 16, RC_BF16, batch, n_tok, heads, ch, scale, d_scratch, d_ktv, stream);
 }
 
 int rc_gma_apply(const void* d_qkvp, const void* d_convv, const void* d_loc, const float* d_ktv, void* d_out, int dtype,

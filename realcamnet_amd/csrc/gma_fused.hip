@@ -118,6 +118,13 @@ template <int C> __device__ __forceinline__ void load_act(const bf16_t* p, int g
     for (int s = 0; s < Act<C>::KS; ++s) a.f[s] = *reinterpret_cast<const uint4*>(p + 32 * s + 8 * g);
     if constexpr (Act<C>::TAIL) a.t = *reinterpret_cast<const uint2*>(p + 32 * Act<C>::KS + 4 * g);
 }
+// the same fragments from a tensor laid out planar by 16-channel segment ([C / 16][tokens][16], `plane` elements per segment):
+// K-step s, lane group g -> half (g & 1) of segment 2 s + (g >> 1): a wave instruction reads two contiguous 512-byte runs
+template <int C> __device__ __forceinline__ void load_act_planar(const bf16_t* base, size_t plane, size_t tok, int g, Act<C>& a) {
+#pragma unroll
+    for (int s = 0; s < Act<C>::KS; ++s) a.f[s] = *reinterpret_cast<const uint4*>(base + (size_t)(2 * s + (g >> 1)) * plane + tok * 16 + 8 * (g & 1));
+    if constexpr (Act<C>::TAIL) a.t = *reinterpret_cast<const uint2*>(base + (size_t)(2 * Act<C>::KS) * plane + tok * 16 + 4 * g);
+}
 template <int C> __device__ __forceinline__ void store_act(bf16_t* p, int g, const Act<C>& a) {
 #pragma unroll
     for (int s = 0; s < Act<C>::KS; ++s) *reinterpret_cast<uint4*>(p + 32 * s + 8 * g) = a.f[s];
@@ -152,6 +159,9 @@ __device__ __forceinline__ void layernorm80(const Act<kC> (&in)[kNT], Act<kC> (&
 // exact-erf GELU to 1.5e-7 absolute in erf (Abramowitz-Stegun 7.1.26), far below the bf16 rounding that follows:
 // 0.5 v (1 + erf(v / sqrt 2)),  erf(z) = sign(z) (1 - (a1 t + .. + a5 t^5) exp(-z^2)),  t = 1 / (1 + p |z|)
 __device__ __forceinline__ float gelu_erf(float v) {
+#ifdef GF_EXP_NOGELU
+    return v;
+#endif
     const float z = fabsf(v) * 0.70710678118654752f;
     const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
@@ -160,6 +170,9 @@ __device__ __forceinline__ float gelu_erf(float v) {
 }
 
 // ---- LayerNorm1 + qkv ------------------------------------------------------------------------------------------------------------
+// Output layout: PLANAR BY 16-CHANNEL SEGMENT, qkv[15][tokens][16] (segment = 5 which + group).  The token-major (tokens, 240) form
+// made this kernel's stores 64-byte pieces at a 480-byte stride (0.52 of its 0.90 ms) and the aggregator's loads 32-byte pieces of
+// 480-byte records; segment planes turn both into contiguous 512-byte runs per instruction.
 constexpr int kQkvThreads = 256;
 __global__ __launch_bounds__(kQkvThreads) void gma_ln_qkv_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ qkv, size_t tokens,
                                                                    const void* __restrict__ w_qkv, const float* __restrict__ b_qkv,
@@ -176,6 +189,16 @@ __global__ __launch_bounds__(kQkvThreads) void gma_ln_qkv_kernel(const bf16_t* _
     __syncthreads();
     const int lane = tid & 63, n = lane & 15, g = lane >> 4;
     const size_t n_tiles = (tokens + 63) / 64, wave = (size_t)blockIdx.x * (kQkvThreads / 64) + (tid >> 6), n_waves = (size_t)gridDim.x * (kQkvThreads / 64);
+    // software pipeline: the next tile's x is in flight while this tile's LayerNorm + 240 MFMAs run (a wave that loads, waits,
+    // computes and stores in turn left the launch at 3 TB/s)
+    Act<kC> xnext[kNT];
+    if (wave < n_tiles) {
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            const size_t t = wave * 64 + 16 * nt + n;
+            load_act<kC>(x + (t < tokens ? t : tokens - 1) * kC, g, xnext[nt]);
+        }
+    }
     for (size_t tile = wave; tile < n_tiles; tile += n_waves) {
         Act<kC> xin[kNT], n1[kNT];
         size_t tok[kNT];
@@ -183,7 +206,14 @@ __global__ __launch_bounds__(kQkvThreads) void gma_ln_qkv_kernel(const bf16_t* _
         for (int nt = 0; nt < kNT; ++nt) {
             const size_t t = tile * 64 + 16 * nt + n;
             tok[nt] = t < tokens ? t : tokens - 1;
-            load_act<kC>(x + tok[nt] * kC, g, xin[nt]);
+            xin[nt] = xnext[nt];
+        }
+        if (tile + n_waves < n_tiles) {
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                const size_t t = (tile + n_waves) * 64 + 16 * nt + n;
+                load_act<kC>(x + (t < tokens ? t : tokens - 1) * kC, g, xnext[nt]);
+            }
         }
         layernorm80(xin, n1, s_gb, g, eps);
 #pragma unroll
@@ -194,8 +224,9 @@ __global__ __launch_bounds__(kQkvThreads) void gma_ln_qkv_kernel(const bf16_t* _
             const f32x4 b0 = bias4(s_bias, 2 * p, g), b1 = bias4(s_bias, 2 * p + 1, g);
 #pragma unroll
             for (int nt = 0; nt < kNT; ++nt)
-                if (tile * 64 + 16 * nt + n < tokens)
-                    *reinterpret_cast<uint4*>(qkv + tok[nt] * (3 * kC) + 32 * p + 8 * g) = pack_pair(acc[0][nt] + b0, acc[1][nt] + b1);
+                if (tile * 64 + 16 * nt + n < tokens)      // channels 32 p + 8 g .. + 8 = half (g & 1) of segment 2 p + (g >> 1)
+                    *reinterpret_cast<uint4*>(qkv + ((size_t)(2 * p + (g >> 1)) * tokens + tok[nt]) * kSEG + 8 * (g & 1)) =
+                        pack_pair(acc[0][nt] + b0, acc[1][nt] + b1);
         }
         if constexpr (MT & 1) {
             f32x4 acc[1][kNT];
@@ -205,7 +236,7 @@ __global__ __launch_bounds__(kQkvThreads) void gma_ln_qkv_kernel(const bf16_t* _
 #pragma unroll
             for (int nt = 0; nt < kNT; ++nt)
                 if (tile * 64 + 16 * nt + n < tokens)
-                    *reinterpret_cast<uint2*>(qkv + tok[nt] * (3 * kC) + 16 * (MT - 1) + 4 * g) = pack_tail(acc[0][nt] + b0);
+                    *reinterpret_cast<uint2*>(qkv + ((size_t)(MT - 1) * tokens + tok[nt]) * kSEG + 4 * g) = pack_tail(acc[0][nt] + b0);
         }
     }
 }
@@ -226,8 +257,9 @@ __global__ void gma_ktv_pack_kernel(const float* __restrict__ ktv /* (B, 8, 8, 8
 
 // ---- attention read-out + proj + LN2 + MLP [+ output conv] ---------------------------------------------------------------------------
 struct TailArgs {
-    const bf16_t* qkvp; int q_stride;        // q = qkvp[tok * q_stride + 0..64)
-    const bf16_t* convv; const bf16_t* loc; const bf16_t* x;
+    const bf16_t* qkvp; size_t plane;        // segment-planar [12][tokens][16]: q = segments 0..3; `plane` = tokens * 16 elements
+    const bf16_t* convv;                      // segment-planar [4][tokens][16]
+    const bf16_t* loc; const bf16_t* x;       // (tokens, 16), (tokens, 80)
     const bf16_t* res;                        // COUT > 0: residual of the output conv (tokens, COUT)
     bf16_t* out;                              // (tokens, COUT > 0 ? COUT : 80)
     const uint4* ktv_frags;
@@ -291,8 +323,8 @@ __global__ __launch_bounds__(kTailThreads, 2) void gma_tail_kernel(TailArgs a) {
             Act<kSEG> lc[kNT];
 #pragma unroll
             for (int nt = 0; nt < kNT; ++nt) {
-                load_act<kCT>(a.qkvp + tok[nt] * a.q_stride, g, q[nt]);
-                load_act<kCT>(a.convv + tok[nt] * kCT, g, cv[nt]);
+                load_act_planar<kCT>(a.qkvp, a.plane, tok[nt], g, q[nt]);
+                load_act_planar<kCT>(a.convv, a.plane, tok[nt], g, cv[nt]);
                 load_act<kSEG>(a.loc + tok[nt] * kSEG, g, lc[nt]);
                 load_act<kC>(a.x + tok[nt] * kC, g, x2[nt]);
             }
@@ -488,7 +520,7 @@ int rc_gma_tail(const void* d_qkvp, const void* d_convv, const void* d_loc, cons
     RC_REQUIRE(cout == 0 || cout == 192, "rc_gma_tail: the output conv is built for 0 (none) or 192 channels");
     if (cout) RC_REQUIRE(d_res && d_w_out && d_b_out, "rc_gma_tail: output conv needs residual, weights and bias");
     TailArgs a;
-    a.qkvp = static_cast<const bf16_t*>(d_qkvp); a.q_stride = 3 * kCT;
+    a.qkvp = static_cast<const bf16_t*>(d_qkvp); a.plane = (size_t)batch * n_tok * kSEG;
     a.convv = static_cast<const bf16_t*>(d_convv); a.loc = static_cast<const bf16_t*>(d_loc); a.x = static_cast<const bf16_t*>(d_x);
     a.res = static_cast<const bf16_t*>(d_res); a.out = static_cast<bf16_t*>(d_out); a.ktv_frags = static_cast<const uint4*>(d_ktv_frags);
     a.w_proj = d_w_proj; a.w_fc1 = d_w_fc1; a.w_fc2 = d_w_fc2; a.w_out = d_w_out;
@@ -538,11 +570,14 @@ namespace gf {
 constexpr int AG_TH = 16, AG_TW = 32, AG_THREADS = 256;
 constexpr int AG_PS = 40;                                                  // LDS pixel stride in bytes (32 of data): 4 pixels = 40 dwords,
                                                                            // so the 8 column groups of a wave hit 8 different bank octets
-constexpr int AG_MAXPIX = (AG_TH + 6) * (AG_TW + 6);
+constexpr int AG_RPAD = 8;                                                 // + 8 bytes per halo row: the two row pairs of a wave (lanes n, n + 8)
+                                                                           // then sit 4 dwords apart modulo 8 instead of on the same banks
+constexpr int AG_LDS = (AG_TH + 6) * ((AG_TW + 6) * AG_PS + AG_RPAD);
 
 struct AggArgs {
     const bf16_t* qkv; bf16_t* qkvp; bf16_t* loc;
     int batch, H, W, tiles_x, tiles_y;
+    size_t plane;                // elements per segment plane = batch * H * W * 16
     const float* dw[3];          // groups 1..3: tap-major [K*K][16], K = 3, 5, 7
     const float* dwl;            // local branch: [3 (q,k,v)][9][16]
     const float* pw;             // [3][16 out][16 in]
@@ -573,20 +608,23 @@ __device__ __forceinline__ void agg_stage(char* s_x, const bf16_t* img, int cs, 
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int i = tid + k * AG_THREADS;
-        if (i < NPIECE) *reinterpret_cast<uint4*>(s_x + (i >> 1) * AG_PS + (i & 1) * 16) = raw[k];
+        if (i < NPIECE) {
+            const int pix = i >> 1, py = pix / TWH;
+            *reinterpret_cast<uint4*>(s_x + pix * AG_PS + py * AG_RPAD + (i & 1) * 16) = raw[k];
+        }
     }
 }
 
 // depth-wise KxK of this lane's 2 x 4 patch, channels 4 q .. 4 q + 3: acc[o][c] (fp32, taps in (dy, dx) order)
 template <int K>
 __device__ __forceinline__ void agg_dw(const char* s_x, const float* s_w, int prow, int pcol, int q, f32x4 (&acc)[2][4]) {
-    constexpr int R = K / 2, TWH = AG_TW + 2 * R;
-    const char* base = s_x + (prow * TWH + pcol) * AG_PS + q * 8;
+    constexpr int R = K / 2, TWH = AG_TW + 2 * R, RS = TWH * AG_PS + AG_RPAD;
+    const char* base = s_x + prow * RS + pcol * AG_PS + q * 8;
 #pragma unroll 1                                                           // rolled: fully unrolled, all 4 K^2 tap vectors were hoisted (256+ VGPRs)
     for (int iy = 0; iy < K + 1; ++iy) {
         f32x4 xin[K + 3];
 #pragma unroll
-        for (int c = 0; c < K + 3; ++c) xin[c] = up_tail(*reinterpret_cast<const uint2*>(base + (iy * TWH + c) * AG_PS));
+        for (int c = 0; c < K + 3; ++c) xin[c] = up_tail(*reinterpret_cast<const uint2*>(base + iy * RS + c * AG_PS));
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             const int dy = iy - o;
@@ -617,7 +655,7 @@ __device__ __forceinline__ void agg_conv_job(const AggArgs& a, char* s_x, float*
                                              int tid, int lane) {
     constexpr int R = K / 2;
     for (int i = tid; i < K * K * 16; i += AG_THREADS) s_w[i] = a.dw[g - 1][i];
-    agg_stage<R>(s_x, img, 3 * kC, which * kC + 16 * g, t.y0, t.x0, a.H, a.W, tid);
+    agg_stage<R>(s_x, img + (size_t)(5 * which + g) * a.plane, kSEG, 0, t.y0, t.x0, a.H, a.W, tid);
     const uint2 apw = agg_afrag(a.pw + (g - 1) * 256, 16, 0, lane);
     const f32x4 sc = ld4(a.bn_scale + 16 * g + 4 * t.q), sh = ld4(a.bn_shift + 16 * g + 4 * t.q);
     __syncthreads();
@@ -627,7 +665,7 @@ __device__ __forceinline__ void agg_conv_job(const AggArgs& a, char* s_x, float*
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[o][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     agg_dw<K>(s_x, s_w, t.prow, t.pcol, t.q, acc);
-    bf16_t* outp = a.qkvp + which * kCT + 16 * g + 4 * t.q;
+    bf16_t* outp = a.qkvp + (size_t)(4 * which + g) * a.plane + 4 * t.q;   // segment-planar [12][tokens][16]
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -638,7 +676,7 @@ __device__ __forceinline__ void agg_conv_job(const AggArgs& a, char* s_x, float*
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
             if (t.y0 + t.prow + o < a.H && t.x0 + t.pcol + c < a.W)
-                *reinterpret_cast<uint2*>(outp + (t.pix0 + (size_t)o * a.W + c) * (3 * kCT)) = pack_tail(v);
+                *reinterpret_cast<uint2*>(outp + (t.pix0 + (size_t)o * a.W + c) * kSEG) = pack_tail(v);
         }
 }
 
@@ -646,11 +684,15 @@ __device__ __forceinline__ void agg_conv_job(const AggArgs& a, char* s_x, float*
 // One short job per block: with 4 blocks per CU in different phases the staging loads of one hide under the FMAs of another
 // (one block walking all of a tile's groups, barrier to barrier, ran at a sixth of its FMA time).
 __global__ __launch_bounds__(AG_THREADS) void gma_agg_kernel(AggArgs a) {
-    __shared__ __attribute__((aligned(16))) char s_x[AG_MAXPIX * AG_PS];
+    __shared__ __attribute__((aligned(16))) char s_x[AG_LDS];
     __shared__ __attribute__((aligned(16))) float s_w[49 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15;
+    // block -> (tile, job): a tile's 10 jobs are placed 8 blocks apart so that they land on ONE XCD (block b runs on XCD b % 8) close in
+    // time: their outputs interleave in the same 384-byte qkvp pixel records, which that XCD's L2 then completes line by line
     int blk = blockIdx.x;
-    const int job = blk % 10; blk /= 10;
+    const int lane8 = blk & 7; blk >>= 3;
+    const int job = blk % 10; blk = (blk / 10) * 8 + lane8;
+    if (blk >= a.tiles_x * a.tiles_y * a.batch) return;
     const int tx = blk % a.tiles_x; blk /= a.tiles_x;
     const int ty = blk % a.tiles_y;
     const int b = blk / a.tiles_y;
@@ -658,7 +700,7 @@ __global__ __launch_bounds__(AG_THREADS) void gma_agg_kernel(AggArgs a) {
     t.y0 = ty * AG_TH; t.x0 = tx * AG_TW; t.q = lane >> 4;
     t.prow = 4 * wave + 2 * (n >> 3); t.pcol = 4 * (n & 7);               // this lane's patch: 2 rows x 4 columns of the tile
     t.pix0 = ((size_t)b * a.H + t.y0 + t.prow) * a.W + t.x0 + t.pcol;
-    const bf16_t* img = a.qkv + (size_t)b * a.H * a.W * (3 * kC);
+    const bf16_t* img = a.qkv + (size_t)b * a.H * a.W * kSEG;             // + segment * plane
     const int q = t.q;
 
     if (job < 9) {
@@ -675,10 +717,10 @@ __global__ __launch_bounds__(AG_THREADS) void gma_agg_kernel(AggArgs a) {
                 for (int c = 0; c < 4; ++c)
                     if (t.y0 + t.prow + o < a.H && t.x0 + t.pcol + c < a.W) {
                         const size_t p = t.pix0 + (size_t)o * a.W + c;
-                        f32x4 v = up_tail(*reinterpret_cast<const uint2*>(a.qkv + p * (3 * kC) + which * kC + 4 * q)) * sc + sh;
+                        f32x4 v = up_tail(*reinterpret_cast<const uint2*>(a.qkv + (size_t)(5 * which) * a.plane + p * kSEG + 4 * q)) * sc + sh;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
-                        *reinterpret_cast<uint2*>(a.qkvp + p * (3 * kCT) + which * kCT + 4 * q) = pack_tail(v);
+                        *reinterpret_cast<uint2*>(a.qkvp + (size_t)(4 * which) * a.plane + p * kSEG + 4 * q) = pack_tail(v);
                     }
         }
     } else {
@@ -691,7 +733,7 @@ __global__ __launch_bounds__(AG_THREADS) void gma_agg_kernel(AggArgs a) {
         for (int wh = 0; wh < 3; ++wh) {
             __syncthreads();
             for (int i = tid; i < 9 * 16; i += AG_THREADS) s_w[i] = a.dwl[wh * 144 + i];
-            agg_stage<1>(s_x, img, 3 * kC, wh * kC + 4 * kSEG, t.y0, t.x0, a.H, a.W, tid);
+            agg_stage<1>(s_x, img + (size_t)(5 * wh + 4) * a.plane, kSEG, 0, t.y0, t.x0, a.H, a.W, tid);
             const uint2 apw = agg_afrag(a.pwl, 48, 16 * wh, lane);
             __syncthreads();
             f32x4 acc[2][4];
@@ -731,7 +773,7 @@ __global__ __launch_bounds__(AG_THREADS) void gma_agg_kernel(AggArgs a) {
 // ---- ConvRelPosEnc's depth-wise conv of v (groupmix.py:108-156): 64 channels in four 16-channel segments with windows 3, 5, 7, 7
 // (segment 2 mixes heads of window 5 and 7: its taps are zero-padded to 7 x 7), + bias.  Same tiles, staging and FMA core. ------------
 struct CrpeArgs {
-    const bf16_t* qkvp; bf16_t* convv; int batch, H, W, tiles_x, tiles_y;
+    const bf16_t* qkvp; bf16_t* convv; int batch, H, W, tiles_x, tiles_y; size_t plane;
     const float* taps[4];        // tap-major [K*K][16] per segment, K = 3, 5, 7, 7
     const float* bias;           // [64]
 };
@@ -740,7 +782,7 @@ template <int K>
 __device__ __forceinline__ void crpe_job(const CrpeArgs& a, char* s_x, float* s_w, const bf16_t* img, const AggGeom& t, int seg, int tid) {
     constexpr int R = K / 2;
     for (int i = tid; i < K * K * 16; i += AG_THREADS) s_w[i] = a.taps[seg][i];
-    agg_stage<R>(s_x, img, 3 * kCT, 2 * kCT + 16 * seg, t.y0, t.x0, a.H, a.W, tid);
+    agg_stage<R>(s_x, img + (size_t)(8 + seg) * a.plane, kSEG, 0, t.y0, t.x0, a.H, a.W, tid);          // v = segments 8..11
     const f32x4 bv = ld4(a.bias + 16 * seg + 4 * t.q);
     __syncthreads();
     f32x4 acc[2][4];
@@ -754,15 +796,17 @@ __device__ __forceinline__ void crpe_job(const CrpeArgs& a, char* s_x, float* s_
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (t.y0 + t.prow + o < a.H && t.x0 + t.pcol + c < a.W)
-                *reinterpret_cast<uint2*>(a.convv + (t.pix0 + (size_t)o * a.W + c) * kCT + 16 * seg + 4 * t.q) = pack_tail(acc[o][c] + 0.f);
+                *reinterpret_cast<uint2*>(a.convv + (size_t)seg * a.plane + (t.pix0 + (size_t)o * a.W + c) * kSEG + 4 * t.q) = pack_tail(acc[o][c] + 0.f);
 }
 
 __global__ __launch_bounds__(AG_THREADS) void gma_crpe_kernel(CrpeArgs a) {
-    __shared__ __attribute__((aligned(16))) char s_x[AG_MAXPIX * AG_PS];
+    __shared__ __attribute__((aligned(16))) char s_x[AG_LDS];
     __shared__ __attribute__((aligned(16))) float s_w[49 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15;
-    int blk = blockIdx.x;
-    const int seg = 3 - (blk & 3); blk >>= 2;                               // heavy segments first
+    int blk = blockIdx.x;                                                   // a tile's 4 segments on one XCD (see gma_agg_kernel)
+    const int lane8 = blk & 7; blk >>= 3;
+    const int seg = 3 - (blk & 3); blk = (blk >> 2) * 8 + lane8;            // heavy segments first
+    if (blk >= a.tiles_x * a.tiles_y * a.batch) return;
     const int tx = blk % a.tiles_x; blk /= a.tiles_x;
     const int ty = blk % a.tiles_y;
     const int b = blk / a.tiles_y;
@@ -770,7 +814,7 @@ __global__ __launch_bounds__(AG_THREADS) void gma_crpe_kernel(CrpeArgs a) {
     t.y0 = ty * AG_TH; t.x0 = tx * AG_TW; t.q = lane >> 4;
     t.prow = 4 * wave + 2 * (n >> 3); t.pcol = 4 * (n & 7);
     t.pix0 = ((size_t)b * a.H + t.y0 + t.prow) * a.W + t.x0 + t.pcol;
-    const bf16_t* img = a.qkvp + (size_t)b * a.H * a.W * (3 * kCT);
+    const bf16_t* img = a.qkvp + (size_t)b * a.H * a.W * kSEG;
     if (seg == 0) crpe_job<3>(a, s_x, s_w, img, t, seg, tid);
     else if (seg == 1) crpe_job<5>(a, s_x, s_w, img, t, seg, tid);
     else crpe_job<7>(a, s_x, s_w, img, t, seg, tid);
@@ -790,9 +834,10 @@ extern "C" int rc_gma_aggregate(const void* d_qkv, void* d_qkvp, void* d_loc, in
     AggArgs a;
     a.qkv = static_cast<const bf16_t*>(d_qkv); a.qkvp = static_cast<bf16_t*>(d_qkvp); a.loc = static_cast<bf16_t*>(d_loc);
     a.batch = batch; a.H = H; a.W = W; a.tiles_x = ceil_div(W, AG_TW); a.tiles_y = ceil_div(H, AG_TH);
+    a.plane = (size_t)batch * H * W * kSEG;
     a.dw[0] = d_dw3; a.dw[1] = d_dw5; a.dw[2] = d_dw7; a.dwl = d_dwl; a.pw = d_pw; a.pwl = d_pwl;
     a.bn_scale = d_bn_scale; a.bn_shift = d_bn_shift; a.ln_g = d_ln_g; a.ln_b = d_ln_b;
-    const size_t blocks = (size_t)a.tiles_x * a.tiles_y * batch * 10;
+    const size_t blocks = (((size_t)a.tiles_x * a.tiles_y * batch + 7) / 8) * 8 * 10;
     RC_REQUIRE(blocks < (1ull << 31), "rc_gma_aggregate: too many tiles");
     hipLaunchKernelGGL(gma_agg_kernel, dim3((unsigned)blocks), dim3(AG_THREADS), 0, as_stream(stream), a);
     RC_HIP_CHECK(hipGetLastError());
@@ -808,8 +853,9 @@ extern "C" int rc_gma_crpe(const void* d_qkvp, void* d_convv, int batch, int H, 
     CrpeArgs a;
     a.qkvp = static_cast<const bf16_t*>(d_qkvp); a.convv = static_cast<bf16_t*>(d_convv);
     a.batch = batch; a.H = H; a.W = W; a.tiles_x = ceil_div(W, AG_TW); a.tiles_y = ceil_div(H, AG_TH);
+    a.plane = (size_t)batch * H * W * kSEG;
     a.taps[0] = d_taps0; a.taps[1] = d_taps1; a.taps[2] = d_taps2; a.taps[3] = d_taps3; a.bias = d_bias;
-    const size_t blocks = (size_t)a.tiles_x * a.tiles_y * batch * 4;
+    const size_t blocks = (((size_t)a.tiles_x * a.tiles_y * batch + 7) / 8) * 8 * 4;
     RC_REQUIRE(blocks < (1ull << 31), "rc_gma_crpe: too many tiles");
     hipLaunchKernelGGL(gma_crpe_kernel, dim3((unsigned)blocks), dim3(AG_THREADS), 0, as_stream(stream), a);
     RC_HIP_CHECK(hipGetLastError());

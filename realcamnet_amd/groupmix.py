@@ -84,11 +84,11 @@ class Aggregator(nn.Module):
         """qkv NHWC (B,H,W,3C) -> qkvp (B,H,W,3,4seg) [q|k|v, channel = head*Ch + i], loc (B,H,W,seg)."""
         if self.seg != 5:
             raise NotImplementedError("Aggregator: seg=5 only (as EfficientAtt builds it)")
+        if qkv.dim() == 5:                                 # segment-planar (15, B, H, W, 16) from realcam::gma_ln_qkv
+            return self._run_fused(qkv)
         b, H, W, c3 = qkv.shape
         c, seg = c3 // 3, c3 // 15
         dev, dt = qkv.device, qkv.dtype
-        if ops.FUSE_GMA and dt == torch.bfloat16 and c == 80:
-            return self._run_fused(qkv)
         # all four depth-wise stages (groups 1..3: k = 3, 5, 7 shared by q/k/v; group 4: the local branch's own 3x3 per
         # q/k/v) in ONE launch: taps zero-padded to 7x7, the true window per weight vector in kvec (padded taps are
         # skipped, never multiplied), output (B,H,W,3,4seg) = [rep][g1 | g2 | g3 | g4] -- qkv is read once, not 4 times
@@ -128,7 +128,8 @@ class Aggregator(nn.Module):
         return ops.host_cached(self, "fold", params, fold)
 
     def _run_fused(self, qkv):
-        """dim 80, bf16: depth-wise, point-wise, BatchNorm, Hardswish and the local branch in ONE launch (rc_gma_aggregate)."""
+        """dim 80, bf16: depth-wise, point-wise, BatchNorm, Hardswish and the local branch in ONE launch (rc_gma_aggregate);
+        qkv in the segment-planar layout (15, B, H, W, 16) that realcam::gma_ln_qkv writes."""
         seg = 16
 
         def taps(w1, w2, w3, w0):
@@ -165,13 +166,15 @@ class ConvRelPosEnc(nn.Module):
 
     def _conv_v(self, qkvp):
         """depth-wise conv of v (channels 2ct..3ct of qkvp) with every window zero-padded to a centred 7x7."""
-        b, H, W, _, ct = qkvp.shape
+        planar = qkvp.dim() == 5 and qkvp.shape[0] == 12 and qkvp.shape[-1] == 16      # realcam::gma_aggregate's segment planes
+        ct = 64 if planar else qkvp.shape[-1]
         kmax = max(self.window.keys())
         if kmax > 7 or any(k % 2 == 0 for k in self.window):
             raise NotImplementedError("ConvRelPosEnc: odd windows up to 7")
         params = [t for cv in self.conv_list for t in (cv.weight, cv.bias)]
-        if (ops.FUSE_GMA and qkvp.dtype == torch.bfloat16 and ct == 64 and list(self.window.items()) == [(3, 2), (5, 3), (7, 3)] and
-                self.channel_splits == [16, 24, 24]):
+        if planar:
+            if list(self.window.items()) != [(3, 2), (5, 3), (7, 3)] or self.channel_splits != [16, 24, 24]:
+                raise NotImplementedError("fused ConvRelPosEnc: windows {3: 2, 5: 3, 7: 3} over 8 heads of 8 channels")
             def seg_taps(*p):   # 16-channel segments: [conv3 (16)] [conv5 0..16] [conv5 16..24 padded to 7x7 | conv7 0..8] [conv7 8..24]
                 w3, w5, w7 = p[0], p[2], p[4]
                 t2 = torch.cat([ops.dw_taps(w5[16:24], pad_to=7), ops.dw_taps(w7[0:8])], dim=1)
@@ -216,7 +219,7 @@ class EfficientAtt(nn.Module):
 
     def _context(self, qkv):
         """qkv (B,H,W,3C) -> (qkvp, loc, convv, ktv): aggregators, crpe's depth-wise conv of v, softmax_N(k)^T v."""
-        seg, ct, ch = self._geometry(qkv.shape[-1] // 3)
+        seg, ct, ch = self._geometry(80 if qkv.dim() == 5 else qkv.shape[-1] // 3)
         qkvp, loc = self.aggregator._run(qkv)
         convv = self.crpe._conv_v(qkvp)
         ktv = torch.ops.realcam.gma_kv(qkvp, self.num_heads, ch, float(self.scale))

@@ -408,15 +408,24 @@ define("gma_pointwise(Tensor qkv, Tensor dwc, Tensor pw, Tensor bn_scale, Tensor
        _gpw_launch)
 
 
+def _planar(qkvp) -> bool:
+    """segment-planar (12, B, H, W, 16) from realcam::gma_aggregate, as opposed to token-major (B, H, W, 3, ct)"""
+    return qkvp.shape[-1] == 16 and qkvp.shape[0] == 12 and qkvp.dim() == 5
+
+
 def _gkv_launch(ktv, qkvp, heads, ch, scale):
-    b, H, W = qkvp.shape[:3]
+    b, H, W = qkvp.shape[1:4] if _planar(qkvp) else qkvp.shape[:3]
     n = H * W
     scratch = torch.empty(lib().rc_gma_kv_scratch_bytes(b, n, heads, ch) // 4, dtype=torch.float32, device=qkvp.device)
-    check(lib().rc_gma_kv(qkvp.data_ptr(), _dt(qkvp), b, n, heads, ch, float(scale), scratch.data_ptr(), ktv.data_ptr(), _stream()), "rc_gma_kv")
+    if _planar(qkvp):
+        check(lib().rc_gma_kv_planar(qkvp.data_ptr(), b, n, heads, ch, float(scale), scratch.data_ptr(), ktv.data_ptr(), _stream()), "rc_gma_kv_planar")
+    else:
+        check(lib().rc_gma_kv(qkvp.data_ptr(), _dt(qkvp), b, n, heads, ch, float(scale), scratch.data_ptr(), ktv.data_ptr(), _stream()), "rc_gma_kv")
 
 
 define("gma_kv(Tensor qkvp, int heads, int ch, float scale) -> Tensor",
-       lambda qkvp, heads, ch, scale: qkvp.new_empty((qkvp.shape[0], heads, ch, ch), dtype=torch.float32), _gkv_launch)
+       lambda qkvp, heads, ch, scale: qkvp.new_empty((qkvp.shape[1] if _planar(qkvp) else qkvp.shape[0], heads, ch, ch), dtype=torch.float32),
+       _gkv_launch)
 
 define("gma_apply(Tensor qkvp, Tensor convv, Tensor loc, Tensor ktv, int heads, int ch, int seg) -> Tensor",
        lambda qkvp, convv, loc, ktv, heads, ch, seg: qkvp.new_empty((*qkvp.shape[:3], heads * ch + seg)),
@@ -458,7 +467,7 @@ def _cpack_launch(outs, weight, bias):
 define("chain_pack_weights(Tensor weight, Tensor? bias) -> (Tensor, Tensor)", _cpack_alloc, _cpack_launch)
 
 define("gma_ln_qkv(Tensor x, Tensor wpacked, Tensor bias_packed, Tensor ln_gamma, Tensor ln_beta, float eps) -> Tensor",
-       lambda x, wp, bp, g, b, eps: x.new_empty((*x.shape[:-1], 3 * x.shape[-1])),
+       lambda x, wp, bp, g, b, eps: x.new_empty((15, *x.shape[:-1], 16)),         # planar by 16-channel segment
        lambda out, x, wp, bp, g, b, eps: check(lib().rc_gma_ln_qkv(x.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], wp.data_ptr(),
                                                                    bp.data_ptr(), g.data_ptr(), b.data_ptr(), float(eps), _stream()),
                                                "rc_gma_ln_qkv"))
@@ -485,14 +494,14 @@ define("gma_tail(Tensor qkvp, Tensor convv, Tensor loc, Tensor x, Tensor ktv, Te
 
 define("gma_aggregate(Tensor qkv, Tensor dw3, Tensor dw5, Tensor dw7, Tensor dwl, Tensor pw, Tensor pwl, Tensor bn_scale, Tensor bn_shift, "
        "Tensor ln_gamma, Tensor ln_beta) -> (Tensor, Tensor)",
-       lambda qkv, *a: (qkv.new_empty((*qkv.shape[:3], 3, 64)), qkv.new_empty((*qkv.shape[:3], 16))),
+       lambda qkv, *a: (qkv.new_empty((12, *qkv.shape[1:4], 16)), qkv.new_empty((*qkv.shape[1:4], 16))),   # qkv: (15, B, H, W, 16)
        lambda outs, qkv, dw3, dw5, dw7, dwl, pw, pwl, sc, sh, lg, lb: check(
-           lib().rc_gma_aggregate(qkv.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), qkv.shape[0], qkv.shape[1], qkv.shape[2], dw3.data_ptr(),
+           lib().rc_gma_aggregate(qkv.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), qkv.shape[1], qkv.shape[2], qkv.shape[3], dw3.data_ptr(),
                                   dw5.data_ptr(), dw7.data_ptr(), dwl.data_ptr(), pw.data_ptr(), pwl.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                   lg.data_ptr(), lb.data_ptr(), _stream()), "rc_gma_aggregate"))
 
 define("gma_crpe(Tensor qkvp, Tensor taps0, Tensor taps1, Tensor taps2, Tensor taps3, Tensor bias) -> Tensor",
-       lambda qkvp, *a: qkvp.new_empty((*qkvp.shape[:3], 64)),
+       lambda qkvp, *a: qkvp.new_empty((4, *qkvp.shape[1:4], 16)),                 # segment-planar in and out
        lambda out, qkvp, t0, t1, t2, t3, bias: check(
-           lib().rc_gma_crpe(qkvp.data_ptr(), out.data_ptr(), qkvp.shape[0], qkvp.shape[1], qkvp.shape[2], t0.data_ptr(), t1.data_ptr(),
+           lib().rc_gma_crpe(qkvp.data_ptr(), out.data_ptr(), qkvp.shape[1], qkvp.shape[2], qkvp.shape[3], t0.data_ptr(), t1.data_ptr(),
                              t2.data_ptr(), t3.data_ptr(), bias.data_ptr(), _stream()), "rc_gma_crpe"))

@@ -19,6 +19,16 @@ R = torch.ops.realcam
 f32 = ops.f32_param
 
 
+def to_planar(t):      # (B,H,W,C) -> (C/16,B,H,W,16)
+    b, h, w, c = t.shape
+    return t.reshape(b, h, w, c // 16, 16).permute(3, 0, 1, 2, 4).contiguous()
+
+
+def from_planar(t):    # (S,B,H,W,16) -> (B,H,W,16 S)
+    s_, b, h, w, _ = t.shape
+    return t.permute(1, 2, 3, 0, 4).reshape(b, h, w, 16 * s_)
+
+
 def cmp(name, got, want):
     g, w = got.float(), want.float()
     bad = ~torch.isfinite(g)
@@ -41,13 +51,17 @@ with torch.no_grad():
     wq, bq = ops.packed_chain(blk.att.qkv)
     qkv_f = R.gma_ln_qkv(x, wq, bq, f32(blk.norm1, "weight"), f32(blk.norm1, "bias"), float(blk.norm1.eps))
     qkv_l = ops.conv2d(ops.layernorm(x, blk.norm1), blk.att.qkv)
+    qkv_planar = qkv_f
+    qkv_f = qkv_f.permute(1, 2, 3, 0, 4).reshape(*qkv_l.shape)
     cmp("ln_qkv", qkv_f, qkv_l)
     qkvp, loc, convv, ktv = blk.att._context(qkv_l)
     # stage 2: tail
     wp, bp = ops.packed_chain(blk.att.proj)
     w1, b1 = ops.packed_chain(blk.mlp.fc1)
     w2, b2 = ops.packed_chain(blk.mlp.fc2)
-    out_f = R.gma_tail(qkvp, convv, loc, x, ktv, wp, bp, f32(blk.norm2, "weight"), f32(blk.norm2, "bias"), float(blk.norm2.eps), w1, b1, w2, b2,
+    qkvp_p, convv_p = to_planar(qkvp.reshape(*qkvp.shape[:3], 192)), to_planar(convv)
+    cmp("kv planar vs token-major", R.gma_kv(qkvp_p, 8, 8, float(blk.att.scale)), ktv)
+    out_f = R.gma_tail(qkvp_p, convv_p, loc, x, ktv, wp, bp, f32(blk.norm2, "weight"), f32(blk.norm2, "bias"), float(blk.norm2.eps), w1, b1, w2, b2,
                        None, None, None)
     y = R.gma_apply(qkvp, convv, loc, ktv, 8, 8, 16)
     x2 = ops.conv2d(y, blk.att.proj, residual=x)
@@ -60,7 +74,7 @@ import copy
 def tail_both(b2k):
     with torch.no_grad():
         wp, bp = ops.packed_chain(b2k.att.proj); w1, b1 = ops.packed_chain(b2k.mlp.fc1); w2, b2 = ops.packed_chain(b2k.mlp.fc2)
-        of = R.gma_tail(qkvp, convv, loc, x, ktv, wp, bp, f32(b2k.norm2, "weight"), f32(b2k.norm2, "bias"), float(b2k.norm2.eps), w1, b1, w2, b2,
+        of = R.gma_tail(qkvp_p, convv_p, loc, x, ktv, wp, bp, f32(b2k.norm2, "weight"), f32(b2k.norm2, "bias"), float(b2k.norm2.eps), w1, b1, w2, b2,
                         None, None, None)
         y = R.gma_apply(qkvp, convv, loc, ktv, 8, 8, 16)
         x2 = ops.conv2d(y, b2k.att.proj, residual=x)
@@ -105,10 +119,11 @@ with torch.no_grad():
     for shape in ((2, 24, 40), (1, 37, 29), (1, 16, 32)):
         qkv_t = torch.randn(*shape, 240, device=dev).to(torch.bfloat16)
         ops.FUSE_GMA = True
-        qf, lf = agg._run(qkv_t)
+        qf, lf = agg._run(qkv_t.reshape(*shape, 15, 16).permute(3, 0, 1, 2, 4).contiguous())
         ops.FUSE_GMA = False
         ql, ll = agg._run(qkv_t)
         ops.FUSE_GMA = True
+        qf = from_planar(qf).reshape(*ql.shape)
         cmp(f"aggregate qkvp {shape}", qf, ql)
         cmp(f"aggregate loc  {shape}", lf, ll)
         for gidx in range(4):
@@ -119,7 +134,7 @@ with torch.no_grad():
     for shape in ((2, 24, 40), (1, 37, 29)):
         qp = torch.randn(*shape, 3, 64, device=dev).to(torch.bfloat16)
         ops.FUSE_GMA = True
-        cf = blk.att.crpe._conv_v(qp)
+        cf = from_planar(blk.att.crpe._conv_v(to_planar(qp.reshape(*shape, 192))))
         ops.FUSE_GMA = False
         cl = blk.att.crpe._conv_v(qp)
         ops.FUSE_GMA = True
