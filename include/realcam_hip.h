@@ -413,6 +413,42 @@ int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* me
 int rc_prof_enable(int on);
 int rc_prof_collect(int64_t* n_launches, double* total_ms, double* total_flops);
 
+/* ---- f3: on-device entropy coding (csrc/rans.hip) ----------------------------------------------------------
+ * Replaces the `.tolist()` symbol dumps + CompressAI `BufferedRansEncoder` / `RansDecoder` calls of compress() / decompress()
+ * (models/tcm.py:511-570, 592-637; models/raw2bit.py:1876-1944, 1961-2027) and the table construction of `update()`
+ * (models/tcm.py:430-435).  The coder is CompressAI's published rANS (64-bit state, 32-bit words, 16-bit probabilities, 4-bit bypass
+ * escapes); CompressAI itself is absent from /root/reference: restated, parity unpinned.
+ *
+ * rc_pmf_to_quantized_cdf (host): `compressai._CXX.pmf_to_quantized_cdf`: n probabilities -> n + 1 cumulative frequencies.
+ * rc_gc_symbols: GaussianConditional side of compress(): y, mu, scale NHWC (B, hw, C) -> symbols = round(y - mu) and CDF indexes
+ *   (`build_indexes`: scale table search with the 0.11 lower bound) as int32 in the coder's (b, c, hw) order, y_hat = symbols + mu
+ *   (NHWC).  d_y == NULL: indexes only (decompress()).   rc_gc_dequantize: y_hat = symbols + mu.
+ * rc_eb_symbols: EntropyBottleneck side: symbols = round(z - median[c]), index = c, z_hat (encode = 1), or z_hat from symbols (0).
+ * rc_rans_encode_chunks: one lane per chunk of `chunk` consecutive symbols, every chunk a complete stream in BufferedRansEncoder's
+ *   layout written at the END of its rc_rans_chunk_words(chunk)-word slot of d_words; d_nbytes[chunk] = its length (-1: bad index).
+ *   rc_rans_compact gathers the streams at the given byte offsets.   rc_rans_decode_chunks: the inverse (d_err != 0: bad index).
+ * rc_rans_encode_host / rc_rans_decode_host: the same primitives on the host for ONE stream over all symbols = CompressAI's wire
+ *   format; decode keeps the decoder state in state[2] (zero-initialised at the start of a stream) like RansDecoder.decode_stream. */
+int rc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, int32_t* cdf);
+int rc_gc_symbols(const void* d_y, const void* d_mu, const void* d_scale, int dtype, int batch, long long hw, int channels,
+                  const float* d_scale_table, int n_levels, float scale_bound, int32_t* d_symbols, int32_t* d_indexes, void* d_y_hat,
+                  void* stream);
+int rc_gc_dequantize(const int32_t* d_symbols, const void* d_mu, int dtype, int batch, long long hw, int channels, void* d_y_hat, void* stream);
+int rc_eb_symbols(const void* d_z, const float* d_medians, int dtype, int batch, long long hw, int channels, int encode, int32_t* d_symbols,
+                  int32_t* d_indexes, void* d_z_hat, void* stream);
+int rc_rans_chunk_words(int chunk);
+int rc_rans_encode_chunks(const int32_t* d_symbols, const int32_t* d_indexes, long long n, int chunk, const int32_t* d_cdf, int cdf_stride,
+                          int n_cdfs, const int32_t* d_cdf_sizes, const int32_t* d_offsets, uint32_t* d_words, int32_t* d_nbytes, void* stream);
+int rc_rans_compact(const uint32_t* d_words, int chunk, const int32_t* d_nbytes, const long long* d_offsets, long long n_chunks, void* d_out,
+                    void* stream);
+int rc_rans_decode_chunks(const void* d_stream, const long long* d_offsets, const int32_t* d_indexes, long long n, int chunk, const int32_t* d_cdf,
+                          int cdf_stride, int n_cdfs, const int32_t* d_cdf_sizes, const int32_t* d_cdf_offsets, int32_t* d_symbols, int32_t* d_err,
+                          void* stream);
+long long rc_rans_encode_host(const int32_t* symbols, const int32_t* indexes, long long n, const int32_t* cdf, int cdf_stride, int n_cdfs,
+                              const int32_t* cdf_sizes, const int32_t* offsets, void* out, long long out_cap);
+int rc_rans_decode_host(const void* stream_bytes, unsigned long long* state, const int32_t* indexes, long long n, const int32_t* cdf,
+                        int cdf_stride, int n_cdfs, const int32_t* cdf_sizes, const int32_t* offsets, int32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,8 +17,8 @@ def det_fill_(state_dict) -> None:
             leaf = key.rsplit(".", 1)[-1]
             g = torch.Generator().manual_seed(zlib.crc32(key.encode()))
             r = lambda *shape: torch.randn(*shape, generator=g)
-            if leaf in ("pedestal", "bound", "target"):
-                continue                                                        # fixed buffers of the re-parametrisations
+            if leaf in ("pedestal", "bound", "target", "scale_bound", "scale_table"):
+                continue                                                        # fixed buffers of the re-parametrisations / entropy models
             if leaf == "beta":                                                  # GDN: stored value = sqrt(effective + pedestal)
                 new = torch.sqrt(1.0 + 0.2 * torch.rand(v.shape, generator=g) + 2.0 ** -36)
             elif leaf == "gamma" and ".igdn." in key:                            # inverse GDN multiplies: keep its gain near 1

@@ -13,7 +13,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 OBJ = PKG / "_build"
 LIB = PKG / "librealcam_hip.so"
-SOURCES = ["lib.hip", "conv.hip", "conv_dispatch.hip", "conv_pair.hip", "chain.hip", "pointwise.hip", "cond.hip", "gma.hip", "gma_fused.hip", "wmsa.hip", "entropy.hip"] + sorted(p.name for p in CSRC.glob("conv_inst_*.hip"))
+SOURCES = ["lib.hip", "conv.hip", "conv_dispatch.hip", "conv_pair.hip", "chain.hip", "pointwise.hip", "cond.hip", "gma.hip", "gma_fused.hip", "wmsa.hip", "entropy.hip", "rans.hip"] + sorted(p.name for p in CSRC.glob("conv_inst_*.hip"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("RC_EXTRA_HIPCC_FLAGS", "").split()   # experiments only
 

@@ -1,0 +1,390 @@
+// On-device entropy coding for the codecs' compress() / decompress() (upstream models/tcm.py:511-570, 592-637;
+// models/raw2bit.py:1876-1944, 1961-2027) -- SURVEY.md 8f rank 3.
+//
+// Upstream dumps every latent to the host (`.tolist()`, raw2bit.py:1943-1944) and feeds CompressAI's C++ rANS coder one Python
+// list at a time.  Here the symbols never leave the GPU until they are bytes:
+//   rc_gc_symbols / rc_eb_symbols   quantise (round(y - mean)), look up the CDF index of every element (scale table search /
+//                                   channel), write y_hat -- one pass, int32 symbols + indexes in the coder's (c, h, w) order
+//   rc_rans_encode_chunks           rANS, ONE LANE PER CHUNK of `chunk` consecutive symbols: every chunk is a complete stream in
+//                                   CompressAI's BufferedRansEncoder layout (64-bit state, 32-bit words emitted back to front,
+//                                   lower bound 2^31, 16-bit probabilities, 4-bit bypass escapes), so chunk = all symbols
+//                                   reproduces CompressAI's single stream byte for byte, and smaller chunks are the parallel form
+//                                   a GPU needs (a rANS state is a serial dependency; 2 M symbols per 4K frame on one lane would
+//                                   take ~0.2 s).  A container (rc_rans_container_*) prefixes the chunk sizes.
+//   rc_rans_decode_chunks           the inverse: binary search of the 16-bit cumulative frequency in the element's CDF row
+//   rc_rans_encode_host / _decode_host   the same primitives compiled for the host: the single-stream CompressAI-layout form
+//                                   (format="compressai") for interchange with a CompressAI decoder.
+// All of it is integer arithmetic: bit-exact against the C oracle (oracle/rans_oracle.c), tests/test_bitstream.py.
+// The coder's definition is CompressAI's (absent from /root/reference, unpinned upstream): restated, parity unpinned.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.hpp"
+
+namespace rc {
+namespace ans {
+
+constexpr uint64_t kL = 1ull << 31;
+constexpr uint32_t kPrec = 16, kBypassBits = 4, kMaxBypass = (1u << kBypassBits) - 1;
+
+struct Tables { const int32_t* cdf; int stride; int n_cdfs; const int32_t* sizes; const int32_t* offsets; };
+
+__host__ __device__ inline bool put(uint64_t& x, uint32_t*& ptr, uint32_t* begin, uint32_t start, uint32_t freq) {
+    const uint64_t x_max = ((kL >> kPrec) << 32) * freq;
+    if (x >= x_max) {
+        if (ptr == begin) return false;
+        *--ptr = (uint32_t)x;
+        x >>= 32;
+    }
+    x = ((x / freq) << kPrec) + (x % freq) + start;
+    return true;
+}
+
+__host__ __device__ inline bool put_bits(uint64_t& x, uint32_t*& ptr, uint32_t* begin, uint32_t val) {
+    const uint32_t freq = 1u << (16 - kBypassBits);
+    const uint64_t x_max = ((kL >> 16) << 32) * freq;
+    if (x >= x_max) {
+        if (ptr == begin) return false;
+        *--ptr = (uint32_t)x;
+        x >>= 32;
+    }
+    x = (x << kBypassBits) | val;
+    return true;
+}
+
+// Encode symbols [i0, i1) as one complete stream whose last word is end[-1]; returns the first word, or NULL (bad index / no room).
+// Symbols are coded LAST TO FIRST (the decoder pops them first to last); an escaped symbol's pieces are therefore emitted in the
+// reverse of BufferedRansEncoder's push order: nibbles high to low, the length's base-15 digits (final digit, then the 15s), the
+// escape symbol itself.
+__host__ __device__ inline uint32_t* encode_range(const int32_t* sym, const int32_t* idx, long i0, long i1, const Tables& t, uint32_t* begin,
+                                                  uint32_t* end) {
+    uint64_t x = kL;
+    uint32_t* ptr = end;
+    for (long i = i1 - 1; i >= i0; --i) {
+        const int32_t ci = idx[i];
+        if (ci < 0 || ci >= t.n_cdfs) return nullptr;
+        const int32_t* cdf = t.cdf + (long)ci * t.stride;
+        const int32_t max_value = t.sizes[ci] - 2;
+        int32_t value = sym[i] - t.offsets[ci];
+        uint32_t raw = 0;
+        if (value < 0) { raw = (uint32_t)(-2 * value - 1); value = max_value; }
+        else if (value >= max_value) { raw = (uint32_t)(2 * (value - max_value)); value = max_value; }
+        if (value == max_value) {
+            int n_bypass = 0;
+            while (n_bypass < 8 && (raw >> (n_bypass * kBypassBits)) != 0) ++n_bypass;
+            for (int j = n_bypass - 1; j >= 0; --j)
+                if (!put_bits(x, ptr, begin, (raw >> (j * kBypassBits)) & kMaxBypass)) return nullptr;
+            if (!put_bits(x, ptr, begin, (uint32_t)n_bypass % kMaxBypass)) return nullptr;
+            for (uint32_t k = 0; k < (uint32_t)n_bypass / kMaxBypass; ++k)
+                if (!put_bits(x, ptr, begin, kMaxBypass)) return nullptr;
+        }
+        if (!put(x, ptr, begin, (uint32_t)cdf[value], (uint32_t)(cdf[value + 1] - cdf[value]))) return nullptr;
+    }
+    if (ptr - begin < 2) return nullptr;
+    ptr -= 2;
+    ptr[0] = (uint32_t)x;
+    ptr[1] = (uint32_t)(x >> 32);
+    return ptr;
+}
+
+struct DecState { uint64_t x; long pos; };
+
+__host__ __device__ inline uint32_t get_bits(DecState& st, const uint32_t* words) {
+    uint64_t x = st.x;
+    const uint32_t val = (uint32_t)(x & kMaxBypass);
+    x >>= kBypassBits;
+    if (x < kL) { x = (x << 32) | words[st.pos]; st.pos += 1; }
+    st.x = x;
+    return val;
+}
+
+// decode symbols [i0, i1) from a stream (state carried in st: call with x = words[0] | words[1] << 32, pos = 2 at its start)
+__host__ __device__ inline bool decode_range(const uint32_t* words, DecState& st, const int32_t* idx, long i0, long i1, const Tables& t,
+                                             int32_t* out) {
+    for (long i = i0; i < i1; ++i) {
+        const int32_t ci = idx[i];
+        if (ci < 0 || ci >= t.n_cdfs) return false;
+        const int32_t* cdf = t.cdf + (long)ci * t.stride;
+        const int32_t size = t.sizes[ci], max_value = size - 2;
+        const uint32_t cum = (uint32_t)(st.x & ((1u << kPrec) - 1));
+        int lo = 0, hi = size;                                   // first entry > cum (the CDF is strictly increasing up to size)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((uint32_t)cdf[mid] <= cum) lo = mid + 1; else hi = mid;
+        }
+        const int32_t s = lo - 1;
+        {
+            const uint32_t start = (uint32_t)cdf[s], freq = (uint32_t)(cdf[s + 1] - cdf[s]);
+            uint64_t x = (uint64_t)freq * (st.x >> kPrec) + (st.x & ((1u << kPrec) - 1)) - start;
+            if (x < kL) { x = (x << 32) | words[st.pos]; st.pos += 1; }
+            st.x = x;
+        }
+        int32_t value = s;
+        if (value == max_value) {
+            int32_t val = (int32_t)get_bits(st, words), n_bypass = val;
+            while (val == (int32_t)kMaxBypass) { val = (int32_t)get_bits(st, words); n_bypass += val; }
+            uint32_t raw = 0;
+            for (int32_t j = 0; j < n_bypass; ++j) raw |= get_bits(st, words) << (j * kBypassBits);
+            value = (int32_t)(raw >> 1);
+            if (raw & 1) value = -value - 1; else value += max_value;
+        }
+        out[i] = value + t.offsets[ci];
+    }
+    return true;
+}
+
+// ---- kernels ------------------------------------------------------------------------------------------------------------------
+// One lane per chunk.  words: [n_chunks][cap] scratch (each chunk's stream ends at its region's end); nbytes[chunk] = stream length,
+// -1 on error.
+__global__ void encode_chunks_kernel(const int32_t* sym, const int32_t* idx, long n, int chunk, Tables t, uint32_t* words, int cap,
+                                     int32_t* nbytes, long n_chunks) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const long i0 = c * chunk, i1 = (i0 + chunk) < n ? (i0 + chunk) : n;
+    uint32_t* begin = words + c * cap;
+    uint32_t* p = encode_range(sym, idx, i0, i1, t, begin, begin + cap);
+    nbytes[c] = p ? (int32_t)((begin + cap - p) * 4) : -1;
+}
+
+// gather the chunk streams into one contiguous buffer: block = chunk
+__global__ void compact_kernel(const uint32_t* words, int cap, const int32_t* nbytes, const long long* offsets /* exclusive, bytes */,
+                               uint8_t* out) {
+    const long c = blockIdx.x;
+    const int nw = nbytes[c] / 4;
+    const uint32_t* src = words + c * cap + (cap - nw);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out + offsets[c]);
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
+}
+
+__global__ void decode_chunks_kernel(const uint8_t* stream, const long long* offsets, const int32_t* idx, long n, int chunk, Tables t,
+                                     int32_t* out, int32_t* err, long n_chunks) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const long i0 = c * chunk, i1 = (i0 + chunk) < n ? (i0 + chunk) : n;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(stream + offsets[c]);
+    DecState st;
+    st.x = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    st.pos = 2;
+    if (!decode_range(w, st, idx, i0, i1, t, out)) atomicExch(err, 1);
+}
+
+// ---- symbol preparation ------------------------------------------------------------------------------------------------------------
+// GaussianConditional: symbols = round(y - mu) (round-half-even, as torch.round), index = n_levels - 1 - #{ table[j] >= max(scale, bound),
+// j < n_levels - 1 } (CompressAI build_indexes), y_hat = symbols + mu.  Inputs NHWC (B, hw, C); int outputs in (b, c, hw) order.
+// y == NULL: indexes only (the decoder's side).
+template <typename T>
+__global__ void gc_symbols_kernel(const T* __restrict__ y, const T* __restrict__ mu, const T* __restrict__ scale, int batch, long hw, int C,
+                                  const float* __restrict__ table, int n_levels, float scale_bound, int32_t* __restrict__ symbols,
+                                  int32_t* __restrict__ indexes, T* __restrict__ y_hat) {
+    const long total = (long)batch * C * hw;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const long p = o % hw;
+        const int c = (int)((o / hw) % C);
+        const long b = o / (hw * C);
+        const long i = (b * hw + p) * C + c;
+        float s = to_f32(scale[i]);
+        s = s > scale_bound ? s : scale_bound;
+        int ix = n_levels - 1;
+        for (int j = 0; j < n_levels - 1; ++j) ix -= (s <= table[j]) ? 1 : 0;
+        indexes[o] = ix;
+        if (y) {
+            const float m = to_f32(mu[i]);
+            const float q = rintf(to_f32(y[i]) - m);
+            symbols[o] = (int32_t)q;
+            y_hat[i] = from_f32<T>(q + m);
+        }
+    }
+}
+
+// y_hat = symbols + mu (GaussianConditional.dequantize); symbols (b, c, hw), mu / y_hat NHWC
+template <typename T>
+__global__ void gc_dequant_kernel(const int32_t* __restrict__ symbols, const T* __restrict__ mu, int batch, long hw, int C, T* __restrict__ y_hat) {
+    const long total = (long)batch * C * hw;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const long p = o % hw;
+        const int c = (int)((o / hw) % C);
+        const long b = o / (hw * C);
+        const long i = (b * hw + p) * C + c;
+        y_hat[i] = from_f32<T>((float)symbols[o] + to_f32(mu[i]));
+    }
+}
+
+// EntropyBottleneck: symbols = round(z - median[c]), index = c, z_hat = symbols + median[c]; encode = 1: from z; 0: z_hat from symbols
+template <typename T>
+__global__ void eb_symbols_kernel(const T* __restrict__ z, const float* __restrict__ med, int batch, long hw, int C, int encode,
+                                  int32_t* __restrict__ symbols, int32_t* __restrict__ indexes, T* __restrict__ z_hat) {
+    const long total = (long)batch * C * hw;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const long p = o % hw;
+        const int c = (int)((o / hw) % C);
+        const long b = o / (hw * C);
+        const long i = (b * hw + p) * C + c;
+        indexes[o] = c;
+        float q;
+        if (encode) { q = rintf(to_f32(z[i]) - med[c]); symbols[o] = (int32_t)q; }
+        else q = (float)symbols[o];
+        z_hat[i] = from_f32<T>(q + med[c]);
+    }
+}
+
+static inline int grid1d(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g));
+}
+
+}  // namespace ans
+}  // namespace rc
+
+using namespace rc;
+using namespace rc::ans;
+
+extern "C" {
+
+// compressai._CXX.pmf_to_quantized_cdf (host): n probabilities -> n + 1 cumulative frequencies summing to 2^precision, none zero
+int rc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, int32_t* cdf) {
+    RC_REQUIRE(pmf && cdf && n >= 1 && precision >= 1 && precision <= 24, "rc_pmf_to_quantized_cdf: bad arguments");
+    for (int i = 0; i < n; ++i) RC_REQUIRE(pmf[i] >= 0.f && isfinite(pmf[i]), "rc_pmf_to_quantized_cdf: pmf must be finite and non-negative");
+    uint32_t* c = reinterpret_cast<uint32_t*>(cdf);
+    c[0] = 0;
+    uint64_t total = 0;
+    for (int i = 0; i < n; ++i) { c[i + 1] = (uint32_t)llroundf(pmf[i] * (float)(1 << precision)); total += c[i + 1]; }
+    RC_REQUIRE(total != 0, "rc_pmf_to_quantized_cdf: pmf sums to zero");
+    uint32_t run = 0;
+    for (int i = 0; i <= n; ++i) { run += (uint32_t)((((uint64_t)1 << precision) * (uint64_t)c[i]) / total); c[i] = run; }
+    c[n] = 1u << precision;
+    for (int i = 0; i < n; ++i) {
+        if (c[i] != c[i + 1]) continue;
+        uint32_t best = ~0u;
+        int steal = -1;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t f = c[j + 1] - c[j];
+            if (f > 1 && f < best) { best = f; steal = j; }
+        }
+        RC_REQUIRE(steal >= 0, "rc_pmf_to_quantized_cdf: no frequency left to redistribute");
+        if (steal < i) { for (int j = steal + 1; j <= i; ++j) c[j]--; }
+        else { for (int j = i + 1; j <= steal; ++j) c[j]++; }
+    }
+    return RC_OK;
+}
+
+int rc_gc_symbols(const void* d_y, const void* d_mu, const void* d_scale, int dtype, int batch, long long hw, int channels,
+                  const float* d_scale_table, int n_levels, float scale_bound, int32_t* d_symbols, int32_t* d_indexes, void* d_y_hat,
+                  void* stream) {
+    RC_REQUIRE(d_scale && d_scale_table && d_indexes && n_levels >= 1, "rc_gc_symbols: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_gc_symbols: bad dtype");
+    RC_REQUIRE(batch >= 1 && hw >= 1 && channels >= 1, "rc_gc_symbols: bad shape");
+    if (d_y) RC_REQUIRE(d_mu && d_symbols && d_y_hat, "rc_gc_symbols: encoding needs mu, symbols and y_hat");
+    const long total = (long)batch * channels * hw;
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(gc_symbols_kernel<float>, dim3(grid1d(total)), dim3(256), 0, as_stream(stream), static_cast<const float*>(d_y),
+                           static_cast<const float*>(d_mu), static_cast<const float*>(d_scale), batch, (long)hw, channels, d_scale_table, n_levels,
+                           scale_bound, d_symbols, d_indexes, static_cast<float*>(d_y_hat));
+    else
+        hipLaunchKernelGGL(gc_symbols_kernel<bf16_t>, dim3(grid1d(total)), dim3(256), 0, as_stream(stream), static_cast<const bf16_t*>(d_y),
+                           static_cast<const bf16_t*>(d_mu), static_cast<const bf16_t*>(d_scale), batch, (long)hw, channels, d_scale_table,
+                           n_levels, scale_bound, d_symbols, d_indexes, static_cast<bf16_t*>(d_y_hat));
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_gc_dequantize(const int32_t* d_symbols, const void* d_mu, int dtype, int batch, long long hw, int channels, void* d_y_hat, void* stream) {
+    RC_REQUIRE(d_symbols && d_mu && d_y_hat, "rc_gc_dequantize: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_gc_dequantize: bad dtype");
+    const long total = (long)batch * channels * hw;
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(gc_dequant_kernel<float>, dim3(grid1d(total)), dim3(256), 0, as_stream(stream), d_symbols, static_cast<const float*>(d_mu),
+                           batch, (long)hw, channels, static_cast<float*>(d_y_hat));
+    else
+        hipLaunchKernelGGL(gc_dequant_kernel<bf16_t>, dim3(grid1d(total)), dim3(256), 0, as_stream(stream), d_symbols,
+                           static_cast<const bf16_t*>(d_mu), batch, (long)hw, channels, static_cast<bf16_t*>(d_y_hat));
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_eb_symbols(const void* d_z, const float* d_medians, int dtype, int batch, long long hw, int channels, int encode, int32_t* d_symbols,
+                  int32_t* d_indexes, void* d_z_hat, void* stream) {
+    RC_REQUIRE(d_medians && d_symbols && d_indexes && d_z_hat && (d_z || !encode), "rc_eb_symbols: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_eb_symbols: bad dtype");
+    const long total = (long)batch * channels * hw;
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(eb_symbols_kernel<float>, dim3(grid1d(total)), dim3(256), 0, as_stream(stream), static_cast<const float*>(d_z), d_medians,
+                           batch, (long)hw, channels, encode, d_symbols, d_indexes, static_cast<float*>(d_z_hat));
+    else
+        hipLaunchKernelGGL(eb_symbols_kernel<bf16_t>, dim3(grid1d(total)), dim3(256), 0, as_stream(stream), static_cast<const bf16_t*>(d_z),
+                           d_medians, batch, (long)hw, channels, encode, d_symbols, d_indexes, static_cast<bf16_t*>(d_z_hat));
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+// words per chunk of scratch that can never overflow: an escaped symbol costs at most 16 + 4 + 8 x 4 = 52 bits < 2 words
+int rc_rans_chunk_words(int chunk) { return chunk > 0 ? 2 * chunk + 8 : 0; }
+
+int rc_rans_encode_chunks(const int32_t* d_symbols, const int32_t* d_indexes, long long n, int chunk, const int32_t* d_cdf, int cdf_stride,
+                          int n_cdfs, const int32_t* d_cdf_sizes, const int32_t* d_offsets, uint32_t* d_words, int32_t* d_nbytes, void* stream) {
+    RC_REQUIRE(d_symbols && d_indexes && d_cdf && d_cdf_sizes && d_offsets && d_words && d_nbytes, "rc_rans_encode_chunks: null pointer");
+    RC_REQUIRE(n >= 1 && chunk >= 1 && cdf_stride >= 2 && n_cdfs >= 1, "rc_rans_encode_chunks: bad shape");
+    const long n_chunks = (n + chunk - 1) / chunk;
+    const Tables t{d_cdf, cdf_stride, n_cdfs, d_cdf_sizes, d_offsets};
+    hipLaunchKernelGGL(encode_chunks_kernel, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), 0, as_stream(stream), d_symbols, d_indexes, (long)n,
+                       chunk, t, d_words, rc_rans_chunk_words(chunk), d_nbytes, n_chunks);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_rans_compact(const uint32_t* d_words, int chunk, const int32_t* d_nbytes, const long long* d_offsets, long long n_chunks, void* d_out,
+                    void* stream) {
+    RC_REQUIRE(d_words && d_nbytes && d_offsets && d_out && n_chunks >= 1, "rc_rans_compact: bad arguments");
+    hipLaunchKernelGGL(compact_kernel, dim3((unsigned)n_chunks), dim3(64), 0, as_stream(stream), d_words, rc_rans_chunk_words(chunk), d_nbytes,
+                       d_offsets, static_cast<uint8_t*>(d_out));
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_rans_decode_chunks(const void* d_stream, const long long* d_offsets, const int32_t* d_indexes, long long n, int chunk, const int32_t* d_cdf,
+                          int cdf_stride, int n_cdfs, const int32_t* d_cdf_sizes, const int32_t* d_cdf_offsets, int32_t* d_symbols, int32_t* d_err,
+                          void* stream) {
+    RC_REQUIRE(d_stream && d_offsets && d_indexes && d_cdf && d_cdf_sizes && d_cdf_offsets && d_symbols && d_err, "rc_rans_decode_chunks: null pointer");
+    RC_REQUIRE(n >= 1 && chunk >= 1, "rc_rans_decode_chunks: bad shape");
+    const long n_chunks = (n + chunk - 1) / chunk;
+    const Tables t{d_cdf, cdf_stride, n_cdfs, d_cdf_sizes, d_cdf_offsets};
+    hipLaunchKernelGGL(decode_chunks_kernel, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), 0, as_stream(stream), static_cast<const uint8_t*>(d_stream),
+                       d_offsets, d_indexes, (long)n, chunk, t, d_symbols, d_err, n_chunks);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+// ---- host forms: one stream in CompressAI's layout (format="compressai") -----------------------------------------------------------
+long long rc_rans_encode_host(const int32_t* symbols, const int32_t* indexes, long long n, const int32_t* cdf, int cdf_stride, int n_cdfs,
+                              const int32_t* cdf_sizes, const int32_t* offsets, void* out, long long out_cap) {
+    if (!symbols || !indexes || !cdf || !cdf_sizes || !offsets || !out || n < 0) { rc::fail(RC_ERR_INVALID, "rc_rans_encode_host: bad arguments"); return -1; }
+    const long cap = 2 * n + 8;
+    uint32_t* words = static_cast<uint32_t*>(malloc((size_t)cap * 4));
+    if (!words) { rc::fail(RC_ERR_INVALID, "rc_rans_encode_host: out of memory"); return -1; }
+    const Tables t{cdf, cdf_stride, n_cdfs, cdf_sizes, offsets};
+    uint32_t* p = encode_range(symbols, indexes, 0, n, t, words, words + cap);
+    long long nbytes = -1;
+    if (p) {
+        nbytes = (long long)(words + cap - p) * 4;
+        if (nbytes > out_cap) { rc::fail(RC_ERR_INVALID, "rc_rans_encode_host: output buffer too small"); nbytes = -1; }
+        else memcpy(out, p, (size_t)nbytes);
+    } else rc::fail(RC_ERR_INVALID, "rc_rans_encode_host: CDF index out of range");
+    free(words);
+    return nbytes;
+}
+
+int rc_rans_decode_host(const void* stream_bytes, unsigned long long* state /* [2]: x, next word; x == 0: start of stream */,
+                        const int32_t* indexes, long long n, const int32_t* cdf, int cdf_stride, int n_cdfs, const int32_t* cdf_sizes,
+                        const int32_t* offsets, int32_t* out) {
+    RC_REQUIRE(stream_bytes && state && indexes && cdf && cdf_sizes && offsets && out && n >= 0, "rc_rans_decode_host: bad arguments");
+    const uint32_t* w = static_cast<const uint32_t*>(stream_bytes);
+    DecState st;
+    if (state[0] == 0) { st.x = (uint64_t)w[0] | ((uint64_t)w[1] << 32); st.pos = 2; }
+    else { st.x = state[0]; st.pos = (long)state[1]; }
+    const Tables t{cdf, cdf_stride, n_cdfs, cdf_sizes, offsets};
+    RC_REQUIRE(decode_range(w, st, indexes, 0, n, t, out), "rc_rans_decode_host: CDF index out of range");
+    state[0] = st.x; state[1] = (unsigned long long)st.pos;
+    return RC_OK;
+}
+
+}  // extern "C"

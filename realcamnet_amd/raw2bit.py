@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from . import networks as N
 from . import ops
+from . import tcm as T
 from .LiteISP import Color_Condition_GFM, Lens_Shading_Correction, Res_GFM
 from .tcm import (Block, ConvTransBlock, EntropyBottleneck, GaussianConditional, ResidualBlock, ResidualBlockUpsample,
                   ResidualBlockWithStride, SWAtten, _slice_loop, conv1x1, conv3x3, slice_transform, subpel_conv3x3)
@@ -200,8 +201,9 @@ class HybridConditionModule(nn.Module):
 
 class raw_compression_tcm_final(nn.Module):
     """The RAW codec (upstream models/raw2bit.py:1614-1855), likelihood path: x = [raw (B,4,H,W), cond (B,4,h,w), coord (B,2,H,W)]
-    -> {"x_hat" (B,3,2H,2W), "y", "lft", "lsc", "likelihoods": {"y","z"}, "para": {"means","scales","y"}}.  Same attribute names as
-    upstream; load a reference checkpoint with strict=False (the entropy models' CDF buffers have no counterpart here)."""
+    -> {"x_hat" (B,3,2H,2W), "y", "lft", "lsc", "likelihoods": {"y","z"}, "para": {"means","scales","y"}}; `update`, `compress`,
+    `decompress` as upstream (GPU rANS coder, realcamnet_amd/bitstream.py).  Same attribute names and entropy-model buffers as
+    upstream: a reference checkpoint loads with strict=True."""
 
     def __init__(self, config=[2, 2, 2, 2, 2, 2, 2], head_dim=[8, 16, 32, 32, 16, 8, 8], drop_path_rate=0, N=64, M=320, num_slices=5,
                  max_support_slices=5, **kwargs):
@@ -252,6 +254,27 @@ class raw_compression_tcm_final(nn.Module):
     def _act_dtype(self):
         return self.conv_first.weight.dtype
 
+    update = T._codec_update
+    load_state_dict = T._codec_load_state_dict
+
+    def _latent(self, x):
+        raw, cond, coord = x[0], x[1], x[2]
+        dt = self._act_dtype()
+        return self._analysis(ops.to_nhwc(raw, dtype=dt), cond, ops.to_nhwc(coord, dtype=dt))[0]
+
+    def compress(self, x, fmt: str = "chunked"):
+        """upstream models/raw2bit.py:1876-1944: x = [raw, cond, coord] -> {"strings": [y_strings, z_strings], "shape"} (one string per
+        image; fmt "chunked": GPU coder, "compressai": one CompressAI-layout stream per image)."""
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        return T._codec_compress(self, self._latent(x), fmt)
+
+    def decompress(self, strings, shape, fmt: str = "chunked"):
+        """upstream models/raw2bit.py:1961-2027: -> {"x_hat": (B,3,2H,2W) clamped to [0, 1]}."""
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        return {"x_hat": T._codec_decompress(self, strings, shape, self._act_dtype(), fmt)}
+
     def forward(self, x):
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
@@ -272,7 +295,8 @@ class raw_compression_tcm_final(nn.Module):
             raise ValueError("coord must be at packed resolution (h, w)")
         return self._forward_nhwc(a, cond, ops.to_nhwc(coord, dtype=dt, pad_hw=(a.shape[1], a.shape[2])))
 
-    def _forward_nhwc(self, a, cond, coord_nhwc):
+    def _analysis(self, a, cond, coord_nhwc):
+        """packed RAW NHWC -> (latent y NHWC, local condition maps, lens-shading map): the encoder half of forward / compress."""
         lsc_fea = self.lsc._nhwc(coord_nhwc)
         vec = self.classifier._vec(ops._req(cond, "cond"))
         local = self.local_condition._nhwc(a)
@@ -284,6 +308,10 @@ class raw_compression_tcm_final(nn.Module):
             for blk in blocks:
                 fea, _ = blk._nhwc((fea, c))
             fea = down._nhwc(fea)
+        return fea, local, lsc_fea
+
+    def _forward_nhwc(self, a, cond, coord_nhwc):
+        fea, local, lsc_fea = self._analysis(a, cond, coord_nhwc)
         out = _slice_loop(self, fea)
         nchw = ops.to_nchw
         out.update({"y": out["para"]["y"], "lft": nchw(local[2]), "lsc": nchw(lsc_fea)})

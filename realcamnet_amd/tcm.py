@@ -15,6 +15,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from . import bitstream
 from . import networks as N
 from . import networks as N_mod      # TCM.__init__ keeps upstream's parameter name `N`
 from . import ops
@@ -360,10 +361,51 @@ class ResidualBlockUpsample(nn.Module):
         return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
 
 
+_CODER_BUFFERS = ("_offset", "_quantized_cdf", "_cdf_length")
+
+
+def _register_coder_buffers(mod, likelihood_bound: float) -> None:
+    """The buffers compressai.entropy_models.EntropyModel.__init__ registers: empty int tables (filled by update() or a checkpoint)
+    and the likelihood LowerBound -- so a reference checkpoint's keys all have a home (strict=True)."""
+    mod.likelihood_lower_bound = _LowerBound(likelihood_bound)
+    for name in _CODER_BUFFERS:
+        mod.register_buffer(name, torch.IntTensor())
+
+
+def _set_coder_buffers(mod, offset, cdf, length) -> None:
+    dev = mod._offset.device
+    mod._offset, mod._quantized_cdf, mod._cdf_length = offset.to(dev), cdf.to(dev), length.to(dev)
+    mod.__dict__.pop("_coder_tables", None)
+
+
+def _coder_tables(mod) -> "bitstream.Tables":
+    dev = next(iter(mod.parameters()), mod._offset).device if any(True for _ in mod.parameters()) else mod._offset.device
+    key = (mod._quantized_cdf.data_ptr(), mod._quantized_cdf._version, str(dev))
+    hit = mod.__dict__.get("_coder_tables")
+    if hit is None or hit[0] != key:
+        hit = (key, bitstream.Tables(mod._quantized_cdf, mod._cdf_length, mod._offset, dev))
+        mod.__dict__["_coder_tables"] = hit
+    return hit[1]
+
+
+def _resize_coder_buffers(mod, prefix: str, names, state_dict) -> None:
+    """compressai.models.utils.update_registered_buffers(policy="resize_if_empty"): make the (empty) table buffers the checkpoint's
+    size so that nn.Module.load_state_dict(strict=True) can copy them (upstream models/tcm.py:492-499)."""
+    for name in names:
+        key = f"{prefix}.{name}"
+        if key in state_dict:
+            cur = getattr(mod, name)
+            new = state_dict[key]
+            if cur.numel() == 0 or cur.shape != new.shape:
+                setattr(mod, name, torch.empty(new.shape, dtype=cur.dtype, device=cur.device))
+    mod.__dict__.pop("_coder_tables", None)
+
+
 class EntropyBottleneck(nn.Module):
-    """compressai.entropy_models.EntropyBottleneck(channels) -- parameters and the eval-mode likelihood path only (restated from
-    its published definition, parity unpinned; no CDF tables, no coder).  Parameter names `_matrix{i}`, `_bias{i}`, `_factor{i}`,
-    `quantiles` and the `target` buffer follow CompressAI's classic layout."""
+    """compressai.entropy_models.EntropyBottleneck(channels): parameters, the eval-mode likelihood path, the CDF tables (`update`) and
+    `compress` / `decompress` over the GPU rANS coder (restated from its published definition, parity unpinned).  Parameter names
+    `_matrix{i}`, `_bias{i}`, `_factor{i}`, `quantiles`, the `target` buffer and EntropyModel's table buffers follow CompressAI's
+    classic layout."""
 
     def __init__(self, channels: int, tail_mass: float = 1e-9, init_scale: float = 10, filters=(3, 3, 3, 3), likelihood_bound: float = 1e-9):
         super().__init__()
@@ -382,6 +424,40 @@ class EntropyBottleneck(nn.Module):
         self.quantiles = nn.Parameter(torch.tensor([-float(init_scale), 0.0, float(init_scale)]).repeat(channels, 1, 1))
         target = math.log(2 / float(tail_mass) - 1)
         self.register_buffer("target", torch.tensor([-target, 0.0, target]))
+        _register_coder_buffers(self, likelihood_bound)
+
+    def update(self, force: bool = False) -> bool:
+        """EntropyBottleneck.update(): (re)build `_offset`, `_quantized_cdf`, `_cdf_length` from the density's parameters."""
+        if self._offset.numel() > 0 and not force:
+            return False
+        _set_coder_buffers(self, *bitstream.bottleneck_tables(self))
+        return True
+
+    def _compress_nhwc(self, z, fmt="chunked", chunk=bitstream.DEFAULT_CHUNK):
+        """z NHWC -> (one byte string per image, z_hat NHWC): symbols = round(z - median), index = channel."""
+        b, h, w, c = z.shape
+        med = self.quantiles.detach()[:, 0, 1].float().contiguous()
+        sym, idx, z_hat = torch.ops.realcam.eb_symbols(ops._req(z, "z"), None, med, b, h, w, z.dtype)
+        tables = _coder_tables(self)
+        return [bitstream.encode(sym[i], idx[i], tables, fmt, chunk) for i in range(b)], z_hat
+
+    def _decompress_nhwc(self, strings, size, dtype, fmt="chunked"):
+        h, w = size
+        b, c = len(strings), self.channels
+        dev = self.quantiles.device
+        med = self.quantiles.detach()[:, 0, 1].float().contiguous()
+        tables = _coder_tables(self)
+        idx = torch.arange(c, dtype=torch.int32, device=dev).view(c, 1).expand(c, h * w).contiguous()
+        sym = torch.stack([bitstream.Decoder(s, tables, dev, fmt).decode(idx).view(c, h * w) for s in strings])
+        return torch.ops.realcam.eb_symbols(None, sym, med, b, h, w, dtype)[2]
+
+    def compress(self, x, fmt="chunked"):
+        """compressai EntropyBottleneck.compress(x NCHW) -> list of byte strings, one per image."""
+        return self._compress_nhwc(ops.to_nhwc(x), fmt)[0]
+
+    def decompress(self, strings, size, fmt="chunked"):
+        """compressai EntropyBottleneck.decompress(strings, size) -> z_hat NCHW (the parameters' dtype)."""
+        return ops.to_nchw(self._decompress_nhwc(strings, tuple(size), self.quantiles.dtype, fmt))
 
     def _get_medians(self):
         return self.quantiles[:, :, 1:2]
@@ -421,14 +497,38 @@ class EntropyBottleneck(nn.Module):
 
 
 class GaussianConditional(nn.Module):
-    """compressai.entropy_models.GaussianConditional(None) -- the eval-mode likelihood path only (restated, parity unpinned)."""
+    """compressai.entropy_models.GaussianConditional(None): the eval-mode likelihood path, the scale table / CDF tables
+    (`update_scale_table`, `update`) and symbol preparation for the coder (restated, parity unpinned).  Buffers as CompressAI
+    registers them: scale_table, scale_bound, lower_bound_scale.bound, likelihood_lower_bound.bound, _offset, _quantized_cdf,
+    _cdf_length."""
 
-    def __init__(self, scale_table=None, scale_bound: float = 0.11, likelihood_bound: float = 1e-9):
+    def __init__(self, scale_table=None, scale_bound: float = 0.11, tail_mass: float = 1e-9, likelihood_bound: float = 1e-9):
         super().__init__()
-        self.scale_bound, self.likelihood_bound = float(scale_bound), float(likelihood_bound)
+        if scale_table is not None:
+            raise NotImplementedError("GaussianConditional: construct with None and call update_scale_table(), as upstream does")
+        self.scale_bound_value, self.likelihood_bound, self.tail_mass = float(scale_bound), float(likelihood_bound), float(tail_mass)
+        _register_coder_buffers(self, likelihood_bound)
+        self.lower_bound_scale = _LowerBound(scale_bound)
+        self.register_buffer("scale_table", torch.Tensor())
+        self.register_buffer("scale_bound", torch.Tensor([float(scale_bound)]))
+
+    def update_scale_table(self, scale_table, force: bool = False) -> bool:
+        if self._offset.numel() > 0 and not force:
+            return False
+        self.scale_table = torch.as_tensor(sorted(float(s) for s in scale_table), dtype=torch.float32).to(self.scale_table.device)
+        self.update()
+        return True
+
+    def update(self) -> None:
+        _set_coder_buffers(self, *bitstream.gaussian_tables(self.scale_table, self.tail_mass))
+
+    def _table(self, device):
+        if self.scale_table.numel() == 0:
+            raise RuntimeError("GaussianConditional has no scale table: call the model's update() first")
+        return self.scale_table.detach().to(device=device, dtype=torch.float32).contiguous()
 
     def _nhwc(self, y, scale, mu):
-        return ops.gaussian_conditional(y, scale, mu, self.scale_bound, self.likelihood_bound)
+        return ops.gaussian_conditional(y, scale, mu, self.scale_bound_value, self.likelihood_bound)
 
     def forward(self, inputs, scales, means):
         if self.training:
@@ -437,12 +537,32 @@ class GaussianConditional(nn.Module):
         return ops.to_nchw(y_hat), ops.to_nchw(lik)
 
 
+def _codec_update(self, scale_table=None, force: bool = False) -> bool:
+    """upstream models/tcm.py:430-435 (TCM.update -> CompressionModel.update): scale table + Gaussian tables, then every
+    EntropyBottleneck child's tables.  Must be called (or a checkpoint with tables loaded) before compress() / decompress()."""
+    if scale_table is None:
+        scale_table = bitstream.get_scale_table()
+    updated = self.gaussian_conditional.update_scale_table(scale_table, force=force)
+    for mod in self.modules():
+        if isinstance(mod, EntropyBottleneck):
+            updated |= mod.update(force=force)
+    return updated
+
+
+def _codec_load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+    """upstream models/tcm.py:492-499: size the entropy models' (empty) table buffers from the checkpoint, then load -- so a reference
+    checkpoint (which carries `_quantized_cdf`, `_offset`, `_cdf_length`, `scale_table`) loads with strict=True."""
+    _resize_coder_buffers(self.gaussian_conditional, "gaussian_conditional", _CODER_BUFFERS + ("scale_table",), state_dict)
+    _resize_coder_buffers(self.entropy_bottleneck, "entropy_bottleneck", _CODER_BUFFERS, state_dict)
+    return nn.Module.load_state_dict(self, state_dict, strict=strict, assign=assign)
+
+
 class TCM(nn.Module):
     """The transforms of upstream's `TCM` codec (models/tcm.py:320-425), built in the same order under the same attribute
     names: g_a, g_s, h_a, h_mean_s, h_scale_s, atten_mean, atten_scale, cc_mean_transforms, cc_scale_transforms,
-    lrp_transforms, entropy_bottleneck, gaussian_conditional, and `forward` (the likelihood path, eval mode).  `compress` /
-    `decompress` (CDF tables, rANS) are NOT built; of the entropy models only the parameters and the likelihood arithmetic exist,
-    so load a reference checkpoint with strict=False (their CDF buffers have no counterpart).  NCHW at this boundary, NHWC inside."""
+    lrp_transforms, entropy_bottleneck, gaussian_conditional; `forward` (the likelihood path, eval mode), `update`, `compress`,
+    `decompress` (CDF tables + rANS on the GPU, realcamnet_amd/bitstream.py) and `load_state_dict` (a reference checkpoint, table
+    buffers included, loads with strict=True).  NCHW at this boundary, NHWC inside."""
 
     def __init__(self, config=[2, 2, 2, 2, 2, 2], head_dim=[8, 16, 32, 32, 16, 8], drop_path_rate=0, N=64, M=320, num_slices=5,
                  max_support_slices=5, **kwargs):
@@ -480,7 +600,92 @@ class TCM(nn.Module):
         Every map stays NHWC between the first and the last line; likelihoods are fp32."""
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
-        return _slice_loop(self, self.g_a._nhwc(ops.to_nhwc(x)))
+        return _slice_loop(self, self.g_a._nhwc(ops.to_nhwc(x, dtype=self._act_dtype())))
+
+    def _act_dtype(self):
+        return next(self.g_a.parameters()).dtype
+
+    update = _codec_update
+    load_state_dict = _codec_load_state_dict
+
+    def compress(self, x, fmt: str = "chunked"):
+        """upstream models/tcm.py:511-570: x (B,3,H,W) -> {"strings": [y_strings, z_strings], "shape": z spatial size}; one string per
+        image in each list.  fmt "chunked" (GPU coder) or "compressai" (one stream per image in CompressAI's layout, host coder)."""
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        return _codec_compress(self, self.g_a._nhwc(ops.to_nhwc(x, dtype=self._act_dtype())), fmt)
+
+    def decompress(self, strings, shape, fmt: str = "chunked"):
+        """upstream models/tcm.py:592-637: -> {"x_hat": (B,3,H,W) clamped to [0, 1]}."""
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        return {"x_hat": _codec_decompress(self, strings, shape, self._act_dtype(), fmt)}
+
+
+def _slice_params(m, i, latent_means, latent_scales, y_hat_slices):
+    """mean / scale of slice i from the hyper-prior maps and the already decoded slices (models/tcm.py:455-468)."""
+    support = y_hat_slices if m.max_support_slices < 0 else y_hat_slices[:m.max_support_slices]
+    mean_support = m.atten_mean[i][0]._nhwc(ops.channel_concat([latent_means] + support))
+    mu = m.cc_mean_transforms[i]._nhwc(mean_support)
+    scale_support = m.atten_scale[i][0]._nhwc(ops.channel_concat([latent_scales] + support))
+    scale = m.cc_scale_transforms[i]._nhwc(scale_support)
+    return mean_support, mu, scale
+
+
+def _refine(m, i, mean_support, y_hat_slice):
+    """y_hat_slice + 0.5 tanh(lrp(cat(mean_support, y_hat_slice)))   (models/tcm.py:475-479)."""
+    return ops.tanh_half_add(y_hat_slice, m.lrp_transforms[i]._nhwc(ops.channel_concat([mean_support, y_hat_slice])))
+
+
+def _codec_compress(m, y, fmt):
+    """Shared by TCM.compress and raw_compression_tcm_final.compress (models/tcm.py:515-570, raw2bit.py:1901-1944): y NHWC latent ->
+    strings.  The symbols and CDF indexes of every slice are produced on the device (realcam::gc_symbols); "chunked": every slice
+    becomes one container of GPU-coded chunk streams, an image's y string is the concatenation of its slices' containers;
+    "compressai": the slices' symbols are concatenated and coded as ONE stream per image, as upstream's single BufferedRansEncoder."""
+    gc = m.gaussian_conditional
+    z = m.h_a._nhwc(y)
+    z_strings, z_hat = m.entropy_bottleneck._compress_nhwc(z, fmt)
+    latent_scales, latent_means = m.h_scale_s._nhwc(z_hat), m.h_mean_s._nhwc(z_hat)
+    if latent_means.shape[1:3] != y.shape[1:3]:
+        raise NotImplementedError("latent size must be a multiple of 4; upstream crops here")
+    b = y.shape[0]
+    per = y.shape[-1] // m.num_slices
+    tables, table = _coder_tables(gc), gc._table(y.device)
+    y_hat_slices, pieces, syms, idxs = [], [[] for _ in range(b)], [], []
+    for i in range(m.num_slices):
+        mean_support, mu, scale = _slice_params(m, i, latent_means, latent_scales, y_hat_slices)
+        sym, idx, y_hat_slice = torch.ops.realcam.gc_symbols(ops.channel_slice(y, i * per, per), mu, scale, table, gc.scale_bound_value)
+        if fmt == "chunked":
+            for k in range(b):
+                pieces[k].append(bitstream.encode(sym[k], idx[k], tables, fmt))
+        else:
+            syms.append(sym); idxs.append(idx)
+        y_hat_slices.append(_refine(m, i, mean_support, y_hat_slice))
+    if fmt == "chunked":
+        y_strings = [b"".join(p) for p in pieces]
+    else:
+        sym, idx = torch.cat([t.reshape(b, -1) for t in syms], dim=1), torch.cat([t.reshape(b, -1) for t in idxs], dim=1)
+        y_strings = [bitstream.encode(sym[k], idx[k], tables, fmt) for k in range(b)]
+    return {"strings": [y_strings, z_strings], "shape": tuple(z.shape[1:3])}
+
+
+def _codec_decompress(m, strings, shape, dtype, fmt):
+    """Shared decompress (models/tcm.py:592-637, raw2bit.py:1961-2027): -> x_hat NCHW clamped to [0, 1]."""
+    gc = m.gaussian_conditional
+    y_strings, z_strings = strings
+    z_hat = m.entropy_bottleneck._decompress_nhwc(z_strings, tuple(shape), dtype, fmt)
+    latent_scales, latent_means = m.h_scale_s._nhwc(z_hat), m.h_mean_s._nhwc(z_hat)
+    b, dev = z_hat.shape[0], z_hat.device
+    tables, table = _coder_tables(gc), gc._table(dev)
+    decoders = [bitstream.Decoder(s, tables, dev, fmt) for s in y_strings]
+    y_hat_slices = []
+    for i in range(m.num_slices):
+        mean_support, mu, scale = _slice_params(m, i, latent_means, latent_scales, y_hat_slices)
+        _, idx, _ = torch.ops.realcam.gc_symbols(None, None, scale, table, gc.scale_bound_value)
+        sym = torch.stack([decoders[k].decode(idx[k]).view(idx.shape[1], idx.shape[2]) for k in range(b)])
+        y_hat_slices.append(_refine(m, i, mean_support, torch.ops.realcam.gc_dequantize(sym, mu)))
+    x_hat = m.g_s._nhwc(ops.channel_concat(y_hat_slices))
+    return ops.to_nchw(x_hat).clamp_(0, 1)
 
 
 def _slice_loop(m, y):

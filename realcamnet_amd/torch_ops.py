@@ -505,3 +505,74 @@ define("gma_crpe(Tensor qkvp, Tensor taps0, Tensor taps1, Tensor taps2, Tensor t
        lambda out, qkvp, t0, t1, t2, t3, bias: check(
            lib().rc_gma_crpe(qkvp.data_ptr(), out.data_ptr(), qkvp.shape[1], qkvp.shape[2], qkvp.shape[3], t0.data_ptr(), t1.data_ptr(),
                              t2.data_ptr(), t3.data_ptr(), bias.data_ptr(), _stream()), "rc_gma_crpe"))
+
+
+# ---- f3: entropy coding (csrc/rans.hip) ------------------------------------------------------------------------------------------------
+def _gcs_alloc(y, mu, scale, table, scale_bound):
+    b, c = scale.shape[0], scale.shape[-1]
+    hw = scale.numel() // (b * c)
+    i32 = lambda: scale.new_empty((b, c, hw), dtype=torch.int32)
+    return (i32() if y is not None else scale.new_empty((0,), dtype=torch.int32)), i32(), (torch.empty_like(y) if y is not None else _none(scale))
+
+
+def _gcs_launch(outs, y, mu, scale, table, scale_bound):
+    sym, idx, y_hat = outs
+    b, c = scale.shape[0], scale.shape[-1]
+    check(lib().rc_gc_symbols(_p(y), _p(mu), scale.data_ptr(), _dt(scale), b, scale.numel() // (b * c), c, table.data_ptr(), table.numel(),
+                              float(scale_bound), _p(sym) if y is not None else None, idx.data_ptr(), _p(y_hat) if y is not None else None,
+                              _stream()), "rc_gc_symbols")
+
+
+define("gc_symbols(Tensor? y, Tensor? mu, Tensor scale, Tensor scale_table, float scale_bound) -> (Tensor, Tensor, Tensor)", _gcs_alloc, _gcs_launch)
+
+define("gc_dequantize(Tensor symbols, Tensor mu) -> Tensor",
+       lambda sym, mu: torch.empty_like(mu),
+       lambda out, sym, mu: check(lib().rc_gc_dequantize(sym.data_ptr(), mu.data_ptr(), _dt(mu), mu.shape[0], mu.numel() // (mu.shape[0] * mu.shape[-1]),
+                                                        mu.shape[-1], out.data_ptr(), _stream()), "rc_gc_dequantize"))
+
+
+def _ebs_alloc(z, symbols, medians, b, h, w, dtype):
+    c = medians.numel()
+    return (symbols.new_empty((b, c, h * w)) if z is None else z.new_empty((b, c, h * w), dtype=torch.int32),
+            medians.new_empty((b, c, h * w), dtype=torch.int32), medians.new_empty((b, h, w, c), dtype=dtype))
+
+
+def _ebs_launch(outs, z, symbols, medians, b, h, w, dtype):
+    sym, idx, z_hat = outs
+    if z is None:
+        sym.copy_(symbols.reshape(sym.shape))
+    check(lib().rc_eb_symbols(_p(z), medians.data_ptr(), _DT[dtype], b, h * w, medians.numel(), 1 if z is not None else 0, sym.data_ptr(),
+                              idx.data_ptr(), z_hat.data_ptr(), _stream()), "rc_eb_symbols")
+
+
+define("eb_symbols(Tensor? z, Tensor? symbols, Tensor medians, int b, int h, int w, ScalarType dtype) -> (Tensor, Tensor, Tensor)", _ebs_alloc, _ebs_launch)
+
+
+def _enc_alloc(sym, idx, cdf, sizes, offsets, chunk):
+    n_chunks = -(-sym.numel() // chunk)
+    return sym.new_empty((n_chunks, lib().rc_rans_chunk_words(chunk)), dtype=torch.int32), sym.new_empty((n_chunks,), dtype=torch.int32)
+
+
+define("rans_encode_chunks(Tensor symbols, Tensor indexes, Tensor cdf, Tensor cdf_sizes, Tensor offsets, int chunk) -> (Tensor, Tensor)", _enc_alloc,
+       lambda outs, sym, idx, cdf, sizes, offsets, chunk: check(
+           lib().rc_rans_encode_chunks(sym.data_ptr(), idx.data_ptr(), sym.numel(), chunk, cdf.data_ptr(), cdf.shape[1], cdf.shape[0], sizes.data_ptr(),
+                                       offsets.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), _stream()), "rc_rans_encode_chunks"))
+
+define("rans_compact(Tensor words, Tensor nbytes, Tensor offsets, int chunk, int total_bytes) -> Tensor",
+       lambda words, nbytes, offsets, chunk, total: words.new_empty((total,), dtype=torch.uint8),
+       lambda out, words, nbytes, offsets, chunk, total: check(
+           lib().rc_rans_compact(words.data_ptr(), chunk, nbytes.data_ptr(), offsets.data_ptr(), nbytes.numel(), out.data_ptr(), _stream()),
+           "rc_rans_compact"))
+
+
+def _dec_launch(out, stream, offsets, idx, cdf, sizes, cdf_offsets, chunk):
+    err = torch.zeros(1, dtype=torch.int32, device=idx.device)
+    check(lib().rc_rans_decode_chunks(stream.data_ptr(), offsets.data_ptr(), idx.data_ptr(), idx.numel(), chunk, cdf.data_ptr(), cdf.shape[1],
+                                      cdf.shape[0], sizes.data_ptr(), cdf_offsets.data_ptr(), out.data_ptr(), err.data_ptr(), _stream()),
+          "rc_rans_decode_chunks")
+    if int(err.item()):
+        raise _lib.HipError("rc_rans_decode_chunks: CDF index out of range")
+
+
+define("rans_decode_chunks(Tensor stream, Tensor offsets, Tensor indexes, Tensor cdf, Tensor cdf_sizes, Tensor cdf_offsets, int chunk) -> Tensor",
+       lambda stream, offsets, idx, *a: torch.empty_like(idx), _dec_launch)
