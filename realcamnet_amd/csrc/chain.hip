@@ -176,12 +176,7 @@ int rc_pointwise_chain48(const void* d_x, int cin0, const void* d_w0packed, cons
         a.wp[m] = d_wpacked[m]; a.bp[m] = d_bias[m];
     }
     a.n_mid = n_mid; a.slope = slope; a.out = static_cast<bf16_t*>(d_out); a.pixels = pixels;
-    static int num_cus = 0;
-    if (num_cus == 0) {
-        int dev = 0;
-        RC_HIP_CHECK(hipGetDevice(&dev));
-        RC_HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    const int num_cus = device_cu_count();          // per device (common.hpp)
     const long long groups = (pixels + 63) / 64;
     long long grid = (groups + 3) / 4;
     if (grid > 3LL * num_cus) grid = 3LL * num_cus;                   // 3 blocks per CU fit the LDS budget

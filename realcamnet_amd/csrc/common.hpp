@@ -100,4 +100,22 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Function attributes (dynamic-LDS limit) and device properties are PER DEVICE in HIP: per-process `static bool` flags would leave a
+// second GPU touched by the same process without them.  Small per-device tables instead (index = hipGetDevice(), < 64).
+inline int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    return dev;
+}
+struct PerDeviceFlag {
+    bool done[64] = {};
+    bool test_and_set() { const int d = current_device(); const bool was = done[d]; done[d] = true; return was; }
+};
+inline int device_cu_count() {
+    static int cus[64] = {};
+    const int d = current_device();
+    if (!cus[d]) (void)hipDeviceGetAttribute(&cus[d], hipDeviceAttributeMultiprocessorCount, d);
+    return cus[d] > 0 ? cus[d] : 256;
+}
+
 }  // namespace rc

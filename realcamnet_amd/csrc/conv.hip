@@ -262,12 +262,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
         a.ep_key = fast ? key : -1;
     }
     {
-        static int num_cus = 0;
-        if (num_cus == 0) {
-            int dev = 0;
-            RC_HIP_CHECK(hipGetDevice(&dev));
-            RC_HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
-        }
+        const int num_cus = device_cu_count();          // per device (common.hpp)
         a.num_cus = num_cus;
         a.persist_ok = g_persist_on;
         a.dbg = g_dbg_ptr;

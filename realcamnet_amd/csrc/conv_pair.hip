@@ -472,11 +472,10 @@ __global__ __launch_bounds__(THREADS) void conv_pair_kernel(const PairArgs a) {
 
 template <bool GATED, int E1, int E2>
 int launch(const PairArgs& a, int num_cus, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceFlag attr_set;
+    if (!attr_set.test_and_set()) {
         RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<GATED, E1, E2>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        attr_set = true;
     }
     const int n_tiles = a.tiles_x * a.tiles_y * a.batch;
     int grid = num_cus < n_tiles ? num_cus : n_tiles;
@@ -531,12 +530,7 @@ int rc_conv_pair(const rc_conv_pair_desc* d, void* stream_) {
     a.tiles_x = ceil_div(d->width, pair::OTW); a.tiles_y = ceil_div(d->height, pair::OTH);
     a.td = make_tile_decode(a.tiles_x, a.tiles_y, kBandRows);
     a.dbg = conv_dbg_ptr();
-    static int num_cus = 0;
-    if (num_cus == 0) {
-        int dev = 0;
-        RC_HIP_CHECK(hipGetDevice(&dev));
-        RC_HIP_CHECK(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    const int num_cus = device_cu_count();          // per device (common.hpp)
     hipStream_t stream = as_stream(stream_);
     void* tok = nullptr;
     conv_prof_begin(2.0 * 2.0 * d->batch * d->height * d->width * 9.0 * pair::C * pair::C, stream, &tok);

@@ -535,11 +535,10 @@ int rc_dwconv2d(const void* d_x, int x_stride_c, int x_c0, void* d_y, int y_stri
     RC_REQUIRE(n_w % 4 == 0, "rc_dwconv2d: n_w must be a multiple of 4");
 #define RC_DW_LAUNCH(TT, KK)                                                                                              \
     do {                                                                                                                  \
-        static bool attr_set = false;                                                                                     \
-        if (!attr_set) {                                                                                                  \
+        static PerDeviceFlag attr_set;                                                                                     \
+        if (!attr_set.test_and_set()) {                                                                                                  \
             RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv2d_kernel<TT, KK>),                     \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                    \
-            attr_set = true;                                                                                              \
         }                                                                                                                 \
         hipLaunchKernelGGL((dwconv2d_kernel<TT, KK>), dim3((unsigned)blocks), dim3(64 * vb), lds, as_stream(stream),      \
                            static_cast<const TT*>(d_x), x_stride_c, x_c0, static_cast<TT*>(d_y), y_stride_c, y_c0, batch, \
@@ -593,11 +592,10 @@ int rc_gma_pointwise(const void* d_qkv, const void* d_dw, const void* d_dwl, int
     const unsigned gx = (unsigned)(n_tiles < 1024 ? n_tiles : 1024);
 #define RC_PW_LAUNCH(TT, SG, TK)                                                                                        \
     do {                                                                                                                \
-        static bool attr = false;                                                                                       \
-        if (!attr) {                                                                                                    \
+        static PerDeviceFlag attr;                                                                                       \
+        if (!attr.test_and_set()) {                                                                                                    \
             RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gma_pointwise_kernel<TT, SG, TK>),          \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                  \
-            attr = true;                                                                                                \
         }                                                                                                               \
         hipLaunchKernelGGL((gma_pointwise_kernel<TT, SG, TK>), dim3(gx), dim3(kPwWaves * 64), lds, as_stream(stream),   \
                            static_cast<const TT*>(d_qkv), static_cast<const TT*>(d_dw), static_cast<const TT*>(d_dwl),  \
@@ -634,7 +632,7 @@ static int gma_kv_impl(const void* d_qkvp, size_t plane, int dtype, int batch, i
     RC_REQUIRE(plane == 0 || (dtype == RC_BF16 && (heads * ch) % 16 == 0), "rc_gma_kv_planar: bf16 with whole 16-channel segments only");
     RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_gma_kv: bad dtype");
     const int U = dtype == RC_F32 ? 4 : 8;
-    RC_REQUIRE(batch >= 1 && batch <= 65535 && n_tok >= 1 && heads >= 1 && ch >= 1 && ch <= 32 && heads * ch * ch <= 256 * 16 &&
+    RC_REQUIRE(batch >= 1 && batch <= 65535 && n_tok >= 1 && heads >= 1 && ch >= 1 && ch <= 32 && heads * ch * ch <= 256 * 16 && heads * ch <= kGThreads /* one thread owns Z[c] */ &&
                (heads * ch) % U == 0 && (heads * ch) / U <= kGThreads, "rc_gma_kv: unsupported head geometry");
     const int ct = heads * ch;
     const int nblk = rc_gma_kv_blocks(n_tok);

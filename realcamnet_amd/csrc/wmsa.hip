@@ -115,11 +115,10 @@ int rc_window_attention(const void* d_qkv, const float* d_relpos, void* d_out, i
     const size_t lds = (size_t)kWmsaWaves * (2 * 64 * (head_dim + 1) + (2 * window - 1) * (2 * window - 1)) * sizeof(float);
 #define RC_WM(TT, HD, WS)                                                                                                 \
     do {                                                                                                                  \
-        static bool attr = false;                                                                                         \
-        if (!attr) {                                                                                                      \
+        static PerDeviceFlag attr;                                                                                         \
+        if (!attr.test_and_set()) {                                                                                                      \
             RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wmsa_kernel<TT, HD, WS>),                     \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));                     \
-            attr = true;                                                                                                  \
         }                                                                                                                 \
         hipLaunchKernelGGL((wmsa_kernel<TT, HD, WS>), dim3((unsigned)blocks), dim3(kWmsaWaves * 64), lds, as_stream(stream), \
                            static_cast<const TT*>(d_qkv), d_relpos, static_cast<TT*>(d_out), batch, H, W, C, shift);     \

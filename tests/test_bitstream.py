@@ -211,3 +211,28 @@ def test_raw_codec_compress_decompress_round_trip(hip):
         out = m.decompress(enc["strings"], enc["shape"])["x_hat"]
         fwd = m(x)
     assert out.shape == (1, 3, 512, 512) and _psnr(out, fwd["x_hat"].clamp(0, 1)) >= 45.0
+
+
+def test_state_dict_contract_equals_the_reference_classes():
+    """tests/golden/codec_state_keys.npz: keys, shapes and dtypes of the reference's TCM / raw_compression_tcm_final after update()
+    (its own __init__ / update / load_state_dict over restated CompressAI entropy models) -- the mirror must have exactly those tensors,
+    and its update() must build the same tables (SHA-256 of the int32 arrays) from the same key-filled parameters."""
+    import hashlib
+    import realcamnet_amd.raw2bit as RB
+    import realcamnet_amd.tcm as T
+    from conftest import load_golden
+    g = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "codec_state_keys.npz"))
+    sha = lambda t: hashlib.sha256(np.ascontiguousarray(t.cpu().numpy()).tobytes()).hexdigest()
+    for pre, build in (("tcm", lambda: T.TCM(N=32, M=320, num_slices=5)), ("raw", lambda: RB.raw_compression_tcm_final(N=32, M=320, num_slices=5))):
+        m = build().eval()
+        det_fill_(m.state_dict())
+        m.update()
+        sd = m.state_dict()
+        want = {k: (s, d) for k, s, d in zip(g[pre + ".keys"].tolist(), g[pre + ".shapes"].tolist(), g[pre + ".dtypes"].tolist())}
+        assert set(sd) == set(want), (sorted(set(sd) ^ set(want))[:10])
+        for k, v in sd.items():
+            assert "x".join(map(str, v.shape)) == want[k][0] and str(v.dtype) == want[k][1], k
+        assert sha(sd["gaussian_conditional._quantized_cdf"]) == str(g[pre + ".sha_gc_cdf"])
+        assert sha(sd["entropy_bottleneck._quantized_cdf"]) == str(g[pre + ".sha_eb_cdf"])
+        assert sha(sd["gaussian_conditional._offset"]) == str(g[pre + ".sha_gc_offset"])
+        assert sha(sd["entropy_bottleneck._cdf_length"]) == str(g[pre + ".sha_eb_length"])
