@@ -211,6 +211,10 @@ int rc_channel_sums(const void* d_x, int dtype, int batch, int n_pix, int c, flo
 int rc_gate_residual(const void* d_r, const float* d_gate, const void* d_x, void* d_y, int dtype,
                      int batch, int n_pix, int c, void* stream);
 
+/* GFMLayer applied to a feature map (models/LiteISP.py:308-321; Res_GFM_LFM :601-620): y = x*scale[b][c] + shift[b][c] + x with the
+ * two (B,C) fp32 vectors of rc_gfm_vector.  NHWC, n_pix = H*W per image. */
+int rc_film_apply(const void* d_x, const float* d_scale, const float* d_shift, void* d_y, int dtype, int batch, int n_pix, int c, void* stream);
+
 /* ---- a19 (SWAtten, models/tcm.py:284-289): y = a * sigmoid(b) + identity, element-wise on NHWC maps of n_elems
  * elements (a multiple of 16 bytes); y may alias a. */
 int rc_sigmoid_gate_add(const void* d_a, const void* d_b, const void* d_identity, void* d_y, int dtype, long long n_elems,
@@ -287,6 +291,11 @@ int rc_color_block(const void* d_x, int x_dtype, float* d_y, int batch, int cin,
                    const float* d_in_beta, void* stream);
 int rc_instance_stats(const float* d_x, float* d_mean, float* d_rstd, int batch, int c, int hw,
                       float eps, void* stream);
+/* InstanceNorm2d(affine) of a standalone CB block (models/LiteISP.py:215-230) with the statistics of rc_instance_stats:
+ * y = (x - mean[b][c]) * rstd[b][c] * gamma[c] + beta[c], fp32 NCHW (inside the colour branch the norm is folded into the next
+ * block's load instead). */
+int rc_instance_norm(const float* d_x, float* d_y, const float* d_mean, const float* d_rstd, const float* d_gamma, const float* d_beta,
+                     int batch, int c, int hw, void* stream);
 int rc_color_head(const float* d_x, float* d_vec, int batch, int cin, int cout, int hw,
                   const float* d_w, const float* d_b, void* stream);
 

@@ -160,6 +160,48 @@ def res_gfm(sd: SD, p: str, x: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     return conv(sd, p + ".conv1", f) + x
 
 
+def color_condition_gfm_lfm(sd: SD, p: str, cond: torch.Tensor, raw: torch.Tensor):
+    """Color_Condition_GFM_LFM.forward (models/LiteISP.py:501-534): six CB blocks (:215-230; conv1x1 -> AvgPool(3,2,1) -> LeakyReLU(0.2)
+    -> InstanceNorm(affine), the sixth without norm), Dropout (identity in eval) -> Conv1x1 -> global mean = the vector; the local map
+    is ONE 3x3 conv of the packed RAW (the 3-layer cond_first of :524-527 is overwritten at :529)."""
+    h = cond
+    i = 0
+    while f"{p}.downblocks.{i}.conv.weight" in sd:
+        q = f"{p}.downblocks.{i}"
+        h = F.leaky_relu(F.avg_pool2d(conv(sd, q + ".conv", h), 3, stride=2, padding=1, count_include_pad=True), 0.2)
+        if q + ".norm.weight" in sd:
+            h = F.instance_norm(h, weight=sd[q + ".norm.weight"], bias=sd[q + ".norm.bias"], use_input_stats=True, eps=1e-5)
+        i += 1
+    return conv(sd, f"{p}.global_vector.1", h).mean(dim=(2, 3)), conv(sd, f"{p}.cond_first.0", raw)
+
+
+def sft_layer(sd: SD, p: str, x: torch.Tensor, cmap: torch.Tensor) -> torch.Tensor:
+    """SFTLayer.forward: x * (scale + 1) + shift, each a Conv1x1 -> LeakyReLU(0.1) -> Conv1x1 of the map.  models/LiteISP.py:293-305."""
+    s = conv(sd, p + ".SFT_scale_conv1", F.leaky_relu(conv(sd, p + ".SFT_scale_conv0", cmap), 0.1))
+    t = conv(sd, p + ".SFT_shift_conv1", F.leaky_relu(conv(sd, p + ".SFT_shift_conv0", cmap), 0.1))
+    return x * (s + 1) + t
+
+
+def res_gfm_lfm(sd: SD, p: str, x: torch.Tensor, v: torch.Tensor, cmap: torch.Tensor) -> torch.Tensor:
+    """Res_GFM_LFM.forward: x + conv2(lfm(lrelu_0.1(conv1(gfm(x, v))), cmap)).  models/LiteISP.py:601-620; GFMLayer :308-321."""
+    c = x.shape[1]
+    s = _gfm_vec(sd, p + ".gfm", "scale", v).view(-1, c, 1, 1)
+    t = _gfm_vec(sd, p + ".gfm", "shift", v).view(-1, c, 1, 1)
+    f = F.leaky_relu(conv(sd, p + ".conv1", x * s + t + x), 0.1)
+    return x + conv(sd, p + ".conv2", sft_layer(sd, p + ".lfm", f, cmap))
+
+
+def _cond_net(sd: SD, p: str, t: torch.Tensor) -> torch.Tensor:
+    """CondNet1..4 (models/LiteISP.py:1668-1676): Conv2d(k, stride k) layers, k in {1, 2}, LeakyReLU(0.1) between them."""
+    idx = sorted(int(k.split(".")[1]) for k in sd if k.startswith(p + ".") and k.endswith(".weight"))
+    for n, i in enumerate(idx):
+        w = sd[f"{p}.{i}.weight"]
+        t = F.conv2d(t, w, sd[f"{p}.{i}.bias"], stride=w.shape[-1])
+        if n + 1 < len(idx):
+            t = F.leaky_relu(t, 0.1)
+    return t
+
+
 # ----------------------------------------------------------------------------------------------
 # a12  full nets
 # ----------------------------------------------------------------------------------------------
@@ -252,9 +294,24 @@ def _strided_unet(sd: SD, x: Sequence[torch.Tensor]) -> torch.Tensor:
     Res_GFM blocks per level."""
     raw = x[0]
     has_gfm, has_lsc = "classifier.model.0.weight" in sd, "lsc.model.0.weight" in sd
+    has_lfm = "classifier.cond_first.0.weight" in sd     # ISPUNet_GFM_LFM (:1535-1707): vector AND map modulation, maps per level from CondNet1..4
     v = color_condition_gfm(sd, "classifier", x[1]) if has_gfm else None
+    lmap = {}
+    if has_lfm:
+        v, lfm = color_condition_gfm_lfm(sd, "classifier", x[1], raw)
+        l1, l2, l4, l8 = (_cond_net(sd, f"CondNet{i}", lfm) for i in (1, 2, 3, 4))
+        lmap = {"encoder_modulation1": l1, "encoder_modulation2": l2, "encoder_modulation3": l4, "middle_modulation": l8,
+                "decoder_modulation3": l4, "decoder_modulation2": l2, "decoder_modulation1": l1}
 
     def gfm(p, t):
+        if has_lfm:
+            if f"{p}.conv1.weight" in sd:
+                return res_gfm_lfm(sd, p, t, v, lmap[p])
+            i = 0
+            while f"{p}.{i}.conv1.weight" in sd:
+                t = res_gfm_lfm(sd, f"{p}.{i}", t, v, lmap[p])
+                i += 1
+            return t
         if not has_gfm:
             return t
         if f"{p}.conv0.weight" in sd:                    # N.seq of ONE module is that module (models/networks.py:117-121)
@@ -317,7 +374,7 @@ def liteispnet_gfmresize(sd: SD, x: Sequence[torch.Tensor]) -> torch.Tensor:
 
 
 FORWARDS = {"ISPUNet_GFM_LSC": ispunet_gfm_lsc, "LiteISPNet": liteispnet, "LiteISPNet_GFM_LSC": liteispnet_gfm_lsc, "LiteISPNet_GFM_LSC_GMA": liteispnet_gfm_lsc_gma,
-            "ISPUNet_GFM": _strided_unet, "ISPUNet_LSC": _strided_unet, "ResUNet": _strided_unet,
+            "ISPUNet_GFM": _strided_unet, "ISPUNet_LSC": _strided_unet, "ResUNet": _strided_unet, "ISPUNet_GFM_LFM": _strided_unet,
             "LiteISPNet_LSC": _dwt_unet, "LiteISPNet_GFM": _dwt_unet, "LiteISPNet_GFMresize": liteispnet_gfmresize}
 
 

@@ -137,6 +137,120 @@ class Res_GFM(nn.Module):
         return ops.to_nchw(y), vec
 
 
+class CB(nn.Module):
+    """Conv1x1 -> AvgPool(3,2,1) -> LeakyReLU(0.2) [-> InstanceNorm(affine)] as a module (upstream LiteISP.py:215-230); executed
+    inside Color_Condition_GFM_LFM through rc_color_block / rc_instance_stats like color_block()."""
+
+    def __init__(self, in_filters, out_filters, normalization=False):
+        super().__init__()
+        self.conv = N.Conv2d(in_filters, out_filters, 1, stride=1, padding=0)
+        self.pooling = nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=True)
+        self.act = nn.LeakyReLU(0.2)
+        self.normalization = normalization
+        if normalization:
+            self.norm = nn.InstanceNorm2d(out_filters, affine=True)
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        y = ops.color_block(x, self.conv)                       # fp32 NCHW like the colour branch
+        return ops.instance_norm(y, self.norm) if self.normalization else y
+
+
+class SFTLayer(nn.Module):
+    """x0 * (scale(cond) + 1) + shift(cond), two 1x1-conv pairs on the condition MAP (upstream LiteISP.py:293-305)."""
+
+    def __init__(self, cond_c=32, out_nc=64, nf=32):
+        super().__init__()
+        self.SFT_scale_conv0 = N.Conv2d(cond_c, nf, 1)
+        self.SFT_scale_conv1 = N.Conv2d(nf, out_nc, 1)
+        self.SFT_shift_conv0 = N.Conv2d(cond_c, nf, 1)
+        self.SFT_shift_conv1 = N.Conv2d(nf, out_nc, 1)
+
+    def _nhwc(self, x):
+        fea, cond = x
+        scale = self.SFT_scale_conv1._nhwc(self.SFT_scale_conv0._nhwc(cond, act="leaky", slope=0.1))
+        shift = self.SFT_shift_conv1._nhwc(self.SFT_shift_conv0._nhwc(cond, act="leaky", slope=0.1))
+        return ops.sft_apply(fea, scale, shift)                 # fea*scale + shift + fea
+
+    def forward(self, x):
+        return ops.to_nchw(self._nhwc((ops.to_nhwc(x[0]), ops.to_nhwc(x[1]))))
+
+
+class GFMLayer(nn.Module):
+    """x0 * scale(vec) + shift(vec) + x0 with two Linear pairs on the global vector (upstream LiteISP.py:308-321)."""
+
+    def __init__(self, cond_c=32, out_nc=64, nf=32):
+        super().__init__()
+        self.GFM_scale_conv0 = nn.Linear(cond_c, nf)
+        self.GFM_scale_conv1 = nn.Linear(nf, out_nc)
+        self.GFM_shift_conv0 = nn.Linear(cond_c, nf)
+        self.GFM_shift_conv1 = nn.Linear(nf, out_nc)
+        self.out_nc = out_nc
+
+    def _nhwc(self, x):
+        fea, vec = x
+        scale = ops.gfm_vector(vec, self.GFM_scale_conv0, self.GFM_scale_conv1)
+        shift = ops.gfm_vector(vec, self.GFM_shift_conv0, self.GFM_shift_conv1)
+        return ops.film_apply(fea, scale, shift)
+
+    def forward(self, x):
+        return ops.to_nchw(self._nhwc((ops.to_nhwc(x[0]), x[1])))
+
+
+class Res_GFM_LFM(nn.Module):
+    """Global (vector) + local (map) modulation block (upstream LiteISP.py:601-620): x0 + conv2(lfm(lrelu0.1(conv1(gfm(x0, vec))), map));
+    triple in / triple out so it chains inside Sequential like upstream."""
+
+    def __init__(self, cond_c=32, out_nc=32, nf=64):
+        super().__init__()
+        self.gfm = GFMLayer(cond_c=cond_c, out_nc=out_nc, nf=nf)
+        self.conv1 = N.Conv2d(out_nc, out_nc, 3, 1, 1)
+        self.lfm = SFTLayer(cond_c=cond_c, out_nc=out_nc, nf=out_nc)
+        self.conv2 = N.Conv2d(out_nc, out_nc, 3, 1, 1)
+
+    def _nhwc(self, x):
+        a, vec, cmap = x
+        f = self.conv1._nhwc(self.gfm._nhwc((a, vec)), act="leaky", slope=0.1)
+        return self.conv2._nhwc(self.lfm._nhwc((f, cmap)), residual=a), vec, cmap
+
+    def forward(self, x):
+        y, vec, cmap = self._nhwc((ops.to_nhwc(x[0]), x[1], ops.to_nhwc(x[2])))
+        return ops.to_nchw(y), vec, x[2]
+
+
+class Color_Condition_GFM_LFM(nn.Module):
+    """Global colour vector from the cond image + a local condition map from the RAW patch (upstream LiteISP.py:501-534)."""
+
+    def __init__(self, in_channels=4, GFM_out_c=32, LFM_out_c=32):
+        super().__init__()
+        self.downblocks = nn.ModuleList([CB(in_channels, 16, True), CB(16, 32, True), CB(32, 64, True), CB(64, 128, True),
+                                         CB(128, 256, True), CB(256, 384, False)])
+        self.global_vector = nn.Sequential(nn.Dropout(p=0.8), N.Conv2d(384, GFM_out_c, 1, stride=1, padding=0), nn.AdaptiveAvgPool2d(1))
+        # upstream builds a 3-layer cond_first and then overwrites the attribute with a single conv (:524-529); the RNG stream of the
+        # discarded layers is consumed all the same, so they are constructed (and dropped) here too
+        self.cond_first = nn.Sequential(N.Conv2d(in_channels, LFM_out_c, 3, 1, 1), nn.LeakyReLU(0.1, True), N.Conv2d(LFM_out_c, LFM_out_c, 1),
+                                        nn.LeakyReLU(0.1, True), N.Conv2d(LFM_out_c, LFM_out_c, 1), nn.LeakyReLU(0.1, True))
+        self.cond_first = nn.Sequential(N.Conv2d(in_channels, LFM_out_c, 3, 1, 1))
+
+    def _run(self, global_raw, local_nhwc):
+        """global_raw NCHW (B,4,h,w) -> vector (B,GFM_out_c) fp32; local_nhwc (B,H,W,4) -> local map NHWC (B,H,W,LFM_out_c)."""
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        x, norm, stats = ops._req(global_raw, "cond"), None, None
+        for blk in self.downblocks:
+            x = ops.color_block(x, blk.conv, norm, stats)
+            if blk.normalization:
+                norm, stats = blk.norm, ops.instance_stats(x, blk.norm.eps)
+            else:
+                norm, stats = None, None
+        return ops.color_head(x, self.global_vector[1]), self.cond_first[0]._nhwc(local_nhwc)
+
+    def forward(self, global_raw, local_patch):
+        vec, lfm = self._run(global_raw, ops.to_nhwc(local_patch))
+        return vec.to(global_raw.dtype).view(vec.shape[0], vec.shape[1], 1, 1), ops.to_nchw(lfm)
+
+
 def _ingest(net, mosaic, cond, dt, pad_to, black_level, white_level, cond_hw):
     """Front end shared by every forward_mosaic: packed NHWC RAW (+ the cond image when the caller did not bring one)."""
     need_cond = hasattr(net, "classifier") and cond is None and not getattr(net, "cond_from_raw", False)
@@ -440,6 +554,92 @@ class ResUNet(_StridedUNet):
     def __init__(self):
         super().__init__()
         self._build(chan=32)
+
+
+class ISPUNet_GFM_LFM(nn.Module):
+    """upstream LiteISP.py:1535-1707: the strided U-Net with GLOBAL + LOCAL modulation -- Color_Condition_GFM_LFM gives a colour vector
+    (from x[1]) and a condition map (3x3 conv of the packed RAW x[0]); CondNet1..4 bring the map to the four resolutions; every level's
+    Res_GFM_LFM applies GFMLayer (vector) and SFTLayer (map).  Same construction order and attribute names as upstream."""
+
+    output_dtype: Optional[torch.dtype] = None
+
+    def __init__(self, cond_c=32, n_blocks=2, modulation_blocks=1, chan=32):
+        super().__init__()
+        self.cond_c = cond_c
+        self.classifier = Color_Condition_GFM_LFM(in_channels=4, GFM_out_c=cond_c, LFM_out_c=cond_c)
+        self.chan, self.n_blocks, self.modulation_blocks = chan, n_blocks, modulation_blocks
+
+        def mod(c):
+            return N.seq(*[Res_GFM_LFM(cond_c=cond_c, out_nc=c, nf=c * 2) for _ in range(modulation_blocks)])
+
+        def lrelu():
+            return nn.LeakyReLU(negative_slope=1e-1, inplace=True)
+
+        self.intro = N.seq(N.Conv2d(4, chan, 3, 1, 1))
+        self.encoder_modulation1 = mod(chan)
+        self.encoder1 = N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.Conv2d(chan, chan, 3, 1, 1), lrelu())
+        self.down1 = N.Conv2d(chan, chan * 2, 2, 2)
+        chan = chan * 2
+        self.encoder_modulation2 = mod(chan)
+        self.encoder2 = N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.Conv2d(chan, chan, 3, 1, 1), lrelu())
+        self.down2 = N.Conv2d(chan, chan * 2, 2, 2)
+        chan = chan * 2
+        self.encoder_modulation3 = mod(chan)
+        self.encoder3 = N.seq(N.Conv2d(chan, chan, 3, 1, 1), N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks),
+                              N.Conv2d(chan, chan, 3, 1, 1), lrelu())
+        self.down3 = N.Conv2d(chan, chan * 2, 2, 2)
+        chan = chan * 2
+        self.middle_modulation = mod(chan)
+        self.middle = N.seq(N.Conv2d(chan, chan, 3, 1, 1), N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks * 2),
+                            N.Conv2d(chan, chan, 3, 1, 1))
+        for i in (3, 2, 1):
+            setattr(self, f"up{i}", N.seq(N.Conv2d(chan, chan * 2, 1, bias=False), nn.PixelShuffle(2)))
+            chan = chan // 2
+            setattr(self, f"decoder_modulation{i}", mod(chan))
+            setattr(self, f"decoder{i}", N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.conv(chan, chan, mode='C')))
+        self.tail = N.seq(N.conv(chan, chan * 4, mode='C'), nn.PixelShuffle(upscale_factor=2), N.conv(chan, 3, mode='C'))
+        c = cond_c
+        self.CondNet1 = N.Sequential(N.Conv2d(c, c, 1), nn.LeakyReLU(0.1, True), N.Conv2d(c, c, 1))
+        self.CondNet2 = N.Sequential(N.Conv2d(c, c, 2, 2), nn.LeakyReLU(0.1, True), N.Conv2d(c, c, 1))
+        self.CondNet3 = N.Sequential(N.Conv2d(c, c, 2, 2), nn.LeakyReLU(0.1, True), N.Conv2d(c, c, 2, 2), nn.LeakyReLU(0.1, True), N.Conv2d(c, c, 1))
+        self.CondNet4 = N.Sequential(N.Conv2d(c, c, 2, 2), nn.LeakyReLU(0.1, True), N.Conv2d(c, c, 2, 2), nn.LeakyReLU(0.1, True),
+                                     N.Conv2d(c, c, 2, 2), nn.LeakyReLU(0.1, True), N.Conv2d(c, c, 1))
+
+    def _act_dtype(self) -> torch.dtype:
+        return self.intro.weight.dtype
+
+    def _run(self, a, cond, crop_hw=None):
+        intro = self.intro._nhwc(a)
+        vec, lfm = self.classifier._run(cond, a)
+        l1, l2, l4, l8 = (getattr(self, f"CondNet{i}")._nhwc(lfm) for i in (1, 2, 3, 4))
+
+        def mod(name, t, cmap):
+            return getattr(self, name)._nhwc((t, vec, cmap))[0]
+
+        d1 = self.down1._nhwc(self.encoder1._nhwc(mod("encoder_modulation1", intro, l1)))
+        d2 = self.down2._nhwc(self.encoder2._nhwc(mod("encoder_modulation2", d1, l2)))
+        d3 = self.down3._nhwc(self.encoder3._nhwc(mod("encoder_modulation3", d2, l4)))
+        m = self.middle._nhwc(mod("middle_modulation", d3, l8), residual=d3)
+        u3 = ops.add(mod("decoder_modulation3", self.decoder3._nhwc(self.up3._nhwc(m)), l4), d2)
+        u2 = ops.add(mod("decoder_modulation2", self.decoder2._nhwc(self.up2._nhwc(u3)), l2), d1)
+        u1 = ops.add(mod("decoder_modulation1", self.decoder1._nhwc(self.up1._nhwc(u2)), l1), intro)
+        t = self.tail[0]._nhwc(u1, out_mode=RC_OUT_PIXEL_SHUFFLE2)
+        return self.tail[2]._nhwc(t, out_mode=RC_OUT_NCHW, crop_hw=crop_hw, out_dtype=self.output_dtype)
+
+    def forward(self, x: Sequence[torch.Tensor]):
+        raw, cond = x[0], x[1]
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        if raw.dim() != 4 or raw.shape[1] != 4 or raw.shape[2] % 8 or raw.shape[3] % 8:
+            raise ValueError(f"raw must be (B,4,H,W) with H,W multiples of 8 (three stride-2 levels), got {tuple(raw.shape)}")
+        return self._run(ops.to_nhwc(raw, dtype=self._act_dtype()), cond)
+
+    def forward_mosaic(self, mosaic, cond=None, coord=None, pad_to: int = 16, black_level: float = 0.0, white_level: float = 1.0,
+                       cond_hw=(256, 256)):
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        a, cond = _ingest(self, mosaic, cond, self._act_dtype(), pad_to, black_level, white_level, cond_hw)
+        return self._run(a, cond, crop_hw=(mosaic.shape[-2], mosaic.shape[-1]))
 
 
 class LiteISPNet_GFM_LSC_GMA(LiteISPNet_GFM_LSC):

@@ -79,6 +79,7 @@ _SIGS = {
     "rc_debug_hbm_probe": (C.c_int, [_P, _P, C.c_size_t, _I, _I, _I, _I, _I, C.POINTER(C.c_double)]),
     "rc_debug_mfma_peak": (C.c_int, [_I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rc_pointwise_chain48": (C.c_int, [_P, _I, _P, _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _F, _P, _I, C.c_longlong, _P]),
+    "rc_film_apply": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rc_sigmoid_gate_add": (C.c_int, [_P, _P, _P, _P, _I, C.c_longlong, _P]),
     "rc_subsample2": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "rc_entropy_bottleneck": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_longlong, _I, C.c_float, _P]),
@@ -103,6 +104,7 @@ _SIGS = {
     "rc_dwt_inverse": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "rc_color_block": (C.c_int, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "rc_instance_stats": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _P]),
+    "rc_instance_norm": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rc_color_head": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "rc_gfm_vector": (C.c_int, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "rc_dwconv2d": (C.c_int, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P]),

@@ -155,6 +155,17 @@ __global__ __launch_bounds__(256) void instance_stats_kernel(const float* __rest
     }
 }
 
+// ---- InstanceNorm2d(affine) applied with given statistics: y = (x - mean) * rstd * gamma + beta, fp32 NCHW ----
+__global__ __launch_bounds__(256) void instance_norm_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int c, int hw) {
+    const int plane = blockIdx.x;                    // b * c + ch
+    const float a = rstd[plane] * gamma[plane % c], o = beta[plane % c] - mean[plane] * a;
+    const float* p = x + (size_t)plane * hw;
+    float* q = y + (size_t)plane * hw;
+    for (int i = threadIdx.x; i < hw; i += 256) q[i] = __builtin_fmaf(p[i], a, o);
+}
+
 // ---- closing Conv1x1 + AdaptiveAvgPool2d(1): vec[b][o] = mean_p (sum_ci w[o][ci] x[b][ci][p] + b[o]) ----
 __global__ __launch_bounds__(256) void color_head_kernel(const float* __restrict__ x, float* __restrict__ vec, int cin,
                                                          int cout, int hw, const float* __restrict__ wgt,
@@ -292,7 +303,12 @@ int rc_color_block(const void* d_x, int x_dtype, float* d_y, int batch, int cin,
     if (d_in_mean) RC_REQUIRE(d_in_rstd && d_in_gamma && d_in_beta, "rc_color_block: incomplete InstanceNorm arguments");
     const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
     const size_t lds = ((size_t)cin + 1) * CB_PX * sizeof(float);
-    RC_REQUIRE(lds <= 64 * 1024, "rc_color_block: cin too large");
+    RC_REQUIRE(lds <= 144 * 1024, "rc_color_block: cin too large");       // cin <= 575 (the LFM colour branch reaches 256)
+    static PerDeviceFlag attr;
+    if (!attr.test_and_set()) {
+        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&color_block_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&color_block_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    }
     const size_t g = (size_t)batch * (((size_t)ho * wo + CB_PX - 1) / CB_PX);
     RC_REQUIRE(g < (1ull << 31), "rc_color_block: too many tiles");
     if (x_dtype == RC_F32)
@@ -311,6 +327,15 @@ int rc_instance_stats(const float* d_x, float* d_mean, float* d_rstd, int batch,
     RC_REQUIRE(d_x && d_mean && d_rstd, "rc_instance_stats: null pointer");
     RC_REQUIRE(batch >= 1 && c >= 1 && hw >= 1, "rc_instance_stats: bad shape");
     hipLaunchKernelGGL(instance_stats_kernel, dim3(batch * c), dim3(256), 0, as_stream(stream), d_x, d_mean, d_rstd, hw, eps);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_instance_norm(const float* d_x, float* d_y, const float* d_mean, const float* d_rstd, const float* d_gamma, const float* d_beta,
+                     int batch, int c, int hw, void* stream) {
+    RC_REQUIRE(d_x && d_y && d_mean && d_rstd && d_gamma && d_beta, "rc_instance_norm: null pointer");
+    RC_REQUIRE(batch >= 1 && c >= 1 && hw >= 1, "rc_instance_norm: bad shape");
+    hipLaunchKernelGGL(instance_norm_kernel, dim3(batch * c), dim3(256), 0, as_stream(stream), d_x, d_y, d_mean, d_rstd, d_gamma, d_beta, c, hw);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

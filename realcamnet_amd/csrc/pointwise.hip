@@ -190,6 +190,26 @@ __global__ void gate_residual_kernel(const T* __restrict__ r, const float* __res
     }
 }
 
+// ---- y = x*scale[b][c] + shift[b][c] + x : GFMLayer on a feature map (models/LiteISP.py:308-321) -----------------------------
+template <typename T>
+__global__ void film_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                  T* __restrict__ y, int batch, size_t n_pix, int c) {
+    constexpr int U = Vec16<T>::N;
+    const int vpp = c / U;
+    const size_t total = (size_t)batch * n_pix * vpp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vpp);
+        const int b = (int)(i / ((size_t)vpp * n_pix));
+        float fx[U];
+        Vec16<T>::unpack(reinterpret_cast<const uint4*>(x)[i], fx);
+        const float* s = scale + (size_t)b * c + v * U;
+        const float* t = shift + (size_t)b * c + v * U;
+#pragma unroll
+        for (int e = 0; e < U; ++e) fx[e] = (fx[e] * s[e] + t[e]) + fx[e];
+        reinterpret_cast<uint4*>(y)[i] = Vec16<T>::pack(fx);
+    }
+}
+
 // ---- y = a * sigmoid(b) + identity ----------------------------------------------------------------------
 template <typename T>
 __global__ void sigmoid_gate_add_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ idn, T* __restrict__ y,
@@ -557,6 +577,22 @@ int rc_gate_residual(const void* d_r, const float* d_gate, const void* d_x, void
     else
         hipLaunchKernelGGL(gate_residual_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
                            static_cast<const bf16_t*>(d_r), d_gate, static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_y), batch, (size_t)n_pix, c);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_film_apply(const void* d_x, const float* d_scale, const float* d_shift, void* d_y, int dtype, int batch, int n_pix, int c, void* stream) {
+    RC_REQUIRE(d_x && d_scale && d_shift && d_y, "rc_film_apply: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_film_apply: bad dtype");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    RC_REQUIRE(batch >= 1 && n_pix >= 1 && c >= U && c % U == 0, "rc_film_apply: c must be a multiple of 16 bytes");
+    const size_t total = (size_t)batch * n_pix * (c / U);
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(film_apply_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream), static_cast<const float*>(d_x),
+                           d_scale, d_shift, static_cast<float*>(d_y), batch, (size_t)n_pix, c);
+    else
+        hipLaunchKernelGGL(film_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream), static_cast<const bf16_t*>(d_x),
+                           d_scale, d_shift, static_cast<bf16_t*>(d_y), batch, (size_t)n_pix, c);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

@@ -542,6 +542,15 @@ def gate_residual(r: torch.Tensor, gate: torch.Tensor, x: Optional[torch.Tensor]
     return _R.gate_residual(r, gate, x)
 
 
+def film_apply(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    """x*scale[b,c] + shift[b,c] + x on an NHWC map (GFMLayer, upstream models/LiteISP.py:317-320)."""
+    x, scale, shift = _req(x, "x"), _req(scale, "scale"), _req(shift, "shift")
+    b, c = x.shape[0], x.shape[-1]
+    if scale.shape != (b, c) or shift.shape != (b, c) or scale.dtype != torch.float32 or shift.dtype != torch.float32:
+        raise ValueError("film_apply: scale / shift must be fp32 (B, C)")
+    return _R.film_apply(x, scale, shift)
+
+
 def channel_sums(x: torch.Tensor) -> torch.Tensor:
     """Per-channel partial sums (B, slots, C) fp32 of an NHWC map, in the layout rc_ca_gate folds (AdaptiveAvgPool2d(1) of a
     CALayer that is not fed by a conv emitting them, models/networks.py:268)."""
@@ -631,6 +640,15 @@ def color_block(x: torch.Tensor, conv, prev_norm=None, prev_stats=None) -> torch
 
 def instance_stats(x: torch.Tensor, eps: float = 1e-5):
     return _R.instance_stats(x, float(eps))
+
+
+def instance_norm(x: torch.Tensor, norm) -> torch.Tensor:
+    """nn.InstanceNorm2d(affine=True) on an fp32 NCHW map (standalone CB block, upstream models/LiteISP.py:226-229)."""
+    x = _req(x, "instance_norm input")
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise ValueError("instance_norm: fp32 NCHW expected")
+    mean, rstd = _R.instance_stats(x, float(norm.eps))
+    return _R.instance_norm(x, mean, rstd, f32_param(norm, "weight"), f32_param(norm, "bias"))
 
 
 def color_head(x: torch.Tensor, conv) -> torch.Tensor:

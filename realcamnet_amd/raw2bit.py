@@ -313,8 +313,7 @@ class raw_compression_tcm_final(nn.Module):
     def _forward_nhwc(self, a, cond, coord_nhwc):
         fea, local, lsc_fea = self._analysis(a, cond, coord_nhwc)
         out = _slice_loop(self, fea)
-        nchw = ops.to_nchw
-        out.update({"y": out["para"]["y"], "lft": nchw(local[2]), "lsc": nchw(lsc_fea)})
+        out.update({"y": out["para"]["y"], "lft": T.nchw_view(local[2]), "lsc": T.nchw_view(lsc_fea)})
         return out
 
 

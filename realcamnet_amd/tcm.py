@@ -622,6 +622,13 @@ class TCM(nn.Module):
         return {"x_hat": _codec_decompress(self, strings, shape, self._act_dtype(), fmt)}
 
 
+def nchw_view(a):
+    """(B,H,W,C) NHWC -> the same memory as a (B,C,H,W) tensor in torch's channels_last format: no copy, no launch.  The result dict's
+    side outputs (likelihoods, means, scales, y, lft, lsc -- up to 2.3 GB at 4K) keep upstream's logical NCHW shapes this way; only
+    x_hat is materialised planar."""
+    return a.permute(0, 3, 1, 2)
+
+
 def _slice_params(m, i, latent_means, latent_scales, y_hat_slices):
     """mean / scale of slice i from the hyper-prior maps and the already decoded slices (models/tcm.py:455-468)."""
     support = y_hat_slices if m.max_support_slices < 0 else y_hat_slices[:m.max_support_slices]
@@ -711,6 +718,6 @@ def _slice_loop(m, y):
         y_hat_slices.append(ops.tanh_half_add(y_hat_slice, lrp))
         y_lik.append(lik); mu_list.append(mu); scale_list.append(scale)
     x_hat = m.g_s._nhwc(ops.channel_concat(y_hat_slices))
-    nchw = ops.to_nchw
-    return {"x_hat": nchw(x_hat), "likelihoods": {"y": nchw(ops.channel_concat(y_lik)), "z": nchw(z_lik)},
+    nchw = nchw_view
+    return {"x_hat": ops.to_nchw(x_hat), "likelihoods": {"y": nchw(ops.channel_concat(y_lik)), "z": nchw(z_lik)},
             "para": {"means": nchw(ops.channel_concat(mu_list)), "scales": nchw(ops.channel_concat(scale_list)), "y": nchw(y)}}

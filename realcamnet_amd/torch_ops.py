@@ -576,3 +576,14 @@ def _dec_launch(out, stream, offsets, idx, cdf, sizes, cdf_offsets, chunk):
 
 define("rans_decode_chunks(Tensor stream, Tensor offsets, Tensor indexes, Tensor cdf, Tensor cdf_sizes, Tensor cdf_offsets, int chunk) -> Tensor",
        lambda stream, offsets, idx, *a: torch.empty_like(idx), _dec_launch)
+
+
+define("film_apply(Tensor x, Tensor scale, Tensor shift) -> Tensor",
+       lambda x, s, t: torch.empty_like(x),
+       lambda out, x, s, t: check(lib().rc_film_apply(x.data_ptr(), s.data_ptr(), t.data_ptr(), out.data_ptr(), _dt(x), x.shape[0], x.shape[1] * x.shape[2],
+                                                     x.shape[3], _stream()), "rc_film_apply"))
+
+define("instance_norm(Tensor x, Tensor mean, Tensor rstd, Tensor gamma, Tensor beta) -> Tensor",
+       lambda x, m, r, g, b: torch.empty_like(x),
+       lambda out, x, m, r, g, b: check(lib().rc_instance_norm(x.data_ptr(), out.data_ptr(), m.data_ptr(), r.data_ptr(), g.data_ptr(), b.data_ptr(),
+                                                               x.shape[0], x.shape[1], x.shape[2] * x.shape[3], _stream()), "rc_instance_norm"))

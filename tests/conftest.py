@@ -40,7 +40,7 @@ def golden_names(prefix):
 
 
 NET_NAMES = ("LiteISPNet", "LiteISPNet_GFM_LSC", "LiteISPNet_LSC", "LiteISPNet_GFM", "LiteISPNet_GFMresize",
-             "ISPUNet_GFM_LSC", "ISPUNet_GFM", "ISPUNet_LSC", "ResUNet")
+             "ISPUNet_GFM_LSC", "ISPUNet_GFM", "ISPUNet_GFM_LFM", "ISPUNet_LSC", "ResUNet")
 
 
 def net_name_of(fixture: str) -> str:

@@ -178,6 +178,40 @@ def test_conditioning_blocks_vs_reference(hip, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+def test_gfm_lfm_blocks_vs_reference(hip, dt):
+    """The global + local modulation blocks of ISPUNet_GFM_LFM (upstream models/LiteISP.py:215-230, 293-321, 501-534, 601-620) on the
+    reference's own outputs."""
+    L = M.LiteISP
+    g = load_golden("block_res_gfm_lfm_64")
+    mod = put(L.Res_GFM_LFM(cond_c=32, out_nc=64, nf=128), g["sd"], dt)
+    with torch.no_grad():
+        y, v, cm = mod((g["x"].to(DEV, dt), g["v"].to(DEV), g["cmap"].to(DEV, dt)))
+    assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
+    g = load_golden("block_sftlayer_32")
+    mod = put(L.SFTLayer(32, 32, 32), g["sd"], dt)
+    with torch.no_grad():
+        y = mod((g["x"].to(DEV, dt), g["cmap"].to(DEV, dt)))
+    assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
+    g = load_golden("block_gfmlayer_128")
+    mod = put(L.GFMLayer(32, 128, 256), g["sd"], dt)
+    with torch.no_grad():
+        y = mod((g["x"].to(DEV, dt), g["v"].to(DEV)))
+    assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
+    g = load_golden("block_color_condition_gfm_lfm")
+    mod = put(L.Color_Condition_GFM_LFM(4, 32, 32), g["sd"], dt)
+    with torch.no_grad():
+        vec, lfm = mod(g["x"].to(DEV, dt), g["local"].to(DEV, dt))
+    assert vec.shape == (2, 32, 1, 1) and lfm.shape == g["lfm"].shape
+    assert rel_err(vec.float().cpu().flatten(1), g["y"]) <= (1e-4 if dt == torch.float32 else 3e-2)
+    assert rel_err(lfm.float().cpu(), g["lfm"]) <= tol(dt)
+    g = load_golden("block_cb_4_16")
+    mod = put(L.CB(4, 16, True), g["sd"], torch.float32)
+    with torch.no_grad():
+        y = mod(g["x"].to(DEV))
+    assert rel_err(y.cpu(), g["y"]) <= 1e-4
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_tail_pixel_shuffle_vs_reference(hip, dt):
     g = load_golden("block_tail_16")
     tail = N.seq(N.conv(16, 64, mode="C"), torch.nn.PixelShuffle(2), N.conv(16, 3, mode="C"))

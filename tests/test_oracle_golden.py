@@ -1,6 +1,7 @@
 """CPU: the oracle restatement vs fixtures produced by the imported reference (oracle/make_golden.py)."""
 import pytest
 import torch
+import torch.nn.functional as F
 
 import liteisp_oracle as O
 from conftest import net_name_of, golden_names, load_golden, sd_digest, seed0_state_dict
@@ -61,6 +62,27 @@ def test_conditioning_blocks():
     _close(O.lens_shading({"l." + k: v for k, v in g["sd"].items()}, "l", g["x"]), g["y"])
     g = load_golden("block_color_condition")
     _close(O.color_condition_gfm({"c." + k: v for k, v in g["sd"].items()}, "c", g["x"]), g["y"])
+
+
+def test_gfm_lfm_blocks():
+    """Oracle restatements of the global + local modulation blocks (models/LiteISP.py:215-230, 293-321, 501-534, 601-620)."""
+    pre = lambda g: {"m." + k: v for k, v in g["sd"].items()}
+    g = load_golden("block_res_gfm_lfm_64")
+    _close(O.res_gfm_lfm(pre(g), "m", g["x"], g["v"], g["cmap"]), g["y"])
+    g = load_golden("block_sftlayer_32")
+    _close(O.sft_layer(pre(g), "m", g["x"], g["cmap"]), g["y"])
+    g = load_golden("block_gfmlayer_128")
+    sd, c = pre(g), g["x"].shape[1]
+    s, t = (O._gfm_vec(sd, "m", w, g["v"]).view(-1, c, 1, 1) for w in ("scale", "shift"))
+    _close(g["x"] * s + t + g["x"], g["y"])
+    g = load_golden("block_color_condition_gfm_lfm")
+    vec, lfm = O.color_condition_gfm_lfm(pre(g), "m", g["x"], g["local"])
+    _close(vec, g["y"]); _close(lfm, g["lfm"])
+    g = load_golden("block_cb_4_16")
+    vec_sd = {"m.downblocks.0." + k: v for k, v in g["sd"].items()}
+    h = O.conv(vec_sd, "m.downblocks.0.conv", g["x"])
+    h = F.leaky_relu(F.avg_pool2d(h, 3, stride=2, padding=1, count_include_pad=True), 0.2)
+    _close(F.instance_norm(h, weight=g["sd"]["norm.weight"], bias=g["sd"]["norm.bias"], use_input_stats=True, eps=1e-5), g["y"])
 
 
 def test_tail_and_padding():
