@@ -1,6 +1,6 @@
 """Generate tests/golden/raw2bit_*.npz by running the IMPORTED reference's models/raw2bit.py classes (build container only).
 
-    python oracle/make_golden_raw2bit.py [--blocks | --forward]
+    python oracle/make_golden_raw2bit.py [--blocks | --gma | --forward | --forward-base]
 
 CompressAI is absent: the reference module is imported over stubs (oracle/_import_reference.py) and the CompressAI classes it
 instantiates are replaced by the restatements of oracle/make_golden_tcm.py, so the fixtures pin UPSTREAM'S OWN code
@@ -81,6 +81,62 @@ def blocks():
     _save("raw2bit_hycond_c32", arrays)
 
 
+def gma_blocks():
+    """GMAAtten / ConvGMABlock (models/raw2bit.py:209-234, 330-355; the sizes of the file's own smoke lines :4362-4363, scaled) and RBU."""
+    torch.set_num_threads(1)
+    T = _load_reference()
+    g = torch.Generator().manual_seed(3344)
+    meta = {"torch_version": np.array(torch.__version__), "reference": np.array(REF)}
+    cases = (("raw2bit_gmaatten_96_hd10_i80", lambda: T.GMAAtten(96, 96, 10, 0., 80), (1, 96, 16, 24), lambda sd, x: RO.gma_atten(sd, "", x, 10)),
+             ("raw2bit_convgma_32_80_hd10", lambda: T.ConvGMABlock(32, 80, 10, drop_path=0.), (1, 112, 16, 24),
+              lambda sd, x: RO.conv_gma_block(sd, "", x, 32, 80, 10)),
+             ("raw2bit_convgma_16_40_hd5", lambda: T.ConvGMABlock(16, 40, 5, drop_path=0.), (2, 56, 8, 16),
+              lambda sd, x: RO.conv_gma_block(sd, "", x, 16, 40, 5)),
+             ("raw2bit_rbu_48_32", lambda: T.RBU(48, 32, 2), (2, 48, 8, 12), lambda sd, x: RO.rbu(sd, "", x)))
+    for name, make, shape, orc in cases:
+        torch.manual_seed(0)
+        m = make().eval()
+        with torch.no_grad():
+            G._perturb(m, g)
+            x = torch.randn(*shape, generator=g)
+            y = m(x)
+            sd = m.state_dict()
+            yo = orc(sd, x)
+        assert (y - yo).abs().max() <= 1e-5 * y.abs().max(), (name, (y - yo).abs().max())
+        arrays = {"x": x.numpy(), "y": y.numpy(), **meta}
+        arrays.update({"sd." + k: v.numpy() for k, v in sd.items()})
+        _save(name, arrays)
+
+
+def forward_base():
+    """raw_compression_tcm (models/raw2bit.py:361-579) at N=32 on a 256 x 256 packed frame (the smallest whose latent is larger than the 8 x 8 window); det_fill parameters."""
+    torch.set_num_threads(8)
+    T = _load_reference()
+    torch.manual_seed(0)
+    n, slices = 32, 5
+    model = T.raw_compression_tcm(N=n, M=320, num_slices=slices).eval()
+    sd = model.state_dict()
+    det_fill_(sd)
+    g = torch.Generator().manual_seed(98)
+    raw = torch.rand(1, 4, 256, 256, generator=g)
+    cond = torch.rand(1, 4, 64, 64, generator=g)
+    import liteisp_oracle as LO
+    coord = LO.make_coord(1, 256, 256)
+    flat = lambda o: {"x_hat": o["x_hat"], "lik_y": o["likelihoods"]["y"], "lik_z": o["likelihoods"]["z"], "means": o["para"]["means"],
+                      "scales": o["para"]["scales"], "y": o["para"]["y"]}
+    with torch.no_grad():
+        out = flat(model([raw, cond, coord]))
+        ours = flat(RO.raw_compression_tcm(sd, [raw, cond, coord], N=n, num_slices=slices))
+    for k in out:
+        assert (out[k] - ours[k]).abs().max() <= 1e-4 * max(out[k].abs().max().item(), 1e-6), (k, (out[k] - ours[k]).abs().max())
+    arrays = {"raw": raw.numpy(), "cond": cond.numpy(), "N": np.array(n), "num_slices": np.array(slices),
+              "n_keys": np.array(len(sd)), "torch_version": np.array(torch.__version__), "reference": np.array(REF + "; det_fill parameters")}
+    arrays.update({"out." + k: v.numpy() for k, v in out.items() if k != "x_hat"})
+    arrays["out.x_hat"] = out["x_hat"].numpy().astype(np.float16)
+    _save("raw2bit_base_forward_n32", arrays)
+    print({k: (tuple(v.shape), float(v.abs().mean())) for k, v in out.items()})
+
+
 def _flat(o):
     return {"x_hat": o["x_hat"], "lik_y": o["likelihoods"]["y"], "lik_z": o["likelihoods"]["z"], "means": o["para"]["means"],
             "scales": o["para"]["scales"], "y": o["para"]["y"], "lft": o["lft"], "lsc": o["lsc"]}
@@ -117,5 +173,9 @@ def forward():
 if __name__ == "__main__":
     if "--forward" in sys.argv:
         forward()
+    elif "--forward-base" in sys.argv:
+        forward_base()
+    elif "--gma" in sys.argv:
+        gma_blocks()
     else:
         blocks()

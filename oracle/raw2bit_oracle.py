@@ -1,4 +1,4 @@
-"""CPU oracle for the RAW codec's own blocks and `raw_compression_tcm_final.forward`.
+"""CPU oracle for the RAW codec's own blocks and `raw_compression_tcm[_final].forward`.
 *** TEST INFRASTRUCTURE *** -- only tests/ (and the fixture generators here) may import this file.
 
 Functional fp32 PyTorch-CPU restatement over the reference's state_dict; every function cites models/raw2bit.py.  The layers
@@ -95,16 +95,73 @@ def raw_compression_tcm_final(sd: SD, x, N: int = 64, num_slices: int = 5, max_s
         else:
             fea = _conv(sd, "m_down3_down", fea, stride=2)
     y = fea
+    specs = _codec_specs(N, config, head_dim)
+    out = slice_loop(sd, y, specs, num_slices, max_support_slices)
+    out.update({"y": y, "lft": local[2], "lsc": lsc_fea})
+    return out
+
+
+def _codec_specs(N, config, head_dim):
     ctb = lambda n, hd, ws: [("ctb", N, hd, ws, "W" if not i % 2 else "SW") for i in range(n)]
-    specs = {
+    return {
         "g_s": [("rbu",)] + ctb(config[3], head_dim[3], 8) + [("rbu",)] + ctb(config[4], head_dim[4], 8) + [("rbu",)] + ctb(config[5], head_dim[5], 8) +
                [("subpel",), ("rb",), ("subpel",)],
         "h_a": [("rbws",)] + ctb(config[0], 32, 4) + [("conv3x3s2",)],
         "h_s": [("rbu",)] + ctb(config[3], 32, 4) + [("subpel",)],
     }
-    out = slice_loop(sd, y, specs, num_slices, max_support_slices)
-    out.update({"y": y, "lft": local[2], "lsc": lsc_fea})
-    return out
+
+
+def raw_compression_tcm(sd: SD, x, N: int = 64, num_slices: int = 5, max_support_slices: int = 5,
+                        config=(2, 2, 2, 2, 2, 2, 2), head_dim=(8, 16, 32, 32, 16, 8, 8)):
+    """raw_compression_tcm.forward, models/raw2bit.py:491-579 (eval): no local condition, plain ConvTransBlocks in m_down1..3
+    (built at :385-400 with their stride-2 stage as the Sequential's last entry)."""
+    raw, cond, coord = x
+    sub = lambda pre: {k[len(pre) + 1:]: v for k, v in sd.items() if k.startswith(pre + ".")}
+    fea = _conv(sd, "conv_first", raw)
+    vec = LO.color_condition_gfm(sd, "classifier", cond)
+    fea = fea * (LO.lens_shading(sd, "lsc", coord) + 1)
+    fea = TO.residual_block_with_stride(sd, "conv_down", fea)
+    for s in range(3):
+        fea = LO.res_gfm(sd, f"gfm{s + 1}.0", fea, vec)
+        spec = [("ctb", N, head_dim[s], 8, "W" if not i % 2 else "SW") for i in range(config[s])] + [("rbws",) if s < 2 else ("conv3x3s2",)]
+        fea = TO.run_transform(sub(f"m_down{s + 1}"), "", spec, fea)
+    return slice_loop(sd, fea, _codec_specs(N, config, head_dim), num_slices, max_support_slices)
+
+
+def gma_block_nchw(sd: SD, p: str, x, heads: int):
+    """GMA_Block (models/raw2bit.py:117-143 == models/groupmix.py:274-299) over the tokens of an NCHW map, as GMABlock (:178-184) and
+    ConvGMABlock (:349-352) call it."""
+    import groupmix_oracle as GO
+    b, c, h, w = x.shape
+    tok = GO.gma_block(sd, x.flatten(2).transpose(1, 2), (h, w), heads, p=p + ".")
+    return tok.transpose(1, 2).reshape(b, c, h, w)
+
+
+def gma_atten(sd: SD, p: str, x, head_dim: int):
+    """GMAAtten.forward with inter_dim set, models/raw2bit.py:225-234 (conv_a / conv_b from CompressAI's AttentionBlock, restated)."""
+    pre = p + "." if p else ""
+    x = _conv(sd, pre + "in_conv", x)
+    heads = x.shape[1] // head_dim
+    z = gma_block_nchw(sd, pre + "non_local_block.block_2", gma_block_nchw(sd, pre + "non_local_block.block_1", x, heads), heads)
+    a = TO.attention_branch(sd, pre + "conv_a", x, False)
+    b = TO.attention_branch(sd, pre + "conv_b", z, True)
+    return _conv(sd, pre + "out_conv", a * torch.sigmoid(b) + x)
+
+
+def conv_gma_block(sd: SD, p: str, x, conv_dim: int, trans_dim: int, head_dim: int):
+    """ConvGMABlock.forward, models/raw2bit.py:345-355."""
+    pre = p + "." if p else ""
+    conv_x, trans_x = torch.split(_conv(sd, pre + "conv1_1", x), (conv_dim, trans_dim), dim=1)
+    conv_x = TO.residual_block(sd, pre + "conv_block", conv_x) + conv_x
+    trans_x = gma_block_nchw(sd, pre + "trans_block", trans_x, trans_dim // head_dim)
+    return x + _conv(sd, pre + "conv1_2", torch.cat((conv_x, trans_x), dim=1))
+
+
+def rbu(sd: SD, p: str, x):
+    """RBU.forward, models/raw2bit.py:3198-3206: ResidualBlockUpsample without the IGDN."""
+    pre = p + "." if p else ""
+    out = F.leaky_relu(TO.subpel_conv3x3(sd, pre + "subpel_conv", x), 0.01)
+    return _conv(sd, pre + "conv", out) + TO.subpel_conv3x3(sd, pre + "upsample", x)
 
 
 def slice_loop(sd: SD, y, specs, num_slices: int, max_support_slices: int):

@@ -1,11 +1,11 @@
-"""Host mirror of the RAW codec's own blocks and of `raw_compression_tcm_final` (upstream
-models/raw2bit.py:238-328, 730-886, 1614-1855): same class names, constructor signatures and attribute names, NCHW tensors at
+"""Host mirror of the RAW codec's own blocks and of `raw_compression_tcm` / `raw_compression_tcm_final` (SURVEY.md rows a18/a19;
+upstream models/raw2bit.py:117-355, 361-727, 730-886, 1614-2027, 3181-3206): same class names, constructor signatures and attribute names, NCHW tensors at
 the module boundary, NHWC inside, every op through librealcam_hip.so.
 
 What is pinned and what is not is the same as in realcamnet_amd/tcm.py: upstream's own composition (these classes' forward
 logic) is checked against fixtures produced by running the reference classes; the CompressAI layers underneath them
-(`ResidualBlockWithStride`, `GDN`, `AttentionBlock`, entropy models ...) are restated and parity-unpinned.  Only the likelihood
-path (`forward`, eval mode) exists: no CDF tables, no `compress` / `decompress`.
+(`ResidualBlockWithStride`, `GDN`, `AttentionBlock`, entropy models ...) are restated and parity-unpinned.  `forward` (eval mode), `update`,
+`compress` and `decompress` exist; training does not.
 """
 from __future__ import annotations
 
@@ -16,6 +16,7 @@ from . import networks as N
 from . import ops
 from . import tcm as T
 from .LiteISP import Color_Condition_GFM, Lens_Shading_Correction, Res_GFM
+from .groupmix import GMA_Block, Mlp
 from .tcm import (Block, ConvTransBlock, EntropyBottleneck, GaussianConditional, ResidualBlock, ResidualBlockUpsample,
                   ResidualBlockWithStride, SWAtten, _slice_loop, conv1x1, conv3x3, slice_transform, subpel_conv3x3)
 
@@ -105,6 +106,101 @@ class ConvTransBlock_mzj(nn.Module):
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
         y, _ = self._nhwc((ops.to_nhwc(xx[0]), ops.to_nhwc(xx[1])))
         return ops.to_nchw(y), xx[1]
+
+
+class GMABlock(nn.Module):
+    """Two GroupMix blocks over the tokens of an NCHW map (upstream models/raw2bit.py:168-184; its GMA_Block, :117-143, is the
+    composition of models/groupmix.py:274-299 re-declared over the imported ConvPosEnc / EfficientAtt -- the same mirror class serves)."""
+
+    def __init__(self, input_dim, head_dim, drop_path) -> None:
+        super().__init__()
+        self.input_dim = input_dim
+        self.num_head = input_dim // head_dim
+        self.block_1 = GMA_Block(input_dim, self.num_head, drop_path_rate=drop_path)
+        self.block_2 = GMA_Block(input_dim, self.num_head, drop_path_rate=drop_path)
+
+    def _nhwc(self, a):
+        return self.block_2._nhwc(self.block_1._nhwc(a))
+
+    def forward(self, x):
+        return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
+
+
+class GMAAtten(T.AttentionBlock):
+    """SWAtten with the GroupMix pair as its non-local branch (upstream models/raw2bit.py:209-234)."""
+
+    def __init__(self, input_dim, output_dim, head_dim, drop_path, inter_dim=192) -> None:
+        if inter_dim is not None:
+            super().__init__(inter_dim)
+            self.num_head, self.head_dim = inter_dim // head_dim, head_dim
+            self.non_local_block = GMABlock(inter_dim, head_dim, drop_path=drop_path)
+            self.in_conv = conv1x1(input_dim, inter_dim)
+            self.out_conv = conv1x1(inter_dim, output_dim)
+        else:
+            super().__init__(input_dim)
+            self.num_head, self.head_dim = input_dim // head_dim, head_dim
+            self.non_local_block = GMABlock(input_dim, self.num_head, drop_path=drop_path)      # (sic) upstream passes num_head as head_dim
+            self.in_conv = self.out_conv = None
+
+    def _nhwc(self, a):
+        if self.in_conv is None:
+            raise AttributeError("GMAAtten without inter_dim has no in_conv (same as upstream, raw2bit.py:225)")
+        x = self.in_conv._nhwc(a)
+        z = self.non_local_block._nhwc(x)
+        return self.out_conv._nhwc(ops.sigmoid_gate_add(self._branch_a(x), self._branch_b(z), x))
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
+
+
+class ConvGMABlock(nn.Module):
+    """ConvTransBlock with a GroupMix block on the transformer half (upstream models/raw2bit.py:330-355)."""
+
+    def __init__(self, conv_dim, trans_dim, head_dim, drop_path=0.):
+        super().__init__()
+        self.conv_dim, self.trans_dim, self.head_dim, self.drop_path = conv_dim, trans_dim, head_dim, drop_path
+        self.num_head = trans_dim // head_dim
+        self.trans_block = GMA_Block(trans_dim, self.num_head, drop_path_rate=drop_path)
+        self.conv1_1 = N.Conv2d(conv_dim + trans_dim, conv_dim + trans_dim, 1, 1, 0, bias=True)
+        self.conv1_2 = N.Conv2d(conv_dim + trans_dim, conv_dim + trans_dim, 1, 1, 0, bias=True)
+        self.conv_block = ResidualBlock(conv_dim, conv_dim)
+
+    def _nhwc(self, a):
+        t = self.conv1_1._nhwc(a)
+        conv_x = ops.channel_slice(t, 0, self.conv_dim)
+        trans_x = ops.channel_slice(t, self.conv_dim, self.trans_dim)
+        conv_x = ops.add(self.conv_block._nhwc(conv_x), conv_x)
+        trans_x = self.trans_block._nhwc(trans_x)
+        return self.conv1_2._nhwc(ops.channel_concat([conv_x, trans_x]), residual=a)
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
+
+
+class RBU(nn.Module):
+    """ResidualBlockUpsample without the IGDN (upstream models/raw2bit.py:3181-3206): conv3x3(LeakyReLU(subpel(x))) + subpel'(x)."""
+
+    def __init__(self, in_ch: int, out_ch: int, upsample: int = 2):
+        super().__init__()
+        self.subpel_conv = subpel_conv3x3(in_ch, out_ch, upsample)
+        self.leaky_relu = nn.LeakyReLU(inplace=True)
+        self.conv = conv3x3(out_ch, out_ch)
+        self.upsample = subpel_conv3x3(in_ch, out_ch, upsample)
+
+    def _nhwc(self, a):
+        slope = float(self.leaky_relu.negative_slope)
+        if (self.subpel_conv[0].out_channels // 4) % 16 == 0:
+            t = self.subpel_conv[0]._nhwc(a, act="leaky", slope=slope, out_mode=N.RC_OUT_PIXEL_SHUFFLE2)
+        else:
+            t = ops.pixel_shuffle2(self.subpel_conv[0]._nhwc(a, act="leaky", slope=slope))
+        return self.conv._nhwc(t, residual=self.upsample._nhwc(a))
+
+    def forward(self, x):
+        return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
 
 
 class HyCondModConvBlock(nn.Module):
@@ -315,6 +411,63 @@ class raw_compression_tcm_final(nn.Module):
         out = _slice_loop(self, fea)
         out.update({"y": out["para"]["y"], "lft": T.nchw_view(local[2]), "lsc": T.nchw_view(lsc_fea)})
         return out
+
+
+class raw_compression_tcm(raw_compression_tcm_final):
+    """The first RAW codec (upstream models/raw2bit.py:361-727): as the final one but without the local (hybrid) condition -- plain
+    ConvTransBlocks in the analysis transform, colour prior of 64 channels -- and `forward` returns only x_hat / likelihoods / para
+    (:491-579).  upstream's `compress` (:600) calls a `g_a` the class never builds; here it runs the analysis path of `forward` on
+    x = [raw, cond, coord], like the final model's compress."""
+
+    def __init__(self, config=[2, 2, 2, 2, 2, 2, 2], head_dim=[8, 16, 32, 32, 16, 8, 8], drop_path_rate=0, N=64, M=320, num_slices=5,
+                 max_support_slices=5, **kwargs):
+        nn.Module.__init__(self)
+        if drop_path_rate != 0:
+            raise NotImplementedError("inference path: drop_path_rate must be 0")
+        self.config, self.head_dim, self.window_size = config, head_dim, 8
+        self.num_slices, self.max_support_slices, self.M = num_slices, max_support_slices, M
+        dim, ws = N, self.window_size
+        n2 = 2 * N
+        cond_c = 64
+        self.classifier = Color_Condition_GFM(in_channels=4, out_c=cond_c)
+        self.lsc = Lens_Shading_Correction(in_channels=2, out_c=n2, nf=n2)
+        self.conv_first = conv3x3(4, n2)
+        self.conv_down = ResidualBlockWithStride(n2, n2, 2)
+
+        def ctb(n, hd, w=ws):
+            return [ConvTransBlock(dim, dim, hd, w, 0, 'W' if not i % 2 else 'SW') for i in range(n)]
+
+        self.gfm1 = nn.Sequential(Res_GFM(in_nc=n2, chan=n2, cond_c=cond_c, nf=4 * N))
+        self.m_down1 = N_seq(*ctb(config[0], head_dim[0]) + [ResidualBlockWithStride(n2, n2, stride=2)])
+        self.gfm2 = nn.Sequential(Res_GFM(in_nc=n2, chan=n2, cond_c=cond_c, nf=4 * N))
+        self.m_down2 = N_seq(*ctb(config[1], head_dim[1]) + [ResidualBlockWithStride(n2, n2, stride=2)])
+        self.gfm3 = nn.Sequential(Res_GFM(in_nc=n2, chan=n2, cond_c=cond_c, nf=4 * N))
+        self.m_down3 = N_seq(*ctb(config[2], head_dim[2]) + [conv3x3(n2, M, stride=2)])
+        self.g_s = N_seq(*[ResidualBlockUpsample(M, n2, 2)] + ctb(config[3], head_dim[3]) + [ResidualBlockUpsample(n2, n2, 2)] +
+                         ctb(config[4], head_dim[4]) + [ResidualBlockUpsample(n2, n2, 2)] + ctb(config[5], head_dim[5]) +
+                         [subpel_conv3x3(n2, n2, 2)] + [ResidualBlock(n2, n2), subpel_conv3x3(n2, 3, 2)])
+        self.h_a = N_seq(*[ResidualBlockWithStride(320, n2, 2)] + ctb(config[0], 32, 4) + [conv3x3(n2, 192, stride=2)])
+        self.h_mean_s = N_seq(*[ResidualBlockUpsample(192, n2, 2)] + ctb(config[3], 32, 4) + [subpel_conv3x3(n2, 320, 2)])
+        self.h_scale_s = N_seq(*[ResidualBlockUpsample(192, n2, 2)] + ctb(config[3], 32, 4) + [subpel_conv3x3(n2, 320, 2)])
+        width = lambda i, cap: 320 + (320 // num_slices) * min(i, cap)
+        self.atten_mean = nn.ModuleList(nn.Sequential(SWAtten(width(i, 5), width(i, 5), 16, ws, 0, inter_dim=128)) for i in range(num_slices))
+        self.atten_scale = nn.ModuleList(nn.Sequential(SWAtten(width(i, 5), width(i, 5), 16, ws, 0, inter_dim=128)) for i in range(num_slices))
+        self.cc_mean_transforms = nn.ModuleList(slice_transform(width(i, 5), 320 // num_slices) for i in range(num_slices))
+        self.cc_scale_transforms = nn.ModuleList(slice_transform(width(i, 5), 320 // num_slices) for i in range(num_slices))
+        self.lrp_transforms = nn.ModuleList(slice_transform(width(i + 1, 6), 320 // num_slices) for i in range(num_slices))
+        self.entropy_bottleneck = EntropyBottleneck(192)
+        self.gaussian_conditional = GaussianConditional(None)
+
+    def _analysis(self, a, cond, coord_nhwc):
+        lsc_fea = self.lsc._nhwc(coord_nhwc)
+        vec = self.classifier._vec(ops._req(cond, "cond"))
+        fea = self.conv_down._nhwc(self.conv_first._nhwc(a, mul_plus1=lsc_fea))
+        for gfm, stage in ((self.gfm1, self.m_down1), (self.gfm2, self.m_down2), (self.gfm3, self.m_down3)):
+            fea = stage._nhwc(gfm[0]._nhwc((fea, vec))[0])
+        return fea, None, lsc_fea
+
+    def _forward_nhwc(self, a, cond, coord_nhwc):
+        return _slice_loop(self, self._analysis(a, cond, coord_nhwc)[0])
 
 
 def N_seq(*mods):

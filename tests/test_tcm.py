@@ -547,3 +547,95 @@ def test_hip_raw_codec_forward_bf16_vs_reference():
     assert rep["y"] >= 55.0 and rep["means"] >= 50.0 and rep["scales"] >= 50.0 and rep["x_hat"] >= 38.0, rep
     assert rep["lft"] >= 55.0 and rep["lsc_s8"] >= 55.0, rep
     assert rep["rate_rel"] <= 0.005, rep
+
+
+# ---- the first RAW codec (raw_compression_tcm) and the GroupMix variants of the codec blocks ------------------------------------
+def _base_mirror(g):
+    import realcamnet_amd.raw2bit as RB
+    m = RB.raw_compression_tcm(N=int(g["N"]), M=320, num_slices=int(g["num_slices"])).eval()
+    sd = m.state_dict()
+    assert len([k for k in sd if not _coder_key(k)]) == int(g["n_keys"])
+    det_fill_(sd)
+    return m, sd
+
+
+def test_oracle_base_raw_codec_forward_equals_reference():
+    """raw_compression_tcm.forward (models/raw2bit.py:491-579) against the reference's own forward over restated CompressAI classes."""
+    g = load_golden("raw2bit_base_forward_n32")
+    _, sd = _base_mirror(g)
+    with torch.no_grad():
+        out = _flat(RO.raw_compression_tcm(sd, _raw_inputs(g), N=int(g["N"]), num_slices=int(g["num_slices"])))
+    for k, v in out.items():
+        assert rel_err(v, g["out." + k].float()) < (2e-3 if k == "x_hat" else 1e-4), k
+
+
+GMA_CODEC_BLOCKS = {
+    "raw2bit_gmaatten_96_hd10_i80": (lambda RB: RB.GMAAtten(96, 96, 10, 0., 80), lambda sd, x: RO.gma_atten(sd, "", x, 10)),
+    "raw2bit_convgma_32_80_hd10": (lambda RB: RB.ConvGMABlock(32, 80, 10, drop_path=0.), lambda sd, x: RO.conv_gma_block(sd, "", x, 32, 80, 10)),
+    "raw2bit_convgma_16_40_hd5": (lambda RB: RB.ConvGMABlock(16, 40, 5, drop_path=0.), lambda sd, x: RO.conv_gma_block(sd, "", x, 16, 40, 5)),
+    "raw2bit_rbu_48_32": (lambda RB: RB.RBU(48, 32, 2), lambda sd, x: RO.rbu(sd, "", x)),
+}
+
+
+@pytest.mark.parametrize("fixture", sorted(GMA_CODEC_BLOCKS))
+def test_oracle_gma_codec_blocks_equal_reference(fixture):
+    """GMAAtten / ConvGMABlock / RBU (models/raw2bit.py:209-234, 330-355, 3181-3206): oracle vs the reference's outputs, and the mirror
+    carries the reference's state_dict keys and shapes."""
+    import realcamnet_amd.raw2bit as RB
+    g = load_golden(fixture)
+    make, orc = GMA_CODEC_BLOCKS[fixture]
+    with torch.no_grad():
+        assert rel_err(orc(g["sd"], g["x"]), g["y"]) < 1e-6
+    m = make(RB)
+    assert list(m.state_dict().keys()) == list(g["sd"].keys())
+    assert [tuple(v.shape) for v in m.state_dict().values()] == [tuple(v.shape) for v in g["sd"].values()]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fixture", sorted(GMA_CODEC_BLOCKS))
+def test_hip_gma_codec_blocks_vs_reference(fixture, dt):
+    import realcamnet_amd.raw2bit as RB
+    g = load_golden(fixture)
+    m = GMA_CODEC_BLOCKS[fixture][0](RB)
+    m.load_state_dict(g["sd"], strict=True)
+    m = m.to("cuda", dt).eval()
+    with torch.no_grad():
+        y = m(g["x"].to("cuda", dt))
+    assert y.shape == g["y"].shape
+    assert rel_err(y.float().cpu(), g["y"]) < (3e-5 if dt == torch.float32 else 4e-2)
+
+
+@pytest.mark.gpu
+def test_hip_base_raw_codec_forward_vs_reference():
+    g = load_golden("raw2bit_base_forward_n32")
+    m, _ = _base_mirror(g)
+    m = m.to("cuda").eval()
+    with torch.no_grad():
+        res = m([t.cuda() for t in _raw_inputs(g)])
+    assert set(res) == {"x_hat", "likelihoods", "para"}                  # :575-579 -- no y / lft / lsc entries in this model's dict
+    out = {k: v.float().cpu() for k, v in _flat(res).items()}
+    assert rel_err(out["y"], g["out.y"]) < 1e-4 and rel_err(out["lik_z"], g["out.lik_z"]) < 1e-3
+    for k in ("means", "scales", "lik_y", "x_hat"):
+        assert _close_fraction(out[k], g["out." + k].float(), 3e-3) > 0.995, k
+    m = m.to(torch.bfloat16)
+    with torch.no_grad():
+        out = _flat(m([t.cuda() for t in _raw_inputs(g)]))
+    rep = _codec_bf16_report(out, g, ("y", "means", "scales", "x_hat"))
+    assert rep["y"] >= 55.0 and rep["means"] >= 50.0 and rep["scales"] >= 50.0 and rep["x_hat"] >= 38.0 and rep["rate_rel"] <= 0.005, rep
+
+
+@pytest.mark.gpu
+def test_hip_base_raw_codec_bitstream_round_trip():
+    """compress -> decompress of raw_compression_tcm: decoded x_hat equals the forward pass's reconstruction up to the clamp."""
+    g = load_golden("raw2bit_base_forward_n32")
+    m, _ = _base_mirror(g)
+    m = m.to("cuda").eval()
+    m.update()
+    x = [t.cuda() for t in _raw_inputs(g)]
+    with torch.no_grad():
+        enc = m.compress(x)
+        dec = m.decompress(enc["strings"], enc["shape"])["x_hat"]
+        fwd = m(x)["x_hat"].clamp(0, 1)
+    assert dec.shape == fwd.shape
+    assert _close_fraction(dec.float().cpu(), fwd.float().cpu(), 3e-3) > 0.995
