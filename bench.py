@@ -187,13 +187,13 @@ def main():
     }
     # HBM traffic comes from PMC counters, which cannot be read inside a timed run: tools/pmc_bench.sh collects them in
     # separate rocprofv3 --pmc passes of this same default command and commits the summary under profiles/
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_bench.json")
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_bench.json")
     if cfg_name == "cfg3" and args.dtype == "bf16" and B == 8 and os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
         res["roofline"]["traffic"] = round(pmc["conv_kernels_all"]["hbm_bytes_per_dispatch"])
         res["roofline"]["traffic_note"] = ("HBM bytes per conv launch (mean over the step's conv launches), FETCH_SIZE x2 + WRITE_SIZE "
-                                           "from profiles/r01_pmc_bench.json")
+                                           "from profiles/r02_pmc_bench.json")
         step_bytes = (pmc["all_kernels_total_bytes"]["fetch"] + pmc["all_kernels_total_bytes"]["write"]) / pmc.get("forwards", 3)
         res["hbm_whole_step"] = {"bytes_per_step": round(step_bytes), "achieved_TBps": round(step_bytes / (elapsed / args.steps) / 1e12, 2),
                                  "copy_rate_TBps": pmc.get("copy_rate_TBps", 5.9), "peak_TBps": 8.0}

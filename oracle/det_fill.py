@@ -25,6 +25,10 @@ def det_fill_(state_dict) -> None:
                 new = torch.sqrt(0.01 * torch.eye(v.shape[0]) + 0.0005 * torch.rand(v.shape, generator=g) + 2.0 ** -36)
             elif leaf == "gamma":
                 new = torch.sqrt(0.1 * torch.eye(v.shape[0]) + 0.02 * torch.rand(v.shape, generator=g) + 2.0 ** -36)
+            elif leaf == "running_mean":                                         # BatchNorm statistics of the GroupMix aggregator
+                new = 0.1 * r(*v.shape)
+            elif leaf == "running_var":
+                new = 1.0 + 0.2 * torch.rand(v.shape, generator=g)
             elif leaf == "quantiles":
                 new = v.clone(); new[:, 0, 1] = 0.5 * r(v.shape[0])
             elif leaf.startswith("_matrix"):

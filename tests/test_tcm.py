@@ -639,3 +639,23 @@ def test_hip_base_raw_codec_bitstream_round_trip():
         fwd = m(x)["x_hat"].clamp(0, 1)
     assert dec.shape == fwd.shape
     assert _close_fraction(dec.float().cpu(), fwd.float().cpu(), 3e-3) > 0.995
+
+
+@pytest.mark.gpu
+def test_hip_gma_codec_blocks_at_upstream_smoke_shapes():
+    """The two shapes upstream's own `test_gma` lines run (models/raw2bit.py:4361-4367): ConvGMABlock(64, 80, 10) on (1,144,32,32) and
+    GMAAtten(320, 320, 25, 0., 200) on (1,320,32,32); det_fill parameters, oracle on the CPU as the checker."""
+    import realcamnet_amd.raw2bit as RB
+    g = torch.Generator().manual_seed(11)
+    for m, shape, orc in ((RB.ConvGMABlock(64, 80, 10, drop_path=0.), (1, 144, 32, 32), lambda sd, x: RO.conv_gma_block(sd, "", x, 64, 80, 10)),
+                          (RB.GMAAtten(320, 320, 25, 0., 200), (1, 320, 32, 32), lambda sd, x: RO.gma_atten(sd, "", x, 25))):
+        sd = m.state_dict()
+        det_fill_(sd)
+        x = torch.randn(*shape, generator=g)
+        with torch.no_grad():
+            want = orc(sd, x)
+            got = m.to("cuda").eval()(x.cuda())
+        assert rel_err(got.cpu(), want) < 5e-5
+        with torch.no_grad():
+            got = m.to(torch.bfloat16)(x.cuda().bfloat16())
+        assert LO.psnr(got.float().cpu(), want) >= 45.0

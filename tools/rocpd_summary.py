@@ -21,10 +21,15 @@ def demangle(name: str) -> str:
     m = re.match(r"_ZN2rc(\d+)(conv_mfma(?:_persist|_wsm|_ws)?_kernel)INS_7ConvCfgI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)E(?:Li\d+E)?EELb([01])E", name)
     if m:
         return f"rc::{m.group(2)}<{_DT[m.group(3)]},CK={m.group(4)},NT={m.group(5)},K={m.group(6)},gated={m.group(7)}>"
-    m = re.match(r"_ZN2rc(\d+)", name)          # generic rc::<kernel><dtype, ints...> (c++filt cannot parse DF16b)
+    m = re.match(r"_ZN2rc(\d+)", name)          # generic rc::[ns::]<kernel><dtype, ints...> (c++filt cannot parse DF16b)
     if m:
         n = int(m.group(1)); start = m.end()
         base, rest = name[start:start + n], name[start + n:]
+        m2 = re.match(r"(\d+)", rest)            # nested namespace (rc::gf::kernel): the next length-prefixed component is the kernel
+        while m2:
+            k = int(m2.group(1))
+            base, rest = base + "::" + rest[m2.end():m2.end() + k], rest[m2.end() + k:]
+            m2 = re.match(r"(\d+)", rest)
         args = []
         if rest.startswith("I"):
             rest = rest[1:]

@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Turn the outputs of tools/final_profiles.sh TAG (under gpurun_out/) into the committed evidence under profiles/.
-usage: python tools/write_profiles.py TAG"""
+usage: python tools/write_profiles.py TAG [ROUND]"""
 import json, os, shutil, subprocess, sys
 tag = sys.argv[1]
+RND = sys.argv[2] if len(sys.argv) > 2 else "r02"
 G = "gpurun_out"
 last = lambda p: open(p).read().strip().splitlines()[-1]
-shutil.copy(f"{G}/pmc_{tag}.json", "profiles/r01_pmc_bench.json")
+shutil.copy(f"{G}/pmc_{tag}.json", f"profiles/{RND}_pmc_bench.json")
 trace, default = last(f"{G}/bench_trace_{tag}.json"), last(f"{G}/bench_default_{tag}.json")
 summ = subprocess.run([sys.executable, "tools/rocpd_summary.py", f"{G}/prof_{tag}/trace_results.db"], capture_output=True, text=True).stdout
-open("profiles/r01_bench_kernel_stats.md", "w").write(f"""# r01 — kernel trace of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline` (cfg3, 1x MI355X)
+open(f"profiles/{RND}_bench_kernel_stats.md", "w").write(f"""# {RND} — kernel trace of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline` (cfg3, 1x MI355X)
 
 Command: `rocprofv3 --kernel-trace --stats -d gpurun_out/prof_{tag} -o trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline`
 (5 forwards in the trace: 1 warm-up + 3 timed + 1 HIP-event profiling pass). Summarised from the rocpd database with
@@ -21,7 +22,7 @@ HIP events on the launch stream.
 
 {summ}
 """)
-open("profiles/r01_bench_default.md", "w").write(f"""# r01 — default `python bench.py` (steps 5, warm-up 2, CPU baseline leg on), 1x MI355X
+open(f"profiles/{RND}_bench_default.md", "w").write(f"""# {RND} — default `python bench.py` (steps 5, warm-up 2, CPU baseline leg on), 1x MI355X
 
 ```json
 {default}
@@ -46,18 +47,18 @@ Matrix-pipe calibration (`tools/mfma_peak.py`, `rc_debug_mfma_peak`: nothing but
 {open(f'{G}/mfma_peak_{tag}.txt').read().strip()}
 ```
 """)
-d = json.load(open("profiles/r01_pmc_bench.json"))
+d = json.load(open(f"profiles/{RND}_pmc_bench.json"))
 dj = json.loads(default)
 rows = sorted(d["kernels"].items(), key=lambda kv: -(kv[1]["fetch_bytes_per_dispatch"] + kv[1]["write_bytes_per_dispatch"]) * kv[1]["dispatches"])
 tb = "\n".join(f"| `{k[:90]}` | {e['dispatches']} | {e['fetch_bytes_per_dispatch'] / 1e9:.3f} | {e['write_bytes_per_dispatch'] / 1e9:.3f} | "
                f"{(e['fetch_bytes_per_dispatch'] + e['write_bytes_per_dispatch']) * e['dispatches'] / 3 / 1e9:.1f} |" for k, e in rows[:24])
 tot = (d["all_kernels_total_bytes"]["fetch"] + d["all_kernels_total_bytes"]["write"]) / 3 / 1e9
 rate = tot / dj["ms_per_step"]
-open("profiles/r01_pmc_bench.md", "w").write(f"""# r01 — HBM traffic of the bench command from PMC counters (cfg3, 1x MI355X)
+open(f"profiles/{RND}_pmc_bench.md", "w").write(f"""# {RND} — HBM traffic of the bench command from PMC counters (cfg3, 1x MI355X)
 
 `tools/pmc_bench.sh`: two passes of `rocprofv3 --pmc <counter> --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline`
 (FETCH_SIZE and WRITE_SIZE do not fit one pass; no other trace domains), 3 forwards per pass, summarised per kernel by
-`tools/pmc_bench_summary.py` into `profiles/r01_pmc_bench.json` (which `bench.py` reads for `roofline.traffic` and
+`tools/pmc_bench_summary.py` into `profiles/{RND}_pmc_bench.json` (which `bench.py` reads for `roofline.traffic` and
 `hbm_whole_step`). Units: FETCH_SIZE KiB x 1024 x 2 (gfx950: a 16-byte-per-lane streaming read is tallied at half, MI355X guide
 section HBM), WRITE_SIZE KiB x 1024 (calibrated earlier on the 48->48 layer: equals the output bytes exactly).
 
@@ -68,6 +69,33 @@ Conv kernels: {d['conv_kernels_all']['dispatches']} dispatches, {d['conv_kernels
 | kernel | dispatches (3 forwards) | fetch GB / dispatch | write GB / dispatch | GB per forward |
 |---|---|---|---|---|
 {tb}
+""")
+codec = last(f"{G}/bench_codec_{tag}.json")
+csumm = subprocess.run([sys.executable, "tools/rocpd_summary.py", f"{G}/prof_codec_{tag}/trace_results.db"], capture_output=True, text=True).stdout
+open(f"profiles/{RND}_rawcodec_kernel_stats.md", "w").write(f"""# {RND} — RAW codec leg: `python bench.py --model raw_compression_tcm_final --frames 4` (cfg5 shape on one GPU, bf16, 1x MI355X)
+
+Default run (steps 5, warm-up 2, CPU baseline leg on):
+
+```json
+{codec}
+```
+
+Kernel trace: `rocprofv3 --kernel-trace --stats -- python bench.py --model raw_compression_tcm_final --frames 4 --steps 2 --warmup 1 --no-cpu-baseline`
+(3 forwards of 4 frames + weight packing in the trace), summarised with `tools/rocpd_summary.py`:
+
+{csumm}
+
+Bitstream legs (`tools/codec_stream_bench.py`: compress / decompress of one 4K mosaic's packed RAW, both stream formats; the forward's time beside them):
+
+```
+{open(f'{G}/codec_stream_{tag}.txt').read().strip()}
+```
+""")
+open(f"profiles/{RND}_gma_stages.md", "w").write(f"""# {RND} — the GroupMix block launch by launch at the cfg3 size (8 x 544 x 960 tokens, dim 80, bf16), `tools/gma_stage_bench.py`, HIP events
+
+```
+{open(f'{G}/gma_stages_{tag}.txt').read().strip()}
+```
 """)
 c2, ng, iu = (json.loads(last(f"{G}/bench_{n}_{tag}.json")) for n in ("cfg2", "nogma", "ispunet"))
 print(json.dumps({"cfg3": [dj["value"], dj["ms_per_step"], dj["roofline"]["achieved"], dj["roofline"]["frac"], dj["hbm_whole_step"], dj["cpu_baseline"]["value"], dj["psnr_db_vs_cpu_fp32"]],
