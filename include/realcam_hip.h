@@ -190,6 +190,20 @@ int rc_pointwise_chain48(const void* d_x, int cin0, const void* d_w0packed, cons
                          const float* const* d_bias, int n_mid, float slope, void* d_out, int dtype, long long pixels,
                          void* stream);
 
+/* The chain with register-resident activations, optionally with the consuming convolution folded in (models/LiteISP.py:363-378 and
+ * :2012-2014 `h = head(raw); h = h * (lsc(coord) + 1)`; ISPUNet :1352-1355; models/raw2bit.py:1775-1781 at width 128):
+ *   d_out = chain(d_x)                                         when d_raw == NULL
+ *   d_out = (conv3x3(d_raw) + bias) * (chain(d_x) + 1)         otherwise -- one launch, the lens-shading map never reaches HBM.
+ * A wave carries 64 pixels through every layer in MFMA fragments (no LDS round trip between layers); the map is rounded to bf16 where the
+ * two-launch path stores it.  bf16 only, c = 48 or 128, cin0 <= 4, raw_c <= 4, 1 <= n_mid <= 4 (layers after the first).
+ * d_blob: rc_lsc_pack's output (rc_lsc_packed_bytes bytes) on the device: w0 (c,cin0), wmid[l] (c,c), whead (c,raw_c,3,3) fp32 as in the
+ * state_dict (+ biases, or NULL) re-ordered into pair-packed MFMA fragments.  d_x NHWC (batch,H,W,cin0), d_raw NHWC (batch,H,W,raw_c). */
+size_t rc_lsc_packed_bytes(int c, int n_mid, int has_head);
+int rc_lsc_pack(const float* w0, const float* b0, int cin0, const float* const* wmid, const float* const* bmid, int n_mid,
+                const float* whead, const float* bhead, int raw_c, int c, void* dst);
+int rc_lsc_chain(const void* d_x, int cin0, const void* d_blob, int c, int n_mid, float slope, const void* d_raw, int raw_c,
+                 void* d_out, int batch, int H, int W, void* stream);
+
 /* ---- a8: CALayer gate -------------------------------------------------------------------------
  * Replaces: AdaptiveAvgPool2d(1) -> Conv1x1(C,C/r) -> ReLU -> Conv1x1(C/r,C) -> Sigmoid
  * (models/networks.py:259-269).  d_sums: (B, n_tiles, C) partials from rc_conv2d; w0 (Cr,C), b0 (Cr),

@@ -102,7 +102,10 @@ class Lens_Shading_Correction(N.HipModule):
         if (all(isinstance(m, N.Conv2d) for m in convs) and all(isinstance(m, nn.LeakyReLU) for m in acts) and
                 len(mods) == 2 * len(convs) - 1):
             slopes = [float(m.negative_slope) for m in acts]
-            if ops.pointwise_chain_ok(a, convs, slopes):       # all four layers in one launch
+            y = ops.lsc_chain(self, a)                          # all four layers in one launch, activations in registers
+            if y is not None:
+                return y
+            if ops.pointwise_chain_ok(a, convs, slopes):       # the LDS-slab form (kept for rc_pointwise_chain48's callers)
                 return ops.pointwise_chain(a, convs, slopes[0])
         return self.model._nhwc(a)
 
@@ -318,7 +321,9 @@ class _DwtUNet(nn.Module):
     def _front(self, a, cond, coord_nhwc):
         """head(raw) [* (lsc(coord) + 1)] and the colour-prior vector (None without a classifier)."""
         if hasattr(self, "lsc"):
-            h = self.head._nhwc(a, mul_plus1=self.lsc._nhwc(coord_nhwc))           # h = head(raw) * (lsc + 1)
+            h = ops.lsc_chain(self.lsc, coord_nhwc, self.head, a)       # h = head(raw) * (lsc + 1), one launch when 48-wide bf16
+            if h is None:
+                h = self.head._nhwc(a, mul_plus1=self.lsc._nhwc(coord_nhwc))
         else:
             h = self.head._nhwc(a)
         vec = self.classifier._vec(ops._req(cond, "cond")) if hasattr(self, "classifier") else None
@@ -469,7 +474,9 @@ class _StridedUNet(nn.Module):
 
     def _run(self, a, cond, coord_nhwc, crop_hw=None):
         if hasattr(self, "lsc"):
-            intro = self.intro._nhwc(a, mul_plus1=self.lsc._nhwc(coord_nhwc))    # intro(raw) * (lsc + 1)
+            intro = ops.lsc_chain(self.lsc, coord_nhwc, self.intro, a)  # intro(raw) * (lsc + 1)
+            if intro is None:
+                intro = self.intro._nhwc(a, mul_plus1=self.lsc._nhwc(coord_nhwc))
         else:
             intro = self.intro._nhwc(a)
         has_gfm = hasattr(self, "classifier")

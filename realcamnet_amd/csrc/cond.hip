@@ -32,26 +32,37 @@ __global__ __launch_bounds__(256) void ca_reduce_kernel(float* __restrict__ sums
     }
 }
 
-// Stage 2: sum `n_tiles` slots spaced `tile_stride` tiles apart, then the 2-layer gate MLP.
-__global__ __launch_bounds__(256) void ca_gate_kernel(const float* __restrict__ sums, int n_tiles, int tile_stride,
-                                                      size_t image_stride, int c, int cr,
-                                                      float inv_hw, const float* __restrict__ w0,
-                                                      const float* __restrict__ b0, const float* __restrict__ w1,
-                                                      const float* __restrict__ b1, float* __restrict__ gate) {
-    extern __shared__ float sm[];          // [256] partials | [c] mean | [cr] hidden
+// Stage 2: sum `n_tiles` slots spaced `tile_stride` tiles apart, then the 2-layer gate MLP.  One block per image on the critical path
+// between two convolutions, so it is built for latency: 1024 threads, every thread's few slot loads independent (4 accumulators, fixed order).
+constexpr int kGateThreads = 1024;
+__global__ __launch_bounds__(kGateThreads) void ca_gate_kernel(const float* __restrict__ sums, int n_tiles, int tile_stride,
+                                                               size_t image_stride, int c, int cr,
+                                                               float inv_hw, const float* __restrict__ w0,
+                                                               const float* __restrict__ b0, const float* __restrict__ w1,
+                                                               const float* __restrict__ b1, float* __restrict__ gate) {
+    extern __shared__ float sm[];          // [kGateThreads] partials | [c] mean | [cr] hidden
     float* part = sm;
-    float* mean = sm + 256;
+    float* mean = sm + kGateThreads;
     float* hid = mean + c;
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* s = sums + (size_t)b * image_stride;
-    for (int c0 = 0; c0 < c; c0 += 256) {
-        const int cw = (c - c0) < 256 ? (c - c0) : 256;   // channels in this pass
-        const int nparts = 256 / cw;                       // >= 1
+    for (int c0 = 0; c0 < c; c0 += kGateThreads) {
+        const int cw = (c - c0) < kGateThreads ? (c - c0) : kGateThreads;   // channels in this pass
+        const int nparts = kGateThreads / cw;                                // >= 1
         const int ch = tid % cw, pt = tid / cw;
-        float acc = 0.f;
-        if (pt < nparts)
-            for (int t = pt; t < n_tiles; t += nparts) acc += s[(size_t)t * tile_stride * c + c0 + ch];
-        part[tid] = acc;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (pt < nparts) {
+            const size_t step = (size_t)tile_stride * c;
+            const float* q = s + c0 + ch;
+            int t = pt;
+            for (; t + 3 * nparts < n_tiles; t += 4 * nparts) {
+                const float v0 = q[(size_t)t * step], v1 = q[(size_t)(t + nparts) * step];
+                const float v2 = q[(size_t)(t + 2 * nparts) * step], v3 = q[(size_t)(t + 3 * nparts) * step];
+                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+            }
+            for (; t < n_tiles; t += nparts) a0 += q[(size_t)t * step];
+        }
+        part[tid] = (a0 + a1) + (a2 + a3);
         __syncthreads();
         if (tid < cw) {
             float tot = 0.f;
@@ -60,13 +71,13 @@ __global__ __launch_bounds__(256) void ca_gate_kernel(const float* __restrict__ 
         }
         __syncthreads();
     }
-    for (int j = tid; j < cr; j += 256) {
+    for (int j = tid; j < cr; j += kGateThreads) {
         float h = b0[j];
         for (int k = 0; k < c; ++k) h += w0[(size_t)j * c + k] * mean[k];
         hid[j] = h > 0.f ? h : 0.f;
     }
     __syncthreads();
-    for (int k = tid; k < c; k += 256) {
+    for (int k = tid; k < c; k += kGateThreads) {
         float z = b1[k];
         for (int j = 0; j < cr; ++j) z += w1[(size_t)k * cr + j] * hid[j];
         gate[(size_t)b * c + k] = 1.f / (1.f + expf(-z));
@@ -278,7 +289,7 @@ int rc_ca_gate(float* d_sums, int batch, int n_tiles, int c, int cr, float inv_h
                float* d_gate, void* stream) {
     RC_REQUIRE(d_sums && d_w0 && d_b0 && d_w1 && d_b1 && d_gate, "rc_ca_gate: null pointer");
     RC_REQUIRE(batch >= 1 && n_tiles >= 1 && c >= 1 && cr >= 1, "rc_ca_gate: bad shape");
-    const size_t lds = (256 + (size_t)c + cr) * sizeof(float);
+    const size_t lds = (kGateThreads + (size_t)c + cr) * sizeof(float);
     RC_REQUIRE(lds <= 64 * 1024, "rc_ca_gate: too many channels");
     RC_REQUIRE(batch <= 65535, "rc_ca_gate: batch > 65535");
     int slots = n_tiles, stride = 1;
@@ -288,7 +299,7 @@ int rc_ca_gate(float* d_sums, int batch, int n_tiles, int c, int cr, float inv_h
         stride = L;
         hipLaunchKernelGGL(ca_reduce_kernel, dim3(slots, batch), dim3(256), 0, as_stream(stream), d_sums, n_tiles, c, L);
     }
-    hipLaunchKernelGGL(ca_gate_kernel, dim3(batch), dim3(256), lds, as_stream(stream), d_sums, slots, stride,
+    hipLaunchKernelGGL(ca_gate_kernel, dim3(batch), dim3(kGateThreads), lds, as_stream(stream), d_sums, slots, stride,
                        (size_t)n_tiles * c, c, cr, inv_hw, d_w0, d_b0, d_w1, d_b1, d_gate);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;

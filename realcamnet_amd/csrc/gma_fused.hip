@@ -861,3 +861,293 @@ extern "C" int rc_gma_crpe(const void* d_qkvp, void* d_convv, int batch, int H, 
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
+
+// =====================================================================================================================================
+// Lens_Shading_Correction as a register-resident chain, optionally with the convolution it modulates
+//   coord (B,H,W,cin0 <= 4) -> Conv1x1(cin0, C) -> LeakyReLU -> [Conv1x1(C, C) -> LeakyReLU] x (n_mid - 1) -> Conv1x1(C, C) = lsc
+//   HEAD:  out = (conv3x3(raw (B,H,W,raw_c <= 4)) + bias) * (lsc + 1)          (models/LiteISP.py:363-378, 2012-2014; ISPUNet :1352-1355)
+// The LDS-slab form of this chain (csrc/chain.hip) is VALU-bound on its per-layer LDS round trips (0.69 ms at 4K x 8, 1.26 ms with the
+// head folded in).  Here a wave's 64 pixels stay in MFMA fragments through every layer (pair-packed rows, see the top of this file):
+// layer 0 is one half-filled K-step (k = 4 q + i < cin0), the head's 9 taps x 4 channels are one full K-step (lane group g: taps 2g, 2g+1)
+// plus a half-filled one (tap 8), and the lsc map is rounded to bf16 exactly where the two-launch path stores it.
+namespace rc {
+namespace gf {
+
+struct LscArgs {
+    const bf16_t* x; int cin0;
+    const char* blob; int n_mid; float slope;      // rc_lsc_pack: [layer 0 | mid layers | head] bf16 fragments, then the packed fp32 biases
+    const bf16_t* raw; int raw_c;                  // HEAD only
+    bf16_t* out; long long pixels; int H, W;
+};
+
+template <int C> __host__ __device__ constexpr int lsc_weight_bytes(int n_mid, bool head) {
+    return (C / 16) * 512 + n_mid * (C / 16) * tile_bytes(C) + (head ? (C / 16) * 1536 : 0);
+}
+
+// acc[m][nt] = W[tile m] . in with a literal-zero C operand on the first K-step (no accumulator initialisation instructions)
+template <int CIN, int MT>
+__device__ __forceinline__ void gemm_fresh(const char* w, int lane, const Act<CIN> (&in)[kNT], f32x4 (&acc)[MT][kNT]) {
+    constexpr int KS = CIN / 32, TB = tile_bytes(CIN);
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        uint4 a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const uint4*>(w + m * TB + s * 1024 + lane * 16);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                if (s == 0) { acc[m][nt] = z; }
+                mma32(a[m], in[nt].f[s], acc[m][nt]);
+            }
+    }
+    if constexpr ((CIN % 32) != 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const uint2 a = *reinterpret_cast<const uint2*>(w + m * TB + KS * 1024 + lane * 8);
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                if (KS == 0) { acc[m][nt] = z; }
+                mma16(a, in[nt].t, acc[m][nt]);
+            }
+        }
+    }
+}
+
+// fp32 accumulator tiles (+ bias [, LeakyReLU]) -> the next layer's B fragments
+template <int C, bool ACT>
+__device__ __forceinline__ void lsc_pack(const f32x4 (&acc)[C / 16][kNT], const float* bias, int g, float slope, Act<C> (&out)[kNT]) {
+    constexpr int MT = C / 16;
+    auto fin = [&](const f32x4& v, const f32x4& b) {
+        f32x4 r = v + b;
+        if constexpr (ACT) {
+            const f32x4 s = r * slope;
+            r = f32x4{fmaxf(r[0], s[0]), fmaxf(r[1], s[1]), fmaxf(r[2], s[2]), fmaxf(r[3], s[3])};      // 0 <= slope <= 1
+        }
+        return r;
+    };
+#pragma unroll
+    for (int p = 0; p < MT / 2; ++p) {
+        const f32x4 b0 = bias4(bias, 2 * p, g), b1 = bias4(bias, 2 * p + 1, g);
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) out[nt].f[p] = pack_pair(fin(acc[2 * p][nt], b0), fin(acc[2 * p + 1][nt], b1));
+    }
+    if constexpr (MT & 1) {
+        const f32x4 b0 = bias4(bias, MT - 1, g);
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) out[nt].t = pack_tail(fin(acc[MT - 1][nt], b0));
+    }
+}
+
+constexpr int kOOBoff = (int)0x80000000;            // buffer offset past any image: the load returns 0
+
+struct LscIn {                                       // one wave tile's inputs in flight
+    uint2 x[kNT];                                    // layer-0 B operand (k = 4 g + i: the coordinates in lane group 0)
+    uint4 rf[kNT]; uint2 rt[kNT];                    // head B operands: taps (2g, 2g+1) x 4 channels; tap 8 in lane group 0
+};
+
+template <bool HEAD>
+__device__ __forceinline__ void lsc_load(const LscArgs& a, long long p0, int n, int g, __amdgpu_buffer_rsrc_t r_x, __amdgpu_buffer_rsrc_t r_raw, LscIn& in) {
+    const unsigned uW = (unsigned)a.W, uH = (unsigned)a.H;
+    unsigned row0 = 0, x0 = 0, y0 = 0;
+    if constexpr (HEAD) {
+        row0 = __builtin_amdgcn_readfirstlane((unsigned)p0 / uW);
+        x0 = (unsigned)p0 - row0 * uW;
+        y0 = __builtin_amdgcn_readfirstlane(row0 % uH);
+    }
+#pragma unroll
+    for (int nt = 0; nt < kNT; ++nt) {
+        const long long p = p0 + 16 * nt + n;
+        const bool live = p < a.pixels;
+        {   // coordinates: cin0 bf16 values of lane group 0
+            const int off = (live && g == 0) ? (int)p * a.cin0 * 2 : kOOBoff;
+            unsigned lo = 0, hi = 0;
+            if (a.cin0 == 2) lo = __builtin_amdgcn_raw_buffer_load_b32(r_x, off, 0, 0);
+            else if (a.cin0 == 4) { const auto v = __builtin_amdgcn_raw_buffer_load_b64(r_x, off, 0, 0); lo = v[0]; hi = v[1]; }
+            else {
+                unsigned short e[4] = {0, 0, 0, 0};
+                for (int i = 0; i < a.cin0; ++i) e[i] = __builtin_amdgcn_raw_buffer_load_b16(r_x, off == kOOBoff ? kOOBoff : off + 2 * i, 0, 0);
+                lo = e[0] | ((unsigned)e[1] << 16); hi = e[2] | ((unsigned)e[3] << 16);
+            }
+            in.x[nt] = make_uint2(lo, hi);
+        }
+        if constexpr (HEAD) {
+            unsigned x = x0 + 16 * nt + n, y = y0;
+            while (x >= uW) { x -= uW; ++y; }
+            while (y >= uH) y -= uH;
+            auto tap = [&](int t) -> uint2 {                                   // 8 bytes of channels of tap t, zero outside the image
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const bool ok = live && (unsigned)((int)y + dy) < uH && (unsigned)((int)x + dx) < uW;
+                const int off = ok ? ((int)p + dy * a.W + dx) * a.raw_c * 2 : kOOBoff;
+                if (a.raw_c == 4) { const auto v = __builtin_amdgcn_raw_buffer_load_b64(r_raw, off, 0, 0); return make_uint2(v[0], v[1]); }
+                unsigned short e[4] = {0, 0, 0, 0};
+                for (int i = 0; i < a.raw_c; ++i) e[i] = __builtin_amdgcn_raw_buffer_load_b16(r_raw, ok ? off + 2 * i : kOOBoff, 0, 0);
+                return make_uint2(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16));
+            };
+            const uint2 t0 = tap(2 * g), t1 = tap(2 * g + 1), t8 = tap(8);
+            in.rf[nt] = make_uint4(t0.x, t0.y, t1.x, t1.y);
+            in.rt[nt] = g == 0 ? t8 : make_uint2(0u, 0u);
+        }
+    }
+}
+
+template <int C> constexpr int lsc_threads() { return C > 64 ? 512 : 256; }   // wide chains keep ~100 KB of weights in LDS: one 8-wave block per CU
+template <int C, bool HEAD>
+__global__ __launch_bounds__(lsc_threads<C>(), 2) void lsc_chain_kernel(const LscArgs a) {    // <= 256 registers: VGPR-form MFMA, no AGPR copies
+    constexpr int kLscThreads = lsc_threads<C>();
+    constexpr int MT = C / 16, TBM = tile_bytes(C);
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int w_bytes = lsc_weight_bytes<C>(a.n_mid, HEAD);
+    const int total = w_bytes + (1 + a.n_mid + (HEAD ? 1 : 0)) * MT * 16 * 4;
+    for (int i = tid; i < total / 16; i += kLscThreads) reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(a.blob)[i];
+    __syncthreads();
+    const char* s_l0 = lds;
+    const char* s_mid = lds + MT * 512;
+    const char* s_head = s_mid + a.n_mid * MT * TBM;
+    const float* s_b = reinterpret_cast<const float*>(lds + w_bytes);
+
+    const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)(a.pixels * a.cin0 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(HEAD ? a.raw : a.x), 0,
+                                                                           (int)(a.pixels * (HEAD ? a.raw_c : a.cin0) * 2), 0x00020000);
+    const long long n_tiles = (a.pixels + 63) / 64, n_waves = (long long)gridDim.x * (kLscThreads / 64);
+    long long tile = (long long)blockIdx.x * (kLscThreads / 64) + (tid >> 6);
+    LscIn nxt;
+    if (tile < n_tiles) lsc_load<HEAD>(a, tile * 64, n, g, r_x, r_raw, nxt);
+    for (; tile < n_tiles; tile += n_waves) {
+        const LscIn in = nxt;
+        if (tile + n_waves < n_tiles) lsc_load<HEAD>(a, (tile + n_waves) * 64, n, g, r_x, r_raw, nxt);     // next tile's operands in flight
+        Act<C> cur[kNT];
+        {   // layer 0
+            f32x4 acc[MT][kNT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const uint2 w = *reinterpret_cast<const uint2*>(s_l0 + m * 512 + lane * 8);
+#pragma unroll
+                for (int nt = 0; nt < kNT; ++nt) { acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; mma16(w, in.x[nt], acc[m][nt]); }
+            }
+            lsc_pack<C, true>(acc, s_b, g, a.slope, cur);
+        }
+#pragma unroll 1
+        for (int l = 0; l < a.n_mid; ++l) {
+            f32x4 acc[MT][kNT];
+            gemm_fresh<C, MT>(s_mid + l * MT * TBM, lane, cur, acc);
+            if (l + 1 < a.n_mid) lsc_pack<C, true>(acc, s_b + (1 + l) * MT * 16, g, a.slope, cur);
+            else lsc_pack<C, false>(acc, s_b + (1 + l) * MT * 16, g, a.slope, cur);
+        }
+        if constexpr (HEAD) {   // out = (conv3x3(raw) + bias) * (lsc + 1), lsc = cur as the two-launch path would re-read it (bf16)
+            f32x4 acc[MT][kNT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const uint4 w4 = *reinterpret_cast<const uint4*>(s_head + m * 1536 + lane * 16);
+                const uint2 w2 = *reinterpret_cast<const uint2*>(s_head + m * 1536 + 1024 + lane * 8);
+#pragma unroll
+                for (int nt = 0; nt < kNT; ++nt) {
+                    acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mma32(w4, in.rf[nt], acc[m][nt]); mma16(w2, in.rt[nt], acc[m][nt]);
+                }
+            }
+            const float* hb = s_b + (1 + a.n_mid) * MT * 16;
+#pragma unroll
+            for (int p = 0; p < MT / 2; ++p) {
+                const f32x4 b0 = bias4(hb, 2 * p, g), b1 = bias4(hb, 2 * p + 1, g);
+#pragma unroll
+                for (int nt = 0; nt < kNT; ++nt)
+                    cur[nt].f[p] = pack_pair((acc[2 * p][nt] + b0) * (up_lo(cur[nt].f[p]) + 1.f), (acc[2 * p + 1][nt] + b1) * (up_hi(cur[nt].f[p]) + 1.f));
+            }
+            if constexpr (MT & 1) {
+                const f32x4 b0 = bias4(hb, MT - 1, g);
+#pragma unroll
+                for (int nt = 0; nt < kNT; ++nt) cur[nt].t = pack_tail((acc[MT - 1][nt] + b0) * (up_tail(cur[nt].t) + 1.f));
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            const long long p = tile * 64 + 16 * nt + n;
+            if (p < a.pixels) store_act<C>(a.out + p * C, g, cur[nt]);
+        }
+    }
+}
+
+}  // namespace gf
+}  // namespace rc
+
+extern "C" size_t rc_lsc_packed_bytes(int c, int n_mid, int has_head) {
+    if (!(c == 48 || c == 128) || n_mid < 1) return 0;
+    const int w = c == 48 ? lsc_weight_bytes<48>(n_mid, has_head != 0) : lsc_weight_bytes<128>(n_mid, has_head != 0);
+    return (size_t)w + (size_t)(1 + n_mid + (has_head ? 1 : 0)) * (c / 16) * 16 * 4;
+}
+
+// Host-side packer: w0 (c, cin0), wmid[l] (c, c), whead (c, raw_c, 3, 3) fp32 row-major as in the state_dict; biases (c) or NULL.
+extern "C" int rc_lsc_pack(const float* w0, const float* b0, int cin0, const float* const* wmid, const float* const* bmid, int n_mid,
+                           const float* whead, const float* bhead, int raw_c, int c, void* dst) {
+    RC_REQUIRE(w0 && wmid && bmid && dst, "rc_lsc_pack: null pointer");
+    RC_REQUIRE((c == 48 || c == 128) && n_mid >= 1 && n_mid <= 4 && cin0 >= 1 && cin0 <= 4, "rc_lsc_pack: width 48 or 128, 1..4 mid layers, cin0 <= 4");
+    RC_REQUIRE(!whead || (raw_c >= 1 && raw_c <= 4), "rc_lsc_pack: the head's input has 1..4 channels");
+    const int mt = c / 16, tbm = tile_bytes(c);
+    char* p = static_cast<char*>(dst);
+    for (int m = 0; m < mt; ++m)                                         // layer 0: half-filled K-step, k = 4 q + i
+        for (int lane = 0; lane < 64; ++lane) {
+            const int ch = row_channel(m, lane & 15, mt), q = lane >> 4;
+            uint16_t* o = reinterpret_cast<uint16_t*>(p + m * 512 + lane * 8);
+            for (int i = 0; i < 4; ++i) o[i] = (4 * q + i < cin0) ? host_f32_to_bf16(w0[(size_t)ch * cin0 + 4 * q + i]) : 0;
+        }
+    p += mt * 512;
+    for (int l = 0; l < n_mid; ++l) {
+        RC_REQUIRE(wmid[l] != nullptr, "rc_lsc_pack: null layer");
+        const int rc = rc_chain_pack_weights(wmid[l], c, c, p);
+        if (rc != RC_OK) return rc;
+        p += mt * tbm;
+    }
+    if (whead) {
+        for (int m = 0; m < mt; ++m)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int ch = row_channel(m, lane & 15, mt), q = lane >> 4;
+                uint16_t* o4 = reinterpret_cast<uint16_t*>(p + m * 1536 + lane * 16);
+                uint16_t* o2 = reinterpret_cast<uint16_t*>(p + m * 1536 + 1024 + lane * 8);
+                auto wv = [&](int tap, int ci) { return ci < raw_c ? host_f32_to_bf16(whead[((size_t)ch * raw_c + ci) * 9 + tap]) : (uint16_t)0; };
+                for (int i = 0; i < 8; ++i) o4[i] = wv(2 * q + (i >> 2), i & 3);                       // k = 8 q + i -> tap 2 q + i / 4, channel i % 4
+                for (int i = 0; i < 4; ++i) o2[i] = q == 0 ? wv(8, i) : (uint16_t)0;                   // k = 32 + 4 q + i -> tap 8 in lane group 0
+            }
+        p += mt * 1536;
+    }
+    float* b = reinterpret_cast<float*>(p);
+    rc_chain_pack_bias(b0, c, b);
+    for (int l = 0; l < n_mid; ++l) rc_chain_pack_bias(bmid[l], c, b + (1 + l) * mt * 16);
+    if (whead) rc_chain_pack_bias(bhead, c, b + (1 + n_mid) * mt * 16);
+    return RC_OK;
+}
+
+extern "C" int rc_lsc_chain(const void* d_x, int cin0, const void* d_blob, int c, int n_mid, float slope, const void* d_raw, int raw_c,
+                            void* d_out, int batch, int H, int W, void* stream) {
+    RC_REQUIRE(d_x && d_blob && d_out, "rc_lsc_chain: null pointer");
+    RC_REQUIRE((c == 48 || c == 128) && n_mid >= 1 && n_mid <= 4 && cin0 >= 1 && cin0 <= 4, "rc_lsc_chain: width 48 or 128, 1..4 mid layers, cin0 <= 4");
+    RC_REQUIRE(!d_raw || (raw_c >= 1 && raw_c <= 4), "rc_lsc_chain: the head's input has 1..4 channels");
+    RC_REQUIRE(batch >= 1 && H >= 1 && W >= 1 && (long long)batch * H * W * 8 < (1LL << 31), "rc_lsc_chain: bad shape (inputs must stay below 2 GiB)");
+    RC_REQUIRE(slope >= 0.f && slope <= 1.f, "rc_lsc_chain: slope must be in [0, 1]");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_out) % 16 == 0 && reinterpret_cast<uintptr_t>(d_blob) % 16 == 0, "rc_lsc_chain: misaligned pointer");
+    LscArgs a{};
+    a.x = static_cast<const bf16_t*>(d_x); a.cin0 = cin0; a.blob = static_cast<const char*>(d_blob); a.n_mid = n_mid; a.slope = slope;
+    a.raw = static_cast<const bf16_t*>(d_raw); a.raw_c = raw_c; a.out = static_cast<bf16_t*>(d_out);
+    a.pixels = (long long)batch * H * W; a.H = H; a.W = W;
+    const size_t lds = rc_lsc_packed_bytes(c, n_mid, d_raw != nullptr);
+    RC_REQUIRE(lds <= 150 * 1024, "rc_lsc_chain: weights do not fit LDS");
+    const long long tiles = (a.pixels + 63) / 64;
+    const int wpb = (c > 64 ? 512 : 256) / 64;
+    long long grid = (tiles + wpb - 1) / wpb;
+    const long long cap = (long long)device_cu_count() * (c > 64 ? 1 : 3);      // resident blocks per CU (LDS for the wide form, VGPRs for the 48-wide)
+    if (grid > cap) grid = cap;
+#define RC_LSC(CC, HH)                                                                                                                    \
+    do {                                                                                                                                  \
+        static PerDeviceFlag attr;                                                                                                        \
+        if (!attr.test_and_set())                                                                                                         \
+            RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lsc_chain_kernel<CC, HH>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+        hipLaunchKernelGGL((lsc_chain_kernel<CC, HH>), dim3((unsigned)grid), dim3(lsc_threads<CC>()), lds, as_stream(stream), a);              \
+    } while (0)
+    if (c == 48) { if (d_raw) RC_LSC(48, true); else RC_LSC(48, false); }
+    else { if (d_raw) RC_LSC(128, true); else RC_LSC(128, false); }
+#undef RC_LSC
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}

@@ -7,7 +7,9 @@ namespace rc {
 
 constexpr int kPwThreads = 256;
 
-static inline int grid_for(size_t n_items, int cap = 256 * 16) {
+// One-shot grids: this part streams fastest when every thread handles one 16-byte item and the hardware scheduler orders the blocks
+// (tools/hbm_probe.py: copy 5.9 TB/s one-shot vs 4.8-5.0 TB/s from a 4096-block grid-stride loop); the loops remain for sizes past the cap.
+static inline int grid_for(size_t n_items, int cap = 1 << 22) {
     size_t g = (n_items + kPwThreads - 1) / kPwThreads;
     if (g < 1) g = 1;
     if (g > (size_t)cap) g = cap;

@@ -521,6 +521,41 @@ def pointwise_chain(x: torch.Tensor, convs, slope: float) -> torch.Tensor:
     return _R.pointwise_chain48(x, p0.wpacked, p0.bias, [p.wpacked for p in packs], [p.bias for p in packs], float(slope))
 
 
+def lsc_chain(lsc, coord: torch.Tensor, head=None, raw: Optional[torch.Tensor] = None):
+    """Lens_Shading_Correction as ONE launch with register-resident activations (realcam::lsc_chain), bf16, width 48 or 128:
+    head is None -> lsc(coord);  else -> head(raw) * (lsc(coord) + 1)  (upstream models/LiteISP.py:2012-2014).  Returns None when the
+    modules are not of that shape (the caller runs the layer-by-layer launches)."""
+    import torch.nn as nn
+    mods = list(lsc.model)
+    convs, acts = mods[0::2], mods[1::2]
+    if not (FUSE_CHAIN and coord.dtype == torch.bfloat16 and len(mods) == 2 * len(convs) - 1 and 2 <= len(convs) <= 5 and
+            all(isinstance(m, nn.LeakyReLU) for m in acts) and all(hasattr(m, "weight") and tuple(m.weight.shape[2:]) == (1, 1) for m in convs)):
+        return None
+    slopes = {float(m.negative_slope) for m in acts}
+    c = convs[0].weight.shape[0]
+    if not (len(slopes) == 1 and 0.0 <= min(slopes) <= 1.0 and c in (48, 128) and convs[0].weight.shape[1] == coord.shape[-1] <= 4 and
+            all(tuple(m.weight.shape[:2]) == (c, c) for m in convs[1:])):
+        return None
+    if head is not None:
+        hw = head.weight
+        if not (raw is not None and raw.dtype == torch.bfloat16 and tuple(hw.shape[2:]) == (3, 3) and hw.shape[0] == c and hw.shape[1] == raw.shape[-1] <= 4 and
+                tuple(head.stride) == (1, 1) and tuple(head.padding) == (1, 1) and raw.shape[:3] == coord.shape[:3]):
+            return None
+        raw = _req(raw, "raw")
+    coord = _req(coord, "coord")
+    params = [p for m in convs for p in (m.weight, m.bias)] + ([head.weight, head.bias] if head is not None else [])
+    cache = _cache(lsc)
+    k = ("lsc", id(head))
+    key = _key(*params)
+    hit = cache.get(k)
+    if hit is None or hit[0] != key:
+        det = lambda t: None if t is None else t.detach()
+        blob = _R.lsc_pack(det(convs[0].weight), det(convs[0].bias), [det(m.weight) for m in convs[1:]], [det(m.bias) for m in convs[1:]],
+                           det(head.weight) if head is not None else None, det(head.bias) if head is not None else None)
+        hit = cache[k] = (key, blob)
+    return _R.lsc_chain(coord, hit[1], int(c), len(convs) - 1, slopes.pop(), raw if head is not None else None)
+
+
 def ca_gate(sums: torch.Tensor, hw: int, ca) -> torch.Tensor:
     """CALayer gate (B,C) from the conv's channel partial sums.  models/networks.py:259-269."""
     c0, c1 = ca.conv_du[0], ca.conv_du[2]

@@ -629,13 +629,53 @@ def nchw_view(a):
     return a.permute(0, 3, 1, 2)
 
 
+BRANCH_STREAMS = True        # run the independent mean / scale branches of the hyper-prior and the slice loop on two HIP streams
+_SIDE_STREAMS = {}
+
+
+def _fork_join(side_fn, main_fn, inputs):
+    """(side_fn(), main_fn()) for two independent sub-graphs.  At the latent's size (1/16 of the packed frame) one launch covers about
+    half of the 256 CUs, so the two branches are enqueued on two streams and overlap: side_fn on a per-device side stream ordered behind the
+    current stream, main_fn on the current stream, which then waits for the side stream.  `inputs`: tensors side_fn reads (the caching
+    allocator is told about the second stream; the side branch's outputs likewise).  One stream under graph capture, fake tensors or
+    BRANCH_STREAMS = False."""
+    from torch._subclasses.fake_tensor import FakeTensor
+    probe = inputs[0]
+    if not BRANCH_STREAMS or not probe.is_cuda or isinstance(probe, FakeTensor) or torch.cuda.is_current_stream_capturing():
+        return side_fn(), main_fn()
+    main = torch.cuda.current_stream(probe.device)
+    side = _SIDE_STREAMS.get(probe.device.index)
+    if side is None:
+        side = _SIDE_STREAMS[probe.device.index] = torch.cuda.Stream(device=probe.device)
+    side.wait_stream(main)
+    for t in inputs:
+        t.record_stream(side)
+    with torch.cuda.stream(side):
+        a = side_fn()
+    b = main_fn()
+    main.wait_stream(side)
+    for t in (a if isinstance(a, (tuple, list)) else (a,)):
+        t.record_stream(main)
+    return a, b
+
+
+def _hyper_synthesis(m, z_hat):
+    """(latent_scales, latent_means) = (h_scale_s(z_hat), h_mean_s(z_hat)): two independent transforms (models/tcm.py:449-450)."""
+    return _fork_join(lambda: m.h_scale_s._nhwc(z_hat), lambda: m.h_mean_s._nhwc(z_hat), [z_hat])
+
+
 def _slice_params(m, i, latent_means, latent_scales, y_hat_slices):
     """mean / scale of slice i from the hyper-prior maps and the already decoded slices (models/tcm.py:455-468)."""
     support = y_hat_slices if m.max_support_slices < 0 else y_hat_slices[:m.max_support_slices]
-    mean_support = m.atten_mean[i][0]._nhwc(ops.channel_concat([latent_means] + support))
-    mu = m.cc_mean_transforms[i]._nhwc(mean_support)
-    scale_support = m.atten_scale[i][0]._nhwc(ops.channel_concat([latent_scales] + support))
-    scale = m.cc_scale_transforms[i]._nhwc(scale_support)
+
+    def mean_branch():
+        mean_support = m.atten_mean[i][0]._nhwc(ops.channel_concat([latent_means] + support))
+        return mean_support, m.cc_mean_transforms[i]._nhwc(mean_support)
+
+    def scale_branch():
+        return m.cc_scale_transforms[i]._nhwc(m.atten_scale[i][0]._nhwc(ops.channel_concat([latent_scales] + support)))
+
+    scale, (mean_support, mu) = _fork_join(scale_branch, mean_branch, [latent_scales] + support)
     return mean_support, mu, scale
 
 
@@ -652,7 +692,7 @@ def _codec_compress(m, y, fmt):
     gc = m.gaussian_conditional
     z = m.h_a._nhwc(y)
     z_strings, z_hat = m.entropy_bottleneck._compress_nhwc(z, fmt)
-    latent_scales, latent_means = m.h_scale_s._nhwc(z_hat), m.h_mean_s._nhwc(z_hat)
+    latent_scales, latent_means = _hyper_synthesis(m, z_hat)
     if latent_means.shape[1:3] != y.shape[1:3]:
         raise NotImplementedError("latent size must be a multiple of 4; upstream crops here")
     b = y.shape[0]
@@ -681,7 +721,7 @@ def _codec_decompress(m, strings, shape, dtype, fmt):
     gc = m.gaussian_conditional
     y_strings, z_strings = strings
     z_hat = m.entropy_bottleneck._decompress_nhwc(z_strings, tuple(shape), dtype, fmt)
-    latent_scales, latent_means = m.h_scale_s._nhwc(z_hat), m.h_mean_s._nhwc(z_hat)
+    latent_scales, latent_means = _hyper_synthesis(m, z_hat)
     b, dev = z_hat.shape[0], z_hat.device
     tables, table = _coder_tables(gc), gc._table(dev)
     decoders = [bitstream.Decoder(s, tables, dev, fmt) for s in y_strings]
@@ -700,22 +740,16 @@ def _slice_loop(m, y):
     `raw_compression_tcm_final.forward` (models/raw2bit.py:1791-1846).  y NHWC; returns the NCHW result dict."""
     z = m.h_a._nhwc(y)
     z_hat, z_lik = m.entropy_bottleneck._nhwc(z)
-    latent_scales = m.h_scale_s._nhwc(z_hat)
-    latent_means = m.h_mean_s._nhwc(z_hat)
+    latent_scales, latent_means = _hyper_synthesis(m, z_hat)
     if latent_means.shape[1:3] != y.shape[1:3]:
         raise NotImplementedError("latent size must be a multiple of 4; upstream crops here")
     per = y.shape[-1] // m.num_slices
     y_hat_slices, y_lik, mu_list, scale_list = [], [], [], []
     for i in range(m.num_slices):
         y_slice = ops.channel_slice(y, i * per, per)
-        support = y_hat_slices if m.max_support_slices < 0 else y_hat_slices[:m.max_support_slices]
-        mean_support = m.atten_mean[i][0]._nhwc(ops.channel_concat([latent_means] + support))
-        mu = m.cc_mean_transforms[i]._nhwc(mean_support)
-        scale_support = m.atten_scale[i][0]._nhwc(ops.channel_concat([latent_scales] + support))
-        scale = m.cc_scale_transforms[i]._nhwc(scale_support)
+        mean_support, mu, scale = _slice_params(m, i, latent_means, latent_scales, y_hat_slices)
         y_hat_slice, lik = m.gaussian_conditional._nhwc(y_slice, scale, mu)
-        lrp = m.lrp_transforms[i]._nhwc(ops.channel_concat([mean_support, y_hat_slice]))
-        y_hat_slices.append(ops.tanh_half_add(y_hat_slice, lrp))
+        y_hat_slices.append(_refine(m, i, mean_support, y_hat_slice))
         y_lik.append(lik); mu_list.append(mu); scale_list.append(scale)
     x_hat = m.g_s._nhwc(ops.channel_concat(y_hat_slices))
     nchw = nchw_view

@@ -237,6 +237,47 @@ define("pointwise_chain48(Tensor x, Tensor w0, Tensor? b0, Tensor[] wmid, Tensor
        lambda x, w0, b0, wmid, bmid, slope: x.new_empty((*x.shape[:-1], 48)), _chain_launch)
 
 
+def _lsc_pack_alloc(w0, b0, wmid, bmid, whead, bhead):
+    n = lib().rc_lsc_packed_bytes(w0.shape[0], len(wmid), 1 if whead is not None else 0) if not _is_fake(w0) else \
+        _lsc_bytes(w0.shape[0], len(wmid), whead is not None)
+    if n == 0:
+        raise ValueError("lsc_pack: width must be 48 or 128 with at least one layer after the first")
+    return w0.new_empty((n,), dtype=torch.uint8)
+
+
+def _lsc_bytes(c, n_mid, head):
+    mt, tb = c // 16, (c // 32) * 1024 + (512 if c % 32 else 0)
+    return mt * 512 + n_mid * mt * tb + (mt * 1536 if head else 0) + (1 + n_mid + (1 if head else 0)) * mt * 64
+
+
+def _is_fake(t):
+    from torch._subclasses.fake_tensor import FakeTensor
+    return isinstance(t, FakeTensor)
+
+
+def _lsc_pack_launch(out, w0, b0, wmid, bmid, whead, bhead):
+    host = lambda t: None if t is None else np.ascontiguousarray(t.detach().float().cpu().numpy())
+    c, cin0, n = w0.shape[0], w0.shape[1], len(wmid)
+    h_w0, h_b0, h_wh, h_bh = host(w0.reshape(c, cin0)), host(b0), host(whead), host(bhead)
+    h_wm, h_bm = [host(w.reshape(c, c)) for w in wmid], [host(b) for b in bmid]
+    ptr = lambda a: None if a is None else a.ctypes.data
+    wp = (C.c_void_p * n)(*[ptr(a) for a in h_wm])
+    bp = (C.c_void_p * n)(*[ptr(a) for a in h_bm])
+    dst = np.zeros(out.numel(), dtype=np.uint8)
+    check(lib().rc_lsc_pack(ptr(h_w0), ptr(h_b0), cin0, wp, bp, n, ptr(h_wh), ptr(h_bh), whead.shape[1] if whead is not None else 0, c,
+                            dst.ctypes.data), "rc_lsc_pack")
+    out.copy_(torch.from_numpy(dst))
+
+
+define("lsc_pack(Tensor w0, Tensor? b0, Tensor[] wmid, Tensor?[] bmid, Tensor? whead, Tensor? bhead) -> Tensor", _lsc_pack_alloc, _lsc_pack_launch)
+
+define("lsc_chain(Tensor x, Tensor blob, int c, int n_mid, float slope, Tensor? raw) -> Tensor",
+       lambda x, blob, c, n_mid, slope, raw: x.new_empty((*x.shape[:-1], c)),
+       lambda out, x, blob, c, n_mid, slope, raw: check(lib().rc_lsc_chain(x.data_ptr(), x.shape[-1], blob.data_ptr(), c, n_mid, float(slope), _p(raw),
+                                                                           raw.shape[-1] if raw is not None else 0, out.data_ptr(), x.shape[0],
+                                                                           x.shape[1], x.shape[2], _stream()), "rc_lsc_chain"))
+
+
 # ---- a8: channel attention ------------------------------------------------------------------------------------------------
 define("ca_gate(Tensor(a!) sums, int hw, Tensor w0, Tensor b0, Tensor w1, Tensor b1) -> Tensor",
        lambda sums, hw, w0, b0, w1, b1: sums.new_empty((sums.shape[0], sums.shape[2])),

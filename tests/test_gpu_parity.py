@@ -545,6 +545,40 @@ def test_lens_shading_chain_equals_layer_by_layer(hip, shape):
     assert rel_err(outs[True], ref) < 3e-2 and rel_err(outs[False], ref) < 3e-2
 
 
+@pytest.mark.parametrize("width", [48, 128])
+@pytest.mark.parametrize("shape", [(1, 5, 7), (2, 37, 70), (3, 64, 96), (1, 16, 200)])
+def test_lsc_chain_in_registers_vs_layer_by_layer(hip, shape, width):
+    """rc_lsc_chain: the lens-shading chain with register-resident activations, alone and with the convolution it modulates folded in
+    (head(raw) * (lsc(coord) + 1) in one launch), against the layer-by-layer launches (same bf16 rounding points, different MFMA k-order:
+    bf16-ulp scale differences) and the fp32 CPU composition.  Borders, 64-pixel groups that straddle rows and images, batch > 1."""
+    b, H, W = shape
+    g = torch.Generator().manual_seed(H * 31 + W)
+    torch.manual_seed(3)
+    lsc = M.LiteISP.Lens_Shading_Correction(in_channels=2, out_c=width, nf=width)
+    head = N.Conv2d(4, width, 3, 1, 1)
+    raw, coord = torch.rand(b, 4, H, W, generator=g), torch.rand(b, 2, H, W, generator=g) * 2 - 1
+    with torch.no_grad():
+        t = coord
+        for m in lsc.model:
+            t = F.conv2d(t, m.weight, m.bias) if isinstance(m, torch.nn.Conv2d) else F.leaky_relu(t, m.negative_slope)
+        ref = F.conv2d(raw, head.weight, head.bias, padding=1) * (t + 1)
+    lsc, head = lsc.to(DEV, torch.bfloat16).eval(), head.to(DEV, torch.bfloat16).eval()
+    a, c = ops.to_nhwc(raw.to(DEV, torch.bfloat16)), ops.to_nhwc(coord.to(DEV, torch.bfloat16))
+    with torch.no_grad():
+        chain = ops.lsc_chain(lsc, c)
+        fused = ops.lsc_chain(lsc, c, head, a)
+        old, ops.FUSE_CHAIN = ops.FUSE_CHAIN, False
+        try:
+            layered = lsc._nhwc(c)
+            two = head._nhwc(a, mul_plus1=layered)
+        finally:
+            ops.FUSE_CHAIN = old
+    assert chain is not None and fused is not None and chain.shape == fused.shape == two.shape == (b, H, W, width)
+    f = lambda v: ops.to_nchw(v).float().cpu()
+    assert rel_err(f(chain), f(layered)) < 2e-2 and rel_err(f(chain), t) < 3e-2
+    assert rel_err(f(fused), f(two)) < 2e-2 and rel_err(f(fused), ref) < 3e-2
+
+
 def test_bench_prints_one_contract_json_line(hip):
     """bench.py on a tiny workload: exactly one JSON line on stdout with the driver's contract keys, the roofline object
     and (with the CPU leg on) the cpu_baseline object."""
