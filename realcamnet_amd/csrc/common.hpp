@@ -71,6 +71,8 @@ template <> struct Vec16<bf16_t> {
     // __builtin_convertvector form keeps the callers' unrolled value arrays from being promoted to registers (scratch).
     // HAZARD: inline asm is opaque to the compiler's hazard recogniser -- never pass an MFMA accumulator straight in (no wait states
     // are inserted for the MFMA result latency); route it through a real VALU op first (the epilogues' bias add / activation do).
+    // The same holds for a transcendental result (v_exp_f32, v_rcp_f32, v_rsq_f32 ...: one wait state before a VALU read, which the
+    // compiler inserts for its own instructions only) -- see wm_pk in wmsa.hip.
     __device__ static __forceinline__ uint32_t rne2(float lo, float hi) {
         uint32_t r;
         asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));

@@ -93,6 +93,161 @@ __global__ __launch_bounds__(kWmsaWaves * 64) void wmsa_kernel(const T* __restri
     for (int c = 0; c < HD; ++c) o[c] = from_f32<T>(acc[c] * inv);
 }
 
+// ---- bf16, 8 x 8 windows: the same attention on the matrix cores --------------------------------------------------------------------
+// One wave = one (window, head): 64 queries x 64 keys.
+//   S^T = K Q^T   : 16 v_mfma_f32_16x16x32_bf16 (A = K rows, B = Q rows; the head_dim <= 32 channels are ONE K-step, zero-padded),
+//   softmax over keys: a lane (n, g) holds 16 of query n's 64 scores per query tile (D layout: rows 4g + j of 4 key tiles); max / sum
+//                   finish with two xor-shuffles across the 4 lanes of a query,
+//   O^T = V^T P^T : the P fragments come straight out of the S accumulators -- the key tiles are loaded in the pair-packed row order
+//                   (tile pair (2s, 2s+1), row 4g + j  <->  key 32s + 8g + 4 (tile & 1) + j), so after fp32 -> bf16 packing lane (n, g)
+//                   already holds keys 32s + 8g + 0..7 of query n = the B operand of K-step s; V^T (A operand) is transposed through a
+//                   wave-private LDS slab.
+// Relative-position bias: a per-head table expanded once per block to [query][key in fragment order] (x log2 e, rows padded to 68
+// floats: conflict-free ds_read_b128), so the softmax runs on v_exp_f32 directly.  The wrap mask of shifted windows is tile-uniform in
+// the row direction and one compare per lane in the column direction, and only the last window row / column takes that path.
+// The one-lane-per-query kernel above spent 1.47 ms per call on the codec's 576 x 960 x 4 map with 8 heads of 8 channels
+// (VALU FMAs + scalar 2-byte loads); this form is bound by the softmax's VALU work (~5 instructions per score).
+constexpr int kWmWaves = 4, kWmBiasRow = 68;
+// fp32 pair -> packed bf16 through the compiler-visible conversion, NOT Vec16::rne2: that one is inline asm, invisible to the hazard
+// recogniser, and both packs of this kernel read registers with pending-result hazards -- the probabilities come straight from v_exp_f32
+// (a transcendental result needs a wait state before a VALU read: the first build packed stale values for a few queries of the first tile
+// when head_dim = 8, and only for that schedule) and the outputs come from MFMA accumulators.
+typedef float wm_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wm_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t wm_pk(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(wm_f32x2{lo, hi}, wm_bf16x2));
+}
+__device__ __forceinline__ void wm_mma(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int HD>
+__global__ __launch_bounds__(kWmWaves * 64, 2) void wmsa_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ relpos,
+                                                                        bf16_t* __restrict__ out, int batch, int H, int W, int C, int shift,
+                                                                        int windows_per_block) {
+    constexpr int WS = 8, RP = 15, DT = (HD + 15) / 16;                 // DT: 16-row tiles of O^T
+    constexpr int VROW = 64 + 8;                                        // V^T slab row (bf16 elements): 144 B, 16-byte aligned, spreads banks
+    extern __shared__ __attribute__((aligned(16))) char wm_lds[];
+    float* s_bias = reinterpret_cast<float*>(wm_lds);                   // [64 queries][kWmBiasRow]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bf16_t* s_vt = reinterpret_cast<bf16_t*>(wm_lds + 64 * kWmBiasRow * 4) + wave * (DT * 16 * VROW);
+    const int n = lane & 15, g = lane >> 4;
+    const int nh = C / HD, hw = H / WS, ww = W / WS;
+    const int h = blockIdx.x % nh;
+    const long long n_win = (long long)batch * hw * ww;
+    const long long w_begin = (long long)(blockIdx.x / nh) * windows_per_block;
+    const long long w_end = (w_begin + windows_per_block) < n_win ? (w_begin + windows_per_block) : n_win;
+    const float kLog2e = 1.4426950408889634f;
+    // expanded bias: entry [tq][16 mt + 4 gg + j] = relpos[h][p1 - j1 + 7][p2 - j2 + 7] * log2(e), key = 32 (mt >> 1) + 8 gg + 4 (mt & 1) + j
+    for (int i = threadIdx.x; i < 64 * 64; i += kWmWaves * 64) {
+        const int tq = i >> 6, e = i & 63, mt = e >> 4, gg = (e >> 2) & 3, j = e & 3;
+        const int key = 32 * (mt >> 1) + 8 * gg + 4 * (mt & 1) + j;
+        const int p1 = tq >> 3, p2 = tq & 7, j1 = key >> 3, j2 = key & 7;
+        s_bias[tq * kWmBiasRow + e] = relpos[(size_t)h * RP * RP + (p1 - j1 + WS - 1) * RP + (p2 - j2 + WS - 1)] * kLog2e;
+    }
+    // zero the padding rows of the V^T slab once (rows HD .. 16 DT - 1 stay zero; rows < HD are rewritten per window)
+    for (int i = lane; i < DT * 16 * VROW; i += 64) s_vt[i] = from_f32<bf16_t>(0.f);
+    __syncthreads();
+    const float scale = rsqrtf((float)HD) * kLog2e;
+    const size_t rec = (size_t)3 * C;                                   // elements per pixel record
+    // this lane's token roles: A operand of key tile mt: key(mt, R = n); B operand of query tile nt: query 16 nt + n; V staging: token = lane
+    for (long long win = w_begin + wave; win < w_end; win += kWmWaves) {
+        const int b = (int)(win / (hw * ww)), w1 = (int)((win / ww) % hw), w2 = (int)(win % ww);
+        auto pixel = [&](int t) -> size_t {                            // window token t -> element offset of its pixel record
+            int y = w1 * WS + (t >> 3) + shift, x = w2 * WS + (t & 7) + shift;
+            if (y >= H) y -= H;
+            if (x >= W) x -= W;
+            return (((size_t)b * H + y) * W + x);
+        };
+        const bool chan = 8 * g < HD;                                   // this lane group carries channels 8 g .. 8 g + 7 of the head
+        uint4 qf[4], kf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int key = 32 * (t >> 1) + 8 * (n >> 2) + 4 * (t & 1) + (n & 3);
+            const bf16_t* kp = qkv + pixel(key) * rec + C + h * HD + 8 * g;
+            const bf16_t* qp = qkv + pixel(16 * t + n) * rec + h * HD + 8 * g;
+            kf[t] = chan ? *reinterpret_cast<const uint4*>(kp) : make_uint4(0u, 0u, 0u, 0u);
+            qf[t] = chan ? *reinterpret_cast<const uint4*>(qp) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        {   // V^T slab: lane = token, rows = channels
+            const bf16_t* vp = qkv + pixel(lane) * rec + 2 * C + h * HD;
+#pragma unroll
+            for (int c8 = 0; c8 < HD / 8; ++c8) {
+                const uint4 v = *reinterpret_cast<const uint4*>(vp + 8 * c8);
+                const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    reinterpret_cast<unsigned short*>(s_vt)[(8 * c8 + e) * VROW + lane] = (unsigned short)(wv[e >> 1] >> (16 * (e & 1)));
+            }
+        }
+        // ---- scores: S^T[key][query], scaled + biased in the log2 domain
+        const bool last_r = shift > 0 && w1 == hw - 1, last_c = shift > 0 && w2 == ww - 1;
+        const bool q_side_c = (n & 7) >= WS - shift;                    // query column side (queries 16 nt + n: p2 = n & 7)
+        uint4 pf[4][2];                                                 // P^T fragments: [query tile][K-step]
+        float inv_den[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 sc[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) { sc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; wm_mma(kf[mt], qf[nt], sc[mt]); }
+            const float* brow = s_bias + (16 * nt + n) * kWmBiasRow + 4 * g;
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float4 bb = *reinterpret_cast<const float4*>(brow + 16 * mt);
+                f32x4 v = sc[mt] * scale + f32x4{bb.x, bb.y, bb.z, bb.w};
+                if (last_r | last_c) {                                  // wave-uniform
+                    // rows: key j1 = 4 (mt >> 1) + g >= 4  <=>  mt >= 2;  query p1 = 2 nt + (n >> 3) >= 4  <=>  nt >= 2   (shift = 4)
+                    const bool mr = last_r && ((mt >> 1) != (nt >> 1));
+                    // columns: key j2 = 4 (mt & 1) + j >= 4  <=>  mt odd
+                    const bool mc = last_c && (((mt & 1) != 0) != q_side_c);
+                    if (mr || mc) v = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+                }
+                sc[mt] = v;
+                mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float den = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                f32x4 e;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(sc[mt][j] - mx);
+                den += (e[0] + e[1]) + (e[2] + e[3]);
+                sc[mt] = e;
+            }
+            den += __shfl_xor(den, 16);
+            den += __shfl_xor(den, 32);
+            inv_den[nt] = 1.f / den;
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+                pf[nt][st] = make_uint4(wm_pk(sc[2 * st][0], sc[2 * st][1]), wm_pk(sc[2 * st][2], sc[2 * st][3]),
+                                        wm_pk(sc[2 * st + 1][0], sc[2 * st + 1][1]), wm_pk(sc[2 * st + 1][2], sc[2 * st + 1][3]));
+        }
+        __builtin_amdgcn_wave_barrier();                                // the slab writes above are complete (one wave's LDS ops are in order)
+        // ---- O^T[d][query] = sum_key V^T[d][key] P^T[key][query]
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            uint4 vf[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) vf[st] = *reinterpret_cast<const uint4*>(s_vt + (16 * dt + n) * VROW + 32 * st + 8 * g);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+                wm_mma(vf[0], pf[nt][0], o);
+                wm_mma(vf[1], pf[nt][1], o);
+                o = o * inv_den[nt];
+                if (16 * dt + 4 * g < HD) {                              // rows 4 g .. 4 g + 3 of this tile are real channels
+                    bf16_t* op = out + pixel(16 * nt + n) * C + h * HD + 16 * dt + 4 * g;
+                    *reinterpret_cast<uint2*>(op) = make_uint2(wm_pk(o[0], o[1]), wm_pk(o[2], o[3]));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                // slab reads done before the next window overwrites it
+    }
+}
+
 }  // namespace rc
 
 using namespace rc;
@@ -108,6 +263,25 @@ int rc_window_attention(const void* d_qkv, const float* d_relpos, void* d_out, i
     RC_REQUIRE(batch >= 1 && H >= window && W >= window && H % window == 0 && W % window == 0, "rc_window_attention: H, W must be multiples of the window size");
     RC_REQUIRE(C >= head_dim && C % head_dim == 0, "rc_window_attention: C must be a multiple of head_dim");
     RC_REQUIRE(shift == 0 || shift == window / 2, "rc_window_attention: shift must be 0 (W-MSA) or window/2 (SW-MSA)");
+    if (dtype == RC_BF16 && window == 8) {                             // matrix-core form
+        const int nh = C / head_dim;
+        const long long n_win = (long long)batch * (H / 8) * (W / 8);
+        const int dtiles = (head_dim + 15) / 16;
+        const size_t lds = (size_t)64 * kWmBiasRow * 4 + (size_t)kWmWaves * dtiles * 16 * (64 + 8) * 2;
+        // enough blocks for ~4 waves of blocks over the chip, each amortising its bias-table expansion over >= 16 windows
+        long long per_block = (n_win * nh + (long long)device_cu_count() * 16 - 1) / ((long long)device_cu_count() * 16);
+        if (per_block < 16) per_block = 16;
+        if (per_block > n_win) per_block = n_win;
+        const long long chunks = (n_win + per_block - 1) / per_block;
+        RC_REQUIRE(chunks * nh < (1LL << 31), "rc_window_attention: too many windows");
+#define RC_WMM(HD)                                                                                                                          \
+        hipLaunchKernelGGL((wmsa_mfma_kernel<HD>), dim3((unsigned)(chunks * nh)), dim3(kWmWaves * 64), lds, as_stream(stream),              \
+                           static_cast<const bf16_t*>(d_qkv), d_relpos, static_cast<bf16_t*>(d_out), batch, H, W, C, shift, (int)per_block)
+        if (head_dim == 8) RC_WMM(8); else if (head_dim == 16) RC_WMM(16); else RC_WMM(32);
+#undef RC_WMM
+        RC_HIP_CHECK(hipGetLastError());
+        return RC_OK;
+    }
     const int nh = C / head_dim, wpw = 64 / (window * window);
     const long long jobs = (((long long)batch * (H / window) * (W / window) + wpw - 1) / wpw) * nh;
     const long long blocks = (jobs + kWmsaWaves - 1) / kWmsaWaves;

@@ -659,3 +659,25 @@ def test_hip_gma_codec_blocks_at_upstream_smoke_shapes():
         with torch.no_grad():
             got = m.to(torch.bfloat16)(x.cuda().bfloat16())
         assert LO.psnr(got.float().cpu(), want) >= 45.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", ["W", "SW"])
+@pytest.mark.parametrize("head_dim", [8, 16, 32])
+def test_hip_window_attention_mfma_form_vs_oracle(head_dim, typ):
+    """The bf16 8x8-window kernel on the matrix cores (csrc/wmsa.hip wmsa_mfma_kernel) for every head size the codecs use, W and SW, on a map
+    with several window rows / columns and batch 2: against the oracle's WMSA (models/tcm.py:179-206) and against the fp32 one-lane-per-query
+    kernel on the same bf16-rounded inputs."""
+    import realcamnet_amd.tcm as T
+    torch.manual_seed(5)
+    c, ws = 64, 8
+    m = T.WMSA(c, c, head_dim, ws, typ).eval()
+    with torch.no_grad():
+        m.relative_position_params.mul_(20.0)                           # default init (std 0.02) would leave the bias term untested
+        sd = {"m." + k: v.clone() for k, v in m.state_dict().items()}
+        x = torch.randn(2, 24, 40, c)
+        want = TO.wmsa(sd, "m", x, head_dim, ws, typ)
+        got32 = m.to("cuda")(x.cuda()).cpu()                            # fp32 first: .to(bfloat16) rounds the parameters in place
+        got16 = m.to(torch.bfloat16)(x.cuda().bfloat16()).float().cpu()
+    assert rel_err(got32, want) < 2e-5
+    assert rel_err(got16, want) < 3e-2 and LO.psnr(got16, want) > 40.0
