@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 5
+#define RC_ABI_VERSION 6
 
 typedef enum rc_status {
     RC_OK = 0,
@@ -368,7 +368,17 @@ int rc_gma_tail(const void* d_qkvp, const void* d_convv, const void* d_loc, cons
  * (BatchNorm(eval) folded); ln (16).  Same values as rc_dwconv2d + rc_gma_pointwise up to the point-wise product's summation order. */
 int rc_gma_aggregate(const void* d_qkv, void* d_qkvp, void* d_loc, int batch, int H, int W, const float* d_dw3, const float* d_dw5,
                      const float* d_dw7, const float* d_dwl, const float* d_pw, const float* d_pwl, const float* d_bn_scale,
-                     const float* d_bn_shift, const float* d_ln_g, const float* d_ln_b, void* stream);
+                     const float* d_bn_shift, const float* d_ln_g, const float* d_ln_b, float* d_kmax, void* stream);
+
+/* d_kmax (optional, may be NULL): (batch, 64) fp32, on return the per-channel maximum over the image of the aggregated k (the stored bf16
+ * values) -- the shift of softmax_N(k) (models/groupmix.py:190) -- accumulated by the aggregator itself with integer atomics (a maximum is
+ * order-independent, so this stays bitwise reproducible).  With it the two-pass rc_gma_kv_planar is replaced by ONE pass on the matrix cores:
+ *   rc_gma_kv_mfma: ktv[b][h][i][j] = scale * sum_t softmax_t(k)[t][h,i] v[t][h,j] for 8 heads x 8 channels, segment-planar bf16 qkv'
+ * (d_scratch: rc_gma_kv_mfma_scratch_bytes bytes).  exp(k - max) is rounded to bf16 for the MFMA (numerator and denominator use the same
+ * rounded values); accumulation fp32, block partials merged in fixed order. */
+int rc_gma_kv_mfma_blocks(int n_tok);
+size_t rc_gma_kv_mfma_scratch_bytes(int batch, int n_tok);
+int rc_gma_kv_mfma(const void* d_qkvp, int batch, int n_tok, float scale, const float* d_kmax, float* d_scratch, float* d_ktv, void* stream);
 
 /* rc_gma_crpe: ConvRelPosEnc's depth-wise conv of v (groupmix.py:127-133,146-150) for dim 80 / 8 heads of 8, bf16: v = segments 8..11
  * of rc_gma_aggregate's segment-planar qkvp -> convv, segment-planar [4][B,H,W][16]; four 16-channel segments with windows 3, 5, 7, 7 (tap-major (K*K,16) fp32 each; segment 2 holds

@@ -17,7 +17,7 @@ HEADER = PKG.parent / "include" / "realcam_hip.h"
 RC_F32, RC_BF16, RC_U16 = 0, 1, 2
 RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY, RC_ACT_GELU, RC_ACT_RELU_POST = 0, 1, 2, 3, 4
 RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ConvDesc(C.Structure):
@@ -119,7 +119,10 @@ _SIGS = {
     "rc_chain_pack_bias": (C.c_int, [_P, _I, _P]),
     "rc_gma_ln_qkv": (C.c_int, [_P, _P, C.c_longlong, _P, _P, _P, _P, _F, _P]),
     "rc_gma_tail": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
-    "rc_gma_aggregate": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rc_gma_aggregate": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rc_gma_kv_mfma_blocks": (C.c_int, [_I]),
+    "rc_gma_kv_mfma_scratch_bytes": (C.c_size_t, [_I, _I]),
+    "rc_gma_kv_mfma": (C.c_int, [_P, _I, _I, _F, _P, _P, _P, _P]),
     "rc_gma_crpe": (C.c_int, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "rc_gma_kv_blocks": (C.c_int, [_I]),
     "rc_gma_kv_scratch_bytes": (_SZ, [_I, _I, _I, _I]),

@@ -496,6 +496,11 @@ __global__ void gma_apply_kernel(const T* __restrict__ qkvp, const T* __restrict
     }
 }
 
+// softmax-normalise + scale the block partials of the 8-head x 8-channel product (also used by csrc/gma_fused.hip's MFMA pass)
+void gma_kv_merge_launch(const float* part, float* ktv, int nblk, int batch, float scale, void* stream) {
+    hipLaunchKernelGGL(gma_kv_merge_kernel, dim3((8 * 8 * 8 + 63) / 64, batch), dim3(kGThreads), 0, as_stream(stream), part, ktv, nblk, 8, 8, scale);
+}
+
 static inline int pw_grid(size_t n) {
     size_t g = (n + kGThreads - 1) / kGThreads;
     if (g < 1) g = 1;

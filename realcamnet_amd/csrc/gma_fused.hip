@@ -574,8 +574,16 @@ constexpr int AG_RPAD = 8;                                                 // + 
                                                                            // then sit 4 dwords apart modulo 8 instead of on the same banks
 constexpr int AG_LDS = (AG_TH + 6) * ((AG_TW + 6) * AG_PS + AG_RPAD);
 
+// float max through the integer atomics (any finite / -inf start value): non-negative floats order like ints, negative ones like
+// reversed unsigneds.  A maximum does not depend on the order of its operands, so the result is deterministic.
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+    if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+
 struct AggArgs {
     const bf16_t* qkv; bf16_t* qkvp; bf16_t* loc;
+    float* kmax;                 // optional (B, 64): per-channel maximum of the aggregated k over the image (the softmax_N(k) shift of rc_gma_kv)
     int batch, H, W, tiles_x, tiles_y;
     size_t plane;                // elements per segment plane = batch * H * W * 16
     const float* dw[3];          // groups 1..3: tap-major [K*K][16], K = 3, 5, 7
@@ -647,7 +655,19 @@ __device__ __forceinline__ uint2 agg_afrag(const float* w, int ld, int col0, int
     return make_uint2(pk(p[0] + 0.f, p[1] + 0.f), pk(p[2] + 0.f, p[3] + 0.f));
 }
 
-struct AggGeom { int y0, x0, prow, pcol, q; size_t pix0; };
+struct AggGeom { int y0, x0, prow, pcol, q, b; size_t pix0; };
+
+// block-wide maximum of 16 channels (lane group q holds channels 4 q .. 4 q + 3) -> one atomic per channel
+__device__ __forceinline__ void agg_block_max(float* dst, f32x4 m, float* s_red, int tid, int lane) {
+#pragma unroll
+    for (int sh = 1; sh < 16; sh <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], __shfl_xor(m[e], sh));
+    __syncthreads();                                                       // s_red aliases the tap table: every wave is done with it
+    if ((lane & 15) == 0) *reinterpret_cast<float4*>(s_red + (tid >> 6) * 16 + 4 * (lane >> 4)) = make_float4(m[0], m[1], m[2], m[3]);
+    __syncthreads();
+    if (tid < 16) atomic_max_f32(dst + tid, fmaxf(fmaxf(s_red[tid], s_red[16 + tid]), fmaxf(s_red[32 + tid], s_red[48 + tid])));
+}
 
 // one conv group: stage -> depth-wise K x K -> point-wise (MFMA) -> BN + Hardswish -> qkvp[.., which, 16 g + ..]
 template <int K>
@@ -666,6 +686,7 @@ __device__ __forceinline__ void agg_conv_job(const AggArgs& a, char* s_x, float*
         for (int c = 0; c < 4; ++c) acc[o][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     agg_dw<K>(s_x, s_w, t.prow, t.pcol, t.q, acc);
     bf16_t* outp = a.qkvp + (size_t)(4 * which + g) * a.plane + 4 * t.q;   // segment-planar [12][tokens][16]
+    f32x4 vmax = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -675,9 +696,15 @@ __device__ __forceinline__ void agg_conv_job(const AggArgs& a, char* s_x, float*
             f32x4 v = d * sc + sh;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
-            if (t.y0 + t.prow + o < a.H && t.x0 + t.pcol + c < a.W)
-                *reinterpret_cast<uint2*>(outp + (t.pix0 + (size_t)o * a.W + c) * kSEG) = pack_tail(v);
+            if (t.y0 + t.prow + o < a.H && t.x0 + t.pcol + c < a.W) {
+                const uint2 pkd = pack_tail(v);
+                *reinterpret_cast<uint2*>(outp + (t.pix0 + (size_t)o * a.W + c) * kSEG) = pkd;
+                const f32x4 r = up_tail(pkd);                                  // the stored (bf16) values are what rc_gma_kv sees
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vmax[e] = fmaxf(vmax[e], r[e]);
+            }
         }
+    if (which == 1 && a.kmax != nullptr) agg_block_max(a.kmax + (size_t)t.b * 64 + 16 * g, vmax, s_w, tid, lane);
 }
 
 // Blocks = tiles x 10 jobs: (which, group 3 / 2 / 1) x 3, the group-1 job also doing the pass-through group 0, and the local branch.
@@ -699,7 +726,7 @@ __global__ __launch_bounds__(AG_THREADS) void gma_agg_kernel(AggArgs a) {
     AggGeom t;
     t.y0 = ty * AG_TH; t.x0 = tx * AG_TW; t.q = lane >> 4;
     t.prow = 4 * wave + 2 * (n >> 3); t.pcol = 4 * (n & 7);               // this lane's patch: 2 rows x 4 columns of the tile
-    t.pix0 = ((size_t)b * a.H + t.y0 + t.prow) * a.W + t.x0 + t.pcol;
+    t.pix0 = ((size_t)b * a.H + t.y0 + t.prow) * a.W + t.x0 + t.pcol; t.b = b;
     const bf16_t* img = a.qkv + (size_t)b * a.H * a.W * kSEG;             // + segment * plane
     const int q = t.q;
 
@@ -711,6 +738,7 @@ __global__ __launch_bounds__(AG_THREADS) void gma_agg_kernel(AggArgs a) {
             agg_conv_job<3>(a, s_x, s_w, img, t, which, g, tid, lane);
             // pass-through group 0: BatchNorm + Hardswish of the segment itself
             const f32x4 sc = ld4(a.bn_scale + 4 * q), sh = ld4(a.bn_shift + 4 * q);
+            f32x4 vmax = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
 #pragma unroll
             for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -720,8 +748,13 @@ __global__ __launch_bounds__(AG_THREADS) void gma_agg_kernel(AggArgs a) {
                         f32x4 v = up_tail(*reinterpret_cast<const uint2*>(a.qkv + (size_t)(5 * which) * a.plane + p * kSEG + 4 * q)) * sc + sh;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
-                        *reinterpret_cast<uint2*>(a.qkvp + (size_t)(4 * which) * a.plane + p * kSEG + 4 * q) = pack_tail(v);
+                        const uint2 pkd = pack_tail(v);
+                        *reinterpret_cast<uint2*>(a.qkvp + (size_t)(4 * which) * a.plane + p * kSEG + 4 * q) = pkd;
+                        const f32x4 r = up_tail(pkd);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vmax[e] = fmaxf(vmax[e], r[e]);
                     }
+            if (which == 1 && a.kmax != nullptr) agg_block_max(a.kmax + (size_t)b * 64, vmax, s_w, tid, lane);
         }
     } else {
         f32x4 d[2][4];
@@ -825,7 +858,7 @@ __global__ __launch_bounds__(AG_THREADS) void gma_crpe_kernel(CrpeArgs a) {
 
 extern "C" int rc_gma_aggregate(const void* d_qkv, void* d_qkvp, void* d_loc, int batch, int H, int W, const float* d_dw3, const float* d_dw5,
                                 const float* d_dw7, const float* d_dwl, const float* d_pw, const float* d_pwl, const float* d_bn_scale,
-                                const float* d_bn_shift, const float* d_ln_g, const float* d_ln_b, void* stream) {
+                                const float* d_bn_shift, const float* d_ln_g, const float* d_ln_b, float* d_kmax, void* stream) {
     using namespace rc;
     using namespace rc::gf;
     RC_REQUIRE(d_qkv && d_qkvp && d_loc && d_dw3 && d_dw5 && d_dw7 && d_dwl && d_pw && d_pwl && d_bn_scale && d_bn_shift && d_ln_g && d_ln_b,
@@ -837,6 +870,8 @@ extern "C" int rc_gma_aggregate(const void* d_qkv, void* d_qkvp, void* d_loc, in
     a.plane = (size_t)batch * H * W * kSEG;
     a.dw[0] = d_dw3; a.dw[1] = d_dw5; a.dw[2] = d_dw7; a.dwl = d_dwl; a.pw = d_pw; a.pwl = d_pwl;
     a.bn_scale = d_bn_scale; a.bn_shift = d_bn_shift; a.ln_g = d_ln_g; a.ln_b = d_ln_b;
+    a.kmax = d_kmax;
+    if (d_kmax) RC_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_kmax), (int)0xff800000u /* -inf */, (size_t)batch * 64, as_stream(stream)));
     const size_t blocks = (((size_t)a.tiles_x * a.tiles_y * batch + 7) / 8) * 8 * 10;
     RC_REQUIRE(blocks < (1ull << 31), "rc_gma_aggregate: too many tiles");
     hipLaunchKernelGGL(gma_agg_kernel, dim3((unsigned)blocks), dim3(AG_THREADS), 0, as_stream(stream), a);
@@ -1148,6 +1183,130 @@ extern "C" int rc_lsc_chain(const void* d_x, int cin0, const void* d_blob, int c
     if (c == 48) { if (d_raw) RC_LSC(48, true); else RC_LSC(48, false); }
     else { if (d_raw) RC_LSC(128, true); else RC_LSC(128, false); }
 #undef RC_LSC
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+
+// =====================================================================================================================================
+// softmax_N(k)^T v on the matrix cores for the dim-80 block (8 heads x 8 channels, segment-planar bf16 qkv'): given the per-channel
+// maxima M (folded into rc_gma_aggregate), one pass accumulates  Z[i] = sum_t exp(k[t][i] - M[i])  and  S[i][j] = sum_t exp(..) v[t][j]
+// for the 4 diagonal 16 x 16 tiles of the 64 x 64 channel product (a head's 8 x 8 block lies inside one of them).  Tokens are the GEMM's
+// K dimension: a 128-token tile of exp(k - M) and of v is transposed through LDS ([channel][token] bf16, 272-byte rows: conflict-free
+// ds_read_b128), wave w owns diagonal tile w: 4 MFMAs per tile.  The VALU kernel it replaces (gma_kvsum_kernel) spent 0.60 ms on 64 FMAs
+// per token and head; this one is bound by reading k and v once.  Partial sums per block, merged in fixed order by gma_kv_merge_kernel.
+namespace rc {
+namespace gf {
+
+constexpr int KV_TILE = 128, KV_ROW = KV_TILE + 8, KV_THREADS = 256;
+__global__ __launch_bounds__(KV_THREADS) void gma_kvsum_mfma_kernel(const bf16_t* __restrict__ qkvp, size_t plane, const float* __restrict__ kmax,
+                                                                     float* __restrict__ part, int n_tok, int L) {
+    __shared__ __attribute__((aligned(16))) unsigned short s_e[64 * KV_ROW];     // exp(k - M), [channel][token]
+    __shared__ __attribute__((aligned(16))) unsigned short s_v[64 * KV_ROW];     // v, [channel][token]
+    __shared__ float s_m[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+    const int blk = blockIdx.x, b = blockIdx.y, nblk = gridDim.x;
+    const float kLog2e = 1.4426950408889634f;
+    if (tid < 64) s_m[tid] = kmax[(size_t)b * 64 + tid] * kLog2e;
+    const int t0 = blk * L, t1 = (t0 + L) < n_tok ? (t0 + L) : n_tok;
+    const int half = tid & 1, tl = tid >> 1;                                    // this thread stages token tl of a tile, channels 16 r + 8 half + 0..7
+    const bf16_t* kbase = qkvp + (size_t)4 * plane + (size_t)b * n_tok * kSEG + 8 * half;     // k = segments 4..7, v = 8..11
+    const bf16_t* vbase = qkvp + (size_t)8 * plane + (size_t)b * n_tok * kSEG + 8 * half;
+    uint4 kr[4], vr[4];
+    auto fetch = [&](int tt) {
+        const int t = tt + tl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            kr[r] = vr[r] = make_uint4(0u, 0u, 0u, 0u);
+            if (t < t1) {
+                kr[r] = *reinterpret_cast<const uint4*>(kbase + (size_t)r * plane + (size_t)t * kSEG);
+                vr[r] = *reinterpret_cast<const uint4*>(vbase + (size_t)r * plane + (size_t)t * kSEG);
+            }
+        }
+    };
+    float z[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[r][e] = 0.f;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t0 < t1) fetch(t0);
+    __syncthreads();
+    for (int tt = t0; tt < t1; tt += KV_TILE) {
+        const bool live = tt + tl < t1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned kw[4] = {kr[r].x, kr[r].y, kr[r].z, kr[r].w}, vw[4] = {vr[r].x, vr[r].y, vr[r].z, vr[r].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = 16 * r + 8 * half + e;
+                const float kf = __uint_as_float((e & 1) ? (kw[e >> 1] & 0xffff0000u) : (kw[e >> 1] << 16));
+                const float ex = live ? __builtin_amdgcn_exp2f(__builtin_fmaf(kf, kLog2e, -s_m[c])) : 0.f;
+                const unsigned short eb = (unsigned short)Vec16<bf16_t>::rne(ex);          // compiler-visible conversion (ex is a v_exp result)
+                z[r][e] += __uint_as_float((unsigned)eb << 16);
+                s_e[c * KV_ROW + tl] = eb;
+                s_v[c * KV_ROW + tl] = (unsigned short)(vw[e >> 1] >> (16 * (e & 1)));
+            }
+        }
+        if (tt + KV_TILE < t1) fetch(tt + KV_TILE);                                // next tile in flight under the MFMA phase
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < KV_TILE / 32; ++st) {
+            const uint4 af = *reinterpret_cast<const uint4*>(s_e + (16 * wave + n) * KV_ROW + 32 * st + 8 * g);
+            const uint4 bf = *reinterpret_cast<const uint4*>(s_v + (16 * wave + n) * KV_ROW + 32 * st + 8 * g);
+            mma32(af, bf, acc);
+        }
+        __syncthreads();
+    }
+    // partial record [Z: 64][S: (h*8 + i)*8 + j], as gma_kv_merge_kernel reads it
+    float* rec = part + ((size_t)b * nblk + blk) * (64 + 512);
+    {   // D[i][j]: lane (n = j, g), rows i = 4 g + r of diagonal tile `wave`; keep the entries inside a head's 8 x 8 block
+        const f32x4 d = acc + 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * g + r;
+            if ((i >> 3) == (n >> 3)) rec[64 + (16 * wave + i) * 8 + (n & 7)] = d[r];
+        }
+    }
+    float* s_z = reinterpret_cast<float*>(s_e);                                    // [64 channels][128 contributors] = 32 KB (s_e + s_v are 34 KB)
+    static_assert(sizeof(s_e) + sizeof(s_v) >= 64 * 128 * 4, "Z reduction buffer");
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_z[(16 * r + 8 * half + e) * 128 + tl] = z[r][e];
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+        for (int k = 0; k < 128; ++k) s += s_z[tid * 128 + k];                   // fixed order
+        rec[tid] = s;
+    }
+}
+
+}  // namespace gf
+}  // namespace rc
+
+namespace rc { void gma_kv_merge_launch(const float* part, float* ktv, int nblk, int batch, float scale, void* stream); }
+
+extern "C" int rc_gma_kv_mfma_blocks(int n_tok) {
+    int nblk = (n_tok + 2047) / 2048;          // >= 2048 tokens per block
+    if (nblk > 512) nblk = 512;
+    return nblk < 1 ? 1 : nblk;
+}
+
+extern "C" size_t rc_gma_kv_mfma_scratch_bytes(int batch, int n_tok) {
+    return (size_t)batch * rc_gma_kv_mfma_blocks(n_tok) * (64 + 512) * sizeof(float);
+}
+
+extern "C" int rc_gma_kv_mfma(const void* d_qkvp, int batch, int n_tok, float scale, const float* d_kmax, float* d_scratch, float* d_ktv, void* stream) {
+    using namespace rc;
+    using namespace rc::gf;
+    RC_REQUIRE(d_qkvp && d_kmax && d_scratch && d_ktv, "rc_gma_kv_mfma: null pointer");
+    RC_REQUIRE(batch >= 1 && batch <= 65535 && n_tok >= 1, "rc_gma_kv_mfma: bad shape");
+    const int nblk = rc_gma_kv_mfma_blocks(n_tok);
+    const int L = ((n_tok + nblk - 1) / nblk + KV_TILE - 1) / KV_TILE * KV_TILE;
+    hipLaunchKernelGGL(gma_kvsum_mfma_kernel, dim3(nblk, batch), dim3(KV_THREADS), 0, as_stream(stream), static_cast<const bf16_t*>(d_qkvp),
+                       (size_t)batch * n_tok * kSEG, d_kmax, d_scratch, n_tok, L);
+    gma_kv_merge_launch(d_scratch, d_ktv, nblk, batch, scale, stream);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

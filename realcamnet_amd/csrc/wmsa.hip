@@ -133,9 +133,16 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void wmsa_mfma_kernel(const bf16_
     bf16_t* s_vt = reinterpret_cast<bf16_t*>(wm_lds + 64 * kWmBiasRow * 4) + wave * (DT * 16 * VROW);
     const int n = lane & 15, g = lane >> 4;
     const int nh = C / HD, hw = H / WS, ww = W / WS;
-    const int h = blockIdx.x % nh;
+    // block -> (window chunk, head): the nh blocks that read the same pixels (one per head, 16 of a pixel record's 384 bytes each when
+    // head_dim = 8) are 8 apart in launch order, i.e. on the same XCD (block b runs on XCD b mod 8), so the chunk's cache lines are
+    // filled into ONE L2 once instead of into eight (head-major order made the head_dim 8 call fabric-bound: 6.8 GB of line fills
+    // for 0.85 GB of data, 1.14 ms)
+    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+    const int h = r % nh;
+    const long long chunk = (long long)(r / nh) * 8 + xcd;
     const long long n_win = (long long)batch * hw * ww;
-    const long long w_begin = (long long)(blockIdx.x / nh) * windows_per_block;
+    const long long w_begin = chunk * windows_per_block;
+    if (w_begin >= n_win) return;
     const long long w_end = (w_begin + windows_per_block) < n_win ? (w_begin + windows_per_block) : n_win;
     const float kLog2e = 1.4426950408889634f;
     // expanded bias: entry [tq][16 mt + 4 gg + j] = relpos[h][p1 - j1 + 7][p2 - j2 + 7] * log2(e), key = 32 (mt >> 1) + 8 gg + 4 (mt & 1) + j
@@ -268,11 +275,11 @@ int rc_window_attention(const void* d_qkv, const float* d_relpos, void* d_out, i
         const long long n_win = (long long)batch * (H / 8) * (W / 8);
         const int dtiles = (head_dim + 15) / 16;
         const size_t lds = (size_t)64 * kWmBiasRow * 4 + (size_t)kWmWaves * dtiles * 16 * (64 + 8) * 2;
-        // enough blocks for ~4 waves of blocks over the chip, each amortising its bias-table expansion over >= 16 windows
-        long long per_block = (n_win * nh + (long long)device_cu_count() * 16 - 1) / ((long long)device_cu_count() * 16);
-        if (per_block < 16) per_block = 16;
+        // small chunks (2 windows per wave) keep the pixels that the nh head-blocks of a chunk share inside one XCD's L2; the bias-table
+        // expansion (16 entries per thread) is noise next to a window's work
+        long long per_block = 2 * kWmWaves;
         if (per_block > n_win) per_block = n_win;
-        const long long chunks = (n_win + per_block - 1) / per_block;
+        const long long chunks = ((n_win + per_block - 1) / per_block + 7) / 8 * 8;      // whole groups of 8 (one chunk per XCD)
         RC_REQUIRE(chunks * nh < (1LL << 31), "rc_window_attention: too many windows");
 #define RC_WMM(HD)                                                                                                                          \
         hipLaunchKernelGGL((wmsa_mfma_kernel<HD>), dim3((unsigned)(chunks * nh)), dim3(kWmWaves * 64), lds, as_stream(stream),              \

@@ -85,7 +85,7 @@ class Aggregator(nn.Module):
         if self.seg != 5:
             raise NotImplementedError("Aggregator: seg=5 only (as EfficientAtt builds it)")
         if qkv.dim() == 5:                                 # segment-planar (15, B, H, W, 16) from realcam::gma_ln_qkv
-            return self._run_fused(qkv)
+            return self._run_fused(qkv)[:2]
         b, H, W, c3 = qkv.shape
         c, seg = c3 // 3, c3 // 15
         dev, dt = qkv.device, qkv.dtype
@@ -129,7 +129,8 @@ class Aggregator(nn.Module):
 
     def _run_fused(self, qkv):
         """dim 80, bf16: depth-wise, point-wise, BatchNorm, Hardswish and the local branch in ONE launch (rc_gma_aggregate);
-        qkv in the segment-planar layout (15, B, H, W, 16) that realcam::gma_ln_qkv writes."""
+        qkv in the segment-planar layout (15, B, H, W, 16) that realcam::gma_ln_qkv writes.  -> (qkvp, loc, kmax): kmax (B, 64) is the
+        per-channel maximum of the aggregated k, reduced by the same launch (the shift of softmax_N(k))."""
         seg = 16
 
         def taps(w1, w2, w3, w0):
@@ -220,6 +221,10 @@ class EfficientAtt(nn.Module):
     def _context(self, qkv):
         """qkv (B,H,W,3C) -> (qkvp, loc, convv, ktv): aggregators, crpe's depth-wise conv of v, softmax_N(k)^T v."""
         seg, ct, ch = self._geometry(80 if qkv.dim() == 5 else qkv.shape[-1] // 3)
+        if qkv.dim() == 5 and self.num_heads == 8 and ch == 8:          # fused path: max folded into the aggregator, k^T v on the matrix cores
+            qkvp, loc, kmax = self.aggregator._run_fused(qkv)
+            convv = self.crpe._conv_v(qkvp)
+            return qkvp, loc, convv, torch.ops.realcam.gma_kv_mfma(qkvp, kmax, float(self.scale))
         qkvp, loc = self.aggregator._run(qkv)
         convv = self.crpe._conv_v(qkvp)
         ktv = torch.ops.realcam.gma_kv(qkvp, self.num_heads, ch, float(self.scale))

@@ -534,12 +534,23 @@ define("gma_tail(Tensor qkvp, Tensor convv, Tensor loc, Tensor x, Tensor ktv, Te
 
 
 define("gma_aggregate(Tensor qkv, Tensor dw3, Tensor dw5, Tensor dw7, Tensor dwl, Tensor pw, Tensor pwl, Tensor bn_scale, Tensor bn_shift, "
-       "Tensor ln_gamma, Tensor ln_beta) -> (Tensor, Tensor)",
-       lambda qkv, *a: (qkv.new_empty((12, *qkv.shape[1:4], 16)), qkv.new_empty((*qkv.shape[1:4], 16))),   # qkv: (15, B, H, W, 16)
+       "Tensor ln_gamma, Tensor ln_beta) -> (Tensor, Tensor, Tensor)",
+       lambda qkv, *a: (qkv.new_empty((12, *qkv.shape[1:4], 16)), qkv.new_empty((*qkv.shape[1:4], 16)),     # qkv: (15, B, H, W, 16)
+                        qkv.new_empty((qkv.shape[1], 64), dtype=torch.float32)),                             # per-channel max of the aggregated k
        lambda outs, qkv, dw3, dw5, dw7, dwl, pw, pwl, sc, sh, lg, lb: check(
            lib().rc_gma_aggregate(qkv.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), qkv.shape[1], qkv.shape[2], qkv.shape[3], dw3.data_ptr(),
                                   dw5.data_ptr(), dw7.data_ptr(), dwl.data_ptr(), pw.data_ptr(), pwl.data_ptr(), sc.data_ptr(), sh.data_ptr(),
-                                  lg.data_ptr(), lb.data_ptr(), _stream()), "rc_gma_aggregate"))
+                                  lg.data_ptr(), lb.data_ptr(), outs[2].data_ptr(), _stream()), "rc_gma_aggregate"))
+
+
+def _kvm_launch(ktv, qkvp, kmax, scale):
+    b, n = qkvp.shape[1], qkvp.shape[2] * qkvp.shape[3]
+    scratch = torch.empty(lib().rc_gma_kv_mfma_scratch_bytes(b, n) // 4, dtype=torch.float32, device=qkvp.device)
+    check(lib().rc_gma_kv_mfma(qkvp.data_ptr(), b, n, float(scale), kmax.data_ptr(), scratch.data_ptr(), ktv.data_ptr(), _stream()), "rc_gma_kv_mfma")
+
+
+define("gma_kv_mfma(Tensor qkvp, Tensor kmax, float scale) -> Tensor",
+       lambda qkvp, kmax, scale: qkvp.new_empty((qkvp.shape[1], 8, 8, 8), dtype=torch.float32), _kvm_launch)
 
 define("gma_crpe(Tensor qkvp, Tensor taps0, Tensor taps1, Tensor taps2, Tensor taps3, Tensor bias) -> Tensor",
        lambda qkvp, *a: qkvp.new_empty((4, *qkvp.shape[1:4], 16)),                 # segment-planar in and out

@@ -6,6 +6,7 @@ import groupmix_oracle as GO
 import liteisp_oracle as O
 import realcamnet_amd as M
 from conftest import golden_names, load_golden, rel_err
+from realcamnet_amd import ops
 
 GMA = golden_names("gma_block_")
 
@@ -175,3 +176,29 @@ def test_gma_model_vs_oracle(hip, dt, floor):
     p = O.psnr(y.float().cpu(), ref)
     _metric(f"gma_model {dt}", p)
     assert p >= floor, p
+
+
+@pytest.mark.gpu
+def test_kv_on_matrix_cores_equals_two_pass_form(hip):
+    """rc_gma_aggregate's per-channel k maximum + rc_gma_kv_mfma against the two-pass VALU form (rc_gma_kv_planar) on the same aggregated
+    planes: ragged token count (not a multiple of the 128-token tile), batch 2, and an outlier token that moves the maximum mid-stream.
+    The MFMA form rounds exp(k - max) to bf16, so the bar is relative (1e-2 of the largest entry), and run-to-run bitwise equality."""
+    R = torch.ops.realcam
+    blk = M.GMA_Block(80, 8).to("cuda", torch.bfloat16).eval()
+    g = torch.Generator().manual_seed(21)
+    b, H, W = 2, 37, 53
+    x = torch.randn(b, H, W, 80, generator=g)
+    x[1, 20, 30] *= 25.0                                               # outlier token
+    x = x.to("cuda", torch.bfloat16)
+    with torch.no_grad():
+        wq, bq = ops.packed_chain(blk.att.qkv)
+        qkv = R.gma_ln_qkv(x, wq, bq, ops.f32_param(blk.norm1, "weight"), ops.f32_param(blk.norm1, "bias"), 1e-5)
+        qkvp, loc, kmax = blk.att.aggregator._run_fused(qkv)
+        k = qkvp[4:8].float().permute(1, 2, 3, 0, 4).reshape(b, H * W, 64)          # (B, tokens, segment * 16 + c)
+        assert torch.equal(kmax, k.amax(dim=1))
+        want = R.gma_kv(qkvp, 8, 8, float(blk.att.scale))
+        got = R.gma_kv_mfma(qkvp, kmax, float(blk.att.scale))
+        again = R.gma_kv_mfma(qkvp, kmax, float(blk.att.scale))
+    assert got.shape == want.shape == (b, 8, 8, 8)
+    assert torch.equal(got, again)
+    assert (got - want).abs().max().item() <= 1e-2 * want.abs().max().item()

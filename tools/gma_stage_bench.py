@@ -36,9 +36,10 @@ with torch.no_grad():
     x = timeit("cpe dw3x3 + identity", lambda: blk.cpe._nhwc(t))
     wq, bq = ops.packed_chain(blk.att.qkv)
     qkv = timeit("ln_qkv", lambda: R.gma_ln_qkv(x, wq, bq, f32(blk.norm1, "weight"), f32(blk.norm1, "bias"), 1e-5))
-    qkvp, loc = timeit("aggregate", lambda: blk.att.aggregator._run(qkv))
+    qkvp, loc, kmax = timeit("aggregate (+ per-channel max of k)", lambda: blk.att.aggregator._run_fused(qkv))
     convv = timeit("crpe", lambda: blk.att.crpe._conv_v(qkvp))
-    ktv = timeit("kv (max, sums, merge)", lambda: R.gma_kv(qkvp, 8, 8, float(blk.att.scale)))
+    timeit("kv, two-pass VALU form (max, sums, merge)", lambda: R.gma_kv(qkvp, 8, 8, float(blk.att.scale)))
+    ktv = timeit("kv on the matrix cores (sums, merge)", lambda: R.gma_kv_mfma(qkvp, kmax, float(blk.att.scale)))
     wp, bp = ops.packed_chain(blk.att.proj); w1, b1 = ops.packed_chain(blk.mlp.fc1); w2, b2 = ops.packed_chain(blk.mlp.fc2)
     wo, bo = ops.packed_chain(gout)
     timeit("tail (+ out conv)", lambda: R.gma_tail(qkvp, convv, loc, x, ktv, wp, bp, f32(blk.norm2, "weight"), f32(blk.norm2, "bias"), 1e-5,
