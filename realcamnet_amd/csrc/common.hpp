@@ -120,4 +120,20 @@ inline int device_cu_count() {
     return cus[d] > 0 ? cus[d] : 256;
 }
 
+// exact-erf GELU, 0.5 v (1 + erf(v / sqrt 2)), with erf by Abramowitz-Stegun 7.1.28: erf(z) = 1 - (1 + a1 z + .. + a6 z^6)^-16 for z >= 0
+// (|error| <= 3e-7, far inside fp32 parity tolerances and below bf16 rounding), odd extension by sign.  One reciprocal, no exponential, no
+// libm call (ocml's erff is ~40 instructions); for large |v| the power overflows to +inf and erf saturates at 1.
+__device__ __forceinline__ float gelu_erf_f32(float v) {
+    const float z = fabsf(v) * 0.70710678118654752f;
+    float p = __builtin_fmaf(z, 0.0000430638f, 0.0002765672f);
+    p = __builtin_fmaf(p, z, 0.0001520143f);
+    p = __builtin_fmaf(p, z, 0.0092705272f);
+    p = __builtin_fmaf(p, z, 0.0422820123f);
+    p = __builtin_fmaf(p, z, 0.0705230784f);
+    p = __builtin_fmaf(p, z, 1.f);
+    p = p * p; p = p * p; p = p * p; p = p * p;
+    const float e = 1.f - __builtin_amdgcn_rcpf(p);
+    return (0.5f * v) * (1.f + copysignf(e, v));
+}
+
 }  // namespace rc

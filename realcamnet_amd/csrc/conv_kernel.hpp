@@ -788,7 +788,7 @@ struct ConvDev {
                 for (int e = 0; e < NV; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.act_slope;
             } else if (a.act == RC_ACT_GELU) {
 #pragma unroll
-                for (int e = 0; e < NV; ++e) v[e] = 0.5f * v[e] * (1.f + erff(v[e] * 0.70710678118654752f));
+                for (int e = 0; e < NV; ++e) v[e] = gelu_erf_f32(v[e]);
             }
             const int pix_off = valid ? ((gy * a.W + gx) * a.cout + jbase) * ES : kOOB;   // NHWC-shaped operands
             if (a.mul_plus1 != nullptr) {
