@@ -13,13 +13,16 @@ struct ConvPlan {
 
 // Must mirror ConvCfg<> (static_asserts in check_plan_consistency below keep them in lock-step).
 static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, ConvPlan* p) {
-    if (cin < 1 || cout < 1 || (ksize != 1 && ksize != 3)) return false;
+    if (cin < 1 || cout < 1 || (ksize != 1 && ksize != 3 && ksize != 2)) return false;
     if (dtype != RC_F32 && dtype != RC_BF16) return false;
+    // ksize 2: the 2x2 window at pixel offsets {-1, 0}^2 = the non-zero taps of a stride-2 3x3 convolution over its space-to-depth map
+    // (bf16, Cin a multiple of 16 that is not routed to the 8- / 48- / 80-wide chunk forms; plain NHWC store)
+    if (ksize == 2 && (dtype != RC_BF16 || cin % 16 != 0 || out_mode != RC_OUT_NHWC || (cin % 48 == 0 && cin % 64 != 0))) return false;
     p->unit = dtype == RC_F32 ? 4 : 8;
     if (dtype == RC_BF16) {
         if (cin <= 8) p->ck = 8;
         else if (ksize == 1 && cin % 80 == 0 && cin % 64 != 0) p->ck = 80;   // GroupMix dims (80, 240, 320 -> 64)
-        else if (ksize == 3 && cin % 64 == 0 && cin > 64) p->ck = 32;         // multi-chunk layers: 32-channel chunks so two
+        else if (ksize >= 2 && cin % 64 == 0 && cin > 64) p->ck = 32;         // multi-chunk layers: 32-channel chunks so two
                                                                                // input + two weight buffers fit one CU's LDS
         else if (cin % 64 == 0) p->ck = 64;
         else if (cin % 48 == 0) p->ck = 48;

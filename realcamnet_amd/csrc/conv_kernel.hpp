@@ -1386,7 +1386,7 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
     // multi-chunk producer/consumer form
     // bf16 only: in fp32 the MFMAs are 4x longer, the layers are MFMA-bound either way and the general kernel's many
     // small blocks balance the B = 1 configurations better (measured 99 vs 88 TF/s on 64 -> 64 at 1080p)
-    if constexpr (WSM_LDS <= 160 * 1024 && Cfg::KS == 3 && Cfg::STEPS >= 2 && sizeof(typename Cfg::elem) == 2) {
+    if constexpr (WSM_LDS <= 160 * 1024 && Cfg::KS >= 2 && Cfg::STEPS >= 2 && sizeof(typename Cfg::elem) == 2) {
         if ((a.n_chunks > 1 || a.n_ct > 1) && a.cin_vec_ok && a.cin_chunk_ok && a.persist_ok && a.cout_packed <= kPersistMaxCout &&
             n_tiles < (1 << 24)) {
             const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch * (a.n_chunks > 1 ? a.n_ct : 1);

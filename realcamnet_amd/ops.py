@@ -120,7 +120,7 @@ def packed_conv(mod, act_dtype: torch.dtype, out_mode: int) -> PackedConv:
         kh = kw = 1
     else:
         cout, cin, kh, kw = w.shape
-    if kh != kw or kh not in (1, 3):
+    if kh != kw or kh not in (1, 2, 3):                    # 2: the {-1, 0}^2 window of a stride-2 3x3 conv over its space-to-depth map
         raise NotImplementedError(f"HIP conv supports 1x1 and 3x3 kernels, got {kh}x{kw}")
     wp, bp = _R.conv_pack_weights(w.detach(), b.detach() if b is not None else None, act_dtype, out_mode)
     pc = PackedConv()
@@ -216,7 +216,11 @@ def _stride2_view(mod) -> "_ConvView":
     if hit is None or hit[0] != key:
         w = mod.weight.detach().float().cpu()
         cout, c, k, _ = w.shape
-        w3 = torch.zeros(cout, 4 * c, k, k)
+        # bf16: the 3x3 case only touches map offsets {-1, 0}^2 -- a 2x2 window (rc_conv2d ksize 2): 16 (tap, phase) blocks of which 9 are
+        # non-zero, instead of the 36 of the 3x3 embedding (fp32 and odd channel counts keep the 3x3 form)
+        kk = 2 if (k == 3 and mod.weight.dtype == torch.bfloat16 and
+                   _lib.load().rc_conv_packed_bytes(4 * c, cout, 2, _DT[torch.bfloat16], RC_OUT_NHWC) != 0) else k
+        w3 = torch.zeros(cout, 4 * c, kk, kk)
         if k == 3:
             place = {-1: (1, -1), 0: (0, 0), 1: (1, 0)}
             for dy, (i, oy) in place.items():
@@ -233,8 +237,8 @@ def _stride2_view(mod) -> "_ConvView":
 
 def conv_stride2(x: torch.Tensor, mod, **fuse):
     """kxk stride-2 padding-k//2 convolution (k in {1, 3}) as a stride-1 rc_conv2d at the OUTPUT resolution over the
-    space-to-depth map (4c channels, re-indexed taps; only 9 of the 36 (tap, phase) blocks are non-zero -- skipping the rest in
-    the packed weights, or a strided input staging, is future work).  1x1 with a vectorisable channel count: sample (rc_subsample2), then convolve."""
+    space-to-depth map (4c channels, re-indexed taps; bf16: a 2x2 window, 9 of 16 (tap, phase) blocks non-zero; fp32: the 3x3 embedding,
+    9 of 36).  1x1 with a vectorisable channel count: sample (rc_subsample2), then convolve."""
     x = _req(x, "conv_stride2 input")
     if any(k not in ("act", "slope") for k in fuse):
         raise NotImplementedError("conv_stride2: only an activation can be fused")

@@ -659,3 +659,23 @@ def test_forward_is_hip_graph_capturable(hip):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(y_graph, y_eager)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 64), (128, 128), (32, 48), (128, 320), (80, 64)])
+@pytest.mark.parametrize("shape", [(1, 16, 24), (2, 38, 70)])
+def test_stride2_conv_as_2x2_window_exact_on_integer_data(hip, cin, cout, shape):
+    """conv3x3(stride 2) in bf16 = rc_space_to_depth2 + rc_conv2d with ksize 2 (the {-1, 0}^2 window: 9 of 16 (tap, phase) blocks non-zero;
+    single-chunk, multi-chunk and odd-width plans): bit-exact against F.conv2d on small-integer data, even and odd map sizes."""
+    b, H, W = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout + H)
+    conv = N.Conv2d(cin, cout, 3, 2, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randint(-2, 3, conv.weight.shape, generator=g).float())
+        conv.bias.copy_(torch.randint(-4, 5, (cout,), generator=g).float())
+    x = torch.randint(-3, 4, (b, cin, H, W), generator=g).float()
+    ref = F.conv2d(x, conv.weight, conv.bias, stride=2, padding=1)
+    conv = conv.to(DEV, torch.bfloat16).eval()
+    with torch.no_grad():
+        y = ops.to_nchw(conv._nhwc(ops.to_nhwc(x.to(DEV, torch.bfloat16))))
+    assert y.shape == ref.shape
+    assert torch.equal(y.float().cpu(), ref.bfloat16().float())     # integer sums are exact in the fp32 accumulators; one rounding to bf16
