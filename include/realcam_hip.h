@@ -95,7 +95,11 @@ int rc_nhwc_to_nchw(const void* d_src, int src_dtype, void* d_dst, int dst_dtype
  */
 typedef struct rc_conv_desc {
     int32_t batch, height, width;   /* input spatial size == conv output size                     */
-    int32_t cin, cout, ksize;       /* ksize: 1 or 3                                              */
+    int32_t cin, cout, ksize;       /* ksize: 1 or 3 (zero padding ksize/2); 2 (bf16, cin % 16 == 0, RC_OUT_NHWC only): the 2x2 window
+                                       at pixel offsets {-1, 0}^2, weights (cout, cin, 2, 2) -- the non-zero taps of a stride-2 3x3
+                                       convolution (compressai conv3x3(stride=2), ResidualBlockWithStride; models/tcm.py:336-345) taken
+                                       over the rc_space_to_depth2 map of its input (9 of the 16 (tap, phase) weight blocks non-zero;
+                                       the 3x3 embedding of the same convolution carries 36 blocks) */
     int32_t dtype;                  /* rc_dtype of activations + packed weights                   */
     /* input x.  in_gate==NULL: x = in0.
      * in_gate!=NULL (CALayer gate + RCAB skip, networks.py:270,311): x = in0*gate[b][c] + in1 and,
