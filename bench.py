@@ -241,7 +241,10 @@ def bench_codec(args, net, sd_cpu, step, inputs, rank, world, dev, dt):
                       "frames_per_gpu": B, "global_frames": total_frames, "parallelism": f"frame-shard x{world}"},
            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                         "traffic": None, "kernel": "conv_mfma_kernel (all instantiations)", "launches_per_step": int(n_launch),
-                        "kernel_ms_per_step": round(conv_ms, 3), "flops_per_step": conv_flops}}
+                        "kernel_ms_per_step": round(conv_ms, 3), "flops_per_step": conv_flops,
+                        "flops_note": ("necessary MACs: stride-2 convolutions (bf16: a 2x2 window over the space-to-depth map) are counted at their "
+                                       "9 real (tap, phase) blocks, not the 16 executed" if args.dtype == "bf16" else
+                                       "fp32 stride-2 convolutions run as a 3x3 embedding over the space-to-depth map and are counted as executed (4x)")}}
     if world == 1 and not args.no_cpu_baseline:
         import liteisp_oracle as O                      # the oracle: checker and CPU baseline only
         import raw2bit_oracle as RO

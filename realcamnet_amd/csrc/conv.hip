@@ -277,7 +277,9 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
 
     hipStream_t stream = as_stream(stream_);
     void* tok = nullptr;
-    conv_prof_begin(2.0 * d->batch * d->height * d->width * (double)d->cin * d->cout * d->ksize * d->ksize, stream, &tok);
+    // algorithmic FLOPs: a ksize-2 launch is a stride-2 3x3 convolution over its space-to-depth map -- 9 of its 16 (tap, phase) blocks are real
+    const double taps = d->ksize == 2 ? 9.0 / 4.0 : (double)d->ksize * d->ksize;
+    conv_prof_begin(2.0 * d->batch * d->height * d->width * (double)d->cin * d->cout * taps, stream, &tok);
     const int rcode = dispatch_conv(d->dtype == RC_BF16, d->ksize, p.ck, p.nt, a, stream);
     conv_prof_end(tok, stream);
     return rcode;

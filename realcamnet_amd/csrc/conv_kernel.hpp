@@ -1368,11 +1368,10 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
         // cout tiles, whose prefetch registers would otherwise spill), 2 = wherever eligible, 3 = never
         const bool ws_auto = GATED || Cfg::NT == 5 || Cfg::CK == 80;
         if (a.n_chunks == 1 && a.n_ct == 1 && a.cin_vec_ok && (a.persist_ok == 2 || (a.persist_ok == 1 && ws_auto)) && n_tiles < (1 << 24)) {
-            static bool attr_set = false;
-            if (!attr_set) {
+            static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
+            if (!attr_set.test_and_set()) {
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_ws_kernel<Cfg, GATED, FAST>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
-                attr_set = true;
             }
             int grid = a.num_cus;
             if (grid > n_tiles) grid = n_tiles;
@@ -1390,11 +1389,10 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
         if ((a.n_chunks > 1 || a.n_ct > 1) && a.cin_vec_ok && a.cin_chunk_ok && a.persist_ok && a.cout_packed <= kPersistMaxCout &&
             n_tiles < (1 << 24)) {
             const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch * (a.n_chunks > 1 ? a.n_ct : 1);
-            static bool attr_set = false;
-            if (!attr_set) {
+            static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
+            if (!attr_set.test_and_set()) {
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_wsm_kernel<Cfg, GATED, FAST>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, WSM_LDS));
-                attr_set = true;
             }
             int grid = a.num_cus;
             if (grid > n_items) grid = n_items;
@@ -1406,11 +1404,10 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
     }
     if constexpr (P_OK) {
         if (a.n_chunks == 1 && a.cout_packed <= kPersistMaxCout && a.persist_ok && n_tiles < (1 << 24)) {
-            static bool attr_set = false;
-            if (!attr_set) {
+            static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
+            if (!attr_set.test_and_set()) {
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_persist_kernel<Cfg, GATED, FAST>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
-                attr_set = true;
             }
             int grid = persist_blocks_per_cu<Cfg>() * a.num_cus;
             if (grid > n_tiles) grid = n_tiles;
@@ -1420,11 +1417,10 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
             return RC_OK;
         }
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
+    if (!attr_set.test_and_set()) {
         RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<Cfg, GATED, FAST>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        attr_set = true;
     }
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.n_ct), (unsigned)a.batch, 1);
     hipLaunchKernelGGL((conv_mfma_kernel<Cfg, GATED, FAST>), grid, dim3(kThreads), Cfg::LDS_BYTES, stream, a);
