@@ -380,6 +380,13 @@ int rc_gma_aggregate(const void* d_qkv, void* d_qkvp, void* d_loc, int batch, in
  *   rc_gma_kv_mfma: ktv[b][h][i][j] = scale * sum_t softmax_t(k)[t][h,i] v[t][h,j] for 8 heads x 8 channels, segment-planar bf16 qkv'
  * (d_scratch: rc_gma_kv_mfma_scratch_bytes bytes).  exp(k - max) is rounded to bf16 for the MFMA (numerator and denominator use the same
  * rounded values); accumulation fp32, block partials merged in fixed order. */
+/* Transformer-block MLP of the codecs (models/tcm.py:234-235: x + mlp(ln2(x)), mlp = Linear(C,4C) -> GELU -> Linear(4C,C)) as ONE launch with
+ * register-resident activations: d_out = d_x + fc2(GELU(fc1(LayerNorm(d_x)))).  bf16, token width c = 32 or 64, d_x / d_out (tokens, c);
+ * weights packed by rc_chain_pack_weights(c -> 4c) and (4c -> c), biases by rc_chain_pack_bias (or NULL).  Rounding points are those of
+ * rc_layernorm + two rc_conv2d launches (LayerNorm output and GELU output to bf16). */
+int rc_ln_mlp(const void* d_x, void* d_out, long long tokens, int c, const void* d_w_fc1, const float* d_b_fc1, const void* d_w_fc2,
+              const float* d_b_fc2, const float* d_ln_gamma, const float* d_ln_beta, float eps, void* stream);
+
 int rc_gma_kv_mfma_blocks(int n_tok);
 size_t rc_gma_kv_mfma_scratch_bytes(int batch, int n_tok);
 int rc_gma_kv_mfma(const void* d_qkvp, int batch, int n_tok, float scale, const float* d_kmax, float* d_scratch, float* d_ktv, void* stream);

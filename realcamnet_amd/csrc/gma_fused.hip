@@ -1331,3 +1331,144 @@ extern "C" int rc_gma_kv_mfma(const void* d_qkvp, int batch, int n_tok, float sc
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
+
+// =====================================================================================================================================
+// Transformer-block MLP of the codecs as one register-resident chain:  out = x + fc2(GELU(fc1(LayerNorm(x))))   (models/tcm.py:234-235)
+// for token width C = 32 or 64 (hidden 4 C), bf16.  Layer by layer this is rc_layernorm + two 1x1 rc_conv2d launches that write and re-read
+// the normalised map and the 4C-wide hidden map (2.8 GB per block at the codec's 576 x 960 x 4 stage); here a wave's 64 tokens stay in MFMA
+// fragments from the load of x to the store of the result (same machinery as gma_tail_kernel: pair-packed weight rows, hidden channels
+// consumed 32 at a time as one fc2 K-step).  Rounding points = the layer-by-layer path's (LayerNorm output and GELU output to bf16).
+namespace rc {
+namespace gf {
+
+template <int C>
+__device__ __forceinline__ void layernorm_c(const Act<C> (&in)[kNT], Act<C> (&out)[kNT], const float* gb, int g, float eps) {
+    constexpr int KS = C / 32;
+    f32x4 gam[2 * KS], bet[2 * KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        gam[2 * s] = ld4(gb + 32 * s + 8 * g); gam[2 * s + 1] = ld4(gb + 32 * s + 8 * g + 4);
+        bet[2 * s] = ld4(gb + C + 32 * s + 8 * g); bet[2 * s + 1] = ld4(gb + C + 32 * s + 8 * g + 4);
+    }
+#pragma unroll
+    for (int nt = 0; nt < kNT; ++nt) {
+        f32x4 v[2 * KS];
+        f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { v[2 * s] = up_lo(in[nt].f[s]); v[2 * s + 1] = up_hi(in[nt].f[s]); sv += v[2 * s] + v[2 * s + 1]; }
+        float sm = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+        sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+        const float mean = sm / (float)C;
+        f32x4 qv = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i) { v[i] = v[i] - mean; qv += v[i] * v[i]; }
+        float q = (qv[0] + qv[1]) + (qv[2] + qv[3]);
+        q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+        const float rstd = 1.f / sqrtf(q / (float)C + eps);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) out[nt].f[s] = pack_pair(v[2 * s] * rstd * gam[2 * s] + bet[2 * s], v[2 * s + 1] * rstd * gam[2 * s + 1] + bet[2 * s + 1]);
+    }
+}
+
+struct MlpArgs {
+    const bf16_t* x; bf16_t* out; size_t tokens;
+    const void* w_fc1; const float* b_fc1; const void* w_fc2; const float* b_fc2;     // rc_chain_pack_weights / rc_chain_pack_bias
+    const float* ln_g; const float* ln_b; float eps;
+};
+
+constexpr int kMlpThreads = 256;
+template <int C>
+__global__ __launch_bounds__(kMlpThreads, 2) void ln_mlp_kernel(const MlpArgs a) {
+    constexpr int HID = 4 * C, MT = C / 16, KS = C / 32, TB1 = tile_bytes(C), TB2 = tile_bytes(HID);
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* s_fc1 = lds;                                                  // [HID / 16 tiles][TB1]
+    char* s_fc2 = s_fc1 + (HID / 16) * TB1;                             // [MT tiles][TB2]
+    float* s_b1 = reinterpret_cast<float*>(s_fc2 + MT * TB2);           // [HID]
+    float* s_b2 = s_b1 + HID;                                           // [C]
+    float* s_gb = s_b2 + C;                                             // gamma[C] | beta[C]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (HID / 16) * TB1 / 16; i += kMlpThreads) reinterpret_cast<uint4*>(s_fc1)[i] = reinterpret_cast<const uint4*>(a.w_fc1)[i];
+    for (int i = tid; i < MT * TB2 / 16; i += kMlpThreads) reinterpret_cast<uint4*>(s_fc2)[i] = reinterpret_cast<const uint4*>(a.w_fc2)[i];
+    for (int i = tid; i < HID; i += kMlpThreads) s_b1[i] = a.b_fc1 ? a.b_fc1[i] : 0.f;
+    for (int i = tid; i < C; i += kMlpThreads) { s_b2[i] = a.b_fc2 ? a.b_fc2[i] : 0.f; s_gb[i] = a.ln_g[i]; s_gb[C + i] = a.ln_b[i]; }
+    __syncthreads();
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const size_t n_tiles = (a.tokens + 63) / 64, n_waves = (size_t)gridDim.x * (kMlpThreads / 64);
+    size_t tile = (size_t)blockIdx.x * (kMlpThreads / 64) + (tid >> 6);
+    Act<C> xnext[kNT];
+    auto fetch = [&](size_t tl) {
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            const size_t t = tl * 64 + 16 * nt + n;
+            load_act<C>(a.x + (t < a.tokens ? t : a.tokens - 1) * C, g, xnext[nt]);
+        }
+    };
+    if (tile < n_tiles) fetch(tile);
+    for (; tile < n_tiles; tile += n_waves) {
+        Act<C> xin[kNT], n2[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) xin[nt] = xnext[nt];
+        if (tile + n_waves < n_tiles) fetch(tile + n_waves);                 // next tile in flight
+        layernorm_c<C>(xin, n2, s_gb, g, a.eps);
+        f32x4 acc[MT][kNT];                                                   // fc2 accumulators, seeded with the residual x
+#pragma unroll
+        for (int p = 0; p < KS; ++p)
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) { acc[2 * p][nt] = up_lo(xin[nt].f[p]); acc[2 * p + 1][nt] = up_hi(xin[nt].f[p]); }
+#pragma unroll 1
+        for (int hc = 0; hc < HID / 32; ++hc) {
+            f32x4 h[2][kNT];
+            const f32x4 c0 = bias4(s_b1, 2 * hc, g), c1 = bias4(s_b1, 2 * hc + 1, g);
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) { h[0][nt] = c0; h[1][nt] = c1; }
+            gemm_tiles<C, 2>(s_fc1, 2 * hc, lane, n2, h);
+            uint4 hb[kNT];
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) hb[nt] = pack_pair(gelu_erf4(h[0][nt]), gelu_erf4(h[1][nt]));
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const uint4 w2 = *reinterpret_cast<const uint4*>(s_fc2 + m * TB2 + hc * 1024 + lane * 16);
+#pragma unroll
+                for (int nt = 0; nt < kNT; ++nt) mma32(w2, hb[nt], acc[m][nt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            Act<C> o;
+#pragma unroll
+            for (int p = 0; p < KS; ++p) o.f[p] = pack_pair(acc[2 * p][nt] + bias4(s_b2, 2 * p, g), acc[2 * p + 1][nt] + bias4(s_b2, 2 * p + 1, g));
+            const size_t t = tile * 64 + 16 * nt + n;
+            if (t < a.tokens) store_act<C>(a.out + t * C, g, o);
+        }
+    }
+}
+
+}  // namespace gf
+}  // namespace rc
+
+extern "C" int rc_ln_mlp(const void* d_x, void* d_out, long long tokens, int c, const void* d_w_fc1, const float* d_b_fc1, const void* d_w_fc2,
+                         const float* d_b_fc2, const float* d_ln_gamma, const float* d_ln_beta, float eps, void* stream) {
+    using namespace rc;
+    using namespace rc::gf;
+    RC_REQUIRE(d_x && d_out && d_w_fc1 && d_w_fc2 && d_ln_gamma && d_ln_beta, "rc_ln_mlp: null pointer");
+    RC_REQUIRE(tokens >= 1 && (c == 32 || c == 64), "rc_ln_mlp: token width 32 or 64");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_x) % 16 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0, "rc_ln_mlp: misaligned tensor");
+    MlpArgs a{static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_out), (size_t)tokens, d_w_fc1, d_b_fc1, d_w_fc2, d_b_fc2, d_ln_gamma, d_ln_beta, eps};
+    const int hid = 4 * c;
+    const size_t lds = (size_t)(hid / 16) * tile_bytes(c) + (size_t)(c / 16) * tile_bytes(hid) + (size_t)(hid + 3 * c) * 4;
+    const long long tiles = (tokens + 63) / 64;
+    long long grid = (tiles + 3) / 4;
+    const long long cap = (long long)device_cu_count() * 2;
+    if (grid > cap) grid = cap;
+#define RC_MLP(CC)                                                                                                                         \
+    do {                                                                                                                                   \
+        static PerDeviceFlag attr;                                                                                                         \
+        if (!attr.test_and_set())                                                                                                          \
+            RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_mlp_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
+        hipLaunchKernelGGL((ln_mlp_kernel<CC>), dim3((unsigned)grid), dim3(kMlpThreads), lds, as_stream(stream), a);                       \
+    } while (0)
+    if (c == 32) RC_MLP(32); else RC_MLP(64);
+#undef RC_MLP
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}

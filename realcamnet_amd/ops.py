@@ -525,6 +525,22 @@ def pointwise_chain(x: torch.Tensor, convs, slope: float) -> torch.Tensor:
     return _R.pointwise_chain48(x, p0.wpacked, p0.bias, [p.wpacked for p in packs], [p.bias for p in packs], float(slope))
 
 
+FUSE_MLP = True     # the codecs' transformer-block MLP (LayerNorm -> Linear -> GELU -> Linear -> + x) as one launch (rc_ln_mlp)
+
+
+def ln_mlp(x: torch.Tensor, ln, fc1, fc2):
+    """x + fc2(gelu(fc1(ln(x)))) in ONE launch (realcam::ln_mlp) for bf16 tokens of width 32 / 64 with a 4x hidden layer; None otherwise."""
+    c = x.shape[-1]
+    if not (FUSE_MLP and x.dtype == torch.bfloat16 and c in (32, 64) and tuple(fc1.weight.shape) == (4 * c, c) and tuple(fc2.weight.shape) == (c, 4 * c) and
+            tuple(ln.normalized_shape) == (c,)):
+        return None
+    x = _req(x, "tokens")
+    w1, b1 = packed_chain(fc1)
+    w2, b2 = packed_chain(fc2)
+    return _R.ln_mlp(x, f32_param(ln, "weight"), f32_param(ln, "bias"), float(ln.eps), w1, b1 if fc1.bias is not None else None, w2,
+                     b2 if fc2.bias is not None else None)
+
+
 def lsc_chain(lsc, coord: torch.Tensor, head=None, raw: Optional[torch.Tensor] = None):
     """Lens_Shading_Correction as ONE launch with register-resident activations (realcam::lsc_chain), bf16, width 48 or 128:
     head is None -> lsc(coord);  else -> head(raw) * (lsc(coord) + 1)  (upstream models/LiteISP.py:2012-2014).  Returns None when the

@@ -72,6 +72,9 @@ class Block(nn.Module):
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
         x = ops._req(x, "Block input")
         x = self.msa._attend(ops.layernorm(x, self.ln1), residual=x)
+        y = ops.ln_mlp(x, self.ln2, self.mlp[0], self.mlp[2])             # bf16, width 32 / 64: one launch, activations in registers
+        if y is not None:
+            return y
         h = ops.conv2d(ops.layernorm(x, self.ln2), self.mlp[0], act="gelu")
         return ops.conv2d(h, self.mlp[2], residual=x)
 

@@ -639,3 +639,10 @@ define("instance_norm(Tensor x, Tensor mean, Tensor rstd, Tensor gamma, Tensor b
        lambda x, m, r, g, b: torch.empty_like(x),
        lambda out, x, m, r, g, b: check(lib().rc_instance_norm(x.data_ptr(), out.data_ptr(), m.data_ptr(), r.data_ptr(), g.data_ptr(), b.data_ptr(),
                                                                x.shape[0], x.shape[1], x.shape[2] * x.shape[3], _stream()), "rc_instance_norm"))
+
+
+define("ln_mlp(Tensor x, Tensor ln_gamma, Tensor ln_beta, float eps, Tensor w_fc1, Tensor? b_fc1, Tensor w_fc2, Tensor? b_fc2) -> Tensor",
+       lambda x, g, b, eps, w1, b1, w2, b2: torch.empty_like(x),
+       lambda out, x, g, b, eps, w1, b1, w2, b2: check(lib().rc_ln_mlp(x.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], w1.data_ptr(),
+                                                                       _p(b1), w2.data_ptr(), _p(b2), g.data_ptr(), b.data_ptr(), float(eps), _stream()),
+                                                       "rc_ln_mlp"))

@@ -681,3 +681,28 @@ def test_hip_window_attention_mfma_form_vs_oracle(head_dim, typ):
         got16 = m.to(torch.bfloat16)(x.cuda().bfloat16()).float().cpu()
     assert rel_err(got32, want) < 2e-5
     assert rel_err(got16, want) < 3e-2 and LO.psnr(got16, want) > 40.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", [32, 64])
+def test_hip_block_mlp_as_one_launch_vs_layer_by_layer(c):
+    """rc_ln_mlp (x + fc2(gelu(fc1(ln2(x)))) with register-resident activations) against rc_layernorm + two rc_conv2d launches on the same bf16
+    inputs (same rounding points: bf16-ulp scale differences) and against the fp32 torch composition; ragged token count."""
+    import realcamnet_amd.tcm as T
+    from realcamnet_amd import ops as OPS
+    torch.manual_seed(c)
+    blk = T.Block(c, c, 16, 8, 0.0, "W").eval()
+    x = torch.randn(2, 24, 40, c) * 2
+    with torch.no_grad():
+        ref = x + blk.mlp(blk.ln2(x))
+    blk = blk.to("cuda", torch.bfloat16)
+    xb = x.cuda().bfloat16()
+    with torch.no_grad():
+        fused = OPS.ln_mlp(xb, blk.ln2, blk.mlp[0], blk.mlp[2])
+        h = OPS.conv2d(OPS.layernorm(xb, blk.ln2), blk.mlp[0], act="gelu")
+        layered = OPS.conv2d(h, blk.mlp[2], residual=xb)
+        odd = OPS.ln_mlp(xb.reshape(1, 1, -1, c)[:, :, :1901].contiguous(), blk.ln2, blk.mlp[0], blk.mlp[2])
+    assert fused is not None and fused.shape == layered.shape
+    assert rel_err(fused.float().cpu(), layered.float().cpu()) < 2e-2
+    assert LO.psnr(fused.float().cpu(), ref) > 45.0 and LO.psnr(layered.float().cpu(), ref) > 45.0
+    assert torch.equal(odd.reshape(-1, c), fused.reshape(-1, c)[:1901])
