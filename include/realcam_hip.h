@@ -387,6 +387,11 @@ int rc_gma_aggregate(const void* d_qkv, void* d_qkvp, void* d_loc, int batch, in
 int rc_ln_mlp(const void* d_x, void* d_out, long long tokens, int c, const void* d_w_fc1, const float* d_b_fc1, const void* d_w_fc2,
               const float* d_b_fc2, const float* d_ln_gamma, const float* d_ln_beta, float eps, void* stream);
 
+/* LayerNorm + Linear in one launch (the W-MSA embedding layer behind ln1, models/tcm.py:179-181, 232): d_out (tokens, cout) =
+ * Linear(LayerNorm(d_x (tokens, c))), bf16, c = 32 or 64, cout a multiple of 32 (<= 512); weights by rc_chain_pack_weights(c -> cout). */
+int rc_ln_linear(const void* d_x, void* d_out, long long tokens, int c, int cout, const void* d_w, const float* d_b, const float* d_ln_gamma,
+                 const float* d_ln_beta, float eps, void* stream);
+
 int rc_gma_kv_mfma_blocks(int n_tok);
 size_t rc_gma_kv_mfma_scratch_bytes(int batch, int n_tok);
 int rc_gma_kv_mfma(const void* d_qkvp, int batch, int n_tok, float scale, const float* d_kmax, float* d_scratch, float* d_ktv, void* stream);

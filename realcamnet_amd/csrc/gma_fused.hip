@@ -1472,3 +1472,87 @@ extern "C" int rc_ln_mlp(const void* d_x, void* d_out, long long tokens, int c, 
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
+
+// =====================================================================================================================================
+// LayerNorm + Linear as one launch:  out = Linear(LayerNorm(x)),  C = 32 / 64 -> COUT (a multiple of 32), bf16 token-major in and out
+// (the W-MSA embedding layer of the codecs' transformer blocks, models/tcm.py:179-181 after :232's ln1).  Same chain machinery; saves the
+// normalised map's round trip and a launch.
+namespace rc {
+namespace gf {
+
+struct LnLinArgs { const bf16_t* x; bf16_t* out; size_t tokens; int cout; const void* w; const float* b; const float* ln_g; const float* ln_b; float eps; };
+
+template <int C>
+__global__ __launch_bounds__(kMlpThreads, 2) void ln_linear_kernel(const LnLinArgs a) {
+    constexpr int TB = tile_bytes(C);
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int mt = a.cout / 16;
+    char* s_w = lds;
+    float* s_b = reinterpret_cast<float*>(lds + mt * TB);
+    float* s_gb = s_b + a.cout;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < mt * TB / 16; i += kMlpThreads) reinterpret_cast<uint4*>(s_w)[i] = reinterpret_cast<const uint4*>(a.w)[i];
+    for (int i = tid; i < a.cout; i += kMlpThreads) s_b[i] = a.b ? a.b[i] : 0.f;
+    for (int i = tid; i < C; i += kMlpThreads) { s_gb[i] = a.ln_g[i]; s_gb[C + i] = a.ln_b[i]; }
+    __syncthreads();
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const size_t n_tiles = (a.tokens + 63) / 64, n_waves = (size_t)gridDim.x * (kMlpThreads / 64);
+    size_t tile = (size_t)blockIdx.x * (kMlpThreads / 64) + (tid >> 6);
+    Act<C> xnext[kNT];
+    auto fetch = [&](size_t tl) {
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            const size_t t = tl * 64 + 16 * nt + n;
+            load_act<C>(a.x + (t < a.tokens ? t : a.tokens - 1) * C, g, xnext[nt]);
+        }
+    };
+    if (tile < n_tiles) fetch(tile);
+    for (; tile < n_tiles; tile += n_waves) {
+        Act<C> xin[kNT], n1[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) xin[nt] = xnext[nt];
+        if (tile + n_waves < n_tiles) fetch(tile + n_waves);
+        layernorm_c<C>(xin, n1, s_gb, g, a.eps);
+#pragma unroll 1
+        for (int p = 0; p < mt / 2; ++p) {                                   // output channels 32 p .. 32 p + 31: this lane's 8 g .. 8 g + 7 of them
+            f32x4 acc[2][kNT];
+            zero<2>(acc);
+            gemm_tiles<C, 2>(s_w, 2 * p, lane, n1, acc);
+            const f32x4 b0 = bias4(s_b, 2 * p, g), b1 = bias4(s_b, 2 * p + 1, g);
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                const size_t t = tile * 64 + 16 * nt + n;
+                if (t < a.tokens) *reinterpret_cast<uint4*>(a.out + t * a.cout + 32 * p + 8 * g) = pack_pair(acc[0][nt] + b0, acc[1][nt] + b1);
+            }
+        }
+    }
+}
+
+}  // namespace gf
+}  // namespace rc
+
+extern "C" int rc_ln_linear(const void* d_x, void* d_out, long long tokens, int c, int cout, const void* d_w, const float* d_b, const float* d_ln_gamma,
+                            const float* d_ln_beta, float eps, void* stream) {
+    using namespace rc;
+    using namespace rc::gf;
+    RC_REQUIRE(d_x && d_out && d_w && d_ln_gamma && d_ln_beta, "rc_ln_linear: null pointer");
+    RC_REQUIRE(tokens >= 1 && (c == 32 || c == 64) && cout >= 32 && cout % 32 == 0 && cout <= 512, "rc_ln_linear: width 32 / 64 -> a multiple of 32 (<= 512)");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_x) % 16 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0, "rc_ln_linear: misaligned tensor");
+    LnLinArgs a{static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_out), (size_t)tokens, cout, d_w, d_b, d_ln_gamma, d_ln_beta, eps};
+    const size_t lds = (size_t)(cout / 16) * tile_bytes(c) + (size_t)(cout + 2 * c) * 4;
+    const long long tiles = (tokens + 63) / 64;
+    long long grid = (tiles + 3) / 4;
+    const long long cap = (long long)device_cu_count() * 2;
+    if (grid > cap) grid = cap;
+#define RC_LL(CC)                                                                                                                          \
+    do {                                                                                                                                   \
+        static PerDeviceFlag attr;                                                                                                         \
+        if (!attr.test_and_set())                                                                                                          \
+            RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_linear_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
+        hipLaunchKernelGGL((ln_linear_kernel<CC>), dim3((unsigned)grid), dim3(kMlpThreads), lds, as_stream(stream), a);                    \
+    } while (0)
+    if (c == 32) RC_LL(32); else RC_LL(64);
+#undef RC_LL
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}

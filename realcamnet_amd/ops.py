@@ -541,6 +541,16 @@ def ln_mlp(x: torch.Tensor, ln, fc1, fc2):
                      b2 if fc2.bias is not None else None)
 
 
+def ln_linear(x: torch.Tensor, ln, lin):
+    """lin(ln(x)) in ONE launch (realcam::ln_linear) for bf16 tokens of width 32 / 64 and an output width that is a multiple of 32; None otherwise."""
+    c, cout = x.shape[-1], lin.weight.shape[0]
+    if not (FUSE_MLP and x.dtype == torch.bfloat16 and c in (32, 64) and lin.weight.dim() == 2 and lin.weight.shape[1] == c and cout % 32 == 0 and
+            cout <= 512 and tuple(ln.normalized_shape) == (c,)):
+        return None
+    w, b = packed_chain(lin)
+    return _R.ln_linear(_req(x, "tokens"), f32_param(ln, "weight"), f32_param(ln, "bias"), float(ln.eps), w, b if lin.bias is not None else None, int(cout))
+
+
 def lsc_chain(lsc, coord: torch.Tensor, head=None, raw: Optional[torch.Tensor] = None):
     """Lens_Shading_Correction as ONE launch with register-resident activations (realcam::lsc_chain), bf16, width 48 or 128:
     head is None -> lsc(coord);  else -> head(raw) * (lsc(coord) + 1)  (upstream models/LiteISP.py:2012-2014).  Returns None when the

@@ -38,14 +38,17 @@ class WMSA(nn.Module):
             rel.view(2 * window_size - 1, 2 * window_size - 1, self.n_heads).transpose(1, 2).transpose(0, 1).contiguous())
         self.linear = nn.Linear(input_dim, output_dim)
 
-    def _attend(self, t, residual=None):
-        """t NHWC (b,h,w,c) (already normalised) -> linear(attention(t)) [+ residual]."""
+    def _attend(self, t, residual=None, ln=None):
+        """t NHWC (b,h,w,c) -> linear(attention(t)) [+ residual]; ln: the LayerNorm in front (applied here, fused into the embedding layer
+        where the shape allows), None when t is already normalised."""
         t = ops._req(t, "WMSA input")
         b, h, w, c = t.shape
         ws = self.window_size
         if c != self.input_dim or h % ws or w % ws:
             raise ValueError(f"WMSA: expected (b, h, w, {self.input_dim}) with h, w multiples of {ws}, got {tuple(t.shape)}")
-        qkv = ops.conv2d(t, self.embedding_layer)
+        qkv = ops.ln_linear(t, ln, self.embedding_layer) if ln is not None else None
+        if qkv is None:
+            qkv = ops.conv2d(t if ln is None else ops.layernorm(t, ln), self.embedding_layer)
         att = torch.ops.realcam.window_attention(qkv, ops.f32_param(self, "relative_position_params"), self.head_dim, ws,
                                                  0 if self.type == 'W' else ws // 2)
         return ops.conv2d(att, self.linear, residual=residual)
@@ -71,7 +74,7 @@ class Block(nn.Module):
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
         x = ops._req(x, "Block input")
-        x = self.msa._attend(ops.layernorm(x, self.ln1), residual=x)
+        x = self.msa._attend(x, residual=x, ln=self.ln1)
         y = ops.ln_mlp(x, self.ln2, self.mlp[0], self.mlp[2])             # bf16, width 32 / 64: one launch, activations in registers
         if y is not None:
             return y

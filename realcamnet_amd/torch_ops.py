@@ -646,3 +646,9 @@ define("ln_mlp(Tensor x, Tensor ln_gamma, Tensor ln_beta, float eps, Tensor w_fc
        lambda out, x, g, b, eps, w1, b1, w2, b2: check(lib().rc_ln_mlp(x.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], w1.data_ptr(),
                                                                        _p(b1), w2.data_ptr(), _p(b2), g.data_ptr(), b.data_ptr(), float(eps), _stream()),
                                                        "rc_ln_mlp"))
+
+define("ln_linear(Tensor x, Tensor ln_gamma, Tensor ln_beta, float eps, Tensor w, Tensor? b, int cout) -> Tensor",
+       lambda x, g, b, eps, w, bias, cout: x.new_empty((*x.shape[:-1], cout)),
+       lambda out, x, g, b, eps, w, bias, cout: check(lib().rc_ln_linear(x.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], cout,
+                                                                         w.data_ptr(), _p(bias), g.data_ptr(), b.data_ptr(), float(eps), _stream()),
+                                                      "rc_ln_linear"))
