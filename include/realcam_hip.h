@@ -257,6 +257,9 @@ int rc_space_to_depth2(const void* d_src, void* d_dst, int dtype, int batch, int
 /* nn.PixelShuffle(2) on NHWC maps of any width: dst (B,2H,2W,c)[2y+i][2x+j][k] = src (B,H,W,4c)[y][x][4k + 2i + j].  (rc_conv2d's
  * RC_OUT_PIXEL_SHUFFLE2 store covers c % 16 == 0; this is for the narrow tails, e.g. subpel_conv3x3(2N, 3, 2) of g_s.) */
 int rc_pixel_shuffle2(const void* d_src, void* d_dst, int dtype, int batch, int H, int W, int c_out, void* stream);
+/* The same shuffle written straight into NCHW: d_src (batch,H,W,4*c_out) NHWC -> d_dst (batch,c_out,2H,2W) -- the codecs' x_hat at the
+ * module boundary (subpel_conv3x3(2N, 3, 2) closing g_s, models/tcm.py:364) without a separate layout pass. */
+int rc_pixel_shuffle2_nchw(const void* d_src, void* d_dst, int dtype, int batch, int H, int W, int c_out, void* stream);
 /* GDN / inverse GDN around a 1x1 rc_conv2d:  rc_square gives x^2 (the conv input, weights gamma, bias beta);
  * rc_gdn_apply gives y = x * rsqrt(norm) (inverse=0) or x * sqrt(norm) (inverse=1), + identity if d_identity != NULL
  * (the residual add that follows the GDN in both residual blocks). */

@@ -92,6 +92,7 @@ _SIGS = {
     "rc_sft_apply": (C.c_int, [_P, _P, _P, _P, _P, _I, C.c_longlong, _P]),
     "rc_space_to_depth2": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "rc_pixel_shuffle2": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "rc_pixel_shuffle2_nchw": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "rc_square": (C.c_int, [_P, _P, _I, C.c_longlong, _P]),
     "rc_gdn_apply": (C.c_int, [_P, _P, _P, _P, _I, _I, C.c_longlong, _P]),
     "rc_channel_copy": (C.c_int, [_P, _I, _I, _P, _I, _I, _I, C.c_longlong, _I, _P]),

@@ -342,6 +342,21 @@ __global__ void pixel_shuffle2_kernel(const T* __restrict__ src, T* __restrict__
     }
 }
 
+// nn.PixelShuffle(2) straight into NCHW (the codecs' x_hat: subpel_conv3x3(2N, 3, 2) at the end of g_s, models/tcm.py:364): one thread per
+// output element in NCHW order, so stores are contiguous; the 4c-channel source pixel is re-read from cache by its 4c consumers.
+template <typename T>
+__global__ void pixel_shuffle2_nchw_kernel(const T* __restrict__ src, T* __restrict__ dst, int batch, int H, int W, int c) {
+    const size_t total = (size_t)batch * c * 2 * H * 2 * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t p = i;
+        const int ox = (int)(p % (2 * W)); p /= (2 * W);
+        const int oy = (int)(p % (2 * H)); p /= (2 * H);
+        const int k = (int)(p % c);
+        const int b = (int)(p / c);
+        dst[i] = src[(((size_t)b * H + (oy >> 1)) * W + (ox >> 1)) * (4 * c) + 4 * k + 2 * (oy & 1) + (ox & 1)];
+    }
+}
+
 // ---- GDN pieces: y = x*x;  y = x * rsqrt(norm) | x * sqrt(norm)  (+ identity) ----------------------------------
 template <typename T>
 __global__ void square_kernel(const T* __restrict__ x, T* __restrict__ y, size_t total) {
@@ -710,6 +725,21 @@ int rc_pixel_shuffle2(const void* d_src, void* d_dst, int dtype, int batch, int 
                            static_cast<const float*>(d_src), static_cast<float*>(d_dst), batch, H, W, c_out);
     else
         hipLaunchKernelGGL(pixel_shuffle2_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const bf16_t*>(d_src), static_cast<bf16_t*>(d_dst), batch, H, W, c_out);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_pixel_shuffle2_nchw(const void* d_src, void* d_dst, int dtype, int batch, int H, int W, int c_out, void* stream) {
+    RC_REQUIRE(d_src && d_dst, "rc_pixel_shuffle2_nchw: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_pixel_shuffle2_nchw: bad dtype");
+    RC_REQUIRE(batch >= 1 && H >= 1 && W >= 1 && c_out >= 1, "rc_pixel_shuffle2_nchw: bad shape");
+    const size_t total = (size_t)batch * 4 * H * W * c_out;
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(pixel_shuffle2_nchw_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
+                           static_cast<const float*>(d_src), static_cast<float*>(d_dst), batch, H, W, c_out);
+    else
+        hipLaunchKernelGGL(pixel_shuffle2_nchw_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
                            static_cast<const bf16_t*>(d_src), static_cast<bf16_t*>(d_dst), batch, H, W, c_out);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;

@@ -202,6 +202,14 @@ def ca_gate_linear(sums: torch.Tensor, hw: int, fc0, fc1) -> torch.Tensor:
     return _R.ca_gate(sums, int(hw), f32_param(fc0, "weight"), z, f32_param(fc1, "weight"), z)
 
 
+def pixel_shuffle2_nchw(x: torch.Tensor) -> torch.Tensor:
+    """nn.PixelShuffle(2) of an NHWC map (B,H,W,4c) written as NCHW (B,c,2H,2W): shuffle + module-boundary layout in one pass."""
+    x = _req(x, "pixel_shuffle2_nchw input")
+    if x.dim() != 4 or x.shape[-1] % 4:
+        raise ValueError("pixel_shuffle2_nchw: (B,H,W,4c) expected")
+    return _R.pixel_shuffle2_nchw(x)
+
+
 def space_to_depth2(x: torch.Tensor) -> torch.Tensor:
     """(B,H,W,c) -> (B,ceil(H/2),ceil(W/2),4c), channel (2i+j)*c + k <- pixel (2y+i, 2x+j), zero beyond the edge."""
     return _R.space_to_depth2(_req(x, "space_to_depth2 input"))

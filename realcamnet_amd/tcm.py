@@ -737,8 +737,21 @@ def _codec_decompress(m, strings, shape, dtype, fmt):
         _, idx, _ = torch.ops.realcam.gc_symbols(None, None, scale, table, gc.scale_bound_value)
         sym = torch.stack([decoders[k].decode(idx[k]).view(idx.shape[1], idx.shape[2]) for k in range(b)])
         y_hat_slices.append(_refine(m, i, mean_support, torch.ops.realcam.gc_dequantize(sym, mu)))
-    x_hat = m.g_s._nhwc(ops.channel_concat(y_hat_slices))
-    return ops.to_nchw(x_hat).clamp_(0, 1)
+    return _synthesis_nchw(m, ops.channel_concat(y_hat_slices)).clamp_(0, 1)
+
+
+def _synthesis_nchw(m, y_hat):
+    """g_s(y_hat) as the NCHW image the module returns: when g_s ends in a narrow subpel_conv3x3 (conv -> PixelShuffle(2), 3 output
+    channels) the shuffle writes NCHW directly instead of an NHWC shuffle followed by a 3-channel layout pass."""
+    mods = list(m.g_s)
+    last = mods[-1]
+    if (isinstance(last, nn.Sequential) and len(last) == 2 and isinstance(last[0], N.Conv2d) and isinstance(last[1], nn.PixelShuffle) and
+            last[1].upscale_factor == 2 and (last[0].out_channels // 4) % 16 != 0):
+        a = y_hat
+        for mod in mods[:-1]:
+            a = mod._nhwc(a)
+        return ops.pixel_shuffle2_nchw(last[0]._nhwc(a))
+    return ops.to_nchw(m.g_s._nhwc(y_hat))
 
 
 def _slice_loop(m, y):
@@ -757,7 +770,7 @@ def _slice_loop(m, y):
         y_hat_slice, lik = m.gaussian_conditional._nhwc(y_slice, scale, mu)
         y_hat_slices.append(_refine(m, i, mean_support, y_hat_slice))
         y_lik.append(lik); mu_list.append(mu); scale_list.append(scale)
-    x_hat = m.g_s._nhwc(ops.channel_concat(y_hat_slices))
+    x_hat = _synthesis_nchw(m, ops.channel_concat(y_hat_slices))
     nchw = nchw_view
-    return {"x_hat": ops.to_nchw(x_hat), "likelihoods": {"y": nchw(ops.channel_concat(y_lik)), "z": nchw(z_lik)},
+    return {"x_hat": x_hat, "likelihoods": {"y": nchw(ops.channel_concat(y_lik)), "z": nchw(z_lik)},
             "para": {"means": nchw(ops.channel_concat(mu_list)), "scales": nchw(ops.channel_concat(scale_list)), "y": nchw(y)}}

@@ -652,3 +652,8 @@ define("ln_linear(Tensor x, Tensor ln_gamma, Tensor ln_beta, float eps, Tensor w
        lambda out, x, g, b, eps, w, bias, cout: check(lib().rc_ln_linear(x.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], cout,
                                                                          w.data_ptr(), _p(bias), g.data_ptr(), b.data_ptr(), float(eps), _stream()),
                                                       "rc_ln_linear"))
+
+define("pixel_shuffle2_nchw(Tensor x) -> Tensor",
+       lambda x: x.new_empty((x.shape[0], x.shape[3] // 4, 2 * x.shape[1], 2 * x.shape[2])),
+       lambda out, x: check(lib().rc_pixel_shuffle2_nchw(x.data_ptr(), out.data_ptr(), _dt(x), x.shape[0], x.shape[1], x.shape[2], x.shape[3] // 4,
+                                                         _stream()), "rc_pixel_shuffle2_nchw"))
