@@ -395,6 +395,13 @@ int rc_ln_mlp(const void* d_x, void* d_out, long long tokens, int c, const void*
 int rc_ln_linear(const void* d_x, void* d_out, long long tokens, int c, int cout, const void* d_w, const float* d_b, const float* d_ln_gamma,
                  const float* d_ln_beta, float eps, void* stream);
 
+/* GDN / inverse GDN (compressai.layers.GDN inside ResidualBlockWithStride / ResidualBlockUpsample; call sites models/tcm.py:336-364) as one
+ * per-token launch: d_out = d_x * rsqrt(beta + gamma . d_x^2)  (inverse != 0: * sqrt(..))  [+ d_identity], bf16, c = 64 or 128 channels,
+ * tensors (tokens, c).  d_gamma_packed = rc_chain_pack_weights of the EFFECTIVE (re-parametrised) gamma (c, c), d_beta_packed =
+ * rc_chain_pack_bias of the effective beta.  Same rounding points as rc_square -> rc_conv2d -> rc_gdn_apply. */
+int rc_gdn_chain(const void* d_x, const void* d_identity, void* d_out, long long tokens, int c, const void* d_gamma_packed,
+                 const float* d_beta_packed, int inverse, void* stream);
+
 int rc_gma_kv_mfma_blocks(int n_tok);
 size_t rc_gma_kv_mfma_scratch_bytes(int batch, int n_tok);
 int rc_gma_kv_mfma(const void* d_qkvp, int batch, int n_tok, float scale, const float* d_kmax, float* d_scratch, float* d_ktv, void* stream);

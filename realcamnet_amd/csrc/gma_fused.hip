@@ -1556,3 +1556,94 @@ extern "C" int rc_ln_linear(const void* d_x, void* d_out, long long tokens, int 
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
+
+// =====================================================================================================================================
+// GDN / inverse GDN as one per-token chain:  y = x * rsqrt(beta + gamma . x^2)  (inverse: * sqrt(..))  [+ identity]
+// (compressai.layers.GDN inside ResidualBlockWithStride / ResidualBlockUpsample, call sites models/tcm.py:336-364).  Layer by layer this
+// is rc_square -> rc_conv2d (1x1, gamma / beta) -> rc_gdn_apply with the squared map and the norm map written and re-read; here the
+// token's channels go x^2 -> MFMA with gamma -> rsqrt -> scale in registers.  Rounding points as in the three-launch form (x^2 and the
+// norm are rounded to bf16 where that form stores them).  bf16, C = 64 or 128.
+namespace rc {
+namespace gf {
+
+struct GdnArgs { const bf16_t* x; const bf16_t* idn; bf16_t* out; size_t tokens; const void* w; const float* b; int inverse; };
+
+template <int C>
+__global__ __launch_bounds__(kMlpThreads, 2) void gdn_chain_kernel(const GdnArgs a) {
+    constexpr int MT = C / 16, KS = C / 32, TB = tile_bytes(C);
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* s_w = lds;
+    float* s_b = reinterpret_cast<float*>(lds + MT * TB);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < MT * TB / 16; i += kMlpThreads) reinterpret_cast<uint4*>(s_w)[i] = reinterpret_cast<const uint4*>(a.w)[i];
+    for (int i = tid; i < C; i += kMlpThreads) s_b[i] = a.b ? a.b[i] : 0.f;
+    __syncthreads();
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const size_t n_tiles = (a.tokens + 63) / 64, n_waves = (size_t)gridDim.x * (kMlpThreads / 64);
+    for (size_t tile = (size_t)blockIdx.x * (kMlpThreads / 64) + (tid >> 6); tile < n_tiles; tile += n_waves) {
+        Act<C> xin[kNT], sq[kNT];
+        size_t tok[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            const size_t t = tile * 64 + 16 * nt + n;
+            tok[nt] = t < a.tokens ? t : a.tokens - 1;
+            load_act<C>(a.x + tok[nt] * C, g, xin[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const f32x4 lo = up_lo(xin[nt].f[s]), hi = up_hi(xin[nt].f[s]);
+                sq[nt].f[s] = pack_pair(lo * lo, hi * hi);
+            }
+#pragma unroll 1
+        for (int p = 0; p < KS; ++p) {
+            f32x4 acc[2][kNT];
+            zero<2>(acc);
+            gemm_tiles<C, 2>(s_w, 2 * p, lane, sq, acc);
+            const f32x4 b0 = bias4(s_b, 2 * p, g), b1 = bias4(s_b, 2 * p + 1, g);
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                const uint4 nb = pack_pair(acc[0][nt] + b0, acc[1][nt] + b1);        // the norm as the three-launch form stores it
+                const f32x4 n0 = up_lo(nb), n1 = up_hi(nb);
+                f32x4 r0, r1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r0[e] = a.inverse ? sqrtf(n0[e]) : 1.f / sqrtf(n0[e]);
+                    r1[e] = a.inverse ? sqrtf(n1[e]) : 1.f / sqrtf(n1[e]);
+                }
+                // the K-step-p fragment of x holds exactly these 8 channels (32 p + 8 g ..): no cross-lane movement
+                f32x4 y0 = up_lo(xin[nt].f[p]) * r0, y1 = up_hi(xin[nt].f[p]) * r1;
+                if (a.idn != nullptr) {
+                    const uint4 iv = *reinterpret_cast<const uint4*>(a.idn + tok[nt] * C + 32 * p + 8 * g);
+                    y0 += up_lo(iv); y1 += up_hi(iv);
+                } else { y0 = y0 + 0.f; y1 = y1 + 0.f; }
+                if (tile * 64 + 16 * nt + n < a.tokens) *reinterpret_cast<uint4*>(a.out + tok[nt] * C + 32 * p + 8 * g) = pack_pair(y0, y1);
+            }
+        }
+    }
+}
+
+}  // namespace gf
+}  // namespace rc
+
+extern "C" int rc_gdn_chain(const void* d_x, const void* d_identity, void* d_out, long long tokens, int c, const void* d_gamma_packed,
+                            const float* d_beta_packed, int inverse, void* stream) {
+    using namespace rc;
+    using namespace rc::gf;
+    RC_REQUIRE(d_x && d_out && d_gamma_packed, "rc_gdn_chain: null pointer");
+    RC_REQUIRE(tokens >= 1 && (c == 64 || c == 128), "rc_gdn_chain: 64 or 128 channels");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_x) % 16 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0 &&
+               (d_identity == nullptr || reinterpret_cast<uintptr_t>(d_identity) % 16 == 0), "rc_gdn_chain: misaligned tensor");
+    GdnArgs a{static_cast<const bf16_t*>(d_x), static_cast<const bf16_t*>(d_identity), static_cast<bf16_t*>(d_out), (size_t)tokens, d_gamma_packed,
+              d_beta_packed, inverse};
+    const size_t lds = (size_t)(c / 16) * tile_bytes(c) + (size_t)c * 4;
+    const long long tiles = (tokens + 63) / 64;
+    long long grid = (tiles + 3) / 4;
+    const long long cap = (long long)device_cu_count() * 4;
+    if (grid > cap) grid = cap;
+    if (c == 64) hipLaunchKernelGGL((gdn_chain_kernel<64>), dim3((unsigned)grid), dim3(kMlpThreads), lds, as_stream(stream), a);
+    else hipLaunchKernelGGL((gdn_chain_kernel<128>), dim3((unsigned)grid), dim3(kMlpThreads), lds, as_stream(stream), a);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}

@@ -243,7 +243,7 @@ def _stride2_view(mod) -> "_ConvView":
     return hit[1]
 
 
-def conv_stride2(x: torch.Tensor, mod, **fuse):
+def conv_stride2(x: torch.Tensor, mod, s2d: Optional[torch.Tensor] = None, **fuse):
     """kxk stride-2 padding-k//2 convolution (k in {1, 3}) as a stride-1 rc_conv2d at the OUTPUT resolution over the
     space-to-depth map (4c channels, re-indexed taps; bf16: a 2x2 window, 9 of 16 (tap, phase) blocks non-zero; fp32: the 3x3 embedding,
     9 of 36).  1x1 with a vectorisable channel count: sample (rc_subsample2), then convolve."""
@@ -257,7 +257,7 @@ def conv_stride2(x: torch.Tensor, mod, **fuse):
         if view is None or view.weight is not mod.weight or view.bias is not mod.bias:
             view = cache["stride2_view"] = _ConvView(mod.weight, mod.bias)
         return conv2d(subsample2(x), view, **fuse)
-    return conv2d(space_to_depth2(x), _stride2_view(mod), **fuse)
+    return conv2d(space_to_depth2(x) if s2d is None else s2d, _stride2_view(mod), **fuse)     # s2d: the caller's shared space-to-depth map of x
 
 
 def entropy_bottleneck(z: torch.Tensor, params: torch.Tensor, medians: torch.Tensor, bound: float = 1e-9):

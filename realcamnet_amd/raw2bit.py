@@ -267,14 +267,19 @@ class HybridConditionModule(nn.Module):
                                       N.Conv2d(c, c, 3, 2, 1))
 
     @staticmethod
-    def _cond(net, y):
+    def _cond(net, y, s2d=None):
+        """s2d: the space-to-depth map of y, shared by the three CondNets (each starts with a stride-2 3x3 conv of the same 64-channel
+        full-resolution map: three separate 2.3 GB re-layout passes at 4K x 4 otherwise)."""
         mods = list(net)
         i = 0
         while i < len(mods):
             kw = {}
             if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
                 kw = dict(act="leaky", slope=float(mods[i + 1].negative_slope))
-            y = mods[i]._nhwc(y, **kw)
+            if i == 0 and s2d is not None and tuple(mods[0].stride) == (2, 2) and mods[0].kernel_size[0] == 3 and ops.is_stride2(mods[0]):
+                y = ops.conv_stride2(y, mods[0], s2d=s2d, **kw)
+            else:
+                y = mods[i]._nhwc(y, **kw)
             i += 2 if kw else 1
         return y
 
@@ -287,7 +292,8 @@ class HybridConditionModule(nn.Module):
         y = self.dec_2._nhwc(y, x2)
         y = self.dec_3._nhwc(y, x1)
         y = self.out_conv._nhwc(y)
-        return [self._cond(self.CondNet1, y), self._cond(self.CondNet2, y), self._cond(self.CondNet3, y)]
+        s2d = ops.space_to_depth2(y)
+        return [self._cond(self.CondNet1, y, s2d), self._cond(self.CondNet2, y, s2d), self._cond(self.CondNet3, y, s2d)]
 
     def forward(self, x):
         if x.shape[-1] % 8 or x.shape[-2] % 8:

@@ -312,6 +312,10 @@ class GDN(nn.Module):
         return hit[1]
 
     def _nhwc(self, a, identity=None):
+        if ops.FUSE_MLP and a.dtype == torch.bfloat16 and a.shape[-1] in (64, 128):        # one per-token launch (rc_gdn_chain)
+            w, b = ops.packed_chain(self._effective())
+            idn = ops._req(identity, "identity") if identity is not None else None
+            return torch.ops.realcam.gdn_chain(ops._req(a, "GDN input"), idn, w, b, self.inverse)
         norm = ops.conv2d(ops.square(a), self._effective())
         return ops.gdn_apply(a, norm, self.inverse, identity)
 

@@ -657,3 +657,8 @@ define("pixel_shuffle2_nchw(Tensor x) -> Tensor",
        lambda x: x.new_empty((x.shape[0], x.shape[3] // 4, 2 * x.shape[1], 2 * x.shape[2])),
        lambda out, x: check(lib().rc_pixel_shuffle2_nchw(x.data_ptr(), out.data_ptr(), _dt(x), x.shape[0], x.shape[1], x.shape[2], x.shape[3] // 4,
                                                          _stream()), "rc_pixel_shuffle2_nchw"))
+
+define("gdn_chain(Tensor x, Tensor? identity, Tensor gamma_packed, Tensor beta_packed, bool inverse) -> Tensor",
+       lambda x, idn, w, b, inv: torch.empty_like(x),
+       lambda out, x, idn, w, b, inv: check(lib().rc_gdn_chain(x.data_ptr(), _p(idn), out.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], w.data_ptr(),
+                                                               b.data_ptr(), 1 if inv else 0, _stream()), "rc_gdn_chain"))

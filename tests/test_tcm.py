@@ -706,3 +706,31 @@ def test_hip_block_mlp_as_one_launch_vs_layer_by_layer(c):
     assert rel_err(fused.float().cpu(), layered.float().cpu()) < 2e-2
     assert LO.psnr(fused.float().cpu(), ref) > 45.0 and LO.psnr(layered.float().cpu(), ref) > 45.0
     assert torch.equal(odd.reshape(-1, c), fused.reshape(-1, c)[:1901])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("c", [64, 128])
+def test_hip_gdn_as_one_launch_vs_three(c, inverse):
+    """rc_gdn_chain (square -> gamma product on MFMA -> rsqrt / sqrt -> scale [+ identity] in registers) against rc_square -> rc_conv2d ->
+    rc_gdn_apply on the same bf16 inputs, and against the fp32 definition; ragged token count, with and without the identity operand."""
+    import realcamnet_amd.tcm as T
+    from realcamnet_amd import ops as OPS
+    torch.manual_seed(c + inverse)
+    gdn = T.GDN(c, inverse=inverse).eval()
+    sd = gdn.state_dict(); det_fill_({"g.igdn." + k if inverse else "g.gdn." + k: v for k, v in sd.items()})
+    x, idn = torch.randn(2, 19, 27, c), torch.randn(2, 19, 27, c)
+    with torch.no_grad():
+        want = TO.gdn({"g." + k: v for k, v in sd.items()}, "g", x.permute(0, 3, 1, 2), inverse).permute(0, 2, 3, 1)
+    gdn = gdn.to("cuda", torch.bfloat16)
+    xb, ib = x.cuda().bfloat16(), idn.cuda().bfloat16()
+    outs = {}
+    for fuse in (True, False):
+        old, OPS.FUSE_MLP = OPS.FUSE_MLP, fuse
+        try:
+            with torch.no_grad():
+                outs[fuse] = (gdn._nhwc(xb).float().cpu(), gdn._nhwc(xb, ib).float().cpu())
+        finally:
+            OPS.FUSE_MLP = old
+    assert rel_err(outs[True][0], outs[False][0]) < 2e-2 and rel_err(outs[True][1], outs[False][1]) < 2e-2
+    assert rel_err(outs[True][0], want) < 3e-2 and rel_err(outs[True][1], want + idn) < 3e-2
