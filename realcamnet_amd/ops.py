@@ -160,6 +160,24 @@ class _ConvView:
         self.weight, self.bias = weight, bias
 
 
+def split_conv_views(mod, sizes):
+    """Views of a convolution's output channels [0, s0), [s0, s0 + s1), ...: `torch.split(conv(x), sizes, dim=1)` (upstream models/tcm.py:261)
+    as separate convolutions of the same input -- the input is read once more, the full-width result and its slice copies never exist."""
+    cache = _cache(mod)
+    key = _key(mod.weight, mod.bias)
+    hit = cache.get("split_views")
+    if hit is None or hit[0] != (key, tuple(sizes)):
+        views, c0 = [], 0
+        for n in sizes:
+            views.append(_ConvView(mod.weight.detach()[c0:c0 + n], mod.bias.detach()[c0:c0 + n] if mod.bias is not None else None))
+            c0 += n
+        if c0 != mod.weight.shape[0]:
+            raise ValueError("split_conv_views: sizes do not add up to the convolution's output channels")
+        hit = ((key, tuple(sizes)), views)
+        cache["split_views"] = hit
+    return hit[1]
+
+
 def is_down2x2(mod) -> bool:
     """nn.Conv2d(c, c2, kernel_size=2, stride=2) without padding: the ISPUNet family's down-sampler (LiteISP.py:1253)."""
     return (tuple(mod.kernel_size) == (2, 2) and tuple(mod.stride) == (2, 2) and tuple(mod.padding) == (0, 0) and

@@ -138,9 +138,8 @@ class ConvTransBlock(nn.Module):
         self.conv_block = ResidualBlock(conv_dim, conv_dim)
 
     def _nhwc(self, a):
-        t = self.conv1_1._nhwc(a)
-        conv_x = ops.channel_slice(t, 0, self.conv_dim)
-        trans_x = ops.channel_slice(t, self.conv_dim, self.trans_dim)
+        va, vb = ops.split_conv_views(self.conv1_1, (self.conv_dim, self.trans_dim))     # torch.split(conv1_1(x)) without the slice copies
+        conv_x, trans_x = ops.conv2d(a, va), ops.conv2d(a, vb)
         conv_x = ops.add(self.conv_block._nhwc(conv_x), conv_x)
         trans_x = self.trans_block(trans_x)
         return self.conv1_2._nhwc(ops.channel_concat([conv_x, trans_x]), residual=a)
