@@ -1075,47 +1075,84 @@ __global__ __launch_bounds__(lsc_threads<C>(), 2) void lsc_chain_kernel(const Ls
         const LscIn in = nxt;
         if (tile + n_waves < n_tiles) lsc_load<HEAD>(a, (tile + n_waves) * 64, n, g, r_x, r_raw, nxt);     // next tile's operands in flight
         Act<C> cur[kNT];
-        {   // layer 0
-            f32x4 acc[MT][kNT];
+        {   // layer 0, one output tile pair at a time (the accumulators of all MT tiles are never live together)
+            auto leaky = [&](f32x4 v) { const f32x4 sl = v * a.slope; return f32x4{fmaxf(v[0], sl[0]), fmaxf(v[1], sl[1]), fmaxf(v[2], sl[2]), fmaxf(v[3], sl[3])}; };
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const uint2 w = *reinterpret_cast<const uint2*>(s_l0 + m * 512 + lane * 8);
+            for (int p = 0; p < MT / 2; ++p) {
+                const uint2 w0 = *reinterpret_cast<const uint2*>(s_l0 + (2 * p) * 512 + lane * 8), w1 = *reinterpret_cast<const uint2*>(s_l0 + (2 * p + 1) * 512 + lane * 8);
+                const f32x4 b0 = bias4(s_b, 2 * p, g), b1 = bias4(s_b, 2 * p + 1, g);
 #pragma unroll
-                for (int nt = 0; nt < kNT; ++nt) { acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f}; mma16(w, in.x[nt], acc[m][nt]); }
+                for (int nt = 0; nt < kNT; ++nt) {
+                    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+                    mma16(w0, in.x[nt], a0); mma16(w1, in.x[nt], a1);
+                    cur[nt].f[p] = pack_pair(leaky(a0 + b0), leaky(a1 + b1));
+                }
             }
-            lsc_pack<C, true>(acc, s_b, g, a.slope, cur);
+            if constexpr (MT & 1) {
+                const uint2 w0 = *reinterpret_cast<const uint2*>(s_l0 + (MT - 1) * 512 + lane * 8);
+                const f32x4 b0 = bias4(s_b, MT - 1, g);
+#pragma unroll
+                for (int nt = 0; nt < kNT; ++nt) {
+                    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mma16(w0, in.x[nt], a0);
+                    cur[nt].t = pack_tail(leaky(a0 + b0));
+                }
+            }
         }
 #pragma unroll 1
         for (int l = 0; l < a.n_mid; ++l) {
-            f32x4 acc[MT][kNT];
-            gemm_fresh<C, MT>(s_mid + l * MT * TBM, lane, cur, acc);
-            if (l + 1 < a.n_mid) lsc_pack<C, true>(acc, s_b + (1 + l) * MT * 16, g, a.slope, cur);
-            else lsc_pack<C, false>(acc, s_b + (1 + l) * MT * 16, g, a.slope, cur);
-        }
-        if constexpr (HEAD) {   // out = (conv3x3(raw) + bias) * (lsc + 1), lsc = cur as the two-launch path would re-read it (bf16)
-            f32x4 acc[MT][kNT];
+            if constexpr (MT <= 4) {
+                f32x4 acc[MT][kNT];
+                gemm_fresh<C, MT>(s_mid + l * MT * TBM, lane, cur, acc);
+                if (l + 1 < a.n_mid) lsc_pack<C, true>(acc, s_b + (1 + l) * MT * 16, g, a.slope, cur);
+                else lsc_pack<C, false>(acc, s_b + (1 + l) * MT * 16, g, a.slope, cur);
+            } else {      // wide chains: 4 output tiles at a time (all MT accumulators + both activation sets do not fit 256 registers)
+                static_assert(MT % 4 == 0, "wide chain: whole groups of 4 output tiles");
+                Act<C> nxt[kNT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const uint4 w4 = *reinterpret_cast<const uint4*>(s_head + m * 1536 + lane * 16);
-                const uint2 w2 = *reinterpret_cast<const uint2*>(s_head + m * 1536 + 1024 + lane * 8);
+                for (int h = 0; h < MT / 4; ++h) {
+                    f32x4 acc[4][kNT];
+                    gemm_fresh<C, 4>(s_mid + (l * MT + 4 * h) * TBM, lane, cur, acc);
+                    const float* bias = s_b + (1 + l) * MT * 16 + 4 * h * 16;
+                    const bool act = l + 1 < a.n_mid;
 #pragma unroll
-                for (int nt = 0; nt < kNT; ++nt) {
-                    acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    mma32(w4, in.rf[nt], acc[m][nt]); mma16(w2, in.rt[nt], acc[m][nt]);
+                    for (int p = 0; p < 2; ++p) {
+                        const f32x4 b0 = bias4(bias, 2 * p, g), b1 = bias4(bias, 2 * p + 1, g);
+#pragma unroll
+                        for (int nt = 0; nt < kNT; ++nt) {
+                            f32x4 v0 = acc[2 * p][nt] + b0, v1 = acc[2 * p + 1][nt] + b1;
+                            if (act) {
+                                const f32x4 s0 = v0 * a.slope, s1 = v1 * a.slope;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], s0[e]); v1[e] = fmaxf(v1[e], s1[e]); }
+                            }
+                            nxt[nt].f[2 * h + p] = pack_pair(v0, v1);
+                        }
+                    }
                 }
+#pragma unroll
+                for (int nt = 0; nt < kNT; ++nt) cur[nt] = nxt[nt];
             }
+        }
+        if constexpr (HEAD) {   // out = (conv3x3(raw) + bias) * (lsc + 1), lsc = cur as the two-launch path would re-read it (bf16); pair by pair
             const float* hb = s_b + (1 + a.n_mid) * MT * 16;
+            auto head_tile = [&](int m, int nt) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                mma32(*reinterpret_cast<const uint4*>(s_head + m * 1536 + lane * 16), in.rf[nt], acc);
+                mma16(*reinterpret_cast<const uint2*>(s_head + m * 1536 + 1024 + lane * 8), in.rt[nt], acc);
+                return acc;
+            };
 #pragma unroll
             for (int p = 0; p < MT / 2; ++p) {
                 const f32x4 b0 = bias4(hb, 2 * p, g), b1 = bias4(hb, 2 * p + 1, g);
 #pragma unroll
                 for (int nt = 0; nt < kNT; ++nt)
-                    cur[nt].f[p] = pack_pair((acc[2 * p][nt] + b0) * (up_lo(cur[nt].f[p]) + 1.f), (acc[2 * p + 1][nt] + b1) * (up_hi(cur[nt].f[p]) + 1.f));
+                    cur[nt].f[p] = pack_pair((head_tile(2 * p, nt) + b0) * (up_lo(cur[nt].f[p]) + 1.f), (head_tile(2 * p + 1, nt) + b1) * (up_hi(cur[nt].f[p]) + 1.f));
             }
             if constexpr (MT & 1) {
                 const f32x4 b0 = bias4(hb, MT - 1, g);
 #pragma unroll
-                for (int nt = 0; nt < kNT; ++nt) cur[nt].t = pack_tail((acc[MT - 1][nt] + b0) * (up_tail(cur[nt].t) + 1.f));
+                for (int nt = 0; nt < kNT; ++nt) cur[nt].t = pack_tail((head_tile(MT - 1, nt) + b0) * (up_tail(cur[nt].t) + 1.f));
             }
         }
 #pragma unroll
@@ -1581,23 +1618,30 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gdn_chain_kernel(const GdnArgs
     const int lane = tid & 63, n = lane & 15, g = lane >> 4;
     const size_t n_tiles = (a.tokens + 63) / 64, n_waves = (size_t)gridDim.x * (kMlpThreads / 64);
     for (size_t tile = (size_t)blockIdx.x * (kMlpThreads / 64) + (tid >> 6); tile < n_tiles; tile += n_waves) {
-        Act<C> xin[kNT], sq[kNT];
+        Act<C> sq[kNT];                                                      // x^2 as the three-launch form stores it (bf16)
         size_t tok[kNT];
 #pragma unroll
         for (int nt = 0; nt < kNT; ++nt) {
             const size_t t = tile * 64 + 16 * nt + n;
             tok[nt] = t < a.tokens ? t : a.tokens - 1;
-            load_act<C>(a.x + tok[nt] * C, g, xin[nt]);
+            load_act<C>(a.x + tok[nt] * C, g, sq[nt]);
         }
 #pragma unroll
         for (int nt = 0; nt < kNT; ++nt)
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const f32x4 lo = up_lo(xin[nt].f[s]), hi = up_hi(xin[nt].f[s]);
+                const f32x4 lo = up_lo(sq[nt].f[s]), hi = up_hi(sq[nt].f[s]);
                 sq[nt].f[s] = pack_pair(lo * lo, hi * hi);
             }
 #pragma unroll 1
         for (int p = 0; p < KS; ++p) {
+            // this step's 8 channels of x (32 p + 8 g ..) and of the identity: re-read (cache-hot) under the MFMAs instead of held in registers
+            uint4 xv[kNT], iv[kNT];
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                xv[nt] = *reinterpret_cast<const uint4*>(a.x + tok[nt] * C + 32 * p + 8 * g);
+                iv[nt] = a.idn != nullptr ? *reinterpret_cast<const uint4*>(a.idn + tok[nt] * C + 32 * p + 8 * g) : make_uint4(0u, 0u, 0u, 0u);
+            }
             f32x4 acc[2][kNT];
             zero<2>(acc);
             gemm_tiles<C, 2>(s_w, 2 * p, lane, sq, acc);
@@ -1608,16 +1652,11 @@ __global__ __launch_bounds__(kMlpThreads, 2) void gdn_chain_kernel(const GdnArgs
                 const f32x4 n0 = up_lo(nb), n1 = up_hi(nb);
                 f32x4 r0, r1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    r0[e] = a.inverse ? sqrtf(n0[e]) : 1.f / sqrtf(n0[e]);
-                    r1[e] = a.inverse ? sqrtf(n1[e]) : 1.f / sqrtf(n1[e]);
+                for (int e = 0; e < 4; ++e) {                                    // v_rsq_f32 / v_sqrt_f32 (1 ulp in fp32, then bf16): the IEEE
+                    r0[e] = a.inverse ? __builtin_amdgcn_sqrtf(n0[e]) : __builtin_amdgcn_rsqf(n0[e]);   // division + square root sequences cost ~25
+                    r1[e] = a.inverse ? __builtin_amdgcn_sqrtf(n1[e]) : __builtin_amdgcn_rsqf(n1[e]);   // instructions per value
                 }
-                // the K-step-p fragment of x holds exactly these 8 channels (32 p + 8 g ..): no cross-lane movement
-                f32x4 y0 = up_lo(xin[nt].f[p]) * r0, y1 = up_hi(xin[nt].f[p]) * r1;
-                if (a.idn != nullptr) {
-                    const uint4 iv = *reinterpret_cast<const uint4*>(a.idn + tok[nt] * C + 32 * p + 8 * g);
-                    y0 += up_lo(iv); y1 += up_hi(iv);
-                } else { y0 = y0 + 0.f; y1 = y1 + 0.f; }
+                const f32x4 y0 = up_lo(xv[nt]) * r0 + up_lo(iv[nt]), y1 = up_hi(xv[nt]) * r1 + up_hi(iv[nt]);
                 if (tile * 64 + 16 * nt + n < a.tokens) *reinterpret_cast<uint4*>(a.out + tok[nt] * C + 32 * p + 8 * g) = pack_pair(y0, y1);
             }
         }
