@@ -265,7 +265,7 @@ class SWAtten(AttentionBlock):
 class _LowerBound(nn.Module):
     def __init__(self, bound: float):
         super().__init__()
-        self.register_buffer("bound", torch.Tensor([float(bound)]))
+        self.register_buffer("bound", torch.tensor([float(bound)], dtype=torch.float32))     # (torch.Tensor([..]) ignores the device context)
 
 
 class _NonNegativeParametrizer(nn.Module):
@@ -274,7 +274,7 @@ class _NonNegativeParametrizer(nn.Module):
     def __init__(self, minimum: float = 0.0, reparam_offset: float = 2 ** -18):
         super().__init__()
         pedestal = float(reparam_offset) ** 2
-        self.register_buffer("pedestal", torch.Tensor([pedestal]))
+        self.register_buffer("pedestal", torch.tensor([pedestal], dtype=torch.float32))
         self.lower_bound = _LowerBound((float(minimum) + pedestal) ** 0.5)
 
     def init(self, x):
@@ -299,7 +299,7 @@ class GDN(nn.Module):
         self.gamma = nn.Parameter(self.gamma_reparam.init(float(gamma_init) * torch.eye(in_channels)))
 
     def _effective(self):
-        key = (self.beta._version, self.gamma._version, self.beta.data_ptr(), self.gamma.data_ptr(), self.beta.dtype)
+        key = ops._key(self.beta, self.gamma)
         hit = getattr(self, "_eff", None)
         if hit is None or hit[0] != key:
             with torch.no_grad():
@@ -474,6 +474,10 @@ class EntropyBottleneck(nn.Module):
     def _packed(self):
         ps = [getattr(self, f"_matrix{i}") for i in range(5)] + [getattr(self, f"_bias{i}") for i in range(5)] + \
              [getattr(self, f"_factor{i}") for i in range(4)] + [self.quantiles]
+        from torch._subclasses.fake_tensor import FakeTensor
+        if isinstance(self.quantiles, FakeTensor):                          # shape tracing: nothing to pack on the host
+            q = self.quantiles
+            return q.new_empty((self.channels, 58), dtype=torch.float32), q.new_empty((self.channels,), dtype=torch.float32)
         key = tuple((p._version, p.data_ptr()) for p in ps)
         hit = getattr(self, "_pk", None)
         if hit is None or hit[0] != key:
@@ -519,7 +523,7 @@ class GaussianConditional(nn.Module):
         _register_coder_buffers(self, likelihood_bound)
         self.lower_bound_scale = _LowerBound(scale_bound)
         self.register_buffer("scale_table", torch.Tensor())
-        self.register_buffer("scale_bound", torch.Tensor([float(scale_bound)]))
+        self.register_buffer("scale_bound", torch.tensor([float(scale_bound)], dtype=torch.float32))
 
     def update_scale_table(self, scale_table, force: bool = False) -> bool:
         if self._offset.numel() > 0 and not force:

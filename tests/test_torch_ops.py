@@ -53,6 +53,30 @@ def test_fake_tensor_trace_of_whole_forwards(dt):
         torch.set_default_dtype(old)
 
 
+def test_fake_tensor_trace_of_the_codecs():
+    """The three codecs' forward under FakeTensorMode (no GPU, no library call): entropy models, GDN, window attention, slice loop, synthesis --
+    every launch is a registered op with a fake kernel, host-side parameter packing is skipped for fake parameters."""
+    import realcamnet_amd.raw2bit as RB
+    import realcamnet_amd.tcm as T
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with FakeTensorMode():
+            with torch.device("cuda"):
+                raw = [torch.empty(2, 4, 256, 256), torch.empty(2, 4, 64, 64), torch.empty(2, 2, 256, 256)]
+                for make, x, keys in ((lambda: RB.raw_compression_tcm_final(N=64), raw, {"x_hat", "likelihoods", "para", "y", "lft", "lsc"}),
+                                      (lambda: RB.raw_compression_tcm(N=64), raw, {"x_hat", "likelihoods", "para"}),
+                                      (lambda: T.TCM(N=64), torch.empty(2, 3, 256, 256), {"x_hat", "likelihoods", "para"})):
+                    net = make().eval()
+                    with torch.no_grad():
+                        out = net(x)
+                    assert set(out) == keys
+                    assert out["x_hat"].shape == ((2, 3, 512, 512) if x is raw else (2, 3, 256, 256)) and out["x_hat"].dtype == torch.bfloat16
+                    assert out["likelihoods"]["y"].shape == (2, 320, 16, 16) and out["likelihoods"]["z"].shape == (2, 192, 4, 4)
+    finally:
+        torch.set_default_dtype(old)
+
+
 def test_fake_kernels_of_single_ops():
     with FakeTensorMode():
         with torch.device("cuda"):
