@@ -734,3 +734,34 @@ def test_hip_gdn_as_one_launch_vs_three(c, inverse):
             OPS.FUSE_MLP = old
     assert rel_err(outs[True][0], outs[False][0]) < 2e-2 and rel_err(outs[True][1], outs[False][1]) < 2e-2
     assert rel_err(outs[True][0], want) < 3e-2 and rel_err(outs[True][1], want + idn) < 3e-2
+
+
+@pytest.mark.gpu
+def test_hip_small_fused_ops_of_the_codec():
+    """rc_pixel_shuffle2_nchw == F.pixel_shuffle bit for bit (both dtypes); rc_ln_linear vs rc_layernorm + rc_conv2d (bf16-ulp scale) on a
+    ragged token count; the two-convolution form of torch.split(conv1_1(x)) == slices of the full-width convolution bit for bit."""
+    import torch.nn.functional as F
+    from realcamnet_amd import ops as OPS, networks as NW
+    torch.manual_seed(9)
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(2, 12, 7, 9).to("cuda", dt)
+        got = OPS.pixel_shuffle2_nchw(OPS.to_nhwc(x))
+        assert torch.equal(got, F.pixel_shuffle(x, 2))
+    ln, lin = torch.nn.LayerNorm(64), torch.nn.Linear(64, 192)
+    x = torch.randn(1, 19, 101, 64) * 3
+    with torch.no_grad():
+        want = lin(ln(x))
+    ln, lin = ln.to("cuda", torch.bfloat16), lin.to("cuda", torch.bfloat16)
+    xb = x.cuda().bfloat16()
+    with torch.no_grad():
+        fused = OPS.ln_linear(xb, ln, lin)
+        layered = OPS.conv2d(OPS.layernorm(xb, ln), lin)
+    assert fused is not None and fused.shape == layered.shape == (1, 19, 101, 192)
+    assert rel_err(fused.float().cpu(), layered.float().cpu()) < 2e-2 and rel_err(fused.float().cpu(), want) < 3e-2
+    conv = NW.Conv2d(128, 128, 1, 1, 0).to("cuda", torch.bfloat16).eval()
+    a = torch.randn(2, 24, 40, 128, device="cuda").bfloat16()
+    with torch.no_grad():
+        full = conv._nhwc(a)
+        va, vb = OPS.split_conv_views(conv, (64, 64))
+        pa, pb = OPS.conv2d(a, va), OPS.conv2d(a, vb)
+    assert torch.equal(pa, full[..., :64]) and torch.equal(pb, full[..., 64:])
