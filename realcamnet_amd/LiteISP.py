@@ -320,13 +320,17 @@ class _DwtUNet(nn.Module):
 
     def _front(self, a, cond, coord_nhwc):
         """head(raw) [* (lsc(coord) + 1)] and the colour-prior vector (None without a classifier)."""
-        if hasattr(self, "lsc"):
+        def head():
+            if not hasattr(self, "lsc"):
+                return self.head._nhwc(a)
             h = ops.lsc_chain(self.lsc, coord_nhwc, self.head, a)       # h = head(raw) * (lsc + 1), one launch when 48-wide bf16
-            if h is None:
-                h = self.head._nhwc(a, mul_plus1=self.lsc._nhwc(coord_nhwc))
-        else:
-            h = self.head._nhwc(a)
-        vec = self.classifier._vec(ops._req(cond, "cond")) if hasattr(self, "classifier") else None
+            return h if h is not None else self.head._nhwc(a, mul_plus1=self.lsc._nhwc(coord_nhwc))
+
+        if not hasattr(self, "classifier"):
+            return head(), None
+        # the colour prior is a chain of ~10 tiny launches on the (small) cond image: on a side stream it runs under the head conv
+        cond = ops._req(cond, "cond")
+        vec, h = ops.fork_join(lambda: self.classifier._vec(cond), head, [cond])
         return h, vec
 
     def _trunk(self, h, vec, crop_hw=None):

@@ -551,6 +551,37 @@ def pointwise_chain(x: torch.Tensor, convs, slope: float) -> torch.Tensor:
     return _R.pointwise_chain48(x, p0.wpacked, p0.bias, [p.wpacked for p in packs], [p.bias for p in packs], float(slope))
 
 
+BRANCH_STREAMS = True        # run independent small sub-graphs (the codec's mean / scale branches, the ISP nets' colour prior) on two HIP streams
+_SIDE_STREAMS = {}
+
+
+def fork_join(side_fn, main_fn, inputs):
+    """(side_fn(), main_fn()) for two independent sub-graphs.  At the latent's size (1/16 of the packed frame) one launch covers about
+    half of the 256 CUs, so the two branches are enqueued on two streams and overlap: side_fn on a per-device side stream ordered behind the
+    current stream, main_fn on the current stream, which then waits for the side stream.  `inputs`: tensors side_fn reads (the caching
+    allocator is told about the second stream; the side branch's outputs likewise).  One stream under graph capture, fake tensors or
+    BRANCH_STREAMS = False."""
+    from torch._subclasses.fake_tensor import FakeTensor
+    probe = inputs[0]
+    if not BRANCH_STREAMS or not probe.is_cuda or isinstance(probe, FakeTensor) or torch.cuda.is_current_stream_capturing():
+        return side_fn(), main_fn()
+    main = torch.cuda.current_stream(probe.device)
+    side = _SIDE_STREAMS.get(probe.device.index)
+    if side is None:
+        side = _SIDE_STREAMS[probe.device.index] = torch.cuda.Stream(device=probe.device)
+    side.wait_stream(main)
+    for t in inputs:
+        t.record_stream(side)
+    with torch.cuda.stream(side):
+        a = side_fn()
+    b = main_fn()
+    main.wait_stream(side)
+    for t in (a if isinstance(a, (tuple, list)) else (a,)):
+        t.record_stream(main)
+    return a, b
+
+
+
 FUSE_MLP = True     # the codecs' transformer-block MLP (LayerNorm -> Linear -> GELU -> Linear -> + x) as one launch (rc_ln_mlp)
 
 

@@ -11,7 +11,7 @@ from realcamnet_amd import ops
 
 ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=4); ap.add_argument("--one-stream", action="store_true")
 a = ap.parse_args()
-T.BRANCH_STREAMS = not a.one_stream
+ops.BRANCH_STREAMS = not a.one_stream
 torch.manual_seed(0)
 g = torch.Generator().manual_seed(1)
 H, W, B, dt = 1152, 1920, a.frames, torch.bfloat16
@@ -50,7 +50,7 @@ for _ in range(3):
 tot = marks[0][1].elapsed_time(marks[-1][1])
 for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
     print(f"{n1:55s} {e0.elapsed_time(e1):8.2f} ms")
-print(f"{'total':55s} {tot:8.2f} ms   (B={B}, two streams: {T.BRANCH_STREAMS})")
+print(f"{'total':55s} {tot:8.2f} ms   (B={B}, two streams: {ops.BRANCH_STREAMS})")
 
 # ---- finer: every top-level stage of the analysis transform and of g_s
 if not a.one_stream:
