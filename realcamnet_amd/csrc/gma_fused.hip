@@ -159,9 +159,6 @@ __device__ __forceinline__ void layernorm80(const Act<kC> (&in)[kNT], Act<kC> (&
 // exact-erf GELU to 1.5e-7 absolute in erf (Abramowitz-Stegun 7.1.26), far below the bf16 rounding that follows:
 // 0.5 v (1 + erf(v / sqrt 2)),  erf(z) = sign(z) (1 - (a1 t + .. + a5 t^5) exp(-z^2)),  t = 1 / (1 + p |z|)
 __device__ __forceinline__ float gelu_erf(float v) {
-#ifdef GF_EXP_NOGELU
-    return v;
-#endif
     const float z = fabsf(v) * 0.70710678118654752f;
     const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
@@ -175,9 +172,6 @@ __device__ __forceinline__ float gelu_erf(float v) {
 // -- a reciprocal and four squarings instead of 7.1.26's reciprocal + exponential.  The MLP's GELU was 0.6 of the tail kernel's 1.9 ms in
 // the scalar form (16 VALU issues per value, two of them quarter-rate).  For large |v| the power overflows to +inf and erf saturates at 1.
 __device__ __forceinline__ f32x4 gelu_erf4(const f32x4 v) {
-#ifdef GF_EXP_NOGELU
-    return v;
-#endif
     const f32x4 z = f32x4{fabsf(v[0]), fabsf(v[1]), fabsf(v[2]), fabsf(v[3])} * 0.70710678118654752f;
     f32x4 p = __builtin_elementwise_fma(z, f32x4{0.0000430638f, 0.0000430638f, 0.0000430638f, 0.0000430638f}, f32x4{0.0002765672f, 0.0002765672f, 0.0002765672f, 0.0002765672f});
     p = __builtin_elementwise_fma(p, z, f32x4{0.0001520143f, 0.0001520143f, 0.0001520143f, 0.0001520143f});
