@@ -156,17 +156,7 @@ __device__ __forceinline__ void layernorm80(const Act<kC> (&in)[kNT], Act<kC> (&
     }
 }
 
-// exact-erf GELU to 1.5e-7 absolute in erf (Abramowitz-Stegun 7.1.26), far below the bf16 rounding that follows:
-// 0.5 v (1 + erf(v / sqrt 2)),  erf(z) = sign(z) (1 - (a1 t + .. + a5 t^5) exp(-z^2)),  t = 1 / (1 + p |z|)
-__device__ __forceinline__ float gelu_erf(float v) {
-    const float z = fabsf(v) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float e = 1.f - poly * __expf(-z * z);                        // erf(|z|)
-    return 0.5f * v * (1.f + copysignf(e, v));
-}
-
-// The same function on four values at once, written on vectors so that it compiles to packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32, two
+// exact-erf GELU, 0.5 v (1 + erf(v / sqrt 2)), on four values at once, written on vectors so that it compiles to packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32, two
 // lanes' worth per instruction) with ONE transcendental per value: Abramowitz-Stegun 7.1.28
 //     erf(z) = 1 - (1 + a1 z + .. + a6 z^6)^-16,  |error| <= 3e-7   (z >= 0; odd extension by sign)
 // -- a reciprocal and four squarings instead of 7.1.26's reciprocal + exponential.  The MLP's GELU was 0.6 of the tail kernel's 1.9 ms in
