@@ -1670,3 +1670,80 @@ extern "C" int rc_gdn_chain(const void* d_x, const void* d_identity, void* d_out
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
+
+// =====================================================================================================================================
+// Linear over the channel concatenation of two token maps, + residual:  out = res + W . [a ; b] + bias   (the closing
+// `conv1_2(torch.cat((conv_x, trans_x), dim=1)) + x` of ConvTransBlock, models/tcm.py:265-267 / raw2bit.py:324-327).  The two halves are read
+// straight into the K-steps of one activation fragment set, so the concatenated map is never written.  bf16, C = 64 or 128 (halves C/2).
+namespace rc {
+namespace gf {
+
+struct CatLinArgs { const bf16_t* a; const bf16_t* b; const bf16_t* res; bf16_t* out; size_t tokens; const void* w; const float* bias; };
+
+template <int C>
+__global__ __launch_bounds__(kMlpThreads, 2) void cat_linear_kernel(const CatLinArgs a) {
+    constexpr int MT = C / 16, KS = C / 32, H = C / 2, TB = tile_bytes(C);
+    static_assert(H % 32 == 0, "each half is a whole number of K-steps");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* s_w = lds;
+    float* s_b = reinterpret_cast<float*>(lds + MT * TB);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < MT * TB / 16; i += kMlpThreads) reinterpret_cast<uint4*>(s_w)[i] = reinterpret_cast<const uint4*>(a.w)[i];
+    for (int i = tid; i < C; i += kMlpThreads) s_b[i] = a.bias ? a.bias[i] : 0.f;
+    __syncthreads();
+    const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const size_t n_tiles = (a.tokens + 63) / 64, n_waves = (size_t)gridDim.x * (kMlpThreads / 64);
+    for (size_t tile = (size_t)blockIdx.x * (kMlpThreads / 64) + (tid >> 6); tile < n_tiles; tile += n_waves) {
+        Act<C> in[kNT];
+        size_t tok[kNT];
+#pragma unroll
+        for (int nt = 0; nt < kNT; ++nt) {
+            const size_t t = tile * 64 + 16 * nt + n;
+            tok[nt] = t < a.tokens ? t : a.tokens - 1;
+#pragma unroll
+            for (int s = 0; s < KS / 2; ++s) {
+                in[nt].f[s] = *reinterpret_cast<const uint4*>(a.a + tok[nt] * H + 32 * s + 8 * g);
+                in[nt].f[KS / 2 + s] = *reinterpret_cast<const uint4*>(a.b + tok[nt] * H + 32 * s + 8 * g);
+            }
+        }
+#pragma unroll 1
+        for (int p = 0; p < KS; ++p) {
+            uint4 rv[kNT];
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt)
+                rv[nt] = a.res != nullptr ? *reinterpret_cast<const uint4*>(a.res + tok[nt] * C + 32 * p + 8 * g) : make_uint4(0u, 0u, 0u, 0u);
+            f32x4 acc[2][kNT];
+            zero<2>(acc);
+            gemm_tiles<C, 2>(s_w, 2 * p, lane, in, acc);
+            const f32x4 b0 = bias4(s_b, 2 * p, g), b1 = bias4(s_b, 2 * p + 1, g);
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt)
+                if (tile * 64 + 16 * nt + n < a.tokens)
+                    *reinterpret_cast<uint4*>(a.out + tok[nt] * C + 32 * p + 8 * g) = pack_pair(acc[0][nt] + b0 + up_lo(rv[nt]), acc[1][nt] + b1 + up_hi(rv[nt]));
+        }
+    }
+}
+
+}  // namespace gf
+}  // namespace rc
+
+extern "C" int rc_cat_linear(const void* d_a, const void* d_b, const void* d_residual, void* d_out, long long tokens, int c, const void* d_w,
+                             const float* d_bias, void* stream) {
+    using namespace rc;
+    using namespace rc::gf;
+    RC_REQUIRE(d_a && d_b && d_out && d_w, "rc_cat_linear: null pointer");
+    RC_REQUIRE(tokens >= 1 && (c == 64 || c == 128), "rc_cat_linear: concatenated width 64 or 128");
+    for (const void* q : {d_a, d_b, d_residual, static_cast<const void*>(d_out)})
+        RC_REQUIRE(q == nullptr || reinterpret_cast<uintptr_t>(q) % 16 == 0, "rc_cat_linear: misaligned tensor");
+    CatLinArgs a{static_cast<const bf16_t*>(d_a), static_cast<const bf16_t*>(d_b), static_cast<const bf16_t*>(d_residual), static_cast<bf16_t*>(d_out),
+                 (size_t)tokens, d_w, d_bias};
+    const size_t lds = (size_t)(c / 16) * tile_bytes(c) + (size_t)c * 4;
+    const long long tiles = (tokens + 63) / 64;
+    long long grid = (tiles + 3) / 4;
+    const long long cap = (long long)device_cu_count() * 4;
+    if (grid > cap) grid = cap;
+    if (c == 64) hipLaunchKernelGGL((cat_linear_kernel<64>), dim3((unsigned)grid), dim3(kMlpThreads), lds, as_stream(stream), a);
+    else hipLaunchKernelGGL((cat_linear_kernel<128>), dim3((unsigned)grid), dim3(kMlpThreads), lds, as_stream(stream), a);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}

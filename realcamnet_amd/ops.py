@@ -608,6 +608,22 @@ def ln_linear(x: torch.Tensor, ln, lin):
     return _R.ln_linear(_req(x, "tokens"), f32_param(ln, "weight"), f32_param(ln, "bias"), float(ln.eps), w, b if lin.bias is not None else None, int(cout))
 
 
+def cat_linear(a: torch.Tensor, b: torch.Tensor, conv, residual: Optional[torch.Tensor] = None):
+    """conv(torch.cat((a, b), channels)) + residual for a 1x1 conv, without writing the concatenated map (realcam::cat_linear): bf16, two
+    equal halves of 32 / 64 channels, output width = input width.  None when the shapes are not of that form."""
+    ca, cb = a.shape[-1], b.shape[-1]
+    w = conv.weight
+    if not (FUSE_MLP and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and ca == cb and ca + cb in (64, 128) and a.shape[:-1] == b.shape[:-1] and
+            tuple(w.shape) == (ca + cb, ca + cb, 1, 1) and tuple(getattr(conv, "stride", (1, 1))) == (1, 1)):
+        return None
+    if residual is not None:
+        residual = _req(residual, "residual")
+        if residual.shape != (*a.shape[:-1], ca + cb) or residual.dtype != a.dtype:
+            raise ValueError("cat_linear: residual shape / dtype mismatch")
+    wp, bp = packed_chain(conv)
+    return _R.cat_linear(_req(a, "a"), _req(b, "b"), residual, wp, bp if conv.bias is not None else None)
+
+
 def lsc_chain(lsc, coord: torch.Tensor, head=None, raw: Optional[torch.Tensor] = None):
     """Lens_Shading_Correction as ONE launch with register-resident activations (realcam::lsc_chain), bf16, width 48 or 128:
     head is None -> lsc(coord);  else -> head(raw) * (lsc(coord) + 1)  (upstream models/LiteISP.py:2012-2014).  Returns None when the

@@ -98,7 +98,8 @@ class ConvTransBlock_mzj(nn.Module):
         conv_x, trans_x = ops.conv2d(a, va), ops.conv2d(a, vb)
         conv_x = self.spatial_transform._nhwc(self.conv_block._nhwc(conv_x), cond, identity=conv_x)
         trans_x = self.trans_block(trans_x)
-        return self.conv1_2._nhwc(ops.channel_concat([conv_x, trans_x]), residual=a), cond
+        y = ops.cat_linear(conv_x, trans_x, self.conv1_2, residual=a)          # conv1_2(cat(conv_x, trans_x)) + x without the concatenated map
+        return y if y is not None else self.conv1_2._nhwc(ops.channel_concat([conv_x, trans_x]), residual=a), cond
 
     def forward(self, xx):
         if self.training:
@@ -171,7 +172,8 @@ class ConvGMABlock(nn.Module):
         conv_x, trans_x = ops.conv2d(a, va), ops.conv2d(a, vb)
         conv_x = ops.add(self.conv_block._nhwc(conv_x), conv_x)
         trans_x = self.trans_block._nhwc(trans_x)
-        return self.conv1_2._nhwc(ops.channel_concat([conv_x, trans_x]), residual=a)
+        y = ops.cat_linear(conv_x, trans_x, self.conv1_2, residual=a)          # conv1_2(cat(conv_x, trans_x)) + x without the concatenated map
+        return y if y is not None else self.conv1_2._nhwc(ops.channel_concat([conv_x, trans_x]), residual=a)
 
     def forward(self, x):
         if self.training:

@@ -765,3 +765,27 @@ def test_hip_small_fused_ops_of_the_codec():
         va, vb = OPS.split_conv_views(conv, (64, 64))
         pa, pb = OPS.conv2d(a, va), OPS.conv2d(a, vb)
     assert torch.equal(pa, full[..., :64]) and torch.equal(pb, full[..., 64:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", [64, 128])
+def test_hip_cat_linear_vs_concat_then_conv(c):
+    """rc_cat_linear (conv1_2(cat(a, b)) + x with the halves read straight into the K-steps) against rc_channel_copy + rc_conv2d on the same bf16
+    inputs, and the fp32 composition; ragged token count, with and without the residual."""
+    import torch.nn.functional as F
+    from realcamnet_amd import ops as OPS, networks as NW
+    torch.manual_seed(c)
+    conv = NW.Conv2d(c, c, 1, 1, 0)
+    a, b, x = torch.randn(2, 21, 37, c // 2), torch.randn(2, 21, 37, c // 2), torch.randn(2, 21, 37, c)
+    with torch.no_grad():
+        want = F.conv2d(torch.cat((a, b), -1).permute(0, 3, 1, 2), conv.weight, conv.bias).permute(0, 2, 3, 1) + x
+    conv = conv.to("cuda", torch.bfloat16).eval()
+    ab, bb, xb = a.cuda().bfloat16(), b.cuda().bfloat16(), x.cuda().bfloat16()
+    with torch.no_grad():
+        fused = OPS.cat_linear(ab, bb, conv, residual=xb)
+        layered = conv._nhwc(OPS.channel_concat([ab, bb]), residual=xb)
+        nores = OPS.cat_linear(ab, bb, conv)
+        nores_l = conv._nhwc(OPS.channel_concat([ab, bb]))
+    assert fused is not None and fused.shape == layered.shape == (2, 21, 37, c)
+    assert rel_err(fused.float().cpu(), layered.float().cpu()) < 2e-2 and rel_err(fused.float().cpu(), want) < 3e-2
+    assert rel_err(nores.float().cpu(), nores_l.float().cpu()) < 2e-2
