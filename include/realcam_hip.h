@@ -405,9 +405,10 @@ int rc_gdn_chain(const void* d_x, const void* d_identity, void* d_out, long long
 /* Linear over the channel concatenation of two token maps + residual, without the concatenated map (the closing
  * `conv1_2(torch.cat((conv_x, trans_x), dim=1)) + x` of ConvTransBlock, models/tcm.py:265-267; raw2bit.py:324-327):
  * d_out (tokens, c) = d_residual + W . [d_a (tokens, c/2) ; d_b (tokens, c/2)] + bias.  bf16, c = 64 or 128; d_w = rc_chain_pack_weights(c -> c),
- * d_bias = rc_chain_pack_bias (or NULL), d_residual may be NULL. */
-int rc_cat_linear(const void* d_a, const void* d_b, const void* d_residual, void* d_out, long long tokens, int c, const void* d_w,
-                  const float* d_bias, void* stream);
+ * d_bias = rc_chain_pack_bias (or NULL), d_residual may be NULL; d_a_add (or NULL): the first half is d_a + d_a_add, rounded to bf16
+ * (ConvTransBlock's `conv_block(conv_x) + conv_x`, models/tcm.py:262, without its own launch). */
+int rc_cat_linear(const void* d_a, const void* d_a_add, const void* d_b, const void* d_residual, void* d_out, long long tokens, int c,
+                  const void* d_w, const float* d_bias, void* stream);
 
 int rc_gma_kv_mfma_blocks(int n_tok);
 size_t rc_gma_kv_mfma_scratch_bytes(int batch, int n_tok);

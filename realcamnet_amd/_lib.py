@@ -121,7 +121,7 @@ _SIGS = {
     "rc_gma_ln_qkv": (C.c_int, [_P, _P, C.c_longlong, _P, _P, _P, _P, _F, _P]),
     "rc_gma_tail": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "rc_gma_aggregate": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "rc_cat_linear": (C.c_int, [_P, _P, _P, _P, C.c_longlong, _I, _P, _P, _P]),
+    "rc_cat_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_longlong, _I, _P, _P, _P]),
     "rc_gdn_chain": (C.c_int, [_P, _P, _P, C.c_longlong, _I, _P, _P, _I, _P]),
     "rc_ln_linear": (C.c_int, [_P, _P, C.c_longlong, _I, _I, _P, _P, _P, _P, _F, _P]),
     "rc_ln_mlp": (C.c_int, [_P, _P, C.c_longlong, _I, _P, _P, _P, _P, _P, _P, _F, _P]),

@@ -1674,11 +1674,12 @@ extern "C" int rc_gdn_chain(const void* d_x, const void* d_identity, void* d_out
 // =====================================================================================================================================
 // Linear over the channel concatenation of two token maps, + residual:  out = res + W . [a ; b] + bias   (the closing
 // `conv1_2(torch.cat((conv_x, trans_x), dim=1)) + x` of ConvTransBlock, models/tcm.py:265-267 / raw2bit.py:324-327).  The two halves are read
-// straight into the K-steps of one activation fragment set, so the concatenated map is never written.  bf16, C = 64 or 128 (halves C/2).
+// straight into the K-steps of one activation fragment set, so the concatenated map is never written; the first half may be given as a
+// sum a + a2 (ConvTransBlock's `conv_block(conv_x) + conv_x`, tcm.py:262).  bf16, C = 64 or 128 (halves C/2).
 namespace rc {
 namespace gf {
 
-struct CatLinArgs { const bf16_t* a; const bf16_t* b; const bf16_t* res; bf16_t* out; size_t tokens; const void* w; const float* bias; };
+struct CatLinArgs { const bf16_t* a; const bf16_t* a2; const bf16_t* b; const bf16_t* res; bf16_t* out; size_t tokens; const void* w; const float* bias; };
 
 template <int C>
 __global__ __launch_bounds__(kMlpThreads, 2) void cat_linear_kernel(const CatLinArgs a) {
@@ -1702,7 +1703,12 @@ __global__ __launch_bounds__(kMlpThreads, 2) void cat_linear_kernel(const CatLin
             tok[nt] = t < a.tokens ? t : a.tokens - 1;
 #pragma unroll
             for (int s = 0; s < KS / 2; ++s) {
-                in[nt].f[s] = *reinterpret_cast<const uint4*>(a.a + tok[nt] * H + 32 * s + 8 * g);
+                uint4 av = *reinterpret_cast<const uint4*>(a.a + tok[nt] * H + 32 * s + 8 * g);
+                if (a.a2 != nullptr) {                        // first half = a + a2, rounded to bf16 like the separate add launch it replaces
+                    const uint4 a2v = *reinterpret_cast<const uint4*>(a.a2 + tok[nt] * H + 32 * s + 8 * g);
+                    av = pack_pair(up_lo(av) + up_lo(a2v), up_hi(av) + up_hi(a2v));
+                }
+                in[nt].f[s] = av;
                 in[nt].f[KS / 2 + s] = *reinterpret_cast<const uint4*>(a.b + tok[nt] * H + 32 * s + 8 * g);
             }
         }
@@ -1727,15 +1733,15 @@ __global__ __launch_bounds__(kMlpThreads, 2) void cat_linear_kernel(const CatLin
 }  // namespace gf
 }  // namespace rc
 
-extern "C" int rc_cat_linear(const void* d_a, const void* d_b, const void* d_residual, void* d_out, long long tokens, int c, const void* d_w,
-                             const float* d_bias, void* stream) {
+extern "C" int rc_cat_linear(const void* d_a, const void* d_a_add, const void* d_b, const void* d_residual, void* d_out, long long tokens, int c,
+                             const void* d_w, const float* d_bias, void* stream) {
     using namespace rc;
     using namespace rc::gf;
     RC_REQUIRE(d_a && d_b && d_out && d_w, "rc_cat_linear: null pointer");
     RC_REQUIRE(tokens >= 1 && (c == 64 || c == 128), "rc_cat_linear: concatenated width 64 or 128");
-    for (const void* q : {d_a, d_b, d_residual, static_cast<const void*>(d_out)})
+    for (const void* q : {d_a, d_a_add, d_b, d_residual, static_cast<const void*>(d_out)})
         RC_REQUIRE(q == nullptr || reinterpret_cast<uintptr_t>(q) % 16 == 0, "rc_cat_linear: misaligned tensor");
-    CatLinArgs a{static_cast<const bf16_t*>(d_a), static_cast<const bf16_t*>(d_b), static_cast<const bf16_t*>(d_residual), static_cast<bf16_t*>(d_out),
+    CatLinArgs a{static_cast<const bf16_t*>(d_a), static_cast<const bf16_t*>(d_a_add), static_cast<const bf16_t*>(d_b), static_cast<const bf16_t*>(d_residual), static_cast<bf16_t*>(d_out),
                  (size_t)tokens, d_w, d_bias};
     const size_t lds = (size_t)(c / 16) * tile_bytes(c) + (size_t)c * 4;
     const long long tiles = (tokens + 63) / 64;

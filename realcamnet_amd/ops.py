@@ -608,7 +608,7 @@ def ln_linear(x: torch.Tensor, ln, lin):
     return _R.ln_linear(_req(x, "tokens"), f32_param(ln, "weight"), f32_param(ln, "bias"), float(ln.eps), w, b if lin.bias is not None else None, int(cout))
 
 
-def cat_linear(a: torch.Tensor, b: torch.Tensor, conv, residual: Optional[torch.Tensor] = None):
+def cat_linear(a: torch.Tensor, b: torch.Tensor, conv, residual: Optional[torch.Tensor] = None, a_add: Optional[torch.Tensor] = None):
     """conv(torch.cat((a, b), channels)) + residual for a 1x1 conv, without writing the concatenated map (realcam::cat_linear): bf16, two
     equal halves of 32 / 64 channels, output width = input width.  None when the shapes are not of that form."""
     ca, cb = a.shape[-1], b.shape[-1]
@@ -620,8 +620,12 @@ def cat_linear(a: torch.Tensor, b: torch.Tensor, conv, residual: Optional[torch.
         residual = _req(residual, "residual")
         if residual.shape != (*a.shape[:-1], ca + cb) or residual.dtype != a.dtype:
             raise ValueError("cat_linear: residual shape / dtype mismatch")
+    if a_add is not None:                                   # first half = a + a_add (rounded to bf16, as a separate add launch would store it)
+        a_add = _req(a_add, "a_add")
+        if a_add.shape != a.shape or a_add.dtype != a.dtype:
+            raise ValueError("cat_linear: a_add shape / dtype mismatch")
     wp, bp = packed_chain(conv)
-    return _R.cat_linear(_req(a, "a"), _req(b, "b"), residual, wp, bp if conv.bias is not None else None)
+    return _R.cat_linear(_req(a, "a"), a_add, _req(b, "b"), residual, wp, bp if conv.bias is not None else None)
 
 
 def lsc_chain(lsc, coord: torch.Tensor, head=None, raw: Optional[torch.Tensor] = None):

@@ -140,10 +140,11 @@ class ConvTransBlock(nn.Module):
     def _nhwc(self, a):
         va, vb = ops.split_conv_views(self.conv1_1, (self.conv_dim, self.trans_dim))     # torch.split(conv1_1(x)) without the slice copies
         conv_x, trans_x = ops.conv2d(a, va), ops.conv2d(a, vb)
-        conv_x = ops.add(self.conv_block._nhwc(conv_x), conv_x)
+        rb = self.conv_block._nhwc(conv_x)
         trans_x = self.trans_block(trans_x)
-        y = ops.cat_linear(conv_x, trans_x, self.conv1_2, residual=a)          # conv1_2(cat(conv_x, trans_x)) + x without the concatenated map
-        return y if y is not None else self.conv1_2._nhwc(ops.channel_concat([conv_x, trans_x]), residual=a)
+        # conv1_2(cat(conv_block(conv_x) + conv_x, trans_x)) + x: the sum and the concatenation happen on the closing launch's operand load
+        y = ops.cat_linear(rb, trans_x, self.conv1_2, residual=a, a_add=conv_x)
+        return y if y is not None else self.conv1_2._nhwc(ops.channel_concat([ops.add(rb, conv_x), trans_x]), residual=a)
 
     def forward(self, x):
         if self.training:

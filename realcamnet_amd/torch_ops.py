@@ -663,7 +663,7 @@ define("gdn_chain(Tensor x, Tensor? identity, Tensor gamma_packed, Tensor beta_p
        lambda out, x, idn, w, b, inv: check(lib().rc_gdn_chain(x.data_ptr(), _p(idn), out.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], w.data_ptr(),
                                                                b.data_ptr(), 1 if inv else 0, _stream()), "rc_gdn_chain"))
 
-define("cat_linear(Tensor a, Tensor b, Tensor? residual, Tensor w, Tensor? bias) -> Tensor",
-       lambda a, b, res, w, bias: a.new_empty((*a.shape[:-1], a.shape[-1] + b.shape[-1])),
-       lambda out, a, b, res, w, bias: check(lib().rc_cat_linear(a.data_ptr(), b.data_ptr(), _p(res), out.data_ptr(), a.numel() // a.shape[-1],
-                                                                 a.shape[-1] + b.shape[-1], w.data_ptr(), _p(bias), _stream()), "rc_cat_linear"))
+define("cat_linear(Tensor a, Tensor? a_add, Tensor b, Tensor? residual, Tensor w, Tensor? bias) -> Tensor",
+       lambda a, a2, b, res, w, bias: a.new_empty((*a.shape[:-1], a.shape[-1] + b.shape[-1])),
+       lambda out, a, a2, b, res, w, bias: check(lib().rc_cat_linear(a.data_ptr(), _p(a2), b.data_ptr(), _p(res), out.data_ptr(), a.numel() // a.shape[-1],
+                                                                     a.shape[-1] + b.shape[-1], w.data_ptr(), _p(bias), _stream()), "rc_cat_linear"))

@@ -784,8 +784,8 @@ def test_hip_cat_linear_vs_concat_then_conv(c):
     with torch.no_grad():
         fused = OPS.cat_linear(ab, bb, conv, residual=xb)
         layered = conv._nhwc(OPS.channel_concat([ab, bb]), residual=xb)
-        nores = OPS.cat_linear(ab, bb, conv)
-        nores_l = conv._nhwc(OPS.channel_concat([ab, bb]))
+        nores = OPS.cat_linear(ab, bb, conv, a_add=bb)                                  # first half given as a sum
+        nores_l = conv._nhwc(OPS.channel_concat([OPS.add(ab, bb), bb]))
     assert fused is not None and fused.shape == layered.shape == (2, 21, 37, c)
     assert rel_err(fused.float().cpu(), layered.float().cpu()) < 2e-2 and rel_err(fused.float().cpu(), want) < 3e-2
     assert rel_err(nores.float().cpu(), nores_l.float().cpu()) < 2e-2
