@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 6
+#define RC_ABI_VERSION 7
 
 typedef enum rc_status {
     RC_OK = 0,
@@ -477,6 +477,8 @@ int rc_debug_stream_create_masked(int kind, void** stream_out);
 int rc_debug_hbm_probe(const void* src, void* dst, size_t bytes, int mode, int nt, int contiguous, int blocks, int iters,
                        double* ms_per_iter);
 int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma);
+/* The same calibration on v_mfma_f32_32x32x16_bf16 (8 independent accumulators per wave). */
+int rc_debug_mfma_peak32(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma);
 int rc_prof_enable(int on);
 int rc_prof_collect(int64_t* n_launches, double* total_ms, double* total_flops);
 

@@ -17,7 +17,7 @@ HEADER = PKG.parent / "include" / "realcam_hip.h"
 RC_F32, RC_BF16, RC_U16 = 0, 1, 2
 RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY, RC_ACT_GELU, RC_ACT_RELU_POST = 0, 1, 2, 3, 4
 RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class ConvDesc(C.Structure):
@@ -78,6 +78,7 @@ _SIGS = {
     "rc_debug_stream_create_masked": (C.c_int, [_I, C.POINTER(C.c_void_p)]),
     "rc_debug_hbm_probe": (C.c_int, [_P, _P, C.c_size_t, _I, _I, _I, _I, _I, C.POINTER(C.c_double)]),
     "rc_debug_mfma_peak": (C.c_int, [_I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rc_debug_mfma_peak32": (C.c_int, [_I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rc_pointwise_chain48": (C.c_int, [_P, _I, _P, _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _F, _P, _I, C.c_longlong, _P]),
     "rc_lsc_packed_bytes": (C.c_size_t, [_I, _I, _I]),
     "rc_lsc_pack": (C.c_int, [_P, _P, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _P, _P, _I, _I, _P]),

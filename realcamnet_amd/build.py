@@ -13,7 +13,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 OBJ = PKG / "_build"
 LIB = PKG / "librealcam_hip.so"
-SOURCES = ["lib.hip", "conv.hip", "conv_dispatch.hip", "conv_pair.hip", "chain.hip", "pointwise.hip", "cond.hip", "gma.hip", "gma_fused.hip", "wmsa.hip", "entropy.hip", "rans.hip"] + sorted(p.name for p in CSRC.glob("conv_inst_*.hip"))
+SOURCES = ["lib.hip", "conv.hip", "conv_dispatch.hip", "conv_pair.hip", "chain.hip", "pointwise.hip", "cond.hip", "gma.hip", "gma_fused.hip", "wmsa.hip", "entropy.hip", "rans.hip"] + sorted(p.name for p in CSRC.glob("conv_inst_*.hip")) + sorted(p.name for p in CSRC.glob("conv32_inst_*.hip"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("RC_EXTRA_HIPCC_FLAGS", "").split()   # experiments only
 
@@ -33,9 +33,19 @@ def _digest(paths) -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True) -> Path:
+def _deps():
     srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
-    deps = srcs + sorted(CSRC.glob("*.hpp")) + [PKG.parent / "include" / "realcam_hip.h"]
+    return srcs, srcs + sorted(CSRC.glob("*.hpp")) + [PKG.parent / "include" / "realcam_hip.h"]
+
+
+def source_digest() -> str:
+    """SHA-256 over the compile flags and every kernel source / header: identifies the code a measurement was taken on
+    (profiles/*_pmc_bench.json carries it; bench.py reports PMC traffic only for a matching digest)."""
+    return _digest(_deps()[1])
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    srcs, deps = _deps()
     stamp = OBJ / "stamp.txt"
     dig = _digest(deps)
     if not force and LIB.exists() and stamp.exists() and stamp.read_text() == dig:

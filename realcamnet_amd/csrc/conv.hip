@@ -2,14 +2,18 @@
 #include <mutex>
 #include <vector>
 
-#include "conv_kernel.hpp"
+#include "conv32_kernel.hpp"
 
 namespace rc {
 
 struct ConvPlan {
     int ck = 0, nt = 0, unit = 0, upt = 0, nu = 0, steps = 0;
     int n_chunks = 0, n_ct = 0, cout_packed = 0;
+    int m32 = 0;          // 32x32x16 form (conv32_kernel.hpp): nt counts 32-row tiles, steps counts K16 steps
 };
+
+static int g_persist_on = 1;       // rc_debug_set("persist", v): 0 general kernel only, 1 automatic (default), 2 producer/consumer wherever eligible, 3 persistent only
+static int g_conv32 = 1;           // rc_debug_set("conv32", v): 0 off (16x16x32 kernels everywhere), 1 on (default), 2 on with 8 compute waves x (64 px x 64 couts)
 
 // Must mirror ConvCfg<> (static_asserts in check_plan_consistency below keep them in lock-step).
 static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, ConvPlan* p) {
@@ -46,6 +50,23 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
     else if (cout % 64 == 0) p->nt = 4;
     else if (cout % 48 == 0) p->nt = 3;
     else p->nt = 1;
+    // 32x32x16 form: 3x3 bf16 layers whose weights are streamed (several 32-channel chunks, or the one-chunk 48 -> 192 layers) and whose
+    // couts fill whole 32-row tiles.  The packed order differs, so the choice depends on the shape (and the debug knobs) only.
+    p->m32 = 0;
+    if (dtype == RC_BF16 && ksize == 3 && g_conv32 != 0 && g_persist_on != 0 && cout <= kPersistMaxCout && out_mode != RC_OUT_NCHW) {
+        const int cw = out_mode == RC_OUT_PIXEL_SHUFFLE2 ? cout / 4 : cout;          // channels a lane's 16-value run must tile
+        if (p->ck == 32 && cin % 32 == 0 && (out_mode == RC_OUT_PIXEL_SHUFFLE2 ? cw % 32 == 0 : cw % 64 == 0)) { p->m32 = 1; p->nt = 2; }
+        else if (cin == 48 && (out_mode == RC_OUT_PIXEL_SHUFFLE2 ? cw % 48 == 0 : cw % 96 == 0)) { p->m32 = 1; p->nt = 3; p->ck = 48; }
+    }
+    if (p->m32) {
+        p->upt = p->ck / p->unit;
+        p->nu = 9 * p->upt;
+        p->steps = 9 * (p->ck / 16);
+        p->n_chunks = cin / p->ck;
+        p->n_ct = cout / (32 * p->nt);
+        p->cout_packed = cout;
+        return true;
+    }
     p->upt = p->ck / p->unit;
     p->nu = ksize * ksize * p->upt;
     p->steps = unit_map_steps(p->upt, ksize * ksize);
@@ -57,6 +78,7 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
 
 // packed cout index j -> conv output channel (or -1 for padding rows)
 static int packed_to_cout(const ConvPlan& p, int cout, int out_mode, int j) {
+    if (p.m32) return c32_packed_to_cout(p.nt, out_mode, j);
     if (out_mode == RC_OUT_PIXEL_SHUFFLE2) {
         // cout tile ct = cb*4 + sub-pixel; inside it packed index = out channel offset within block cb
         const int tile = 16 * p.nt;
@@ -67,7 +89,6 @@ static int packed_to_cout(const ConvPlan& p, int cout, int out_mode, int j) {
     return j < cout ? j : -1;
 }
 
-static int g_persist_on = 1;       // rc_debug_set("persist", v): 0 general kernel only, 1 automatic (default), 2 producer/consumer wherever eligible, 3 persistent only
 static int g_dbg_flags = 0;
 static long long* g_dbg_ptr = nullptr;   // rc_debug_set_ptr("conv_phase_timing", device buffer of >= 512 int64)
 static std::mutex g_prof_mu;
@@ -120,6 +141,27 @@ int rc_conv_pack_weights(const float* w, int cin, int cout, int ksize, int dtype
     RC_REQUIRE(make_plan(cin, cout, ksize, dtype, out_mode, &p), "rc_conv_pack_weights: bad shape");
     const int kk = ksize * ksize;
     char* out = static_cast<char*>(dst);
+    if (p.m32) {
+        // layout: [ct][chunk][K16 step][row tile t][lane 0..63][8 bf16].  Lane l supplies MFMA row m = l & 31, channels 8*(l >> 5) + e of
+        // the step's 16; D row m comes out in lane half (m >> 2) & 1, register (m & 3) + 4 * (m >> 3), so row m carries packed channel
+        // 16 * half + register: a lane's 16 registers are 16 consecutive channels.
+        const int spt = p.ck / 16;
+        for (int ct = 0; ct < p.n_ct; ++ct)
+            for (int chunk = 0; chunk < p.n_chunks; ++chunk)
+                for (int s = 0; s < p.steps; ++s)
+                    for (int t = 0; t < p.nt; ++t)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int m = lane & 31, kg = lane >> 5;
+                            const int c = 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3);
+                            const int co = packed_to_cout(p, cout, out_mode, ct * 32 * p.nt + 32 * t + c);
+                            const int tap = s / spt, ci0 = chunk * p.ck + (2 * (s % spt) + kg) * 8;
+                            for (int e = 0; e < 8; ++e) {
+                                *reinterpret_cast<uint16_t*>(out) = host_f32_to_bf16(w[((size_t)co * cin + ci0 + e) * kk + tap]);
+                                out += 2;
+                            }
+                        }
+        return RC_OK;
+    }
     // layout: [ct][chunk][step][nt][lane 0..63][UNIT elements]   (16 bytes per lane)
     for (int ct = 0; ct < p.n_ct; ++ct)
         for (int chunk = 0; chunk < p.n_chunks; ++chunk)
@@ -167,6 +209,7 @@ int rc_debug_set(const char* key, int value) {
     RC_REQUIRE(key != nullptr, "rc_debug_set: null key");
     if (std::string(key) == "persist") { g_persist_on = value < 0 ? 0 : (value > 3 ? 3 : value); return RC_OK; }
     if (std::string(key) == "conv_flags") { g_dbg_flags = value; return RC_OK; }
+    if (std::string(key) == "conv32") { g_conv32 = value < 0 ? 0 : (value > 2 ? 2 : value); return RC_OK; }
     return fail(RC_ERR_INVALID, std::string("rc_debug_set: unknown key ") + key);
 }
 
@@ -243,6 +286,8 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     a.batch = d->batch; a.H = d->height; a.W = d->width; a.cin = d->cin; a.cout = d->cout;
     a.n_chunks = p.n_chunks; a.n_ct = p.n_ct;
     a.tiles_x = ceil_div(d->width, kTW); a.tiles_y = ceil_div(d->height, kTH);
+    if (p.m32) RC_REQUIRE(!d->film_scale || (reinterpret_cast<uintptr_t>(d->film_scale) % 16 == 0 && reinterpret_cast<uintptr_t>(d->film_shift) % 16 == 0),
+                          "rc_conv2d: film vectors must be 16-byte aligned");
     auto aligned16 = [](const void* q) { return q == nullptr || reinterpret_cast<uintptr_t>(q) % 16 == 0; };
     a.cin_vec_ok = (d->cin % p.unit == 0) && aligned16(d->in0) && aligned16(d->in1) && aligned16(d->in_store) &&
                    (d->in_gate == nullptr || reinterpret_cast<uintptr_t>(d->in_gate) % 4 == 0);
@@ -280,7 +325,8 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     // algorithmic FLOPs: a ksize-2 launch is a stride-2 3x3 convolution over its space-to-depth map -- 9 of its 16 (tap, phase) blocks are real
     const double taps = d->ksize == 2 ? 9.0 / 4.0 : (double)d->ksize * d->ksize;
     conv_prof_begin(2.0 * d->batch * d->height * d->width * (double)d->cin * d->cout * taps, stream, &tok);
-    const int rcode = dispatch_conv(d->dtype == RC_BF16, d->ksize, p.ck, p.nt, a, stream);
+    const int rcode = p.m32 ? (p.ck == 32 ? conv32_ck32(g_conv32 == 2 ? 1 : 0, a, stream) : conv32_ck48(0, a, stream))
+                            : dispatch_conv(d->dtype == RC_BF16, d->ksize, p.ck, p.nt, a, stream);
     conv_prof_end(tok, stream);
     return rcode;
 }

@@ -34,6 +34,30 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* sink, int iters, 
     if (s == 123.456f) sink[0] = s;                       // keep the chain alive
     if (blockIdx.x == 0 && threadIdx.x == 0 && cycles) cycles[0] = t1 - t0;
 }
+__global__ __launch_bounds__(256) void mfma_peak32_kernel(float* sink, int iters, long long* cycles) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    const float seed = (float)threadIdx.x * 1e-3f;
+    bf16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + i); b[i] = (__bf16)(seed - i); }
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    const long long t1 = (long long)__builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][5] + acc[i][10] + acc[i][15];
+    if (s == 123.456f) sink[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && cycles) cycles[0] = t1 - t0;
+}
 }  // namespace rc
 
 
@@ -99,6 +123,30 @@ int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* me
     RC_HIP_CHECK(hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost));
     *tflops = (double)grid * 4 * iters * 16 * 16384.0 / (ms * 1e-3) / 1e12;
     if (memtime_ticks_per_mfma) *memtime_ticks_per_mfma = (double)h / ((double)iters * 16 * waves_per_simd);
+    (void)hipFree(sink); (void)hipFree(cyc); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return RC_OK;
+}
+
+int rc_debug_mfma_peak32(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma) {
+    RC_REQUIRE(tflops != nullptr && iters >= 1 && waves_per_simd >= 1 && waves_per_simd <= 2, "rc_debug_mfma_peak32: bad arguments");
+    const int cus = rc::device_cu_count();
+    float* sink = nullptr; long long* cyc = nullptr;
+    RC_HIP_CHECK(hipMalloc(&sink, 4)); RC_HIP_CHECK(hipMalloc(&cyc, 8));
+    hipEvent_t e0, e1;
+    RC_HIP_CHECK(hipEventCreate(&e0)); RC_HIP_CHECK(hipEventCreate(&e1));
+    const int grid = cus * waves_per_simd;
+    for (int rep = 0; rep < 3; ++rep) {
+        RC_HIP_CHECK(hipEventRecord(e0, nullptr));
+        hipLaunchKernelGGL(rc::mfma_peak32_kernel, dim3(grid), dim3(256), 0, nullptr, sink, iters, cyc);
+        RC_HIP_CHECK(hipEventRecord(e1, nullptr));
+        RC_HIP_CHECK(hipEventSynchronize(e1));
+    }
+    float ms = 0.f;
+    RC_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    long long h = 0;
+    RC_HIP_CHECK(hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost));
+    *tflops = (double)grid * 4 * iters * 8 * 32768.0 / (ms * 1e-3) / 1e12;
+    if (memtime_ticks_per_mfma) *memtime_ticks_per_mfma = (double)h / ((double)iters * 8 * waves_per_simd);
     (void)hipFree(sink); (void)hipFree(cyc); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return RC_OK;
 }

@@ -150,3 +150,102 @@ def test_pixel_shuffle_packing_permutation():
     for j in range(cout):
         ct, within = divmod(j, tile)
         assert dst[j] == 4 * ((ct >> 2) * tile + within) + (ct & 3)
+
+
+# ---- 32x32x16 form (realcamnet_amd/csrc/conv32_kernel.hpp) ---------------------------------------------------------------------
+def _emulate32(w, x, out_mode):
+    """Host-packed weights of the 32x32x16 conv replayed through v_mfma_f32_32x32x16_bf16's documented lane maps (A: lane = (row m = l & 31,
+    k group l >> 5), B: lane = (column n = l & 31, k group l >> 5), D: lane (n, h) register i <- row (i & 3) + 8 (i >> 2) + 4 h) for one
+    8 x 32 pixel tile.  Returns {(packed channel j): (8, 32) map} in PACKED order plus the plan (ck, nt32, n_ct)."""
+    lib = _lib.load()
+    cout, cin = w.shape[:2]
+    ck = 48 if cin == 48 else 32
+    nt = 3 if cin == 48 else 2
+    spt, steps = ck // 16, 9 * (ck // 16)
+    n_chunks, n_ct = cin // ck, cout // (32 * nt)
+    nbytes = lib.rc_conv_packed_bytes(cin, cout, 3, RC_BF16, out_mode)
+    assert nbytes == n_ct * n_chunks * steps * nt * 1024
+    assert lib.rc_conv_packed_cout(cin, cout, 3, RC_BF16, out_mode) == cout
+    buf = np.empty(nbytes, np.uint8)
+    wc = np.ascontiguousarray(w, np.float32)
+    assert lib.rc_conv_pack_weights(wc.ctypes.data, cin, cout, 3, RC_BF16, out_mode, buf.ctypes.data) == 0
+    pk = _bf16_to_f32(buf.view(np.uint16)).reshape(n_ct, n_chunks, steps, nt, 64, 8)
+    H, W = 8, 32
+    xp = np.zeros((cin, H + 2, W + 2), np.float32)
+    xp[:, 1:1 + H, 1:1 + W] = x
+    out = np.zeros((cout, H, W), np.float64)          # indexed by PACKED channel
+    m_of, kg_of = np.arange(64) & 31, np.arange(64) >> 5
+    for ct in range(n_ct):
+        for row in range(H):
+            for t in range(nt):
+                D = np.zeros((32, 32))
+                for chunk in range(n_chunks):
+                    for s in range(steps):
+                        tap, j = divmod(s, spt)
+                        dy, dx = divmod(tap, 3)
+                        A = np.zeros((32, 2, 8)); B = np.zeros((2, 8, 32))
+                        for lane in range(64):
+                            A[m_of[lane], kg_of[lane]] = pk[ct, chunk, s, t, lane]
+                            c0 = chunk * ck + (2 * j + kg_of[lane]) * 8
+                            B[kg_of[lane], :, m_of[lane]] = xp[c0:c0 + 8, row + dy, m_of[lane] + dx]
+                        D += np.einsum("mke,ken->mn", A, B)
+                for lane in range(64):
+                    n, h = lane & 31, lane >> 5
+                    for i in range(16):
+                        out[ct * 32 * nt + 32 * t + 16 * h + i, row, n] = D[(i & 3) + 8 * (i >> 2) + 4 * h, n]
+    return out, nt, n_ct
+
+
+@pytest.mark.parametrize("cin,cout", [(128, 64), (48, 96)])
+def test_packed_weight_layout_32x32_reproduces_conv(cin, cout):
+    rng = np.random.default_rng(2)
+    w = rng.integers(-2, 3, size=(cout, cin, 3, 3)).astype(np.float32) / 2
+    x = rng.integers(-2, 3, size=(cin, 8, 32)).astype(np.float32) / 2
+    out, nt, n_ct = _emulate32(w, x, RC_OUT_NHWC)
+    ref = F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), padding=1)[0].numpy()
+    np.testing.assert_allclose(out, ref, atol=1e-4)             # NHWC: packed order == channel order
+
+
+def test_pixel_shuffle_packing_32x32():
+    lib = _lib.load()
+    cin, cout = 48, 192                                          # the flagship tail: 48 -> 4 x 48, PixelShuffle(2)
+    rng = np.random.default_rng(3)
+    w = rng.integers(-2, 3, size=(cout, cin, 3, 3)).astype(np.float32) / 2
+    x = rng.integers(-2, 3, size=(cin, 8, 32)).astype(np.float32) / 2
+    out, nt, n_ct = _emulate32(w, x, RC_OUT_PIXEL_SHUFFLE2)
+    assert (nt, n_ct) == (3, 2)
+    ref = F.pixel_shuffle(F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), padding=1), 2)[0].numpy()
+    got = np.zeros_like(ref)
+    cps = cout // 4
+    for j in range(cout):   # kernel epilogue: cout tile ct = (out-channel block ct>>1, sub-row ct&1); row tile t; lane half h = sub-column
+        ct, within = divmod(j, 32 * nt)
+        t, c = divmod(within, 32)
+        h, e = divmod(c, 16)
+        oc = (ct >> 1) * 16 * nt + 16 * t + e
+        assert oc < cps
+        got[oc, (ct & 1)::2, h::2] = out[j]
+    np.testing.assert_allclose(got, ref, atol=1e-4)
+    bias = np.arange(cout, dtype=np.float32)
+    dst = np.zeros(cout, np.float32)
+    assert lib.rc_conv_pack_bias(bias.ctypes.data, cin, cout, 3, RC_BF16, RC_OUT_PIXEL_SHUFFLE2, dst.ctypes.data) == 0
+    for j in range(cout):
+        ct, within = divmod(j, 32 * nt)
+        t, c = divmod(within, 32)
+        h, e = divmod(c, 16)
+        assert dst[j] == 4 * ((ct >> 1) * 16 * nt + 16 * t + e) + 2 * (ct & 1) + h
+
+
+def test_conv32_knob_switches_the_packed_layout():
+    """rc_debug_set("conv32", 0) routes the multi-chunk layers back to the 16x16x32 kernels: the packed size is the same, the order is not."""
+    lib = _lib.load()
+    w = np.random.default_rng(4).standard_normal((64, 128, 3, 3)).astype(np.float32)
+    n = lib.rc_conv_packed_bytes(128, 64, 3, RC_BF16, RC_OUT_NHWC)
+    a, b = np.empty(n, np.uint8), np.empty(n, np.uint8)
+    assert lib.rc_conv_pack_weights(w.ctypes.data, 128, 64, 3, RC_BF16, RC_OUT_NHWC, a.ctypes.data) == 0
+    assert lib.rc_debug_set(b"conv32", 0) == 0
+    try:
+        assert lib.rc_conv_packed_bytes(128, 64, 3, RC_BF16, RC_OUT_NHWC) == n
+        assert lib.rc_conv_pack_weights(w.ctypes.data, 128, 64, 3, RC_BF16, RC_OUT_NHWC, b.ctypes.data) == 0
+    finally:
+        lib.rc_debug_set(b"conv32", 1)
+    assert not np.array_equal(a, b) and np.array_equal(np.sort(a), np.sort(b))

@@ -10,3 +10,8 @@ for wps in (1, 2):
     for iters in (20000, 200000):
         ops.check(ops.lib().rc_debug_mfma_peak(wps, iters, C.byref(tf), C.byref(ticks)), "mfma_peak")
         print(f"{wps} wave(s)/SIMD, {iters} x16 MFMAs/wave: {tf.value:7.1f} TF/s   {ticks.value:5.2f} s_memtime ticks per MFMA per SIMD")
+for wps in (1, 2):
+    tf, ticks = C.c_double(), C.c_double()
+    for iters in (20000, 200000):
+        ops.check(ops.lib().rc_debug_mfma_peak32(wps, iters, C.byref(tf), C.byref(ticks)), "mfma_peak32")
+        print(f"32x32x16: {wps} wave(s)/SIMD, {iters} x8 MFMAs/wave: {tf.value:7.1f} TF/s   {ticks.value:5.2f} s_memtime ticks per MFMA per SIMD")

@@ -31,7 +31,7 @@ for k in sorted(set(f) | set(w)):
         continue
     e = {"dispatches": n, "fetch_bytes_per_dispatch": fv * 2048.0 / n, "write_bytes_per_dispatch": wv * 1024.0 / n}
     out["kernels"][k] = e
-    if "conv_mfma" in k or "conv_pair" in k:
+    if "conv_mfma" in k or "conv_pair" in k or "conv32_kernel" in k:
         conv["fetch"] += fv * 2048.0; conv["write"] += wv * 1024.0; conv["dispatches"] += n
 out["conv_kernels_all"] = {"dispatches": conv["dispatches"],
                            "hbm_bytes_per_dispatch": (conv["fetch"] + conv["write"]) / max(conv["dispatches"], 1),
@@ -39,5 +39,8 @@ out["conv_kernels_all"] = {"dispatches": conv["dispatches"],
 tot_f = sum(v[0] for v in f.values()) * 2048.0; tot_w = sum(v[0] for v in w.values()) * 1024.0
 out["all_kernels_total_bytes"] = {"fetch": tot_f, "write": tot_w}
 out["forwards"] = 3
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from realcamnet_amd import build as _b          # digest of the kernel sources these counters were taken on: bench.py refuses a stale file
+out["source_digest"] = _b.source_digest()
 out["copy_rate_TBps"] = 5.9   # measured: 1.6 GB -> 1.6 GB float4 copy, one-shot grid (tools/hbm_probe.py)
 print(json.dumps(out, indent=1))
