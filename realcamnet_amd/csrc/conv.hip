@@ -13,7 +13,9 @@ struct ConvPlan {
 };
 
 static int g_persist_on = 1;       // rc_debug_set("persist", v): 0 general kernel only, 1 automatic (default), 2 producer/consumer wherever eligible, 3 persistent only
-static int g_conv32 = 1;           // rc_debug_set("conv32", v): 0 off (16x16x32 kernels everywhere), 1 on (default), 2 on with 8 compute waves x (64 px x 64 couts)
+static int g_conv32 = 4;           // rc_debug_set("conv32", v): which layers take the 32x32x16 forms (conv32_kernel.hpp).  0 none; 4 (default) only where they
+                                   // measured faster on MI355X (the one-chunk 48 -> 96k NHWC layers: 1.24 vs 1.39 ms at 544x960x8); 1 all eligible layers, multi-chunk
+                                   // NHWC ones in the staged-output form; 2 / 3 multi-chunk layers in the two-barrier form with 4 / 8 compute waves (A/B experiments)
 
 // Must mirror ConvCfg<> (static_asserts in check_plan_consistency below keep them in lock-step).
 static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, ConvPlan* p) {
@@ -55,8 +57,9 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
     p->m32 = 0;
     if (dtype == RC_BF16 && ksize == 3 && g_conv32 != 0 && g_persist_on != 0 && cout <= kPersistMaxCout && out_mode != RC_OUT_NCHW) {
         const int cw = out_mode == RC_OUT_PIXEL_SHUFFLE2 ? cout / 4 : cout;          // channels a lane's 16-value run must tile
-        if (p->ck == 32 && cin % 32 == 0 && (out_mode == RC_OUT_PIXEL_SHUFFLE2 ? cw % 32 == 0 : cw % 64 == 0)) { p->m32 = 1; p->nt = 2; }
-        else if (cin == 48 && (out_mode == RC_OUT_PIXEL_SHUFFLE2 ? cw % 48 == 0 : cw % 96 == 0)) { p->m32 = 1; p->nt = 3; p->ck = 48; }
+        const bool all = g_conv32 != 4;
+        if (all && p->ck == 32 && cin % 32 == 0 && (out_mode == RC_OUT_PIXEL_SHUFFLE2 ? cw % 32 == 0 : cw % 64 == 0)) { p->m32 = 1; p->nt = 2; p->ck = (g_conv32 == 1 && out_mode == RC_OUT_NHWC) ? 16 : 32; }
+        else if (cin == 48 && (out_mode == RC_OUT_PIXEL_SHUFFLE2 ? (all && cw % 48 == 0) : cw % 96 == 0)) { p->m32 = 1; p->nt = 3; p->ck = 48; }
     }
     if (p->m32) {
         p->upt = p->ck / p->unit;
@@ -209,7 +212,7 @@ int rc_debug_set(const char* key, int value) {
     RC_REQUIRE(key != nullptr, "rc_debug_set: null key");
     if (std::string(key) == "persist") { g_persist_on = value < 0 ? 0 : (value > 3 ? 3 : value); return RC_OK; }
     if (std::string(key) == "conv_flags") { g_dbg_flags = value; return RC_OK; }
-    if (std::string(key) == "conv32") { g_conv32 = value < 0 ? 0 : (value > 2 ? 2 : value); return RC_OK; }
+    if (std::string(key) == "conv32") { g_conv32 = value < 0 ? 0 : (value > 4 ? 4 : value); return RC_OK; }
     return fail(RC_ERR_INVALID, std::string("rc_debug_set: unknown key ") + key);
 }
 
@@ -325,7 +328,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     // algorithmic FLOPs: a ksize-2 launch is a stride-2 3x3 convolution over its space-to-depth map -- 9 of its 16 (tap, phase) blocks are real
     const double taps = d->ksize == 2 ? 9.0 / 4.0 : (double)d->ksize * d->ksize;
     conv_prof_begin(2.0 * d->batch * d->height * d->width * (double)d->cin * d->cout * taps, stream, &tok);
-    const int rcode = p.m32 ? (p.ck == 32 ? conv32_ck32(g_conv32 == 2 ? 1 : 0, a, stream) : conv32_ck48(0, a, stream))
+    const int rcode = p.m32 ? (p.ck == 16 ? conv32_ck16(0, a, stream) : p.ck == 32 ? conv32_ck32(g_conv32 == 3 ? 1 : 0, a, stream) : conv32_ck48(0, a, stream))
                             : dispatch_conv(d->dtype == RC_BF16, d->ksize, p.ck, p.nt, a, stream);
     conv_prof_end(tok, stream);
     return rcode;

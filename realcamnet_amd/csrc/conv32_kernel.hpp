@@ -270,6 +270,114 @@ struct C32Dev {
             }
         }
     }
+
+    // Staged epilogue: same math as epilogue<>, but the packed bf16 tile goes to LDS ([row][pixel][8 slots of 16 B], slot ^= pixel & 7)
+    // for the loader waves to store.  NHWC only.
+    __device__ static __forceinline__ void epilogue_staged(const ConvArgs& a, int b, int y0, int x0, int ct, int wave, int lane,
+                                                           f32x16 (&acc)[PT][NT32], char* s_out) {
+        constexpr int ES = 2;
+        // launder the lane id: everything below is loop-invariant per lane, and hoisted out of the unit loop it would sit in ~40 VGPRs
+        // across the MFMA loop (the first build of this kernel spilled 250 registers that way)
+        asm volatile("" : "+v"(lane));
+        const int n = lane & 31, h = lane >> 5;
+        const size_t img_out = (size_t)a.H * a.W * a.cout;
+        const unsigned img_bytes = (unsigned)(img_out * ES);
+        const int gy0 = y0 + wave * PT, gx = x0 + n;
+        const int cb0 = ct * K::COUT_TILE + 16 * h;
+        const int in_off00 = ((gy0 * a.W + gx) * a.cout + cb0) * ES;
+        const int in_row_b = a.W * a.cout * ES;
+        const float inf = __builtin_inff();
+        const bool film = a.film_scale != nullptr, sums = a.chan_sums != nullptr;
+        char* s_lane = s_out + ((wave * PT) * 32 + n) * 128;
+        const int hm = (2 * h) ^ (n & 7);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT32; ++t) {
+            const int cpk = ct * K::COUT_TILE + 32 * t + 16 * h;
+            float fs[16], ft[16];
+            if (film) {
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(a.film_scale + (size_t)b * a.cout + cpk + e);
+                    const float4 t4 = *reinterpret_cast<const float4*>(a.film_shift + (size_t)b * a.cout + cpk + e);
+                    fs[e] = s4.x; fs[e + 1] = s4.y; fs[e + 2] = s4.z; fs[e + 3] = s4.w;
+                    ft[e] = t4.x; ft[e + 1] = t4.y; ft[e + 2] = t4.z; ft[e + 3] = t4.w;
+                }
+            }
+            float csum[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) csum[e] = 0.f;
+#pragma unroll
+            for (int r = 0; r < PT; ++r) {
+                const bool valid = gy0 + r < a.H && gx < a.W;
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = acc[r][t][e];
+                if (film) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = v[e] * fs[e] + ft[e] + v[e];
+                }
+                if (a.act == RC_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.f, inf);
+                } else if (a.act == RC_ACT_LEAKY) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.act_slope;
+                } else if (a.act == RC_ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = gelu_erf_f32(v[e]);
+                }
+                const int po = valid ? in_off00 + r * in_row_b + t * 64 : kOOB;
+                if (a.mul_plus1 != nullptr) {
+                    float m[16];
+                    buf_load_row<bf16_t, 16>(make_rsrc(static_cast<const bf16_t*>(a.mul_plus1) + (size_t)b * img_out, img_bytes), po, m);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] = v[e] * (m[e] + 1.f);
+                }
+                if (a.residual != nullptr) {
+                    float m[16];
+                    buf_load_row<bf16_t, 16>(make_rsrc(static_cast<const bf16_t*>(a.residual) + (size_t)b * img_out, img_bytes), po, m);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] += m[e];
+                    if (a.act == RC_ACT_RELU_POST) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.f, inf);
+                    }
+                }
+                if (sums) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) csum[e] += valid ? v[e] : 0.f;
+                }
+                unsigned w[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+                // slot (4t + 2h + j) ^ (n & 7) = (4t + j) ^ hm with hm = 2h ^ (n & 7): t and j touch bits 2 and 0, h bit 1
+                char* dst = s_lane + r * 4096;
+                *reinterpret_cast<uint4*>(dst + (((4 * t) ^ hm) << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
+                *reinterpret_cast<uint4*>(dst + (((4 * t + 1) ^ hm) << 4)) = make_uint4(w[4], w[5], w[6], w[7]);
+                __builtin_amdgcn_sched_barrier(0);       // keep one row's operand loads from being clustered with the next rows' (register pressure)
+            }
+            if (sums) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) csum[e] = SD::row_sum16(csum[e]);
+                if constexpr (PT == 2) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        csum[e] += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(csum[e]), 0x401F));
+                }
+                const int row8 = (gy0 >> 3);
+                const int slot = PT == 4 ? ((wave & 1) * 2 + ((lane >> 4) & 1)) : (wave & 3);
+                const bool writer = PT == 4 ? (lane & 15) == 0 : (lane & 31) == 0;
+                if (writer && row8 < a.tiles_y) {
+                    float* dst = a.chan_sums + (((size_t)b * (a.tiles_x * a.tiles_y) + (size_t)row8 * a.tiles_x + (x0 / kTW)) * 4 + slot) * a.cout + cpk;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dst[e] = csum[e];
+                }
+            }
+        }
+    }
 };
 
 template <class K, bool GATED, bool DEFER>
@@ -502,8 +610,243 @@ int launch_conv32(const ConvArgs& a, hipStream_t stream) {
     return a.in_gate != nullptr ? launch_conv32_g<K, true>(a, stream) : launch_conv32_g<K, false>(a, stream);
 }
 
+// ==================================================================================================================================
+// Staged-output form ("conv32s") for the multi-chunk layers.  What bounded the form above was not the matrix pipe (its MFMA phases run at
+// 35 of 32 cycles per MFMA) but what sits between them (profiles/r03_conv32_phases.md):
+//   * a wave needs ~225-650 cycles per buffer_store_dwordx4 (tools/ubench/store_issue.hip: 4 waves storing row-per-lane pieces reach one
+//     store instruction per 158 cycles per CU, 8 waves writing whole 128-byte runs one per 43), so the four compute waves sat ~4 600 cycles
+//     in every tile's epilogue with the matrix pipe idle
+//   * two barriers per stage (weights single-buffered by halves).
+// Here a stage is ONE tap-major pass over a 16-channel chunk (9 K16 steps), input tile AND packed weights are double-buffered (one
+// barrier per stage), and the LDS this frees holds the tile's packed bf16 output (64 KB): the compute waves' epilogue is cvt + 16
+// ds_write_b128, and the four loader waves -- who have the slack -- drain it to HBM over the next stages with 8-pixel x 128-byte
+// store instructions (every 16-byte slot of a pixel's 64 couts is XOR-swizzled with the pixel index: conflict-free on both sides).
+// ==================================================================================================================================
+template <int NCW_>
+struct C32SCfg {
+    using Stage = C32Stage<16, 16>;
+    static constexpr int CK = 16, TH = 16, NCW = NCW_, NT32 = 2;
+    static constexpr int SPT = 1, STEPS = 9, SA = 9;
+    static constexpr int PT = TH / NCW;
+    static constexpr int COUT_TILE = 64;
+    static constexpr int W_BYTES = STEPS * NT32 * 1024;            // 18 KB per (cout tile, chunk)
+    static constexpr int COMPUTE = NCW * 64, THREADS = COMPUTE + kThreads;
+    static constexpr int OUT_BYTES = TH * kTW * 128;               // 16 x 32 pixels x 64 couts bf16
+    static constexpr int LDS_BYTES = 2 * W_BYTES + kPersistMaxCout * 4 + 2 * Stage::IN_BYTES + OUT_BYTES;
+    static constexpr int FR = NT32 + PT, FM = NT32 * PT;
+    static constexpr int NPEND = PT * NT32 * 2;
+    static constexpr int NWR = (W_BYTES / 16 + kThreads - 1) / kThreads;   // weight pieces per loader thread
+    static constexpr int DRAIN = OUT_BYTES / 16 / kThreads;                // store instructions per loader wave per tile (16)
+    static constexpr int DRAIN_PER_STAGE = 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "conv32s: LDS budget");
+};
+
+template <class K, bool GATED>
+__global__ __launch_bounds__(K::THREADS) void conv32s_kernel(const ConvArgs a) {
+    using St = typename K::Stage;
+    using D = ConvDev<St>;
+    using C = C32Dev<K>;
+    constexpr int NT32 = K::NT32, PT = K::PT, WALL = K::W_BYTES, NWR = K::NWR;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_w0 = smem;                                               // 2 x packed weights
+    float* s_bias = reinterpret_cast<float*>(smem + 2 * WALL);
+    char* s_in0 = smem + 2 * WALL + kPersistMaxCout * 4;             // 2 x halo tile
+    char* s_out = s_in0 + 2 * St::IN_BYTES;                          // packed output tile [row][pixel][8 swizzled 16-byte slots]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wv >= K::NCW;
+
+    const int tiles_y = (a.H + K::TH - 1) / K::TH;
+    const TileDecode& td = a.td_wsm;
+    const int sp_total = a.tiles_x * tiles_y;
+    const int n_tiles = sp_total * a.batch;
+    const int n_chunks = a.n_chunks, n_ct = a.n_ct;                  // n_chunks >= 2: unit = (tile, cout tile), cout tile fastest
+    const int n_units = n_tiles * n_ct;
+    const int slots = gridDim.x >> 3;
+    const int pos = (blockIdx.x & 7) * slots + (blockIdx.x >> 3);
+    const int stride = (int)gridDim.x;
+    const int my_units = pos < n_units ? (n_units - pos + stride - 1) / stride : 0;
+    const int my_stages = my_units * n_chunks;
+    constexpr bool staged = true;                                    // NHWC only: PixelShuffle layers take the two-barrier form above (make_plan)
+
+    for (int i = tid; i < a.cout_packed; i += K::THREADS) s_bias[i] = a.bias ? a.bias[i] : 0.f;
+
+    auto decode = [&](int unit, int& b, int& ty, int& tx, int& ct) {
+        const int tile = magic_div(unit, a.div_n_ct);
+        ct = unit - tile * n_ct;
+        b = magic_div(tile, td.sp_total);
+        band_decode(tile - b * sp_total, a.tiles_x, tiles_y, td, ty, tx);
+    };
+
+    if (loader) {
+        // ---------------------------------------------------------------- producer waves
+        const int rtid = tid - K::COMPUTE;
+        const int lw = wv - K::NCW;
+        uint4 r0[D::NI], r1[GATED ? D::NI : 1], wr[NWR];
+        float gv[GATED ? D::UNIT : 1];
+        typename D::TileSrc ts;
+        typename D::TileOffs to;
+        D::tile_offsets(a, rtid, to);
+        int wo[NWR];
+#pragma unroll
+        for (int k = 0; k < NWR; ++k) wo[k] = (k * kThreads + rtid) * 16 < WALL ? (k * kThreads + rtid) * 16 : kOOB;
+        const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpacked, (unsigned)((size_t)n_ct * n_chunks * WALL));
+        ConvArgs aa = a;
+
+        // stage whose loads are issued next
+        int i_unit = 0, i_chunk = 0, i_g = 0;
+        int b = 0, ty = 0, tx = 0, ct = 0;
+        int c_chunk = 0, c_buf = 0;                                   // of the stage held in registers
+        auto issue = [&]() {
+            if (i_chunk == 0) {
+                decode(pos + i_unit * stride, b, ty, tx, ct);
+                aa.in_store = ct == 0 ? a.in_store : nullptr;        // only one cout tile materialises a gated input
+                ts = D::tile_src(aa, b, ty * K::TH, tx * kTW);
+            }
+            c_buf = i_g & 1; c_chunk = i_chunk;
+            D::template load_tile<GATED>(aa, ts, to, b, i_chunk, rtid, r0, r1, gv);
+            const int wsoff = (ct * n_chunks + i_chunk) * WALL;
+#pragma unroll
+            for (int k = 0; k < NWR; ++k) wr[k] = buf_load16(r_w, wo[k], wsoff);
+            ++i_g;
+            if (++i_chunk == n_chunks) { i_chunk = 0; ++i_unit; }
+        };
+        auto commit = [&]() {
+            D::template commit_tile<GATED>(aa, ts, to, c_chunk, rtid, r0, r1, gv, s_in0 + c_buf * St::IN_BYTES);
+            char* wdst = s_w0 + c_buf * WALL;
+#pragma unroll
+            for (int k = 0; k < NWR; ++k)
+                if (wo[k] != kOOB) *reinterpret_cast<uint4*>(wdst + wo[k]) = wr[k];
+        };
+        // drain of the staged output tile: store instruction i of this wave covers pieces ((i*4 + lw)*64 + lane) of the tile's 4096
+        // 16-byte pieces, piece = (row*32 + px)*8 + slot: one instruction = 8 pixels x 128 contiguous bytes
+        __amdgpu_buffer_rsrc_t d_r = make_rsrc(nullptr, 0u);
+        int d_y0 = 0, d_x0 = 0, d_ct = 0, d_left = 0;
+        auto drain = [&](int count) {
+            for (int q = 0; q < count && d_left > 0; ++q, --d_left) {
+                const int i = K::DRAIN - d_left;
+                const int piece = (i * 4 + lw) * 64 + lane;
+                const int row = piece >> 8, px = (piece >> 3) & 31, slot = piece & 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(s_out + (row * 32 + px) * 128 + ((slot ^ (px & 7)) << 4));
+                const int gy = d_y0 + row, gx = d_x0 + px;
+                const int off = (gy < a.H && gx < a.W && !(a.dbg_flags & 1)) ? ((gy * a.W + gx) * a.cout + d_ct * 64) * 2 + slot * 16 : kOOB;
+                buf_store16(d_r, off, 0, v);
+            }
+        };
+
+        if (my_stages > 0) { issue(); commit(); }
+        if (my_stages > 1) issue();
+        __syncthreads();                                             // barrier 0: bias, stage 0 visible
+        const bool rec = a.dbg != nullptr && blockIdx.x == 8 && lw == 0 && lane == 0;
+        int g_chunk = 0, g_unit = 0;                                 // the stage the computers are working on
+        for (int g = 0; g < my_stages; ++g) {
+            const long long t0 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            if (g + 1 < my_stages) commit();                         // stage g+1 (loaded during stage g-1) -> the buffers stage g-1 used
+            if (g + 2 < my_stages) issue();
+            const long long t1 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            if (staged) drain(K::DRAIN_PER_STAGE);
+            const long long t2 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            __syncthreads();
+            if (rec && g < 60) {
+                long long* d = a.dbg + 512 + 4 * g;
+                d[0] = t1 - t0; d[1] = t2 - t1; d[2] = (long long)__builtin_amdgcn_s_memtime() - t2; d[3] = 0;
+            }
+            if (++g_chunk == n_chunks) {                             // the computers have just staged unit g_unit's output
+                g_chunk = 0;
+                if (staged) {
+                    int db, dty, dtx;
+                    decode(pos + g_unit * stride, db, dty, dtx, d_ct);
+                    d_y0 = dty * K::TH; d_x0 = dtx * kTW;
+                    const size_t img_out = (size_t)a.H * a.W * a.cout;
+                    d_r = make_rsrc(static_cast<bf16_t*>(a.out) + (size_t)db * img_out, (unsigned)(img_out * 2));
+                    d_left = K::DRAIN;
+                }
+                ++g_unit;
+            }
+        }
+        if (staged) drain(K::DRAIN);
+    } else {
+        // ---------------------------------------------------------------- consumer waves
+        const int n = lane & 31, h = lane >> 5;
+        const int lane_in = ((wv * PT) * St::TWH + n) * St::SPIX + h * 16;
+        typename C::Pend pend;
+        pend.has = false;
+        __syncthreads();                                             // barrier 0
+        const bool rec = a.dbg != nullptr && blockIdx.x == 8 && wv == 0 && lane == 0;
+        int g = 0;
+        for (int k = 0; k < my_units; ++k) {
+            int b, ty, tx, ct;
+            decode(pos + k * stride, b, ty, tx, ct);
+            f32x16 acc[PT][NT32];
+#pragma unroll
+            for (int t = 0; t < NT32; ++t) {
+                const float* bp = s_bias + ct * K::COUT_TILE + 32 * t + 16 * h;
+                f32x16 bv;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) bv[e] = bp[e];
+#pragma unroll
+                for (int r = 0; r < PT; ++r) acc[r][t] = bv;
+            }
+            // (the epilogue sits AFTER the chunk loop: placed conditionally inside it hipcc kept a second copy of the 128 accumulator registers)
+            long long t0 = 0, t1 = 0;
+            int c = 0;
+            do {                                                     // (do-while: with a possibly-zero-trip for loop hipcc merges the bias-initialised and the accumulated tiles through copies and spills ~150 registers)
+                const char* in_lane = s_in0 + (g & 1) * St::IN_BYTES + lane_in;
+                const char* w_lane = s_w0 + (g & 1) * WALL + lane * 16;
+                t0 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+                if (!(a.dbg_flags & 2)) C::template mma_steps<0, K::STEPS, false>(in_lane, w_lane, acc, pend);
+                t1 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+                if (c + 1 < n_chunks) {
+                    __syncthreads();
+                    if (rec && g < 60) {
+                        long long* d = a.dbg + 8 * g;
+                        d[0] = t1 - t0; d[1] = 0; d[2] = 0; d[3] = 0; d[4] = 0; d[5] = (long long)__builtin_amdgcn_s_memtime() - t1;
+                    }
+                }
+                ++c; ++g;
+            } while (c < n_chunks);
+            C::epilogue_staged(a, b, ty * K::TH, tx * kTW, ct, wv, lane, acc, s_out);
+            const long long t2 = rec ? (long long)__builtin_amdgcn_s_memtime() : 0;
+            __syncthreads();
+            if (rec && g - 1 < 60) {
+                long long* d = a.dbg + 8 * (g - 1);
+                d[0] = t1 - t0; d[1] = 0; d[2] = 0; d[3] = 0; d[4] = t2 - t1; d[5] = (long long)__builtin_amdgcn_s_memtime() - t2;
+            }
+        }
+    }
+}
+
+template <class K, bool GATED>
+int launch_conv32s_g(const ConvArgs& a, hipStream_t stream) {
+    const int tiles_y = (a.H + K::TH - 1) / K::TH;
+    const int n_items = a.tiles_x * tiles_y * a.batch * a.n_ct;
+    int grid = a.num_cus;
+    if (grid > n_items) grid = n_items;
+    grid = (grid + 7) / 8 * 8;
+    static PerDeviceFlag attr_set;
+    if (!attr_set.test_and_set())
+        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv32s_kernel<K, GATED>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS_BYTES));
+    hipLaunchKernelGGL((conv32s_kernel<K, GATED>), dim3((unsigned)grid), dim3(K::THREADS), K::LDS_BYTES, stream, a);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+template <class K>
+int launch_conv32s(const ConvArgs& a, hipStream_t stream) {
+    if (!a.cin_vec_ok || !a.cin_chunk_ok) return fail(RC_ERR_INVALID, "conv32: tensors must be 16-byte aligned and Cin a whole number of chunks");
+    if (a.tiles_x * ((a.H + K::TH - 1) / K::TH) * a.batch >= (1 << 24)) return fail(RC_ERR_INVALID, "conv32: too many tiles");
+    // the loaders drain a staged tile DRAIN_PER_STAGE instructions per stage and finish the rest when the next tile is staged
+    // (4 stages); the computers overwrite the staging buffer in a unit's LAST stage, so a unit must have more than 5 stages
+    if (a.n_chunks < 6) return fail(RC_ERR_INVALID, "conv32s: needs at least six 16-channel Cin chunks");
+    if (a.out_mode != RC_OUT_NHWC) return fail(RC_ERR_INVALID, "conv32s: NHWC store only");
+    return a.in_gate != nullptr ? launch_conv32s_g<K, true>(a, stream) : launch_conv32s_g<K, false>(a, stream);
+}
+
 // defined in conv32_inst_*.hip
 int conv32_ck32(int variant, const ConvArgs& a, hipStream_t s);
+int conv32_ck16(int variant, const ConvArgs& a, hipStream_t s);
 int conv32_ck48(int variant, const ConvArgs& a, hipStream_t s);
 
 }  // namespace rc

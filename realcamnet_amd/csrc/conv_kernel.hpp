@@ -1303,14 +1303,17 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
         __syncthreads();                                             // barrier 0: bias, Wa(0), tile(0) visible
         for (int g = 0; g < my_stages; ++g) {
             // every load is issued at the START of a half and consumed one half later: a whole half of latency budget
+            // In both halves the commit comes BEFORE the issue: hipcc cannot count the conditionally issued younger loads, so a commit
+            // placed after them waits vmcnt(0) -- i.e. for the loads of its own half (round 3, tools/conv32_phases.py: 2650 + 1660
+            // loader cycles per stage became 1660 + 1630).  This way its wait covers only loads that have had a whole half-stage.
             const int wsoff_g = wsoff;                               // stage g's weights (issue_a moves wsoff on to g+1)
             if constexpr (WDMA) dma(WA, WB, wsoff_g);                // half a: Wb(g) straight into its (free) LDS half
-            if (g + 1 < my_stages) issue_a();                        //         fetch Wa(g+1) (+ tile) ...
-            commit_b();                                              //         ... and write Wb(g); the computers read Wa(g)
+            commit_b();                                              //         write Wb(g); the computers read Wa(g) ...
+            if (g + 1 < my_stages) issue_a();                        //         ... and fetch Wa(g+1) (+ tile)
             __syncthreads();
-            if (g + 1 < my_stages) {                                 // half b: fetch Wb(g+1); write Wa(g+1) (+ tile)
+            if (g + 1 < my_stages) {                                 // half b: write Wa(g+1) (+ tile); fetch Wb(g+1)
                 if constexpr (WDMA) dma(0, WA, wsoff);
-                issue_b(); commit_a();
+                commit_a(); issue_b();
             }
             __syncthreads();
         }

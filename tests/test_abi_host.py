@@ -153,13 +153,13 @@ def test_pixel_shuffle_packing_permutation():
 
 
 # ---- 32x32x16 form (realcamnet_amd/csrc/conv32_kernel.hpp) ---------------------------------------------------------------------
-def _emulate32(w, x, out_mode):
+def _emulate32(w, x, out_mode, ck32=32):
     """Host-packed weights of the 32x32x16 conv replayed through v_mfma_f32_32x32x16_bf16's documented lane maps (A: lane = (row m = l & 31,
     k group l >> 5), B: lane = (column n = l & 31, k group l >> 5), D: lane (n, h) register i <- row (i & 3) + 8 (i >> 2) + 4 h) for one
     8 x 32 pixel tile.  Returns {(packed channel j): (8, 32) map} in PACKED order plus the plan (ck, nt32, n_ct)."""
     lib = _lib.load()
     cout, cin = w.shape[:2]
-    ck = 48 if cin == 48 else 32
+    ck = 48 if cin == 48 else ck32
     nt = 3 if cin == 48 else 2
     spt, steps = ck // 16, 9 * (ck // 16)
     n_chunks, n_ct = cin // ck, cout // (32 * nt)
@@ -196,12 +196,18 @@ def _emulate32(w, x, out_mode):
     return out, nt, n_ct
 
 
-@pytest.mark.parametrize("cin,cout", [(128, 64), (48, 96)])
-def test_packed_weight_layout_32x32_reproduces_conv(cin, cout):
+@pytest.mark.parametrize("cin,cout,knob", [(128, 64, 2), (128, 64, 1), (48, 96, 4)])
+def test_packed_weight_layout_32x32_reproduces_conv(cin, cout, knob):
+    """knob = rc_debug_set("conv32"): 2 -> 32-channel chunks (two-barrier form), 1 -> 16-channel chunks (staged-output form), 4 = the default."""
     rng = np.random.default_rng(2)
     w = rng.integers(-2, 3, size=(cout, cin, 3, 3)).astype(np.float32) / 2
     x = rng.integers(-2, 3, size=(cin, 8, 32)).astype(np.float32) / 2
-    out, nt, n_ct = _emulate32(w, x, RC_OUT_NHWC)
+    lib = _lib.load()
+    assert lib.rc_debug_set(b"conv32", knob) == 0
+    try:
+        out, nt, n_ct = _emulate32(w, x, RC_OUT_NHWC, ck32=16 if knob == 1 else 32)
+    finally:
+        lib.rc_debug_set(b"conv32", 4)
     ref = F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), padding=1)[0].numpy()
     np.testing.assert_allclose(out, ref, atol=1e-4)             # NHWC: packed order == channel order
 
@@ -212,7 +218,14 @@ def test_pixel_shuffle_packing_32x32():
     rng = np.random.default_rng(3)
     w = rng.integers(-2, 3, size=(cout, cin, 3, 3)).astype(np.float32) / 2
     x = rng.integers(-2, 3, size=(cin, 8, 32)).astype(np.float32) / 2
-    out, nt, n_ct = _emulate32(w, x, RC_OUT_PIXEL_SHUFFLE2)
+    assert lib.rc_debug_set(b"conv32", 1) == 0      # the PixelShuffle tail stays on the 16x16x32 kernel by default (measured a tie)
+    try:
+        out, nt, n_ct = _emulate32(w, x, RC_OUT_PIXEL_SHUFFLE2)
+        bias = np.arange(cout, dtype=np.float32)
+        dst = np.zeros(cout, np.float32)
+        assert lib.rc_conv_pack_bias(bias.ctypes.data, cin, cout, 3, RC_BF16, RC_OUT_PIXEL_SHUFFLE2, dst.ctypes.data) == 0
+    finally:
+        lib.rc_debug_set(b"conv32", 4)
     assert (nt, n_ct) == (3, 2)
     ref = F.pixel_shuffle(F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), padding=1), 2)[0].numpy()
     got = np.zeros_like(ref)
@@ -225,9 +238,6 @@ def test_pixel_shuffle_packing_32x32():
         assert oc < cps
         got[oc, (ct & 1)::2, h::2] = out[j]
     np.testing.assert_allclose(got, ref, atol=1e-4)
-    bias = np.arange(cout, dtype=np.float32)
-    dst = np.zeros(cout, np.float32)
-    assert lib.rc_conv_pack_bias(bias.ctypes.data, cin, cout, 3, RC_BF16, RC_OUT_PIXEL_SHUFFLE2, dst.ctypes.data) == 0
     for j in range(cout):
         ct, within = divmod(j, 32 * nt)
         t, c = divmod(within, 32)
@@ -236,16 +246,16 @@ def test_pixel_shuffle_packing_32x32():
 
 
 def test_conv32_knob_switches_the_packed_layout():
-    """rc_debug_set("conv32", 0) routes the multi-chunk layers back to the 16x16x32 kernels: the packed size is the same, the order is not."""
+    """rc_debug_set("conv32", 2) routes the multi-chunk layers to the 32x32x16 kernel: the packed size is the same, the order is not."""
     lib = _lib.load()
     w = np.random.default_rng(4).standard_normal((64, 128, 3, 3)).astype(np.float32)
     n = lib.rc_conv_packed_bytes(128, 64, 3, RC_BF16, RC_OUT_NHWC)
     a, b = np.empty(n, np.uint8), np.empty(n, np.uint8)
-    assert lib.rc_conv_pack_weights(w.ctypes.data, 128, 64, 3, RC_BF16, RC_OUT_NHWC, a.ctypes.data) == 0
-    assert lib.rc_debug_set(b"conv32", 0) == 0
+    assert lib.rc_conv_pack_weights(w.ctypes.data, 128, 64, 3, RC_BF16, RC_OUT_NHWC, a.ctypes.data) == 0     # default: 16x16x32 order
+    assert lib.rc_debug_set(b"conv32", 2) == 0
     try:
         assert lib.rc_conv_packed_bytes(128, 64, 3, RC_BF16, RC_OUT_NHWC) == n
         assert lib.rc_conv_pack_weights(w.ctypes.data, 128, 64, 3, RC_BF16, RC_OUT_NHWC, b.ctypes.data) == 0
     finally:
-        lib.rc_debug_set(b"conv32", 1)
+        lib.rc_debug_set(b"conv32", 4)
     assert not np.array_equal(a, b) and np.array_equal(np.sort(a), np.sort(b))

@@ -518,6 +518,62 @@ def test_multichunk_conv_exact_on_integer_data(hip, persist, gated, shape):
     assert torch.equal(y, ref)
 
 
+@pytest.mark.parametrize("knob", [1, 2, 3])
+@pytest.mark.parametrize("mode", ["plain", "gated", "res", "sums", "film", "ps"])
+@pytest.mark.parametrize("shape", [(128, 64, 16, 40), (192, 192, 9, 33), (128, 128, 37, 100), (48, 192, 21, 70)])
+def test_conv32_forms_exact_on_integer_data(hip, knob, mode, shape):
+    """The 32x32x16 conv forms (csrc/conv32_kernel.hpp; rc_debug_set("conv32"): 1 = staged-output form on 16-channel chunks + the one-chunk
+    48-channel form, 2 / 3 = two-barrier form with 4 / 8 compute waves) equal F.conv2d BIT FOR BIT on integer data in every operand form:
+    gated input + materialised sum, residual, CALayer partial sums, FiLM + LeakyReLU, PixelShuffle store; ragged multi-tile images."""
+    cin, cout, h, w = shape
+    if cin == 48 and knob != 1:
+        pytest.skip("the one-chunk 48-channel form has one variant")
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    c = N.Conv2d(cin, cout, 3, 1, 1)
+    with torch.no_grad():
+        sparse = (torch.rand(c.weight.shape, generator=g) < 96.0 / cin).float()
+        c.weight.copy_(torch.randint(-1, 2, c.weight.shape, generator=g).float() * sparse)
+        c.bias.copy_(torch.randint(-2, 3, c.bias.shape, generator=g).float())
+    x = torch.randint(-1, 2, (2, cin, h, w), generator=g).float()
+    xin, kw = x, {}
+    if mode == "gated":
+        r = torch.randint(-1, 2, (2, cin, h, w), generator=g).float()
+        gate = torch.randint(0, 2, (2, cin), generator=g).float()
+        xin = r * gate[:, :, None, None] + x
+    ref = F.conv2d(xin, c.weight.detach(), c.bias.detach(), padding=1)
+    if mode == "res":
+        res = torch.randint(-2, 3, (2, cout, h, w), generator=g).float()
+        ref = ref + res
+    if mode == "film":
+        fs = torch.randint(0, 2, (2, cout), generator=g).float(); ft = torch.randint(-1, 2, (2, cout), generator=g).float()
+        ref = ref * fs[:, :, None, None] + ft[:, :, None, None] + ref
+        ref = torch.where(ref > 0, ref, ref * 0.5)
+        kw = dict(act="leaky", slope=0.5, film=(fs.to(DEV), ft.to(DEV)))
+    if mode == "ps":
+        ref = F.pixel_shuffle(ref, 2); kw = dict(out_mode=ops.RC_OUT_PIXEL_SHUFFLE2)
+    assert ref.abs().max() <= 256
+    assert hip.rc_debug_set(b"conv32", knob) == 0
+    try:
+        c = c.to(DEV, torch.bfloat16)
+        xd = ops.to_nhwc(x.to(DEV, torch.bfloat16))
+        with torch.no_grad():
+            if mode == "gated":
+                y, stored = ops.conv2d(ops.to_nhwc(r.to(DEV, torch.bfloat16)), c, gate=gate.to(DEV), skip=xd, store_input=True)
+                assert torch.equal(ops.to_nchw(stored).float().cpu(), xin)
+            elif mode == "res":
+                y = ops.conv2d(xd, c, residual=ops.to_nhwc(res.to(DEV, torch.bfloat16)))
+            elif mode == "sums":
+                y, sums = ops.conv2d(xd, c, want_sums=True)
+                assert torch.equal(sums.float().reshape(2, -1, cout).sum(1).cpu(), ref.sum(dim=(2, 3)))
+            else:
+                y = ops.conv2d(xd, c, **kw)
+            y = ops.to_nchw(y).float().cpu()
+    finally:
+        hip.rc_debug_set(b"conv32", 4)
+    assert torch.equal(y, ref)
+
+
+
 @pytest.mark.parametrize("shape", [(1, 5, 7), (2, 37, 70), (1, 64, 96)])
 def test_lens_shading_chain_equals_layer_by_layer(hip, shape):
     """rc_pointwise_chain48 (all four 1x1 layers in one launch, activations in LDS) against the same module run as

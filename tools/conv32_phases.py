@@ -25,11 +25,14 @@ L.rc_debug_set_ptr(b"conv_phase_timing", dbg.data_ptr())
 t0 = time.perf_counter()
 ops.conv2d(x, c, **kw); torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-L.rc_debug_set_ptr(b"conv_phase_timing", None); L.rc_debug_set(b"conv_flags", 0); L.rc_debug_set(b"conv32", 1)
+L.rc_debug_set_ptr(b"conv_phase_timing", None); L.rc_debug_set(b"conv_flags", 0); L.rc_debug_set(b"conv32", 4)
 d = dbg.cpu()
 cw = d[:480].view(60, 8)[6:54].float(); lw = d[512:752].view(60, 4)[6:54].float()
 epi = cw[:, 4][cw[:, 4] > 0]
 print(f"{cin}->{cout} {h}x{w}x{b} {sys.argv[6:] if len(nums)==5 else ''} V={variant} flags={flags}: wall {dt*1e3:.2f} ms")
 print(f"  compute wave / stage: mfma-a {cw[:,0].mean():.0f}  bar1 {cw[:,1].mean():.0f}  mfma-b {cw[:,2].mean():.0f}  bar2(mid-chunk) {cw[:,3].mean():.0f}  "
       f"epilogue {epi.mean() if len(epi) else 0:.0f} (x{len(epi)}/{len(cw)})  bar-after-epi {cw[:,5][cw[:,4]>0].mean() if len(epi) else 0:.0f}   sum {cw[:, :6].sum(1).mean():.0f}")
+if variant == 1 and cin != 48:
+    print(f"  (staged form) compute: mfma {cw[:,0].mean():.0f}  epilogue->LDS {epi.mean() if len(epi) else 0:.0f} (x{len(epi)}/{len(cw)})  barrier {cw[:,5].mean():.0f}   "
+          f"loader: commit+issue {lw[:,0].mean():.0f}  drain {lw[:,1].mean():.0f}  barrier {lw[:,2].mean():.0f}")
 print(f"  loader wave / stage:  issue_a+commit_b {lw[:,0].mean():.0f}  bar1 {lw[:,1].mean():.0f}  issue_b+commit_a {lw[:,2].mean():.0f}  bar2 {lw[:,3].mean():.0f}   sum {lw.sum(1).mean():.0f}")

@@ -12,7 +12,7 @@ L = ops.lib()
 dev, bf = "cuda", torch.bfloat16
 
 
-def setk(conv32=1, persist=1, flags=0):
+def setk(conv32=4, persist=1, flags=0):
     L.rc_debug_set(b"conv32", conv32); L.rc_debug_set(b"persist", persist); L.rc_debug_set(b"conv_flags", flags)
 
 
@@ -43,10 +43,10 @@ def report(tag, y, ref):
 
 def check():
     ok = True
-    for variant in (1, 2):
+    for variant in (1, 2, 3):
         for shape in [(128, 64, 16, 40), (192, 192, 9, 33), (512, 128, 8, 32), (128, 128, 37, 100), (48, 192, 16, 40), (48, 96, 21, 70)]:
             cin, cout, h, w = shape
-            if cin == 48 and variant == 2:
+            if cin == 48 and variant != 1:
                 continue
             for mode in ("plain", "relu", "gated", "res", "sums", "film", "ps", "relu_post", "gelu"):
                 if mode == "ps" and (cout // 4) % 16 != 0:
@@ -138,11 +138,11 @@ def timing():
             kw = dict(out_mode=ops.RC_OUT_PIXEL_SHUFFLE2)
         fl = 2.0 * b * h * w * cin * cout * 9
         line = f"{cin:3d}->{cout:3d} {h}x{w}x{b} {mode:6s}:"
-        variants = [("old", 0, 0), ("v1", 1, 0), ("v2", 2, 0)]
+        variants = [("old", 0, 0), ("staged", 1, 0), ("ck32", 2, 0)]
         if cin == 48:
             variants = [("old", 0, 0), ("v1", 1, 0), ("v1-nodefer", 1, 8), ("v1-nostore", 1, 1), ("old-nostore", 0, 1)]
         else:
-            variants += [("v1-nomfma", 1, 2)]
+            variants += [("staged-nomfma", 1, 2), ("staged-nostore", 1, 1)]
         for name, v, fl_ in variants:
             setk(conv32=v, flags=fl_)
             c = N.Conv2d(cin, cout, 3, 1, 1).to(dev, bf)
