@@ -80,6 +80,104 @@ def cpu_baseline(name, sd, frame_hw=(2160, 3840), budget_s=20.0):
     return info, (mosaic, cond, coord, out)
 
 
+def load_pmc_summary():
+    """The newest profiles/rNN_pmc_bench.json whose `source_digest` equals this build's kernel-source digest, else None."""
+    from realcamnet_amd import build as rb
+    dig = rb.source_digest()
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_bench.json")), reverse=True):
+        try:
+            with open(os.path.join(pdir, name)) as f:
+                pmc = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if pmc.get("source_digest") == dig:
+            pmc["_file"] = name
+            return pmc
+    return None
+
+
+from torch.utils._python_dispatch import TorchDispatchMode
+
+
+class _LaunchCounter(TorchDispatchMode):
+    """Counts dispatched ops of one forward: every realcam:: op is one C-ABI kernel launch; ATen ops that touch data are counted beside them."""
+    def __init__(self):
+        super().__init__()
+        self.realcam = 0
+        self.aten = 0
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if name.startswith("realcam."):
+            self.realcam += 1
+        elif not any(k in name for k in ("view", "reshape", "permute", "transpose", "slice", "select", "detach", "alias", "expand", "squeeze",
+                                         "unsqueeze", "empty", "as_strided", "t.default", "size", "stride", "unbind", "split", "chunk", "_unsafe_view")):
+            self.aten += 1
+        return func(*args, **(kwargs or {}))
+
+
+def codec_leg(dev, dt, H2, W2, frames=4, steps=6, warmup=2, with_psnr=True):
+    """SURVEY cfg5's one-GPU shape inside the default run: raw_compression_tcm_final.forward_mosaic (models/raw2bit.py:1766-1855, likelihood
+    path, no entropy coder) on `frames` 4K mosaics, timed after a warm-up that also packs the weights.  Returned as the extra key
+    `codec_leg`; the contract keys of the headline line are untouched."""
+    import realcamnet_amd as M
+    from realcamnet_amd import ops
+    torch.manual_seed(0)
+    net = M.raw2bit.raw_compression_tcm_final().eval()
+    sd_cpu = {k: v.clone() for k, v in net.state_dict().items()} if with_psnr else None
+    net = net.to(device=dev, dtype=dt)
+    g = torch.Generator(device=dev).manual_seed(4321)
+    mosaic = torch.rand(frames, 1, H2, W2, generator=g, device=dev).to(dt)
+    coord = ops.make_coord(frames, H2 // 2, W2 // 2, device=dev, dtype=dt)
+
+    def step():
+        with torch.no_grad():
+            return net.forward_mosaic(mosaic, None, coord)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    ops.prof_enable(True)
+    step()
+    n_conv, conv_ms, conv_flops = ops.prof_collect()
+    ops.prof_enable(False)
+    launches = None
+    try:
+        with _LaunchCounter() as lc:
+            step()
+        launches = {"realcam_ops": lc.realcam, "aten_ops": lc.aten}
+    except Exception as e:                                   # counting is diagnostics only
+        launches = {"error": str(e)[:80]}
+    torch.cuda.synchronize()
+    leg = {"metric": f"megapixels/sec RAW mosaic {W2}x{H2} -> raw_compression_tcm_final.forward (likelihood path)",
+           "value": round(frames * H2 * W2 / 1e6 / el, 2), "unit": "MP/s", "ms_per_step": round(1e3 * el, 3), "frames": frames, "steps": steps,
+           "warmup": warmup, "launches_per_forward": launches, "conv_launches": int(n_conv), "conv_ms_per_step": round(conv_ms, 3),
+           "flops_necessary": conv_flops, "conv_TFLOPs": round(conv_flops / (conv_ms * 1e-3) / 1e12, 1) if conv_ms > 0 else 0.0}
+    if with_psnr:
+        import liteisp_oracle as O                          # the oracle: checker only
+        import raw2bit_oracle as RO
+        gc = torch.Generator().manual_seed(1234)
+        S = 1024                                            # bounded: one 1024 x 1024 mosaic (~3 s of CPU work)
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        with torch.no_grad():
+            mos = torch.rand(1, 1, S, S, generator=gc)
+            raw, cond = O.raw_ingest(mos); co = O.make_coord(1, S // 2, S // 2)
+            ref = RO.raw_compression_tcm_final(sd_cpu, [raw, cond, co])
+            y = net([raw.to(dev, dt), cond.to(dev, dt), co.to(dev, dt)])
+        leg["psnr_y"] = round(O.psnr(y["para"]["y"].float().cpu(), ref["para"]["y"]), 2)
+        leg["psnr_x_hat"] = round(O.psnr(y["x_hat"].float().cpu(), ref["x_hat"]), 2)
+        leg["psnr_sample"] = f"1 frame, {S}x{S} mosaic, fp32 CPU oracle (oracle/raw2bit_oracle.py)"
+    del net, mosaic, coord
+    torch.cuda.empty_cache()
+    return leg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +192,7 @@ def main():
                          "raw_compression_tcm_final = the RAW codec's forward (likelihood path), SURVEY cfg5's codec leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of the output frames (replicas only)")
+    ap.add_argument("--no-codec-leg", action="store_true", help="default cfg3 run: skip the extra codec_leg key (raw_compression_tcm_final at 4 frames)")
     args = ap.parse_args()
 
     import realcamnet_amd as M
@@ -185,18 +284,23 @@ def main():
                      "kernel": "conv_mfma_kernel (all instantiations)", "launches_per_step": int(n_launch),
                      "kernel_ms_per_step": round(conv_ms, 3), "flops_per_step": conv_flops},
     }
-    # HBM traffic comes from PMC counters, which cannot be read inside a timed run: tools/pmc_bench.sh collects them in
-    # separate rocprofv3 --pmc passes of this same default command and commits the summary under profiles/
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_bench.json")
-    if cfg_name == "cfg3" and args.dtype == "bf16" and B == 8 and os.path.exists(pmc_path):
-        with open(pmc_path) as f:
-            pmc = json.load(f)
+    # HBM traffic comes from PMC counters, which cannot be read inside a timed run: tools/pmc_bench.sh collects them in separate
+    # rocprofv3 --pmc passes of this same default command and commits the summary under profiles/.  The summary carries the digest of
+    # the kernel sources it was measured on; a file taken on other sources is ignored (traffic stays null) rather than replayed.
+    pmc = load_pmc_summary() if (cfg_name == "cfg3" and args.dtype == "bf16" and B == 8) else None
+    if pmc is not None:
         res["roofline"]["traffic"] = round(pmc["conv_kernels_all"]["hbm_bytes_per_dispatch"])
-        res["roofline"]["traffic_note"] = ("HBM bytes per conv launch (mean over the step's conv launches), FETCH_SIZE x2 + WRITE_SIZE "
-                                           "from profiles/r02_pmc_bench.json")
+        res["roofline"]["traffic_note"] = ("HBM bytes per conv launch (mean over the step's conv launches), FETCH_SIZE x2 + WRITE_SIZE from "
+                                           f"profiles/{pmc['_file']} (same kernel-source digest {pmc['source_digest'][:12]} as this build)")
         step_bytes = (pmc["all_kernels_total_bytes"]["fetch"] + pmc["all_kernels_total_bytes"]["write"]) / pmc.get("forwards", 3)
         res["hbm_whole_step"] = {"bytes_per_step": round(step_bytes), "achieved_TBps": round(step_bytes / (elapsed / args.steps) / 1e12, 2),
                                  "copy_rate_TBps": pmc.get("copy_rate_TBps", 5.9), "peak_TBps": 8.0}
+    else:
+        res["roofline"]["traffic_note"] = "null: no PMC summary under profiles/ was taken on this build's kernel sources (tools/pmc_bench.sh)"
+    if world == 1 and cfg_name == "cfg3" and not args.no_codec_leg:
+        del out, gathered
+        torch.cuda.empty_cache()
+        res["codec_leg"] = codec_leg(dev, dt, H2, W2, frames=4, with_psnr=not args.no_cpu_baseline)
     if world == 1 and not args.no_cpu_baseline:
         info, (m_c, c_c, co_c, ref) = cpu_baseline(args.model, sd_cpu, (H2, W2))
         with torch.no_grad():

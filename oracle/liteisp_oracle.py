@@ -286,16 +286,18 @@ def liteispnet_gfm_lsc_gma(sd: SD, x: Sequence[torch.Tensor], heads: int = 8) ->
     return _unet_trunk(sd, h, v, refine)
 
 
-def _strided_unet(sd: SD, x: Sequence[torch.Tensor]) -> torch.Tensor:
+def _strided_unet(sd: SD, x: Sequence[torch.Tensor], cond_from_raw: bool = False, skips: bool = True) -> torch.Tensor:
     """Shared body of the ISPUNet / ResUNet family: ISPUNet_GFM_LSC (models/LiteISP.py:1340-1380),
     ISPUNet_GFM (:1076-1110), ISPUNet_LSC (:1196-1225), ResUNet (:2121-2146).  Conv2d(c, 2c, 2, 2) down-samplers (:1253),
     Conv1x1(c, 2c, bias=False) + PixelShuffle(2) up-samplers (:1292-1295), RCAGroups of 2 blocks (middle: 4).  Which of the
     optional parts exist (colour prior + Res_GFM modulation, lens shading) is read off the state_dict, like the count of
-    Res_GFM blocks per level."""
+    Res_GFM blocks per level.  Round 3: ISPUNet_GFM_crop (:811-960: the colour prior reads x[0]), ISPUNet_GFM_LSC1 (:1382-1532: coord
+    concatenated to the RAW in front of a 6-channel intro conv, seen from intro.weight's shape), ISPUNet_GFM_LSC_noskip (:2522-2652: no
+    additive skips, no decoder modulation)."""
     raw = x[0]
     has_gfm, has_lsc = "classifier.model.0.weight" in sd, "lsc.model.0.weight" in sd
     has_lfm = "classifier.cond_first.0.weight" in sd     # ISPUNet_GFM_LFM (:1535-1707): vector AND map modulation, maps per level from CondNet1..4
-    v = color_condition_gfm(sd, "classifier", x[1]) if has_gfm else None
+    v = color_condition_gfm(sd, "classifier", raw if cond_from_raw else x[1]) if has_gfm else None
     lmap = {}
     if has_lfm:
         v, lfm = color_condition_gfm_lfm(sd, "classifier", x[1], raw)
@@ -335,17 +337,21 @@ def _strided_unet(sd: SD, x: Sequence[torch.Tensor]) -> torch.Tensor:
         t = rcag(sd, f"{p}.{i}", t, nb=2)
         return F.leaky_relu(conv(sd, f"{p}.{i + 1}", t), 0.1)
 
-    intro = conv(sd, "intro", raw)
+    intro = conv(sd, "intro", torch.cat([raw, x[2]], dim=1) if sd["intro.weight"].shape[1] == 6 else raw)     # :1497
     if has_lsc:
         intro = intro * (lens_shading(sd, "lsc", x[2]) + 1)
     d1 = down("down1", enc("encoder1", gfm("encoder_modulation1", intro), False))
     d2 = down("down2", enc("encoder2", gfm("encoder_modulation2", d1), False))
     d3 = down("down3", enc("encoder3", gfm("encoder_modulation3", d2), True))
     m = gfm("middle_modulation", d3)
-    m = conv(sd, "middle.2", rcag(sd, "middle.1", conv(sd, "middle.0", m), nb=4)) + d3
+    m = conv(sd, "middle.2", rcag(sd, "middle.1", conv(sd, "middle.0", m), nb=4))
+    if skips:
+        m = m + d3
 
     def dec(i, t, skip):
         t = conv(sd, f"decoder{i}.1", rcag(sd, f"decoder{i}.0", up(f"up{i}", t), nb=2))
+        if not skips:                                    # :2646-2648
+            return t
         return gfm(f"decoder_modulation{i}", t) + skip
 
     u = dec(1, dec(2, dec(3, m, d2), d1), intro)
@@ -373,7 +379,16 @@ def liteispnet_gfmresize(sd: SD, x: Sequence[torch.Tensor]) -> torch.Tensor:
     return _dwt_unet(sd, x, cond_from_raw=True)
 
 
-FORWARDS = {"ISPUNet_GFM_LSC": ispunet_gfm_lsc, "LiteISPNet": liteispnet, "LiteISPNet_GFM_LSC": liteispnet_gfm_lsc, "LiteISPNet_GFM_LSC_GMA": liteispnet_gfm_lsc_gma,
+def ispunet_gfm_crop(sd: SD, x: Sequence[torch.Tensor]) -> torch.Tensor:
+    return _strided_unet(sd, x, cond_from_raw=True)
+
+
+def ispunet_gfm_lsc_noskip(sd: SD, x: Sequence[torch.Tensor]) -> torch.Tensor:
+    return _strided_unet(sd, x, skips=False)
+
+
+FORWARDS = {"ISPUNet_GFM_crop": ispunet_gfm_crop, "ISPUNet_GFM_LSC1": _strided_unet, "ISPUNet_GFM_LSC_noskip": ispunet_gfm_lsc_noskip,
+            "ISPUNet_GFM_LSC": ispunet_gfm_lsc, "LiteISPNet": liteispnet, "LiteISPNet_GFM_LSC": liteispnet_gfm_lsc, "LiteISPNet_GFM_LSC_GMA": liteispnet_gfm_lsc_gma,
             "ISPUNet_GFM": _strided_unet, "ISPUNet_LSC": _strided_unet, "ResUNet": _strided_unet, "ISPUNet_GFM_LFM": _strided_unet,
             "LiteISPNet_LSC": _dwt_unet, "LiteISPNet_GFM": _dwt_unet, "LiteISPNet_GFMresize": liteispnet_gfmresize}
 

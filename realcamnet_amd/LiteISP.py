@@ -435,7 +435,11 @@ class _StridedUNet(nn.Module):
 
     output_dtype: Optional[torch.dtype] = None
 
-    def _build(self, chan=32, cond_c=None, lsc=False, m_blocks=2):
+    cond_from_raw = False        # ISPUNet_GFM_crop: the colour prior reads the packed RAW x[0] itself (upstream :928)
+    coord_in_intro = False       # ISPUNet_GFM_LSC1: coord is concatenated to the RAW in front of a 6-channel intro conv (upstream :1497)
+    skips = True                 # ISPUNet_GFM_LSC_noskip: no additive skips and no modulation on the way up (upstream :2626-2650)
+
+    def _build(self, chan=32, cond_c=None, lsc=False, m_blocks=2, lsc_nf=None, intro_in=4, dec_gfm=True):
         n_blocks = 2
         if cond_c is not None:
             self.classifier = Color_Condition_GFM(in_channels=4, out_c=cond_c)
@@ -447,9 +451,9 @@ class _StridedUNet(nn.Module):
         def lrelu():
             return nn.LeakyReLU(negative_slope=1e-1, inplace=True)
 
-        self.intro = N.seq(N.Conv2d(4, chan, 3, 1, 1))
+        self.intro = N.seq(N.Conv2d(intro_in, chan, 3, 1, 1))
         if lsc:
-            self.lsc = Lens_Shading_Correction(in_channels=2, out_c=chan, nf=chan)
+            self.lsc = Lens_Shading_Correction(in_channels=2, out_c=chan, nf=chan if lsc_nf is None else lsc_nf)
         gfm("encoder_modulation1", chan)
         self.encoder1 = N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.Conv2d(chan, chan, 3, 1, 1), lrelu())
         self.down1 = N.Conv2d(chan, chan * 2, 2, 2)
@@ -469,7 +473,8 @@ class _StridedUNet(nn.Module):
         for i in (3, 2, 1):
             setattr(self, f"up{i}", N.seq(N.Conv2d(chan, chan * 2, 1, bias=False), nn.PixelShuffle(2)))
             chan = chan // 2
-            gfm(f"decoder_modulation{i}", chan)
+            if dec_gfm:
+                gfm(f"decoder_modulation{i}", chan)
             setattr(self, f"decoder{i}", N.seq(N.RCAGroup(in_channels=chan, out_channels=chan, nb=n_blocks), N.conv(chan, chan, mode='C')))
         self.tail = N.seq(N.conv(chan, chan * 4, mode='C'), nn.PixelShuffle(upscale_factor=2), N.conv(chan, 3, mode='C'))
 
@@ -477,9 +482,12 @@ class _StridedUNet(nn.Module):
         return self.intro.weight.dtype
 
     def _run(self, a, cond, coord_nhwc, crop_hw=None):
-        if hasattr(self, "lsc"):
-            intro = ops.lsc_chain(self.lsc, coord_nhwc, self.intro, a)  # intro(raw) * (lsc + 1)
-            if intro is None:
+        if self.coord_in_intro:                                          # intro(torch.cat([x[0], x[2]], dim=1)) as conv(raw) + conv(coord)
+            w_raw, w_co = ops.split_conv_input_views(self.intro, (4, 2))
+            intro = ops.conv2d(coord_nhwc, w_co, residual=ops.conv2d(a, w_raw))
+        elif hasattr(self, "lsc"):
+            intro = ops.lsc_chain(self.lsc, coord_nhwc, self.intro, a) if self.lsc.model[0].out_channels == self.intro.out_channels else None
+            if intro is None:                                            # intro(raw) * (lsc + 1); lsc_chain fuses it for equal widths
                 intro = self.intro._nhwc(a, mul_plus1=self.lsc._nhwc(coord_nhwc))
         else:
             intro = self.intro._nhwc(a)
@@ -487,18 +495,20 @@ class _StridedUNet(nn.Module):
         vec = self.classifier._vec(ops._req(cond, "cond")) if has_gfm else None
 
         def gfm(name, t):
-            return getattr(self, name)._nhwc((t, vec))[0] if has_gfm else t
+            return getattr(self, name)._nhwc((t, vec))[0] if (has_gfm and hasattr(self, name)) else t
 
         def dec(i, t, skip):
             t = getattr(self, f"up{i}")._nhwc(t)
-            if has_gfm:
+            if not self.skips:
+                return getattr(self, f"decoder{i}")._nhwc(t)
+            if has_gfm and hasattr(self, f"decoder_modulation{i}"):
                 return ops.add(gfm(f"decoder_modulation{i}", getattr(self, f"decoder{i}")._nhwc(t)), skip)
             return getattr(self, f"decoder{i}")._nhwc(t, residual=skip)            # decoder's last conv takes the skip add
 
         d1 = self.down1._nhwc(self.encoder1._nhwc(gfm("encoder_modulation1", intro)))
         d2 = self.down2._nhwc(self.encoder2._nhwc(gfm("encoder_modulation2", d1)))
         d3 = self.down3._nhwc(self.encoder3._nhwc(gfm("encoder_modulation3", d2)))
-        m = self.middle._nhwc(gfm("middle_modulation", d3), residual=d3)
+        m = self.middle._nhwc(gfm("middle_modulation", d3), residual=d3 if self.skips else None)
         u1 = dec(1, dec(2, dec(3, m, d2), d1), intro)
         t = self.tail[0]._nhwc(u1, out_mode=RC_OUT_PIXEL_SHUFFLE2)
         return self.tail[2]._nhwc(t, out_mode=RC_OUT_NCHW, crop_hw=crop_hw, out_dtype=self.output_dtype)
@@ -511,12 +521,13 @@ class _StridedUNet(nn.Module):
             raise ValueError(f"raw must be (B,4,H,W) with H,W multiples of 8 (three stride-2 levels), got {tuple(raw.shape)}")
         dt = self._act_dtype()
         co = None
-        if hasattr(self, "lsc"):
+        if hasattr(self, "lsc") or self.coord_in_intro:
             coord = x[2]
             if coord.shape[0] != raw.shape[0] or coord.shape[1] != 2 or coord.shape[2:] != raw.shape[2:]:
                 raise ValueError(f"coord must be (B,2,H,W) matching raw, got {tuple(coord.shape)}")
             co = ops.to_nhwc(coord, dtype=dt)
-        return self._run(ops.to_nhwc(raw, dtype=dt), x[1] if hasattr(self, "classifier") else None, co)
+        cond = (raw if self.cond_from_raw else x[1]) if hasattr(self, "classifier") else None
+        return self._run(ops.to_nhwc(raw, dtype=dt), cond, co)
 
     def forward_mosaic(self, mosaic, cond=None, coord=None, pad_to: int = 16, black_level: float = 0.0, white_level: float = 1.0,
                        cond_hw=(256, 256)):
@@ -528,10 +539,12 @@ class _StridedUNet(nn.Module):
         a, cond = _ingest(self, mosaic, cond, dt, pad_to, black_level, white_level, cond_hw)
         b, hp, wp, _ = a.shape
         co = None
-        if hasattr(self, "lsc"):
+        if hasattr(self, "lsc") or self.coord_in_intro:
             if coord is None or coord.shape[-2:] != (mosaic.shape[-2] // 2, mosaic.shape[-1] // 2):
                 raise ValueError("coord must be at packed resolution (h, w)")
             co = ops.to_nhwc(coord, dtype=dt, pad_hw=(hp, wp))
+        if hasattr(self, "classifier") and self.cond_from_raw:
+            cond = ops.to_nchw(a)                             # the padded packed RAW, as upstream's x[0]
         return self._run(a, cond, co, crop_hw=(mosaic.shape[-2], mosaic.shape[-1]))
 
 
@@ -565,6 +578,36 @@ class ResUNet(_StridedUNet):
     def __init__(self):
         super().__init__()
         self._build(chan=32)
+
+
+class ISPUNet_GFM_crop(_StridedUNet):
+    """upstream LiteISP.py:811-960: ISPUNet_GFM at 64 channels, cond_c = 64, one Res_GFM per level, and the colour prior reading the
+    packed RAW x[0] itself (:928) -- "its own crop as the global condition"."""
+    cond_from_raw = True
+
+    def __init__(self):
+        super().__init__()
+        self._build(chan=64, cond_c=64, lsc=False, m_blocks=1)
+
+
+class ISPUNet_GFM_LSC1(_StridedUNet):
+    """upstream LiteISP.py:1382-1532: the position code is concatenated to the RGGB planes (intro = Conv2d(6, 32, 3)) instead of going
+    through a Lens_Shading_Correction branch."""
+    coord_in_intro = True
+
+    def __init__(self):
+        super().__init__()
+        self._build(chan=32, cond_c=32, lsc=False, m_blocks=2, intro_in=6)
+
+
+class ISPUNet_GFM_LSC_noskip(_StridedUNet):
+    """upstream LiteISP.py:2522-2652: ISPUNet_GFM_LSC with one Res_GFM per level on the way down only, no additive skips (middle,
+    decoders) and a lens-shading MLP of hidden width lsc_c."""
+    skips = False
+
+    def __init__(self, cond_c=32, lsc_c=32):
+        super().__init__()
+        self._build(chan=32, cond_c=cond_c, lsc=True, m_blocks=1, lsc_nf=lsc_c, dec_gfm=False)
 
 
 class ISPUNet_GFM_LFM(nn.Module):

@@ -140,11 +140,13 @@ _SIGS = {
     "rc_gc_dequantize": (C.c_int, [_P, _P, _I, _I, C.c_longlong, _I, _P, _P]),
     "rc_eb_symbols": (C.c_int, [_P, _P, _I, _I, C.c_longlong, _I, _I, _P, _P, _P, _P]),
     "rc_rans_chunk_words": (C.c_int, [_I]),
-    "rc_rans_encode_chunks": (C.c_int, [_P, _P, C.c_longlong, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "rc_rans_encode_scratch_bytes": (_SZ, [C.c_longlong, _I]),
+    "rc_rans_encode_chunks": (C.c_int, [_P, _P, C.c_longlong, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "rc_debug_rans_rcp_selftest": (C.c_longlong, [C.c_longlong, C.c_ulonglong]),
     "rc_rans_compact": (C.c_int, [_P, _I, _P, _P, C.c_longlong, _P, _P]),
-    "rc_rans_decode_chunks": (C.c_int, [_P, _P, _P, C.c_longlong, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "rc_rans_decode_chunks": (C.c_int, [_P, C.c_longlong, _P, _P, C.c_longlong, _I, _P, _I, _I, _P, _P, _P, _P, _P]),
     "rc_rans_encode_host": (C.c_longlong, [_P, _P, C.c_longlong, _P, _I, _I, _P, _P, _P, C.c_longlong]),
-    "rc_rans_decode_host": (C.c_int, [_P, _P, _P, C.c_longlong, _P, _I, _I, _P, _P, _P]),
+    "rc_rans_decode_host": (C.c_int, [_P, C.c_longlong, _P, _P, C.c_longlong, _P, _I, _I, _P, _P, _P]),
     "rc_debug_set": (C.c_int, [C.c_char_p, _I]),
     "rc_debug_set_ptr": (C.c_int, [C.c_char_p, _P]),
     "rc_prof_enable": (C.c_int, [_I]),

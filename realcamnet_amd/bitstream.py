@@ -64,10 +64,11 @@ def gaussian_tables(scale_table: torch.Tensor, tail_mass: float = 1e-9):
 
 def bottleneck_tables(eb):
     """EntropyBottleneck.update(): tables of the factorised density from the module's parameters (fp32 on the host)."""
-    q = eb.quantiles.detach().float().cpu()
-    mats = [torch.nn.functional.softplus(getattr(eb, f"_matrix{i}").detach().float().cpu()) for i in range(5)]
-    biases = [getattr(eb, f"_bias{i}").detach().float().cpu() for i in range(5)]
-    factors = [torch.tanh(getattr(eb, f"_factor{i}").detach().float().cpu()) for i in range(4)]
+    g = (lambda n: eb._master(n).cpu()) if hasattr(eb, "_master") else (lambda n: getattr(eb, n).detach().float().cpu())   # fp32 masters (tcm._Fp32Masters)
+    q = g("quantiles")
+    mats = [torch.nn.functional.softplus(g(f"_matrix{i}")) for i in range(5)]
+    biases = [g(f"_bias{i}") for i in range(5)]
+    factors = [torch.tanh(g(f"_factor{i}")) for i in range(4)]
 
     def logits(x):
         for i in range(5):
@@ -154,16 +155,25 @@ class Decoder:
             idx = np.ascontiguousarray(indexes.cpu().numpy())
             cdf, sizes, offs = self.tables.host()
             out = np.empty(n, dtype=np.int32)
-            check(L.rc_rans_decode_host(self.buf.ctypes.data, self.state, idx.ctypes.data, n, cdf.ctypes.data, cdf.shape[1], cdf.shape[0],
-                                        sizes.ctypes.data, offs.ctypes.data, out.ctypes.data), "rc_rans_decode_host")
+            if self.buf.size < 8 or self.buf.size % 4:
+                raise ValueError("corrupt rANS stream: not a whole number of 32-bit words / shorter than the flushed state")
+            check(L.rc_rans_decode_host(self.buf.ctypes.data, self.buf.size, self.state, idx.ctypes.data, n, cdf.ctypes.data, cdf.shape[1],
+                                        cdf.shape[0], sizes.ctypes.data, offs.ctypes.data, out.ctypes.data), "rc_rans_decode_host")
             return torch.from_numpy(out).to(self.device)
+        # the container is validated BEFORE anything is uploaded: the kernels bound every read by these sizes
+        if self.buf.size - self.pos < 16:
+            raise ValueError("corrupt chunked rANS container: truncated header")
         magic, n_sym, chunk, n_chunks = struct.unpack_from("<4sIII", self.buf, self.pos)
-        if magic != MAGIC or n_sym != n or n_chunks != -(-n // chunk):
+        if magic != MAGIC or chunk < 1 or n_sym != n or n_chunks != -(-n // chunk):
             raise ValueError("corrupt or mismatched chunked rANS container")
         p = self.pos + 16
+        if self.buf.size - p < 4 * n_chunks:
+            raise ValueError("corrupt chunked rANS container: truncated size table")
         sizes = np.frombuffer(self.buf, dtype="<u4", count=n_chunks, offset=p).astype(np.int64)
         p += 4 * n_chunks
         total = int(sizes.sum())
+        if int(sizes.min()) < 8 or np.any(sizes % 4) or p + total > self.buf.size:
+            raise ValueError("corrupt chunked rANS container: a chunk is shorter than its flushed state / not word-sized, or the payload is truncated")
         payload = torch.from_numpy(self.buf[p:p + total].copy()).to(self.device)
         offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)).to(self.device)
         self.pos = p + total

@@ -88,13 +88,59 @@ __host__ __device__ inline uint32_t* encode_range(const int32_t* sym, const int3
     return ptr;
 }
 
-struct DecState { uint64_t x; long pos; };
+// ---- division-free put (ryg rans64 "RansEncSymbol"): bit-identical to put(), the per-symbol reciprocal is computed where it is cheap ----
+// q = floor(x / freq) = mulhi(x, rcp) >> shift for every x < 2^63, with shift = ceil(log2 freq) - 1 and rcp = ceil(2^(shift + 64) / freq);
+// freq == 1 takes rcp = 2^64 - 1, shift 0 and the bias start + 2^16 - 1 (mulhi gives x - 1).  Then x' = x + bias + q * (2^16 - freq).
+struct Rcp { uint64_t rcp; uint32_t shift; };
+__host__ __device__ inline Rcp make_rcp(uint32_t freq) {
+    Rcp r;
+    if (freq < 2) { r.rcp = ~0ull; r.shift = 0; return r; }
+    uint32_t shift = 0;
+    while (freq > (1u << shift)) ++shift;
+    // ((1 << (shift + 63)) + freq - 1) / freq as a 128 / 32-bit long division in two 64-bit halves
+    uint64_t x0 = freq - 1;
+    const uint64_t x1 = 1ull << (shift + 31);
+    const uint64_t t1 = x1 / freq;
+    x0 += (x1 % freq) << 32;
+    const uint64_t t0 = x0 / freq;
+    r.rcp = t0 + (t1 << 32);
+    r.shift = shift - 1;
+    return r;
+}
+__host__ __device__ inline uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+__host__ __device__ inline bool put_rcp(uint64_t& x, uint32_t*& ptr, uint32_t* begin, uint32_t start, uint32_t freq, const Rcp& r) {
+    const uint64_t x_max = ((kL >> kPrec) << 32) * freq;
+    if (x >= x_max) {
+        if (ptr == begin) return false;
+        *--ptr = (uint32_t)x;
+        x >>= 32;
+    }
+    const uint64_t q = mulhi64(x, r.rcp) >> r.shift;
+    const uint64_t bias = freq < 2 ? (uint64_t)start + (1u << kPrec) - 1 : (uint64_t)start;
+    x = x + bias + q * ((1u << kPrec) - freq);
+    return true;
+}
+
+// n_words: length of the stream in 32-bit words.  A renormalisation that would read past it sets `bad` (and reads nothing): a truncated or
+// corrupt stream ends in an error, never in an out-of-bounds read.
+struct DecState { uint64_t x; long pos; long n_words; bool bad; };
+
+__host__ __device__ inline uint32_t next_word(DecState& st, const uint32_t* words) {
+    if (st.pos >= st.n_words) { st.bad = true; return 0u; }
+    return words[st.pos++];
+}
 
 __host__ __device__ inline uint32_t get_bits(DecState& st, const uint32_t* words) {
     uint64_t x = st.x;
     const uint32_t val = (uint32_t)(x & kMaxBypass);
     x >>= kBypassBits;
-    if (x < kL) { x = (x << 32) | words[st.pos]; st.pos += 1; }
+    if (x < kL) x = (x << 32) | next_word(st, words);
     st.x = x;
     return val;
 }
@@ -117,34 +163,115 @@ __host__ __device__ inline bool decode_range(const uint32_t* words, DecState& st
         {
             const uint32_t start = (uint32_t)cdf[s], freq = (uint32_t)(cdf[s + 1] - cdf[s]);
             uint64_t x = (uint64_t)freq * (st.x >> kPrec) + (st.x & ((1u << kPrec) - 1)) - start;
-            if (x < kL) { x = (x << 32) | words[st.pos]; st.pos += 1; }
+            if (x < kL) x = (x << 32) | next_word(st, words);
             st.x = x;
         }
         int32_t value = s;
         if (value == max_value) {
             int32_t val = (int32_t)get_bits(st, words), n_bypass = val;
-            while (val == (int32_t)kMaxBypass) { val = (int32_t)get_bits(st, words); n_bypass += val; }
+            while (val == (int32_t)kMaxBypass && !st.bad && n_bypass <= 8) { val = (int32_t)get_bits(st, words); n_bypass += val; }
+            if (n_bypass > 8) st.bad = true;                     // a 32-bit escape has at most 8 nibbles: anything longer is a corrupt stream
+            if (st.bad) return false;
             uint32_t raw = 0;
             for (int32_t j = 0; j < n_bypass; ++j) raw |= get_bits(st, words) << (j * kBypassBits);
             value = (int32_t)(raw >> 1);
             if (raw & 1) value = -value - 1; else value += max_value;
         }
         out[i] = value + t.offsets[ci];
+        if (st.bad) return false;
     }
     return true;
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------------------------------
-// One lane per chunk.  words: [n_chunks][cap] scratch (each chunk's stream ends at its region's end); nbytes[chunk] = stream length,
-// -1 on error.
-__global__ void encode_chunks_kernel(const int32_t* sym, const int32_t* idx, long n, int chunk, Tables t, uint32_t* words, int cap,
-                                     int32_t* nbytes, long n_chunks) {
+// Encoding in two launches.  Everything about a symbol except the state update is independent of the rANS state: which CDF row, the
+// escape decision, (start, freq) and the reciprocal of freq.  prepare_kernel does that for all symbols in parallel and writes the
+// operations TRANSPOSED, op i of chunk c at [i][c], so the lanes of the serial kernel (one per chunk) read consecutive addresses; the
+// serial kernel is then ~25 integer instructions per symbol with no dependent loads and no 64-bit division.  (As ONE kernel -- idx ->
+// sizes/offsets -> cdf as three dependent global loads at an 8 KB lane stride, then a 64-bit division -- a 2048-symbol chunk took 1.5 ms:
+// 6 calls = 9 of compress()'s 30 ms per 4K frame, profiles/r03_codec_stream.md.)
+struct EncOps { uint64_t* rcp; uint32_t* fs; uint32_t* raw; uint16_t* meta; };   // fs = start | freq << 16; meta = rcp shift | n_bypass << 8 (0xFF: no escape)
+
+__host__ __device__ inline EncOps enc_ops(void* scratch, long n_pad) {
+    EncOps o;
+    char* p = static_cast<char*>(scratch);
+    o.rcp = reinterpret_cast<uint64_t*>(p); p += 8 * n_pad;
+    o.fs = reinterpret_cast<uint32_t*>(p); p += 4 * n_pad;
+    o.raw = reinterpret_cast<uint32_t*>(p); p += 4 * n_pad;
+    o.meta = reinterpret_cast<uint16_t*>(p);
+    return o;
+}
+
+__global__ void prepare_kernel(const int32_t* __restrict__ sym, const int32_t* __restrict__ idx, long n, int chunk, long n_chunks, Tables t, EncOps ops,
+                               int32_t* __restrict__ err) {
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
+        const long c = o / chunk, i = o - c * chunk;
+        const long dst = i * n_chunks + c;
+        const int32_t ci = idx[o];
+        if (ci < 0 || ci >= t.n_cdfs) { atomicExch(err, 1); ops.fs[dst] = 1u << 16; ops.meta[dst] = 0xFF00; ops.rcp[dst] = ~0ull; continue; }
+        const int32_t* cdf = t.cdf + (long)ci * t.stride;
+        const int32_t max_value = t.sizes[ci] - 2;
+        int32_t value = sym[o] - t.offsets[ci];
+        uint32_t raw = 0;
+        if (value < 0) { raw = (uint32_t)(-2 * value - 1); value = max_value; }
+        else if (value >= max_value) { raw = (uint32_t)(2 * (value - max_value)); value = max_value; }
+        uint32_t nb = 0xFF;
+        if (value == max_value) {
+            nb = 0;
+            while (nb < 8 && (raw >> (nb * kBypassBits)) != 0) ++nb;
+        }
+        const uint32_t start = (uint32_t)cdf[value], freq = (uint32_t)(cdf[value + 1] - cdf[value]);
+        const Rcp r = make_rcp(freq);
+        ops.rcp[dst] = r.rcp;
+        ops.fs[dst] = start | (freq << 16);
+        ops.raw[dst] = raw;
+        ops.meta[dst] = (uint16_t)(r.shift | (nb << 8));
+    }
+}
+
+// One lane per chunk: the serial part.  words: [n_chunks][cap] scratch (each chunk's stream ends at its region's end); nbytes[chunk] = stream
+// length, -1 on error.  Symbols are coded LAST TO FIRST (see encode_range for the order of an escape's pieces).
+__global__ void encode_serial_kernel(long n, int chunk, long n_chunks, EncOps ops, uint32_t* words, int cap, int32_t* nbytes, const int32_t* err) {
     const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
-    const long i0 = c * chunk, i1 = (i0 + chunk) < n ? (i0 + chunk) : n;
+    const long i0 = c * chunk, len = ((i0 + chunk) < n ? (i0 + chunk) : n) - i0;
     uint32_t* begin = words + c * cap;
-    uint32_t* p = encode_range(sym, idx, i0, i1, t, begin, begin + cap);
-    nbytes[c] = p ? (int32_t)((begin + cap - p) * 4) : -1;
+    uint32_t* ptr = begin + cap;
+    uint64_t x = kL;
+    bool ok = *err == 0;
+    // batches of kB symbols: their operations are loaded together (the addresses do not depend on the state), so one memory latency is
+    // paid per batch instead of per symbol (one symbol per iteration measured ~1000 cycles per symbol: all of it load latency)
+    constexpr int kB = 16;
+    for (long hi = len; hi > 0 && ok; hi -= kB) {
+        uint32_t fs[kB], meta[kB];
+        uint64_t rcp[kB];
+#pragma unroll
+        for (int k = 0; k < kB; ++k) {
+            const long i = hi - 1 - k;
+            const long src = (i >= 0 ? i : 0) * n_chunks + c;
+            fs[k] = ops.fs[src]; meta[k] = ops.meta[src]; rcp[k] = ops.rcp[src];
+        }
+#pragma unroll
+        for (int k = 0; k < kB; ++k) {
+            const long i = hi - 1 - k;
+            if (i < 0 || !ok) continue;
+            Rcp r; r.rcp = rcp[k]; r.shift = meta[k] & 0xFF;
+            const uint32_t nb = meta[k] >> 8;
+            if (nb != 0xFF) {
+                const uint32_t raw = ops.raw[i * n_chunks + c];
+                for (int j = (int)nb - 1; j >= 0; --j) ok = ok && put_bits(x, ptr, begin, (raw >> (j * kBypassBits)) & kMaxBypass);
+                ok = ok && put_bits(x, ptr, begin, nb % kMaxBypass);
+                for (uint32_t q = 0; q < nb / kMaxBypass; ++q) ok = ok && put_bits(x, ptr, begin, kMaxBypass);
+            }
+            ok = ok && put_rcp(x, ptr, begin, fs[k] & 0xFFFFu, fs[k] >> 16, r);
+        }
+    }
+    if (ok && ptr - begin >= 2) {
+        ptr -= 2;
+        ptr[0] = (uint32_t)x;
+        ptr[1] = (uint32_t)(x >> 32);
+        nbytes[c] = (int32_t)((begin + cap - ptr) * 4);
+    } else nbytes[c] = -1;
 }
 
 // gather the chunk streams into one contiguous buffer: block = chunk
@@ -157,16 +284,18 @@ __global__ void compact_kernel(const uint32_t* words, int cap, const int32_t* nb
     for (int i = threadIdx.x; i < nw; i += blockDim.x) dst[i] = src[i];
 }
 
-__global__ void decode_chunks_kernel(const uint8_t* stream, const long long* offsets, const int32_t* idx, long n, int chunk, Tables t,
-                                     int32_t* out, int32_t* err, long n_chunks) {
+__global__ void decode_chunks_kernel(const uint8_t* stream, long long stream_bytes, const long long* offsets, const int32_t* idx, long n, int chunk,
+                                     Tables t, int32_t* out, int32_t* err, long n_chunks) {
     const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const long i0 = c * chunk, i1 = (i0 + chunk) < n ? (i0 + chunk) : n;
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(stream + offsets[c]);
+    const long long b0 = offsets[c], b1 = c + 1 < n_chunks ? offsets[c + 1] : stream_bytes;
+    if (b0 < 0 || b1 > stream_bytes || b1 - b0 < 8 || ((b1 - b0) & 3) || (b0 & 3)) { atomicExch(err, 2); return; }   // a stream is >= one flushed state, whole words
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(stream + b0);
     DecState st;
     st.x = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-    st.pos = 2;
-    if (!decode_range(w, st, idx, i0, i1, t, out)) atomicExch(err, 1);
+    st.pos = 2; st.n_words = (long)((b1 - b0) >> 2); st.bad = false;
+    if (!decode_range(w, st, idx, i0, i1, t, out)) atomicExch(err, st.bad ? 2 : 1);
 }
 
 // ---- symbol preparation ------------------------------------------------------------------------------------------------------------
@@ -320,16 +449,55 @@ int rc_eb_symbols(const void* d_z, const float* d_medians, int dtype, int batch,
 // words per chunk of scratch that can never overflow: an escaped symbol costs at most 16 + 4 + 8 x 4 = 52 bits < 2 words
 int rc_rans_chunk_words(int chunk) { return chunk > 0 ? 2 * chunk + 8 : 0; }
 
+// scratch of rc_rans_encode_chunks: the prepared operations (18 bytes per symbol slot, chunk-padded) + an error word
+size_t rc_rans_encode_scratch_bytes(long long n, int chunk) {
+    if (n < 1 || chunk < 1) return 0;
+    const long long n_pad = (n + chunk - 1) / chunk * chunk;
+    return (size_t)n_pad * 18 + 16;
+}
+
 int rc_rans_encode_chunks(const int32_t* d_symbols, const int32_t* d_indexes, long long n, int chunk, const int32_t* d_cdf, int cdf_stride,
-                          int n_cdfs, const int32_t* d_cdf_sizes, const int32_t* d_offsets, uint32_t* d_words, int32_t* d_nbytes, void* stream) {
-    RC_REQUIRE(d_symbols && d_indexes && d_cdf && d_cdf_sizes && d_offsets && d_words && d_nbytes, "rc_rans_encode_chunks: null pointer");
+                          int n_cdfs, const int32_t* d_cdf_sizes, const int32_t* d_offsets, uint32_t* d_words, int32_t* d_nbytes, void* d_scratch,
+                          void* stream) {
+    RC_REQUIRE(d_symbols && d_indexes && d_cdf && d_cdf_sizes && d_offsets && d_words && d_nbytes && d_scratch, "rc_rans_encode_chunks: null pointer");
     RC_REQUIRE(n >= 1 && chunk >= 1 && cdf_stride >= 2 && n_cdfs >= 1, "rc_rans_encode_chunks: bad shape");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_scratch) % 8 == 0, "rc_rans_encode_chunks: scratch must be 8-byte aligned");
     const long n_chunks = (n + chunk - 1) / chunk;
+    const long n_pad = n_chunks * chunk;
     const Tables t{d_cdf, cdf_stride, n_cdfs, d_cdf_sizes, d_offsets};
-    hipLaunchKernelGGL(encode_chunks_kernel, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), 0, as_stream(stream), d_symbols, d_indexes, (long)n,
-                       chunk, t, d_words, rc_rans_chunk_words(chunk), d_nbytes, n_chunks);
+    const EncOps ops = enc_ops(d_scratch, n_pad);
+    int32_t* d_err = reinterpret_cast<int32_t*>(static_cast<char*>(d_scratch) + (size_t)n_pad * 18 + ((8 - ((size_t)n_pad * 18) % 8) % 8));
+    RC_HIP_CHECK(hipMemsetAsync(d_err, 0, 4, as_stream(stream)));
+    hipLaunchKernelGGL(prepare_kernel, dim3(grid1d(n)), dim3(256), 0, as_stream(stream), d_symbols, d_indexes, (long)n, chunk, n_chunks, t, ops, d_err);
+    hipLaunchKernelGGL(encode_serial_kernel, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), 0, as_stream(stream), (long)n, chunk, n_chunks, ops,
+                       d_words, rc_rans_chunk_words(chunk), d_nbytes, d_err);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
+}
+
+// self-test of the division-free put against the dividing one on random (state, start, freq): returns the number of mismatches
+long long rc_debug_rans_rcp_selftest(long long trials, unsigned long long seed) {
+    long long bad = 0;
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto next = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    uint32_t buf[4];
+    for (long long i = 0; i < trials; ++i) {
+        uint32_t freq = 1 + (uint32_t)(next() % 65535u);
+        if (i % 7 == 0) freq = 1u << (next() % 16);                       // powers of two and tiny frequencies are the edge cases
+        if (i % 11 == 0) freq = 1 + (uint32_t)(next() % 3);
+        const uint32_t start = (uint32_t)(next() % (65536u - freq + 1));
+        uint64_t x = kL + next() % ((kL << 32) - kL);                       // any reachable state in [2^31, 2^63)
+        if (i % 5 == 0) x = (i & 1) ? kL : (kL << 32) - 1;
+        uint64_t xa = x, xb = x;
+        uint32_t *pa = buf + 2, *pb = buf + 4;
+        uint32_t keep[4] = {0, 0, 0, 0};
+        put(xa, pa, buf, start, freq);
+        keep[0] = buf[1]; const long na = (buf + 2) - pa;
+        put_rcp(xb, pb, buf + 2, start, freq, make_rcp(freq));
+        const long nb = (buf + 4) - pb;
+        if (xa != xb || na != nb || (na == 1 && keep[0] != buf[3])) ++bad;
+    }
+    return bad;
 }
 
 int rc_rans_compact(const uint32_t* d_words, int chunk, const int32_t* d_nbytes, const long long* d_offsets, long long n_chunks, void* d_out,
@@ -341,15 +509,15 @@ int rc_rans_compact(const uint32_t* d_words, int chunk, const int32_t* d_nbytes,
     return RC_OK;
 }
 
-int rc_rans_decode_chunks(const void* d_stream, const long long* d_offsets, const int32_t* d_indexes, long long n, int chunk, const int32_t* d_cdf,
-                          int cdf_stride, int n_cdfs, const int32_t* d_cdf_sizes, const int32_t* d_cdf_offsets, int32_t* d_symbols, int32_t* d_err,
-                          void* stream) {
+int rc_rans_decode_chunks(const void* d_stream, long long stream_bytes, const long long* d_offsets, const int32_t* d_indexes, long long n, int chunk,
+                          const int32_t* d_cdf, int cdf_stride, int n_cdfs, const int32_t* d_cdf_sizes, const int32_t* d_cdf_offsets, int32_t* d_symbols,
+                          int32_t* d_err, void* stream) {
     RC_REQUIRE(d_stream && d_offsets && d_indexes && d_cdf && d_cdf_sizes && d_cdf_offsets && d_symbols && d_err, "rc_rans_decode_chunks: null pointer");
-    RC_REQUIRE(n >= 1 && chunk >= 1, "rc_rans_decode_chunks: bad shape");
+    RC_REQUIRE(n >= 1 && chunk >= 1 && stream_bytes >= 8, "rc_rans_decode_chunks: bad shape");
     const long n_chunks = (n + chunk - 1) / chunk;
     const Tables t{d_cdf, cdf_stride, n_cdfs, d_cdf_sizes, d_cdf_offsets};
     hipLaunchKernelGGL(decode_chunks_kernel, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), 0, as_stream(stream), static_cast<const uint8_t*>(d_stream),
-                       d_offsets, d_indexes, (long)n, chunk, t, d_symbols, d_err, n_chunks);
+                       stream_bytes, d_offsets, d_indexes, (long)n, chunk, t, d_symbols, d_err, n_chunks);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
@@ -373,16 +541,20 @@ long long rc_rans_encode_host(const int32_t* symbols, const int32_t* indexes, lo
     return nbytes;
 }
 
-int rc_rans_decode_host(const void* stream_bytes, unsigned long long* state /* [2]: x, next word; x == 0: start of stream */,
+int rc_rans_decode_host(const void* stream_bytes, long long n_bytes, unsigned long long* state /* [2]: x, next word; x == 0: start of stream */,
                         const int32_t* indexes, long long n, const int32_t* cdf, int cdf_stride, int n_cdfs, const int32_t* cdf_sizes,
                         const int32_t* offsets, int32_t* out) {
     RC_REQUIRE(stream_bytes && state && indexes && cdf && cdf_sizes && offsets && out && n >= 0, "rc_rans_decode_host: bad arguments");
+    RC_REQUIRE(n_bytes >= 8 && n_bytes % 4 == 0, "rc_rans_decode_host: a stream is a whole number of 32-bit words, at least the flushed state");
     const uint32_t* w = static_cast<const uint32_t*>(stream_bytes);
     DecState st;
+    st.n_words = (long)(n_bytes / 4); st.bad = false;
     if (state[0] == 0) { st.x = (uint64_t)w[0] | ((uint64_t)w[1] << 32); st.pos = 2; }
-    else { st.x = state[0]; st.pos = (long)state[1]; }
+    else { st.x = state[0]; st.pos = (long)state[1]; RC_REQUIRE(st.pos >= 2 && st.pos <= st.n_words, "rc_rans_decode_host: bad decoder state"); }
     const Tables t{cdf, cdf_stride, n_cdfs, cdf_sizes, offsets};
-    RC_REQUIRE(decode_range(w, st, indexes, 0, n, t, out), "rc_rans_decode_host: CDF index out of range");
+    const bool ok = decode_range(w, st, indexes, 0, n, t, out);
+    RC_REQUIRE(ok || !st.bad, "rc_rans_decode_host: truncated or corrupt stream (read past its end / escape longer than 8 nibbles)");
+    RC_REQUIRE(ok, "rc_rans_decode_host: CDF index out of range");
     state[0] = st.x; state[1] = (unsigned long long)st.pos;
     return RC_OK;
 }

@@ -73,8 +73,8 @@ def invalidate_caches(module) -> None:
     """Drop every derived-parameter cache (packed MFMA weights, fp32 views, folded BatchNorm, CDF tables ...) below `module`.
     load_state_dict / optimizer steps / .to() are detected automatically; edits through `.data` are not."""
     for m in module.modules():
-        m.__dict__.pop("_rc_cache", None)
-        m.__dict__.pop("_pk", None)
+        for k in ("_rc_cache", "_pk", "_eff", "_coder_tables", "_f32_masters"):
+            m.__dict__.pop(k, None)
 
 
 def _cache(mod) -> dict:
@@ -175,6 +175,25 @@ def split_conv_views(mod, sizes):
             raise ValueError("split_conv_views: sizes do not add up to the convolution's output channels")
         hit = ((key, tuple(sizes)), views)
         cache["split_views"] = hit
+    return hit[1]
+
+
+def split_conv_input_views(mod, sizes):
+    """Views of a convolution's INPUT channels [0, s0), [s0, s0 + s1), ...: conv(torch.cat(parts, dim=1)) = sum_i conv_i(parts[i]) (only the
+    first view carries the bias).  Lets `intro(torch.cat([raw, coord], 1))` (upstream models/LiteISP.py:1497) run without the 6-channel
+    concatenated map -- whose 8-byte coord pixels are no whole 16-byte vectors for rc_channel_copy anyway."""
+    cache = _cache(mod)
+    key = _key(mod.weight, mod.bias)
+    hit = cache.get("split_in_views")
+    if hit is None or hit[0] != (key, tuple(sizes)):
+        views, c0 = [], 0
+        for i, n in enumerate(sizes):
+            views.append(_ConvView(mod.weight.detach()[:, c0:c0 + n].contiguous(), mod.bias.detach() if (mod.bias is not None and i == 0) else None))
+            c0 += n
+        if c0 != mod.weight.shape[1]:
+            raise ValueError("split_conv_input_views: sizes do not add up to the convolution's input channels")
+        hit = ((key, tuple(sizes)), views)
+        cache["split_in_views"] = hit
     return hit[1]
 
 

@@ -412,11 +412,55 @@ def _resize_coder_buffers(mod, prefix: str, names, state_dict) -> None:
     mod.__dict__.pop("_coder_tables", None)
 
 
-class EntropyBottleneck(nn.Module):
+class _Fp32Masters:
+    """fp32 master copies of the tensors the CODER depends on (CDF-index thresholds, medians, the density's parameters).  `.to(bfloat16)`
+    rounds a module's floating-point parameters and buffers; thresholds and medians rounded on one side only make a stream that does not
+    decode, and tables built before / after the cast differ.  The masters are taken the moment a cast would round an fp32 tensor (and
+    from the checkpoint's own values in load_state_dict), follow device moves, and are what update() / the symbol kernels read -- so
+    update() -> .to(bf16) and .to(bf16) -> update() give identical strings.  Never part of the state_dict."""
+    _MASTER_NAMES: tuple = ()
+
+    def _master(self, name: str) -> torch.Tensor:
+        live = getattr(self, name)
+        m = self.__dict__.get("_f32_masters", {}).get(name)
+        if live.dtype == torch.float32 or m is None or m.shape != live.shape:
+            return live.detach().float()
+        return m.to(live.device)
+
+    def _apply(self, fn, recurse=True):
+        masters = self.__dict__.setdefault("_f32_masters", {})
+        # snapshot first: nn.Module._apply swaps a Parameter's .data in place, so the "old" object would show the new dtype afterwards
+        pre = {n: getattr(self, n).detach().clone() for n in self._MASTER_NAMES
+               if getattr(self, n).dtype == torch.float32 and getattr(self, n).numel() > 0}
+        out = super()._apply(fn, recurse) if recurse is True else super()._apply(fn)
+        for n in self._MASTER_NAMES:
+            new = getattr(self, n)
+            if new.dtype == torch.float32:
+                masters.pop(n, None)                                  # the live tensor is exact (again)
+            elif n in pre:
+                masters[n] = pre[n]                                   # this cast rounded an fp32 tensor: keep what it rounded
+            if n in masters:
+                masters[n] = masters[n].to(new.device)
+                if n in self._buffers:                                # a buffer (scale_table) simply stays fp32: the state_dict keeps exact values
+                    self._buffers[n] = masters.pop(n)
+        self.__dict__.pop("_coder_tables", None)
+        return out
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        masters = self.__dict__.setdefault("_f32_masters", {})
+        for n in self._MASTER_NAMES:
+            v = state_dict.get(prefix + n)
+            if v is not None and v.is_floating_point() and getattr(self, n).dtype != torch.float32:
+                masters[n] = v.detach().float().clone().to(getattr(self, n).device)   # the checkpoint's exact values, not their rounding
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class EntropyBottleneck(_Fp32Masters, nn.Module):
     """compressai.entropy_models.EntropyBottleneck(channels): parameters, the eval-mode likelihood path, the CDF tables (`update`) and
     `compress` / `decompress` over the GPU rANS coder (restated from its published definition, parity unpinned).  Parameter names
     `_matrix{i}`, `_bias{i}`, `_factor{i}`, `quantiles`, the `target` buffer and EntropyModel's table buffers follow CompressAI's
     classic layout."""
+    _MASTER_NAMES = tuple(f"_matrix{i}" for i in range(5)) + tuple(f"_bias{i}" for i in range(5)) + tuple(f"_factor{i}" for i in range(4)) + ("quantiles",)
 
     def __init__(self, channels: int, tail_mass: float = 1e-9, init_scale: float = 10, filters=(3, 3, 3, 3), likelihood_bound: float = 1e-9):
         super().__init__()
@@ -447,7 +491,7 @@ class EntropyBottleneck(nn.Module):
     def _compress_nhwc(self, z, fmt="chunked", chunk=bitstream.DEFAULT_CHUNK):
         """z NHWC -> (one byte string per image, z_hat NHWC): symbols = round(z - median), index = channel."""
         b, h, w, c = z.shape
-        med = self.quantiles.detach()[:, 0, 1].float().contiguous()
+        med = self._master("quantiles")[:, 0, 1].contiguous()
         sym, idx, z_hat = torch.ops.realcam.eb_symbols(ops._req(z, "z"), None, med, b, h, w, z.dtype)
         tables = _coder_tables(self)
         return [bitstream.encode(sym[i], idx[i], tables, fmt, chunk) for i in range(b)], z_hat
@@ -456,7 +500,7 @@ class EntropyBottleneck(nn.Module):
         h, w = size
         b, c = len(strings), self.channels
         dev = self.quantiles.device
-        med = self.quantiles.detach()[:, 0, 1].float().contiguous()
+        med = self._master("quantiles")[:, 0, 1].contiguous()
         tables = _coder_tables(self)
         idx = torch.arange(c, dtype=torch.int32, device=dev).view(c, 1).expand(c, h * w).contiguous()
         sym = torch.stack([bitstream.Decoder(s, tables, dev, fmt).decode(idx).view(c, h * w) for s in strings])
@@ -511,11 +555,12 @@ class EntropyBottleneck(nn.Module):
         return ops.to_nchw(z_hat), ops.to_nchw(lik)
 
 
-class GaussianConditional(nn.Module):
+class GaussianConditional(_Fp32Masters, nn.Module):
     """compressai.entropy_models.GaussianConditional(None): the eval-mode likelihood path, the scale table / CDF tables
     (`update_scale_table`, `update`) and symbol preparation for the coder (restated, parity unpinned).  Buffers as CompressAI
     registers them: scale_table, scale_bound, lower_bound_scale.bound, likelihood_lower_bound.bound, _offset, _quantized_cdf,
     _cdf_length."""
+    _MASTER_NAMES = ("scale_table",)
 
     def __init__(self, scale_table=None, scale_bound: float = 0.11, tail_mass: float = 1e-9, likelihood_bound: float = 1e-9):
         super().__init__()
@@ -531,16 +576,17 @@ class GaussianConditional(nn.Module):
         if self._offset.numel() > 0 and not force:
             return False
         self.scale_table = torch.as_tensor(sorted(float(s) for s in scale_table), dtype=torch.float32).to(self.scale_table.device)
+        self.__dict__.get("_f32_masters", {}).pop("scale_table", None)      # always stored as fp32: the live buffer is the master
         self.update()
         return True
 
     def update(self) -> None:
-        _set_coder_buffers(self, *bitstream.gaussian_tables(self.scale_table, self.tail_mass))
+        _set_coder_buffers(self, *bitstream.gaussian_tables(self._master("scale_table"), self.tail_mass))
 
     def _table(self, device):
         if self.scale_table.numel() == 0:
             raise RuntimeError("GaussianConditional has no scale table: call the model's update() first")
-        return self.scale_table.detach().to(device=device, dtype=torch.float32).contiguous()
+        return self._master("scale_table").to(device=device, dtype=torch.float32).contiguous()
 
     def _nhwc(self, y, scale, mu):
         return ops.gaussian_conditional(y, scale, mu, self.scale_bound_value, self.likelihood_bound)
@@ -637,11 +683,19 @@ class TCM(nn.Module):
         return {"x_hat": _codec_decompress(self, strings, shape, self._act_dtype(), fmt)}
 
 
+CONTIGUOUS_OUTPUTS = False   # True: every tensor of the result dicts is materialised as a contiguous NCHW tensor, exactly like upstream's
+
+
 def nchw_view(a):
     """(B,H,W,C) NHWC -> the same memory as a (B,C,H,W) tensor in torch's channels_last format: no copy, no launch.  The result dict's
-    side outputs (likelihoods, means, scales, y, lft, lsc -- up to 2.3 GB at 4K) keep upstream's logical NCHW shapes this way; only
-    x_hat is materialised planar."""
-    return a.permute(0, 3, 1, 2)
+    side outputs (likelihoods, means, scales, y, lft, lsc -- up to 2.3 GB at 4K) keep upstream's logical NCHW shapes, values and indexing
+    this way; only x_hat is materialised planar.
+    BOUNDARY NOTE (differs from upstream, which returns contiguous NCHW): these tensors satisfy `is_contiguous(memory_format=
+    torch.channels_last)`, not plain `is_contiguous()`: `.view(...)` across the channel dimension raises (use `.reshape`), and consumers
+    that need dense NCHW memory (`all_gather_into_tensor`, raw pointer / DLPack / NumPy hand-offs) must call `.contiguous()` -- or set
+    `realcamnet_amd.tcm.CONTIGUOUS_OUTPUTS = True` to get upstream's layout everywhere at the cost of one transpose pass per tensor."""
+    v = a.permute(0, 3, 1, 2)
+    return v.contiguous() if CONTIGUOUS_OUTPUTS else v
 
 
 def _fork_join(side_fn, main_fn, inputs):

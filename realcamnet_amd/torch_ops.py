@@ -605,10 +605,14 @@ def _enc_alloc(sym, idx, cdf, sizes, offsets, chunk):
     return sym.new_empty((n_chunks, lib().rc_rans_chunk_words(chunk)), dtype=torch.int32), sym.new_empty((n_chunks,), dtype=torch.int32)
 
 
-define("rans_encode_chunks(Tensor symbols, Tensor indexes, Tensor cdf, Tensor cdf_sizes, Tensor offsets, int chunk) -> (Tensor, Tensor)", _enc_alloc,
-       lambda outs, sym, idx, cdf, sizes, offsets, chunk: check(
-           lib().rc_rans_encode_chunks(sym.data_ptr(), idx.data_ptr(), sym.numel(), chunk, cdf.data_ptr(), cdf.shape[1], cdf.shape[0], sizes.data_ptr(),
-                                       offsets.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), _stream()), "rc_rans_encode_chunks"))
+def _enc_launch(outs, sym, idx, cdf, sizes, offsets, chunk):
+    # the prepared per-symbol operations live only for this call (the caching allocator keeps the block alive until the stream passes it)
+    scratch = torch.empty((lib().rc_rans_encode_scratch_bytes(sym.numel(), chunk) + 7) // 8, dtype=torch.int64, device=sym.device)
+    check(lib().rc_rans_encode_chunks(sym.data_ptr(), idx.data_ptr(), sym.numel(), chunk, cdf.data_ptr(), cdf.shape[1], cdf.shape[0], sizes.data_ptr(),
+                                      offsets.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), scratch.data_ptr(), _stream()), "rc_rans_encode_chunks")
+
+
+define("rans_encode_chunks(Tensor symbols, Tensor indexes, Tensor cdf, Tensor cdf_sizes, Tensor offsets, int chunk) -> (Tensor, Tensor)", _enc_alloc, _enc_launch)
 
 define("rans_compact(Tensor words, Tensor nbytes, Tensor offsets, int chunk, int total_bytes) -> Tensor",
        lambda words, nbytes, offsets, chunk, total: words.new_empty((total,), dtype=torch.uint8),
@@ -619,11 +623,12 @@ define("rans_compact(Tensor words, Tensor nbytes, Tensor offsets, int chunk, int
 
 def _dec_launch(out, stream, offsets, idx, cdf, sizes, cdf_offsets, chunk):
     err = torch.zeros(1, dtype=torch.int32, device=idx.device)
-    check(lib().rc_rans_decode_chunks(stream.data_ptr(), offsets.data_ptr(), idx.data_ptr(), idx.numel(), chunk, cdf.data_ptr(), cdf.shape[1],
-                                      cdf.shape[0], sizes.data_ptr(), cdf_offsets.data_ptr(), out.data_ptr(), err.data_ptr(), _stream()),
+    check(lib().rc_rans_decode_chunks(stream.data_ptr(), stream.numel(), offsets.data_ptr(), idx.data_ptr(), idx.numel(), chunk, cdf.data_ptr(),
+                                      cdf.shape[1], cdf.shape[0], sizes.data_ptr(), cdf_offsets.data_ptr(), out.data_ptr(), err.data_ptr(), _stream()),
           "rc_rans_decode_chunks")
-    if int(err.item()):
-        raise _lib.HipError("rc_rans_decode_chunks: CDF index out of range")
+    e = int(err.item())
+    if e:
+        raise _lib.HipError("rc_rans_decode_chunks: " + ("CDF index out of range" if e == 1 else "truncated or corrupt stream"))
 
 
 define("rans_decode_chunks(Tensor stream, Tensor offsets, Tensor indexes, Tensor cdf, Tensor cdf_sizes, Tensor cdf_offsets, int chunk) -> Tensor",

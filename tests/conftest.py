@@ -40,13 +40,14 @@ def golden_names(prefix):
 
 
 NET_NAMES = ("LiteISPNet", "LiteISPNet_GFM_LSC", "LiteISPNet_LSC", "LiteISPNet_GFM", "LiteISPNet_GFMresize",
-             "ISPUNet_GFM_LSC", "ISPUNet_GFM", "ISPUNet_GFM_LFM", "ISPUNet_LSC", "ResUNet")
+             "ISPUNet_GFM_LSC", "ISPUNet_GFM", "ISPUNet_GFM_LFM", "ISPUNet_LSC", "ResUNet",
+             "ISPUNet_GFM_crop", "ISPUNet_GFM_LSC1", "ISPUNet_GFM_LSC_noskip")
 
 
 def net_name_of(fixture: str) -> str:
     """e2e_<Net>_<size> -> the net's class name."""
     import re
-    m = re.match(r"e2e_([A-Za-z_]+?)_(?:randn_)?\d+x\d+$", fixture)
+    m = re.match(r"e2e_([A-Za-z_0-9]+?)_(?:randn_)?\d+x\d+$", fixture)
     if m is None or m.group(1) not in NET_NAMES:
         raise KeyError(fixture)
     return m.group(1)

@@ -57,6 +57,69 @@ def test_host_coder_equals_oracle_stream_and_round_trips():
         assert np.array_equal(o.decode_stream(idx, t), sym)
 
 
+def test_division_free_put_equals_the_dividing_put():
+    """The GPU encoder's state update is ryg's reciprocal form (csrc/rans.hip put_rcp); it must equal CompressAI's dividing Rans64EncPut for
+    every reachable state: checked on 2 M random (state, start, freq) incl. freq 1..3, powers of two and the two ends of the state range."""
+    assert _lib.load().rc_debug_rans_rcp_selftest(2_000_000, 12345) == 0
+
+
+def test_truncated_or_corrupt_streams_are_errors_not_overreads():
+    """a short / corrupt string must raise, never read past the stream (host coder here; the chunked container's header is
+    validated before upload and the kernel bounds every chunk: GPU test below)."""
+    t, tables = _tables()
+    sym, idx = _symbols(4000, t, 9)
+    stream = bitstream.encode(torch.from_numpy(sym), torch.from_numpy(idx), tables, "compressai")
+    for bad in (stream[:4], stream[:len(stream) // 2 // 4 * 4], stream[:-3], b""):
+        with pytest.raises((ValueError, _lib.HipError)):
+            bitstream.Decoder(bad, tables, "cpu", "compressai").decode(torch.from_numpy(idx))
+    # chunked container: every malformed header is rejected on the host
+    good = struct_pack_container(4000, 2048, [4000, 4000])
+    for mutate in (lambda b: b[:10], lambda b: b[:20],                                   # truncated header / size table
+                   lambda b: b[:16] + (7).to_bytes(4, "little") + b[20:],               # a chunk shorter than its flushed state
+                   lambda b: b[:16] + (4002).to_bytes(4, "little") + b[20:],            # not word-sized
+                   lambda b: b[:-8],                                                    # payload truncated
+                   lambda b: b[:8] + (0).to_bytes(4, "little") + b[12:]):               # chunk = 0
+        with pytest.raises(ValueError):
+            bitstream.Decoder(mutate(good), tables, "cpu", "chunked").decode(torch.from_numpy(idx))
+
+
+def struct_pack_container(n, chunk, sizes):
+    import struct
+    return struct.pack("<4sIII", bitstream.MAGIC, n, chunk, len(sizes)) + np.asarray(sizes, "<u4").tobytes() + bytes(sum(sizes))
+
+
+def test_coder_tables_do_not_depend_on_the_order_of_cast_and_update():
+    """`.to(bfloat16)` used to round GaussianConditional.scale_table (63 of 64 thresholds moved) and, after a cast, update() built
+    the EntropyBottleneck tables from rounded parameters -- two processes with the same weights but another order of .to(bf16) / update() /
+    load_state_dict produced streams the other could not decode.  The coder now reads fp32 masters (tcm._Fp32Masters)."""
+    from realcamnet_amd import tcm
+    gc = tcm.GaussianConditional(None)
+    gc.update_scale_table(bitstream.get_scale_table())
+    want = gc.scale_table.clone()
+    gc.to(torch.bfloat16)
+    assert gc.scale_table.dtype == torch.float32 and torch.equal(gc._table("cpu"), want)      # the buffer itself stays fp32
+    gc2 = tcm.GaussianConditional(None).to(torch.bfloat16)
+    gc2.update_scale_table(bitstream.get_scale_table())
+    assert torch.equal(gc2._table("cpu"), want) and torch.equal(gc2._quantized_cdf, gc._quantized_cdf)
+
+    torch.manual_seed(3)
+    eb = tcm.EntropyBottleneck(8)
+    with torch.no_grad():
+        eb.quantiles.add_(torch.randn_like(eb.quantiles) * 0.37)
+        for i in range(5):
+            getattr(eb, f"_matrix{i}").add_(torch.randn_like(getattr(eb, f"_matrix{i}")) * 0.1)
+    sd = {k: v.clone() for k, v in eb.state_dict().items() if k.split(".")[-1] not in ("_offset", "_quantized_cdf", "_cdf_length")}
+    eb.update()
+    cdf, med = eb._quantized_cdf.clone(), eb.quantiles[:, 0, 1].clone()
+    a = tcm.EntropyBottleneck(8); a.load_state_dict(sd, strict=False); a = a.to(torch.bfloat16); a.update(force=True)       # load, cast, update
+    b = tcm.EntropyBottleneck(8).to(torch.bfloat16); b.load_state_dict(sd, strict=False); b.update(force=True)             # cast, load, update
+    c = tcm.EntropyBottleneck(8); c.load_state_dict(sd, strict=False); c.update(); c = c.to(torch.bfloat16)               # load, update, cast
+    for m in (a, b, c):
+        assert m.quantiles.dtype == torch.bfloat16
+        assert torch.equal(m._quantized_cdf, cdf) and torch.equal(m._master("quantiles")[:, 0, 1], med)
+    assert not torch.equal(a.quantiles[:, 0, 1].float(), med)                                   # (the live bf16 parameter IS rounded)
+
+
 def test_bad_index_is_an_error():
     t, tables = _tables()
     with pytest.raises(Exception):
@@ -170,6 +233,22 @@ def _psnr(a, b):
 
 
 @pytest.mark.gpu
+def test_chunked_decoder_flags_corrupt_payload_instead_of_overreading(hip):
+    """A payload whose words were zeroed makes the decoder renormalise on every symbol: it must stop at the chunk's end with an error."""
+    t, _ = _tables()
+    tables = bitstream.Tables(t["_quantized_cdf"], t["_cdf_length"], t["_offset"], "cuda")
+    sym, idx = _symbols(10000, t, 5)
+    d_idx = torch.from_numpy(idx).cuda()
+    stream = bytearray(bitstream.encode(torch.from_numpy(sym).cuda(), d_idx, tables, "chunked"))
+    hdr = 16 + 4 * 5
+    ok = bitstream.Decoder(bytes(stream), tables, "cuda", "chunked").decode(d_idx)
+    assert np.array_equal(ok.cpu().numpy(), sym)
+    stream[hdr:] = bytes(len(stream) - hdr)                          # all-zero payload: state 0 -> a word per symbol
+    with pytest.raises(_lib.HipError, match="truncated or corrupt"):
+        bitstream.Decoder(bytes(stream), tables, "cuda", "chunked").decode(d_idx)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("fmt", ["chunked", "compressai"])
 def test_tcm_compress_decompress_round_trip(hip, dt, fmt):
@@ -194,6 +273,18 @@ def test_tcm_compress_decompress_round_trip(hip, dt, fmt):
     assert 0.75 * est <= bits <= 1.15 * est, (bits, est)
     one = m.compress(x[1:2], fmt)                                          # frames are independent: same strings alone as in the batch
     assert one["strings"][0][0] == enc["strings"][0][1] and one["strings"][1][0] == enc["strings"][1][1]
+
+
+@pytest.mark.gpu
+def test_strings_do_not_depend_on_the_order_of_cast_and_update(hip):
+    """update() -> .to(bf16) and .to(bf16) -> update() compress to identical strings, and each decodes the other's."""
+    x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(8)).to("cuda", torch.bfloat16)
+    a = _tcm(); a.update(); a = a.to("cuda", torch.bfloat16)
+    b = _tcm().to("cuda", torch.bfloat16); b.update()
+    with torch.no_grad():
+        ea, eb_ = a.compress(x), b.compress(x)
+        assert ea["strings"] == eb_["strings"]
+        assert torch.equal(a.decompress(eb_["strings"], eb_["shape"])["x_hat"], b.decompress(ea["strings"], ea["shape"])["x_hat"])
 
 
 @pytest.mark.gpu

@@ -4,7 +4,8 @@ needs minutes per 4K frame, so full-size parity is proven by properties; fixture
   cfg2  1080p, LiteISPNet, B=1, fp32   : the whole frame against the CPU oracle (PSNR >= 100 dB; ~10 s of CPU work) + conv
                                          linearity of the 64-channel general kernel at that size
   cfg3  4K, LiteISPNet_GFM_LSC_GMA, bf16: GMA_Block at N = 544*960 = 522 240 tokens: frame i of a batch == frame i alone (bitwise),
-                                         run-to-run bitwise, finite, shape
+                                         run-to-run bitwise, finite, shape -- at B = 2 with a caller-supplied cond, and at the bench's own
+                                         B = 8 with the ingest kernel's cond
   cfg5  4K, raw_compression_tcm_final, bf16, packed 1152x1920: the same properties for every entry of the result dict
 """
 import pytest
@@ -69,6 +70,24 @@ def test_cfg3_4k_with_groupmix_block_batch_invariant(hip):
     with torch.no_grad():
         y0 = base.to(DEV, dt).eval().forward_mosaic(mosaic[1:2], cond[1:2], coord[1:2])
     assert not torch.equal(y0, y1)
+
+
+def test_cfg3_at_the_bench_batch_of_8(hip):
+    """cfg3 exactly as bench.py runs it (8 frames of 4K per GPU, ingest included, ~15 GB live): frame 5 of the batch == frame 5 alone
+    (bitwise), run-to-run bitwise, finite."""
+    dt = torch.bfloat16
+    torch.manual_seed(0)
+    net = M.LiteISPNet_GFM_LSC_GMA().to(DEV, dt).eval()
+    g = torch.Generator(device=DEV).manual_seed(1234)
+    mosaic = torch.rand(8, 1, 2160, 3840, generator=g, device=DEV).to(dt)
+    coord = ops.make_coord(8, 1080, 1920, device=DEV, dtype=dt)
+    with torch.no_grad():
+        y = net.forward_mosaic(mosaic, None, coord)                # cond = the resized packed RAW (rc_raw_ingest), as in bench.py
+        y5 = net.forward_mosaic(mosaic[5:6], None, coord[5:6])
+        y_again = net.forward_mosaic(mosaic, None, coord)
+    torch.cuda.synchronize()
+    assert y.shape == (8, 3, 2160, 3840) and y.dtype == dt and torch.isfinite(y.float()).all()
+    assert torch.equal(y, y_again) and torch.equal(y5[0], y[5])
 
 
 def _flatten(d, prefix=""):

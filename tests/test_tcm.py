@@ -348,6 +348,12 @@ def _codec_bf16_report(out, g, keys):
     rep = {k: LO.psnr(out[k].float().cpu(), g["out." + k].float()) for k in keys}
     ref_bits = _bits(g["out.lik_y"]) + _bits(g["out.lik_z"])
     rep["rate_rel"] = abs(_bits(out["lik_y"].float().cpu()) + _bits(out["lik_z"].float().cpu()) - ref_bits) / ref_bits
+    # the coder's symbols round(y - mean): the fraction that differs from the fp32 reference's is what "isolated rounding flips" means in
+    # numbers -- x_hat's PSNR floor alone would let a 6 dB regression through
+    sym = torch.round(out["y"].float().cpu() - out["means"].float().cpu())
+    ref_sym = torch.round(g["out.y"].float() - g["out.means"].float())
+    rep["flip_frac"] = float((sym != ref_sym).float().mean())
+    rep["flip_max"] = float((sym - ref_sym).abs().max())
     path = os.environ.get("RC_METRICS_OUT")
     if path:
         import json
@@ -379,7 +385,8 @@ def test_hip_tcm_forward_vs_reference_fp32():
 def test_hip_tcm_forward_bf16_vs_reference():
     """bf16 storage / fp32 accumulate against the fp32 reference fixture (models/tcm.py:481-485's dict).  Floors (measured on
     MI355X: y 61.5, means 60.9, scales 58.9, x_hat 43.5 dB, rate delta 0.07 %): the latent y (before any rounding) >= 55 dB;
-    means / scales (downstream of ste_round: an isolated half-integer flip moves a latent by 1) >= 50 dB; x_hat >= 38 dB;
+    means / scales (downstream of ste_round: an isolated half-integer flip moves a latent by 1) >= 50 dB; x_hat >= 41 dB;
+    the coder's symbols round(y - mean) differ from the reference's in <= 0.6 % of the positions, each by exactly 1;
     total rate sum(-log2 lik_y) + sum(-log2 lik_z) within 0.5 % of the reference's."""
     g = load_golden("tcm_forward_n32")
     m, _ = _mirror_with_det_params(g)
@@ -392,8 +399,10 @@ def test_hip_tcm_forward_bf16_vs_reference():
         assert tuple(v.shape) == tuple(g["out." + k].shape), k
     assert float(out["lik_y"].min()) >= 0.99e-9 and float(out["lik_y"].max()) <= 1.0 + 1e-6      # the 1e-9 bound in fp32
     rep = _codec_bf16_report(out, g, ("y", "means", "scales", "x_hat"))
-    assert rep["y"] >= 55.0 and rep["means"] >= 50.0 and rep["scales"] >= 50.0 and rep["x_hat"] >= 38.0, rep
+    assert rep["y"] >= 55.0 and rep["means"] >= 50.0 and rep["scales"] >= 50.0 and rep["x_hat"] >= 41.0, rep
     assert rep["rate_rel"] <= 0.005, rep
+    # "isolated rounding flips" in numbers (measured r3: 0.22 % of the symbols differ from the fp32 reference's, each by exactly 1)
+    assert rep["flip_frac"] <= 0.006 and rep["flip_max"] <= 1.0, rep
 
 
 @pytest.mark.gpu
@@ -544,7 +553,8 @@ def test_hip_raw_codec_forward_bf16_vs_reference():
         assert torch.isfinite(v.float()).all(), k
         assert tuple(v.shape) == tuple(g["out." + k].shape), k
     rep = _codec_bf16_report(out, g, ("y", "means", "scales", "x_hat", "lft", "lsc_s8"))
-    assert rep["y"] >= 55.0 and rep["means"] >= 50.0 and rep["scales"] >= 50.0 and rep["x_hat"] >= 38.0, rep
+    assert rep["y"] >= 55.0 and rep["means"] >= 50.0 and rep["scales"] >= 50.0 and rep["x_hat"] >= 41.0, rep
+    assert rep["flip_frac"] <= 0.006 and rep["flip_max"] <= 1.0, rep             # measured r3: 0.26 %, each flip by exactly 1
     assert rep["lft"] >= 55.0 and rep["lsc_s8"] >= 55.0, rep
     assert rep["rate_rel"] <= 0.005, rep
 
@@ -622,7 +632,8 @@ def test_hip_base_raw_codec_forward_vs_reference():
     with torch.no_grad():
         out = _flat(m([t.cuda() for t in _raw_inputs(g)]))
     rep = _codec_bf16_report(out, g, ("y", "means", "scales", "x_hat"))
-    assert rep["y"] >= 55.0 and rep["means"] >= 50.0 and rep["scales"] >= 50.0 and rep["x_hat"] >= 38.0 and rep["rate_rel"] <= 0.005, rep
+    assert rep["y"] >= 55.0 and rep["means"] >= 50.0 and rep["scales"] >= 50.0 and rep["x_hat"] >= 41.0 and rep["rate_rel"] <= 0.005, rep
+    assert rep["flip_frac"] <= 0.006 and rep["flip_max"] <= 1.0, rep
 
 
 @pytest.mark.gpu
@@ -658,7 +669,9 @@ def test_hip_gma_codec_blocks_at_upstream_smoke_shapes():
         assert rel_err(got.cpu(), want) < 5e-5
         with torch.no_grad():
             got = m.to(torch.bfloat16)(x.cuda().bfloat16())
-        assert LO.psnr(got.float().cpu(), want) >= 45.0
+        p = LO.psnr(got.float().cpu(), want)
+        print(f"[smoke-shape bf16 PSNR] {type(m).__name__}: {p:.2f} dB")
+        assert p >= 50.0, p
 
 
 @pytest.mark.gpu

@@ -38,7 +38,8 @@ def test_fake_tensor_trace_of_whole_forwards(dt):
                 mosaic, cond, coord = torch.empty(2, 1, 172, 280), torch.empty(2, 4, 64, 64), torch.empty(2, 2, 86, 140)
                 raw, coord_p = torch.empty(2, 4, 64, 96), torch.empty(2, 2, 64, 96)
                 for name in ("LiteISPNet_GFM_LSC", "LiteISPNet_GFM_LSC_GMA", "ISPUNet_GFM_LSC", "LiteISPNet", "ResUNet", "ISPUNet_GFM", "ISPUNet_LSC",
-                             "LiteISPNet_LSC", "LiteISPNet_GFM", "LiteISPNet_GFMresize", "ISPUNet_GFM_LFM"):
+                             "LiteISPNet_LSC", "LiteISPNet_GFM", "LiteISPNet_GFMresize", "ISPUNet_GFM_LFM", "ISPUNet_GFM_crop", "ISPUNet_GFM_LSC1",
+                             "ISPUNet_GFM_LSC_noskip"):
                     net = getattr(M, name)().eval()
                     with torch.no_grad():
                         y = net.forward_mosaic(mosaic, cond, coord)
