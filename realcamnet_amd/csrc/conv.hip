@@ -93,6 +93,8 @@ static int packed_to_cout(const ConvPlan& p, int cout, int out_mode, int j) {
 }
 
 static int g_dbg_flags = 0;
+static int g_pair_impl = 0;         // rc_debug_set("pair_impl", v): 0 = the faster one per form (gated: the first pair kernel; else pair2), 1 = the first pair kernel
+                                   // (weights in LDS, 8 + 4 waves), 2 = pair2 (weights in registers, two teams of four waves)
 static long long* g_dbg_ptr = nullptr;   // rc_debug_set_ptr("conv_phase_timing", device buffer of >= 512 int64)
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -100,6 +102,7 @@ struct ProfRec { hipEvent_t e0, e1; double flops; };
 static std::vector<ProfRec> g_prof;
 
 long long* conv_dbg_ptr() { return g_dbg_ptr; }
+int conv_pair_impl() { return g_pair_impl; }
 
 // HIP-event bracket around one conv launch on its own stream (rc_prof_enable); shared with conv_pair.hip
 void conv_prof_begin(double flops, hipStream_t stream, void** token) {
@@ -212,6 +215,7 @@ int rc_debug_set(const char* key, int value) {
     RC_REQUIRE(key != nullptr, "rc_debug_set: null key");
     if (std::string(key) == "persist") { g_persist_on = value < 0 ? 0 : (value > 3 ? 3 : value); return RC_OK; }
     if (std::string(key) == "conv_flags") { g_dbg_flags = value; return RC_OK; }
+    if (std::string(key) == "pair_impl") { g_pair_impl = value < 0 || value > 2 ? 0 : value; return RC_OK; }
     if (std::string(key) == "conv32") { g_conv32 = value < 0 ? 0 : (value > 4 ? 4 : value); return RC_OK; }
     return fail(RC_ERR_INVALID, std::string("rc_debug_set: unknown key ") + key);
 }

@@ -420,15 +420,20 @@ def _pair_case(hip, H, W, b, mode, seed):
     return fused, ref
 
 
+@pytest.mark.parametrize("impl", [1, 2])
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["plain", "sums", "gated", "film"])
 @pytest.mark.parametrize("shape", [(5, 7, 1), (37, 70, 2), (64, 96, 1), (8, 32, 3), (90, 200, 1)])
-def test_conv_pair_equals_two_convs(hip, mode, shape):
+def test_conv_pair_equals_two_convs(hip, mode, shape, impl):
     """The fused pair keeps the bf16 intermediate in LDS: same unit map, same accumulation order, same rounding
     points as two rc_conv2d launches, so the feature maps are bit-identical (ragged, multi-tile, border and
     interior tiles); the channel partial sums differ only in how they are split, so their totals agree."""
     H, W, b = shape
-    fused, ref = _pair_case(hip, H, W, b, mode, seed=H * 131 + W)
+    assert hip.rc_debug_set(b"pair_impl", impl) == 0         # 1: weights in LDS (8 + 4 waves); 2: weights in registers, two teams (pair2)
+    try:
+        fused, ref = _pair_case(hip, H, W, b, mode, seed=H * 131 + W)
+    finally:
+        hip.rc_debug_set(b"pair_impl", 0)
     assert torch.equal(fused[0], ref[0])
     if mode == "gated":
         assert torch.equal(fused[1], ref[1])

@@ -671,7 +671,7 @@ def test_hip_gma_codec_blocks_at_upstream_smoke_shapes():
             got = m.to(torch.bfloat16)(x.cuda().bfloat16())
         p = LO.psnr(got.float().cpu(), want)
         print(f"[smoke-shape bf16 PSNR] {type(m).__name__}: {p:.2f} dB")
-        assert p >= 50.0, p
+        assert p >= 60.0, p          # measured r3: ConvGMABlock 69.5, GMAAtten 67.5 dB
 
 
 @pytest.mark.gpu
