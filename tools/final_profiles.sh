@@ -2,7 +2,7 @@
 # Round-end evidence: PMC traffic passes, kernel-trace of the bench command, default bench line (with CPU baseline),
 # the other table rows, MFMA calibration.  usage: tools/final_profiles.sh TAG [ROUND]   (outputs under gpurun_out/)
 TAG=${1:-fin}
-ROUND=${2:-r02}
+ROUND=${2:-r03}
 mkdir -p gpurun_out
 bash tools/pmc_bench.sh $TAG > gpurun_out/pmc_${TAG}.log 2>&1
 
@@ -18,6 +18,13 @@ timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_codec_$TAG -o tr
 timeout 300 python tools/gma_stage_bench.py > gpurun_out/gma_stages_$TAG.txt 2>&1
 timeout 300 python tools/codec_stream_bench.py > gpurun_out/codec_stream_$TAG.txt 2>&1
 timeout 120 python tools/mfma_peak.py > gpurun_out/mfma_peak_$TAG.txt 2>/dev/null
+# round 3 evidence: the 32x32x16 conv forms, store-issue microbenchmark, pair2, matrix-pipe / LDS counters, the bitstream legs
+timeout 400 python tools/conv32_probe.py > gpurun_out/conv32_probe_$TAG.txt 2>&1
+( for V in 2 3 1; do V=$V timeout 100 python tools/conv32_phases.py; done; timeout 100 python tools/conv32_phases.py 512 512 136 240 8; V=2 timeout 100 python tools/conv32_phases.py 128 128 272 480 8 --gated; V=1 timeout 100 python tools/conv32_phases.py 48 192 1088 1920 8 --ps; V=1 FLAGS=8 timeout 100 python tools/conv32_phases.py 48 192 1088 1920 8 --ps ) > gpurun_out/conv32_phases_$TAG.txt 2>&1
+timeout 120 ./tools/ubench/store_issue > gpurun_out/store_issue_$TAG.txt 2>&1
+timeout 300 python tools/pair2_probe.py sums plain gated film > gpurun_out/pair2_$TAG.txt 2>&1
+bash tools/pmc_mfma.sh $TAG > gpurun_out/pmc_mfma_${TAG}.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_cmp_$TAG -o trace -- python tools/compress_trace.py > gpurun_out/compress_$TAG.txt 2>&1
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_torchrun_$TAG.json 2>/dev/null
 
 tail -c 400 gpurun_out/bench_default_$TAG.json; echo; cut -c1-160 gpurun_out/bench_nogma_$TAG.json gpurun_out/bench_cfg2_$TAG.json gpurun_out/bench_ispunet_$TAG.json gpurun_out/bench_codec_$TAG.json gpurun_out/bench_torchrun_$TAG.json

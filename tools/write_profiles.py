@@ -3,7 +3,7 @@
 usage: python tools/write_profiles.py TAG [ROUND]"""
 import json, os, shutil, subprocess, sys
 tag = sys.argv[1]
-RND = sys.argv[2] if len(sys.argv) > 2 else "r02"
+RND = sys.argv[2] if len(sys.argv) > 2 else "r03"
 G = "gpurun_out"
 last = lambda p: open(p).read().strip().splitlines()[-1]
 shutil.copy(f"{G}/pmc_{tag}.json", f"profiles/{RND}_pmc_bench.json")
@@ -97,8 +97,68 @@ open(f"profiles/{RND}_gma_stages.md", "w").write(f"""# {RND} — the GroupMix bl
 {open(f'{G}/gma_stages_{tag}.txt').read().strip()}
 ```
 """)
+def rd(name):
+    p = f"{G}/{name}_{tag}.txt"
+    return open(p).read().replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", "").strip() if os.path.exists(p) else "(not collected)"
+
+
+open(f"profiles/{RND}_conv32.md", "w").write(f"""# {RND} — the 32x32x16 conv forms (csrc/conv32_kernel.hpp) against the 16x16x32 kernels, 1x MI355X
+
+`tools/conv32_probe.py`: exact-integer parity of every form (knob 1 = staged-output form on 16-channel chunks + the one-chunk 48-channel form,
+2 / 3 = two-barrier form on 32-channel chunks with 4 / 8 compute waves) in every operand mode, then steady-state layer times at the flagship's
+shapes (`old` = conv_mfma_wsm_kernel, 16x16x32, 8 compute + 4 loader waves; `*-nomfma` / `*-nostore` = knock-outs):
+
+```
+{rd('conv32_probe')[-4200:]}
+```
+
+Phase stamps (`tools/conv32_phases.py`, `s_memtime` of one compute and one loader wave of block 8, cycles per stage):
+
+```
+{rd('conv32_phases')}
+```
+
+Store issue microbenchmark (`tools/ubench/store_issue.hip`; pattern 0 = 16 bytes per lane at a row stride, what an MFMA D layout gives;
+1 = fully coalesced; 2 = 8 lanes x 16 B = 128 contiguous bytes per pixel; drop = out-of-bounds offsets, nothing written):
+
+```
+{rd('store_issue')}
+```
+""")
+open(f"profiles/{RND}_pair2_probe.md", "w").write(f"""# {RND} — `tools/pair2_probe.py` at the final build (see {RND}_pair2_phases.md for the history of the experiment)
+
+```
+{rd('pair2')}
+```
+""")
+mf = f"{G}/pmc_mfma_{tag}.md"
+if os.path.exists(mf):
+    open(f"profiles/{RND}_pmc_mfma_lds.md", "w").write(f"""# {RND} — matrix-pipe and LDS counters of the bench command (cfg3), `tools/pmc_mfma.sh`
+
+One `rocprofv3 --pmc <counter> --kernel-trace` pass per counter over `python bench.py --steps 1 --warmup 1 --no-cpu-baseline` (3 forwards; never combined
+with other trace domains).  `SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)` = fraction of the CUs' busy time in which a SIMD's matrix pipe is busy.
+
+{open(mf).read().strip()}
+""")
+cmp_db = f"{G}/prof_cmp_{tag}/trace_results.db"
+if os.path.exists(cmp_db):
+    cs = subprocess.run([sys.executable, "tools/rocpd_summary.py", cmp_db], capture_output=True, text=True).stdout
+    ans = "\n".join(l for l in cs.splitlines() if "ans::" in l or l.startswith("| kernel") or l.startswith("|---"))
+    open(f"profiles/{RND}_codec_stream.md", "w").write(f"""# {RND} — entropy-coding kernels inside compress() / decompress() of one 4K frame (`tools/compress_trace.py` under rocprofv3 --kernel-trace)
+
+```
+{rd('compress')}
+```
+
+{ans}
+
+Round 2's one-kernel encoder (idx -> sizes/offsets -> cdf as three dependent global loads per symbol at an 8 KB lane stride, then a 64-bit
+division): `rc::ans::encode_chunks_kernel` 1 547 us per call, 6 calls per compress = 9.3 of its 30 ms.  Round 3: `prepare_kernel` (all symbols in
+parallel: CDF row, escape, start / freq, reciprocal of freq; operations written transposed) + `encode_serial_kernel` (one lane per chunk, 16 symbols'
+operations loaded per batch, division-free state update bit-identical to the dividing one).
+""")
 c2, ng, iu = (json.loads(last(f"{G}/bench_{n}_{tag}.json")) for n in ("cfg2", "nogma", "ispunet"))
-print(json.dumps({"cfg3": [dj["value"], dj["ms_per_step"], dj["roofline"]["achieved"], dj["roofline"]["frac"], dj["hbm_whole_step"], dj["cpu_baseline"]["value"], dj["psnr_db_vs_cpu_fp32"]],
+print(json.dumps({"codec_leg": dj.get("codec_leg"), "cfg3": [dj["value"], dj["ms_per_step"], dj["roofline"]["achieved"], dj["roofline"]["frac"], dj.get("hbm_whole_step"), dj["cpu_baseline"]["value"], dj["psnr_db_vs_cpu_fp32"]],
                   "cfg2": [c2["value"], c2["ms_per_step"], c2["roofline"]["achieved"], c2["roofline"]["frac"], c2["cpu_baseline"]["value"], c2["psnr_db_vs_cpu_fp32"]],
                   "nogma": [ng["value"], ng["ms_per_step"], ng["roofline"]["achieved"], ng["roofline"]["frac"]],
                   "ispunet": [iu["value"], iu["ms_per_step"], iu["roofline"]["achieved"]]}, indent=1))
