@@ -22,7 +22,7 @@ def per_kernel(path, counter):
 
 f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"units": "bytes", "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950: wide coalesced reads are tallied at half), WRITE_SIZE KiB x 1024",
-       "command": "python bench.py --steps 1 --warmup 1 --no-cpu-baseline (3 forwards: warm-up, timed, HIP-event pass)", "kernels": {}}
+       "command": "python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-codec-leg (3 forwards: warm-up, timed, HIP-event pass)", "kernels": {}}
 conv = {"fetch": 0.0, "write": 0.0, "dispatches": 0}
 for k in sorted(set(f) | set(w)):
     fv, fn = f.get(k, (0.0, 0)); wv, wn = w.get(k, (0.0, 0))

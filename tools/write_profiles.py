@@ -4,12 +4,14 @@ usage: python tools/write_profiles.py TAG [ROUND]"""
 import json, os, shutil, subprocess, sys
 tag = sys.argv[1]
 RND = sys.argv[2] if len(sys.argv) > 2 else "r03"
+OUT = sys.argv[3] if len(sys.argv) > 3 else "profiles"      # the GPU box writes under gpurun_out/ (the only directory that travels back)
+os.makedirs(OUT, exist_ok=True)
 G = "gpurun_out"
 last = lambda p: open(p).read().strip().splitlines()[-1]
-shutil.copy(f"{G}/pmc_{tag}.json", f"profiles/{RND}_pmc_bench.json")
+shutil.copy(f"{G}/pmc_{tag}.json", f"{OUT}/{RND}_pmc_bench.json")
 trace, default = last(f"{G}/bench_trace_{tag}.json"), last(f"{G}/bench_default_{tag}.json")
 summ = subprocess.run([sys.executable, "tools/rocpd_summary.py", f"{G}/prof_{tag}/trace_results.db"], capture_output=True, text=True).stdout
-open(f"profiles/{RND}_bench_kernel_stats.md", "w").write(f"""# {RND} — kernel trace of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline` (cfg3, 1x MI355X)
+open(f"{OUT}/{RND}_bench_kernel_stats.md", "w").write(f"""# {RND} — kernel trace of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-codec-leg` (cfg3, 1x MI355X)
 
 Command: `rocprofv3 --kernel-trace --stats -d gpurun_out/prof_{tag} -o trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline`
 (5 forwards in the trace: 1 warm-up + 3 timed + 1 HIP-event profiling pass). Summarised from the rocpd database with
@@ -22,7 +24,7 @@ HIP events on the launch stream.
 
 {summ}
 """)
-open(f"profiles/{RND}_bench_default.md", "w").write(f"""# {RND} — default `python bench.py` (steps 5, warm-up 2, CPU baseline leg on), 1x MI355X
+open(f"{OUT}/{RND}_bench_default.md", "w").write(f"""# {RND} — default `python bench.py` (steps 5, warm-up 2, CPU baseline leg on), 1x MI355X
 
 ```json
 {default}
@@ -47,16 +49,16 @@ Matrix-pipe calibration (`tools/mfma_peak.py`, `rc_debug_mfma_peak`: nothing but
 {open(f'{G}/mfma_peak_{tag}.txt').read().strip()}
 ```
 """)
-d = json.load(open(f"profiles/{RND}_pmc_bench.json"))
+d = json.load(open(f"{OUT}/{RND}_pmc_bench.json"))
 dj = json.loads(default)
 rows = sorted(d["kernels"].items(), key=lambda kv: -(kv[1]["fetch_bytes_per_dispatch"] + kv[1]["write_bytes_per_dispatch"]) * kv[1]["dispatches"])
 tb = "\n".join(f"| `{k[:90]}` | {e['dispatches']} | {e['fetch_bytes_per_dispatch'] / 1e9:.3f} | {e['write_bytes_per_dispatch'] / 1e9:.3f} | "
                f"{(e['fetch_bytes_per_dispatch'] + e['write_bytes_per_dispatch']) * e['dispatches'] / 3 / 1e9:.1f} |" for k, e in rows[:24])
 tot = (d["all_kernels_total_bytes"]["fetch"] + d["all_kernels_total_bytes"]["write"]) / 3 / 1e9
 rate = tot / dj["ms_per_step"]
-open(f"profiles/{RND}_pmc_bench.md", "w").write(f"""# {RND} — HBM traffic of the bench command from PMC counters (cfg3, 1x MI355X)
+open(f"{OUT}/{RND}_pmc_bench.md", "w").write(f"""# {RND} — HBM traffic of the bench command from PMC counters (cfg3, 1x MI355X)
 
-`tools/pmc_bench.sh`: two passes of `rocprofv3 --pmc <counter> --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline`
+`tools/pmc_bench.sh`: two passes of `rocprofv3 --pmc <counter> --kernel-trace -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-codec-leg`
 (FETCH_SIZE and WRITE_SIZE do not fit one pass; no other trace domains), 3 forwards per pass, summarised per kernel by
 `tools/pmc_bench_summary.py` into `profiles/{RND}_pmc_bench.json` (which `bench.py` reads for `roofline.traffic` and
 `hbm_whole_step`). Units: FETCH_SIZE KiB x 1024 x 2 (gfx950: a 16-byte-per-lane streaming read is tallied at half, MI355X guide
@@ -72,7 +74,7 @@ Conv kernels: {d['conv_kernels_all']['dispatches']} dispatches, {d['conv_kernels
 """)
 codec = last(f"{G}/bench_codec_{tag}.json")
 csumm = subprocess.run([sys.executable, "tools/rocpd_summary.py", f"{G}/prof_codec_{tag}/trace_results.db"], capture_output=True, text=True).stdout
-open(f"profiles/{RND}_rawcodec_kernel_stats.md", "w").write(f"""# {RND} — RAW codec leg: `python bench.py --model raw_compression_tcm_final --frames 4` (cfg5 shape on one GPU, bf16, 1x MI355X)
+open(f"{OUT}/{RND}_rawcodec_kernel_stats.md", "w").write(f"""# {RND} — RAW codec leg: `python bench.py --model raw_compression_tcm_final --frames 4` (cfg5 shape on one GPU, bf16, 1x MI355X)
 
 Default run (steps 5, warm-up 2, CPU baseline leg on):
 
@@ -91,7 +93,7 @@ Bitstream legs (`tools/codec_stream_bench.py`: compress / decompress of one 4K m
 {open(f'{G}/codec_stream_{tag}.txt').read().strip()}
 ```
 """)
-open(f"profiles/{RND}_gma_stages.md", "w").write(f"""# {RND} — the GroupMix block launch by launch at the cfg3 size (8 x 544 x 960 tokens, dim 80, bf16), `tools/gma_stage_bench.py`, HIP events
+open(f"{OUT}/{RND}_gma_stages.md", "w").write(f"""# {RND} — the GroupMix block launch by launch at the cfg3 size (8 x 544 x 960 tokens, dim 80, bf16), `tools/gma_stage_bench.py`, HIP events
 
 ```
 {open(f'{G}/gma_stages_{tag}.txt').read().strip()}
@@ -102,7 +104,7 @@ def rd(name):
     return open(p).read().replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", "").strip() if os.path.exists(p) else "(not collected)"
 
 
-open(f"profiles/{RND}_conv32.md", "w").write(f"""# {RND} — the 32x32x16 conv forms (csrc/conv32_kernel.hpp) against the 16x16x32 kernels, 1x MI355X
+open(f"{OUT}/{RND}_conv32.md", "w").write(f"""# {RND} — the 32x32x16 conv forms (csrc/conv32_kernel.hpp) against the 16x16x32 kernels, 1x MI355X
 
 `tools/conv32_probe.py`: exact-integer parity of every form (knob 1 = staged-output form on 16-channel chunks + the one-chunk 48-channel form,
 2 / 3 = two-barrier form on 32-channel chunks with 4 / 8 compute waves) in every operand mode, then steady-state layer times at the flagship's
@@ -125,7 +127,7 @@ Store issue microbenchmark (`tools/ubench/store_issue.hip`; pattern 0 = 16 bytes
 {rd('store_issue')}
 ```
 """)
-open(f"profiles/{RND}_pair2_probe.md", "w").write(f"""# {RND} — `tools/pair2_probe.py` at the final build (see {RND}_pair2_phases.md for the history of the experiment)
+open(f"{OUT}/{RND}_pair2_probe.md", "w").write(f"""# {RND} — `tools/pair2_probe.py` at the final build (see {RND}_pair2_phases.md for the history of the experiment)
 
 ```
 {rd('pair2')}
@@ -133,9 +135,9 @@ open(f"profiles/{RND}_pair2_probe.md", "w").write(f"""# {RND} — `tools/pair2_p
 """)
 mf = f"{G}/pmc_mfma_{tag}.md"
 if os.path.exists(mf):
-    open(f"profiles/{RND}_pmc_mfma_lds.md", "w").write(f"""# {RND} — matrix-pipe and LDS counters of the bench command (cfg3), `tools/pmc_mfma.sh`
+    open(f"{OUT}/{RND}_pmc_mfma_lds.md", "w").write(f"""# {RND} — matrix-pipe and LDS counters of the bench command (cfg3), `tools/pmc_mfma.sh`
 
-One `rocprofv3 --pmc <counter> --kernel-trace` pass per counter over `python bench.py --steps 1 --warmup 1 --no-cpu-baseline` (3 forwards; never combined
+One `rocprofv3 --pmc <counter> --kernel-trace` pass per counter over `python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-codec-leg` (3 forwards; never combined
 with other trace domains).  `SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)` = fraction of the CUs' busy time in which a SIMD's matrix pipe is busy.
 
 {open(mf).read().strip()}
@@ -144,7 +146,7 @@ cmp_db = f"{G}/prof_cmp_{tag}/trace_results.db"
 if os.path.exists(cmp_db):
     cs = subprocess.run([sys.executable, "tools/rocpd_summary.py", cmp_db], capture_output=True, text=True).stdout
     ans = "\n".join(l for l in cs.splitlines() if "ans::" in l or l.startswith("| kernel") or l.startswith("|---"))
-    open(f"profiles/{RND}_codec_stream.md", "w").write(f"""# {RND} — entropy-coding kernels inside compress() / decompress() of one 4K frame (`tools/compress_trace.py` under rocprofv3 --kernel-trace)
+    open(f"{OUT}/{RND}_codec_stream.md", "w").write(f"""# {RND} — entropy-coding kernels inside compress() / decompress() of one 4K frame (`tools/compress_trace.py` under rocprofv3 --kernel-trace)
 
 ```
 {rd('compress')}
