@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 7
+#define RC_ABI_VERSION 8
 
 typedef enum rc_status {
     RC_OK = 0,
@@ -129,6 +129,11 @@ typedef struct rc_conv_desc {
     /* optional per-channel partial sums of v (the value stored), for CALayer's global mean
      * (networks.py:268): fp32 (B, rc_conv_sum_tiles(), cout), reduced in fixed order by rc_ca_gate */
     float* chan_sums;
+    /* ksize 2 only, 0 = unused: in0 is the stride-2 convolution's OWN input (B, src_h, src_w, cin / 4) and the kernel gathers the
+     * space-to-depth channels while staging (channel p*(cin/4) + k of map pixel (y, x) = channel k of source pixel (2y + (p >> 1),
+     * 2x + (p & 1)), zero beyond the source edge -- rc_space_to_depth2's order), so no space-to-depth pass is launched.  Needs
+     * height = ceil(src_h / 2), width = ceil(src_w / 2), cin / 4 a multiple of 64, no gated input.                                     */
+    int32_t src_h, src_w;
 } rc_conv_desc;
 
 /* Size in bytes of the packed weight buffer for (cin,cout,ksize,dtype,out_mode); 0 on error. */

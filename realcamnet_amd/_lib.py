@@ -17,7 +17,7 @@ HEADER = PKG.parent / "include" / "realcam_hip.h"
 RC_F32, RC_BF16, RC_U16 = 0, 1, 2
 RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY, RC_ACT_GELU, RC_ACT_RELU_POST = 0, 1, 2, 3, 4
 RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class ConvDesc(C.Structure):
@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("out", C.c_void_p), ("out_mode", C.c_int32), ("out_dtype", C.c_int32),
         ("out_h", C.c_int32), ("out_w", C.c_int32),
         ("chan_sums", C.c_void_p),
+        ("src_h", C.c_int32), ("src_w", C.c_int32),
     ]
 
 

@@ -286,6 +286,14 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
         RC_REQUIRE((double)d->height * d->width * d->cin * es < lim, "rc_conv2d: one input image must be < 2 GiB");
         RC_REQUIRE((double)d->height * d->width * d->cout * 4.0 < lim, "rc_conv2d: one output image must be < 2 GiB");
     }
+    const bool fold = d->src_h != 0 || d->src_w != 0;      // ksize 2 reading the stride-2 convolution's own input (no space-to-depth map)
+    if (fold) {
+        RC_REQUIRE(d->ksize == 2 && d->cin % 4 == 0 && (d->cin / 4) % p.ck == 0, "rc_conv2d: src_h/src_w need ksize 2 and cin / 4 a whole number of Cin chunks");
+        RC_REQUIRE(d->src_h >= 1 && d->src_w >= 1 && d->height == (d->src_h + 1) / 2 && d->width == (d->src_w + 1) / 2,
+                   "rc_conv2d: height/width must be ceil(src_h / 2), ceil(src_w / 2)");
+        RC_REQUIRE(d->in_gate == nullptr && d->in1 == nullptr && d->in_store == nullptr, "rc_conv2d: src_h/src_w exclude the gated input");
+        RC_REQUIRE((double)d->src_h * d->src_w * (d->cin / 4) * es < 2147483647.0, "rc_conv2d: one input image must be < 2 GiB");
+    }
     if (d->residual) RC_REQUIRE(reinterpret_cast<uintptr_t>(d->residual) % 16 == 0, "rc_conv2d: residual must be 16-byte aligned");
     if (d->mul_plus1) RC_REQUIRE(reinterpret_cast<uintptr_t>(d->mul_plus1) % 16 == 0, "rc_conv2d: mul_plus1 must be 16-byte aligned");
 
@@ -299,6 +307,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     a.cin_vec_ok = (d->cin % p.unit == 0) && aligned16(d->in0) && aligned16(d->in1) && aligned16(d->in_store) &&
                    (d->in_gate == nullptr || reinterpret_cast<uintptr_t>(d->in_gate) % 4 == 0);
     a.cin_chunk_ok = d->cin % p.ck == 0;
+    a.fold2 = fold ? 1 : 0; a.src_H = d->src_h; a.src_W = d->src_w; a.cfold = d->cin / 4;
     a.in0 = d->in0; a.in1 = d->in1; a.in_gate = d->in_gate; a.in_store = d->in_store;
     a.wpacked = d->wpacked; a.bias = d->bias;
     a.film_scale = d->film_scale; a.film_shift = d->film_shift;

@@ -62,6 +62,7 @@ struct ConvArgs {
     int ep_key;                        // epilogue_fast feature mask, or -1 for the generic epilogue (ep_key_for)
     TileDecode td, td_wsm;             // division constants of the persistent kernels' tile decode (8- and 16-row tiles)
     MagicDiv div_n_ct;
+    int fold2, src_H, src_W, cfold;    // ksize 2 over the UN-shuffled input: in0 is (B, src_H, src_W, cfold = cin / 4), see ConvDev::fold_*
     long long* dbg;                    // optional phase-timing buffer (rc_debug_set_ptr), normally NULL
     int dbg_flags;                     // knock-out experiments (rc_debug_set "conv_flags"): 1 no stores, 2 no MFMA, 4 no tile loads
 };
@@ -295,16 +296,37 @@ struct ConvDev {
         int soff;                             // byte offset of halo pixel (0,0), channel 0 (interior tiles)
         bool interior;                        // whole halo tile inside the image and Cin a multiple of CK (uniform)
     };
+    // ksize 2 with a.fold2 (a stride-2 3x3 convolution read straight from its input, no space-to-depth pass): in0 is the un-shuffled
+    // (B, src_H, src_W, cfold) map; channel c0 of the (H, W, 4 cfold) map the MFMA loop sees is channel c0 % cfold of pixel
+    // (2y + i, 2x + j), phase 2i + j = c0 / cfold (rc_space_to_depth2's order), zero beyond the source edge.  cfold % CK == 0 (host),
+    // so a chunk lies inside one phase and an interior tile's address is still lane constant + scalar.
+    __device__ static __forceinline__ bool folded(const ConvArgs& a) {
+        if constexpr (Cfg::KS == 2) return a.fold2 != 0; else return false;
+    }
+    __device__ static __forceinline__ int fold_phase(const ConvArgs& a, int c0) { return (c0 >= a.cfold) + (c0 >= 2 * a.cfold) + (c0 >= 3 * a.cfold); }
+    __device__ static __forceinline__ int chunk_soff(const ConvArgs& a, int chunk) {   // byte offset a Cin chunk adds to an interior tile's address
+        if (folded(a)) {
+            const int c0 = chunk * CK, ph = fold_phase(a, c0);
+            return (((ph >> 1) * a.src_W + (ph & 1)) * a.cfold + (c0 - ph * a.cfold)) * ES;
+        }
+        return chunk * CK * ES;
+    }
     __device__ static __forceinline__ TileSrc tile_src(const ConvArgs& a, int b, int y0, int x0) {
-        const size_t img = (size_t)a.H * a.W * a.cin;
+        const bool fold = folded(a);
+        const size_t img = fold ? (size_t)a.src_H * a.src_W * a.cfold : (size_t)a.H * a.W * a.cin;
         const unsigned bytes = (unsigned)(img * ES);
         TileSrc t;
         t.r0 = make_rsrc(static_cast<const T*>(a.in0) + (size_t)b * img, bytes);
         t.r1 = make_rsrc(a.in1 ? static_cast<const T*>(a.in1) + (size_t)b * img : nullptr, a.in1 ? bytes : 0u);
         t.rst = make_rsrc(a.in_store ? static_cast<T*>(a.in_store) + (size_t)b * img : nullptr, a.in_store ? bytes : 0u);
         t.gy0 = y0 - HALO; t.gx0 = x0 - HALO;
-        t.soff = (t.gy0 * a.W + t.gx0) * a.cin * ES;
-        t.interior = t.gy0 >= 0 && t.gx0 >= 0 && t.gy0 + THH <= a.H && t.gx0 + TWH <= a.W && a.cin_chunk_ok;
+        if (fold) {
+            t.soff = (2 * t.gy0 * a.src_W + 2 * t.gx0) * a.cfold * ES;
+            t.interior = t.gy0 >= 0 && t.gx0 >= 0 && 2 * (t.gy0 + THH) <= a.src_H && 2 * (t.gx0 + TWH) <= a.src_W;
+        } else {
+            t.soff = (t.gy0 * a.W + t.gx0) * a.cin * ES;
+            t.interior = t.gy0 >= 0 && t.gx0 >= 0 && t.gy0 + THH <= a.H && t.gx0 + TWH <= a.W && a.cin_chunk_ok;
+        }
         return t;
     }
     // Per-thread, per-launch constants: byte offset of (halo pixel k of this thread, its channel group) relative
@@ -320,7 +342,8 @@ struct ConvDev {
             const int pix = p0 + k * PPP;
             const int py = pix / TWH, px = pix - py * TWH;
             const bool center = py >= HALO && py < HALO + Cfg::TH && px >= HALO && px < HALO + kTW;
-            t.o[k] = (live && pix < NPIX) ? ((py * a.W + px) * a.cin + v * UNIT) * ES : kOOB;
+            const int o = folded(a) ? ((2 * py * a.src_W + 2 * px) * a.cfold + v * UNIT) * ES : ((py * a.W + px) * a.cin + v * UNIT) * ES;
+            t.o[k] = (live && pix < NPIX) ? o : kOOB;
             t.ctr[k] = center ? t.o[k] : kOOB;
         }
     }
@@ -331,6 +354,11 @@ struct ConvDev {
         const int gy = t.gy0 + py, gx = t.gx0 + px;
         const int c0 = chunk * CK + v * UNIT;
         center = py >= HALO && py < HALO + Cfg::TH && px >= HALO && px < HALO + kTW;
+        if (folded(a)) {
+            const int ph = fold_phase(a, c0), sy = 2 * gy + (ph >> 1), sx = 2 * gx + (ph & 1);       // gy, gx >= -1: negative stays negative
+            const bool ok = live && pix < NPIX && (unsigned)sy < (unsigned)a.src_H && (unsigned)sx < (unsigned)a.src_W && c0 < a.cin;
+            return ok ? ((sy * a.src_W + sx) * a.cfold + c0 - ph * a.cfold) * ES : kOOB;
+        }
         const bool ok = live && pix < NPIX && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && c0 < a.cin;
         return ok ? ((gy * a.W + gx) * a.cin + c0) * ES : kOOB;
     }
@@ -341,7 +369,7 @@ struct ConvDev {
                                                      uint4 (&r0)[NI], uint4 (&r1)[GATED ? NI : 1],
                                                      float (&gv)[GATED ? UNIT : 1]) {
         load_gate<GATED>(a, b, chunk, tid, gv);
-        if (t.interior) load_tile_interior<GATED>(t, to, chunk, r0, r1);
+        if (t.interior) load_tile_interior<GATED>(a, t, to, chunk, r0, r1);
         else load_tile_border<GATED>(a, t, chunk, tid, r0, r1);
     }
     template <bool GATED>
@@ -353,9 +381,9 @@ struct ConvDev {
         }
     }
     template <bool GATED>
-    __device__ static __forceinline__ void load_tile_interior(const TileSrc& t, const TileOffs& to, int chunk,
+    __device__ static __forceinline__ void load_tile_interior(const ConvArgs& a, const TileSrc& t, const TileOffs& to, int chunk,
                                                               uint4 (&r0)[NI], uint4 (&r1)[GATED ? NI : 1]) {
-        const int soff = t.soff + chunk * CK * ES;
+        const int soff = t.soff + chunk_soff(a, chunk);
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             r0[k] = buf_load16(t.r0, to.o[k], soff);
@@ -985,7 +1013,7 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
         ts = D::tile_src(a, b, y0, x0);
         if (a.cin_vec_ok) {
             D::template load_gate<GATED>(a, b, 0, tid, gv);
-            if (ts.interior) D::template load_tile_interior<GATED>(ts, to, 0, r0, r1);
+            if (ts.interior) D::template load_tile_interior<GATED>(a, ts, to, 0, r0, r1);
         }
     }
     float run[NV];                                     // CALayer channel sums carried across this block's tiles
@@ -1016,7 +1044,7 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
                 ts = D::tile_src(a, b, y0, x0);
                 if (a.cin_vec_ok) {
                     D::template load_gate<GATED>(a, b, 0, tid, gv);
-                    if (ts.interior) D::template load_tile_interior<GATED>(ts, to, 0, r0, r1);
+                    if (ts.interior) D::template load_tile_interior<GATED>(a, ts, to, 0, r0, r1);
                 }
             }
             f32x4 acc[4][NT];                          // initial C operand = bias

@@ -280,6 +280,10 @@ def _stride2_view(mod) -> "_ConvView":
     return hit[1]
 
 
+# stride-2 3x3 convolutions with 64 | channels read their input directly (no rc_space_to_depth2 pass); False: always via the map
+FOLD_STRIDE2 = True
+
+
 def conv_stride2(x: torch.Tensor, mod, s2d: Optional[torch.Tensor] = None, **fuse):
     """kxk stride-2 padding-k//2 convolution (k in {1, 3}) as a stride-1 rc_conv2d at the OUTPUT resolution over the
     space-to-depth map (4c channels, re-indexed taps; bf16: a 2x2 window, 9 of 16 (tap, phase) blocks non-zero; fp32: the 3x3 embedding,
@@ -294,7 +298,12 @@ def conv_stride2(x: torch.Tensor, mod, s2d: Optional[torch.Tensor] = None, **fus
         if view is None or view.weight is not mod.weight or view.bias is not mod.bias:
             view = cache["stride2_view"] = _ConvView(mod.weight, mod.bias)
         return conv2d(subsample2(x), view, **fuse)
-    return conv2d(space_to_depth2(x) if s2d is None else s2d, _stride2_view(mod), **fuse)     # s2d: the caller's shared space-to-depth map of x
+    view = _stride2_view(mod)
+    if FOLD_STRIDE2 and s2d is None and view.weight.shape[-1] == 2 and x.shape[-1] % 64 == 0:
+        # the 2x2-window kernel gathers the space-to-depth channels itself (rc_conv_desc.src_h / src_w): no map is written or re-read
+        pc = packed_conv(view, x.dtype, RC_OUT_NHWC)
+        return _R.conv2d_fold2(x, pc.wpacked, pc.bias, pc.cout, _ACT[fuse.get("act")], float(fuse.get("slope", 0.0)))
+    return conv2d(space_to_depth2(x) if s2d is None else s2d, view, **fuse)     # s2d: the caller's shared space-to-depth map of x
 
 
 def entropy_bottleneck(z: torch.Tensor, params: torch.Tensor, medians: torch.Tensor, bound: float = 1e-9):

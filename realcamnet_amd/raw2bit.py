@@ -293,7 +293,8 @@ class HybridConditionModule(nn.Module):
         y = self.dec_2._nhwc(y, x2)
         y = self.dec_3._nhwc(y, x1)
         y = self.out_conv._nhwc(y)
-        s2d = ops.space_to_depth2(y)
+        # one shared map only where the 2x2-window kernel cannot read y directly (ops.FOLD_STRIDE2: 64 | channels)
+        s2d = None if (ops.FOLD_STRIDE2 and y.dtype == torch.bfloat16 and y.shape[-1] % 64 == 0) else ops.space_to_depth2(y)
         return [self._cond(self.CondNet1, y, s2d), self._cond(self.CondNet2, y, s2d), self._cond(self.CondNet3, y, s2d)]
 
     def forward(self, x):

@@ -195,6 +195,22 @@ define("conv2d(Tensor x, Tensor wpacked, Tensor? bias, int cout, int ksize, int 
        "int crop_h, int crop_w, ScalarType? out_dtype) -> (Tensor, Tensor, Tensor)", _conv_alloc, _conv_launch)
 
 
+def _conv_fold2_launch(out, x, wpacked, bias, cout, act, slope):
+    b, H, W, c = x.shape
+    d = ConvDesc()
+    d.batch, d.height, d.width, d.cin, d.cout, d.ksize, d.dtype = b, (H + 1) // 2, (W + 1) // 2, 4 * c, cout, 2, _dt(x)
+    d.src_h, d.src_w = H, W
+    d.in0, d.wpacked, d.bias = x.data_ptr(), wpacked.data_ptr(), _p(bias)
+    d.act, d.act_slope = act, float(slope)
+    d.out, d.out_mode, d.out_dtype = out.data_ptr(), RC_OUT_NHWC, _dt(out)
+    check(lib().rc_conv2d(C.byref(d), _stream()), "rc_conv2d")
+
+
+# 3x3 stride-2 convolution straight from its input (rc_conv_desc.src_h / src_w): the 2x2-window kernel gathers the space-to-depth channels itself
+define("conv2d_fold2(Tensor x, Tensor wpacked, Tensor? bias, int cout, int act, float slope) -> Tensor",
+       lambda x, wpacked, bias, cout, act, slope: x.new_empty((x.shape[0], (x.shape[1] + 1) // 2, (x.shape[2] + 1) // 2, cout)), _conv_fold2_launch)
+
+
 def _pair_alloc(x, w1, b1, w2, b2, act, slope, film_scale, film_shift, gate, skip, store_input, residual, want_sums):
     b, H, W, c = x.shape
     stored = torch.empty_like(x) if (store_input and gate is not None) else _none(x)

@@ -722,6 +722,45 @@ def test_forward_is_hip_graph_capturable(hip):
     assert torch.equal(y_graph, y_eager)
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 192), (192, 320), (320, 128), (64, 3)])
+@pytest.mark.parametrize("shape", [(1, 16, 24), (2, 37, 71), (1, 130, 200)])
+def test_stride2_conv_reading_its_own_input_exact_on_integer_data(hip, cin, cout, shape):
+    """conv3x3(stride 2) with 64 | channels: the 2x2-window kernel gathers the space-to-depth channels while staging (rc_conv_desc.src_h /
+    src_w, no rc_space_to_depth2 launch).  Bit-exact against F.conv2d on small-integer data -- interior tiles, border tiles, odd source
+    sizes (the phase-1 row / column beyond the edge reads zero) -- and bit-identical to the route through the map, with a fused activation."""
+    b, H, W = shape
+    g = torch.Generator().manual_seed(cin * 5 + cout + H)
+    conv = N.Conv2d(cin, cout, 3, 2, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randint(-2, 3, conv.weight.shape, generator=g).float())
+        conv.bias.copy_(torch.randint(-4, 5, (cout,), generator=g).float())
+    x = torch.randint(-3, 4, (b, cin, H, W), generator=g).float()
+    ref = F.conv2d(x, conv.weight, conv.bias, stride=2, padding=1)
+    conv = conv.to(DEV, torch.bfloat16).eval()
+    a = ops.to_nhwc(x.to(DEV, torch.bfloat16))
+    assert ops.FOLD_STRIDE2
+    with torch.no_grad():
+        y = ops.conv_stride2(a, conv)
+        ya = ops.conv_stride2(a, conv, act="leaky", slope=0.25)
+        ops.FOLD_STRIDE2 = False
+        try:
+            y_map = ops.conv_stride2(a, conv)
+            ya_map = ops.conv_stride2(a, conv, act="leaky", slope=0.25)
+        finally:
+            ops.FOLD_STRIDE2 = True
+    assert torch.equal(ops.to_nchw(y).float().cpu(), ref.bfloat16().float())
+    assert torch.equal(y, y_map) and torch.equal(ya, ya_map)
+    xr = torch.randn(b, H, W, cin, generator=g).to(DEV, torch.bfloat16)                 # real-valued data: same accumulation order either way
+    with torch.no_grad():
+        y1 = ops.conv_stride2(xr, conv)
+        ops.FOLD_STRIDE2 = False
+        try:
+            y2 = ops.conv_stride2(xr, conv)
+        finally:
+            ops.FOLD_STRIDE2 = True
+    assert torch.equal(y1, y2)
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 64), (128, 128), (32, 48), (128, 320), (80, 64)])
 @pytest.mark.parametrize("shape", [(1, 16, 24), (2, 38, 70)])
 def test_stride2_conv_as_2x2_window_exact_on_integer_data(hip, cin, cout, shape):
