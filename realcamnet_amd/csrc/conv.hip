@@ -13,6 +13,8 @@ struct ConvPlan {
 };
 
 static int g_persist_on = 1;       // rc_debug_set("persist", v): 0 general kernel only, 1 automatic (default), 2 producer/consumer wherever eligible, 3 persistent only
+static int g_pss = 0;              // rc_debug_set("pss", v): 1: single-chunk pixel-shuffle layers (the tail 48 -> 192) take kernel 5 (output staged through LDS, stored by the
+                                   // loader waves); 0 (default): kernel 4.  Measured on MI355X at 8 x 1088 x 1920: 3.16-3.29 vs 3.24-3.27 ms (conv_kernel.hpp, kernel 5)
 static int g_conv32 = 4;           // rc_debug_set("conv32", v): which layers take the 32x32x16 forms (conv32_kernel.hpp).  0 none; 4 (default) only where they
                                    // measured faster on MI355X (the one-chunk 48 -> 96k NHWC layers: 1.24 vs 1.39 ms at 544x960x8); 1 all eligible layers, multi-chunk
                                    // NHWC ones in the staged-output form; 2 / 3 multi-chunk layers in the two-barrier form with 4 / 8 compute waves (A/B experiments)
@@ -216,6 +218,7 @@ int rc_debug_set(const char* key, int value) {
     if (std::string(key) == "persist") { g_persist_on = value < 0 ? 0 : (value > 3 ? 3 : value); return RC_OK; }
     if (std::string(key) == "conv_flags") { g_dbg_flags = value; return RC_OK; }
     if (std::string(key) == "pair_impl") { g_pair_impl = value < 0 || value > 2 ? 0 : value; return RC_OK; }
+    if (std::string(key) == "pss") { g_pss = value != 0; return RC_OK; }
     if (std::string(key) == "conv32") { g_conv32 = value < 0 ? 0 : (value > 4 ? 4 : value); return RC_OK; }
     return fail(RC_ERR_INVALID, std::string("rc_debug_set: unknown key ") + key);
 }
@@ -324,6 +327,9 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
             fast = fast && d->cout % 4 == 0 && reinterpret_cast<uintptr_t>(d->film_scale) % 16 == 0 && reinterpret_cast<uintptr_t>(d->film_shift) % 16 == 0;
         switch (key) { case 0: case 1: case 2: case 16: case 32: case 8: case 6: break; default: fast = false; }
         a.ep_key = fast ? key : -1;
+        // a cout tile of a single-chunk pixel-shuffle layer with cout = 4 cout tiles is one sub-pixel of every pixel: kernel 5
+        a.pss = g_pss && d->out_mode == RC_OUT_PIXEL_SHUFFLE2 && !p.m32 && p.n_chunks == 1 && p.n_ct == 4 && d->cout == 4 * 16 * p.nt &&
+                d->dtype == RC_BF16 && d->in_gate == nullptr && fast && (key == 0 || key == 1 || key == 2);
     }
     {
         const int num_cus = device_cu_count();          // per device (common.hpp)

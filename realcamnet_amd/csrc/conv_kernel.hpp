@@ -62,6 +62,7 @@ struct ConvArgs {
     int ep_key;                        // epilogue_fast feature mask, or -1 for the generic epilogue (ep_key_for)
     TileDecode td, td_wsm;             // division constants of the persistent kernels' tile decode (8- and 16-row tiles)
     MagicDiv div_n_ct;
+    int pss;                           // single-chunk pixel-shuffle layer: kernel 5 (output staged through LDS)
     int fold2, src_H, src_W, cfold;    // ksize 2 over the UN-shuffled input: in0 is (B, src_H, src_W, cfold = cin / 4), see ConvDev::fold_*
     long long* dbg;                    // optional phase-timing buffer (rc_debug_set_ptr), normally NULL
     int dbg_flags;                     // knock-out experiments (rc_debug_set "conv_flags"): 1 no stores, 2 no MFMA, 4 no tile loads
@@ -741,7 +742,8 @@ struct ConvDev {
                     for (int e = 0; e < NV; ++e) csum[e] += valid ? v[e] : 0.f;
                 }
             }
-            const int oo = (valid && !(a.dbg_flags & 1)) ? o_off0 + dy * o_row + dx * o_col : kOOB;
+            int oo = (valid && !(a.dbg_flags & 1)) ? o_off0 + dy * o_row + dx * o_col : kOOB;
+            if ((a.dbg_flags & 8) && oo != kOOB) oo &= 0x3fffff;      // knock-out: every store lands in one 4 MB window (L2-resident: no HBM write stream)
             buf_store_row<T, NV, PK_RELU>(r_out, oo, v);
         }
         if constexpr ((F & EP_SUMS) != 0) {
@@ -1381,6 +1383,225 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
     }
 }
 
+// ==================================================================================================
+// Kernel 5: kernel 4 for the single-chunk pixel-shuffle layers (the tail 48 -> 192 + PixelShuffle(2): 6.4 GB of output at cfg3) with the
+// OUTPUT staged through LDS and stored by the loader waves.  OFF by default (rc_debug_set("pss", 1)): it ties with kernel 4.
+// Knock-outs of kernel 4 on that layer (tools/tail_probe.py, tools/pss_flags.py; 8 x 1088 x 1920): 3.27 ms; 2.04 ms without its stores
+// (MFMA floor 1.6 ms at the clock these kernels run at); 2.64 ms with every store redirected into one L2-resident 4 MB window -- so
+// about half of the 1.2 ms the stores cost is issuing them (all 8 compute waves reach the epilogue together, each of their 8 store
+// instructions holds the wave's issue port until the write path takes it) and half is the HBM write stream itself (96-byte sub-pixel
+// pieces = half of every 128-byte line per cout tile; tools/ubench/store_issue.hip writes that pattern at 2.3 TB/s when the two halves of
+// a line are more than ~1 MB per XCD apart, 5 TB/s when they leave together).  Tried on kernel 4 and dropped: the previous tile's stores
+// issued one by one inside the next stage's MFMA stream (3.6 ms), and holding the even sub-pixel in registers to store complete lines with
+// the odd one (3.31 ms).  Here the compute waves never touch the write path: they pack a cout tile (= one sub-pixel of every pixel) to
+// bf16, drop it into an LDS out tile (3 ds_write_b64 per pixel tile) and go on; the 4 loader waves drain it in address order while the
+// next stage's MFMAs run.  LDS: the out tile (48 KB) takes the place of the second input buffer -- a tile's 4 stages read one input tile,
+// and the next one is committed from registers in the short phase in which the computers write the out tile:
+//
+//            compute waves 0-7                                   loader waves 8-11
+//   phase 0  packed result of stage g-1 -> out tile              Wb(g) registers -> LDS; first stage of a tile: input tile registers -> LDS
+//   barrier
+//   half a   MFMA steps [0, SA) of stage g    (Wa)               issue loads Wa(g+1) (+ the next input tile during a tile's last stage);
+//                                                                drain the out tile, first half  (LDS -> HBM, pixel-shuffled address)
+//   barrier
+//   half b   MFMA steps [SA, STEPS)           (Wb); pack         Wa(g+1) registers -> LDS; issue loads Wb(g+1); drain, second half
+//   barrier
+//
+// Result: the exposed store time halves (3.16-3.29 ms with stores, 2.60 without) but the third barrier, the single input buffer and the
+// out tile's LDS traffic cost what that gains (2.60 vs 2.04 ms without stores): bit-identical to kernel 4, not faster.
+// ==================================================================================================
+template <class Cfg>
+constexpr int pss_lds_bytes() { return (int)Cfg::CHUNK_W_BYTES + kPersistMaxCout * 4 + WsmCfg<Cfg>::IN_BYTES + kWsmTH * kTW * Cfg::COUT_TILE * 2; }
+
+template <class Cfg8>
+__global__ __launch_bounds__(kWsmThreads) void conv_mfma_pss_kernel(const ConvArgs a) {
+    using Cfg = WsmCfg<Cfg8>;
+    using D = ConvDev<Cfg>;
+    using T = typename Cfg::elem;
+    static_assert(sizeof(T) == 2, "bf16 form");
+    constexpr int NT = Cfg::NT, STEPS = Cfg::STEPS, NV = 4 * NT, NH = NV / 2;
+    constexpr int SA = (STEPS + 1) / 2;
+    constexpr int WA = SA * NT * 1024, WB = (STEPS - SA) * NT * 1024, WALL = (int)Cfg::CHUNK_W_BYTES;
+    constexpr int NWA = (WA / 16 + kThreads - 1) / kThreads, NWB = (WB / 16 + kThreads - 1) / kThreads;
+    constexpr int PXB = Cfg::COUT_TILE * 2, ROWB = kTW * PXB, OUTB = kWsmTH * ROWB;   // out tile: [16 rows][32 pixels][COUT_TILE bf16]
+    constexpr int UPP = PXB / 16, UPR = kTW * UPP;                   // 16-byte units per pixel / per row
+    constexpr int NDR = OUTB / 16 / kThreads;                        // units per loader thread
+    static_assert(STEPS >= 2 && WA + WB == WALL && OUTB % (16 * kThreads) == 0 && NDR % 2 == 0 && PXB % 16 == 0, "pss shapes");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_w = smem;
+    float* s_bias = reinterpret_cast<float*>(smem + WALL);
+    char* s_in = smem + WALL + kPersistMaxCout * 4;
+    char* s_out = s_in + Cfg::IN_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave12 >= 8;
+    const int q = lane >> 4, n = lane & 15;
+
+    const int tiles_y = (a.H + kWsmTH - 1) / kWsmTH;
+    const int sp_total = a.tiles_x * tiles_y;
+    const int n_tiles = sp_total * a.batch;
+    constexpr int n_ct = 4;                                          // host: cout = 4 cout tiles = the 4 sub-pixels
+    const int slots = gridDim.x >> 3;                                // XCD x takes a run of consecutive tiles
+    const int pos = (blockIdx.x & 7) * slots + (blockIdx.x >> 3);
+    const int stride = (int)gridDim.x;
+    const int my_units = pos < n_tiles ? (n_tiles - pos + stride - 1) / stride : 0;
+    const int my_stages = my_units * n_ct;
+    const int cps = a.cout >> 2;                                     // == COUT_TILE
+
+    for (int i = tid; i < a.cout_packed; i += kWsmThreads) s_bias[i] = a.bias ? a.bias[i] : 0.f;
+
+    auto decode = [&](int unit, int& b, int& ty, int& tx) {
+        b = magic_div(unit, a.td_wsm.sp_total);
+        band_decode(unit - b * sp_total, a.tiles_x, tiles_y, a.td_wsm, ty, tx);
+    };
+
+    if (loader) {
+        const int rtid = tid - kWsmCompute;
+        uint4 r0[D::NI], r1[1], wra[NWA], wrb[NWB];
+        float gv[1];
+        typename D::TileSrc ts;
+        typename D::TileOffs to;
+        D::tile_offsets(a, rtid, to);
+        // this thread's 16-byte pieces of the two weight halves (recomputed where used: the loader's registers go to the tile and the weights)
+        // (through `lt`, the thread index hidden from loop-invariant code motion: hoisted, these offsets and the drain's would be spilled)
+        int lt = rtid;
+        auto woa = [&](int k) { return (k * kThreads + lt) * 16 < WA ? (k * kThreads + lt) * 16 : kOOB; };
+        auto wob = [&](int k) { return (k * kThreads + lt) * 16 < WB ? WA + (k * kThreads + lt) * 16 : kOOB; };
+        const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpacked, (unsigned)((size_t)n_ct * WALL));
+        const size_t img_out = (size_t)a.H * a.W * a.cout;
+
+        int b = 0, ty = 0, tx = 0;                                   // tile whose loads were issued last
+        int d_b = 0, d_y0 = 0, d_x0 = 0, d_ct = 0;                  // stage whose result sits in the out tile
+        int wsoff = 0;
+        auto issue_tile = [&](int k) {
+            decode(pos + k * stride, b, ty, tx);
+            ts = D::tile_src(a, b, ty * kWsmTH, tx * kTW);
+            D::template load_tile<false>(a, ts, to, b, 0, rtid, r0, r1, gv);
+        };
+        auto issue_wa = [&](int ct) {
+            wsoff = ct * WALL;
+#pragma unroll
+            for (int k = 0; k < NWA; ++k) wra[k] = buf_load16(r_w, woa(k), wsoff);
+        };
+        auto issue_wb = [&]() {
+#pragma unroll
+            for (int k = 0; k < NWB; ++k) wrb[k] = buf_load16(r_w, wob(k), wsoff);
+        };
+        auto commit_tile = [&]() { D::template commit_tile<false>(a, ts, to, 0, rtid, r0, r1, gv, s_in); };
+        auto commit_wa = [&]() {
+#pragma unroll
+            for (int k = 0; k < NWA; ++k)
+                if (woa(k) != kOOB) *reinterpret_cast<uint4*>(s_w + woa(k)) = wra[k];
+        };
+        auto commit_wb = [&]() {
+#pragma unroll
+            for (int k = 0; k < NWB; ++k)
+                if (wob(k) != kOOB) *reinterpret_cast<uint4*>(s_w + wob(k)) = wrb[k];
+        };
+        auto drain = [&](int j0, bool live) {                        // NDR / 2 units: LDS -> the pixel-shuffled NHWC output (always issued: countable)
+            const __amdgpu_buffer_rsrc_t r_out = make_rsrc(static_cast<T*>(a.out) + (size_t)d_b * img_out, (unsigned)(img_out * 2));
+            const int base = (((2 * d_y0 + (d_ct >> 1)) * (2 * a.W) + 2 * d_x0 + (d_ct & 1)) * cps) * 2;
+            const bool full = live && d_y0 + kWsmTH <= a.H && d_x0 + kTW <= a.W && !(a.dbg_flags & 1);     // uniform
+            asm volatile("" : "+v"(lt));
+            // unit u = rtid + 256 j of the out tile is (row, pixel, 16-byte part) -> pixel (2 row, 2 pixel) of the stage's sub-pixel plane
+#pragma unroll
+            for (int j = j0; j < j0 + NDR / 2; ++j) {
+                const int u = lt + kThreads * j, row = u / UPR, rem = u - row * UPR, px = rem / UPP, part = rem - px * UPP;
+                const uint4 v = *reinterpret_cast<const uint4*>(s_out + u * 16);
+                int off = base + ((2 * row * (2 * a.W) + 2 * px) * cps) * 2 + part * 16;
+                if (!full && (!live || d_y0 + row >= a.H || d_x0 + px >= a.W || (a.dbg_flags & 1))) off = kOOB;
+                buf_store16(r_out, off, 0, v);
+                if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // two units in flight: the registers belong to the tile and the weights
+            }
+        };
+
+        if (my_stages > 0) {
+            issue_tile(0); issue_wa(0);
+            commit_tile(); commit_wa();
+            issue_wb();
+        }
+        __syncthreads();                                             // barrier 0: bias, Wa(0), tile(0) visible
+        for (int g = 0; g < my_stages; ++g) {
+            const int k = g >> 2, ct = g & 3;
+            asm volatile("" : "+v"(lt));
+            // ---- phase 0: LDS writes only (the computers wait for it)
+            commit_wb();                                             // Wb(g)
+            if (ct == 0 && g > 0) commit_tile();                     // this tile's input (loaded during the previous tile's last stage)
+            __syncthreads();
+            // ---- half a: loads first, then the stores (a commit waits for everything older than its loads, see kernel 4)
+            if (g + 1 < my_stages) issue_wa((g + 1) & 3);            // Wa(g+1)
+            if (ct == 3 && k + 1 < my_units) issue_tile(k + 1);
+            drain(0, g > 0);
+            __syncthreads();
+            // ---- half b
+            if (g + 1 < my_stages) { commit_wa(); issue_wb(); }
+            drain(NDR / 2, g > 0);
+            // the stage the computers are packing now is drained during the next one
+            {
+                int cb, cty, ctx;
+                decode(pos + k * stride, cb, cty, ctx);
+                d_b = cb; d_y0 = cty * kWsmTH; d_x0 = ctx * kTW; d_ct = ct;
+            }
+            __syncthreads();
+        }
+        __syncthreads();                                             // the last stage's result is in the out tile
+        drain(0, my_stages > 0); drain(NDR / 2, my_stages > 0);
+    } else {
+        const int wave = wave12;                                     // rows 2*wave, 2*wave+1 of the 16-row tile
+        typename D::LaneOff lo;
+        D::lane_offsets(q, lo);
+        const int lane_x = ((2 * wave) * D::TWH + n) * D::SPIX;
+        const int lane_w = lane * 16;
+        const int o_lane = (2 * wave) * ROWB + n * PXB + q * NV * 2;  // this lane's slot of pixel tile 0 in the out tile
+        unsigned pend[4][NH];
+        auto put = [&]() {
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                char* dst = s_out + o_lane + (pt >> 1) * ROWB + (pt & 1) * 16 * PXB;
+                if constexpr (NV * 2 % 16 == 0) {
+#pragma unroll
+                    for (int i = 0; i < NH; i += 4) *reinterpret_cast<uint4*>(dst + 4 * i) = make_uint4(pend[pt][i], pend[pt][i + 1], pend[pt][i + 2], pend[pt][i + 3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NH; i += 2) *reinterpret_cast<uint2*>(dst + 4 * i) = make_uint2(pend[pt][i], pend[pt][i + 1]);
+                }
+            }
+        };
+        const float inf = __builtin_inff();
+        __syncthreads();                                             // barrier 0
+        for (int g = 0; g < my_stages; ++g) {
+            const int ct = g & 3;
+            if (g > 0) put();                                        // phase 0
+            __syncthreads();
+            f32x4 acc[4][NT];                                        // initial C operand = bias
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 t4 = *reinterpret_cast<const float4*>(s_bias + ct * Cfg::COUT_TILE + q * NV + nt * 4);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
+            }
+            D::template mma_steps<0, SA, 0, true>(s_in, s_w, lane_x, lane_w, q, lo, acc);
+            __syncthreads();
+            D::template mma_steps<SA, STEPS - SA, 0, true>(s_in, s_w, lane_x, lane_w, q, lo, acc);
+            const int key = a.ep_key;                                // 0 none, EP_RELU, EP_LEAKY (host: nothing else takes this kernel)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                for (int i = 0; i < NH; ++i) {
+                    float v0 = acc[pt][(2 * i) >> 2][(2 * i) & 3], v1 = acc[pt][(2 * i + 1) >> 2][(2 * i + 1) & 3];
+                    if (key == D::EP_RELU) { v0 = __builtin_amdgcn_fmed3f(v0, 0.f, inf); v1 = __builtin_amdgcn_fmed3f(v1, 0.f, inf); }
+                    else if (key == D::EP_LEAKY) { v0 = __builtin_amdgcn_fmed3f(v0, v0 * a.act_slope, inf); v1 = __builtin_amdgcn_fmed3f(v1, v1 * a.act_slope, inf); }
+                    pend[pt][i] = pack_bf16x2(v0, v1);
+                }
+            __syncthreads();
+        }
+        if (my_stages > 0) put();
+        __syncthreads();
+    }
+}
+
 template <class Cfg>
 constexpr int ws_lds_bytes() { return 2 * Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + 16 * Cfg::NT * 4; }
 
@@ -1408,6 +1629,24 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
             if (grid > n_tiles) grid = n_tiles;
             grid = (grid + 7) / 8 * 8;
             hipLaunchKernelGGL((conv_mfma_ws_kernel<Cfg, GATED, FAST>), dim3((unsigned)grid), dim3(kWsThreads), WS_LDS, stream, a);
+            RC_HIP_CHECK(hipGetLastError());
+            return RC_OK;
+        }
+    }
+    if constexpr (!GATED && FAST && sizeof(typename Cfg::elem) == 2 && Cfg::KS == 3 && Cfg::STEPS >= 2 && pss_lds_bytes<Cfg>() <= 160 * 1024 &&
+                  (kWsmTH * kTW * Cfg::COUT_TILE * 2) % (16 * kThreads * 2) == 0) {
+        // single-chunk pixel-shuffle layers: output staged through LDS, stored by the loader waves (kernel 5)
+        if (a.pss && a.n_chunks == 1 && a.n_ct == 4 && a.cin_vec_ok && a.cin_chunk_ok && a.persist_ok && n_tiles < (1 << 24)) {
+            constexpr int PSS_LDS = pss_lds_bytes<Cfg>();
+            const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch;
+            static PerDeviceFlag attr_set;
+            if (!attr_set.test_and_set()) {
+                RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_pss_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, PSS_LDS));
+            }
+            int grid = a.num_cus;
+            if (grid > n_items) grid = n_items;
+            grid = (grid + 7) / 8 * 8;
+            hipLaunchKernelGGL((conv_mfma_pss_kernel<Cfg>), dim3((unsigned)grid), dim3(kWsmThreads), PSS_LDS, stream, a);
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }

@@ -523,6 +523,41 @@ def test_multichunk_conv_exact_on_integer_data(hip, persist, gated, shape):
     assert torch.equal(y, ref)
 
 
+@pytest.mark.parametrize("act", [None, "relu", "leaky"])
+@pytest.mark.parametrize("shape", [(1, 16, 32), (2, 37, 70), (1, 130, 200), (3, 48, 96)])
+def test_tail_conv_with_lds_staged_pixel_shuffle_exact(hip, act, shape):
+    """Kernel 5 (csrc/conv_kernel.hpp, rc_debug_set("pss", 1): the 48 -> 192 + PixelShuffle(2) layer with its output staged through LDS and
+    stored by the loader waves; off by default, it ties with kernel 4): bit-exact against F.conv2d + pixel_shuffle on integer data -- one
+    tile, ragged edges, several tiles per block, fused ReLU / LeakyReLU -- and bit-identical to the default kernel on real-valued data."""
+    b, h, w = shape
+    g = torch.Generator().manual_seed(h * 3 + w)
+    c = N.Conv2d(48, 192, 3, 1, 1)
+    with torch.no_grad():
+        c.weight.copy_(torch.randint(-1, 2, c.weight.shape, generator=g).float())
+        c.bias.copy_(torch.randint(-2, 3, c.bias.shape, generator=g).float())
+    x = torch.randint(-1, 2, (b, 48, h, w), generator=g).float()
+    ref = F.conv2d(x, c.weight.detach(), c.bias.detach(), padding=1)
+    kw = {}
+    if act == "relu":
+        ref = ref.relu(); kw = dict(act="relu")
+    elif act == "leaky":
+        ref = torch.where(ref > 0, ref, ref * 0.5); kw = dict(act="leaky", slope=0.5)
+    ref = F.pixel_shuffle(ref, 2)
+    assert ref.abs().max() <= 512                                    # half-integers up to 512 are exact in bf16
+    c = c.to(DEV, torch.bfloat16)
+    xd = ops.to_nhwc(x.to(DEV, torch.bfloat16))
+    xr = torch.randn(b, h, w, 48, generator=g).to(DEV, torch.bfloat16)
+    with torch.no_grad():
+        y0, r0 = (ops.conv2d(t, c, out_mode=ops.RC_OUT_PIXEL_SHUFFLE2, **kw) for t in (xd, xr))
+        assert hip.rc_debug_set(b"pss", 1) == 0
+        try:
+            y1, r1 = (ops.conv2d(t, c, out_mode=ops.RC_OUT_PIXEL_SHUFFLE2, **kw) for t in (xd, xr))
+        finally:
+            assert hip.rc_debug_set(b"pss", 0) == 0
+    assert torch.equal(ops.to_nchw(y1).float().cpu(), ref)
+    assert torch.equal(y0, y1) and torch.equal(r0, r1)
+
+
 @pytest.mark.parametrize("knob", [1, 2, 3])
 @pytest.mark.parametrize("mode", ["plain", "gated", "res", "sums", "film", "ps"])
 @pytest.mark.parametrize("shape", [(128, 64, 16, 40), (192, 192, 9, 33), (128, 128, 37, 100), (48, 192, 21, 70)])

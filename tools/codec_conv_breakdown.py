@@ -26,7 +26,9 @@ class T(TorchDispatchMode):
         e0.record(); out = func(*args, **(kwargs or {})); e1.record(); torch.cuda.synchronize()
         shp = tuple(args[0].shape) if hasattr(args[0], "shape") else ()
         extra = ""
-        if "conv2d" in name:
+        if "conv2d_fold2" in name:
+            extra = f"cout={args[3]} k=s2 act={args[4]}"
+        elif "conv2d" in name:
             extra = f"cout={args[3]} k={args[4]} act={args[5]} mode={args[14]}"
         recs.append((name.replace("realcam.", "").replace(".default", ""), shp, extra, e0.elapsed_time(e1)))
         return out
@@ -39,7 +41,10 @@ for n, s, e, t in recs:
     agg[(n, s, e)][0] += 1; agg[(n, s, e)][1] += t
 for (n, s, e), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
     fl = ""
-    if n == "conv2d":
+    if n == "conv2d_fold2":
+        cout = int(e.split()[0][5:]); b, h, w, cin = s
+        fl = f"{2.0*b*(h//2)*(w//2)*cin*cout*9/(t/c)/1e9:7.0f} TF/s"
+    elif n == "conv2d":
         cout = int(e.split()[0][5:]); k = int(e.split()[1][2:]); b, h, w, cin = s
         fl = f"{2.0*b*h*w*cin*cout*k*k/(t/c)/1e9:7.0f} TF/s"
     print(f"{t:7.2f} ms  x{c:3d}  {t/c*1e3:8.1f} us  {n:22s} {str(s):26s} {e:32s} {fl}")
