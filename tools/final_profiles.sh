@@ -22,6 +22,8 @@ timeout 120 python tools/mfma_peak.py > gpurun_out/mfma_peak_$TAG.txt 2>/dev/nul
 timeout 400 python tools/conv32_probe.py > gpurun_out/conv32_probe_$TAG.txt 2>&1
 ( for V in 2 3 1; do V=$V timeout 100 python tools/conv32_phases.py; done; timeout 100 python tools/conv32_phases.py 512 512 136 240 8; V=2 timeout 100 python tools/conv32_phases.py 128 128 272 480 8 --gated; V=1 timeout 100 python tools/conv32_phases.py 48 192 1088 1920 8 --ps; V=1 FLAGS=8 timeout 100 python tools/conv32_phases.py 48 192 1088 1920 8 --ps ) > gpurun_out/conv32_phases_$TAG.txt 2>&1
 timeout 120 ./tools/ubench/store_issue > gpurun_out/store_issue_$TAG.txt 2>&1
+( timeout 200 python tools/tail_probe.py; timeout 200 python tools/pss_flags.py ) > gpurun_out/tail_$TAG.txt 2>&1
+( timeout 200 python tools/codec_graph_probe.py; timeout 200 python tools/codec_conv32_probe.py; timeout 200 python tools/codec_conv_breakdown.py ) > gpurun_out/codec_probes_$TAG.txt 2>&1
 timeout 300 python tools/pair2_probe.py sums plain gated film > gpurun_out/pair2_$TAG.txt 2>&1
 bash tools/pmc_mfma.sh $TAG > gpurun_out/pmc_mfma_${TAG}.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_cmp_$TAG -o trace -- python tools/compress_trace.py > gpurun_out/compress_$TAG.txt 2>&1
@@ -31,6 +33,7 @@ tail -c 400 gpurun_out/bench_default_$TAG.json; echo; cut -c1-160 gpurun_out/ben
 
 # summaries are written ON the box (gpurun_out/ is capped at 64 MiB on the way back): keep them, the bench trace database and the small logs
 mkdir -p gpurun_out/profiles_$TAG
+cp gpurun_out/tail_$TAG.txt gpurun_out/codec_probes_$TAG.txt gpurun_out/store_issue_$TAG.txt gpurun_out/profiles_$TAG/ 2>/dev/null
 python tools/write_profiles.py $TAG $ROUND gpurun_out/profiles_$TAG > gpurun_out/profiles_$TAG/summary.json 2> gpurun_out/write_profiles_$TAG.err
 mkdir -p gpurun_out/keep_$TAG && cp gpurun_out/prof_$TAG/trace_results.db gpurun_out/keep_$TAG/bench_trace_results.db 2>/dev/null
 rm -rf gpurun_out/prof_* gpurun_out/pmc_${TAG}_* gpurun_out/pmcm_${TAG}_*
