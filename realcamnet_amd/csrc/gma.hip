@@ -510,6 +510,13 @@ static inline int pw_grid(size_t n) {
 
 }  // namespace rc
 
+namespace rc {
+int g_dw3_seg16 = 1;     // rc_debug_set("dw3_seg16", v): 1 (default) bf16 3x3 single-rep calls of rc_dwconv2d take the 16-channel-segment kernel (gma_fused.hip); 0: the general one
+namespace gf {
+int launch_dw3x3_seg16(const void* x, int xs, int x_c0, void* y, int ys, int y_c0, int batch, int H, int W, int n_ch, const float* wT, int n_w,
+                       const float* bias, int add_identity, hipStream_t stream);
+}
+}
 using namespace rc;
 
 extern "C" {
@@ -528,6 +535,9 @@ int rc_dwconv2d(const void* d_x, int x_stride_c, int x_c0, void* d_y, int y_stri
                "rc_dwconv2d: channel counts/offsets must be multiples of 16 bytes");
     RC_REQUIRE(x_c0 + (n_rep - 1) * x_rep_stride + n_ch <= x_stride_c && y_c0 + (n_rep - 1) * y_rep_stride + n_ch <= y_stride_c &&
                (n_rep - 1) * w_rep_stride + n_ch <= n_w, "rc_dwconv2d: channel range exceeds tensor");
+    // bf16 3x3 on 16-channel segments without reps / per-vector windows (ConvPosEnc): the aggregator's conflict-free core, same bits (gma_fused.hip)
+    if (dtype == RC_BF16 && ksize == 3 && n_rep == 1 && d_kvec == nullptr && n_ch % 16 == 0 && g_dw3_seg16)
+        return gf::launch_dw3x3_seg16(d_x, x_stride_c, x_c0, d_y, y_stride_c, y_c0, batch, H, W, n_ch, d_wT, n_w, d_bias, add_identity, as_stream(stream));
     const int vpc = n_ch / U;
     int vb = 1;                                           // channel vectors (= waves) per block: largest divisor of vpc <= 5
     for (int c = 5; c >= 1; --c) if (vpc % c == 0) { vb = c; break; }   // (narrower blocks for mixed kvec windows measured slower:

@@ -902,6 +902,97 @@ extern "C" int rc_gma_crpe(const void* d_qkvp, void* d_convv, int batch, int H, 
     return RC_OK;
 }
 
+// ---- depth-wise 3x3 (+ bias, + identity) of NHWC maps whose channel count is a multiple of 16: rc_dwconv2d's bf16 3x3 single-rep case
+// (ConvPosEnc, upstream groupmix.py:33-53: x = t + dw3x3(t) + b).  The general rc_dwconv2d kernel (gma.hip) stages 40-channel pixel slots with an
+// odd 16-byte stride and ran at 2.6 TB/s with 47 % of its LDS cycles in bank conflicts (profiles/r03_pmc_mfma_lds.md); this is the aggregator's
+// core instead -- one (16 x 32 tile, 16-channel segment) per block, conflict-free 40-byte pixel slots, six blocks per CU -- with the same
+// accumulation order (bias; taps in (dy, dx) order by fmaf; the identity after the centre row), so the two give the same bits. ----------------
+namespace rc {
+namespace gf {
+
+struct Dw3Args {
+    const bf16_t* x; bf16_t* y; int xs, x_c0, ys, y_c0;     // channel strides / first channels (elements)
+    int batch, H, W, n_seg, tiles_x, tiles_y;
+    const float* wT; int n_w;                               // tap-major [9][n_w]
+    const float* bias; int add_identity;
+};
+
+constexpr int DW3_LDS = (AG_TH + 2) * ((AG_TW + 2) * AG_PS + AG_RPAD);
+
+__global__ __launch_bounds__(AG_THREADS) void dw3x3_seg16_kernel(Dw3Args a) {
+    __shared__ __attribute__((aligned(16))) char s_x[DW3_LDS];
+    __shared__ __attribute__((aligned(16))) float s_w[9 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+    int blk = blockIdx.x;                                   // a tile's segments on one XCD, close in time (see gma_agg_kernel)
+    const int lane8 = blk & 7; blk >>= 3;
+    const int seg = blk % a.n_seg; blk = (blk / a.n_seg) * 8 + lane8;
+    if (blk >= a.tiles_x * a.tiles_y * a.batch) return;
+    const int tx = blk % a.tiles_x; blk /= a.tiles_x;
+    const int ty = blk % a.tiles_y;
+    const int b = blk / a.tiles_y;
+    const int y0 = ty * AG_TH, x0 = tx * AG_TW;
+    const int prow = 4 * wave + 2 * (n >> 3), pcol = 4 * (n & 7);      // this lane's 2 x 4 patch, channels 4 q .. 4 q + 3 of the segment
+    for (int i = tid; i < 9 * 16; i += AG_THREADS) s_w[i] = a.wT[(i >> 4) * a.n_w + 16 * seg + (i & 15)];
+    agg_stage<1>(s_x, a.x + (size_t)b * a.H * a.W * a.xs, a.xs, a.x_c0 + 16 * seg, y0, x0, a.H, a.W, tid);
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bv = ld4(a.bias + 16 * seg + 4 * q);
+    __syncthreads();
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[o][c] = bv;
+    constexpr int RS = (AG_TW + 2) * AG_PS + AG_RPAD;
+    const char* base = s_x + prow * RS + pcol * AG_PS + q * 8;
+#pragma unroll
+    for (int iy = 0; iy < 4; ++iy) {
+        f32x4 xin[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) xin[c] = up_tail(*reinterpret_cast<const uint2*>(base + iy * RS + c * AG_PS));
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int dy = iy - o;
+            if (dy < 0 || dy >= 3) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const f32x4 w = ld4(s_w + (dy * 3 + dx) * 16 + 4 * q);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[o][c][e] = __builtin_fmaf(w[e], xin[c + dx][e], acc[o][c][e]);
+            }
+            if (a.add_identity && dy == 1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[o][c] = acc[o][c] + xin[c + 1];
+            }
+        }
+    }
+    bf16_t* yb = a.y + (size_t)b * a.H * a.W * a.ys + a.y_c0 + 16 * seg + 4 * q;
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (y0 + prow + o < a.H && x0 + pcol + c < a.W)
+                *reinterpret_cast<uint2*>(yb + ((size_t)(y0 + prow + o) * a.W + x0 + pcol + c) * a.ys) = pack_tail(acc[o][c] + 0.f);
+}
+
+// called by rc_dwconv2d (gma.hip) for bf16, 3x3, one rep, no per-vector windows, 16 | n_ch
+int launch_dw3x3_seg16(const void* x, int xs, int x_c0, void* y, int ys, int y_c0, int batch, int H, int W, int n_ch, const float* wT, int n_w,
+                       const float* bias, int add_identity, hipStream_t stream) {
+    Dw3Args a;
+    a.x = static_cast<const bf16_t*>(x); a.y = static_cast<bf16_t*>(y); a.xs = xs; a.x_c0 = x_c0; a.ys = ys; a.y_c0 = y_c0;
+    a.batch = batch; a.H = H; a.W = W; a.n_seg = n_ch / 16; a.tiles_x = ceil_div(W, AG_TW); a.tiles_y = ceil_div(H, AG_TH);
+    a.wT = wT; a.n_w = n_w; a.bias = bias; a.add_identity = add_identity;
+    const size_t blocks = (((size_t)a.tiles_x * a.tiles_y * batch + 7) / 8) * 8 * a.n_seg;
+    RC_REQUIRE(blocks < (1ull << 31), "rc_dwconv2d: too many tiles");
+    hipLaunchKernelGGL(dw3x3_seg16_kernel, dim3((unsigned)blocks), dim3(AG_THREADS), 0, stream, a);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+}  // namespace gf
+}  // namespace rc
+
 // =====================================================================================================================================
 // Lens_Shading_Correction as a register-resident chain, optionally with the convolution it modulates
 //   coord (B,H,W,cin0 <= 4) -> Conv1x1(cin0, C) -> LeakyReLU -> [Conv1x1(C, C) -> LeakyReLU] x (n_mid - 1) -> Conv1x1(C, C) = lsc

@@ -202,3 +202,27 @@ def test_kv_on_matrix_cores_equals_two_pass_form(hip):
     assert got.shape == want.shape == (b, 8, 8, 8)
     assert torch.equal(got, again)
     assert (got - want).abs().max().item() <= 1e-2 * want.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,hw", [(80, (37, 70)), (80, (16, 32)), (48, (130, 65)), (160, (9, 200))])
+@pytest.mark.parametrize("identity", [True, False])
+def test_depthwise3x3_segment_kernel_equals_the_general_one(hip, c, hw, identity):
+    """rc_dwconv2d's bf16 3x3 single-rep case (ConvPosEnc) runs on the aggregator's 16-channel-segment core (csrc/gma_fused.hip,
+    rc_debug_set("dw3_seg16")): same accumulation order as the general kernel -> the same bits, ragged tiles included; and both agree with
+    an fp32 torch depth-wise convolution of the bf16 inputs to bf16 rounding."""
+    g = torch.Generator().manual_seed(c + hw[0])
+    x = torch.randn(2, *hw, c, generator=g).to("cuda", torch.bfloat16)
+    w = (torch.randn(c, 1, 3, 3, generator=g) * 0.3).to("cuda")
+    bias = torch.randn(c, generator=g).to("cuda")
+    wT = ops.dw_taps(w)
+    y1 = ops.dwconv2d(x, 0, (c,), 0, c, 3, wT, bias=bias, add_identity=identity)
+    assert hip.rc_debug_set(b"dw3_seg16", 0) == 0
+    try:
+        y0 = ops.dwconv2d(x, 0, (c,), 0, c, 3, wT, bias=bias, add_identity=identity)
+    finally:
+        assert hip.rc_debug_set(b"dw3_seg16", 1) == 0
+    assert torch.equal(y0, y1)
+    xf = x.float().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xf, w, bias, padding=1, groups=c) + (xf if identity else 0)
+    assert rel_err(y1.float().permute(0, 3, 1, 2), ref) <= 6e-3
