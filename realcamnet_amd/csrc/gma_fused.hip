@@ -1134,6 +1134,8 @@ __global__ __launch_bounds__(lsc_threads<C>(), 2) void lsc_chain_kernel(const Ls
     const int total = w_bytes + (1 + a.n_mid + (HEAD ? 1 : 0)) * MT * 16 * 4;
     for (int i = tid; i < total / 16; i += kLscThreads) reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(a.blob)[i];
     __syncthreads();
+    constexpr bool STAGE = C <= 64;                      // narrow chains: per-wave output staging behind the weights (the wide form's LDS is full)
+    [[maybe_unused]] char* s_stage = lds + ((total + 15) & ~15);
     const char* s_l0 = lds;
     const char* s_mid = lds + MT * 512;
     const char* s_head = s_mid + a.n_mid * MT * TBM;
@@ -1230,10 +1232,29 @@ __global__ __launch_bounds__(lsc_threads<C>(), 2) void lsc_chain_kernel(const Ls
                 for (int nt = 0; nt < kNT; ++nt) cur[nt].t = pack_tail((head_tile(MT - 1, nt) + b0) * (up_tail(cur[nt].t) + 1.f));
             }
         }
+        if constexpr (STAGE) {
+            // The tile's 64 x C output leaves as whole kilobytes: a lane's pieces (16 + 16 [+ 8] bytes of one token) go through this wave's
+            // 6 KB of LDS and come back as 16-byte units in address order.  Stored straight from the B-operand layout they were 64-byte runs at a
+            // C * 2-byte pitch, 2-3 instructions per 16 tokens, and those instructions' issue (tools/ubench/store_issue.hip: ~2x the cycles of a
+            // whole-kilobyte store, CU-wide) was what the kernel waited for: 1.12 -> see DESIGN.md 4.9 at cfg3.  Same wave writes and reads: the LDS
+            // queue is in order, no barrier.
+            char* st = s_stage + (tid >> 6) * (64 * C * 2);
 #pragma unroll
-        for (int nt = 0; nt < kNT; ++nt) {
-            const long long p = tile * 64 + 16 * nt + n;
-            if (p < a.pixels) store_act<C>(a.out + p * C, g, cur[nt]);
+            for (int nt = 0; nt < kNT; ++nt) store_act<C>(reinterpret_cast<bf16_t*>(st) + (16 * nt + n) * C, g, cur[nt]);
+            const long long left = (a.pixels - tile * 64) * (C * 2);                       // bytes of this tile inside the tensor
+            const __amdgpu_buffer_rsrc_t r_o = __builtin_amdgcn_make_buffer_rsrc(a.out + tile * 64 * C, 0, (int)(left < 64 * C * 2 ? left : 64 * C * 2), 0x00020000);
+#pragma unroll
+            for (int j = 0; j < (64 * C * 2) / 1024; ++j) {
+                const uint4 v = *reinterpret_cast<const uint4*>(st + (lane + 64 * j) * 16);
+                typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_raw_buffer_store_b128(u4_t{v.x, v.y, v.z, v.w}, r_o, (lane + 64 * j) * 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) {
+                const long long p = tile * 64 + 16 * nt + n;
+                if (p < a.pixels) store_act<C>(a.out + p * C, g, cur[nt]);
+            }
         }
     }
 }
@@ -1299,8 +1320,9 @@ extern "C" int rc_lsc_chain(const void* d_x, int cin0, const void* d_blob, int c
     a.x = static_cast<const bf16_t*>(d_x); a.cin0 = cin0; a.blob = static_cast<const char*>(d_blob); a.n_mid = n_mid; a.slope = slope;
     a.raw = static_cast<const bf16_t*>(d_raw); a.raw_c = raw_c; a.out = static_cast<bf16_t*>(d_out);
     a.pixels = (long long)batch * H * W; a.H = H; a.W = W;
-    const size_t lds = rc_lsc_packed_bytes(c, n_mid, d_raw != nullptr);
+    size_t lds = rc_lsc_packed_bytes(c, n_mid, d_raw != nullptr);
     RC_REQUIRE(lds <= 150 * 1024, "rc_lsc_chain: weights do not fit LDS");
+    if (c <= 64) lds = ((lds + 15) & ~(size_t)15) + 4 * 64 * (size_t)c * 2;            // + the four waves' output staging (lsc_chain_kernel)
     const long long tiles = (a.pixels + 63) / 64;
     const int wpb = (c > 64 ? 512 : 256) / 64;
     long long grid = (tiles + wpb - 1) / wpb;
