@@ -765,6 +765,63 @@ struct ConvDev {
         }
     }
 
+    // ---- residual epilogue with the residual PREFETCHED (persistent kernel, bf16 NHWC, key == EP_RES) -------------------------------------
+    // epilogue_fast<EP_RES> loads the residual when the MFMA loop is over: one exposed HBM round trip per tile (level-0 48 -> 48 + residual:
+    // 1.14 ms for 4.8 GB where the plain layer moves 3.2 GB in 0.75, tools/conv48_knockouts.py).  Here its loads are issued BEFORE the loop
+    // (the tile's output coordinates are known) and land under the MFMAs; NV / 2 more registers per pixel tile.  Same arithmetic, same bits.
+    static constexpr int NRH = NV / 2;
+    __device__ static __forceinline__ void res_prefetch(const ConvArgs& a, int b, int y0, int x0, int ct, int tid, unsigned (&rp)[4][NRH]) {
+        const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
+        const int jbase = ct * Cfg::COUT_TILE + q * NV;
+        const size_t img_out = (size_t)a.H * a.W * a.cout;
+        const __amdgpu_buffer_rsrc_t r_res = make_rsrc(static_cast<const T*>(a.residual) + (size_t)b * img_out, (unsigned)(img_out * ES));
+        const int gy = y0 + 2 * wave, gx = x0 + n;
+        const int row_b = a.W * a.cout * ES, col_b = 16 * a.cout * ES;
+        const int off0 = ((gy * a.W + gx) * a.cout + jbase) * ES;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const int dy = pt >> 1, dx = pt & 1;
+            const bool valid = gy + dy < a.H && gx + 16 * dx < a.W;
+            const int po = valid ? off0 + dy * row_b + dx * col_b : kOOB;
+#pragma unroll
+            for (int i = 0; i < NRH / 4; ++i) {
+                const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r_res, po + 16 * i, 0, 0);
+                rp[pt][4 * i] = t.x; rp[pt][4 * i + 1] = t.y; rp[pt][4 * i + 2] = t.z; rp[pt][4 * i + 3] = t.w;
+            }
+            if constexpr (NRH % 4 != 0) {
+                const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(r_res, po + 16 * (NRH / 4), 0, 0);
+                rp[pt][4 * (NRH / 4)] = t.x; rp[pt][4 * (NRH / 4) + 1] = t.y;
+            }
+        }
+    }
+    __device__ static __forceinline__ void epilogue_res_pre(const ConvArgs& a, int b, int y0, int x0, int ct, int tid, f32x4 (&acc)[4][NT],
+                                                            const unsigned (&rp)[4][NRH]) {
+        const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
+        const int jbase = ct * Cfg::COUT_TILE + q * NV;
+        const size_t img_out = (size_t)a.H * a.W * a.cout;
+        const __amdgpu_buffer_rsrc_t r_out = make_rsrc(static_cast<T*>(a.out) + (size_t)b * img_out, (unsigned)(img_out * ES));
+        const int gy = y0 + 2 * wave, gx = x0 + n;
+        const int row_b = a.W * a.cout * ES, col_b = 16 * a.cout * ES;
+        const int off0 = ((gy * a.W + gx) * a.cout + jbase) * ES;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const int dy = pt >> 1, dx = pt & 1;
+            const bool valid = gy + dy < a.H && gx + 16 * dx < a.W;
+            float v[NV];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[pt][nt][r];
+#pragma unroll
+            for (int i = 0; i < NRH; ++i) {
+                v[2 * i] += __uint_as_float(rp[pt][i] << 16);
+                v[2 * i + 1] += __uint_as_float(rp[pt][i] & 0xffff0000u);
+            }
+            const int oo = (valid && !(a.dbg_flags & 1)) ? off0 + dy * row_b + dx * col_b : kOOB;
+            buf_store_row<T, NV, false>(r_out, oo, v);
+        }
+    }
+
     __device__ static __forceinline__ void epilogue_generic(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
                                                             f32x4 (&acc)[4][NT]) {
         const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
@@ -1056,11 +1113,22 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
             }
+            constexpr bool RESPRE = FAST && !GATED && sizeof(typename Cfg::elem) == 2 && NT <= 3;   // NT 4: the 32 extra registers spill
+            [[maybe_unused]] unsigned rpre[RESPRE ? 4 : 1][RESPRE ? D::NRH : 1];
+            bool res_pre = false;
+            if constexpr (RESPRE) {
+                if (a.ep_key == D::EP_RES && a.out_mode == RC_OUT_NHWC) {   // uniform: the residual's loads go out before the MFMA loop
+                    res_pre = true;
+                    D::res_prefetch(a, cb, cy0, cx0, ct, tid, rpre);
+                }
+            }
             D::template mma_steps<0, STEPS, 0, (!GATED && NT < 5)>(s_in, s_w, lane_x, lane_w, q, lo, acc);
             if constexpr (FAST && sizeof(typename Cfg::elem) == 2) {
                 if (a.ep_key == D::EP_SUMS && n_ct == 1)    // uniform
                     D::template epilogue_fast_impl<D::EP_SUMS, true>(a, cb, cy0, cx0, csp, ct, tid, acc, run, tile < 0 || b != cb);
-                else D::template epilogue<FAST>(a, cb, cy0, cx0, csp, ct, tid, acc);
+                else if (res_pre) {
+                    if constexpr (RESPRE) D::epilogue_res_pre(a, cb, cy0, cx0, ct, tid, acc, rpre);
+                } else D::template epilogue<FAST>(a, cb, cy0, cx0, csp, ct, tid, acc);
             } else D::template epilogue<FAST>(a, cb, cy0, cx0, csp, ct, tid, acc);
         }
     }
