@@ -1078,11 +1078,15 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
     float run[NV];                                     // CALayer channel sums carried across this block's tiles
 #pragma unroll
     for (int e = 0; e < NV; ++e) run[e] = 0.f;
+    // the 3x3 kernels with 3-4 cout tiles (256-register budget) prefetch border tiles too; elsewhere the bounds-checked addressing spills
+    constexpr bool BORDER_PRE = !GATED && Cfg::KS == 3 && (NT == 3 || NT == 4) && sizeof(typename Cfg::elem) == 2;
+    bool first_tile = true;                            // the first tile's border loads are never prefetched
     while (tile >= 0) {
         __syncthreads();                               // every wave finished reading s_in / s_w (previous tile)
         // border tiles (5 % at 4K) were not prefetched: their bounds-checked addressing would otherwise sit,
         // as live masks and offsets, across the MFMA loop of every tile
-        if (a.cin_vec_ok && !ts.interior) D::template load_tile_border<GATED>(a, ts, 0, tid, r0, r1);
+        if (a.cin_vec_ok && !ts.interior && (!BORDER_PRE || first_tile || (a.dbg_flags & 16))) D::template load_tile_border<GATED>(a, ts, 0, tid, r0, r1);   // conv_flags 16: A/B
+        first_tile = false;
         if (a.cin_vec_ok) D::template commit_tile<GATED>(a, ts, to, 0, tid, r0, r1, gv, s_in);
         else D::stage_tile_scalar(a, b, y0, x0, 0, tid, s_in, static_cast<typename Cfg::elem*>(a.in_store));
         const int cb = b, csp = sp, cy0 = y0, cx0 = x0;
@@ -1104,7 +1108,8 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
                 if (a.cin_vec_ok) {
                     D::template load_gate<GATED>(a, b, 0, tid, gv);
                     if (ts.interior) D::template load_tile_interior<GATED>(a, ts, to, 0, r0, r1);
-                }
+                    else if constexpr (BORDER_PRE) { if (!(a.dbg_flags & 16)) D::template load_tile_border<GATED>(a, ts, 0, tid, r0, r1); }   // plain input: border tiles are prefetched too
+                }                                                                                        // (their offsets die with the issue; 9-18 % of the tiles at levels 1-2)
             }
             f32x4 acc[4][NT];                          // initial C operand = bias
 #pragma unroll
