@@ -14,6 +14,7 @@ struct ConvPlan {
 
 static int g_persist_on = 1;       // rc_debug_set("persist", v): 0 general kernel only, 1 automatic (default), 2 producer/consumer wherever eligible, 3 persistent only
 extern int g_dw3_seg16;            // gma.hip
+extern int g_dec_lds;              // rans.hip
 static int g_pss = 0;              // rc_debug_set("pss", v): 1: single-chunk pixel-shuffle layers (the tail 48 -> 192) take kernel 5 (output staged through LDS, stored by the
                                    // loader waves); 0 (default): kernel 4.  Measured on MI355X at 8 x 1088 x 1920: 3.16-3.29 vs 3.24-3.27 ms (conv_kernel.hpp, kernel 5)
 static int g_conv32 = 4;           // rc_debug_set("conv32", v): which layers take the 32x32x16 forms (conv32_kernel.hpp).  0 none; 4 (default) only where they
@@ -219,6 +220,7 @@ int rc_debug_set(const char* key, int value) {
     if (std::string(key) == "persist") { g_persist_on = value < 0 ? 0 : (value > 3 ? 3 : value); return RC_OK; }
     if (std::string(key) == "conv_flags") { g_dbg_flags = value; return RC_OK; }
     if (std::string(key) == "pair_impl") { g_pair_impl = value < 0 || value > 2 ? 0 : value; return RC_OK; }
+    if (std::string(key) == "dec_lds") { g_dec_lds = value != 0; return RC_OK; }
     if (std::string(key) == "dw3_seg16") { g_dw3_seg16 = value != 0; return RC_OK; }
     if (std::string(key) == "pss") { g_pss = value != 0; return RC_OK; }
     if (std::string(key) == "conv32") { g_conv32 = value < 0 ? 0 : (value > 4 ? 4 : value); return RC_OK; }

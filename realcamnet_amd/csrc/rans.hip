@@ -298,6 +298,134 @@ __global__ void decode_chunks_kernel(const uint8_t* stream, long long stream_byt
     if (!decode_range(w, st, idx, i0, i1, t, out)) atomicExch(err, st.bad ? 2 : 1);
 }
 
+// Decoding with the tables in LDS.  A lane's symbol costs one dependent chain: CDF index -> row size -> binary search over the row (8-12 probes) ->
+// (start, freq) -> state -> (every other symbol) the next 32-bit word of ITS stream.  From global memory that was 1.8 ms per 2 048-symbol call
+// (10.8 of decompress()'s 30 ms per 4K frame).  Here (a) every block first copies sizes, offsets and ALL rows, packed back to back as 16-bit entries
+// (a quantised CDF fits: only a row's last entry is 2^16, and the search never needs to read it), into LDS -- 54 KB for the 64 Gaussian rows -- so
+// the probes are LDS reads; (b) a lane always holds the NEXT word of its stream in a register, loaded when the previous one is consumed; (c) the CDF
+// indexes of the next 8 symbols are loaded ahead (they do not depend on the state) and the symbols leave 16 bytes at a time.  Tables that do not fit
+// the LDS given to the kernel fall back to probes in global memory.  Same arithmetic and error codes as decode_range.
+// Measured: 1.80 -> 1.50 ms per call, all of it from (a).  What a step of the wave waits for is the DEEPEST search among its 64 lanes (12 dependent LDS
+// probes of ~110 cycles for the 3 133-entry rows): (b) and (c) changed nothing, and a 256-bucket table per row in front of the search (tried, removed)
+// made it slower -- the buckets at the two ends of a wide row still hold up to 256 one-count entries, some lane of 64 lands in one at most steps,
+// and the table's own two reads are added to every lane's chain.
+constexpr int kDecLdsEntries = 60 * 1024;                        // 16-bit CDF entries the kernel's dynamic LDS holds (120 KB)
+__global__ __launch_bounds__(64) void decode_chunks_lds_kernel(const uint8_t* stream, long long stream_bytes, const long long* offsets, const int32_t* idx,
+                                                               long n, int chunk, Tables t, int32_t* out, int32_t* err, long n_chunks) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    int32_t* s_size = reinterpret_cast<int32_t*>(dsm);
+    int32_t* s_off = s_size + t.n_cdfs;
+    int32_t* s_start = s_off + t.n_cdfs;
+    uint16_t* s_cdf = reinterpret_cast<uint16_t*>(s_start + t.n_cdfs + 2);
+    __shared__ int s_total;
+    const int tid = threadIdx.x;
+    for (int r = tid; r < t.n_cdfs; r += 64) { s_size[r] = t.sizes[r]; s_off[r] = t.offsets[r]; }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0; bool ok = true;
+        for (int r = 0; r < t.n_cdfs; ++r) {
+            const int sz = s_size[r];
+            if (sz < 2 || sz > t.stride) ok = false;
+            s_start[r] = acc; acc += ok ? sz : 0;
+            if (acc > kDecLdsEntries) ok = false;
+        }
+        s_total = ok ? acc : -1;
+    }
+    __syncthreads();
+    const bool in_lds = s_total >= 0;
+    if (in_lds)
+        for (int r = 0; r < t.n_cdfs; ++r) {
+            const int sz = s_size[r], st0 = s_start[r];
+            const int32_t* row = t.cdf + (long)r * t.stride;
+            for (int j = tid; j < sz; j += 64) s_cdf[st0 + j] = (uint16_t)row[j];
+        }
+    __syncthreads();
+
+    const long c = (long)blockIdx.x * 64 + tid;
+    if (c >= n_chunks) return;
+    const long i0 = c * chunk, i1 = (i0 + chunk) < n ? (i0 + chunk) : n;
+    const long long b0 = offsets[c], b1 = c + 1 < n_chunks ? offsets[c + 1] : stream_bytes;
+    if (b0 < 0 || b1 > stream_bytes || b1 - b0 < 8 || ((b1 - b0) & 3) || (b0 & 3)) { atomicExch(err, 2); return; }
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(stream + b0);
+    const int n_words = (int)((b1 - b0) >> 2);
+    int pos = 2;                                                   // next word to consume
+    uint64_t x = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    uint32_t w_ahead = pos < n_words ? w[pos] : 0u;               // ... which is already on its way: loaded when the previous one was consumed
+    bool bad = false;
+    auto next_w = [&]() -> uint32_t {
+        if (pos >= n_words) { bad = true; return 0u; }
+        const uint32_t v = w_ahead;
+        ++pos;
+        w_ahead = pos < n_words ? w[pos] : 0u;
+        return v;
+    };
+    auto bits = [&]() -> uint32_t {
+        const uint32_t val = (uint32_t)(x & kMaxBypass);
+        x >>= kBypassBits;
+        if (x < kL) x = (x << 32) | next_w();
+        return val;
+    };
+    const bool vec_out = (chunk & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    int32_t pend[4];
+    constexpr int kAhead = 8;
+    for (long ib = i0; ib < i1; ib += kAhead) {
+        int32_t cis[kAhead];
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) cis[k] = ib + k < i1 ? idx[ib + k] : 0;
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) {
+            const long i = ib + k;
+            if (i >= i1) break;
+            const int32_t ci = cis[k];
+            if (ci < 0 || ci >= t.n_cdfs) { atomicExch(err, 1); return; }
+            const int32_t size = s_size[ci], max_value = size - 2;
+            const uint32_t cum = (uint32_t)(x & ((1u << kPrec) - 1));
+            uint32_t start, freq;
+            int32_t s;
+            if (in_lds) {
+                const uint16_t* row = s_cdf + s_start[ci];
+                int lo = 0, hi = size - 1;                           // the last entry (2^16) is above every cum
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((uint32_t)row[mid] <= cum) lo = mid + 1; else hi = mid;
+                }
+                s = lo - 1;
+                start = row[s];
+                freq = (s + 1 == size - 1 ? (1u << kPrec) : (uint32_t)row[s + 1]) - start;
+            } else {
+                const int32_t* row = t.cdf + (long)ci * t.stride;
+                int lo = 0, hi = size;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((uint32_t)row[mid] <= cum) lo = mid + 1; else hi = mid;
+                }
+                s = lo - 1;
+                start = (uint32_t)row[s]; freq = (uint32_t)(row[s + 1] - row[s]);
+            }
+            x = (uint64_t)freq * (x >> kPrec) + (x & ((1u << kPrec) - 1)) - start;
+            if (x < kL) x = (x << 32) | next_w();
+            int32_t value = s;
+            if (value == max_value) {
+                int32_t val = (int32_t)bits(), n_bypass = val;
+                while (val == (int32_t)kMaxBypass && !bad && n_bypass <= 8) { val = (int32_t)bits(); n_bypass += val; }
+                if (n_bypass > 8) bad = true;
+                if (bad) { atomicExch(err, 2); return; }
+                uint32_t raw = 0;
+                for (int32_t j = 0; j < n_bypass; ++j) raw |= bits() << (j * kBypassBits);
+                value = (int32_t)(raw >> 1);
+                if (raw & 1) value = -value - 1; else value += max_value;
+            }
+            if (bad) { atomicExch(err, 2); return; }
+            const int32_t sym = value + s_off[ci];
+            if (vec_out) {
+                pend[k & 3] = sym;
+                if ((k & 3) == 3) *reinterpret_cast<int4*>(out + i - 3) = make_int4(pend[0], pend[1], pend[2], pend[3]);
+                else if (i + 1 == i1) for (int e = 0; e <= (k & 3); ++e) out[i - (k & 3) + e] = pend[e];
+            } else out[i] = sym;
+        }
+    }
+}
+
 // ---- symbol preparation ------------------------------------------------------------------------------------------------------------
 // GaussianConditional: symbols = round(y - mu) (round-half-even, as torch.round), index = n_levels - 1 - #{ table[j] >= max(scale, bound),
 // j < n_levels - 1 } (CompressAI build_indexes), y_hat = symbols + mu.  Inputs NHWC (B, hw, C); int outputs in (b, c, hw) order.
@@ -365,6 +493,7 @@ static inline int grid1d(long n) {
 }  // namespace ans
 }  // namespace rc
 
+namespace rc { int g_dec_lds = 1; }     // rc_debug_set("dec_lds", v): 1 (default) rc_rans_decode_chunks keeps the CDF rows in LDS; 0: probes in global memory
 using namespace rc;
 using namespace rc::ans;
 
@@ -513,11 +642,19 @@ int rc_rans_decode_chunks(const void* d_stream, long long stream_bytes, const lo
                           const int32_t* d_cdf, int cdf_stride, int n_cdfs, const int32_t* d_cdf_sizes, const int32_t* d_cdf_offsets, int32_t* d_symbols,
                           int32_t* d_err, void* stream) {
     RC_REQUIRE(d_stream && d_offsets && d_indexes && d_cdf && d_cdf_sizes && d_cdf_offsets && d_symbols && d_err, "rc_rans_decode_chunks: null pointer");
-    RC_REQUIRE(n >= 1 && chunk >= 1 && stream_bytes >= 8, "rc_rans_decode_chunks: bad shape");
+    RC_REQUIRE(n >= 1 && chunk >= 1 && stream_bytes >= 8 && stream_bytes < (1ll << 31), "rc_rans_decode_chunks: bad shape (a container is < 2 GiB)");
     const long n_chunks = (n + chunk - 1) / chunk;
     const Tables t{d_cdf, cdf_stride, n_cdfs, d_cdf_sizes, d_cdf_offsets};
-    hipLaunchKernelGGL(decode_chunks_kernel, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), 0, as_stream(stream), static_cast<const uint8_t*>(d_stream),
-                       stream_bytes, d_offsets, d_indexes, (long)n, chunk, t, d_symbols, d_err, n_chunks);
+    const size_t lds = (size_t)(3 * n_cdfs + 2) * 4 + (size_t)kDecLdsEntries * 2;
+    if (g_dec_lds && n_cdfs >= 1 && n_cdfs <= 1024 && cdf_stride >= 2) {       // tables in LDS (falls back to global probes inside the kernel if they do not fit)
+        static PerDeviceFlag attr;
+        if (!attr.test_and_set())
+            RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_chunks_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        hipLaunchKernelGGL(decode_chunks_lds_kernel, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), lds, as_stream(stream), static_cast<const uint8_t*>(d_stream),
+                           stream_bytes, d_offsets, d_indexes, (long)n, chunk, t, d_symbols, d_err, n_chunks);
+    } else
+        hipLaunchKernelGGL(decode_chunks_kernel, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), 0, as_stream(stream), static_cast<const uint8_t*>(d_stream),
+                           stream_bytes, d_offsets, d_indexes, (long)n, chunk, t, d_symbols, d_err, n_chunks);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
