@@ -305,10 +305,11 @@ __global__ void decode_chunks_kernel(const uint8_t* stream, long long stream_byt
 // the probes are LDS reads; (b) a lane always holds the NEXT word of its stream in a register, loaded when the previous one is consumed; (c) the CDF
 // indexes of the next 8 symbols are loaded ahead (they do not depend on the state) and the symbols leave 16 bytes at a time.  Tables that do not fit
 // the LDS given to the kernel fall back to probes in global memory.  Same arithmetic and error codes as decode_range.
-// Measured: 1.80 -> 1.50 ms per call, all of it from (a).  What a step of the wave waits for is the DEEPEST search among its 64 lanes (12 dependent LDS
-// probes of ~110 cycles for the 3 133-entry rows): (b) and (c) changed nothing, and a 256-bucket table per row in front of the search (tried, removed)
-// made it slower -- the buckets at the two ends of a wide row still hold up to 256 one-count entries, some lane of 64 lands in one at most steps,
-// and the table's own two reads are added to every lane's chain.
+// Measured: 1.80 -> 1.50 ms per call, from (a).  The rest is what ONE wave per CU can issue: a 2 048-symbol chunk per lane makes 1 350 lanes = 21 waves
+// for a whole 4K latent, each alone on its SIMD, executing every branch of a divergent ~250-instruction step (search, renormalisation, escape) in turn.
+// (b) and (c) changed nothing; a 256-bucket table per row in front of the search (1.73 ms) and an 8-ary search with 8 independent probes per level
+// (1.69 ms) were both slower -- fewer dependent probes, more instructions.  More lanes means smaller chunks: 512-symbol chunks would be 4x faster
+// and cost +20 % bytes (8 B flush + 4 B size per chunk), which is why 2 048 stays.
 constexpr int kDecLdsEntries = 60 * 1024;                        // 16-bit CDF entries the kernel's dynamic LDS holds (120 KB)
 __global__ __launch_bounds__(64) void decode_chunks_lds_kernel(const uint8_t* stream, long long stream_bytes, const long long* offsets, const int32_t* idx,
                                                                long n, int chunk, Tables t, int32_t* out, int32_t* err, long n_chunks) {
