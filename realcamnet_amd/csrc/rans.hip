@@ -305,14 +305,15 @@ __global__ void decode_chunks_kernel(const uint8_t* stream, long long stream_byt
 // the probes are LDS reads; (b) a lane always holds the NEXT word of its stream in a register, loaded when the previous one is consumed; (c) the CDF
 // indexes of the next 8 symbols are loaded ahead (they do not depend on the state) and the symbols leave 16 bytes at a time.  Tables that do not fit
 // the LDS given to the kernel fall back to probes in global memory.  Same arithmetic and error codes as decode_range.
-// Measured: 1.80 -> 1.50 ms per call, from (a).  The rest is what ONE wave per CU can issue: a 2 048-symbol chunk per lane makes 1 350 lanes = 21 waves
-// for a whole 4K latent, each alone on its SIMD, executing every branch of a divergent ~250-instruction step (search, renormalisation, escape) in turn.
-// (b) and (c) changed nothing; a 256-bucket table per row in front of the search (1.73 ms) and an 8-ary search with 8 independent probes per level
-// (1.69 ms) were both slower -- fewer dependent probes, more instructions.  More lanes means smaller chunks: 512-symbol chunks would be 4x faster
-// and cost +20 % bytes (8 B flush + 4 B size per chunk), which is why 2 048 stays.
-constexpr int kDecLdsEntries = 60 * 1024;                        // 16-bit CDF entries the kernel's dynamic LDS holds (120 KB)
+// Measured: 1.80 -> 1.50 ms per call from (a), 1.42 with 3 instead of 64 chunks per wave.  What is left is ONE lane's dependent chain per symbol
+// (row size/start -> 12 probes -> start/freq -> 64-bit multiply -> word: ~14 LDS round trips of ~80 cycles): a 2 048-symbol chunk per lane makes only
+// 1 350 chains for a whole 4K latent.  (b) and (c) changed nothing; a 256-bucket table per row in front of the search (1.73 ms with 64 lanes per wave,
+// 2.5 ms with 3: its construction per block) and an 8-ary search with 8 independent probes per level (1.69 ms) were slower -- fewer dependent probes,
+// more instructions per level.  More chains means smaller chunks: 512-symbol chunks would be 4x faster and cost +20 % bytes (8 B flush + 4 B size per
+// chunk), which is why 2 048 stays.
+constexpr int kDecLdsEntries = 32 * 1024;                        // 16-bit CDF entries the kernel's dynamic LDS holds (64 KB: two blocks per CU)
 __global__ __launch_bounds__(64) void decode_chunks_lds_kernel(const uint8_t* stream, long long stream_bytes, const long long* offsets, const int32_t* idx,
-                                                               long n, int chunk, Tables t, int32_t* out, int32_t* err, long n_chunks) {
+                                                               long n, int chunk, Tables t, int32_t* out, int32_t* err, long n_chunks, int lanes) {
     extern __shared__ __attribute__((aligned(16))) char dsm[];
     int32_t* s_size = reinterpret_cast<int32_t*>(dsm);
     int32_t* s_off = s_size + t.n_cdfs;
@@ -342,8 +343,9 @@ __global__ __launch_bounds__(64) void decode_chunks_lds_kernel(const uint8_t* st
         }
     __syncthreads();
 
-    const long c = (long)blockIdx.x * 64 + tid;
-    if (c >= n_chunks) return;
+    // only `lanes` lanes of the wave decode (the others helped to fill the LDS)
+    const long c = (long)blockIdx.x * lanes + tid;
+    if (tid >= lanes || c >= n_chunks) return;
     const long i0 = c * chunk, i1 = (i0 + chunk) < n ? (i0 + chunk) : n;
     const long long b0 = offsets[c], b1 = c + 1 < n_chunks ? offsets[c + 1] : stream_bytes;
     if (b0 < 0 || b1 > stream_bytes || b1 - b0 < 8 || ((b1 - b0) & 3) || (b0 & 3)) { atomicExch(err, 2); return; }
@@ -651,8 +653,12 @@ int rc_rans_decode_chunks(const void* d_stream, long long stream_bytes, const lo
         static PerDeviceFlag attr;
         if (!attr.test_and_set())
             RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_chunks_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        hipLaunchKernelGGL(decode_chunks_lds_kernel, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), lds, as_stream(stream), static_cast<const uint8_t*>(d_stream),
-                           stream_bytes, d_offsets, d_indexes, (long)n, chunk, t, d_symbols, d_err, n_chunks);
+        // chunks per wave: as few as keeps every CU busy with two blocks -- a wave executes every branch any of its lanes takes, and the chunk count
+        // (1 350 for a 4K latent) leaves most of the chip idle either way: 1.50 -> 1.42 ms
+        long lanes = (n_chunks + 2 * device_cu_count() - 1) / (2 * device_cu_count());
+        lanes = lanes < 1 ? 1 : (lanes > 64 ? 64 : lanes);
+        hipLaunchKernelGGL(decode_chunks_lds_kernel, dim3((unsigned)((n_chunks + lanes - 1) / lanes)), dim3(64), lds, as_stream(stream), static_cast<const uint8_t*>(d_stream),
+                           stream_bytes, d_offsets, d_indexes, (long)n, chunk, t, d_symbols, d_err, n_chunks, (int)lanes);
     } else
         hipLaunchKernelGGL(decode_chunks_kernel, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), 0, as_stream(stream), static_cast<const uint8_t*>(d_stream),
                            stream_bytes, d_offsets, d_indexes, (long)n, chunk, t, d_symbols, d_err, n_chunks);
