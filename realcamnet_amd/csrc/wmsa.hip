@@ -275,9 +275,13 @@ int rc_window_attention(const void* d_qkv, const float* d_relpos, void* d_out, i
         const long long n_win = (long long)batch * (H / 8) * (W / 8);
         const int dtiles = (head_dim + 15) / 16;
         const size_t lds = (size_t)64 * kWmBiasRow * 4 + (size_t)kWmWaves * dtiles * 16 * (64 + 8) * 2;
-        // small chunks (2 windows per wave) keep the pixels that the nh head-blocks of a chunk share inside one XCD's L2; the bias-table
-        // expansion (16 entries per thread) is noise next to a window's work
-        long long per_block = 2 * kWmWaves;
+        // windows per wave: 8 where that still leaves >= 4 blocks per CU, else 4, else 2.  Every block expands its head's bias table first (4 096
+        // entries with an integer divide each): at 2 windows per wave that was ~15 % of the big head_dim-8 call (700 -> 590 us at 576 x 960 x 4);
+        // the small latent-resolution maps need the blocks more than the amortisation (30 us at 2, 37 at 4).  The nh head-blocks of a chunk stay 8
+        // apart in launch order (one XCD), so a chunk's pixels are still filled into one L2
+        long long per_wave = 8;
+        while (per_wave > 2 && ((n_win + per_wave * kWmWaves - 1) / (per_wave * kWmWaves)) * nh < 4LL * device_cu_count()) per_wave >>= 1;
+        long long per_block = per_wave * kWmWaves;
         if (per_block > n_win) per_block = n_win;
         const long long chunks = ((n_win + per_block - 1) / per_block + 7) / 8 * 8;      // whole groups of 8 (one chunk per XCD)
         RC_REQUIRE(chunks * nh < (1LL << 31), "rc_window_attention: too many windows");
