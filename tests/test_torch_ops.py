@@ -93,6 +93,8 @@ def test_fake_kernels_of_single_ops():
             assert packed.shape == (3, 64, 32, 4) and cnd.shape == (3, 4, 32, 48)
             assert torch.ops.realcam.haar_dwt(x, torch.empty(192, 1, 2, 2), True).shape == (2, 8, 12, 192)
             assert torch.ops.realcam.channel_concat([x, x[..., :16]]).shape == (2, 16, 24, 64)
+            y = torch.ops.realcam.conv2d_fold2(torch.empty(2, 37, 71, 64, dtype=torch.bfloat16), wp, None, 96, 0, 0.0)
+            assert y.shape == (2, 19, 36, 96)                    # 3x3 stride-2 convolution reading its own input: ceil(H / 2) x ceil(W / 2)
 
 
 @pytest.mark.gpu
