@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 8
+#define RC_ABI_VERSION 9
 
 typedef enum rc_status {
     RC_OK = 0,
@@ -47,8 +47,11 @@ typedef enum rc_out_mode {
     RC_OUT_NHWC = 0,           /* out[b][y][x][cout]                                             */
     RC_OUT_PIXEL_SHUFFLE2 = 1, /* nn.PixelShuffle(2) folded into the store:
                                   out[b][2y+i][2x+j][c] <- conv channel 4c+2i+j; out is NHWC (2H,2W,cout/4) */
-    RC_OUT_NCHW = 2            /* planar out[b][cout][y][x], cropped to (out_h,out_w); the network's
+    RC_OUT_NCHW = 2,           /* planar out[b][cout][y][x], cropped to (out_h,out_w); the network's
                                   final tensor (reference forward returns NCHW)                   */
+    RC_OUT_PIXEL_SHUFFLE2_NCHW = 3 /* nn.PixelShuffle(2) + planar store: out[b][c][2y+i][2x+j] <- conv channel 4c+2i+j, cropped to
+                                  (out_h,out_w) <= (2 height, 2 width); out_dtype fp32 or bf16.  The folded tail's store
+                                  (rc_tail_fold_weights)                                          */
 } rc_out_mode;
 
 /* ---- library -------------------------------------------------------------------------------- */
@@ -95,7 +98,8 @@ int rc_nhwc_to_nchw(const void* d_src, int src_dtype, void* d_dst, int dst_dtype
  */
 typedef struct rc_conv_desc {
     int32_t batch, height, width;   /* input spatial size == conv output size                     */
-    int32_t cin, cout, ksize;       /* ksize: 1 or 3 (zero padding ksize/2); 2 (bf16, cin % 16 == 0, RC_OUT_NHWC only): the 2x2 window
+    int32_t cin, cout, ksize;       /* ksize: 1 or 3 (zero padding ksize/2); 5 (bf16, cin = 48, cout <= 16: the folded tail, rc_tail_fold_weights);
+                                       2 (bf16, cin % 16 == 0, RC_OUT_NHWC only): the 2x2 window
                                        at pixel offsets {-1, 0}^2, weights (cout, cin, 2, 2) -- the non-zero taps of a stride-2 3x3
                                        convolution (compressai conv3x3(stride=2), ResidualBlockWithStride; models/tcm.py:336-345) taken
                                        over the rc_space_to_depth2 map of its input (9 of the 16 (tap, phase) weight blocks non-zero;
@@ -125,7 +129,7 @@ typedef struct rc_conv_desc {
     int32_t out_mode;               /* rc_out_mode                                                */
     int32_t out_dtype;              /* rc_dtype of `out` (RC_OUT_NCHW may emit fp32 from a bf16 net;
                                        other modes require out_dtype == dtype)                    */
-    int32_t out_h, out_w;           /* RC_OUT_NCHW crop size (<= height,width); else ignored      */
+    int32_t out_h, out_w;           /* RC_OUT_NCHW crop size (<= height,width), RC_OUT_PIXEL_SHUFFLE2_NCHW crop size (<= 2 height, 2 width); else ignored */
     /* optional per-channel partial sums of v (the value stored), for CALayer's global mean
      * (networks.py:268): fp32 (B, rc_conv_sum_tiles(), cout), reduced in fixed order by rc_ca_gate */
     float* chan_sums;
@@ -152,6 +156,26 @@ int rc_conv_sum_tiles(int height, int width);
 int rc_conv2d(const rc_conv_desc* desc, void* stream);
 /* sizeof(rc_conv_desc) as compiled into the library: lets an FFI binding verify its struct mirror. */
 size_t rc_conv_desc_size(void);
+
+/* ---- a11 folded: the tail as ONE convolution ------------------------------------------------------
+ * Replaces: self.tail = seq(conv(C, 4C, 'C'), nn.PixelShuffle(2), conv(C, 3, 'C')) (models/LiteISP.py:1996-2000, 2379-2383; applied at
+ * :2033, :2410).  There is no activation between the two convolutions, so conv2(PixelShuffle(conv1(x))) is one linear map: a 5x5 convolution
+ * C -> 4*O whose channel 4o + 2i + j is output channel o at sub-pixel (i, j) (each sub-pixel uses a 4x4 subset of the 5x5 taps; 36 % of the
+ * folded weights are structurally zero).  It does 19 200 instead of 88 128 MACs per packed pixel and the 2H x 2W x C intermediate map (6.4 GB
+ * written + 7.7 GB read per 8 frames of 4K) never exists.
+ *   rc_tail_fold_weights (host): w1 (4C,C,3,3), b1 (4C) or NULL, w2 (O,C,3,3), b2 (O) or NULL -> wc (4O,C,5,5), bc (4O); accumulated in
+ *     double.  Run the result as rc_conv2d ksize 5 (bf16, C = 48, 4O <= 16) with RC_OUT_PIXEL_SHUFFLE2_NCHW.
+ * The fold is exact everywhere except the outermost ring of output pixels (the second convolution zero-pads the shuffled map; the fold sees
+ * conv1 evaluated beyond the edge there).  The ring is recomputed with the two original convolutions on four thin strips:
+ *   rc_tail_ring_gather : x NHWC (B,H,W,C) -> rows (2B,2,W,C) = [x[:,0:2], x[:,H-2:H]], cols (2B,H,2,C) = [x[:,:,0:2], x[:,:,W-2:W]]
+ *   (caller: conv1 with RC_OUT_PIXEL_SHUFFLE2 + conv2 with RC_OUT_NCHW on both strip batches -> rows_out (2B,O,4,2W), cols_out (2B,O,2H,4))
+ *   rc_tail_ring_scatter: output row 0 / row 2H-1 from rows_out rows 0 / 3, column 0 / 2W-1 from cols_out columns 0 / 3 -> out (B,O,out_h,out_w),
+ *     skipping what the crop (out_h < 2H, out_w < 2W) removes.  dtype = element type of the strips and of out. */
+int rc_tail_fold_weights(const float* w1_host, const float* b1_host, const float* w2_host, const float* b2_host, int c, int o,
+                         float* wc_host, float* bc_host);
+int rc_tail_ring_gather(const void* d_x, void* d_rows, void* d_cols, int dtype, int batch, int H, int W, int c, void* stream);
+int rc_tail_ring_scatter(const void* d_rows_out, const void* d_cols_out, void* d_out, int dtype, int batch, int c_out, int H, int W,
+                         int out_h, int out_w, void* stream);
 
 /* ---- a5+a6 fused: two 3x3 convolutions with the intermediate kept on chip ------------------------
  * Replaces, for 48-channel bf16 feature maps (the flagship width):

@@ -343,6 +343,8 @@ class _DwtUNet(nn.Module):
         u3 = self.up3._nhwc(m, residual=d2)
         u2 = self.up2._nhwc(u3, residual=d1)
         u1 = self.up1._nhwc(u2, residual=h)
+        if ops.tail_fold_ok(u1, self.tail[0], self.tail[2]):          # no activation between the two tail convs: one folded 5x5 launch + border ring
+            return ops.tail_fold(u1, self.tail[0], self.tail[2], crop_hw=crop_hw, out_dtype=self.output_dtype)
         t = self.tail[0]._nhwc(u1, out_mode=RC_OUT_PIXEL_SHUFFLE2)
         return self.tail[2]._nhwc(t, out_mode=RC_OUT_NCHW, crop_hw=crop_hw, out_dtype=self.output_dtype)
 
@@ -510,6 +512,8 @@ class _StridedUNet(nn.Module):
         d3 = self.down3._nhwc(self.encoder3._nhwc(gfm("encoder_modulation3", d2)))
         m = self.middle._nhwc(gfm("middle_modulation", d3), residual=d3 if self.skips else None)
         u1 = dec(1, dec(2, dec(3, m, d2), d1), intro)
+        if ops.tail_fold_ok(u1, self.tail[0], self.tail[2]):          # no activation between the two tail convs: one folded 5x5 launch + border ring
+            return ops.tail_fold(u1, self.tail[0], self.tail[2], crop_hw=crop_hw, out_dtype=self.output_dtype)
         t = self.tail[0]._nhwc(u1, out_mode=RC_OUT_PIXEL_SHUFFLE2)
         return self.tail[2]._nhwc(t, out_mode=RC_OUT_NCHW, crop_hw=crop_hw, out_dtype=self.output_dtype)
 
@@ -677,6 +681,8 @@ class ISPUNet_GFM_LFM(nn.Module):
         u3 = ops.add(mod("decoder_modulation3", self.decoder3._nhwc(self.up3._nhwc(m)), l4), d2)
         u2 = ops.add(mod("decoder_modulation2", self.decoder2._nhwc(self.up2._nhwc(u3)), l2), d1)
         u1 = ops.add(mod("decoder_modulation1", self.decoder1._nhwc(self.up1._nhwc(u2)), l1), intro)
+        if ops.tail_fold_ok(u1, self.tail[0], self.tail[2]):          # no activation between the two tail convs: one folded 5x5 launch + border ring
+            return ops.tail_fold(u1, self.tail[0], self.tail[2], crop_hw=crop_hw, out_dtype=self.output_dtype)
         t = self.tail[0]._nhwc(u1, out_mode=RC_OUT_PIXEL_SHUFFLE2)
         return self.tail[2]._nhwc(t, out_mode=RC_OUT_NCHW, crop_hw=crop_hw, out_dtype=self.output_dtype)
 

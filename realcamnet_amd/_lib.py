@@ -16,8 +16,8 @@ HEADER = PKG.parent / "include" / "realcam_hip.h"
 
 RC_F32, RC_BF16, RC_U16 = 0, 1, 2
 RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY, RC_ACT_GELU, RC_ACT_RELU_POST = 0, 1, 2, 3, 4
-RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW = 0, 1, 2
-ABI_VERSION = 8
+RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW = 0, 1, 2, 3
+ABI_VERSION = 9
 
 
 class ConvDesc(C.Structure):
@@ -76,6 +76,9 @@ _SIGS = {
     "rc_conv_sum_tiles": (C.c_int, [_I, _I]),
     "rc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "rc_conv_desc_size": (_SZ, []),
+    "rc_tail_fold_weights": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P]),
+    "rc_tail_ring_gather": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "rc_tail_ring_scatter": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "rc_debug_stream_create_masked": (C.c_int, [_I, C.POINTER(C.c_void_p)]),
     "rc_debug_hbm_probe": (C.c_int, [_P, _P, C.c_size_t, _I, _I, _I, _I, _I, C.POINTER(C.c_double)]),
     "rc_debug_mfma_peak": (C.c_int, [_I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -23,8 +23,11 @@ static int g_conv32 = 4;           // rc_debug_set("conv32", v): which layers ta
 
 // Must mirror ConvCfg<> (static_asserts in check_plan_consistency below keep them in lock-step).
 static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, ConvPlan* p) {
-    if (cin < 1 || cout < 1 || (ksize != 1 && ksize != 3 && ksize != 2)) return false;
+    if (cin < 1 || cout < 1 || (ksize != 1 && ksize != 3 && ksize != 2 && ksize != 5)) return false;
     if (dtype != RC_F32 && dtype != RC_BF16) return false;
+    // ksize 5: the folded tail (rc_tail_fold_weights): bf16, 48 input channels, one 16-wide cout tile
+    if (ksize == 5 && (dtype != RC_BF16 || cin != 48 || cout > 16 || out_mode == RC_OUT_PIXEL_SHUFFLE2)) return false;
+    if (out_mode == RC_OUT_PIXEL_SHUFFLE2_NCHW && cout % 4 != 0) return false;
     // ksize 2: the 2x2 window at pixel offsets {-1, 0}^2 = the non-zero taps of a stride-2 3x3 convolution over its space-to-depth map
     // (bf16, Cin a multiple of 16 that is not routed to the 8- / 48- / 80-wide chunk forms; plain NHWC store)
     if (ksize == 2 && (dtype != RC_BF16 || cin % 16 != 0 || out_mode != RC_OUT_NHWC || (cin % 48 == 0 && cin % 64 != 0))) return false;
@@ -59,7 +62,7 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
     // 32x32x16 form: 3x3 bf16 layers whose weights are streamed (several 32-channel chunks, or the one-chunk 48 -> 192 layers) and whose
     // couts fill whole 32-row tiles.  The packed order differs, so the choice depends on the shape (and the debug knobs) only.
     p->m32 = 0;
-    if (dtype == RC_BF16 && ksize == 3 && g_conv32 != 0 && g_persist_on != 0 && cout <= kPersistMaxCout && out_mode != RC_OUT_NCHW) {
+    if (dtype == RC_BF16 && ksize == 3 && g_conv32 != 0 && g_persist_on != 0 && cout <= kPersistMaxCout && out_mode != RC_OUT_NCHW && out_mode != RC_OUT_PIXEL_SHUFFLE2_NCHW) {
         const int cw = out_mode == RC_OUT_PIXEL_SHUFFLE2 ? cout / 4 : cout;          // channels a lane's 16-value run must tile
         const bool all = g_conv32 != 4;
         if (all && p->ck == 32 && cin % 32 == 0 && (out_mode == RC_OUT_PIXEL_SHUFFLE2 ? cw % 32 == 0 : cw % 64 == 0)) { p->m32 = 1; p->nt = 2; p->ck = (g_conv32 == 1 && out_mode == RC_OUT_NHWC) ? 16 : 32; }
@@ -213,6 +216,36 @@ int rc_conv_pack_bias(const float* bias, int cin, int cout, int ksize, int dtype
 
 size_t rc_conv_desc_size(void) { return sizeof(rc_conv_desc); }
 
+int rc_tail_fold_weights(const float* w1, const float* b1, const float* w2, const float* b2, int c, int o, float* wc, float* bc) {
+    RC_REQUIRE(w1 && w2 && wc && bc && c >= 1 && o >= 1, "rc_tail_fold_weights: bad arguments");
+    // out[o][2y+i][2x+j] = b2[o] + sum_{cc,dy,dx} w2[o][cc][dy][dx] * T[cc][2y+i+dy-1][2x+j+dx-1],  T[cc][2y'+i'][2x'+j'] = t[4cc+2i'+j'][y'][x'],
+    // t = conv3x3(x; w1, b1): substitute, collect the taps of x around (y, x).  With a = i + dy - 1: y' = y + floor(a / 2), i' = a mod 2.
+    std::vector<double> acc((size_t)4 * o * c * 25, 0.0), bacc((size_t)4 * o, 0.0);
+    for (int oo = 0; oo < o; ++oo)
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) {
+                const int row = oo * 4 + 2 * i + j;
+                bacc[row] = b2 ? (double)b2[oo] : 0.0;
+                for (int dy = 0; dy < 3; ++dy)
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int a = i + dy - 1, b = j + dx - 1;
+                        const int fy = a < 0 ? -1 : a >> 1, ii = a & 1, fx = b < 0 ? -1 : b >> 1, jj = b & 1;
+                        for (int cc = 0; cc < c; ++cc) {
+                            const int m = 4 * cc + 2 * ii + jj;
+                            const double v2 = w2[(((size_t)oo * c + cc) * 3 + dy) * 3 + dx];
+                            if (b1) bacc[row] += v2 * (double)b1[m];
+                            for (int k = 0; k < c; ++k)
+                                for (int ey = 0; ey < 3; ++ey)
+                                    for (int ex = 0; ex < 3; ++ex)
+                                        acc[(((size_t)row * c + k) * 5 + (fy + ey + 1)) * 5 + (fx + ex + 1)] += v2 * (double)w1[(((size_t)m * c + k) * 3 + ey) * 3 + ex];
+                        }
+                    }
+            }
+    for (size_t n = 0; n < acc.size(); ++n) wc[n] = (float)acc[n];
+    for (size_t n = 0; n < bacc.size(); ++n) bc[n] = (float)bacc[n];
+    return RC_OK;
+}
+
 int rc_conv_sum_tiles(int height, int width) { return 4 * ceil_div(height, kTH) * ceil_div(width, kTW); }  // one slot per wave
 
 int rc_debug_set(const char* key, int value) {
@@ -263,7 +296,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     RC_REQUIRE(d->batch >= 1 && d->height >= 1 && d->width >= 1, "rc_conv2d: empty tensor");
     RC_REQUIRE(d->batch <= 65535, "rc_conv2d: batch > 65535");
     RC_REQUIRE(d->in0 && d->wpacked && d->out, "rc_conv2d: null in0/wpacked/out");
-    RC_REQUIRE(d->out_mode >= RC_OUT_NHWC && d->out_mode <= RC_OUT_NCHW, "rc_conv2d: bad out_mode");
+    RC_REQUIRE(d->out_mode >= RC_OUT_NHWC && d->out_mode <= RC_OUT_PIXEL_SHUFFLE2_NCHW, "rc_conv2d: bad out_mode");
     RC_REQUIRE(d->act >= RC_ACT_NONE && d->act <= RC_ACT_RELU_POST, "rc_conv2d: bad act");
     RC_REQUIRE(d->act != RC_ACT_RELU_POST || (d->residual != nullptr && d->mul_plus1 == nullptr && d->film_scale == nullptr && d->chan_sums == nullptr),
                "rc_conv2d: RC_ACT_RELU_POST is relu(conv + residual): needs residual, excludes film / mul_plus1 / chan_sums");
@@ -284,6 +317,11 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
         RC_REQUIRE(full_tiles && ((d->cout / 4) * es) % 8 == 0, "rc_conv2d: pixel-shuffle store needs (cout/4)*elem_size % 8 == 0");
         RC_REQUIRE(!d->film_scale, "rc_conv2d: film not supported with pixel-shuffle store");
         RC_REQUIRE(reinterpret_cast<uintptr_t>(d->out) % 16 == 0, "rc_conv2d: out must be 16-byte aligned");
+    } else if (d->out_mode == RC_OUT_PIXEL_SHUFFLE2_NCHW) {
+        RC_REQUIRE(d->out_h >= 1 && d->out_h <= 2 * d->height && d->out_w >= 1 && d->out_w <= 2 * d->width, "rc_conv2d: bad pixel-shuffle NCHW crop");
+        RC_REQUIRE(d->out_dtype == RC_F32 || d->out_dtype == RC_BF16, "rc_conv2d: bad out_dtype");
+        RC_REQUIRE(!d->chan_sums, "rc_conv2d: chan_sums needs RC_OUT_NHWC");
+        RC_REQUIRE((double)d->out_h * d->out_w * (d->cout / 4) * 4.0 < 2147483647.0, "rc_conv2d: one output image must be < 2 GiB");
     } else {
         RC_REQUIRE(d->out_h >= 1 && d->out_h <= d->height && d->out_w >= 1 && d->out_w <= d->width, "rc_conv2d: bad NCHW crop");
         RC_REQUIRE(d->out_dtype == RC_F32 || d->out_dtype == RC_BF16, "rc_conv2d: bad out_dtype");
@@ -325,7 +363,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     {   // epilogue feature mask (ConvDev::EP_*); anything outside the compiled set takes the generic epilogue
         int key = (d->act == RC_ACT_RELU ? 1 : 0) | (d->act == RC_ACT_LEAKY ? 2 : 0) | (d->film_scale ? 4 : 0) |
                   (d->mul_plus1 ? 8 : 0) | (d->residual ? 16 : 0) | (d->chan_sums ? 32 : 0);
-        bool fast = full_tiles && d->out_mode != RC_OUT_NCHW && d->act != RC_ACT_GELU && d->act != RC_ACT_RELU_POST;
+        bool fast = full_tiles && d->out_mode != RC_OUT_NCHW && d->out_mode != RC_OUT_PIXEL_SHUFFLE2_NCHW && d->act != RC_ACT_GELU && d->act != RC_ACT_RELU_POST;
         if (d->act == RC_ACT_LEAKY) fast = fast && d->act_slope >= 0.f && d->act_slope <= 1.f;
         if (d->film_scale)
             fast = fast && d->cout % 4 == 0 && reinterpret_cast<uintptr_t>(d->film_scale) % 16 == 0 && reinterpret_cast<uintptr_t>(d->film_shift) % 16 == 0;

@@ -248,13 +248,13 @@ struct ConvDev {
     struct LaneOff {
         int a;   // q*16                                   : steps whose 4 units are consecutive in one tap
         int b;   // (q>>1)*SPIX          + (4+(q&1))*16    : paired step, second tap = next column
-        int c;   // (q>>1)*(TWH-2)*SPIX  + (4+(q&1))*16    : paired step, second tap = first column of next row
+        int c;   // (q>>1)*(TWH-(KS-1))*SPIX + (4+(q&1))*16 : paired step, second tap = first column of next row
         int tab[TABLE ? STEPS : 1];
     };
     __device__ static __forceinline__ void lane_offsets(int q, LaneOff& lo) {
         lo.a = q * 16;
         lo.b = (q >> 1) * SPIX + (4 + (q & 1)) * 16;
-        lo.c = (q >> 1) * (TWH - 2) * SPIX + (4 + (q & 1)) * 16;
+        lo.c = (q >> 1) * (TWH - (KS - 1)) * SPIX + (4 + (q & 1)) * 16;
         if constexpr (TABLE) {
 #pragma unroll
             for (int s = 0; s < STEPS; ++s) {
@@ -844,10 +844,11 @@ struct ConvDev {
         const size_t img_out = (size_t)a.H * a.W * a.cout;    // NHWC output / residual / mul image (elements)
         const unsigned img_bytes_out = (unsigned)(img_out * ES);
         __amdgpu_buffer_rsrc_t r_out;
-        if (a.out_mode == RC_OUT_NCHW) {
+        if (a.out_mode == RC_OUT_NCHW || a.out_mode == RC_OUT_PIXEL_SHUFFLE2_NCHW) {
             const size_t plane = (size_t)a.out_h * a.out_w;
             const int osz = a.out_dtype == RC_F32 ? 4 : 2;
-            r_out = make_rsrc(static_cast<char*>(a.out) + (size_t)b * a.cout * plane * osz, (unsigned)(a.cout * plane * osz));
+            const int planes = a.out_mode == RC_OUT_NCHW ? a.cout : a.cout >> 2;
+            r_out = make_rsrc(static_cast<char*>(a.out) + (size_t)b * planes * plane * osz, (unsigned)(planes * plane * osz));
         } else {  // NHWC (H,W,cout) or pixel-shuffled (2H,2W,cout/4): same bytes per image
             r_out = make_rsrc(static_cast<T*>(a.out) + (size_t)b * img_out, img_bytes_out);
         }
@@ -916,6 +917,34 @@ struct ConvDev {
                 const int cps = a.cout >> 2, sub = ct & 3;
                 const int o = valid ? (((2 * gy + (sub >> 1)) * (2 * a.W) + (2 * gx + (sub & 1))) * cps + (ct >> 2) * Cfg::COUT_TILE + q * NV) * ES : kOOB;
                 buf_store_row<T, NV, false>(r_out, o, v);
+            } else if (a.out_mode == RC_OUT_PIXEL_SHUFFLE2_NCHW) {
+                // nn.PixelShuffle(2) + planar store: conv channel 4c + 2i + j -> out[b][c][2 gy + i][2 gx + j], cropped to (out_h, out_w).
+                // A lane's 4 values of cout tile nt are the 2x2 sub-pixels of ONE out channel: two 2-element row pieces.
+                const bool pair_ok = (a.out_w & 1) == 0;                       // uniform: keeps the 2-element stores naturally aligned
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int co = jbase + 4 * nt, c = co >> 2;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int Y = 2 * gy + i, X = 2 * gx;
+                        const bool in0 = valid && co < a.cout && Y < a.out_h && X < a.out_w, in1 = in0 && X + 1 < a.out_w;
+                        const int idx = (c * a.out_h + Y) * a.out_w + X;
+                        const float v0 = v[4 * nt + 2 * i], v1 = v[4 * nt + 2 * i + 1];
+                        if (a.out_dtype == RC_F32) {
+                            if (pair_ok) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{__float_as_uint(v0), __float_as_uint(v1)}, r_out, in1 ? idx * 4 : kOOB, 0, 0);
+                            else {
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), r_out, in0 ? idx * 4 : kOOB, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), r_out, in1 ? idx * 4 + 4 : kOOB, 0, 0);
+                            }
+                        } else {
+                            if (pair_ok) __builtin_amdgcn_raw_buffer_store_b32(pack_bf16x2(v0, v1), r_out, in1 ? idx * 2 : kOOB, 0, 0);
+                            else {
+                                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)Vec16<bf16_t>::rne(v0), r_out, in0 ? idx * 2 : kOOB, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)Vec16<bf16_t>::rne(v1), r_out, in1 ? idx * 2 + 2 : kOOB, 0, 0);
+                            }
+                        }
+                    }
+                }
             } else {  // RC_OUT_NCHW, cropped
                 const bool inside = gy < a.out_h && gx < a.out_w;
 #pragma unroll
@@ -1019,8 +1048,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvArgs a
 // Two such blocks share a CU and drift out of phase (one in MFMA while the other stores / stages).
 // ==================================================================================================
 constexpr int kPersistMaxCout = 512;   // bias slots kept in LDS
+// the 5x5 form (the folded tail, <= 16 couts): 64 slots, so that halo tile (12 x 36) + 38 KiB of weights still fit twice per CU
 template <class Cfg>
-constexpr int persist_lds_bytes_c() { return Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + kPersistMaxCout * 4; }
+constexpr int persist_bias_slots() { return Cfg::KS == 5 ? 64 : kPersistMaxCout; }
+template <class Cfg>
+constexpr int persist_lds_bytes_c() { return Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + persist_bias_slots<Cfg>() * 4; }
 
 // blocks per CU: layers with one 16-wide cout tile (the 48 -> 3 output conv) do almost no math per byte, so what
 // matters is bytes in flight: three blocks (their accumulators are small enough for 168 VGPRs)
@@ -1035,7 +1067,7 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_w = smem;                                  // weights first: their ds_read immediates stay below 64 KiB
     float* s_bias = reinterpret_cast<float*>(smem + Cfg::CHUNK_W_BYTES);
-    char* s_in = smem + Cfg::CHUNK_W_BYTES + kPersistMaxCout * 4;
+    char* s_in = smem + Cfg::CHUNK_W_BYTES + persist_bias_slots<Cfg>() * 4;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, n = lane & 15;
@@ -1680,7 +1712,7 @@ constexpr int ws_lds_bytes() { return 2 * Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTE
 
 // ---- host side: per-instantiation launcher ----------------------------------------------------------
 template <class Cfg>
-constexpr int persist_lds_bytes() { return Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + kPersistMaxCout * 4; }
+constexpr int persist_lds_bytes() { return persist_lds_bytes_c<Cfg>(); }
 
 template <class Cfg, bool GATED, bool FAST>
 int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
@@ -1746,7 +1778,7 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
         }
     }
     if constexpr (P_OK) {
-        if (a.n_chunks == 1 && a.cout_packed <= kPersistMaxCout && a.persist_ok && n_tiles < (1 << 24)) {
+        if (a.n_chunks == 1 && a.cout_packed <= persist_bias_slots<Cfg>() && a.persist_ok && n_tiles < (1 << 24)) {
             static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
             if (!attr_set.test_and_set()) {
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_persist_kernel<Cfg, GATED, FAST>),

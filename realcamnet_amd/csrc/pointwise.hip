@@ -488,6 +488,57 @@ __global__ void dwt_inverse_kernel(const T* __restrict__ x, T* __restrict__ y, c
     }
 }
 
+// ---- folded tail, border ring (rc_tail_ring_gather / rc_tail_ring_scatter) -----------------------------------------
+// The tail conv 3x3 C -> 4C, PixelShuffle(2), conv 3x3 C -> 3 (models/LiteISP.py:1996-2000) has no activation in between and runs as ONE 5x5
+// convolution (rc_tail_fold_weights).  The two differ on the outermost ring of output pixels only: the second conv zero-pads the SHUFFLED map,
+// the composition sees conv1 evaluated outside the image there.  The ring is recomputed by the two original convolutions on four thin strips of
+// the input (2 rows / 2 columns: output row 0 of the top strip, row 3 of the bottom strip, column 0 / 3 of the side strips are exact).
+//   gather : x (B,H,W,C) -> rows (2B,2,W,C) = [x[:, 0:2], x[:, H-2:H]],  cols (2B,H,2,C) = [x[:, :, 0:2], x[:, :, W-2:W]]
+//   scatter: strip results rows_out (2B,Co,4,2W), cols_out (2B,Co,2H,4) -> ring of out (B,Co,out_h,out_w) (the parts of it inside the crop)
+__global__ void tail_ring_gather_kernel(const uint4* __restrict__ x, uint4* __restrict__ rows, uint4* __restrict__ cols,
+                                        int batch, int H, int W, int pix16) {
+    const size_t row16 = (size_t)W * pix16, n_rows = (size_t)2 * batch * 2 * row16, n_cols = (size_t)2 * batch * H * 2 * pix16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows + n_cols; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < n_rows) {
+            const size_t off = i % row16; size_t p = i / row16;
+            const int r = (int)(p % 2); const int img = (int)(p / 2);
+            const int b = img % batch, y = img < batch ? r : H - 2 + r;
+            rows[i] = x[((size_t)b * H + y) * row16 + off];
+        } else {
+            size_t p = i - n_rows;
+            const int part = (int)(p % pix16); p /= pix16;
+            const int cx = (int)(p % 2); p /= 2;
+            const int y = (int)(p % H); const int img = (int)(p / H);
+            const int b = img % batch, xx = img < batch ? cx : W - 2 + cx;
+            cols[i - n_rows] = x[(((size_t)b * H + y) * W + xx) * pix16 + part];
+        }
+    }
+}
+template <typename T>
+__global__ void tail_ring_scatter_kernel(const T* __restrict__ rows_out, const T* __restrict__ cols_out, T* __restrict__ out,
+                                         int batch, int co, int H, int W, int out_h, int out_w) {
+    const int per = 2 * out_w + 2 * out_h;
+    const size_t total = (size_t)batch * co * per;
+    const bool bottom = out_h == 2 * H, right = out_w == 2 * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        int k = (int)(i % per); const size_t pc = i / per;
+        const int c = (int)(pc % co), b = (int)(pc / co);
+        T* o = out + ((size_t)b * co + c) * out_h * out_w;
+        if (k < 2 * out_w) {
+            const int bot = k >= out_w, X = bot ? k - out_w : k;
+            if (bot && !bottom) continue;
+            const T* src = rows_out + (((size_t)(bot ? batch + b : b) * co + c) * 4 + (bot ? 3 : 0)) * (2 * W);
+            o[(size_t)(bot ? out_h - 1 : 0) * out_w + X] = src[X];
+        } else {
+            k -= 2 * out_w;
+            const int rgt = k >= out_h, Y = rgt ? k - out_h : k;
+            if (rgt && !right) continue;
+            const T* src = cols_out + ((size_t)(rgt ? batch + b : b) * co + c) * (2 * H) * 4;
+            o[(size_t)Y * out_w + (rgt ? out_w - 1 : 0)] = src[(size_t)Y * 4 + (rgt ? 3 : 0)];
+        }
+    }
+}
+
 }  // namespace rc
 
 using namespace rc;
@@ -842,6 +893,36 @@ int rc_dwt_inverse(const void* d_x, void* d_y, const float* d_taps, int taps_uni
         else hipLaunchKernelGGL((dwt_inverse_kernel<bf16_t, false>), dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
                            static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_y), d_taps, batch, h, w, c4);
     }
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_tail_ring_gather(const void* d_x, void* d_rows, void* d_cols, int dtype, int batch, int H, int W, int c, void* stream) {
+    RC_REQUIRE(d_x && d_rows && d_cols, "rc_tail_ring_gather: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_tail_ring_gather: bad dtype");
+    RC_REQUIRE(batch >= 1 && H >= 2 && W >= 2 && c >= 1 && (c * dtype_size(dtype)) % 16 == 0, "rc_tail_ring_gather: H, W >= 2 and a pixel record of whole 16-byte vectors");
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_x) % 16 == 0 && reinterpret_cast<uintptr_t>(d_rows) % 16 == 0 && reinterpret_cast<uintptr_t>(d_cols) % 16 == 0,
+               "rc_tail_ring_gather: 16-byte alignment");
+    const int pix16 = (int)(c * dtype_size(dtype) / 16);
+    const size_t total = (size_t)4 * batch * pix16 * ((size_t)W + H);
+    hipLaunchKernelGGL(tail_ring_gather_kernel, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream), static_cast<const uint4*>(d_x),
+                       static_cast<uint4*>(d_rows), static_cast<uint4*>(d_cols), batch, H, W, pix16);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_tail_ring_scatter(const void* d_rows_out, const void* d_cols_out, void* d_out, int dtype, int batch, int c_out, int H, int W,
+                         int out_h, int out_w, void* stream) {
+    RC_REQUIRE(d_rows_out && d_cols_out && d_out, "rc_tail_ring_scatter: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_tail_ring_scatter: bad dtype");
+    RC_REQUIRE(batch >= 1 && c_out >= 1 && H >= 2 && W >= 2 && out_h >= 1 && out_h <= 2 * H && out_w >= 1 && out_w <= 2 * W, "rc_tail_ring_scatter: bad shape");
+    const size_t total = (size_t)batch * c_out * (2 * (size_t)out_w + 2 * (size_t)out_h);
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(tail_ring_scatter_kernel<float>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream), static_cast<const float*>(d_rows_out),
+                           static_cast<const float*>(d_cols_out), static_cast<float*>(d_out), batch, c_out, H, W, out_h, out_w);
+    else
+        hipLaunchKernelGGL(tail_ring_scatter_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream), static_cast<const bf16_t*>(d_rows_out),
+                           static_cast<const bf16_t*>(d_cols_out), static_cast<bf16_t*>(d_out), batch, c_out, H, W, out_h, out_w);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

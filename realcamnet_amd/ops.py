@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from . import torch_ops as _T  # noqa: F401  (registers torch.ops.realcam.*)
 from ._lib import (RC_ACT_GELU, RC_ACT_LEAKY, RC_ACT_NONE, RC_ACT_RELU, RC_ACT_RELU_POST, RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC,
-                   RC_OUT_PIXEL_SHUFFLE2, ConvDesc, ConvPairDesc, check)
+                   RC_OUT_PIXEL_SHUFFLE2, RC_OUT_PIXEL_SHUFFLE2_NCHW, ConvDesc, ConvPairDesc, check)
 
 _DT = {torch.float32: RC_F32, torch.bfloat16: RC_BF16}
 _R = torch.ops.realcam          # every launch below goes through the dispatcher op registered in torch_ops.py
@@ -120,7 +120,7 @@ def packed_conv(mod, act_dtype: torch.dtype, out_mode: int) -> PackedConv:
         kh = kw = 1
     else:
         cout, cin, kh, kw = w.shape
-    if kh != kw or kh not in (1, 2, 3):                    # 2: the {-1, 0}^2 window of a stride-2 3x3 conv over its space-to-depth map
+    if kh != kw or kh not in (1, 2, 3, 5):                 # 2: the {-1, 0}^2 window of a stride-2 3x3 conv over its space-to-depth map; 5: the folded tail
         raise NotImplementedError(f"HIP conv supports 1x1 and 3x3 kernels, got {kh}x{kw}")
     wp, bp = _R.conv_pack_weights(w.detach(), b.detach() if b is not None else None, act_dtype, out_mode)
     pc = PackedConv()
@@ -505,14 +505,54 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
     for name, t in (("mul_plus1", mul_plus1), ("residual", residual)):
         if t is not None and (t.shape != (b, H, W, pc.cout) or t.dtype != x.dtype):
             raise ValueError(f"{name} must be NHWC {(b, H, W, pc.cout)} {x.dtype}, got {tuple(t.shape)} {t.dtype}")
-    ch, cw = (crop_hw if crop_hw is not None else (0, 0)) if out_mode == RC_OUT_NCHW else (0, 0)
+    planar = out_mode in (RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW)
+    ch, cw = (crop_hw if crop_hw is not None else (0, 0)) if planar else (0, 0)
     if out_dtype is not None:
         _DT[out_dtype]
     out, stored, sums = _R.conv2d(x, pc.wpacked, pc.bias, pc.cout, pc.ksize, _ACT[act], float(slope), residual, mul_plus1, fs, ft, gate, skip,
                                   bool(store_input), int(out_mode), bool(want_sums), int(ch), int(cw),
-                                  out_dtype if out_mode == RC_OUT_NCHW else None)
+                                  out_dtype if planar else None)
     extras = [t for t in (_opt(stored), _opt(sums)) if t is not None]
     return (out, *extras) if extras else out
+
+
+# The tail conv(C -> 4C) -> PixelShuffle(2) -> conv(C -> 3) (upstream models/LiteISP.py:1996-2000) has no activation in between: it is ONE linear map,
+# a 5x5 convolution C -> 12 whose channel 4o + 2i + j is colour o at sub-pixel (i, j) (rc_tail_fold_weights, composed once per checkpoint like weight
+# packing).  4.6x fewer MACs and the 2H x 2W x C intermediate map never exists (4K x 8: 6.4 GB written + 7.7 GB read, 5.4 -> 0.9 ms).  The fold differs
+# from the two convolutions on the outermost ring of output pixels only (zero padding of the SHUFFLED map); that ring is recomputed by the two original
+# convolutions on four thin strips.  False: the two launches of the reference's module list.
+FOLD_TAIL = True
+
+
+def tail_fold_ok(x: torch.Tensor, conv1, conv2) -> bool:
+    w1, w2 = conv1.weight, conv2.weight
+    return (FOLD_TAIL and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] == 48 and x.shape[1] >= 2 and x.shape[2] >= 2 and
+            w1.dim() == 4 and tuple(w1.shape) == (192, 48, 3, 3) and w2.dim() == 4 and w2.shape[1:] == (48, 3, 3) and 4 * w2.shape[0] <= 16)
+
+
+def _folded_tail(conv1, conv2) -> "_ConvView":
+    cache = _cache(conv2)
+    key = (_key(conv1.weight, conv1.bias), _key(conv2.weight, conv2.bias))
+    hit = cache.get("tail_fold")
+    if hit is None or hit[0] != key:
+        det = lambda t: None if t is None else t.detach()
+        wc, bc = _R.tail_fold_weights(conv1.weight.detach(), det(conv1.bias), conv2.weight.detach(), det(conv2.bias))
+        hit = cache["tail_fold"] = (key, _ConvView(wc, bc))
+    return hit[1]
+
+
+def tail_fold(x: torch.Tensor, conv1, conv2, crop_hw: Optional[Tuple[int, int]] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """conv2(PixelShuffle2(conv1(x))) of NHWC `x` (B,H,W,48) -> NCHW (B,O,2H,2W) cropped to crop_hw: one folded 5x5 launch + the exact border ring."""
+    x = _req(x, "tail input")
+    b, H, W, _ = x.shape
+    odt = out_dtype or x.dtype
+
+    def ring():      # six small launches, independent of the folded one until the scatter: they run beside it on the side stream
+        return [conv2d(conv2d(t, conv1, out_mode=RC_OUT_PIXEL_SHUFFLE2), conv2, out_mode=RC_OUT_NCHW, out_dtype=odt) for t in _R.tail_ring_gather(x)]
+
+    strips, out = fork_join(ring, lambda: conv2d(x, _folded_tail(conv1, conv2), out_mode=RC_OUT_PIXEL_SHUFFLE2_NCHW, crop_hw=crop_hw, out_dtype=odt), [x])
+    _R.tail_ring_scatter(out, strips[0], strips[1], H, W)
+    return out
 
 
 # conv -> act -> conv pairs (RCABlock.res, Res_GFM) as ONE launch with the intermediate in LDS (rc_conv_pair).

@@ -21,7 +21,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, ConvDesc, ConvPairDesc, check
+from ._lib import RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_PIXEL_SHUFFLE2_NCHW, ConvDesc, ConvPairDesc, check
 
 _DT = {torch.float32: RC_F32, torch.bfloat16: RC_BF16}
 _LIB = torch.library.Library("realcam", "DEF")
@@ -159,6 +159,8 @@ def _conv_alloc(x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, 
         out = x.new_empty((b, H, W, cout))
     elif out_mode == RC_OUT_PIXEL_SHUFFLE2:
         out = x.new_empty((b, 2 * H, 2 * W, cout // 4))
+    elif out_mode == RC_OUT_PIXEL_SHUFFLE2_NCHW:
+        out = x.new_empty((b, cout // 4, crop_h if crop_h > 0 else 2 * H, crop_w if crop_w > 0 else 2 * W), dtype=out_dtype or x.dtype)
     else:
         out = x.new_empty((b, cout, crop_h if crop_h > 0 else H, crop_w if crop_w > 0 else W), dtype=out_dtype or x.dtype)
     stored = torch.empty_like(x) if (store_input and gate is not None) else _none(x)
@@ -183,7 +185,7 @@ def _conv_launch(outs, x, wpacked, bias, cout, ksize, act, slope, residual, mul_
     d.mul_plus1, d.residual = _p(mul_plus1), _p(residual)
     d.out, d.out_mode = out.data_ptr(), out_mode
     d.out_dtype = _dt(out)
-    if out_mode == RC_OUT_NCHW:
+    if out_mode in (RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW):
         d.out_h, d.out_w = out.shape[2], out.shape[3]
     if want_sums:
         d.chan_sums = sums.data_ptr()
@@ -209,6 +211,35 @@ def _conv_fold2_launch(out, x, wpacked, bias, cout, act, slope):
 # 3x3 stride-2 convolution straight from its input (rc_conv_desc.src_h / src_w): the 2x2-window kernel gathers the space-to-depth channels itself
 define("conv2d_fold2(Tensor x, Tensor wpacked, Tensor? bias, int cout, int act, float slope) -> Tensor",
        lambda x, wpacked, bias, cout, act, slope: x.new_empty((x.shape[0], (x.shape[1] + 1) // 2, (x.shape[2] + 1) // 2, cout)), _conv_fold2_launch)
+
+
+
+# ---- a11 folded: the tail as one 5x5 convolution + its border ring (rc_tail_fold_weights / rc_tail_ring_*) -----------------------------
+def _tail_fold_launch(outs, w1, b1, w2, b2):
+    wc, bc = outs
+    c, o = w1.shape[1], w2.shape[0]
+    h = [None if t is None else np.ascontiguousarray(t.detach().float().cpu().numpy()) for t in (w1, b1, w2, b2)]
+    wch, bch = np.empty(tuple(wc.shape), dtype=np.float32), np.empty(tuple(bc.shape), dtype=np.float32)
+    check(lib().rc_tail_fold_weights(h[0].ctypes.data, None if h[1] is None else h[1].ctypes.data, h[2].ctypes.data,
+                                     None if h[3] is None else h[3].ctypes.data, c, o, wch.ctypes.data, bch.ctypes.data), "rc_tail_fold_weights")
+    wc.copy_(torch.from_numpy(wch)); bc.copy_(torch.from_numpy(bch))
+
+
+# one-time host-side composition (like weight packing): conv2(PixelShuffle(conv1(x))) = conv5x5(x; wc, bc), fp32 results of a double accumulation
+define("tail_fold_weights(Tensor w1, Tensor? b1, Tensor w2, Tensor? b2) -> (Tensor, Tensor)",
+       lambda w1, b1, w2, b2: (w1.new_empty((4 * w2.shape[0], w1.shape[1], 5, 5), dtype=torch.float32), w1.new_empty((4 * w2.shape[0],), dtype=torch.float32)),
+       _tail_fold_launch)
+
+define("tail_ring_gather(Tensor x) -> (Tensor, Tensor)",
+       lambda x: (x.new_empty((2 * x.shape[0], 2, x.shape[2], x.shape[3])), x.new_empty((2 * x.shape[0], x.shape[1], 2, x.shape[3]))),
+       lambda outs, x: check(lib().rc_tail_ring_gather(x.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), _dt(x), x.shape[0], x.shape[1], x.shape[2],
+                                                       x.shape[3], _stream()), "rc_tail_ring_gather"))
+
+define("tail_ring_scatter(Tensor(a!) out, Tensor rows_out, Tensor cols_out, int H, int W) -> Tensor",
+       lambda out, rows_out, cols_out, H, W: out.new_empty((0,)),
+       lambda ret, out, rows_out, cols_out, H, W: check(lib().rc_tail_ring_scatter(rows_out.data_ptr(), cols_out.data_ptr(), out.data_ptr(), _dt(out),
+                                                                                   out.shape[0], out.shape[1], H, W, out.shape[2], out.shape[3],
+                                                                                   _stream()), "rc_tail_ring_scatter"))
 
 
 def _pair_alloc(x, w1, b1, w2, b2, act, slope, film_scale, film_shift, gate, skip, store_input, residual, want_sums):
