@@ -118,6 +118,7 @@ typedef struct rc_conv_desc {
      *   film_scale!=NULL: v = v*scale[b][c] + shift[b][c] + v        (Res_GFM, LiteISP.py:556)
      *   act                                                          (none / relu / leaky)
      *   mul_plus1!=NULL : v = v * (mul_plus1[b][y][x][c] + 1)        (LiteISP.py:2014)
+     *   out_scale!=NULL : v = v * out_scale[b][c]                    (networks.py:270, last field)
      *   residual!=NULL  : v = v + residual[b][y][x][c]                                         */
     const float* film_scale;        /* (B, cout) fp32                                             */
     const float* film_shift;        /* (B, cout) fp32                                             */
@@ -138,6 +139,10 @@ typedef struct rc_conv_desc {
      * 2x + (p & 1)), zero beyond the source edge -- rc_space_to_depth2's order), so no space-to-depth pass is launched.  Needs
      * height = ceil(src_h / 2), width = ceil(src_w / 2), cin / 4 a multiple of 64, no gated input.                                     */
     int32_t src_h, src_w;
+    /* optional (B, cout) fp32: v = v * out_scale[b][c], applied after act / mul_plus1 and BEFORE the residual add -- the CALayer gate of this
+     * conv's own output when it is known ahead of the launch (rc_ca_gate_ahead): RCABlock's x + CA(conv(...)) (networks.py:311, 270) leaves
+     * the second conv as ONE map, x_new = conv2(t) * gate + x, instead of r = conv2(t) followed by r * gate + x in the next layer's staging. */
+    const float* out_scale;
 } rc_conv_desc;
 
 /* Size in bytes of the packed weight buffer for (cin,cout,ksize,dtype,out_mode); 0 on error. */
@@ -245,6 +250,17 @@ int rc_lsc_chain(const void* d_x, int cin0, const void* d_blob, int c, int n_mid
 int rc_ca_gate(float* d_sums, int batch, int n_tiles, int c, int cr, float inv_hw,
                const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,
                float* d_gate, void* stream);
+
+/* The same gate, computed AHEAD of the convolution whose output CALayer pools: RCABlock is x + CA(conv2(t)), t = relu(conv1(x))
+ * (models/networks.py:296-311), and mean_HW(conv2(t)) is linear in t: b2 + 1/HW * sum_{c,tap} W2[o][c][tap] * S_tap[c], S_tap = the sum of t[c] over
+ * the pixels tap (dy,dx) reaches inside the image (total - cut-off border row / column + corner).  d_sums: conv1's channel-sum partials of t
+ * (B, n_tiles, C) (scratch after the call, as in rc_ca_gate); d_t: the NHWC map t itself (B,H,W,C), read for its four border lines only;
+ * d_w2 (C,C,3,3) OIHW fp32 / d_b2 (C) or NULL: conv2's parameters; d_scratch: rc_ca_gate_ahead_scratch_floats(B, C) floats.  The gate then goes
+ * into conv2's launch as rc_conv_desc.out_scale (+ residual = x): one map written per RCAB body instead of r and r*gate + x. */
+size_t rc_ca_gate_ahead_scratch_floats(int batch, int c);
+int rc_ca_gate_ahead(float* d_sums, int batch, int n_tiles, int c, int cr, const void* d_t, int dtype, int H, int W,
+                     const float* d_w2, const float* d_b2, const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,
+                     float* d_scratch, float* d_gate, void* stream);
 
 /* Per-channel partial sums of an NHWC map (B, n_pix, C): the AdaptiveAvgPool2d(1) of a standalone CALayer
  * (models/networks.py:259,268) when no producing conv emitted them.  d_sums: fp32 (B, rc_channel_sums_slots(n_pix), C),

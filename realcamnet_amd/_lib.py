@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("out_h", C.c_int32), ("out_w", C.c_int32),
         ("chan_sums", C.c_void_p),
         ("src_h", C.c_int32), ("src_w", C.c_int32),
+        ("out_scale", C.c_void_p),
     ]
 
 
@@ -106,6 +107,8 @@ _SIGS = {
     "rc_conv_pair_sum_slots": (C.c_int, [_I, _I]),
     "rc_conv_pair_desc_size": (_SZ, []),
     "rc_ca_gate": (C.c_int, [_P, _I, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
+    "rc_ca_gate_ahead_scratch_floats": (_SZ, [_I, _I]),
+    "rc_ca_gate_ahead": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rc_gate_residual": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "rc_channel_sums_slots": (C.c_int, [_I]),
     "rc_channel_sums": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),

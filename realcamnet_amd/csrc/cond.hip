@@ -84,6 +84,131 @@ __global__ __launch_bounds__(kGateThreads) void ca_gate_kernel(const float* __re
     }
 }
 
+// ---- CALayer gate AHEAD of the convolution that feeds it (rc_ca_gate_ahead) --------------------------------------------------
+// RCABlock is x + CA(conv2(t)), t = relu(conv1(x)) (models/networks.py:296-311); CA's gate needs mean_HW(conv2(t)), and the mean of a
+// convolution is linear in its input: mean_HW(conv2(t))[o] = b2[o] + 1/HW * sum_{c,tap} W2[o][c][tap] * S_tap[c], where S_tap[c] is the sum of
+// t[c] over the pixels tap (dy, dx) reaches inside the image = the total minus the row / column the tap's zero padding cuts off, plus the
+// doubly-subtracted corner.  So the gate follows from conv1's channel sums (its epilogue emits them) and t's four border lines -- BEFORE conv2
+// runs, whose epilogue can then write x_new = conv2(t) * gate + x directly (rc_conv_desc.out_scale + residual).
+constexpr int kEdgeSegs = 8;
+// grid (4 * kEdgeSegs, B): fixed-order partial sums of row 0 / row H-1 / column 0 / column W-1 of an NHWC map, and its four corner pixels
+template <typename T>
+__global__ __launch_bounds__(256) void ca_border_sums_kernel(const T* __restrict__ t, float* __restrict__ edge, float* __restrict__ corner,
+                                                             int H, int W, int c) {
+    __shared__ float part[256];
+    const int e = blockIdx.x / kEdgeSegs, seg = blockIdx.x % kEdgeSegs, b = blockIdx.y, tid = threadIdx.x;
+    const T* img = t + (size_t)b * H * W * c;
+    const int n = e < 2 ? W : H, per = (n + kEdgeSegs - 1) / kEdgeSegs;
+    const int i0 = seg * per, i1 = (i0 + per) < n ? (i0 + per) : n;
+    const size_t base = e == 0 ? 0 : e == 1 ? (size_t)(H - 1) * W * c : e == 2 ? 0 : (size_t)(W - 1) * c;
+    const size_t step = e < 2 ? (size_t)c : (size_t)W * c;
+    for (int c0 = 0; c0 < c; c0 += 64) {
+        const int ch = c0 + (tid & 63), sub = tid >> 6;
+        float acc = 0.f;
+        if (ch < c) {
+#pragma unroll 4
+            for (int i = i0 + sub; i < i1; i += 4) acc += to_f32(img[base + (size_t)i * step + ch]);
+        }
+        part[tid] = acc;
+        __syncthreads();
+        if (tid < 64 && ch < c) edge[(((size_t)b * 4 + e) * kEdgeSegs + seg) * c + ch] = (part[tid] + part[tid + 64]) + (part[tid + 128] + part[tid + 192]);
+        __syncthreads();
+    }
+    if (blockIdx.x == 0)
+        for (int ch = tid; ch < c; ch += 256) {
+            corner[((size_t)b * 4 + 0) * c + ch] = to_f32(img[ch]);
+            corner[((size_t)b * 4 + 1) * c + ch] = to_f32(img[(size_t)(W - 1) * c + ch]);
+            corner[((size_t)b * 4 + 2) * c + ch] = to_f32(img[(size_t)(H - 1) * W * c + ch]);
+            corner[((size_t)b * 4 + 3) * c + ch] = to_f32(img[((size_t)(H - 1) * W + (W - 1)) * c + ch]);
+        }
+}
+
+__global__ __launch_bounds__(kGateThreads) void ca_gate_ahead_kernel(const float* __restrict__ sums, int n_tiles, int tile_stride, size_t image_stride,
+                                                                     const float* __restrict__ edge, const float* __restrict__ corner,
+                                                                     const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                     int c, int cr, float inv_hw, const float* __restrict__ w0,
+                                                                     const float* __restrict__ b0, const float* __restrict__ w1,
+                                                                     const float* __restrict__ b1, float* __restrict__ gate) {
+    extern __shared__ float sm[];          // [kGateThreads] partials | S[c] | E[4][c] | K[4][c] | mean[c] | hid[cr]
+    float* part = sm;
+    float* S = sm + kGateThreads;
+    float* E = S + c;
+    float* K = E + 4 * c;
+    float* mean = K + 4 * c;
+    float* hid = mean + c;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* s = sums + (size_t)b * image_stride;
+    for (int c0 = 0; c0 < c; c0 += kGateThreads) {             // total of t per channel: the same fixed-order fold as ca_gate_kernel
+        const int cw = (c - c0) < kGateThreads ? (c - c0) : kGateThreads;
+        const int nparts = kGateThreads / cw;
+        const int ch = tid % cw, pt = tid / cw;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (pt < nparts) {
+            const size_t step = (size_t)tile_stride * c;
+            const float* q = s + c0 + ch;
+            int t = pt;
+            for (; t + 3 * nparts < n_tiles; t += 4 * nparts) {
+                const float v0 = q[(size_t)t * step], v1 = q[(size_t)(t + nparts) * step];
+                const float v2 = q[(size_t)(t + 2 * nparts) * step], v3 = q[(size_t)(t + 3 * nparts) * step];
+                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+            }
+            for (; t < n_tiles; t += nparts) a0 += q[(size_t)t * step];
+        }
+        part[tid] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (tid < cw) {
+            float tot = 0.f;
+            for (int p = 0; p < nparts; ++p) tot += part[p * cw + tid];
+            S[c0 + tid] = tot;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < 4 * c; i += kGateThreads) {          // border lines: fold the segments in order; corners as they are
+        const int e = i / c, ch = i - e * c;
+        float tot = 0.f;
+        for (int g = 0; g < kEdgeSegs; ++g) tot += edge[(((size_t)b * 4 + e) * kEdgeSegs + g) * c + ch];
+        E[i] = tot;
+        K[i] = corner[(size_t)b * 4 * c + i];
+    }
+    __syncthreads();
+    // mean_HW(conv2(t))[o]: thread (o, pt) takes every nparts-th input channel; fixed-order fold over pt
+    for (int o0 = 0; o0 < c; o0 += kGateThreads) {
+        const int cw = (c - o0) < kGateThreads ? (c - o0) : kGateThreads;
+        const int nparts = kGateThreads / cw;
+        const int o = o0 + tid % cw, pt = tid / cw;
+        float acc = 0.f;
+        if (pt < nparts) {
+            for (int cc = pt; cc < c; cc += nparts) {
+                const float* wr = w2 + ((size_t)o * c + cc) * 9;
+                const float tot = S[cc], r0 = E[cc], r1 = E[c + cc], q0 = E[2 * c + cc], q1 = E[3 * c + cc];
+                // tap (dy, dx) reads t at (y + dy - 1, x + dx - 1): dy = 2 never reaches row 0, dy = 0 never row H-1 (likewise columns)
+                acc += wr[0] * (tot - r1 - q1 + K[3 * c + cc]) + wr[1] * (tot - r1) + wr[2] * (tot - r1 - q0 + K[2 * c + cc]);
+                acc += wr[3] * (tot - q1) + wr[4] * tot + wr[5] * (tot - q0);
+                acc += wr[6] * (tot - r0 - q1 + K[c + cc]) + wr[7] * (tot - r0) + wr[8] * (tot - r0 - q0 + K[cc]);
+            }
+        }
+        part[tid] = acc;
+        __syncthreads();
+        if (tid < cw) {
+            float tot = 0.f;
+            for (int p = 0; p < nparts; ++p) tot += part[p * cw + tid];
+            mean[o0 + tid] = (b2 ? b2[o0 + tid] : 0.f) + tot * inv_hw;
+        }
+        __syncthreads();
+    }
+    for (int j = tid; j < cr; j += kGateThreads) {
+        float h = b0[j];
+        for (int k = 0; k < c; ++k) h += w0[(size_t)j * c + k] * mean[k];
+        hid[j] = h > 0.f ? h : 0.f;
+    }
+    __syncthreads();
+    for (int k = tid; k < c; k += kGateThreads) {
+        float z = b1[k];
+        for (int j = 0; j < cr; ++j) z += w1[(size_t)k * cr + j] * hid[j];
+        gate[(size_t)b * c + k] = 1.f / (1.f + expf(-z));
+    }
+}
+
 // ---- color_block: conv1x1 -> avgpool(3, s2, p1, count_include_pad) -> LeakyReLU(0.2) -------------
 // x NCHW (B,cin,h,w), optionally instance-normalised on load; y fp32 NCHW (B,cout,ho,wo).
 // Both stages are linear, so the pool runs FIRST, on the cin input channels (9x fewer multiply-adds than pooling
@@ -301,6 +426,35 @@ int rc_ca_gate(float* d_sums, int batch, int n_tiles, int c, int cr, float inv_h
     }
     hipLaunchKernelGGL(ca_gate_kernel, dim3(batch), dim3(kGateThreads), lds, as_stream(stream), d_sums, slots, stride,
                        (size_t)n_tiles * c, c, cr, inv_hw, d_w0, d_b0, d_w1, d_b1, d_gate);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+size_t rc_ca_gate_ahead_scratch_floats(int batch, int c) { return (size_t)(batch > 0 ? batch : 0) * (4 * kEdgeSegs + 4) * (c > 0 ? c : 0); }
+
+int rc_ca_gate_ahead(float* d_sums, int batch, int n_tiles, int c, int cr, const void* d_t, int dtype, int H, int W,
+                     const float* d_w2, const float* d_b2, const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,
+                     float* d_scratch, float* d_gate, void* stream) {
+    RC_REQUIRE(d_sums && d_t && d_w2 && d_w0 && d_b0 && d_w1 && d_b1 && d_scratch && d_gate, "rc_ca_gate_ahead: null pointer");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_ca_gate_ahead: bad dtype");
+    RC_REQUIRE(batch >= 1 && batch <= 65535 && n_tiles >= 1 && c >= 1 && cr >= 1 && H >= 1 && W >= 1, "rc_ca_gate_ahead: bad shape");
+    const size_t lds = (kGateThreads + 10 * (size_t)c + cr) * sizeof(float);
+    RC_REQUIRE(lds <= 64 * 1024, "rc_ca_gate_ahead: too many channels");
+    float* edge = d_scratch;
+    float* corner = d_scratch + (size_t)batch * 4 * kEdgeSegs * c;
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(ca_border_sums_kernel<float>, dim3(4 * kEdgeSegs, batch), dim3(256), 0, as_stream(stream), static_cast<const float*>(d_t), edge, corner, H, W, c);
+    else
+        hipLaunchKernelGGL(ca_border_sums_kernel<bf16_t>, dim3(4 * kEdgeSegs, batch), dim3(256), 0, as_stream(stream), static_cast<const bf16_t*>(d_t), edge, corner, H, W, c);
+    int slots = n_tiles, stride = 1;
+    if (n_tiles > 128) {
+        const int L = ceil_div(n_tiles, 256);
+        slots = ceil_div(n_tiles, L);
+        stride = L;
+        hipLaunchKernelGGL(ca_reduce_kernel, dim3(slots, batch), dim3(256), 0, as_stream(stream), d_sums, n_tiles, c, L);
+    }
+    hipLaunchKernelGGL(ca_gate_ahead_kernel, dim3(batch), dim3(kGateThreads), lds, as_stream(stream), d_sums, slots, stride, (size_t)n_tiles * c,
+                       edge, corner, d_w2, d_b2, c, cr, 1.0f / ((float)H * (float)W), d_w0, d_b0, d_w1, d_b1, d_gate);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

@@ -306,6 +306,10 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     if (d->mul_plus1 || d->residual)   // a lane's 4-channel group must be wholly inside or outside [0, cout)
         RC_REQUIRE((full_tiles || d->cout % 4 == 0) && d->out_mode == RC_OUT_NHWC, "rc_conv2d: mul_plus1/residual need cout % 4 == 0 and RC_OUT_NHWC");
     if (d->chan_sums) RC_REQUIRE(d->out_mode == RC_OUT_NHWC, "rc_conv2d: chan_sums needs RC_OUT_NHWC");
+    if (d->out_scale) {
+        RC_REQUIRE(d->out_mode == RC_OUT_NHWC && !p.m32, "rc_conv2d: out_scale needs RC_OUT_NHWC and a layer outside the 32x32x16 forms");
+        RC_REQUIRE(reinterpret_cast<uintptr_t>(d->out_scale) % 4 == 0, "rc_conv2d: out_scale must be 4-byte aligned");
+    }
     const size_t es = dtype_size(d->dtype);
     if (d->out_mode == RC_OUT_NHWC) {
         RC_REQUIRE(d->out_dtype == d->dtype, "rc_conv2d: out_dtype must equal dtype for RC_OUT_NHWC");
@@ -357,17 +361,18 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     a.wpacked = d->wpacked; a.bias = d->bias;
     a.film_scale = d->film_scale; a.film_shift = d->film_shift;
     a.act = d->act; a.act_slope = d->act_slope;
-    a.mul_plus1 = d->mul_plus1; a.residual = d->residual;
+    a.mul_plus1 = d->mul_plus1; a.residual = d->residual; a.out_scale = d->out_scale;
     a.out = d->out; a.out_mode = d->out_mode; a.out_dtype = d->out_dtype; a.out_h = d->out_h; a.out_w = d->out_w;
     a.chan_sums = d->chan_sums; a.cout_packed = p.cout_packed;
     {   // epilogue feature mask (ConvDev::EP_*); anything outside the compiled set takes the generic epilogue
         int key = (d->act == RC_ACT_RELU ? 1 : 0) | (d->act == RC_ACT_LEAKY ? 2 : 0) | (d->film_scale ? 4 : 0) |
-                  (d->mul_plus1 ? 8 : 0) | (d->residual ? 16 : 0) | (d->chan_sums ? 32 : 0);
+                  (d->mul_plus1 ? 8 : 0) | (d->residual ? 16 : 0) | (d->chan_sums ? 32 : 0) | (d->out_scale ? 64 : 0);
         bool fast = full_tiles && d->out_mode != RC_OUT_NCHW && d->out_mode != RC_OUT_PIXEL_SHUFFLE2_NCHW && d->act != RC_ACT_GELU && d->act != RC_ACT_RELU_POST;
         if (d->act == RC_ACT_LEAKY) fast = fast && d->act_slope >= 0.f && d->act_slope <= 1.f;
         if (d->film_scale)
             fast = fast && d->cout % 4 == 0 && reinterpret_cast<uintptr_t>(d->film_scale) % 16 == 0 && reinterpret_cast<uintptr_t>(d->film_shift) % 16 == 0;
-        switch (key) { case 0: case 1: case 2: case 16: case 32: case 8: case 6: break; default: fast = false; }
+        if (d->out_scale) fast = fast && d->cout % 4 == 0 && reinterpret_cast<uintptr_t>(d->out_scale) % 16 == 0;
+        switch (key) { case 0: case 1: case 2: case 16: case 32: case 8: case 6: case 33: case 80: break; default: fast = false; }
         a.ep_key = fast ? key : -1;
         // a cout tile of a single-chunk pixel-shuffle layer with cout = 4 cout tiles is one sub-pixel of every pixel: kernel 5
         a.pss = g_pss && d->out_mode == RC_OUT_PIXEL_SHUFFLE2 && !p.m32 && p.n_chunks == 1 && p.n_ct == 4 && d->cout == 4 * 16 * p.nt &&

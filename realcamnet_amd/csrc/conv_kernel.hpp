@@ -56,6 +56,7 @@ struct ConvArgs {
     const float* film_scale; const float* film_shift;
     int act; float act_slope;
     const void* mul_plus1; const void* residual;
+    const float* out_scale;            // (B, cout) fp32 or NULL: v *= out_scale[b][c] after act / mul_plus1, before the residual (CALayer gate applied by the producing conv)
     void* out; int out_mode; int out_dtype; int out_h, out_w;
     float* chan_sums; int cout_packed;
     int num_cus; int persist_ok;
@@ -603,7 +604,7 @@ struct ConvDev {
     // epilogue is ~100 VALU instead of ~370 (a lone wave issues about one instruction per 4 cycles -- the
     // epilogue's instruction COUNT was costing as much time as the 168-MFMA loop).  epilogue_generic handles
     // everything (GELU, ragged cout, planar NCHW store, any operand mix) with run-time branches.
-    enum : int { EP_RELU = 1, EP_LEAKY = 2, EP_FILM = 4, EP_MUL = 8, EP_RES = 16, EP_SUMS = 32 };
+    enum : int { EP_RELU = 1, EP_LEAKY = 2, EP_FILM = 4, EP_MUL = 8, EP_RES = 16, EP_SUMS = 32, EP_GATE = 64 };
 
     template <bool FAST>
     __device__ static __forceinline__ void epilogue(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
@@ -619,6 +620,8 @@ struct ConvDev {
             case EP_SUMS: return epilogue_fast<EP_SUMS>(a, b, y0, x0, sp, ct, tid, acc);
             case EP_MUL: return epilogue_fast<EP_MUL>(a, b, y0, x0, sp, ct, tid, acc);
             case EP_FILM | EP_LEAKY: return epilogue_fast<EP_FILM | EP_LEAKY>(a, b, y0, x0, sp, ct, tid, acc);
+            case EP_RELU | EP_SUMS: return epilogue_fast<EP_RELU | EP_SUMS>(a, b, y0, x0, sp, ct, tid, acc);       // RCAB conv1 of the early-gate schedule
+            case EP_GATE | EP_RES: return epilogue_fast<EP_GATE | EP_RES>(a, b, y0, x0, sp, ct, tid, acc);         // RCAB conv2: conv * gate + x
             default: return;                      // unreachable: the host launches the !FAST kernel for other masks
         }
     }
@@ -690,6 +693,14 @@ struct ConvDev {
                 ft[e] = t4.x; ft[e + 1] = t4.y; ft[e + 2] = t4.z; ft[e + 3] = t4.w;
             }
         }
+        float gs[NV];
+        if constexpr ((F & EP_GATE) != 0) {                      // CALayer gate of THIS conv's output, known ahead (rc_ca_gate_ahead)
+#pragma unroll
+            for (int e = 0; e < NV; e += 4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(a.out_scale + (size_t)b * a.cout + jbase + e);
+                gs[e] = g4.x; gs[e + 1] = g4.y; gs[e + 2] = g4.z; gs[e + 3] = g4.w;
+            }
+        }
         float csum[NV];
 #pragma unroll
         for (int e = 0; e < NV; ++e) csum[e] = RUN ? run[e] : 0.f;
@@ -725,6 +736,10 @@ struct ConvDev {
                     buf_load_row<T, NV>(make_rsrc(static_cast<const T*>(a.mul_plus1) + (size_t)b * img_out, img_bytes), po, m);
 #pragma unroll
                     for (int e = 0; e < NV; ++e) v[e] = v[e] * (m[e] + 1.f);
+                }
+                if constexpr ((F & EP_GATE) != 0) {
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) v[e] *= gs[e];
                 }
                 if constexpr ((F & EP_RES) != 0) {
                     float m[NV];
@@ -798,6 +813,18 @@ struct ConvDev {
                                                             const unsigned (&rp)[4][NRH]) {
         const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
         const int jbase = ct * Cfg::COUT_TILE + q * NV;
+        // key EP_GATE | EP_RES (uniform): v * out_scale[b][c] first.  ONE copy of this epilogue with a uniform branch: a second instantiation
+        // beside the plain one cost the kernel 9 spilled registers.  Without a gate the multipliers are 1.0f (exact: the same bits).
+        float gs[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) gs[e] = 1.f;
+        if (a.ep_key == (EP_GATE | EP_RES)) {
+#pragma unroll
+            for (int e = 0; e < NV; e += 4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(a.out_scale + (size_t)b * a.cout + jbase + e);
+                gs[e] = g4.x; gs[e + 1] = g4.y; gs[e + 2] = g4.z; gs[e + 3] = g4.w;
+            }
+        }
         const size_t img_out = (size_t)a.H * a.W * a.cout;
         const __amdgpu_buffer_rsrc_t r_out = make_rsrc(static_cast<T*>(a.out) + (size_t)b * img_out, (unsigned)(img_out * ES));
         const int gy = y0 + 2 * wave, gx = x0 + n;
@@ -812,6 +839,8 @@ struct ConvDev {
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[pt][nt][r];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) v[e] *= gs[e];
 #pragma unroll
             for (int i = 0; i < NRH; ++i) {
                 v[2 * i] += __uint_as_float(rp[pt][i] << 16);
@@ -885,6 +914,10 @@ struct ConvDev {
                 buf_load_row<T, NV>(r_mul, pix_off, m);
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] = v[e] * (m[e] + 1.f);
+            }
+            if (a.out_scale != nullptr) {
+#pragma unroll
+                for (int e = 0; e < NV; ++e) v[e] *= (jbase + e < a.cout) ? a.out_scale[(size_t)b * a.cout + jbase + e] : 0.f;
             }
             if (a.residual != nullptr) {
                 float m[NV];
@@ -1154,7 +1187,7 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
             [[maybe_unused]] unsigned rpre[RESPRE ? 4 : 1][RESPRE ? D::NRH : 1];
             bool res_pre = false;
             if constexpr (RESPRE) {
-                if (a.ep_key == D::EP_RES && a.out_mode == RC_OUT_NHWC) {   // uniform: the residual's loads go out before the MFMA loop
+                if ((a.ep_key == D::EP_RES || a.ep_key == (D::EP_GATE | D::EP_RES)) && a.out_mode == RC_OUT_NHWC) {   // uniform: the residual's loads go out before the MFMA loop
                     res_pre = true;
                     D::res_prefetch(a, cb, cy0, cx0, ct, tid, rpre);
                 }
@@ -1163,8 +1196,12 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
             if constexpr (FAST && sizeof(typename Cfg::elem) == 2) {
                 if (a.ep_key == D::EP_SUMS && n_ct == 1)    // uniform
                     D::template epilogue_fast_impl<D::EP_SUMS, true>(a, cb, cy0, cx0, csp, ct, tid, acc, run, tile < 0 || b != cb);
+                else if (a.ep_key == (D::EP_RELU | D::EP_SUMS) && n_ct == 1)
+                    D::template epilogue_fast_impl<D::EP_RELU | D::EP_SUMS, true>(a, cb, cy0, cx0, csp, ct, tid, acc, run, tile < 0 || b != cb);
                 else if (res_pre) {
-                    if constexpr (RESPRE) D::epilogue_res_pre(a, cb, cy0, cx0, ct, tid, acc, rpre);
+                    if constexpr (RESPRE) {
+                        D::epilogue_res_pre(a, cb, cy0, cx0, ct, tid, acc, rpre);
+                    }
                 } else D::template epilogue<FAST>(a, cb, cy0, cx0, csp, ct, tid, acc);
             } else D::template epilogue<FAST>(a, cb, cy0, cx0, csp, ct, tid, acc);
         }

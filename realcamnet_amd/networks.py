@@ -255,7 +255,23 @@ class RCABlock(HipModule):
         gate = ops.ca_gate(sums, a.shape[1] * a.shape[2], self.ca)
         return r, gate, stored
 
+    def _early(self, a) -> bool:
+        mods = list(self.res)
+        return (ops.EARLY_GATE and len(mods) == 3 and isinstance(mods[0], Conv2d) and _is_act(mods[1]) and isinstance(mods[2], Conv2d) and
+                tuple(mods[2].weight.shape[2:]) == (3, 3) and mods[2].weight.shape[0] == mods[2].weight.shape[1] and
+                not (isinstance(mods[1], nn.ReLU) and ops.conv_pair_ok(a, mods[0], mods[2])))
+
+    def _nhwc_early(self, a):
+        """x + CA(conv2(t)), t = act(conv1(x)), as two launches + the small gate kernels: conv1 emits t's channel sums, the gate of conv2(t) follows
+        from them ahead of conv2 (ops.ca_gate_ahead), conv2's epilogue writes conv2(t) * gate + x."""
+        mods = list(self.res)
+        t, sums = mods[0]._nhwc(a, **_act_args(mods[1]), want_sums=True)
+        gate = ops.ca_gate_ahead(sums, t, mods[2], self.ca)
+        return mods[2]._nhwc(t, out_scale=gate, residual=a)
+
     def _nhwc(self, a):
+        if self._early(a):
+            return self._nhwc_early(a)
         r, gate, _ = self._body(a)
         return ops.gate_residual(r, gate, a)
 
@@ -278,8 +294,8 @@ class RCAGroup(HipModule):
         last = blocks[-1]
         if not isinstance(last, Conv2d) or not all(isinstance(b, RCABlock) for b in blocks[:-1]):
             raise NotImplementedError("RCAGroup: unexpected layout")
-        if not ops.FUSE_GATE:
-            y = a
+        if not ops.FUSE_GATE or (len(blocks) > 1 and all(blk._early(a) for blk in blocks[:-1])):
+            y = a                                    # early-gate schedule: every block is two plain launches, nothing is carried between blocks
             for blk in blocks[:-1]:
                 y = blk._nhwc(y)
             return last._nhwc(y, residual=a)

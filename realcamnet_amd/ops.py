@@ -472,11 +472,13 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
            film: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
            gate: Optional[torch.Tensor] = None, skip: Optional[torch.Tensor] = None, store_input: bool = False,
            out_mode: int = RC_OUT_NHWC, want_sums: bool = False,
-           crop_hw: Optional[Tuple[int, int]] = None, out_dtype: Optional[torch.dtype] = None):
+           crop_hw: Optional[Tuple[int, int]] = None, out_dtype: Optional[torch.dtype] = None,
+           out_scale: Optional[torch.Tensor] = None):
     """KxK stride-1 'same' convolution of NHWC `x` with `mod`'s weights (an nn.Conv2d-shaped module).
 
     gate/skip: the conv input is x*gate[b,c] + skip (CALayer gate + RCAB skip); with store_input the
     combined tensor is also materialised and returned.
+    out_scale: (B, cout) fp32, multiplies the result before the residual is added (the CALayer gate of this conv's own output, ca_gate_ahead).
     Returns out, or a tuple (out, [stored_input], [chan_sums]) when extras are requested.
     """
     if mod.weight.dim() == 4:
@@ -500,6 +502,10 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
             raise ValueError("film tensors must be fp32 (B, cout)")
     if mul_plus1 is not None:
         mul_plus1 = _req(mul_plus1, "mul_plus1")
+    if out_scale is not None:
+        out_scale = _req(out_scale, "out_scale")
+        if out_scale.shape != (b, pc.cout) or out_scale.dtype != torch.float32 or out_mode != RC_OUT_NHWC:
+            raise ValueError("out_scale must be fp32 (B, cout) and needs the NHWC store")
     if residual is not None:
         residual = _req(residual, "residual")
     for name, t in (("mul_plus1", mul_plus1), ("residual", residual)):
@@ -511,7 +517,7 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
         _DT[out_dtype]
     out, stored, sums = _R.conv2d(x, pc.wpacked, pc.bias, pc.cout, pc.ksize, _ACT[act], float(slope), residual, mul_plus1, fs, ft, gate, skip,
                                   bool(store_input), int(out_mode), bool(want_sums), int(ch), int(cw),
-                                  out_dtype if planar else None)
+                                  out_dtype if planar else None, out_scale)
     extras = [t for t in (_opt(stored), _opt(sums)) if t is not None]
     return (out, *extras) if extras else out
 
@@ -737,6 +743,23 @@ def ca_gate(sums: torch.Tensor, hw: int, ca) -> torch.Tensor:
     cr, c = c0.weight.shape[0], c0.weight.shape[1]
     return _R.ca_gate(sums, int(hw), f32_param(c0, "weight").reshape(cr, c), f32_param(c0, "bias"), f32_param(c1, "weight").reshape(c, cr),
                       f32_param(c1, "bias"))
+
+
+# RCABlock as two plain launches: the CALayer gate of conv2's output is computed BEFORE conv2 runs (ca_gate_ahead: the mean of a convolution is
+# linear in its input, so conv1's channel sums + t's four border lines give it), and conv2's epilogue writes x_new = conv2(t) * gate + x directly.
+# Per block 5 map passes instead of 6 (the gated staging form read r and skip and wrote x and t); False: gate folded into the NEXT conv's staging.
+EARLY_GATE = True
+
+
+def ca_gate_ahead(sums_t: torch.Tensor, t: torch.Tensor, conv2, ca) -> torch.Tensor:
+    """CALayer gate (B,C) of conv2(t) from t's channel partial sums (emitted by the conv that produced t) and t itself (border lines only)."""
+    c0, c1 = ca.conv_du[0], ca.conv_du[2]
+    cr, c = c0.weight.shape[0], c0.weight.shape[1]
+    if tuple(conv2.weight.shape) != (c, c, 3, 3):
+        raise ValueError("ca_gate_ahead: conv2 must be a 3x3 convolution C -> C")
+    gate, _ = _R.ca_gate_ahead(sums_t, _req(t, "t"), f32_param(conv2, "weight"), f32_param(conv2, "bias") if conv2.bias is not None else None,
+                               f32_param(c0, "weight").reshape(cr, c), f32_param(c0, "bias"), f32_param(c1, "weight").reshape(c, cr), f32_param(c1, "bias"))
+    return gate
 
 
 def gate_residual(r: torch.Tensor, gate: torch.Tensor, x: Optional[torch.Tensor]) -> torch.Tensor:

@@ -153,7 +153,7 @@ define("conv_pack_weights(Tensor weight, Tensor? bias, ScalarType act_dtype, int
 
 
 def _conv_alloc(x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, film_scale, film_shift, gate, skip, store_input, out_mode,
-                want_sums, crop_h, crop_w, out_dtype):
+                want_sums, crop_h, crop_w, out_dtype, out_scale=None):
     b, H, W, _ = x.shape
     if out_mode == RC_OUT_NHWC:
         out = x.new_empty((b, H, W, cout))
@@ -169,7 +169,7 @@ def _conv_alloc(x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, 
 
 
 def _conv_launch(outs, x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, film_scale, film_shift, gate, skip, store_input,
-                 out_mode, want_sums, crop_h, crop_w, out_dtype):
+                 out_mode, want_sums, crop_h, crop_w, out_dtype, out_scale=None):
     out, stored, sums = outs
     b, H, W, cin = x.shape
     d = ConvDesc()
@@ -182,7 +182,7 @@ def _conv_launch(outs, x, wpacked, bias, cout, ksize, act, slope, residual, mul_
     d.wpacked, d.bias = wpacked.data_ptr(), _p(bias)
     d.film_scale, d.film_shift = _p(film_scale), _p(film_shift)
     d.act, d.act_slope = act, float(slope)
-    d.mul_plus1, d.residual = _p(mul_plus1), _p(residual)
+    d.mul_plus1, d.residual, d.out_scale = _p(mul_plus1), _p(residual), _p(out_scale)
     d.out, d.out_mode = out.data_ptr(), out_mode
     d.out_dtype = _dt(out)
     if out_mode in (RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW):
@@ -194,7 +194,7 @@ def _conv_launch(outs, x, wpacked, bias, cout, ksize, act, slope, residual, mul_
 
 define("conv2d(Tensor x, Tensor wpacked, Tensor? bias, int cout, int ksize, int act, float slope, Tensor? residual, Tensor? mul_plus1, "
        "Tensor? film_scale, Tensor? film_shift, Tensor? gate, Tensor? skip, bool store_input, int out_mode, bool want_sums, "
-       "int crop_h, int crop_w, ScalarType? out_dtype) -> (Tensor, Tensor, Tensor)", _conv_alloc, _conv_launch)
+       "int crop_h, int crop_w, ScalarType? out_dtype, Tensor? out_scale=None) -> (Tensor, Tensor, Tensor)", _conv_alloc, _conv_launch)
 
 
 def _conv_fold2_launch(out, x, wpacked, bias, cout, act, slope):
@@ -331,6 +331,25 @@ define("ca_gate(Tensor(a!) sums, int hw, Tensor w0, Tensor b0, Tensor w1, Tensor
        lambda out, sums, hw, w0, b0, w1, b1: check(lib().rc_ca_gate(sums.data_ptr(), sums.shape[0], sums.shape[1], sums.shape[2], w0.shape[0],
                                                                     1.0 / float(hw), w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(),
                                                                     out.data_ptr(), _stream()), "rc_ca_gate"))
+
+
+
+def _gate_ahead_alloc(sums, t, w2, b2, w0, b0, w1, b1):
+    b, c = sums.shape[0], sums.shape[2]
+    return sums.new_empty((b, c)), sums.new_empty((b * (4 * 8 + 4) * c,))      # gate, scratch (rc_ca_gate_ahead_scratch_floats)
+
+
+def _gate_ahead_launch(outs, sums, t, w2, b2, w0, b0, w1, b1):
+    gate, scratch = outs
+    b, n_tiles, c = sums.shape
+    assert scratch.numel() >= lib().rc_ca_gate_ahead_scratch_floats(b, c)
+    check(lib().rc_ca_gate_ahead(sums.data_ptr(), b, n_tiles, c, w0.shape[0], t.data_ptr(), _dt(t), t.shape[1], t.shape[2], w2.data_ptr(), _p(b2),
+                                 w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), scratch.data_ptr(), gate.data_ptr(), _stream()), "rc_ca_gate_ahead")
+
+
+# CALayer's gate of conv2(t) from t's channel sums + border lines, before conv2 runs (the mean of a convolution is linear in its input)
+define("ca_gate_ahead(Tensor(a!) sums, Tensor t, Tensor w2, Tensor? b2, Tensor w0, Tensor b0, Tensor w1, Tensor b1) -> (Tensor, Tensor)",
+       _gate_ahead_alloc, _gate_ahead_launch)
 
 define("gate_residual(Tensor r, Tensor gate, Tensor? x) -> Tensor",
        lambda r, gate, x: torch.empty_like(r),

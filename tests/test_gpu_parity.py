@@ -126,10 +126,12 @@ def test_conv_blocks_vs_reference(hip, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("fuse", [True, False])
-def test_channel_attention_blocks_vs_reference(hip, dt, fuse):
-    old = ops.FUSE_GATE
-    ops.FUSE_GATE = fuse
+@pytest.mark.parametrize("schedule", ["early", "staged", "unfused"])
+def test_channel_attention_blocks_vs_reference(hip, dt, schedule):
+    """RCABlock / RCAGroup against the reference fixtures in all three schedules: `early` (default: gate of conv2's output computed ahead of conv2,
+    applied in its epilogue), `staged` (gate + skip folded into the NEXT conv's input staging), `unfused` (rc_gate_residual pass)."""
+    old = ops.FUSE_GATE, ops.EARLY_GATE
+    ops.EARLY_GATE, ops.FUSE_GATE = schedule == "early", schedule != "unfused"
     try:
         g = load_golden("block_rcab_32")
         y = run(put(N.RCABlock(32, 32), g["sd"], dt), g["x"], dt=dt)
@@ -141,7 +143,59 @@ def test_channel_attention_blocks_vs_reference(hip, dt, fuse):
         y = run(put(N.RCAGroup(48, 48, nb=2), g["sd"], dt), g["x"], dt=dt)
         assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
     finally:
-        ops.FUSE_GATE = old
+        ops.FUSE_GATE, ops.EARLY_GATE = old
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("c,H,W", [(48, 37, 70), (48, 1, 5), (32, 2, 2), (128, 24, 33), (64, 9, 1)])
+def test_gate_ahead_equals_gate_of_the_conv_output(hip, dt, c, H, W):
+    """rc_ca_gate_ahead (gate of conv2(t) from t's channel sums + border lines, by linearity of the mean) against rc_ca_gate on the channel sums
+    conv2 itself emits: same MLP, two orders of summation -> fp32 rounding only (tolerance 2e-5 absolute on a sigmoid output); degenerate images
+    (one row / one column / 2 x 2: border lines coincide) included."""
+    g = torch.Generator().manual_seed(c + H * W)
+    blk = N.RCABlock(c, c).to(DEV, dt).eval()
+    with torch.no_grad():
+        for p_ in blk.ca.parameters():
+            p_.mul_(4.0)                                     # spread the gates away from 0.5
+        x = torch.randn(2, H, W, c, generator=g).to(DEV, dt)
+        t, sums_t = blk.res[0]._nhwc(x, act="relu", want_sums=True)
+        r, sums_r = blk.res[2]._nhwc(t, want_sums=True)
+        ref = ops.ca_gate(sums_r, H * W, blk.ca)
+        ahead = ops.ca_gate_ahead(sums_t, t, blk.res[2], blk.ca)
+    assert ahead.shape == ref.shape == (2, c)
+    # bf16: conv1's sums are taken before t is rounded to bf16 (conv2 reads the rounded map): |mean| differs by ~1e-4 relative
+    assert (ahead - ref).abs().max().item() <= (2e-5 if dt == torch.float32 else 5e-4)
+    assert ref.std().item() > 1e-3
+
+
+@pytest.mark.parametrize("persist", [1, 2, 3, 0])
+@pytest.mark.parametrize("dt,cin,H,W", [(torch.bfloat16, 48, 16, 40), (torch.bfloat16, 48, 9, 33), (torch.bfloat16, 128, 21, 70), (torch.float32, 32, 9, 33)])
+def test_conv_out_scale_and_relu_sums_exact_on_integer_data(hip, persist, dt, cin, H, W):
+    """The two epilogues of the early-gate RCAB on integer data, every launch form: conv + ReLU with channel sums (sums == the stored map's sums
+    exactly), and conv * out_scale[b][c] + residual (power-of-two scales: exact) -- bit for bit against F.conv2d."""
+    g = torch.Generator().manual_seed(cin * 7 + H)
+    c = N.Conv2d(cin, cin, 3, 1, 1)
+    with torch.no_grad():
+        c.weight.copy_(torch.randint(-2, 3, c.weight.shape, generator=g).float() / 2)
+        c.bias.copy_(torch.randint(-2, 3, c.bias.shape, generator=g).float())
+    x = torch.randint(-2, 3, (2, cin, H, W), generator=g).float() / 2
+    res = torch.randint(-4, 5, (2, cin, H, W), generator=g).float() / 2
+    scale = 2.0 ** torch.randint(-2, 2, (2, cin), generator=g).float()
+    ref = F.conv2d(x, c.weight.detach(), c.bias.detach(), padding=1)
+    rb = (lambda t: t.bfloat16().float()) if dt == torch.bfloat16 else (lambda t: t)
+    c = c.to(DEV, dt).eval()
+    a, r = ops.to_nhwc(x.to(DEV, dt)), ops.to_nhwc(res.to(DEV, dt))
+    assert hip.rc_debug_set(b"persist", persist) == 0
+    try:
+        with torch.no_grad():
+            y1, sums = ops.conv2d(a, c, act="relu", want_sums=True)
+            y2 = ops.conv2d(a, c, out_scale=scale.to(DEV), residual=r)
+    finally:
+        hip.rc_debug_set(b"persist", 1)
+    relu = ref.clamp_min(0)
+    assert torch.equal(y1.float().cpu().permute(0, 3, 1, 2), rb(relu))
+    assert torch.equal(sums.sum(1).cpu(), relu.sum((2, 3)))                  # small integers: every partial sum is exact in fp32
+    assert torch.equal(y2.float().cpu().permute(0, 3, 1, 2), rb(ref * scale[:, :, None, None] + res))
 
 
 @pytest.mark.parametrize("dt", DTYPES)

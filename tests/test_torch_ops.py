@@ -84,10 +84,10 @@ def test_fake_kernels_of_single_ops():
             x = torch.empty(2, 16, 24, 48, dtype=torch.bfloat16)
             wp = torch.empty(1024, dtype=torch.uint8)
             out, stored, sums = torch.ops.realcam.conv2d(x, wp, None, 192, 3, 0, 0.0, None, None, None, None, None, None, False, 1, False, 0, 0,
-                                                         None)
+                                                         None, None)
             assert out.shape == (2, 32, 48, 48) and stored.numel() == 0 and sums.numel() == 0     # PixelShuffle(2) folded into the store
             out, _, sums = torch.ops.realcam.conv2d(x, wp, None, 3, 3, 0, 0.0, None, None, None, None, None, None, False, 2, True, 10, 20,
-                                                    torch.float32)
+                                                    torch.float32, None)
             assert out.shape == (2, 3, 10, 20) and out.dtype == torch.float32 and sums.shape[0] == 2 and sums.shape[2] == 3
             packed, cnd = torch.ops.realcam.raw_ingest(torch.empty(3, 100, 60), torch.bfloat16, 16, 64.0, 1023.0, 32, 48)
             assert packed.shape == (3, 64, 32, 4) and cnd.shape == (3, 4, 32, 48)
