@@ -172,9 +172,11 @@ size_t rc_conv_desc_size(void);
  *     double.  Run the result as rc_conv2d ksize 5 (bf16, C = 48, 4O <= 16) with RC_OUT_PIXEL_SHUFFLE2_NCHW.
  * The fold is exact everywhere except the outermost ring of output pixels (the second convolution zero-pads the shuffled map; the fold sees
  * conv1 evaluated beyond the edge there).  The ring is recomputed with the two original convolutions on four thin strips:
- *   rc_tail_ring_gather : x NHWC (B,H,W,C) -> rows (2B,2,W,C) = [x[:,0:2], x[:,H-2:H]], cols (2B,H,2,C) = [x[:,:,0:2], x[:,:,W-2:W]]
- *   (caller: conv1 with RC_OUT_PIXEL_SHUFFLE2 + conv2 with RC_OUT_NCHW on both strip batches -> rows_out (2B,O,4,2W), cols_out (2B,O,2H,4))
- *   rc_tail_ring_scatter: output row 0 / row 2H-1 from rows_out rows 0 / 3, column 0 / 2W-1 from cols_out columns 0 / 3 -> out (B,O,out_h,out_w),
+ *   rc_tail_ring_gather : x NHWC (B,H,W,C) -> rows (2B,2,W,C) = [x[:,0:2], x[:,H-2:H]], cols (2B,2,H,C) = [x[:,:,0:2], x[:,:,W-2:W]] TRANSPOSED
+ *     (cols pixel (r, y) = x[b][y][r]: the side strips run as 2 x H images -- a 2-pixel-wide image would waste 15/16 of every conv tile)
+ *   (caller: conv1 with RC_OUT_PIXEL_SHUFFLE2 + conv2 with RC_OUT_NCHW on both strip batches, the transposed batch with ky <-> kx swapped weights and
+ *    conv1's sub-pixel order 4c+2i+j <-> 4c+2j+i -> rows_out (2B,O,4,2W), cols_out (2B,O,4,2H))
+ *   rc_tail_ring_scatter: output row 0 / row 2H-1 from rows_out rows 0 / 3, column 0 / 2W-1 from cols_out ROWS 0 / 3 -> out (B,O,out_h,out_w),
  *     skipping what the crop (out_h < 2H, out_w < 2W) removes.  dtype = element type of the strips and of out. */
 int rc_tail_fold_weights(const float* w1_host, const float* b1_host, const float* w2_host, const float* b2_host, int c, int o,
                          float* wc_host, float* bc_host);
@@ -255,11 +257,11 @@ int rc_ca_gate(float* d_sums, int batch, int n_tiles, int c, int cr, float inv_h
  * (models/networks.py:296-311), and mean_HW(conv2(t)) is linear in t: b2 + 1/HW * sum_{c,tap} W2[o][c][tap] * S_tap[c], S_tap = the sum of t[c] over
  * the pixels tap (dy,dx) reaches inside the image (total - cut-off border row / column + corner).  d_sums: conv1's channel-sum partials of t
  * (B, n_tiles, C) (scratch after the call, as in rc_ca_gate); d_t: the NHWC map t itself (B,H,W,C), read for its four border lines only;
- * d_w2 (C,C,3,3) OIHW fp32 / d_b2 (C) or NULL: conv2's parameters; d_scratch: rc_ca_gate_ahead_scratch_floats(B, C) floats.  The gate then goes
+ * d_w2t (C_in,3,3,C_out) fp32 = conv2's OIHW weight permuted (1,2,3,0) / d_b2 (C) or NULL: conv2's parameters; d_scratch: rc_ca_gate_ahead_scratch_floats(B, C) floats.  The gate then goes
  * into conv2's launch as rc_conv_desc.out_scale (+ residual = x): one map written per RCAB body instead of r and r*gate + x. */
 size_t rc_ca_gate_ahead_scratch_floats(int batch, int c);
 int rc_ca_gate_ahead(float* d_sums, int batch, int n_tiles, int c, int cr, const void* d_t, int dtype, int H, int W,
-                     const float* d_w2, const float* d_b2, const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,
+                     const float* d_w2t, const float* d_b2, const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,
                      float* d_scratch, float* d_gate, void* stream);
 
 /* Per-channel partial sums of an NHWC map (B, n_pix, C): the AdaptiveAvgPool2d(1) of a standalone CALayer

@@ -9,9 +9,7 @@ namespace rc {
 // ---- CALayer gate: fixed-order reduction of the conv's per-tile channel sums + 2-layer MLP -------
 // Stage 1 (large images): block (k, b) folds tiles [k*L, (k+1)*L) of image b into slot k*L, in place
 // (a block only ever writes inside its own range, so there is no cross-block hazard).  Fixed order.
-__global__ __launch_bounds__(256) void ca_reduce_kernel(float* __restrict__ sums, int n_tiles, int c, int L) {
-    __shared__ float part[256];
-    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+__device__ __forceinline__ void ca_reduce_body(float* __restrict__ sums, int n_tiles, int c, int L, int k, int b, int tid, float* part) {
     float* s = sums + (size_t)b * n_tiles * c;
     const int t0 = k * L, t1 = (t0 + L) < n_tiles ? (t0 + L) : n_tiles;
     for (int c0 = 0; c0 < c; c0 += 256) {
@@ -30,6 +28,10 @@ __global__ __launch_bounds__(256) void ca_reduce_kernel(float* __restrict__ sums
         }
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(256) void ca_reduce_kernel(float* __restrict__ sums, int n_tiles, int c, int L) {
+    __shared__ float part[256];
+    ca_reduce_body(sums, n_tiles, c, L, blockIdx.x, blockIdx.y, threadIdx.x, part);
 }
 
 // Stage 2: sum `n_tiles` slots spaced `tile_stride` tiles apart, then the 2-layer gate MLP.  One block per image on the critical path
@@ -93,10 +95,9 @@ __global__ __launch_bounds__(kGateThreads) void ca_gate_kernel(const float* __re
 constexpr int kEdgeSegs = 8;
 // grid (4 * kEdgeSegs, B): fixed-order partial sums of row 0 / row H-1 / column 0 / column W-1 of an NHWC map, and its four corner pixels
 template <typename T>
-__global__ __launch_bounds__(256) void ca_border_sums_kernel(const T* __restrict__ t, float* __restrict__ edge, float* __restrict__ corner,
-                                                             int H, int W, int c) {
-    __shared__ float part[256];
-    const int e = blockIdx.x / kEdgeSegs, seg = blockIdx.x % kEdgeSegs, b = blockIdx.y, tid = threadIdx.x;
+__device__ __forceinline__ void ca_border_body(const T* __restrict__ t, float* __restrict__ edge, float* __restrict__ corner,
+                                               int H, int W, int c, int idx, int b, int tid, float* part) {
+    const int e = idx / kEdgeSegs, seg = idx % kEdgeSegs;
     const T* img = t + (size_t)b * H * W * c;
     const int n = e < 2 ? W : H, per = (n + kEdgeSegs - 1) / kEdgeSegs;
     const int i0 = seg * per, i1 = (i0 + per) < n ? (i0 + per) : n;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void ca_border_sums_kernel(const T* __restrict
         if (tid < 64 && ch < c) edge[(((size_t)b * 4 + e) * kEdgeSegs + seg) * c + ch] = (part[tid] + part[tid + 64]) + (part[tid + 128] + part[tid + 192]);
         __syncthreads();
     }
-    if (blockIdx.x == 0)
+    if (idx == 0)
         for (int ch = tid; ch < c; ch += 256) {
             corner[((size_t)b * 4 + 0) * c + ch] = to_f32(img[ch]);
             corner[((size_t)b * 4 + 1) * c + ch] = to_f32(img[(size_t)(W - 1) * c + ch]);
@@ -123,9 +124,18 @@ __global__ __launch_bounds__(256) void ca_border_sums_kernel(const T* __restrict
         }
 }
 
+// ca_reduce_kernel's slot folding and the border lines in ONE launch (they are independent): blocks [0, n_red) fold, the next 4 * kEdgeSegs take the borders
+template <typename T>
+__global__ __launch_bounds__(256) void ca_reduce_border_kernel(float* __restrict__ sums, int n_tiles, int c, int L, int n_red, const T* __restrict__ t,
+                                                               float* __restrict__ edge, float* __restrict__ corner, int H, int W) {
+    __shared__ float part[256];
+    if ((int)blockIdx.x < n_red) ca_reduce_body(sums, n_tiles, c, L, blockIdx.x, blockIdx.y, threadIdx.x, part);
+    else ca_border_body<T>(t, edge, corner, H, W, c, (int)blockIdx.x - n_red, blockIdx.y, threadIdx.x, part);
+}
+
 __global__ __launch_bounds__(kGateThreads) void ca_gate_ahead_kernel(const float* __restrict__ sums, int n_tiles, int tile_stride, size_t image_stride,
                                                                      const float* __restrict__ edge, const float* __restrict__ corner,
-                                                                     const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                     const float* __restrict__ w2t, const float* __restrict__ b2,
                                                                      int c, int cr, float inv_hw, const float* __restrict__ w0,
                                                                      const float* __restrict__ b0, const float* __restrict__ w1,
                                                                      const float* __restrict__ b1, float* __restrict__ gate) {
@@ -179,12 +189,12 @@ __global__ __launch_bounds__(kGateThreads) void ca_gate_ahead_kernel(const float
         float acc = 0.f;
         if (pt < nparts) {
             for (int cc = pt; cc < c; cc += nparts) {
-                const float* wr = w2 + ((size_t)o * c + cc) * 9;
+                const float* wr = w2t + (size_t)cc * 9 * c + o;              // [cin][tap][cout]: the threads of a wave read consecutive couts
                 const float tot = S[cc], r0 = E[cc], r1 = E[c + cc], q0 = E[2 * c + cc], q1 = E[3 * c + cc];
                 // tap (dy, dx) reads t at (y + dy - 1, x + dx - 1): dy = 2 never reaches row 0, dy = 0 never row H-1 (likewise columns)
-                acc += wr[0] * (tot - r1 - q1 + K[3 * c + cc]) + wr[1] * (tot - r1) + wr[2] * (tot - r1 - q0 + K[2 * c + cc]);
-                acc += wr[3] * (tot - q1) + wr[4] * tot + wr[5] * (tot - q0);
-                acc += wr[6] * (tot - r0 - q1 + K[c + cc]) + wr[7] * (tot - r0) + wr[8] * (tot - r0 - q0 + K[cc]);
+                acc += wr[0] * (tot - r1 - q1 + K[3 * c + cc]) + wr[c] * (tot - r1) + wr[2 * c] * (tot - r1 - q0 + K[2 * c + cc]);
+                acc += wr[3 * c] * (tot - q1) + wr[4 * c] * tot + wr[5 * c] * (tot - q0);
+                acc += wr[6 * c] * (tot - r0 - q1 + K[c + cc]) + wr[7 * c] * (tot - r0) + wr[8 * c] * (tot - r0 - q0 + K[cc]);
             }
         }
         part[tid] = acc;
@@ -433,28 +443,30 @@ int rc_ca_gate(float* d_sums, int batch, int n_tiles, int c, int cr, float inv_h
 size_t rc_ca_gate_ahead_scratch_floats(int batch, int c) { return (size_t)(batch > 0 ? batch : 0) * (4 * kEdgeSegs + 4) * (c > 0 ? c : 0); }
 
 int rc_ca_gate_ahead(float* d_sums, int batch, int n_tiles, int c, int cr, const void* d_t, int dtype, int H, int W,
-                     const float* d_w2, const float* d_b2, const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,
+                     const float* d_w2t, const float* d_b2, const float* d_w0, const float* d_b0, const float* d_w1, const float* d_b1,
                      float* d_scratch, float* d_gate, void* stream) {
-    RC_REQUIRE(d_sums && d_t && d_w2 && d_w0 && d_b0 && d_w1 && d_b1 && d_scratch && d_gate, "rc_ca_gate_ahead: null pointer");
+    RC_REQUIRE(d_sums && d_t && d_w2t && d_w0 && d_b0 && d_w1 && d_b1 && d_scratch && d_gate, "rc_ca_gate_ahead: null pointer");
     RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_ca_gate_ahead: bad dtype");
     RC_REQUIRE(batch >= 1 && batch <= 65535 && n_tiles >= 1 && c >= 1 && cr >= 1 && H >= 1 && W >= 1, "rc_ca_gate_ahead: bad shape");
     const size_t lds = (kGateThreads + 10 * (size_t)c + cr) * sizeof(float);
     RC_REQUIRE(lds <= 64 * 1024, "rc_ca_gate_ahead: too many channels");
     float* edge = d_scratch;
     float* corner = d_scratch + (size_t)batch * 4 * kEdgeSegs * c;
-    if (dtype == RC_F32)
-        hipLaunchKernelGGL(ca_border_sums_kernel<float>, dim3(4 * kEdgeSegs, batch), dim3(256), 0, as_stream(stream), static_cast<const float*>(d_t), edge, corner, H, W, c);
-    else
-        hipLaunchKernelGGL(ca_border_sums_kernel<bf16_t>, dim3(4 * kEdgeSegs, batch), dim3(256), 0, as_stream(stream), static_cast<const bf16_t*>(d_t), edge, corner, H, W, c);
-    int slots = n_tiles, stride = 1;
-    if (n_tiles > 128) {
-        const int L = ceil_div(n_tiles, 256);
+    int slots = n_tiles, stride = 1, L = 1, n_red = 0;
+    if (n_tiles > 128) {      // two-stage fold as in rc_ca_gate
+        L = ceil_div(n_tiles, 256);
         slots = ceil_div(n_tiles, L);
         stride = L;
-        hipLaunchKernelGGL(ca_reduce_kernel, dim3(slots, batch), dim3(256), 0, as_stream(stream), d_sums, n_tiles, c, L);
+        n_red = slots;
     }
+    if (dtype == RC_F32)
+        hipLaunchKernelGGL(ca_reduce_border_kernel<float>, dim3(n_red + 4 * kEdgeSegs, batch), dim3(256), 0, as_stream(stream), d_sums, n_tiles, c, L, n_red,
+                           static_cast<const float*>(d_t), edge, corner, H, W);
+    else
+        hipLaunchKernelGGL(ca_reduce_border_kernel<bf16_t>, dim3(n_red + 4 * kEdgeSegs, batch), dim3(256), 0, as_stream(stream), d_sums, n_tiles, c, L, n_red,
+                           static_cast<const bf16_t*>(d_t), edge, corner, H, W);
     hipLaunchKernelGGL(ca_gate_ahead_kernel, dim3(batch), dim3(kGateThreads), lds, as_stream(stream), d_sums, slots, stride, (size_t)n_tiles * c,
-                       edge, corner, d_w2, d_b2, c, cr, 1.0f / ((float)H * (float)W), d_w0, d_b0, d_w1, d_b1, d_gate);
+                       edge, corner, d_w2t, d_b2, c, cr, 1.0f / ((float)H * (float)W), d_w0, d_b0, d_w1, d_b1, d_gate);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

@@ -493,8 +493,10 @@ __global__ void dwt_inverse_kernel(const T* __restrict__ x, T* __restrict__ y, c
 // convolution (rc_tail_fold_weights).  The two differ on the outermost ring of output pixels only: the second conv zero-pads the SHUFFLED map,
 // the composition sees conv1 evaluated outside the image there.  The ring is recomputed by the two original convolutions on four thin strips of
 // the input (2 rows / 2 columns: output row 0 of the top strip, row 3 of the bottom strip, column 0 / 3 of the side strips are exact).
-//   gather : x (B,H,W,C) -> rows (2B,2,W,C) = [x[:, 0:2], x[:, H-2:H]],  cols (2B,H,2,C) = [x[:, :, 0:2], x[:, :, W-2:W]]
-//   scatter: strip results rows_out (2B,Co,4,2W), cols_out (2B,Co,2H,4) -> ring of out (B,Co,out_h,out_w) (the parts of it inside the crop)
+//   gather : x (B,H,W,C) -> rows (2B,2,W,C) = [x[:, 0:2], x[:, H-2:H]],  cols (2B,2,H,C) = [x[:, :, 0:2], x[:, :, W-2:W]] TRANSPOSED (pixel (r, y) =
+//            x[b, y, r]): a 2-pixel-wide image wastes 15/16 of every 8 x 32 conv tile, so the side strips run as 2 x H images through the same two
+//            convolutions with ky <-> kx swapped (and conv1's sub-pixel order 2i + j <-> 2j + i)
+//   scatter: strip results rows_out (2B,Co,4,2W), cols_out (2B,Co,4,2H) (transposed) -> ring of out (B,Co,out_h,out_w) (the parts inside the crop)
 __global__ void tail_ring_gather_kernel(const uint4* __restrict__ x, uint4* __restrict__ rows, uint4* __restrict__ cols,
                                         int batch, int H, int W, int pix16) {
     const size_t row16 = (size_t)W * pix16, n_rows = (size_t)2 * batch * 2 * row16, n_cols = (size_t)2 * batch * H * 2 * pix16;
@@ -507,8 +509,8 @@ __global__ void tail_ring_gather_kernel(const uint4* __restrict__ x, uint4* __re
         } else {
             size_t p = i - n_rows;
             const int part = (int)(p % pix16); p /= pix16;
-            const int cx = (int)(p % 2); p /= 2;
-            const int y = (int)(p % H); const int img = (int)(p / H);
+            const int y = (int)(p % H); p /= H;
+            const int cx = (int)(p % 2); const int img = (int)(p / 2);
             const int b = img % batch, xx = img < batch ? cx : W - 2 + cx;
             cols[i - n_rows] = x[(((size_t)b * H + y) * W + xx) * pix16 + part];
         }
@@ -533,8 +535,8 @@ __global__ void tail_ring_scatter_kernel(const T* __restrict__ rows_out, const T
             k -= 2 * out_w;
             const int rgt = k >= out_h, Y = rgt ? k - out_h : k;
             if (rgt && !right) continue;
-            const T* src = cols_out + ((size_t)(rgt ? batch + b : b) * co + c) * (2 * H) * 4;
-            o[(size_t)Y * out_w + (rgt ? out_w - 1 : 0)] = src[(size_t)Y * 4 + (rgt ? 3 : 0)];
+            const T* src = cols_out + (((size_t)(rgt ? batch + b : b) * co + c) * 4 + (rgt ? 3 : 0)) * (2 * H);     // transposed strip: row = output column
+            o[(size_t)Y * out_w + (rgt ? out_w - 1 : 0)] = src[Y];
         }
     }
 }

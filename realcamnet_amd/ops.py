@@ -543,8 +543,14 @@ def _folded_tail(conv1, conv2) -> "_ConvView":
     if hit is None or hit[0] != key:
         det = lambda t: None if t is None else t.detach()
         wc, bc = _R.tail_fold_weights(conv1.weight.detach(), det(conv1.bias), conv2.weight.detach(), det(conv2.bias))
-        hit = cache["tail_fold"] = (key, _ConvView(wc, bc))
-    return hit[1]
+        # the two side strips (H x 2 pixels) run TRANSPOSED (2 x H: a 2-pixel-wide image wastes 15/16 of every 8 x 32 tile): the same two convolutions
+        # with ky <-> kx swapped and conv1's sub-pixel order 4c + 2i + j <-> 4c + 2j + i
+        c = conv1.weight.shape[1]
+        perm = (torch.arange(c, device=conv1.weight.device)[:, None] * 4 + torch.tensor([0, 2, 1, 3], device=conv1.weight.device)[None, :]).reshape(-1)
+        v1t = _ConvView(conv1.weight.detach().transpose(2, 3)[perm].contiguous(), None if conv1.bias is None else conv1.bias.detach()[perm].contiguous())
+        v2t = _ConvView(conv2.weight.detach().transpose(2, 3).contiguous(), det(conv2.bias))
+        hit = cache["tail_fold"] = (key, _ConvView(wc, bc), v1t, v2t)
+    return hit[1:]
 
 
 def tail_fold(x: torch.Tensor, conv1, conv2, crop_hw: Optional[Tuple[int, int]] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -553,10 +559,13 @@ def tail_fold(x: torch.Tensor, conv1, conv2, crop_hw: Optional[Tuple[int, int]] 
     b, H, W, _ = x.shape
     odt = out_dtype or x.dtype
 
-    def ring():      # six small launches, independent of the folded one until the scatter: they run beside it on the side stream
-        return [conv2d(conv2d(t, conv1, out_mode=RC_OUT_PIXEL_SHUFFLE2), conv2, out_mode=RC_OUT_NCHW, out_dtype=odt) for t in _R.tail_ring_gather(x)]
+    folded, c1t, c2t = _folded_tail(conv1, conv2)
 
-    strips, out = fork_join(ring, lambda: conv2d(x, _folded_tail(conv1, conv2), out_mode=RC_OUT_PIXEL_SHUFFLE2_NCHW, crop_hw=crop_hw, out_dtype=odt), [x])
+    def ring():      # six small launches, independent of the folded one until the scatter: they run beside it on the side stream
+        rows, cols_t = _R.tail_ring_gather(x)              # (2B,2,W,C), and the side strips transposed: (2B,2,H,C)
+        return [conv2d(conv2d(t, m1, out_mode=RC_OUT_PIXEL_SHUFFLE2), m2, out_mode=RC_OUT_NCHW, out_dtype=odt) for t, m1, m2 in ((rows, conv1, conv2), (cols_t, c1t, c2t))]
+
+    strips, out = fork_join(ring, lambda: conv2d(x, folded, out_mode=RC_OUT_PIXEL_SHUFFLE2_NCHW, crop_hw=crop_hw, out_dtype=odt), [x])
     _R.tail_ring_scatter(out, strips[0], strips[1], H, W)
     return out
 
@@ -757,7 +766,8 @@ def ca_gate_ahead(sums_t: torch.Tensor, t: torch.Tensor, conv2, ca) -> torch.Ten
     cr, c = c0.weight.shape[0], c0.weight.shape[1]
     if tuple(conv2.weight.shape) != (c, c, 3, 3):
         raise ValueError("ca_gate_ahead: conv2 must be a 3x3 convolution C -> C")
-    gate, _ = _R.ca_gate_ahead(sums_t, _req(t, "t"), f32_param(conv2, "weight"), f32_param(conv2, "bias") if conv2.bias is not None else None,
+    w2t, = host_cached(conv2, "w2_cin_tap_cout", [conv2.weight], lambda w: w.permute(1, 2, 3, 0))     # (C_in, 3, 3, C_out): coalesced over C_out
+    gate, _ = _R.ca_gate_ahead(sums_t, _req(t, "t"), w2t, f32_param(conv2, "bias") if conv2.bias is not None else None,
                                f32_param(c0, "weight").reshape(cr, c), f32_param(c0, "bias"), f32_param(c1, "weight").reshape(c, cr), f32_param(c1, "bias"))
     return gate
 

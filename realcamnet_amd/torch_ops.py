@@ -231,7 +231,7 @@ define("tail_fold_weights(Tensor w1, Tensor? b1, Tensor w2, Tensor? b2) -> (Tens
        _tail_fold_launch)
 
 define("tail_ring_gather(Tensor x) -> (Tensor, Tensor)",
-       lambda x: (x.new_empty((2 * x.shape[0], 2, x.shape[2], x.shape[3])), x.new_empty((2 * x.shape[0], x.shape[1], 2, x.shape[3]))),
+       lambda x: (x.new_empty((2 * x.shape[0], 2, x.shape[2], x.shape[3])), x.new_empty((2 * x.shape[0], 2, x.shape[1], x.shape[3]))),
        lambda outs, x: check(lib().rc_tail_ring_gather(x.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), _dt(x), x.shape[0], x.shape[1], x.shape[2],
                                                        x.shape[3], _stream()), "rc_tail_ring_gather"))
 
@@ -334,21 +334,21 @@ define("ca_gate(Tensor(a!) sums, int hw, Tensor w0, Tensor b0, Tensor w1, Tensor
 
 
 
-def _gate_ahead_alloc(sums, t, w2, b2, w0, b0, w1, b1):
+def _gate_ahead_alloc(sums, t, w2t, b2, w0, b0, w1, b1):
     b, c = sums.shape[0], sums.shape[2]
     return sums.new_empty((b, c)), sums.new_empty((b * (4 * 8 + 4) * c,))      # gate, scratch (rc_ca_gate_ahead_scratch_floats)
 
 
-def _gate_ahead_launch(outs, sums, t, w2, b2, w0, b0, w1, b1):
+def _gate_ahead_launch(outs, sums, t, w2t, b2, w0, b0, w1, b1):
     gate, scratch = outs
     b, n_tiles, c = sums.shape
     assert scratch.numel() >= lib().rc_ca_gate_ahead_scratch_floats(b, c)
-    check(lib().rc_ca_gate_ahead(sums.data_ptr(), b, n_tiles, c, w0.shape[0], t.data_ptr(), _dt(t), t.shape[1], t.shape[2], w2.data_ptr(), _p(b2),
+    check(lib().rc_ca_gate_ahead(sums.data_ptr(), b, n_tiles, c, w0.shape[0], t.data_ptr(), _dt(t), t.shape[1], t.shape[2], w2t.data_ptr(), _p(b2),
                                  w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), scratch.data_ptr(), gate.data_ptr(), _stream()), "rc_ca_gate_ahead")
 
 
 # CALayer's gate of conv2(t) from t's channel sums + border lines, before conv2 runs (the mean of a convolution is linear in its input)
-define("ca_gate_ahead(Tensor(a!) sums, Tensor t, Tensor w2, Tensor? b2, Tensor w0, Tensor b0, Tensor w1, Tensor b1) -> (Tensor, Tensor)",
+define("ca_gate_ahead(Tensor(a!) sums, Tensor t, Tensor w2t, Tensor? b2, Tensor w0, Tensor b0, Tensor w1, Tensor b1) -> (Tensor, Tensor)",
        _gate_ahead_alloc, _gate_ahead_launch)
 
 define("gate_residual(Tensor r, Tensor gate, Tensor? x) -> Tensor",

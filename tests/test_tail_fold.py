@@ -46,7 +46,7 @@ def test_folded_weights_equal_the_composition_away_from_the_border(c, o, bias):
 @pytest.mark.parametrize("H,W,crop", [(6, 9, None), (8, 8, (15, 16)), (5, 7, (10, 13)), (2, 2, None), (3, 2, (5, 4))])
 def test_ring_scheme_reproduces_the_two_convolutions_exactly(H, W, crop):
     """ops.tail_fold's algorithm with F.conv2d standing in for the kernels: folded 5x5 everywhere, then output row 0 / 2H-1 from the two-conv result
-    on x[:, 0:2] / x[:, H-2:H] (rows 0 / 3) and column 0 / 2W-1 from x[:, :, 0:2] / x[:, :, W-2:W] (columns 0 / 3), skipping what the crop removes."""
+    on x[:, 0:2] / x[:, H-2:H] (rows 0 / 3) and column 0 / 2W-1 from x[:, :, 0:2] / x[:, :, W-2:W] run transposed (rows 0 / 3 of that result), skipping what the crop removes."""
     g = torch.Generator().manual_seed(H * 100 + W)
     c, o, B = 8, 3, 2
     w1, w2 = torch.randn(4 * c, c, 3, 3, generator=g, dtype=torch.float64), torch.randn(o, c, 3, 3, generator=g, dtype=torch.float64)
@@ -68,13 +68,16 @@ def test_ring_scheme_reproduces_the_two_convolutions_exactly(H, W, crop):
                     bc[rows] += w2[:, :, dy, dx] @ b1[m]
     out = F.pixel_shuffle(F.conv2d(x, wc, bc, padding=2), 2)[:, :, :oh, :ow].clone()
     rows = _two_step(torch.cat([x[:, :, 0:2], x[:, :, H - 2:H]], 0), w1, b1, w2, b2)           # (2B, o, 4, 2W)
-    cols = _two_step(torch.cat([x[:, :, :, 0:2], x[:, :, :, W - 2:W]], 0), w1, b1, w2, b2)     # (2B, o, 2H, 4)
+    # the side strips run TRANSPOSED (2 x H images): ky <-> kx swapped weights, conv1's sub-pixel order 4c + 2i + j <-> 4c + 2j + i (ops._folded_tail)
+    perm = (torch.arange(c)[:, None] * 4 + torch.tensor([0, 2, 1, 3])[None, :]).reshape(-1)
+    w1t, b1t, w2t = w1.transpose(2, 3)[perm], b1[perm], w2.transpose(2, 3)
+    cols_t = _two_step(torch.cat([x[:, :, :, 0:2], x[:, :, :, W - 2:W]], 0).transpose(2, 3), w1t, b1t, w2t, b2)     # (2B, o, 4, 2H)
     out[:, :, 0, :] = rows[:B, :, 0, :ow]
     if oh == 2 * H:
         out[:, :, oh - 1, :] = rows[B:, :, 3, :ow]
-    out[:, :, :, 0] = cols[:B, :, :oh, 0]
+    out[:, :, :, 0] = cols_t[:B, :, 0, :oh]
     if ow == 2 * W:
-        out[:, :, :, ow - 1] = cols[B:, :, :oh, 3]
+        out[:, :, :, ow - 1] = cols_t[B:, :, 3, :oh]
     assert (out - ref).abs().max() <= 1e-12
 
 

@@ -52,7 +52,7 @@ with torch.no_grad():
     for _ in range(10): c1._nhwc(x, out_mode=RC_OUT_PIXEL_SHUFFLE2)
     t_two = timed(lambda: c2._nhwc(c1._nhwc(x, out_mode=RC_OUT_PIXEL_SHUFFLE2), out_mode=RC_OUT_NCHW, crop_hw=crop))
     print(f"two launches (48->192 + PixelShuffle, 48->3): {t_two:.3f} ms")
-    view = ops._folded_tail(c1, c2)
+    view = ops._folded_tail(c1, c2)[0]
     for persist, name in ((1, "persistent, 2 blocks/CU"), (2, "producer/consumer"), (0, "general")):
         L.rc_debug_set(b"persist", persist)
         t = timed(lambda: ops.conv2d(x, view, out_mode=RC_OUT_PIXEL_SHUFFLE2_NCHW, crop_hw=crop))
