@@ -512,11 +512,14 @@ int rc_window_attention(const void* d_qkv, const float* d_relpos, void* d_out, i
  * wherever eligible, 3 = persistent only.  Results must be identical in all modes.
  * Others (all bit-identical alternatives of one operation, defaults in brackets): "conv32" [4] which layers take the
  * 32x32x16 MFMA forms (0 none, 4 = where measured faster, 1 / 2 / 3 = everywhere eligible in one of three forms; set BEFORE
- * packing: the packed weight order depends on it); "pair_impl" [0] which of the two rc_conv_pair kernels; "pss" [0] the
+ * packing: the packed weight order depends on it -- and on no other knob: such a layer runs its own kernel in every "persist" mode); "pair_impl" [0] which of the two rc_conv_pair kernels; "pss" [0] the
  * 48 -> 192 + PixelShuffle layer with its output staged through LDS; "dw3_seg16" [1] rc_dwconv2d's bf16 3x3 single-rep
  * case on 16-channel segments; "conv_flags" knock-outs for timing experiments (1 no stores, 8 stores into one 4 MB
  * window: results are then meaningless). */
 int rc_debug_set(const char* key, int value);
+/* Current value of an integer knob ("persist", "conv32", "conv_flags", "pss"), -1 for an unknown key.  The host mirror keys its packed-weight cache
+ * on "conv32" (the packed order of the 32x32x16 layers depends on it and on nothing else). */
+int rc_debug_get(const char* key);
 /* "conv_phase_timing": device buffer of >= 512 int64; the producer/consumer conv kernel then records s_memtime
  * cycle counts per tile phase for one compute wave and one loader wave (NULL switches it off). */
 int rc_debug_set_ptr(const char* key, void* d_ptr);

@@ -155,6 +155,7 @@ _SIGS = {
     "rc_rans_encode_host": (C.c_longlong, [_P, _P, C.c_longlong, _P, _I, _I, _P, _P, _P, C.c_longlong]),
     "rc_rans_decode_host": (C.c_int, [_P, C.c_longlong, _P, _P, C.c_longlong, _P, _I, _I, _P, _P, _P]),
     "rc_debug_set": (C.c_int, [C.c_char_p, _I]),
+    "rc_debug_get": (C.c_int, [C.c_char_p]),
     "rc_debug_set_ptr": (C.c_int, [C.c_char_p, _P]),
     "rc_prof_enable": (C.c_int, [_I]),
     "rc_prof_collect": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

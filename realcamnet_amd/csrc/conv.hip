@@ -60,9 +60,11 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
     else if (cout % 48 == 0) p->nt = 3;
     else p->nt = 1;
     // 32x32x16 form: 3x3 bf16 layers whose weights are streamed (several 32-channel chunks, or the one-chunk 48 -> 192 layers) and whose
-    // couts fill whole 32-row tiles.  The packed order differs, so the choice depends on the shape (and the debug knobs) only.
+    // couts fill whole 32-row tiles.  The packed order differs, so the choice depends on the shape and on the `conv32` knob ONLY (not on `persist`:
+    // a 32x32x16 layer runs its own kernel in every persist mode) -- weights packed under one conv32 setting must not be used under another
+    // (rc_debug_get("conv32") is part of the host mirror's pack-cache key).
     p->m32 = 0;
-    if (dtype == RC_BF16 && ksize == 3 && g_conv32 != 0 && g_persist_on != 0 && cout <= kPersistMaxCout && out_mode != RC_OUT_NCHW && out_mode != RC_OUT_PIXEL_SHUFFLE2_NCHW) {
+    if (dtype == RC_BF16 && ksize == 3 && g_conv32 != 0 && cout <= kPersistMaxCout && out_mode != RC_OUT_NCHW && out_mode != RC_OUT_PIXEL_SHUFFLE2_NCHW) {
         const int cw = out_mode == RC_OUT_PIXEL_SHUFFLE2 ? cout / 4 : cout;          // channels a lane's 16-value run must tile
         const bool all = g_conv32 != 4;
         if (all && p->ck == 32 && cin % 32 == 0 && (out_mode == RC_OUT_PIXEL_SHUFFLE2 ? cw % 32 == 0 : cw % 64 == 0)) { p->m32 = 1; p->nt = 2; p->ck = (g_conv32 == 1 && out_mode == RC_OUT_NHWC) ? 16 : 32; }
@@ -260,6 +262,15 @@ int rc_debug_set(const char* key, int value) {
     return fail(RC_ERR_INVALID, std::string("rc_debug_set: unknown key ") + key);
 }
 
+int rc_debug_get(const char* key) {
+    if (key == nullptr) return -1;
+    if (std::string(key) == "persist") return g_persist_on;
+    if (std::string(key) == "conv32") return g_conv32;
+    if (std::string(key) == "conv_flags") return g_dbg_flags;
+    if (std::string(key) == "pss") return g_pss;
+    return -1;
+}
+
 int rc_debug_set_ptr(const char* key, void* p) {
     RC_REQUIRE(key != nullptr, "rc_debug_set_ptr: null key");
     if (std::string(key) == "conv_phase_timing") { g_dbg_ptr = static_cast<long long*>(p); return RC_OK; }
@@ -341,6 +352,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
         RC_REQUIRE(d->src_h >= 1 && d->src_w >= 1 && d->height == (d->src_h + 1) / 2 && d->width == (d->src_w + 1) / 2,
                    "rc_conv2d: height/width must be ceil(src_h / 2), ceil(src_w / 2)");
         RC_REQUIRE(d->in_gate == nullptr && d->in1 == nullptr && d->in_store == nullptr, "rc_conv2d: src_h/src_w exclude the gated input");
+        RC_REQUIRE(reinterpret_cast<uintptr_t>(d->in0) % 16 == 0, "rc_conv2d: src_h/src_w need a 16-byte aligned in0 (the scalar staging path does not gather)");
         RC_REQUIRE((double)d->src_h * d->src_w * (d->cin / 4) * es < 2147483647.0, "rc_conv2d: one input image must be < 2 GiB");
     }
     if (d->residual) RC_REQUIRE(reinterpret_cast<uintptr_t>(d->residual) % 16 == 0, "rc_conv2d: residual must be 16-byte aligned");

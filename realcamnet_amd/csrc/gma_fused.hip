@@ -1241,6 +1241,8 @@ __global__ __launch_bounds__(lsc_threads<C>(), 2) void lsc_chain_kernel(const Ls
             char* st = s_stage + (tid >> 6) * (64 * C * 2);
 #pragma unroll
             for (int nt = 0; nt < kNT; ++nt) store_act<C>(reinterpret_cast<bf16_t*>(st) + (16 * nt + n) * C, g, cur[nt]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                         // other lanes' writes are read back below: keep the compiler from
+            __builtin_amdgcn_wave_barrier();                                               // moving the reads above them (the LDS queue itself is in order)
             const long long left = (a.pixels - tile * 64) * (C * 2);                       // bytes of this tile inside the tensor
             const __amdgpu_buffer_rsrc_t r_o = __builtin_amdgcn_make_buffer_rsrc(a.out + tile * 64 * C, 0, (int)(left < 64 * C * 2 ? left : 64 * C * 2), 0x00020000);
 #pragma unroll
@@ -1321,8 +1323,8 @@ extern "C" int rc_lsc_chain(const void* d_x, int cin0, const void* d_blob, int c
     a.raw = static_cast<const bf16_t*>(d_raw); a.raw_c = raw_c; a.out = static_cast<bf16_t*>(d_out);
     a.pixels = (long long)batch * H * W; a.H = H; a.W = W;
     size_t lds = rc_lsc_packed_bytes(c, n_mid, d_raw != nullptr);
-    RC_REQUIRE(lds <= 150 * 1024, "rc_lsc_chain: weights do not fit LDS");
     if (c <= 64) lds = ((lds + 15) & ~(size_t)15) + 4 * 64 * (size_t)c * 2;            // + the four waves' output staging (lsc_chain_kernel)
+    RC_REQUIRE(lds <= 150 * 1024, "rc_lsc_chain: weights (+ output staging) do not fit LDS");
     const long long tiles = (a.pixels + 63) / 64;
     const int wpb = (c > 64 ? 512 : 256) / 64;
     long long grid = (tiles + wpb - 1) / wpb;

@@ -334,14 +334,23 @@ __global__ __launch_bounds__(64) void decode_chunks_lds_kernel(const uint8_t* st
         s_total = ok ? acc : -1;
     }
     __syncthreads();
-    const bool in_lds = s_total >= 0;
-    if (in_lds)
+    // 16-bit LDS entries assume a well-formed row: row[0] == 0 and only the LAST entry equal to 65536 (stored as 0, never compared).  A row that
+    // breaks this would make the LDS search differ from decode_range's: such tables take the global-memory path (s_total = -1) instead.
+    __shared__ int s_bad;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    if (s_total >= 0)
         for (int r = 0; r < t.n_cdfs; ++r) {
             const int sz = s_size[r], st0 = s_start[r];
             const int32_t* row = t.cdf + (long)r * t.stride;
-            for (int j = tid; j < sz; j += 64) s_cdf[st0 + j] = (uint16_t)row[j];
+            for (int j = tid; j < sz; j += 64) {
+                const int32_t v = row[j];
+                if ((j == 0 && v != 0) || v < 0 || (j < sz - 1 ? v >= 65536 : v > 65536)) s_bad = 1;     // benign race: every writer stores 1
+                s_cdf[st0 + j] = (uint16_t)v;
+            }
         }
     __syncthreads();
+    const bool in_lds = s_total >= 0 && s_bad == 0;
 
     // only `lanes` lanes of the wave decode (the others helped to fill the LDS)
     const long c = (long)blockIdx.x * lanes + tid;

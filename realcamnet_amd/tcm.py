@@ -412,6 +412,10 @@ def _resize_coder_buffers(mod, prefix: str, names, state_dict) -> None:
     mod.__dict__.pop("_coder_tables", None)
 
 
+import inspect as _inspect
+_APPLY_TAKES_RECURSE = "recurse" in _inspect.signature(nn.Module._apply).parameters      # torch >= 2.0; older: _apply(fn)
+
+
 class _Fp32Masters:
     """fp32 master copies of the tensors the CODER depends on (CDF-index thresholds, medians, the density's parameters).  `.to(bfloat16)`
     rounds a module's floating-point parameters and buffers; thresholds and medians rounded on one side only make a stream that does not
@@ -432,11 +436,14 @@ class _Fp32Masters:
         # snapshot first: nn.Module._apply swaps a Parameter's .data in place, so the "old" object would show the new dtype afterwards
         pre = {n: getattr(self, n).detach().clone() for n in self._MASTER_NAMES
                if getattr(self, n).dtype == torch.float32 and getattr(self, n).numel() > 0}
-        out = super()._apply(fn, recurse) if recurse is True else super()._apply(fn)
+        out = super()._apply(fn, recurse) if _APPLY_TAKES_RECURSE else super()._apply(fn)
         for n in self._MASTER_NAMES:
             new = getattr(self, n)
             if new.dtype == torch.float32:
-                masters.pop(n, None)                                  # the live tensor is exact (again)
+                m = masters.pop(n, None)
+                if m is not None and m.shape == new.shape:            # back to fp32 after a rounding cast: restore what the cast rounded, so
+                    with torch.no_grad():                             # .to(bf16).float() leaves the coder's tensors exact (tables stay identical)
+                        new.copy_(m.to(new.device))
             elif n in pre:
                 masters[n] = pre[n]                                   # this cast rounded an fp32 tensor: keep what it rounded
             if n in masters:

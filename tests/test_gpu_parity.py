@@ -780,7 +780,7 @@ def test_bench_codec_leg_prints_one_contract_json_line(hip):
         assert k in d, k
     assert d["unit"] == "MP/s" and d["value"] > 0 and "raw_compression_tcm_final" in d["config"]["workload"]
     assert d["cpu_baseline"]["kind"] == "port" and d["psnr_db_vs_cpu_fp32"]["y (latent, before rounding)"] >= 55.0
-    assert d["psnr_db_vs_cpu_fp32"]["x_hat"] >= 38.0
+    assert d["psnr_db_vs_cpu_fp32"]["x_hat"] >= 41.0
 
 
 def test_forward_is_hip_graph_capturable(hip):

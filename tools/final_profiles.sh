@@ -2,7 +2,7 @@
 # Round-end evidence: PMC traffic passes, kernel-trace of the bench command, default bench line (with CPU baseline),
 # the other table rows, MFMA calibration.  usage: tools/final_profiles.sh TAG [ROUND]   (outputs under gpurun_out/)
 TAG=${1:-fin}
-ROUND=${2:-r03}
+ROUND=${2:-r04}
 mkdir -p gpurun_out
 bash tools/pmc_bench.sh $TAG > gpurun_out/pmc_${TAG}.log 2>&1
 
@@ -36,5 +36,6 @@ mkdir -p gpurun_out/profiles_$TAG
 cp gpurun_out/tail_$TAG.txt gpurun_out/codec_probes_$TAG.txt gpurun_out/store_issue_$TAG.txt gpurun_out/profiles_$TAG/ 2>/dev/null
 python tools/write_profiles.py $TAG $ROUND gpurun_out/profiles_$TAG > gpurun_out/profiles_$TAG/summary.json 2> gpurun_out/write_profiles_$TAG.err
 mkdir -p gpurun_out/keep_$TAG && cp gpurun_out/prof_$TAG/trace_results.db gpurun_out/keep_$TAG/bench_trace_results.db 2>/dev/null
+cp gpurun_out/prof_codec_$TAG/trace_results.db gpurun_out/keep_$TAG/codec_trace_results.db 2>/dev/null
 rm -rf gpurun_out/prof_* gpurun_out/pmc_${TAG}_* gpurun_out/pmcm_${TAG}_*
 du -sh gpurun_out

@@ -59,11 +59,19 @@ def short(name: str) -> str:
     return name if len(name) <= 90 else name[:87] + "..."
 
 
-def main(path):
+def main(path, last_forwards=0, marker="raw_ingest_kernel"):
+    """last_forwards = N > 0: steady state only -- the dispatches from the N-th last launch of `marker` (a kernel every forward starts with) on, so the
+    first forward's weight packing (H2D copies, bf16 -> f32 conversions) is out of the table."""
     db = sqlite3.connect(path)
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     namecol = "name" if "name" in cols else "kernel_name"
-    rows = db.execute(f"select {namecol}, start, end from kernels").fetchall()
+    rows = db.execute(f"select {namecol}, start, end from kernels order by start").fetchall()
+    if last_forwards > 0:
+        marks = [s for name, s, e in rows if marker in name]
+        if len(marks) >= last_forwards:
+            t0 = marks[-last_forwards]
+            rows = [r for r in rows if r[1] >= t0]
+            print(f"steady state: the last {last_forwards} forwards (from the {len(marks) - last_forwards + 1}-th of {len(marks)} `{marker}` launches on)\n")
     agg = {}
     for name, s, e in rows:
         k = short(name)
@@ -78,4 +86,8 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if "--last-forwards" in sys.argv:
+        i = sys.argv.index("--last-forwards")
+        main(sys.argv[1], int(sys.argv[i + 1]), *(sys.argv[i + 2:i + 3]))
+    else:
+        main(sys.argv[1])

@@ -10,12 +10,12 @@ G = "gpurun_out"
 last = lambda p: open(p).read().strip().splitlines()[-1]
 shutil.copy(f"{G}/pmc_{tag}.json", f"{OUT}/{RND}_pmc_bench.json")
 trace, default = last(f"{G}/bench_trace_{tag}.json"), last(f"{G}/bench_default_{tag}.json")
-summ = subprocess.run([sys.executable, "tools/rocpd_summary.py", f"{G}/prof_{tag}/trace_results.db"], capture_output=True, text=True).stdout
+summ = subprocess.run([sys.executable, "tools/rocpd_summary.py", f"{G}/prof_{tag}/trace_results.db", "--last-forwards", "4"], capture_output=True, text=True).stdout
 open(f"{OUT}/{RND}_bench_kernel_stats.md", "w").write(f"""# {RND} — kernel trace of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-codec-leg` (cfg3, 1x MI355X)
 
 Command: `rocprofv3 --kernel-trace --stats -d gpurun_out/prof_{tag} -o trace -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline`
-(5 forwards in the trace: 1 warm-up + 3 timed + 1 HIP-event profiling pass). Summarised from the rocpd database with
-`tools/rocpd_summary.py`. The conv kernels (`conv_mfma_*`) sum to the `kernel_ms_per_step` that `bench.py` measures live with
+(5 forwards in the trace: 1 warm-up + 3 timed + 1 HIP-event profiling pass; the table counts the LAST FOUR -- steady state, the first forward's weight
+packing is out). Summarised from the rocpd database (kept: `gpurun_out/keep_{tag}/bench_trace_results.db`) with `tools/rocpd_summary.py --last-forwards 4`. The conv kernels (`conv_mfma_*`) sum to the `kernel_ms_per_step` that `bench.py` measures live with
 HIP events on the launch stream.
 
 ```
@@ -73,7 +73,7 @@ Conv kernels: {d['conv_kernels_all']['dispatches']} dispatches, {d['conv_kernels
 {tb}
 """)
 codec = last(f"{G}/bench_codec_{tag}.json")
-csumm = subprocess.run([sys.executable, "tools/rocpd_summary.py", f"{G}/prof_codec_{tag}/trace_results.db"], capture_output=True, text=True).stdout
+csumm = subprocess.run([sys.executable, "tools/rocpd_summary.py", f"{G}/prof_codec_{tag}/trace_results.db", "--last-forwards", "2"], capture_output=True, text=True).stdout
 open(f"{OUT}/{RND}_rawcodec_kernel_stats.md", "w").write(f"""# {RND} — RAW codec leg: `python bench.py --model raw_compression_tcm_final --frames 4` (cfg5 shape on one GPU, bf16, 1x MI355X)
 
 Default run (steps 5, warm-up 2, CPU baseline leg on):
@@ -83,7 +83,8 @@ Default run (steps 5, warm-up 2, CPU baseline leg on):
 ```
 
 Kernel trace: `rocprofv3 --kernel-trace --stats -- python bench.py --model raw_compression_tcm_final --frames 4 --steps 2 --warmup 1 --no-cpu-baseline`
-(3 forwards of 4 frames + weight packing in the trace), summarised with `tools/rocpd_summary.py`:
+(3 forwards of 4 frames in the trace; the table counts the LAST TWO -- steady state, weight packing and its copies are out), summarised with
+`tools/rocpd_summary.py --last-forwards 2`:
 
 {csumm}
 
