@@ -117,7 +117,7 @@ class _LaunchCounter(TorchDispatchMode):
         return func(*args, **(kwargs or {}))
 
 
-def codec_leg(dev, dt, H2, W2, frames=4, steps=6, warmup=2, with_psnr=True):
+def codec_leg(dev, dt, H2, W2, frames=8, steps=4, warmup=2, with_psnr=True):
     """SURVEY cfg5's one-GPU shape inside the default run: raw_compression_tcm_final.forward_mosaic (models/raw2bit.py:1766-1855, likelihood
     path, no entropy coder) on `frames` 4K mosaics, timed after a warm-up that also packs the weights.  Returned as the extra key
     `codec_leg`; the contract keys of the headline line are untouched."""
@@ -300,7 +300,7 @@ def main():
     if world == 1 and cfg_name == "cfg3" and not args.no_codec_leg:
         del out, gathered
         torch.cuda.empty_cache()
-        res["codec_leg"] = codec_leg(dev, dt, H2, W2, frames=4, with_psnr=not args.no_cpu_baseline)
+        res["codec_leg"] = codec_leg(dev, dt, H2, W2, frames=args.frames, steps=4, with_psnr=not args.no_cpu_baseline)     # cfg5: the same frames per GPU as the headline (8)
     if world == 1 and not args.no_cpu_baseline:
         info, (m_c, c_c, co_c, ref) = cpu_baseline(args.model, sd_cpu, (H2, W2))
         with torch.no_grad():

@@ -384,7 +384,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
         if (d->film_scale)
             fast = fast && d->cout % 4 == 0 && reinterpret_cast<uintptr_t>(d->film_scale) % 16 == 0 && reinterpret_cast<uintptr_t>(d->film_shift) % 16 == 0;
         if (d->out_scale) fast = fast && d->cout % 4 == 0 && reinterpret_cast<uintptr_t>(d->out_scale) % 16 == 0;
-        switch (key) { case 0: case 1: case 2: case 16: case 32: case 8: case 6: case 33: case 80: break; default: fast = false; }
+        switch (key) { case 0: case 1: case 2: case 16: case 32: case 8: case 6: case 33: case 34: case 80: break; default: fast = false; }
         a.ep_key = fast ? key : -1;
         // a cout tile of a single-chunk pixel-shuffle layer with cout = 4 cout tiles is one sub-pixel of every pixel: kernel 5
         a.pss = g_pss && d->out_mode == RC_OUT_PIXEL_SHUFFLE2 && !p.m32 && p.n_chunks == 1 && p.n_ct == 4 && d->cout == 4 * 16 * p.nt &&

@@ -761,14 +761,21 @@ EARLY_GATE = True
 
 
 def ca_gate_ahead(sums_t: torch.Tensor, t: torch.Tensor, conv2, ca) -> torch.Tensor:
-    """CALayer gate (B,C) of conv2(t) from t's channel partial sums (emitted by the conv that produced t) and t itself (border lines only)."""
-    c0, c1 = ca.conv_du[0], ca.conv_du[2]
+    """CALayer gate (B,C) of conv2(t) from t's channel partial sums (emitted by the conv that produced t) and t itself (border lines only).
+    `ca`: networks.CALayer (1x1 convs with bias, upstream models/networks.py:255-270) or raw2bit.CALayer (bias-free Linears, models/raw2bit.py:238-254)."""
+    if hasattr(ca, "conv_du"):
+        c0, c1 = ca.conv_du[0], ca.conv_du[2]
+    else:
+        c0, c1 = ca.fc[0], ca.fc[2]
     cr, c = c0.weight.shape[0], c0.weight.shape[1]
     if tuple(conv2.weight.shape) != (c, c, 3, 3):
         raise ValueError("ca_gate_ahead: conv2 must be a 3x3 convolution C -> C")
+    z = _const(0.0, (max(c, cr),), sums_t)
+    b0 = f32_param(c0, "bias") if c0.bias is not None else z
+    b1 = f32_param(c1, "bias") if c1.bias is not None else z
     w2t, = host_cached(conv2, "w2_cin_tap_cout", [conv2.weight], lambda w: w.permute(1, 2, 3, 0))     # (C_in, 3, 3, C_out): coalesced over C_out
     gate, _ = _R.ca_gate_ahead(sums_t, _req(t, "t"), w2t, f32_param(conv2, "bias") if conv2.bias is not None else None,
-                               f32_param(c0, "weight").reshape(cr, c), f32_param(c0, "bias"), f32_param(c1, "weight").reshape(c, cr), f32_param(c1, "bias"))
+                               f32_param(c0, "weight").reshape(cr, c), b0, f32_param(c1, "weight").reshape(c, cr), b1)
     return gate
 
 

@@ -44,10 +44,14 @@ class ResidualBlockWithCA(nn.Module):
         self.skip = conv1x1(in_ch, out_ch) if in_ch != out_ch else None
 
     def _nhwc(self, a):
+        identity = a if self.skip is None else self.skip._nhwc(a)
+        if ops.EARLY_GATE and tuple(self.conv2.weight.shape[2:]) == (3, 3) and self.conv2.weight.shape[0] == self.conv2.weight.shape[1]:
+            # the gate of conv2's output from conv1's channel sums, ahead of conv2 (ops.ca_gate_ahead); conv2's epilogue writes conv2(t) * gate + skip
+            t, sums = self.conv1._nhwc(a, act="leaky", slope=float(self.leaky_relu.negative_slope), want_sums=True)
+            return self.conv2._nhwc(t, out_scale=ops.ca_gate_ahead(sums, t, self.conv2, self.ca), residual=identity)
         t = self.conv1._nhwc(a, act="leaky", slope=float(self.leaky_relu.negative_slope))
         r, sums = self.conv2._nhwc(t, want_sums=True)
         gate = ops.ca_gate_linear(sums, a.shape[1] * a.shape[2], self.ca.fc[0], self.ca.fc[2])
-        identity = a if self.skip is None else self.skip._nhwc(a)
         return ops.gate_residual(r, gate, identity)
 
     def forward(self, x):
