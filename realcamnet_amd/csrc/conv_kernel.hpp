@@ -760,21 +760,6 @@ struct ConvDev {
             }
             int oo = (valid && !(a.dbg_flags & 1)) ? o_off0 + dy * o_row + dx * o_col : kOOB;
             if ((a.dbg_flags & 8) && oo != kOOB) oo &= 0x3fffff;      // knock-out: every store lands in one 4 MB window (L2-resident: no HBM write stream)
-            if constexpr (ES == 2 && NV >= 8 && NV % 4 == 0) {
-                if ((a.dbg_flags & 32) && a.out_mode == RC_OUT_NHWC) {     // timing experiment (WRONG channel order): a store instruction's 4 lane groups write 64
-                    // contiguous bytes of a pixel (piece p of lane group q at 64 p + 16 q) instead of four 16-byte pieces 2 NV bytes apart
-                    unsigned w[NV / 2];
-#pragma unroll
-                    for (int i = 0; i < NV / 2; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-                    const int pb = oo == kOOB ? kOOB : oo - q * NV * ES;
-#pragma unroll
-                    for (int p = 0; p < NV / 8; ++p)
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[4 * p], w[4 * p + 1], w[4 * p + 2], w[4 * p + 3]}, r_out, pb == kOOB ? kOOB : pb + 64 * p + 16 * q, 0, 0);
-                    if constexpr (NV % 8 != 0)
-                        __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{w[NV / 2 - 2], w[NV / 2 - 1]}, r_out, pb == kOOB ? kOOB : pb + 64 * (NV / 8) + 8 * q, 0, 0);
-                    continue;
-                }
-            }
             buf_store_row<T, NV, PK_RELU>(r_out, oo, v);
         }
         if constexpr ((F & EP_SUMS) != 0) {
