@@ -98,7 +98,8 @@ int rc_nhwc_to_nchw(const void* d_src, int src_dtype, void* d_dst, int dst_dtype
  */
 typedef struct rc_conv_desc {
     int32_t batch, height, width;   /* input spatial size == conv output size                     */
-    int32_t cin, cout, ksize;       /* ksize: 1 or 3 (zero padding ksize/2); 5 (bf16, cin = 48, cout <= 16: the folded tail, rc_tail_fold_weights);
+    int32_t cin, cout, ksize;       /* ksize: 1 or 3 (zero padding ksize/2); 5 (cout <= 16; bf16 with cin % 48 == 0 or cin % 32 == 0, fp32 with cin % 16 == 0:
+                                       the folded tail, rc_tail_fold_weights);
                                        2 (bf16, cin % 16 == 0, RC_OUT_NHWC only): the 2x2 window
                                        at pixel offsets {-1, 0}^2, weights (cout, cin, 2, 2) -- the non-zero taps of a stride-2 3x3
                                        convolution (compressai conv3x3(stride=2), ResidualBlockWithStride; models/tcm.py:336-345) taken
@@ -169,7 +170,7 @@ size_t rc_conv_desc_size(void);
  * folded weights are structurally zero).  It does 19 200 instead of 88 128 MACs per packed pixel and the 2H x 2W x C intermediate map (6.4 GB
  * written + 7.7 GB read per 8 frames of 4K) never exists.
  *   rc_tail_fold_weights (host): w1 (4C,C,3,3), b1 (4C) or NULL, w2 (O,C,3,3), b2 (O) or NULL -> wc (4O,C,5,5), bc (4O); accumulated in
- *     double.  Run the result as rc_conv2d ksize 5 (bf16, C = 48, 4O <= 16) with RC_OUT_PIXEL_SHUFFLE2_NCHW.
+ *     double.  Run the result as rc_conv2d ksize 5 (4O <= 16; bf16 C = 48 k / 32 k, fp32 C = 16 k) with RC_OUT_PIXEL_SHUFFLE2_NCHW.
  * The fold is exact everywhere except the outermost ring of output pixels (the second convolution zero-pads the shuffled map; the fold sees
  * conv1 evaluated beyond the edge there).  The ring is recomputed with the two original convolutions on four thin strips:
  *   rc_tail_ring_gather : x NHWC (B,H,W,C) -> rows (2B,2,W,C) = [x[:,0:2], x[:,H-2:H]], cols (2B,2,H,C) = [x[:,:,0:2], x[:,:,W-2:W]] TRANSPOSED

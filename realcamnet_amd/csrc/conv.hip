@@ -25,14 +25,15 @@ static int g_conv32 = 4;           // rc_debug_set("conv32", v): which layers ta
 static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, ConvPlan* p) {
     if (cin < 1 || cout < 1 || (ksize != 1 && ksize != 3 && ksize != 2 && ksize != 5)) return false;
     if (dtype != RC_F32 && dtype != RC_BF16) return false;
-    // ksize 5: the folded tail (rc_tail_fold_weights): bf16, 48 input channels, one 16-wide cout tile
-    if (ksize == 5 && (dtype != RC_BF16 || cin != 48 || cout > 16 || out_mode == RC_OUT_PIXEL_SHUFFLE2)) return false;
+    // ksize 5: the folded tail (rc_tail_fold_weights): one 16-wide cout tile; bf16 with 48 k or 32 k input channels, fp32 with 16 k
+    if (ksize == 5 && (cout > 16 || out_mode == RC_OUT_PIXEL_SHUFFLE2 || (dtype == RC_BF16 ? (cin % 48 != 0 && cin % 32 != 0) : cin % 16 != 0))) return false;
     if (out_mode == RC_OUT_PIXEL_SHUFFLE2_NCHW && cout % 4 != 0) return false;
     // ksize 2: the 2x2 window at pixel offsets {-1, 0}^2 = the non-zero taps of a stride-2 3x3 convolution over its space-to-depth map
     // (bf16, Cin a multiple of 16 that is not routed to the 8- / 48- / 80-wide chunk forms; plain NHWC store)
     if (ksize == 2 && (dtype != RC_BF16 || cin % 16 != 0 || out_mode != RC_OUT_NHWC || (cin % 48 == 0 && cin % 64 != 0))) return false;
     p->unit = dtype == RC_F32 ? 4 : 8;
-    if (dtype == RC_BF16) {
+    if (ksize == 5) p->ck = dtype == RC_BF16 ? (cin % 48 == 0 ? 48 : 32) : 16;      // 25 taps: chunks that keep halo tile + weights inside 80 KB of LDS
+    else if (dtype == RC_BF16) {
         if (cin <= 8) p->ck = 8;
         else if (ksize == 1 && cin % 80 == 0 && cin % 64 != 0) p->ck = 80;   // GroupMix dims (80, 240, 320 -> 64)
         else if (ksize >= 2 && cin % 64 == 0 && cin > 64) p->ck = 32;         // multi-chunk layers: 32-channel chunks so two

@@ -7,6 +7,8 @@ int conv_bf16_k3_ck32(int nt, const ConvArgs& a, hipStream_t s);
 int conv_bf16_k3_ck48(int nt, const ConvArgs& a, hipStream_t s);
 int conv_bf16_k3_ck64(int nt, const ConvArgs& a, hipStream_t s);
 int conv_bf16_k5_ck48(int nt, const ConvArgs& a, hipStream_t s);
+int conv_bf16_k5_ck32(int nt, const ConvArgs& a, hipStream_t s);
+int conv_f32_k5_ck16(int nt, const ConvArgs& a, hipStream_t s);
 int conv_bf16_k2_ck16(int nt, const ConvArgs& a, hipStream_t s);
 int conv_bf16_k2_ck32(int nt, const ConvArgs& a, hipStream_t s);
 int conv_bf16_k2_ck64(int nt, const ConvArgs& a, hipStream_t s);
@@ -27,6 +29,8 @@ int dispatch_conv(bool bf16, int ksize, int ck, int nt, const ConvArgs& a, hipSt
     if (bf16 && ksize == 3 && ck == 48) return conv_bf16_k3_ck48(nt, a, s);
     if (bf16 && ksize == 3 && ck == 64) return conv_bf16_k3_ck64(nt, a, s);
     if (bf16 && ksize == 5 && ck == 48) return conv_bf16_k5_ck48(nt, a, s);
+    if (bf16 && ksize == 5 && ck == 32) return conv_bf16_k5_ck32(nt, a, s);
+    if (!bf16 && ksize == 5 && ck == 16) return conv_f32_k5_ck16(nt, a, s);
     if (bf16 && ksize == 2 && ck == 16) return conv_bf16_k2_ck16(nt, a, s);
     if (bf16 && ksize == 2 && ck == 32) return conv_bf16_k2_ck32(nt, a, s);
     if (bf16 && ksize == 2 && ck == 64) return conv_bf16_k2_ck64(nt, a, s);

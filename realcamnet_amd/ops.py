@@ -531,9 +531,13 @@ FOLD_TAIL = True
 
 
 def tail_fold_ok(x: torch.Tensor, conv1, conv2) -> bool:
+    """conv(C -> 4C, 3x3) -> PixelShuffle(2) -> conv(C -> O, 3x3) with a 5x5 kernel instantiation for (C, 4 O, dtype): bf16 C = 48 k / 32 k, fp32 C = 16 k."""
     w1, w2 = conv1.weight, conv2.weight
-    return (FOLD_TAIL and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[-1] == 48 and x.shape[1] >= 2 and x.shape[2] >= 2 and
-            w1.dim() == 4 and tuple(w1.shape) == (192, 48, 3, 3) and w2.dim() == 4 and w2.shape[1:] == (48, 3, 3) and 4 * w2.shape[0] <= 16)
+    if not (FOLD_TAIL and x.dim() == 4 and x.dtype in _DT and x.shape[1] >= 2 and x.shape[2] >= 2 and w1.dim() == 4 and w2.dim() == 4):
+        return False
+    c = x.shape[-1]
+    return (tuple(w1.shape) == (4 * c, c, 3, 3) and tuple(w2.shape[1:]) == (c, 3, 3) and 4 * w2.shape[0] <= 16 and
+            _lib.load().rc_conv_packed_bytes(c, 4 * w2.shape[0], 5, _DT[x.dtype], RC_OUT_PIXEL_SHUFFLE2_NCHW) != 0)
 
 
 def _folded_tail(conv1, conv2) -> "_ConvView":

@@ -29,7 +29,8 @@ def test_conv_desc_layout_matches_header():
 
 def test_bad_arguments_are_reported_not_fixed():
     lib = _lib.load()
-    assert lib.rc_conv_packed_bytes(16, 16, 5, RC_F32, RC_OUT_NHWC) == 0          # 5x5 unsupported
+    assert lib.rc_conv_packed_bytes(16, 16, 7, RC_F32, RC_OUT_NHWC) == 0          # 7x7 unsupported (5x5: the folded tail only, cout <= 16)
+    assert lib.rc_conv_packed_bytes(16, 32, 5, RC_F32, RC_OUT_NHWC) == 0
     assert b"bad shape" in lib.rc_last_error()
     assert lib.rc_conv2d(None, None) < 0
     assert lib.rc_bayer_unshuffle(None, RC_F32, None, RC_F32, 1, 4, 4, 4, 4, None) < 0

@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from realcamnet_amd import _lib
-from realcamnet_amd._lib import RC_BF16, RC_OUT_NCHW, RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_PIXEL_SHUFFLE2_NCHW
+from realcamnet_amd._lib import RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_PIXEL_SHUFFLE2_NCHW
 
 
 def _fold(w1, b1, w2, b2):
@@ -86,7 +86,10 @@ def test_5x5_plan_is_reported_and_bounded():
     assert lib.rc_conv_packed_bytes(48, 12, 5, RC_BF16, RC_OUT_PIXEL_SHUFFLE2_NCHW) == 38 * 1024       # 25 + 13 MFMA steps of one 16-row tile
     assert lib.rc_conv_packed_cout(48, 12, 5, RC_BF16, RC_OUT_PIXEL_SHUFFLE2_NCHW) == 16
     assert lib.rc_conv_packed_bytes(48, 48, 5, RC_BF16, RC_OUT_NHWC) == 0                              # one cout tile only
-    assert lib.rc_conv_packed_bytes(64, 12, 5, RC_BF16, RC_OUT_NHWC) == 0                              # 48 input channels only
+    assert lib.rc_conv_packed_bytes(64, 12, 5, RC_BF16, RC_OUT_NHWC) == 2 * 25 * 1024                  # 64 channels: two 32-channel chunks of 25 steps
+    assert lib.rc_conv_packed_bytes(32, 12, 5, RC_BF16, RC_OUT_NHWC) == 25 * 1024
+    assert lib.rc_conv_packed_bytes(64, 12, 5, RC_F32, RC_OUT_NHWC) == 4 * 25 * 1024                   # fp32: 16-channel chunks
+    assert lib.rc_conv_packed_bytes(40, 12, 5, RC_BF16, RC_OUT_NHWC) == 0 and lib.rc_conv_packed_bytes(24, 12, 5, RC_F32, RC_OUT_NHWC) == 0
     assert lib.rc_conv_packed_bytes(48, 10, 3, RC_BF16, RC_OUT_PIXEL_SHUFFLE2_NCHW) == 0               # pixel shuffle needs cout % 4 == 0
     assert lib.rc_tail_fold_weights(None, None, None, None, 48, 3, None, None) < 0
     assert lib.rc_tail_ring_gather(None, None, None, RC_BF16, 1, 8, 8, 48, None) < 0
@@ -99,20 +102,23 @@ DEV = "cuda"
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("persist", [1, 2, 3, 0])
-@pytest.mark.parametrize("cout,H,W", [(12, 16, 40), (16, 9, 33), (12, 37, 70), (4, 8, 32)])
-def test_conv5x5_exact_on_small_integer_data(hip, persist, cout, H, W):
+@pytest.mark.parametrize("cin,dt,cout,H,W", [(48, torch.bfloat16, 12, 16, 40), (48, torch.bfloat16, 16, 9, 33), (48, torch.bfloat16, 12, 37, 70),
+                                             (48, torch.bfloat16, 4, 8, 32), (32, torch.bfloat16, 12, 21, 40), (64, torch.bfloat16, 12, 9, 70),
+                                             (64, torch.float32, 12, 21, 40), (16, torch.float32, 8, 9, 33)])
+def test_conv5x5_exact_on_small_integer_data(hip, persist, cin, dt, cout, H, W):
     """Integer-valued data: every product and partial sum is exact, so the 5x5 kernel must equal F.conv2d bit for bit -- in NHWC, NCHW and the
-    pixel-shuffled planar store (cropped), in every launch form (persistent / producer-consumer / general)."""
+    pixel-shuffled planar store (cropped), in every launch form (persistent / producer-consumer / general) and instantiation (bf16 48- and 32-channel
+    chunks, fp32 16-channel chunks)."""
     from realcamnet_amd import networks as N, ops
     g = torch.Generator().manual_seed(cout * 1000 + H)
-    c = N.Conv2d(48, cout, 5, 1, 2)
+    c = N.Conv2d(cin, cout, 5, 1, 2)
     with torch.no_grad():
         c.weight.copy_(torch.randint(-2, 3, c.weight.shape, generator=g).float() / 2)
         c.bias.copy_(torch.randint(-2, 3, c.bias.shape, generator=g).float())
-    x = torch.randint(-2, 3, (2, 48, H, W), generator=g).float() / 2
+    x = torch.randint(-2, 3, (2, cin, H, W), generator=g).float() / 2
     ref = F.conv2d(x, c.weight.detach(), c.bias.detach(), padding=2)
-    c = c.to(DEV, torch.bfloat16).eval()
-    a = ops.to_nhwc(x.to(DEV, torch.bfloat16))
+    c = c.to(DEV, dt).eval()
+    a = ops.to_nhwc(x.to(DEV, dt))
     assert hip.rc_debug_set(b"persist", persist) == 0
     try:
         with torch.no_grad():
@@ -123,7 +129,7 @@ def test_conv5x5_exact_on_small_integer_data(hip, persist, cout, H, W):
             y_ps_even = ops.conv2d(a, c, out_mode=RC_OUT_PIXEL_SHUFFLE2_NCHW, crop_hw=(2 * H - 1, 2 * W - 6))
     finally:
         hip.rc_debug_set(b"persist", 1)
-    rb = lambda t: t.bfloat16().float()              # bf16 outputs: the exact fp32 sum rounded once (1200 terms reach |v| > 64, where 0.25 steps need 9 bits)
+    rb = (lambda t: t.bfloat16().float()) if dt == torch.bfloat16 else (lambda t: t)   # bf16 outputs: the exact fp32 sum rounded once (1200 terms reach |v| > 64)
     assert torch.equal(y_nhwc.float().cpu().permute(0, 3, 1, 2), rb(ref))
     assert torch.equal(y_nchw.cpu(), ref[:, :, :H - 1, :W - 3])
     ps = F.pixel_shuffle(ref, 2)
@@ -134,6 +140,31 @@ def test_conv5x5_exact_on_small_integer_data(hip, persist, cout, H, W):
 
 def _psnr(a, b):
     return float(10 * torch.log10((b.max() - b.min()) ** 2 / ((a - b) ** 2).mean()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,dt", [(32, torch.bfloat16), (64, torch.bfloat16), (64, torch.float32)])
+def test_folded_tail_of_the_other_widths_vs_fp64_reference(hip, C, dt):
+    """The fold at the ISPUNet family's 32 channels, LiteISPNet's 64 (bf16) and in fp32 (cfg2): against conv -> PixelShuffle -> conv in double.
+    fp32 tolerance: 2e-5 * max|ref| (reassociation only); bf16: as the 48-channel test."""
+    from realcamnet_amd import networks as N, ops
+    torch.manual_seed(2)
+    tail = N.seq(N.conv(C, 4 * C, mode="C"), torch.nn.PixelShuffle(2), N.conv(C, 3, mode="C")).to(DEV, dt).eval()
+    c1, c2 = tail[0], tail[2]
+    x = torch.randn(2, 21, 70, C, generator=torch.Generator().manual_seed(C)).to(DEV, dt)
+    crop = (41, 140)
+    with torch.no_grad():
+        assert ops.tail_fold_ok(x, c1, c2)
+        one = ops.tail_fold(x, c1, c2, crop_hw=crop)
+        two = c2._nhwc(c1._nhwc(x, out_mode=RC_OUT_PIXEL_SHUFFLE2), out_mode=RC_OUT_NCHW, crop_hw=crop)
+    d = lambda t: t.detach().double().cpu()
+    ref = _two_step(d(x).permute(0, 3, 1, 2), d(c1.weight), d(c1.bias), d(c2.weight), d(c2.bias))[:, :, :crop[0], :crop[1]]
+    o, t = d(one), d(two)
+    if dt == torch.float32:
+        assert (o - ref).abs().max() <= 2e-5 * ref.abs().max() and (t - ref).abs().max() <= 2e-5 * ref.abs().max()
+    else:
+        assert _psnr(o, ref) >= 60.0 and _psnr(o, ref) >= _psnr(t, ref) - 1.0
+        assert (o - ref)[:, :, 0].abs().max() <= 2 * (t - ref).abs().max() + 1e-6 and (o - ref)[:, :, :, 0].abs().max() <= 2 * (t - ref).abs().max() + 1e-6
 
 
 @pytest.mark.gpu
