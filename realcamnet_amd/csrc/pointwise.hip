@@ -535,6 +535,8 @@ __global__ void tail_ring_scatter_kernel(const T* __restrict__ rows_out, const T
             k -= 2 * out_w;
             const int rgt = k >= out_h, Y = rgt ? k - out_h : k;
             if (rgt && !right) continue;
+            if (Y == 0 || (bottom && Y == out_h - 1)) continue;      // corners belong to the row strips: the transposed strips sum their taps in another
+                                                                     // order, and two writers of one pixel would make the result depend on a race
             const T* src = cols_out + (((size_t)(rgt ? batch + b : b) * co + c) * 4 + (rgt ? 3 : 0)) * (2 * H);     // transposed strip: row = output column
             o[(size_t)Y * out_w + (rgt ? out_w - 1 : 0)] = src[Y];
         }
