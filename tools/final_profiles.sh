@@ -13,18 +13,14 @@ timeout 900 python bench.py > gpurun_out/bench_default_$TAG.json 2> gpurun_out/b
 timeout 300 python bench.py --model LiteISPNet_GFM_LSC --no-cpu-baseline > gpurun_out/bench_nogma_$TAG.json 2>/dev/null
 timeout 300 python bench.py --model LiteISPNet --dtype f32 --frames 1 --height 1080 --width 1920 --steps 20 --warmup 5 > gpurun_out/bench_cfg2_$TAG.json 2>/dev/null
 timeout 300 python bench.py --model ISPUNet_GFM_LSC --no-cpu-baseline > gpurun_out/bench_ispunet_$TAG.json 2>/dev/null
-timeout 600 python bench.py --model raw_compression_tcm_final --frames 4 > gpurun_out/bench_codec_$TAG.json 2>/dev/null
-timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_codec_$TAG -o trace -- python bench.py --model raw_compression_tcm_final --frames 4 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_codec_trace_$TAG.json 2> gpurun_out/bench_codec_trace_$TAG.err
+timeout 600 python bench.py --model raw_compression_tcm_final --frames 8 > gpurun_out/bench_codec_$TAG.json 2>/dev/null
+timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_codec_$TAG -o trace -- python bench.py --model raw_compression_tcm_final --frames 8 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_codec_trace_$TAG.json 2> gpurun_out/bench_codec_trace_$TAG.err
 timeout 300 python tools/gma_stage_bench.py > gpurun_out/gma_stages_$TAG.txt 2>&1
 timeout 300 python tools/codec_stream_bench.py > gpurun_out/codec_stream_$TAG.txt 2>&1
 timeout 120 python tools/mfma_peak.py > gpurun_out/mfma_peak_$TAG.txt 2>/dev/null
-# round 3 evidence: the 32x32x16 conv forms, store-issue microbenchmark, pair2, matrix-pipe / LDS counters, the bitstream legs
-timeout 400 python tools/conv32_probe.py > gpurun_out/conv32_probe_$TAG.txt 2>&1
-( for V in 2 3 1; do V=$V timeout 100 python tools/conv32_phases.py; done; timeout 100 python tools/conv32_phases.py 512 512 136 240 8; V=2 timeout 100 python tools/conv32_phases.py 128 128 272 480 8 --gated; V=1 timeout 100 python tools/conv32_phases.py 48 192 1088 1920 8 --ps; V=1 FLAGS=8 timeout 100 python tools/conv32_phases.py 48 192 1088 1920 8 --ps ) > gpurun_out/conv32_phases_$TAG.txt 2>&1
-timeout 120 ./tools/ubench/store_issue > gpurun_out/store_issue_$TAG.txt 2>&1
-( timeout 200 python tools/tail_probe.py; timeout 200 python tools/pss_flags.py ) > gpurun_out/tail_$TAG.txt 2>&1
-( timeout 200 python tools/codec_graph_probe.py; timeout 200 python tools/codec_conv32_probe.py; timeout 200 python tools/codec_conv_breakdown.py ) > gpurun_out/codec_probes_$TAG.txt 2>&1
-timeout 300 python tools/pair2_probe.py sums plain gated film > gpurun_out/pair2_$TAG.txt 2>&1
+# round 4 evidence: the folded tail against the two launches it replaces, the early-gate RCAGroup, the codec's per-launch breakdown
+( timeout 200 python tools/tail_fold_probe.py; timeout 200 python tools/rcag_probe.py ) > gpurun_out/tail_fold_$TAG.txt 2>&1
+timeout 200 python tools/codec_conv_breakdown.py > gpurun_out/codec_probes_$TAG.txt 2>&1
 bash tools/pmc_mfma.sh $TAG > gpurun_out/pmc_mfma_${TAG}.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_cmp_$TAG -o trace -- python tools/compress_trace.py > gpurun_out/compress_$TAG.txt 2>&1
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_torchrun_$TAG.json 2>/dev/null
@@ -33,7 +29,7 @@ tail -c 400 gpurun_out/bench_default_$TAG.json; echo; cut -c1-160 gpurun_out/ben
 
 # summaries are written ON the box (gpurun_out/ is capped at 64 MiB on the way back): keep them, the bench trace database and the small logs
 mkdir -p gpurun_out/profiles_$TAG
-cp gpurun_out/tail_$TAG.txt gpurun_out/codec_probes_$TAG.txt gpurun_out/store_issue_$TAG.txt gpurun_out/profiles_$TAG/ 2>/dev/null
+cp gpurun_out/tail_fold_$TAG.txt gpurun_out/codec_probes_$TAG.txt gpurun_out/profiles_$TAG/ 2>/dev/null
 python tools/write_profiles.py $TAG $ROUND gpurun_out/profiles_$TAG > gpurun_out/profiles_$TAG/summary.json 2> gpurun_out/write_profiles_$TAG.err
 mkdir -p gpurun_out/keep_$TAG && cp gpurun_out/prof_$TAG/trace_results.db gpurun_out/keep_$TAG/bench_trace_results.db 2>/dev/null
 cp gpurun_out/prof_codec_$TAG/trace_results.db gpurun_out/keep_$TAG/codec_trace_results.db 2>/dev/null

@@ -74,7 +74,7 @@ Conv kernels: {d['conv_kernels_all']['dispatches']} dispatches, {d['conv_kernels
 """)
 codec = last(f"{G}/bench_codec_{tag}.json")
 csumm = subprocess.run([sys.executable, "tools/rocpd_summary.py", f"{G}/prof_codec_{tag}/trace_results.db", "--last-forwards", "2"], capture_output=True, text=True).stdout
-open(f"{OUT}/{RND}_rawcodec_kernel_stats.md", "w").write(f"""# {RND} — RAW codec leg: `python bench.py --model raw_compression_tcm_final --frames 4` (cfg5 shape on one GPU, bf16, 1x MI355X)
+open(f"{OUT}/{RND}_rawcodec_kernel_stats.md", "w").write(f"""# {RND} — RAW codec leg: `python bench.py --model raw_compression_tcm_final --frames 8` (cfg5 shape on one GPU, bf16, 1x MI355X)
 
 Default run (steps 5, warm-up 2, CPU baseline leg on):
 
@@ -82,7 +82,7 @@ Default run (steps 5, warm-up 2, CPU baseline leg on):
 {codec}
 ```
 
-Kernel trace: `rocprofv3 --kernel-trace --stats -- python bench.py --model raw_compression_tcm_final --frames 4 --steps 2 --warmup 1 --no-cpu-baseline`
+Kernel trace: `rocprofv3 --kernel-trace --stats -- python bench.py --model raw_compression_tcm_final --frames 8 --steps 2 --warmup 1 --no-cpu-baseline`
 (3 forwards of 4 frames in the trace; the table counts the LAST TWO -- steady state, weight packing and its copies are out), summarised with
 `tools/rocpd_summary.py --last-forwards 2`:
 
@@ -105,34 +105,15 @@ def rd(name):
     return open(p).read().replace("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n", "").strip() if os.path.exists(p) else "(not collected)"
 
 
-open(f"{OUT}/{RND}_conv32.md", "w").write(f"""# {RND} — the 32x32x16 conv forms (csrc/conv32_kernel.hpp) against the 16x16x32 kernels, 1x MI355X
-
-`tools/conv32_probe.py`: exact-integer parity of every form (knob 1 = staged-output form on 16-channel chunks + the one-chunk 48-channel form,
-2 / 3 = two-barrier form on 32-channel chunks with 4 / 8 compute waves) in every operand mode, then steady-state layer times at the flagship's
-shapes (`old` = conv_mfma_wsm_kernel, 16x16x32, 8 compute + 4 loader waves; `*-nomfma` / `*-nostore` = knock-outs):
+open(f"{OUT}/{RND}_tail_fold_rcag.md", "w").write(f"""# {RND} — the folded tail against the two launches it replaces, and the early-gate RCAGroup (`tools/tail_fold_probe.py`, `tools/rcag_probe.py`), 1x MI355X
 
 ```
-{rd('conv32_probe')[-4200:]}
+{rd('tail_fold')}
 ```
 
-Phase stamps (`tools/conv32_phases.py`, `s_memtime` of one compute and one loader wave of block 8, cycles per stage):
-
-```
-{rd('conv32_phases')}
-```
-
-Store issue microbenchmark (`tools/ubench/store_issue.hip`; pattern 0 = 16 bytes per lane at a row stride, what an MFMA D layout gives;
-1 = fully coalesced; 2 = 8 lanes x 16 B = 128 contiguous bytes per pixel; drop = out-of-bounds offsets, nothing written):
-
-```
-{rd('store_issue')}
-```
-""")
-open(f"{OUT}/{RND}_pair2_probe.md", "w").write(f"""# {RND} — `tools/pair2_probe.py` at the final build (see {RND}_pair2_phases.md for the history of the experiment)
-
-```
-{rd('pair2')}
-```
+`RCAGroup shipped` = the early-gate schedule (default); `proxy kernels` = the same schedule timed with round 3's kernels before the new epilogues existed
+(conv + sums, conv + residual) -- the estimate the work was started on.  Round 3's schedule (gate folded into the next conv's staging) measured 9.16 / 2.36 ms
+at the two sizes on the same tool.
 """)
 mf = f"{G}/pmc_mfma_{tag}.md"
 if os.path.exists(mf):
