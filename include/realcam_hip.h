@@ -511,7 +511,7 @@ int rc_window_attention(const void* d_qkv, const float* d_relpos, void* d_out, i
 /* A/B switches for tests and benches.  "persist": 0 = general kernel only, 1 (default) = automatic choice between the
  * persistent weights-resident kernel and its producer/consumer (wave-specialised) form, 2 = producer/consumer
  * wherever eligible, 3 = persistent only.  Results must be identical in all modes.
- * Others (all bit-identical alternatives of one operation, defaults in brackets): "conv32" [4] which layers take the
+ * Others (all bit-identical alternatives of one operation, defaults in brackets): "conv32" [0] which layers take the
  * 32x32x16 MFMA forms (0 none, 4 = where measured faster, 1 / 2 / 3 = everywhere eligible in one of three forms; set BEFORE
  * packing: the packed weight order depends on it -- and on no other knob: such a layer runs its own kernel in every "persist" mode); "pair_impl" [0] which of the two rc_conv_pair kernels; "pss" [0] the
  * 48 -> 192 + PixelShuffle layer with its output staged through LDS; "dw3_seg16" [1] rc_dwconv2d's bf16 3x3 single-rep

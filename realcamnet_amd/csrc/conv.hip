@@ -17,8 +17,9 @@ extern int g_dw3_seg16;            // gma.hip
 extern int g_dec_lds;              // rans.hip
 static int g_pss = 0;              // rc_debug_set("pss", v): 1: single-chunk pixel-shuffle layers (the tail 48 -> 192) take kernel 5 (output staged through LDS, stored by the
                                    // loader waves); 0 (default): kernel 4.  Measured on MI355X at 8 x 1088 x 1920: 3.16-3.29 vs 3.24-3.27 ms (conv_kernel.hpp, kernel 5)
-static int g_conv32 = 4;           // rc_debug_set("conv32", v): which layers take the 32x32x16 forms (conv32_kernel.hpp).  0 none; 4 (default) only where they
-                                   // measured faster on MI355X (the one-chunk 48 -> 96k NHWC layers: 1.24 vs 1.39 ms at 544x960x8); 1 all eligible layers, multi-chunk
+static int g_conv32 = 0;           // rc_debug_set("conv32", v): which layers take the 32x32x16 forms (conv32_kernel.hpp).  0 (default) none: the one layer they were
+                                   // faster on (48 -> 192 + residual at 544x960x8: 1.25 vs 1.31 ms) now runs on the persistent kernel with the residual prefetched
+                                   // (1.13 ms); 4 = that layer family (one-chunk 48 -> 96k NHWC) only; 1 all eligible layers, multi-chunk
                                    // NHWC ones in the staged-output form; 2 / 3 multi-chunk layers in the two-barrier form with 4 / 8 compute waves (A/B experiments)
 
 // Must mirror ConvCfg<> (static_asserts in check_plan_consistency below keep them in lock-step).

@@ -1799,7 +1799,11 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
     // bf16 only: in fp32 the MFMAs are 4x longer, the layers are MFMA-bound either way and the general kernel's many
     // small blocks balance the B = 1 configurations better (measured 99 vs 88 TF/s on 64 -> 64 at 1080p)
     if constexpr (WSM_LDS <= 160 * 1024 && Cfg::KS >= 2 && Cfg::STEPS >= 2 && sizeof(typename Cfg::elem) == 2) {
-        if ((a.n_chunks > 1 || a.n_ct > 1) && a.cin_vec_ok && a.cin_chunk_ok && a.persist_ok && a.cout_packed <= kPersistMaxCout &&
+        // one-chunk layers with several cout tiles AND a residual (the U-Net's 48 -> 192 + skip at level 1) stay on the persistent kernel: input tile
+        // resident, weights per cout tile, the residual's loads issued before the MFMA loop (1.13 vs 1.31 ms here, 1.25 in the 32x32x16 form);
+        // persist_ok 3 ("persistent only") sends every one-chunk layer there
+        const bool res_pre_form = FAST && !GATED && sizeof(typename Cfg::elem) == 2 && Cfg::NT <= 3 && a.ep_key == ConvDev<Cfg>::EP_RES && a.out_mode == RC_OUT_NHWC;
+        if ((a.n_chunks > 1 || (a.n_ct > 1 && a.persist_ok != 3 && !(P_OK && res_pre_form))) && a.cin_vec_ok && a.cin_chunk_ok && a.persist_ok && a.cout_packed <= kPersistMaxCout &&
             n_tiles < (1 << 24)) {
             const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch * (a.n_chunks > 1 ? a.n_ct : 1);
             static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)

@@ -199,7 +199,7 @@ def _emulate32(w, x, out_mode, ck32=32):
 
 @pytest.mark.parametrize("cin,cout,knob", [(128, 64, 2), (128, 64, 1), (48, 96, 4)])
 def test_packed_weight_layout_32x32_reproduces_conv(cin, cout, knob):
-    """knob = rc_debug_set("conv32"): 2 -> 32-channel chunks (two-barrier form), 1 -> 16-channel chunks (staged-output form), 4 = the default."""
+    """knob = rc_debug_set("conv32"): 2 -> 32-channel chunks (two-barrier form), 1 -> 16-channel chunks (staged-output form), 0 = the default (none), 4 = the one-chunk 48 -> 96k NHWC layers only."""
     rng = np.random.default_rng(2)
     w = rng.integers(-2, 3, size=(cout, cin, 3, 3)).astype(np.float32) / 2
     x = rng.integers(-2, 3, size=(cin, 8, 32)).astype(np.float32) / 2
@@ -208,7 +208,7 @@ def test_packed_weight_layout_32x32_reproduces_conv(cin, cout, knob):
     try:
         out, nt, n_ct = _emulate32(w, x, RC_OUT_NHWC, ck32=16 if knob == 1 else 32)
     finally:
-        lib.rc_debug_set(b"conv32", 4)
+        lib.rc_debug_set(b"conv32", 0)
     ref = F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), padding=1)[0].numpy()
     np.testing.assert_allclose(out, ref, atol=1e-4)             # NHWC: packed order == channel order
 
@@ -226,7 +226,7 @@ def test_pixel_shuffle_packing_32x32():
         dst = np.zeros(cout, np.float32)
         assert lib.rc_conv_pack_bias(bias.ctypes.data, cin, cout, 3, RC_BF16, RC_OUT_PIXEL_SHUFFLE2, dst.ctypes.data) == 0
     finally:
-        lib.rc_debug_set(b"conv32", 4)
+        lib.rc_debug_set(b"conv32", 0)
     assert (nt, n_ct) == (3, 2)
     ref = F.pixel_shuffle(F.conv2d(torch.from_numpy(x)[None], torch.from_numpy(w), padding=1), 2)[0].numpy()
     got = np.zeros_like(ref)
@@ -258,5 +258,5 @@ def test_conv32_knob_switches_the_packed_layout():
         assert lib.rc_conv_packed_bytes(128, 64, 3, RC_BF16, RC_OUT_NHWC) == n
         assert lib.rc_conv_pack_weights(w.ctypes.data, 128, 64, 3, RC_BF16, RC_OUT_NHWC, b.ctypes.data) == 0
     finally:
-        lib.rc_debug_set(b"conv32", 4)
+        lib.rc_debug_set(b"conv32", 0)
     assert not np.array_equal(a, b) and np.array_equal(np.sort(a), np.sort(b))

@@ -663,7 +663,7 @@ def test_conv32_forms_exact_on_integer_data(hip, knob, mode, shape):
                 y = ops.conv2d(xd, c, **kw)
             y = ops.to_nchw(y).float().cpu()
     finally:
-        hip.rc_debug_set(b"conv32", 4)
+        hip.rc_debug_set(b"conv32", 0)
     assert torch.equal(y, ref)
 
 
