@@ -107,6 +107,18 @@ def dwt_inverse(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     return F.conv_transpose2d(x, sd[p + ".weight"], None, stride=2, groups=x.shape[1] // 4)
 
 
+def dwt_forward_(weight: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """DWTForward_ (the channel-count-agnostic variant: ONE (4,1,2,2) tap set repeated over the input's channels).  models/networks.py:9-26."""
+    c = x.shape[1]
+    return F.conv2d(x, torch.cat([weight] * c, dim=0), None, stride=2, groups=c)
+
+
+def dwt_inverse_(weight: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """DWTInverse_: grouped transposed conv with the same repeated taps.  models/networks.py:29-47."""
+    c = x.shape[1] // 4
+    return F.conv_transpose2d(x, torch.cat([weight] * c, dim=0), None, stride=2, groups=c)
+
+
 def pixel_shuffle2(x: torch.Tensor) -> torch.Tensor:
     """nn.PixelShuffle(2): out[b,c,2y+i,2x+j] = in[b,4c+2i+j,y,x].  models/networks.py:201-202."""
     return F.pixel_shuffle(x, 2)

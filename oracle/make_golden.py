@@ -119,6 +119,16 @@ def main():
             coord = torch.randn(1, 2, 32, 32, generator=gn)
             save(f"e2e_{name}_randn_32x32", raw=raw, cond=cond, coord=coord, y=net([raw, cond, coord]), sd_digest=np.array(dig))
 
+        # ---- added in round 4 (LAST, with their own generator, so that every earlier fixture regenerates bit-identically):
+        # the channel-count-agnostic Haar pair (models/networks.py:9-47): one (4,1,2,2) tap set repeated over any C
+        g4 = torch.Generator().manual_seed(2024)
+        m = N.DWTForward_().eval()
+        x = torch.rand(2, 24, 12, 20, generator=g4) * 2 - 1
+        save("block_dwt_forward_anyc", x=x, y=m(x), **sd_arrays(m))
+        m = N.DWTInverse_().eval()
+        x = torch.rand(2, 32, 6, 10, generator=g4) * 2 - 1
+        save("block_dwt_inverse_anyc", x=x, y=m(x), **sd_arrays(m))
+
 
 if __name__ == "__main__":
     main()

@@ -1824,12 +1824,14 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
             static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
             if (!attr_set.test_and_set()) {
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_persist_kernel<Cfg, GATED, FAST>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS));
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS > 100 * 1024 ? P_LDS : 100 * 1024));
             }
             int grid = persist_blocks_per_cu<Cfg>() * a.num_cus;
+            const bool one_per_cu = (a.dbg_flags & 64) != 0 && P_LDS <= 80 * 1024;      // occupancy experiment: LDS padded so that ONE block fits a CU
+            if (one_per_cu) grid = a.num_cus;
             if (grid > n_tiles) grid = n_tiles;
             grid = (grid + 7) / 8 * 8;
-            hipLaunchKernelGGL((conv_mfma_persist_kernel<Cfg, GATED, FAST>), dim3((unsigned)grid), dim3(kThreads), P_LDS, stream, a);
+            hipLaunchKernelGGL((conv_mfma_persist_kernel<Cfg, GATED, FAST>), dim3((unsigned)grid), dim3(kThreads), one_per_cu ? 100 * 1024 : P_LDS, stream, a);
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }

@@ -189,6 +189,35 @@ class DWTInverse(nn.ConvTranspose2d):
         return ops.dwt_inverse(a, self)
 
 
+class DWTForward_(nn.Module):
+    """Haar analysis for ANY channel count: one (4,1,2,2) tap set in the state_dict (the flipped taps upstream builds), repeated over the input's
+    channels at call time (upstream models/networks.py:9-26)."""
+
+    def __init__(self):
+        super().__init__()
+        ll, lh, hl, hh = [[0.5, 0.5], [0.5, 0.5]], [[-0.5, -0.5], [0.5, 0.5]], [[-0.5, 0.5], [-0.5, 0.5]], [[0.5, -0.5], [-0.5, 0.5]]
+        flip = lambda f: [row[::-1] for row in f[::-1]]
+        self.weight = nn.Parameter(torch.tensor([[flip(f)] for f in (ll, lh, hl, hh)], dtype=torch.get_default_dtype()), requires_grad=False)
+
+    def _taps(self, c):
+        return ops.host_cached(self, f"taps_x{c}", [self.weight], lambda w: w.repeat(c, 1, 1, 1))[0]
+
+    def forward(self, x):
+        return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
+
+    def _nhwc(self, a):
+        return ops.dwt_forward(a, ops._ConvView(self._taps(a.shape[-1]), None))
+
+
+class DWTInverse_(DWTForward_):
+    """Haar synthesis for any channel count (upstream models/networks.py:29-47)."""
+
+    def _nhwc(self, a):
+        if a.shape[-1] % 4:
+            raise ValueError("DWTInverse_: channels must be a multiple of 4")
+        return ops.dwt_inverse(a, ops._ConvView(self._taps(a.shape[-1] // 4), None))
+
+
 class CALayer(HipModule):
     """Channel attention (upstream models/networks.py:255-270).  The global mean needs the whole
     feature map, so inside RCABlock the producing conv emits per-tile channel sums and only the tiny

@@ -277,6 +277,21 @@ def test_tail_pixel_shuffle_vs_reference(hip, dt):
     assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+def test_dwt_any_channel_count_pair_vs_reference(hip, dt):
+    """networks.DWTForward_ / DWTInverse_ (upstream models/networks.py:9-47) on the reference's fixtures; the state_dict is the single (4,1,2,2) tap set."""
+    g = load_golden("block_dwt_forward_anyc")
+    fwd = put(N.DWTForward_(), g["sd"], dt)
+    assert rel_err(run(fwd, g["x"], dt=dt).float().cpu(), g["y"]) <= tol(dt)
+    gi = load_golden("block_dwt_inverse_anyc")
+    inv = put(N.DWTInverse_(), gi["sd"], dt)
+    assert rel_err(run(inv, gi["x"], dt=dt).float().cpu(), gi["y"]) <= tol(dt)
+    assert list(fwd.state_dict()) == ["weight"] and tuple(fwd.weight.shape) == (4, 1, 2, 2)
+    x = torch.randn(1, 16, 8, 12, generator=torch.Generator().manual_seed(1))
+    back = run(inv, run(fwd, x, dt=torch.float32) if dt == torch.float32 else run(fwd, x, dt=dt), dt=dt)
+    assert rel_err(back.float().cpu(), x) <= (1e-6 if dt == torch.float32 else 2e-2)
+
+
 # ---- end to end ---------------------------------------------------------------------------------------
 _NETS = {}
 

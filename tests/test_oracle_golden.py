@@ -26,6 +26,16 @@ def test_dwt_blocks():
     _close(O.dwt_inverse({"w.weight": g["sd"]["weight"]}, "w", g["x"]), g["y"])
 
 
+def test_dwt_any_channel_count_pair():
+    """DWTForward_ / DWTInverse_ (upstream models/networks.py:9-47): one (4,1,2,2) tap set for any channel count."""
+    g = load_golden("block_dwt_forward_anyc")
+    _close(O.dwt_forward_(g["sd"]["weight"], g["x"]), g["y"])
+    gi = load_golden("block_dwt_inverse_anyc")
+    _close(O.dwt_inverse_(gi["sd"]["weight"], gi["x"]), gi["y"])
+    assert tuple(g["sd"]["weight"].shape) == (4, 1, 2, 2)
+    _close(O.dwt_inverse_(gi["sd"]["weight"], O.dwt_forward_(g["sd"]["weight"], g["x"])), g["x"])       # analysis -> synthesis = identity
+
+
 def test_dwt_roundtrip_is_identity():
     g = load_golden("block_dwt_forward")
     gi = load_golden("block_dwt_inverse")
