@@ -292,6 +292,12 @@ def main():
         res["roofline"]["traffic"] = round(pmc["conv_kernels_all"]["hbm_bytes_per_dispatch"])
         res["roofline"]["traffic_note"] = ("HBM bytes per conv launch (mean over the step's conv launches), FETCH_SIZE x2 + WRITE_SIZE from "
                                            f"profiles/{pmc['_file']} (same kernel-source digest {pmc['source_digest'][:12]} as this build)")
+        # the mean hides very different layers: also the three kernels that move the most, per launch and per forward (same PMC passes)
+        fw = pmc.get("forwards", 3)
+        top = sorted(((k, v["dispatches"], v["fetch_bytes_per_dispatch"] + v["write_bytes_per_dispatch"]) for k, v in pmc["kernels"].items()),
+                     key=lambda t: -t[1] * t[2])[:3]
+        res["roofline"]["traffic_by_kernel"] = [{"kernel": k.split("(")[0][-70:], "launches_per_forward": round(n / fw, 1), "hbm_bytes_per_launch": round(bpl),
+                                                 "hbm_GB_per_forward": round(n * bpl / fw / 1e9, 1)} for k, n, bpl in top]
         step_bytes = (pmc["all_kernels_total_bytes"]["fetch"] + pmc["all_kernels_total_bytes"]["write"]) / pmc.get("forwards", 3)
         res["hbm_whole_step"] = {"bytes_per_step": round(step_bytes), "achieved_TBps": round(step_bytes / (elapsed / args.steps) / 1e12, 2),
                                  "copy_rate_TBps": pmc.get("copy_rate_TBps", 5.9), "peak_TBps": 8.0}
