@@ -522,6 +522,8 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
     return (out, *extras) if extras else out
 
 
+FUSE_SHUFFLE_STORE = True    # narrow subpel tails (conv -> PixelShuffle(2), 3 output channels: the codecs' x_hat): shuffle + NCHW in the conv's store
+
 # The tail conv(C -> 4C) -> PixelShuffle(2) -> conv(C -> 3) (upstream models/LiteISP.py:1996-2000) has no activation in between: it is ONE linear map,
 # a 5x5 convolution C -> 12 whose channel 4o + 2i + j is colour o at sub-pixel (i, j) (rc_tail_fold_weights, composed once per checkpoint like weight
 # packing).  4.6x fewer MACs and the 2H x 2W x C intermediate map never exists (4K x 8: 6.4 GB written + 7.7 GB read, 5.4 -> 0.9 ms).  The fold differs

@@ -794,6 +794,8 @@ def _synthesis_nchw(m, y_hat):
         a = y_hat
         for mod in mods[:-1]:
             a = mod._nhwc(a)
+        if ops.FUSE_SHUFFLE_STORE:            # the conv's own store does the shuffle + planar layout (RC_OUT_PIXEL_SHUFFLE2_NCHW): no 12-channel map, no extra pass
+            return last[0]._nhwc(a, out_mode=ops.RC_OUT_PIXEL_SHUFFLE2_NCHW)
         return ops.pixel_shuffle2_nchw(last[0]._nhwc(a))
     return ops.to_nchw(m.g_s._nhwc(y_hat))
 

@@ -223,3 +223,25 @@ def test_net_with_folded_tail_matches_the_module_list_form(hip):
         ops.FOLD_TAIL = True
     assert outs[True].shape == outs[False].shape == (2, 3, 88, 144)
     assert _psnr(outs[True], outs[False]) >= 60.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,dt", [(128, torch.bfloat16), (64, torch.bfloat16), (64, torch.float32)])
+def test_3x3_conv_with_pixel_shuffled_planar_store_exact_on_integer_data(hip, cin, dt):
+    """RC_OUT_PIXEL_SHUFFLE2_NCHW on an ordinary 3x3 convolution (the codecs' subpel_conv3x3(2N, 3, 2) writing x_hat: multi-chunk and general
+    kernels): equals F.pixel_shuffle(F.conv2d(...)) bit for bit, and the separate rc_pixel_shuffle2_nchw pass it replaces."""
+    from realcamnet_amd import networks as N, ops
+    g = torch.Generator().manual_seed(cin)
+    c = N.Conv2d(cin, 12, 3, 1, 1)
+    with torch.no_grad():
+        c.weight.copy_(torch.randint(-2, 3, c.weight.shape, generator=g).float() / 2)
+        c.bias.copy_(torch.randint(-2, 3, c.bias.shape, generator=g).float())
+    x = torch.randint(-2, 3, (2, cin, 21, 40), generator=g).float() / 2
+    ref = F.pixel_shuffle(F.conv2d(x, c.weight.detach(), c.bias.detach(), padding=1), 2)
+    c = c.to(DEV, dt).eval()
+    a = ops.to_nhwc(x.to(DEV, dt))
+    with torch.no_grad():
+        y = ops.conv2d(a, c, out_mode=RC_OUT_PIXEL_SHUFFLE2_NCHW)
+        y2 = ops.pixel_shuffle2_nchw(ops.conv2d(a, c))
+    rb = (lambda t: t.bfloat16().float()) if dt == torch.bfloat16 else (lambda t: t)
+    assert torch.equal(y.float().cpu(), rb(ref)) and torch.equal(y, y2)
