@@ -493,6 +493,9 @@ int rc_gma_apply(const void* d_qkvp, const void* d_convv, const void* d_loc, con
  * dst[p, dst_c0 + c] = src[p, src_c0 + c] for c < n_ch, all offsets / counts whole 16-byte vectors. */
 int rc_channel_copy(const void* d_src, int src_stride_c, int src_c0, void* d_dst, int dst_stride_c, int dst_c0, int n_ch,
                     long long pixels, int dtype, void* stream);
+/* torch.cat of 1..8 NHWC tensors along the channel dim in ONE launch (the slice loop's `torch.cat([latent_means] + support_slices, dim=1)`,
+ * models/tcm.py:460-466, 609-617: 2..6 parts, 22 times per forward): d_parts[k] is (pixels, widths[k]) dense, dst (pixels, sum widths). */
+int rc_channel_concat(const void* const* d_parts, const int* widths, int n_parts, void* d_dst, long long pixels, int dtype, void* stream);
 
 /* ---- a17: TCM window attention -------------------------------------------------------------------
  * Replaces the core of WMSA.forward (models/tcm.py:179-206): per ws x ws window of the cyclically shifted NHWC map

@@ -102,6 +102,7 @@ _SIGS = {
     "rc_square": (C.c_int, [_P, _P, _I, C.c_longlong, _P]),
     "rc_gdn_apply": (C.c_int, [_P, _P, _P, _P, _I, _I, C.c_longlong, _P]),
     "rc_channel_copy": (C.c_int, [_P, _I, _I, _P, _I, _I, _I, C.c_longlong, _I, _P]),
+    "rc_channel_concat": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), _I, _P, C.c_longlong, _I, _P]),
     "rc_window_attention": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "rc_conv_pair": (C.c_int, [C.POINTER(ConvPairDesc), _P]),
     "rc_conv_pair_sum_slots": (C.c_int, [_I, _I]),

@@ -403,6 +403,20 @@ __global__ void channel_copy_kernel(const T* __restrict__ src, int src_stride, i
     }
 }
 
+// ---- torch.cat along the channel dim of up to 8 NHWC tensors in ONE launch (the slice loop concatenates 2 .. 6 maps, 22 times per forward) ----
+struct ConcatArgs { const uint4* src[8]; int vec[8]; int vec0[8]; int n; int dst_vec; };
+__global__ void channel_concat_kernel(ConcatArgs a, uint4* __restrict__ dst, size_t pixels) {
+    const size_t total = pixels * a.dst_vec;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / a.dst_vec;
+        const int v = (int)(i - p * a.dst_vec);
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) k += (j < a.n && v >= a.vec0[j]) ? 1 : 0;
+        dst[i] = a.src[k][p * a.vec[k] + (v - a.vec0[k])];
+    }
+}
+
 // ---- Haar DWT as the reference's frozen grouped conv (taps read from the state_dict tensor) ------
 // forward: x (B,H,W,C) -> y (B,H/2,W/2,4C): y[.., 4c+k] = sum_{i,j} taps[4c+k][i][j] * x[2y+i][2x+j][c]
 // One thread per (output pixel, 16-byte group of input channels).
@@ -851,6 +865,24 @@ int rc_channel_copy(const void* d_src, int src_stride_c, int src_c0, void* d_dst
     else
         hipLaunchKernelGGL(channel_copy_kernel<bf16_t>, dim3(grid_for(total)), dim3(kPwThreads), 0, as_stream(stream),
                            static_cast<const bf16_t*>(d_src), src_stride_c, src_c0, static_cast<bf16_t*>(d_dst), dst_stride_c, dst_c0, n_ch, (size_t)pixels);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+int rc_channel_concat(const void* const* d_parts, const int* widths, int n_parts, void* d_dst, long long pixels, int dtype, void* stream) {
+    RC_REQUIRE(d_parts && widths && d_dst && n_parts >= 1 && n_parts <= 8 && pixels >= 1, "rc_channel_concat: 1..8 parts");
+    RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_channel_concat: bad dtype");
+    const int U = dtype == RC_F32 ? 4 : 8;
+    ConcatArgs a{};
+    int v0 = 0;
+    for (int k = 0; k < n_parts; ++k) {
+        RC_REQUIRE(d_parts[k] && widths[k] >= U && widths[k] % U == 0 && reinterpret_cast<uintptr_t>(d_parts[k]) % 16 == 0,
+                   "rc_channel_concat: every part a whole number of 16-byte vectors, 16-byte aligned");
+        a.src[k] = static_cast<const uint4*>(d_parts[k]); a.vec[k] = widths[k] / U; a.vec0[k] = v0; v0 += widths[k] / U;
+    }
+    RC_REQUIRE(reinterpret_cast<uintptr_t>(d_dst) % 16 == 0, "rc_channel_concat: 16-byte alignment");
+    a.n = n_parts; a.dst_vec = v0;
+    hipLaunchKernelGGL(channel_concat_kernel, dim3(grid_for((size_t)pixels * v0)), dim3(kPwThreads), 0, as_stream(stream), a, static_cast<uint4*>(d_dst), (size_t)pixels);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

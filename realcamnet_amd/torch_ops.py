@@ -413,6 +413,12 @@ define("channel_slice(Tensor x, int c0, int n) -> Tensor",
 
 
 def _concat_launch(out, parts):
+    unit = 16 // out.element_size()
+    if len(parts) <= 8 and all(t.shape[-1] % unit == 0 for t in parts):       # one launch for all parts
+        ptrs = (C.c_void_p * len(parts))(*[t.data_ptr() for t in parts])
+        widths = (C.c_int * len(parts))(*[t.shape[-1] for t in parts])
+        check(lib().rc_channel_concat(ptrs, widths, len(parts), out.data_ptr(), out.numel() // out.shape[-1], _dt(out), _stream()), "rc_channel_concat")
+        return
     ctot, c0 = out.shape[-1], 0
     for t in parts:
         check(lib().rc_channel_copy(t.data_ptr(), t.shape[-1], 0, out.data_ptr(), ctot, c0, t.shape[-1], t.numel() // t.shape[-1], _dt(t),

@@ -828,3 +828,15 @@ def test_hip_raw_codec_at_1024_mosaic_vs_oracle_psnr_and_flip_count():
     assert LO.psnr(out["x_hat"].float().cpu(), ref["x_hat"]) >= 41.0
     sym, ref_sym = torch.round(y - mu), torch.round(ref["para"]["y"] - ref["para"]["means"])
     assert float((sym != ref_sym).float().mean()) <= 0.006 and float((sym - ref_sym).abs().max()) <= 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_channel_concat_in_one_launch_equals_torch_cat(dt):
+    """rc_channel_concat (up to 8 parts, one launch: the slice loop's torch.cat([latent] + support_slices), upstream models/tcm.py:460-466) and the
+    per-part fallback (more than 8 parts) against torch.cat, bit for bit."""
+    g = torch.Generator().manual_seed(3)
+    for widths in ((320, 64), (320, 64, 64, 64, 64, 64), (8, 16, 24), (64,) * 9):
+        parts = [torch.randn(2, 9, 13, w, generator=g).to("cuda", dt) for w in widths]
+        got = OPS.channel_concat(parts)
+        assert torch.equal(got, torch.cat(parts, dim=-1))
