@@ -835,6 +835,7 @@ def test_hip_raw_codec_at_1024_mosaic_vs_oracle_psnr_and_flip_count():
 def test_channel_concat_in_one_launch_equals_torch_cat(dt):
     """rc_channel_concat (up to 8 parts, one launch: the slice loop's torch.cat([latent] + support_slices), upstream models/tcm.py:460-466) and the
     per-part fallback (more than 8 parts) against torch.cat, bit for bit."""
+    from realcamnet_amd import ops as OPS
     g = torch.Generator().manual_seed(3)
     for widths in ((320, 64), (320, 64, 64, 64, 64, 64), (8, 16, 24), (64,) * 9):
         parts = [torch.randn(2, 9, 13, w, generator=g).to("cuda", dt) for w in widths]
