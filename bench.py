@@ -193,10 +193,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of the output frames (replicas only)")
     ap.add_argument("--no-codec-leg", action="store_true", help="default cfg3 run: skip the extra codec_leg key (raw_compression_tcm_final at 4 frames)")
+    ap.add_argument("--layer-by-layer-tail", action="store_true", help="A/B: the tail as the module list's two launches (ops.FOLD_TAIL = False) instead of the folded 5x5 conv")
+    ap.add_argument("--staged-gate", action="store_true", help="A/B: round 3's RCAB schedule (CALayer gate folded into the next conv's staging, ops.EARLY_GATE = False)")
     args = ap.parse_args()
 
     import realcamnet_amd as M
     from realcamnet_amd import ops, shard
+    ops.FOLD_TAIL, ops.EARLY_GATE = not args.layer_by_layer_tail, not args.staged_gate
 
     rank, world, local_rank = shard.init_distributed()
     if world != args.gpus:
@@ -278,7 +281,9 @@ def main():
                                f"{B} frames/GPU, {args.dtype} storage / fp32 accumulate",
                    "frames_per_gpu": B, "global_frames": total_frames, "parallelism": f"frame-shard x{world}",
                    "collective": (f"all_gather of the sRGB frames over RCCL, {out.numel() * out.element_size()} bytes per rank per step, on a side "
-                                  "stream overlapped with the next step's forward") if gather is not None else "none"},
+                                  "stream overlapped with the next step's forward") if gather is not None else "none",
+                   **({"schedule": ("tail as two launches; " if args.layer_by_layer_tail else "") + ("CALayer gate staged in the next conv" if args.staged_gate else "")}
+                      if (args.layer_by_layer_tail or args.staged_gate) else {})},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": None,
                      "kernel": "conv_mfma_kernel (all instantiations)", "launches_per_step": int(n_launch),
