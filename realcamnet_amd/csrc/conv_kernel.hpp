@@ -627,6 +627,14 @@ struct ConvDev {
         }
     }
 
+    // RUN form of the channel sums (persistent kernel): a tile whose sums are carried on to the block's next tile leaves ZEROS in its 4 slots.  One 16-byte store
+    // per lane of wave 0 covers them (4 waves x cout floats) -- per-wave element stores cost 12 store instructions per wave and tile, more than the tile's own output.
+    // Issued between the tile's two workgroup barriers, so a later flush store of any wave to the same slot is ordered behind it.
+    __device__ static __forceinline__ void zero_sum_slots(const ConvArgs& a, int b, int sp, int tid) {
+        float* dst = a.chan_sums + ((size_t)b * (a.tiles_x * a.tiles_y) + sp) * 4 * a.cout;     // 4 * cout floats, 16-byte aligned (cout % 4 == 0 in FAST kernels)
+        for (int i = tid; i < a.cout; i += kThreads) *reinterpret_cast<float4*>(dst + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
     template <int CTRL>
     __device__ static __forceinline__ float dpp_add(float s) {   // s + (s of the lane CTRL selects inside the 16-lane row)
         return s + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), CTRL, 0xf, 0xf, false));
@@ -771,12 +779,7 @@ struct ConvDev {
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < NV; ++e) run[e] = csum[e];
-                if (n == 0) {
-                    float* dst = a.chan_sums + (((size_t)b * (a.tiles_x * a.tiles_y) + sp) * 4 + wave) * a.cout;
-#pragma unroll
-                    for (int e = 0; e < NV; ++e) dst[jbase + e] = 0.f;
-                }
+                for (int e = 0; e < NV; ++e) run[e] = csum[e];       // this tile's slots hold zeros: written by the kernel before the tile's MFMA loop (zero_sum_slots)
             }
         }
     }
@@ -1155,6 +1158,9 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
         first_tile = false;
         if (a.cin_vec_ok) D::template commit_tile<GATED>(a, ts, to, 0, tid, r0, r1, gv, s_in);
         else D::stage_tile_scalar(a, b, y0, x0, 0, tid, s_in, static_cast<typename Cfg::elem*>(a.in_store));
+        if constexpr (FAST && sizeof(typename Cfg::elem) == 2) {
+            if ((a.ep_key == D::EP_SUMS || a.ep_key == (D::EP_RELU | D::EP_SUMS)) && n_ct == 1) D::zero_sum_slots(a, b, sp, tid);   // uniform; RUN form below
+        }
         const int cb = b, csp = sp, cy0 = y0, cx0 = x0;
         const int next = tile + (int)gridDim.x;
         tile = next < n_tiles ? next : -1;
