@@ -1158,7 +1158,9 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
         first_tile = false;
         if (a.cin_vec_ok) D::template commit_tile<GATED>(a, ts, to, 0, tid, r0, r1, gv, s_in);
         else D::stage_tile_scalar(a, b, y0, x0, 0, tid, s_in, static_cast<typename Cfg::elem*>(a.in_store));
-        if constexpr (FAST && sizeof(typename Cfg::elem) == 2) {
+        constexpr bool RUN_SUMS = FAST && sizeof(typename Cfg::elem) == 2 && NT >= 3;   // sums carried across the block's tiles (narrow tiles: per-tile sums; their
+                                                                                        // 168-register instantiations have no room for the carried values)
+        if constexpr (RUN_SUMS) {
             if ((a.ep_key == D::EP_SUMS || a.ep_key == (D::EP_RELU | D::EP_SUMS)) && n_ct == 1) D::zero_sum_slots(a, b, sp, tid);   // uniform; RUN form below
         }
         const int cb = b, csp = sp, cy0 = y0, cx0 = x0;
@@ -1201,10 +1203,10 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
             }
             D::template mma_steps<0, STEPS, 0, (!GATED && NT < 5)>(s_in, s_w, lane_x, lane_w, q, lo, acc);
             if constexpr (FAST && sizeof(typename Cfg::elem) == 2) {
-                if (a.ep_key == D::EP_SUMS && n_ct == 1)    // uniform
-                    D::template epilogue_fast_impl<D::EP_SUMS, true>(a, cb, cy0, cx0, csp, ct, tid, acc, run, tile < 0 || b != cb);
-                else if (a.ep_key == (D::EP_RELU | D::EP_SUMS) && n_ct == 1)
-                    D::template epilogue_fast_impl<D::EP_RELU | D::EP_SUMS, true>(a, cb, cy0, cx0, csp, ct, tid, acc, run, tile < 0 || b != cb);
+                if (RUN_SUMS && a.ep_key == D::EP_SUMS && n_ct == 1)    // uniform
+                    D::template epilogue_fast_impl<D::EP_SUMS, RUN_SUMS>(a, cb, cy0, cx0, csp, ct, tid, acc, run, tile < 0 || b != cb);
+                else if (RUN_SUMS && a.ep_key == (D::EP_RELU | D::EP_SUMS) && n_ct == 1)
+                    D::template epilogue_fast_impl<D::EP_RELU | D::EP_SUMS, RUN_SUMS>(a, cb, cy0, cx0, csp, ct, tid, acc, run, tile < 0 || b != cb);
                 else if (res_pre) {
                     if constexpr (RESPRE) {
                         D::epilogue_res_pre(a, cb, cy0, cx0, ct, tid, acc, rpre);
