@@ -41,6 +41,7 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
                                                                                // input + two weight buffers fit one CU's LDS
         else if (cin % 64 == 0) p->ck = 64;
         else if (cin % 48 == 0) p->ck = 48;
+        else if (ksize == 3 && cin == 32) p->ck = 32;                              // the 32-channel nets (ISPUNet family): ONE chunk -> persistent kernel
         else p->ck = 16;
     } else {
         p->ck = cin <= 4 ? 4 : 16;
@@ -57,6 +58,7 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
         else if (cps % 16 == 0) p->nt = 1;
         else return false;
     } else if (cout % 48 == 0 && dtype == RC_BF16 && cin == 48) p->nt = 3;
+    else if (dtype == RC_BF16 && ksize == 3 && cin == 32 && cout == 32) p->nt = 2;   // 32 -> 32: one 32-wide cout tile, three persistent blocks per CU
     else if (ksize == 1 && cout % 80 == 0) p->nt = 5;          // 80-wide cout tiles for the GroupMix Linears
     else if (cout % 64 == 0) p->nt = 4;
     else if (cout % 48 == 0) p->nt = 3;

@@ -1094,7 +1094,7 @@ constexpr int persist_lds_bytes_c() { return Cfg::IN_BYTES + (int)Cfg::CHUNK_W_B
 // blocks per CU: layers with one 16-wide cout tile (the 48 -> 3 output conv) do almost no math per byte, so what
 // matters is bytes in flight: three blocks (their accumulators are small enough for 168 VGPRs)
 template <class Cfg>
-constexpr int persist_blocks_per_cu() { return Cfg::NT == 1 && persist_lds_bytes_c<Cfg>() * 3 <= 160 * 1024 ? 3 : 2; }
+constexpr int persist_blocks_per_cu() { return Cfg::NT <= 2 && persist_lds_bytes_c<Cfg>() * 3 <= 160 * 1024 ? 3 : 2; }
 
 template <class Cfg, bool GATED, bool FAST>
 __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_mfma_persist_kernel(const ConvArgs a) {

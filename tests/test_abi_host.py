@@ -42,10 +42,11 @@ def test_bad_arguments_are_reported_not_fixed():
 def _plan(cin, cout, dtype):
     unit = 4 if dtype == RC_F32 else 8
     if dtype == RC_BF16:
-        ck = 8 if cin <= 8 else 64 if cin % 64 == 0 else 48 if cin % 48 == 0 else 16
+        ck = 8 if cin <= 8 else 64 if cin % 64 == 0 else 48 if cin % 48 == 0 else 32 if cin == 32 else 16      # 3x3 (the emulated case)
     else:
         ck = 4 if cin <= 4 else 16
-    nt = 3 if (cout % 48 == 0 and dtype == RC_BF16 and cin == 48) else 4 if cout % 64 == 0 else 3 if cout % 48 == 0 else 1
+    nt = (3 if (cout % 48 == 0 and dtype == RC_BF16 and cin == 48) else 2 if (dtype == RC_BF16 and cin == 32 and cout == 32) else
+          4 if cout % 64 == 0 else 3 if cout % 48 == 0 else 1)
     return unit, ck, nt
 
 
@@ -117,7 +118,7 @@ def _emulate(w, x, dtype, out_mode, ks=3):
     return out, nt
 
 
-@pytest.mark.parametrize("cin,cout,dtype", [(4, 48, RC_BF16), (48, 48, RC_BF16), (16, 32, RC_F32), (64, 64, RC_BF16),
+@pytest.mark.parametrize("cin,cout,dtype", [(4, 48, RC_BF16), (48, 48, RC_BF16), (16, 32, RC_F32), (64, 64, RC_BF16), (32, 32, RC_BF16), (32, 64, RC_BF16),
                                             (4, 16, RC_F32), (48, 3, RC_BF16), (80, 16, RC_F32)])
 def test_packed_weight_layout_reproduces_conv(cin, cout, dtype):
     rng = np.random.default_rng(0)

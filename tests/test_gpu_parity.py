@@ -169,7 +169,8 @@ def test_gate_ahead_equals_gate_of_the_conv_output(hip, dt, c, H, W):
 
 
 @pytest.mark.parametrize("persist", [1, 2, 3, 0])
-@pytest.mark.parametrize("dt,cin,H,W", [(torch.bfloat16, 48, 16, 40), (torch.bfloat16, 48, 9, 33), (torch.bfloat16, 128, 21, 70), (torch.float32, 32, 9, 33)])
+@pytest.mark.parametrize("dt,cin,H,W", [(torch.bfloat16, 48, 16, 40), (torch.bfloat16, 48, 9, 33), (torch.bfloat16, 128, 21, 70), (torch.float32, 32, 9, 33),
+                                        (torch.bfloat16, 32, 21, 70), (torch.bfloat16, 64, 9, 33)])
 def test_conv_out_scale_and_relu_sums_exact_on_integer_data(hip, persist, dt, cin, H, W):
     """The two epilogues of the early-gate RCAB on integer data, every launch form: conv + ReLU with channel sums (sums == the stored map's sums
     exactly), and conv * out_scale[b][c] + residual (power-of-two scales: exact) -- bit for bit against F.conv2d."""
@@ -434,7 +435,7 @@ def test_dwt_with_arbitrary_per_channel_taps(hip, dt):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("persist", [1, 2, 3, 0])
-@pytest.mark.parametrize("shape", [(48, 48, 16, 40, 3), (48, 48, 9, 33, 3), (48, 3, 8, 32, 3), (4, 48, 24, 70, 3),
+@pytest.mark.parametrize("shape", [(48, 48, 16, 40, 3), (48, 48, 9, 33, 3), (48, 3, 8, 32, 3), (4, 48, 24, 70, 3), (32, 32, 21, 70, 3), (32, 64, 9, 33, 3), (32, 3, 16, 40, 3),
                                    (64, 64, 8, 40, 3), (96, 48, 8, 32, 3), (48, 48, 8, 32, 1), (2, 48, 10, 34, 1)])
 def test_conv_exact_on_small_integer_data(hip, dt, persist, shape):
     """Small-integer weights/inputs make every product and partial sum exactly representable, so the HIP conv
