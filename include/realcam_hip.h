@@ -236,7 +236,7 @@ int rc_pointwise_chain48(const void* d_x, int cin0, const void* d_w0packed, cons
  *   d_out = chain(d_x)                                         when d_raw == NULL
  *   d_out = (conv3x3(d_raw) + bias) * (chain(d_x) + 1)         otherwise -- one launch, the lens-shading map never reaches HBM.
  * A wave carries 64 pixels through every layer in MFMA fragments (no LDS round trip between layers); the map is rounded to bf16 where the
- * two-launch path stores it.  bf16 only, c = 48 or 128, cin0 <= 4, raw_c <= 4, 1 <= n_mid <= 4 (layers after the first).
+ * two-launch path stores it.  bf16 only, c = 32, 48, 64 or 128, cin0 <= 4, raw_c <= 4, 1 <= n_mid <= 4 (layers after the first).
  * d_blob: rc_lsc_pack's output (rc_lsc_packed_bytes bytes) on the device: w0 (c,cin0), wmid[l] (c,c), whead (c,raw_c,3,3) fp32 as in the
  * state_dict (+ biases, or NULL) re-ordered into pair-packed MFMA fragments.  d_x NHWC (batch,H,W,cin0), d_raw NHWC (batch,H,W,raw_c). */
 size_t rc_lsc_packed_bytes(int c, int n_mid, int has_head);

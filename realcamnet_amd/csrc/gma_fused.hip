@@ -1265,8 +1265,9 @@ __global__ __launch_bounds__(lsc_threads<C>(), 2) void lsc_chain_kernel(const Ls
 }  // namespace rc
 
 extern "C" size_t rc_lsc_packed_bytes(int c, int n_mid, int has_head) {
-    if (!(c == 48 || c == 128) || n_mid < 1) return 0;
-    const int w = c == 48 ? lsc_weight_bytes<48>(n_mid, has_head != 0) : lsc_weight_bytes<128>(n_mid, has_head != 0);
+    if (!(c == 32 || c == 48 || c == 64 || c == 128) || n_mid < 1) return 0;
+    const bool hd = has_head != 0;
+    const int w = c == 32 ? lsc_weight_bytes<32>(n_mid, hd) : c == 48 ? lsc_weight_bytes<48>(n_mid, hd) : c == 64 ? lsc_weight_bytes<64>(n_mid, hd) : lsc_weight_bytes<128>(n_mid, hd);
     return (size_t)w + (size_t)(1 + n_mid + (has_head ? 1 : 0)) * (c / 16) * 16 * 4;
 }
 
@@ -1274,7 +1275,7 @@ extern "C" size_t rc_lsc_packed_bytes(int c, int n_mid, int has_head) {
 extern "C" int rc_lsc_pack(const float* w0, const float* b0, int cin0, const float* const* wmid, const float* const* bmid, int n_mid,
                            const float* whead, const float* bhead, int raw_c, int c, void* dst) {
     RC_REQUIRE(w0 && wmid && bmid && dst, "rc_lsc_pack: null pointer");
-    RC_REQUIRE((c == 48 || c == 128) && n_mid >= 1 && n_mid <= 4 && cin0 >= 1 && cin0 <= 4, "rc_lsc_pack: width 48 or 128, 1..4 mid layers, cin0 <= 4");
+    RC_REQUIRE((c == 32 || c == 48 || c == 64 || c == 128) && n_mid >= 1 && n_mid <= 4 && cin0 >= 1 && cin0 <= 4, "rc_lsc_pack: width 32, 48, 64 or 128, 1..4 mid layers, cin0 <= 4");
     RC_REQUIRE(!whead || (raw_c >= 1 && raw_c <= 4), "rc_lsc_pack: the head's input has 1..4 channels");
     const int mt = c / 16, tbm = tile_bytes(c);
     char* p = static_cast<char*>(dst);
@@ -1313,7 +1314,7 @@ extern "C" int rc_lsc_pack(const float* w0, const float* b0, int cin0, const flo
 extern "C" int rc_lsc_chain(const void* d_x, int cin0, const void* d_blob, int c, int n_mid, float slope, const void* d_raw, int raw_c,
                             void* d_out, int batch, int H, int W, void* stream) {
     RC_REQUIRE(d_x && d_blob && d_out, "rc_lsc_chain: null pointer");
-    RC_REQUIRE((c == 48 || c == 128) && n_mid >= 1 && n_mid <= 4 && cin0 >= 1 && cin0 <= 4, "rc_lsc_chain: width 48 or 128, 1..4 mid layers, cin0 <= 4");
+    RC_REQUIRE((c == 32 || c == 48 || c == 64 || c == 128) && n_mid >= 1 && n_mid <= 4 && cin0 >= 1 && cin0 <= 4, "rc_lsc_chain: width 32, 48, 64 or 128, 1..4 mid layers, cin0 <= 4");
     RC_REQUIRE(!d_raw || (raw_c >= 1 && raw_c <= 4), "rc_lsc_chain: the head's input has 1..4 channels");
     RC_REQUIRE(batch >= 1 && H >= 1 && W >= 1 && (long long)batch * H * W * 8 < (1LL << 31), "rc_lsc_chain: bad shape (inputs must stay below 2 GiB)");
     RC_REQUIRE(slope >= 0.f && slope <= 1.f, "rc_lsc_chain: slope must be in [0, 1]");
@@ -1337,7 +1338,9 @@ extern "C" int rc_lsc_chain(const void* d_x, int cin0, const void* d_blob, int c
             RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lsc_chain_kernel<CC, HH>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
         hipLaunchKernelGGL((lsc_chain_kernel<CC, HH>), dim3((unsigned)grid), dim3(lsc_threads<CC>()), lds, as_stream(stream), a);              \
     } while (0)
-    if (c == 48) { if (d_raw) RC_LSC(48, true); else RC_LSC(48, false); }
+    if (c == 32) { if (d_raw) RC_LSC(32, true); else RC_LSC(32, false); }            // the ISPUNet family's width
+    else if (c == 48) { if (d_raw) RC_LSC(48, true); else RC_LSC(48, false); }
+    else if (c == 64) { if (d_raw) RC_LSC(64, true); else RC_LSC(64, false); }
     else { if (d_raw) RC_LSC(128, true); else RC_LSC(128, false); }
 #undef RC_LSC
     RC_HIP_CHECK(hipGetLastError());

@@ -718,7 +718,7 @@ def cat_linear(a: torch.Tensor, b: torch.Tensor, conv, residual: Optional[torch.
 
 
 def lsc_chain(lsc, coord: torch.Tensor, head=None, raw: Optional[torch.Tensor] = None):
-    """Lens_Shading_Correction as ONE launch with register-resident activations (realcam::lsc_chain), bf16, width 48 or 128:
+    """Lens_Shading_Correction as ONE launch with register-resident activations (realcam::lsc_chain), bf16, width 32 / 48 / 64 / 128:
     head is None -> lsc(coord);  else -> head(raw) * (lsc(coord) + 1)  (upstream models/LiteISP.py:2012-2014).  Returns None when the
     modules are not of that shape (the caller runs the layer-by-layer launches)."""
     import torch.nn as nn
@@ -729,7 +729,7 @@ def lsc_chain(lsc, coord: torch.Tensor, head=None, raw: Optional[torch.Tensor] =
         return None
     slopes = {float(m.negative_slope) for m in acts}
     c = convs[0].weight.shape[0]
-    if not (len(slopes) == 1 and 0.0 <= min(slopes) <= 1.0 and c in (48, 128) and convs[0].weight.shape[1] == coord.shape[-1] <= 4 and
+    if not (len(slopes) == 1 and 0.0 <= min(slopes) <= 1.0 and c in (32, 48, 64, 128) and convs[0].weight.shape[1] == coord.shape[-1] <= 4 and
             all(tuple(m.weight.shape[:2]) == (c, c) for m in convs[1:])):
         return None
     if head is not None:

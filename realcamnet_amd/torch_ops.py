@@ -288,7 +288,7 @@ def _lsc_pack_alloc(w0, b0, wmid, bmid, whead, bhead):
     n = lib().rc_lsc_packed_bytes(w0.shape[0], len(wmid), 1 if whead is not None else 0) if not _is_fake(w0) else \
         _lsc_bytes(w0.shape[0], len(wmid), whead is not None)
     if n == 0:
-        raise ValueError("lsc_pack: width must be 48 or 128 with at least one layer after the first")
+        raise ValueError("lsc_pack: width must be 32, 48, 64 or 128 with at least one layer after the first")
     return w0.new_empty((n,), dtype=torch.uint8)
 
 

@@ -711,7 +711,7 @@ def test_lens_shading_chain_equals_layer_by_layer(hip, shape):
     assert rel_err(outs[True], ref) < 3e-2 and rel_err(outs[False], ref) < 3e-2
 
 
-@pytest.mark.parametrize("width", [48, 128])
+@pytest.mark.parametrize("width", [32, 48, 64, 128])
 @pytest.mark.parametrize("shape", [(1, 5, 7), (2, 37, 70), (3, 64, 96), (1, 16, 200)])
 def test_lsc_chain_in_registers_vs_layer_by_layer(hip, shape, width):
     """rc_lsc_chain: the lens-shading chain with register-resident activations, alone and with the convolution it modulates folded in
