@@ -536,6 +536,8 @@ int rc_debug_stream_create_masked(int kind, void** stream_out);
  * contiguous = one range per block (else grid-stride); blocks = 0 -> one-shot grid (4 x 16 B per thread). */
 int rc_debug_hbm_probe(const void* src, void* dst, size_t bytes, int mode, int nt, int contiguous, int blocks, int iters,
                        double* ms_per_iter);
+/* waves_per_simd 11 / 12 (both calibrations): the same loop on RANDOM operands that change from MFMA to MFMA (4 A x 4 B register sets per wave):
+ * on toggling data the part runs at its board power cap, not at its maximum clock (tools/power_probe.py); ticks are not reported (0). */
 int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma);
 /* The same calibration on v_mfma_f32_32x32x16_bf16 (8 independent accumulators per wave). */
 int rc_debug_mfma_peak32(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma);

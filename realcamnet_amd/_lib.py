@@ -184,6 +184,11 @@ def load() -> C.CDLL:
     if lib.rc_abi_version() != ABI_VERSION:
         raise RuntimeError(f"ABI mismatch: library {lib.rc_abi_version()} vs binding {ABI_VERSION}")
     _lib = lib
+    # kernel experiments only: RC_DEBUG="key=value,key=value" applies rc_debug_set knobs at load (A/B runs of bench.py without code edits)
+    for kv in filter(None, os.environ.get("RC_DEBUG", "").split(",")):
+        k, _, v = kv.partition("=")
+        if lib.rc_debug_set(k.strip().encode(), int(v or "1")) != 0:
+            raise RuntimeError(f"RC_DEBUG: unknown knob {k!r}")
     return lib
 
 

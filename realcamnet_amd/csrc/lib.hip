@@ -58,6 +58,55 @@ __global__ __launch_bounds__(256) void mfma_peak32_kernel(float* sink, int iters
     if (s == 123.456f) sink[0] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0 && cycles) cycles[0] = t1 - t0;
 }
+// The same two loops with RANDOM operands that change from MFMA to MFMA (4 A and 4 B register sets per wave, random sign / exponent / mantissa bits):
+// what the matrix pipe sustains -- and draws -- on data that toggles like real activations and weights.  With constant operands (above) the part runs
+// at its maximum clock; on random data it sits at the board's power cap (tools/power_probe.py), which is the ceiling a conv kernel sees.
+__device__ __forceinline__ unsigned rnd_hash(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__device__ __forceinline__ unsigned rnd_bf16_pair(unsigned h) {          // two bf16 values +-[0.5, 4): sign, 2 exponent bits, 7 mantissa bits each from h
+    const unsigned lo = ((h & 1u) << 15) | ((126u + ((h >> 1) & 3u)) << 7) | ((h >> 3) & 127u);
+    const unsigned hi = (((h >> 10) & 1u) << 15) | ((126u + ((h >> 11) & 3u)) << 7) | ((h >> 13) & 127u);
+    return lo | (hi << 16);
+}
+template <int KIND>
+__global__ __launch_bounds__(256) void mfma_power_kernel(float* sink, int iters) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    bf16x8 a[4], b[4];
+    unsigned h = rnd_hash(blockIdx.x * 256u + threadIdx.x + 1u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32x4 ua, ub;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h = rnd_hash(h + e + 17u * i); ua[e] = rnd_bf16_pair(h); h = rnd_hash(h); ub[e] = rnd_bf16_pair(h); }
+        a[i] = __builtin_bit_cast(bf16x8, ua); b[i] = __builtin_bit_cast(bf16x8, ub);
+    }
+    float s = 0.f;
+    if constexpr (KIND == 16) {
+        f32x4 acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else {
+        f32x16 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 3], b[(i >> 1) & 3], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][5] + acc[i][10] + acc[i][15];
+    }
+    if (s == 123.456f) sink[0] = s;
+}
 }  // namespace rc
 
 
@@ -102,6 +151,8 @@ __global__ void __launch_bounds__(256) hbm_probe_kernel(const f4_t* __restrict__
 extern "C" {
 
 int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma) {
+    const bool random_ops = waves_per_simd > 10;             // 11 / 12: random operands that change from MFMA to MFMA (power, not clock, limits those)
+    if (random_ops) waves_per_simd -= 10;
     RC_REQUIRE(tflops != nullptr && iters >= 1 && waves_per_simd >= 1 && waves_per_simd <= 2, "rc_debug_mfma_peak: bad arguments");
     int dev = 0, cus = 0;
     RC_HIP_CHECK(hipGetDevice(&dev));
@@ -113,7 +164,8 @@ int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* me
     const int grid = cus * waves_per_simd;                // 256 threads = 4 waves = one per SIMD
     for (int rep = 0; rep < 3; ++rep) {                   // first passes bring the clocks up
         RC_HIP_CHECK(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(rc::mfma_peak_kernel, dim3(grid), dim3(256), 0, nullptr, sink, iters, cyc);
+        if (random_ops) hipLaunchKernelGGL(rc::mfma_power_kernel<16>, dim3(grid), dim3(256), 0, nullptr, sink, iters);
+        else hipLaunchKernelGGL(rc::mfma_peak_kernel, dim3(grid), dim3(256), 0, nullptr, sink, iters, cyc);
         RC_HIP_CHECK(hipEventRecord(e1, nullptr));
         RC_HIP_CHECK(hipEventSynchronize(e1));
     }
@@ -128,6 +180,8 @@ int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* me
 }
 
 int rc_debug_mfma_peak32(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma) {
+    const bool random_ops = waves_per_simd > 10;
+    if (random_ops) waves_per_simd -= 10;
     RC_REQUIRE(tflops != nullptr && iters >= 1 && waves_per_simd >= 1 && waves_per_simd <= 2, "rc_debug_mfma_peak32: bad arguments");
     const int cus = rc::device_cu_count();
     float* sink = nullptr; long long* cyc = nullptr;
@@ -137,7 +191,8 @@ int rc_debug_mfma_peak32(int waves_per_simd, int iters, double* tflops, double* 
     const int grid = cus * waves_per_simd;
     for (int rep = 0; rep < 3; ++rep) {
         RC_HIP_CHECK(hipEventRecord(e0, nullptr));
-        hipLaunchKernelGGL(rc::mfma_peak32_kernel, dim3(grid), dim3(256), 0, nullptr, sink, iters, cyc);
+        if (random_ops) hipLaunchKernelGGL(rc::mfma_power_kernel<32>, dim3(grid), dim3(256), 0, nullptr, sink, iters);
+        else hipLaunchKernelGGL(rc::mfma_peak32_kernel, dim3(grid), dim3(256), 0, nullptr, sink, iters, cyc);
         RC_HIP_CHECK(hipEventRecord(e1, nullptr));
         RC_HIP_CHECK(hipEventSynchronize(e1));
     }

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Is the level-0 48 -> 48 layer power / clock bound?  Runs the layer back to back for ~1.2 s per variant and samples rocm-smi (sclk, power) in the middle:
+kernel 2 and kernel 6 as shipped, kernel 6 with its stores / MFMAs / tile loads knocked out (conv_flags 1 / 2 / 4), a plain copy, and a pure MFMA loop."""
+import os, sys, time, subprocess, threading
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+from realcamnet_amd import networks as N, ops, _lib
+L = _lib.load()
+c = N.Conv2d(48, 48, 3, 1, 1).to("cuda", torch.bfloat16)
+x = torch.rand(8, 1088, 1920, 48, device="cuda").to(torch.bfloat16)
+y = torch.empty_like(x)
+
+
+def smi():
+    r = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True)
+    keep = []
+    for l in r.stdout.splitlines():
+        if "sclk" in l or "mclk" in l or "fclk" in l or "Power" in l:
+            keep.append(l.split(":", 1)[-1].strip() if "Power" not in l else "P " + l.split(":")[-1].strip())
+    return " | ".join(keep)
+
+
+def run(tag, fn, secs=1.2):
+    for _ in range(60): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn(); torch.cuda.synchronize()
+    e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+    n = max(50, int(secs * 1e3 / max(e0.elapsed_time(e1), 1e-3)))
+    out = {}
+    th = threading.Thread(target=lambda: (time.sleep(secs * 0.55), out.setdefault("smi", smi())))
+    e0.record()
+    th.start()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize(); th.join()
+    print(f"{tag:34s} {e0.elapsed_time(e1) / n:7.3f} ms   {out.get('smi')}", flush=True)
+
+
+def knobs(auto, flags):
+    assert L.rc_debug_set(b"persist_auto", auto) == 0 and L.rc_debug_set(b"conv_flags", flags) == 0
+
+
+print("idle:", smi())
+with torch.no_grad():
+    for tag, auto, flags in (("kernel 2", 0, 0), ("kernel 6", 1, 0), ("kernel 6, no stores", 1, 1), ("kernel 6, no MFMA", 1, 2), ("kernel 6, no tile loads", 1, 4),
+                             ("kernel 6, no loads, no stores", 1, 5), ("kernel 6, no MFMA no loads", 1, 6), ("kernel 7 (16 waves)", 2, 0), ("kernel 7, no MFMA", 2, 2)):
+        knobs(auto, flags)
+        run(tag, lambda: ops.conv2d(x, c, act="relu"))
+    knobs(0, 0)
+    # the multi-chunk kernel (wsm) on the two layer shapes that carry its time
+    for cin, H, W in ((192, 544, 960), (512, 136, 240), (128, 272, 480)):
+        cm = N.Conv2d(cin, cin, 3, 1, 1).to("cuda", torch.bfloat16)
+        xm = torch.rand(8, H, W, cin, device="cuda").to(torch.bfloat16)
+        fl = 2 * 8 * H * W * cin * cin * 9
+        for tag, flags in (("", 0), (", no MFMA", 2), (", no stores", 1)):
+            knobs(0, flags)
+            run(f"wsm {cin}->{cin} {H}x{W}{tag}", lambda: ops.conv2d(xm, cm, act="relu"))
+        print(f"    ({fl / 1e12:.3f} TFLOP per launch)")
+    knobs(0, 0)
+    import ctypes as C
+    for name, fn, wps in (("16x16x32 const", L.rc_debug_mfma_peak, 2), ("16x16x32 random", L.rc_debug_mfma_peak, 12), ("32x32x16 const", L.rc_debug_mfma_peak32, 2),
+                          ("32x32x16 random", L.rc_debug_mfma_peak32, 12), ("32x32x16 random, 1 wave/SIMD", L.rc_debug_mfma_peak32, 11)):
+        tf, tk = C.c_double(), C.c_double()
+        out = {}
+        th = threading.Thread(target=lambda: (time.sleep(1.6), out.setdefault("smi", smi())))
+        th.start()
+        assert fn(wps, 1600000 if "16x16" in name else 1600000, C.byref(tf), C.byref(tk)) == 0      # three launches of ~1 s each: the sample falls inside the second
+        th.join()
+        print(f"pure MFMA {name:30s} {tf.value:7.1f} TF/s   {out.get('smi')}", flush=True)
+    run("torch copy 1.6 -> 1.6 GB", lambda: y.copy_(x))
+    a = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16); b = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+    run("torch.matmul 8192^3 bf16", lambda: torch.matmul(a, b))
