@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """RAW->sRGB throughput benchmark (BASELINE.json metric: megapixels/sec at 4K; PSNR vs CPU reference).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One step = one pass of the hot path (RAW ingest: Bayer unshuffle + pad + bilinear cond resize -> LiteISPNet_GFM_LSC_GMA ->
@@ -195,15 +195,23 @@ def main():
     ap.add_argument("--no-codec-leg", action="store_true", help="default cfg3 run: skip the extra codec_leg key (raw_compression_tcm_final at 4 frames)")
     ap.add_argument("--layer-by-layer-tail", action="store_true", help="A/B: the tail as the module list's two launches (ops.FOLD_TAIL = False) instead of the folded 5x5 conv")
     ap.add_argument("--staged-gate", action="store_true", help="A/B: round 3's RCAB schedule (CALayer gate folded into the next conv's staging, ops.EARLY_GATE = False)")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="no GPU work: the launch / rendezvous / barrier / max-over-ranks skeleton with a trivial CPU step over gloo; prints a line marked as a self-test (tests only)")
     args = ap.parse_args()
 
+    from realcamnet_amd import shard
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:     # plain `python bench.py --gpus N`: become the N-rank torchrun job (does not return)
+        shard.relaunch_under_torchrun(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+    if args.launcher_selftest:
+        return launcher_selftest(args)
+
     import realcamnet_amd as M
-    from realcamnet_amd import ops, shard
+    from realcamnet_amd import ops
     ops.FOLD_TAIL, ops.EARLY_GATE = not args.layer_by_layer_tail, not args.staged_gate
 
     rank, world, local_rank = shard.init_distributed()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -321,6 +329,36 @@ def main():
         import liteisp_oracle as O
         res["psnr_db_vs_cpu_fp32"] = round(O.psnr(y.float().cpu(), ref), 2)
     print(json.dumps(res), flush=True)
+
+
+def launcher_selftest(args):
+    """The multi-rank skeleton of main() without a GPU: rendezvous (gloo), frame shard, K trivial CPU steps with the all-gather of their output
+    overlapped, barrier, max-over-ranks.  Rank 0 prints one JSON line whose metric says it is a self-test, never a measurement."""
+    import torch.distributed as dist
+    from realcamnet_amd import shard
+    rank, world, _ = shard.init_distributed("gloo")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+    B = args.frames
+    s, e = shard.frame_shard(B * world, rank, world)
+    x = torch.arange(s, e, dtype=torch.float32).view(B, 1, 1, 1).expand(B, 3, 4, 4).contiguous()
+    gather = shard.OverlappedGather(B * world) if dist.is_initialized() else None
+    shard.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = x * 2.0
+        if gather is not None:
+            gather.submit(out)
+    got = gather.wait() if gather is not None else out
+    shard.barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0)
+    ok = bool(torch.equal(got[:, 0, 0, 0], 2.0 * torch.arange(B * world, dtype=torch.float32)))
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (no GPU work, not a measurement)", "n_gpus": world, "steps": args.steps, "gathered_ok": ok,
+                          "launched_by": "self (torch.distributed.run re-exec)" if os.environ.get("TORCHELASTIC_RUN_ID") else "single process",
+                          "ms_per_step": round(1e3 * elapsed / max(args.steps, 1), 3)}), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def bench_codec(args, net, sd_cpu, step, inputs, rank, world, dev, dt):

@@ -163,6 +163,15 @@ _SIGS = {
 }
 
 _lib = None
+_knobs = {}
+
+
+def knob(key: bytes) -> int:
+    """rc_debug_get(key), cached until the knob is set again (rc_debug_set through this binding drops the cached value)."""
+    v = _knobs.get(key)
+    if v is None:
+        v = _knobs[key] = load().rc_debug_get(key)
+    return v
 
 
 def load() -> C.CDLL:
@@ -183,6 +192,13 @@ def load() -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     if lib.rc_abi_version() != ABI_VERSION:
         raise RuntimeError(f"ABI mismatch: library {lib.rc_abi_version()} vs binding {ABI_VERSION}")
+    # rc_debug_get is asked on every conv (pack-cache key): mirror the knobs here and invalidate the mirror whenever one is set through this binding
+    raw_set = lib.rc_debug_set
+
+    def _set(key, value):
+        _knobs.pop(bytes(key), None)
+        return raw_set(key, value)
+    lib.rc_debug_set = _set
     _lib = lib
     # kernel experiments only: RC_DEBUG="key=value,key=value" applies rc_debug_set knobs at load (A/B runs of bench.py without code edits)
     for kv in filter(None, os.environ.get("RC_DEBUG", "").split(",")):

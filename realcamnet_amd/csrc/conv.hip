@@ -17,7 +17,8 @@ extern int g_dw3_seg16;            // gma.hip
 extern int g_dec_lds;              // rans.hip
 static int g_pss = 0;              // rc_debug_set("pss", v): 1: single-chunk pixel-shuffle layers (the tail 48 -> 192) take kernel 5 (output staged through LDS, stored by the
                                    // loader waves); 0 (default): kernel 4.  Measured on MI355X at 8 x 1088 x 1920: 3.16-3.29 vs 3.24-3.27 ms (conv_kernel.hpp, kernel 5)
-static int g_auto = 0;             // rc_debug_set("persist_auto", v): 1: single-chunk, single-cout-tile bf16 3x3 layers (48 -> 48, 32 -> 32) take kernel 6 (wave-autonomous strips)
+static int g_auto = 1;             // rc_debug_set("persist_auto", v): single-chunk, single-cout-tile bf16 3x3 layers (48 -> 48, 32 -> 32) on kernel 6 (wave-autonomous strips):
+                                   // 0 never, 1 (default) the plain / ReLU / LeakyReLU / +sums forms (1-5 % faster than kernel 2; profiles/r05_power_wall.md), 2 also the residual forms (4-5 % slower)
 static int g_conv32 = 0;           // rc_debug_set("conv32", v): which layers take the 32x32x16 forms (conv32_kernel.hpp).  0 (default) none: the one layer they were
                                    // faster on (48 -> 192 + residual at 544x960x8: 1.25 vs 1.31 ms) now runs on the persistent kernel with the residual prefetched
                                    // (1.13 ms); 4 = that layer family (one-chunk 48 -> 96k NHWC) only; 1 all eligible layers, multi-chunk
@@ -263,7 +264,7 @@ int rc_debug_set(const char* key, int value) {
     if (std::string(key) == "dec_lds") { g_dec_lds = value != 0; return RC_OK; }
     if (std::string(key) == "dw3_seg16") { g_dw3_seg16 = value != 0; return RC_OK; }
     if (std::string(key) == "pss") { g_pss = value != 0; return RC_OK; }
-    if (std::string(key) == "persist_auto") { g_auto = value < 0 ? 0 : (value > 5 ? 5 : value); return RC_OK; }
+    if (std::string(key) == "persist_auto") { g_auto = value < 0 ? 0 : (value > 2 ? 2 : value); return RC_OK; }
     if (std::string(key) == "conv32") { g_conv32 = value < 0 ? 0 : (value > 4 ? 4 : value); return RC_OK; }
     return fail(RC_ERR_INVALID, std::string("rc_debug_set: unknown key ") + key);
 }

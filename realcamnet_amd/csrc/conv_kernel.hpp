@@ -99,17 +99,17 @@ __host__ __device__ constexpr bool unit_map(int upt, int taps, int s, int q, int
     return u < taps * upt;
 }
 
-template <typename T, int CK_, int NT_, int KS_, int TH_ = kTH, int TW_ = kTW>
+template <typename T, int CK_, int NT_, int KS_, int TH_ = kTH>
 struct ConvCfg {
     using elem = T;
-    static constexpr int CK = CK_, NT = NT_, KS = KS_, TH = TH_, TW = TW_;   // TH x TW: pixel-tile rows / columns staged per block (2 rows per compute wave; TW != 32: kernel 7 only)
+    static constexpr int CK = CK_, NT = NT_, KS = KS_, TH = TH_;   // TH: pixel-tile rows staged per block (2 per compute wave)
     static constexpr int UNIT = 16 / (int)sizeof(T);
     static_assert(CK % UNIT == 0, "CK must be a whole number of 16-byte units");
     static constexpr int UPT = CK / UNIT;         // units per tap
     static constexpr int TAPS = KS * KS;
     static constexpr int STEPS = unit_map_steps(UPT, TAPS);  // MFMA steps per Cin chunk
     static constexpr int HALO = KS / 2;
-    static constexpr int THH = TH + 2 * HALO, TWH = TW + 2 * HALO;
+    static constexpr int THH = TH + 2 * HALO, TWH = kTW + 2 * HALO;
     static constexpr int SPIX = pix_stride_bytes(CK * (int)sizeof(T));
     static constexpr int IN_BYTES = THH * TWH * SPIX;
     static constexpr int G_RAW = (80 * 1024 - IN_BYTES) / (NT * 1024);
@@ -189,29 +189,6 @@ __device__ __forceinline__ void buf_store_row(__amdgpu_buffer_rsrc_t r, int voff
             __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]}, r, voff + 16 * i, 0, 0);
         if constexpr (NV % 8 != 0)
             __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{w[4 * NQ], w[4 * NQ + 1]}, r, voff + 16 * NQ, 0, 0);
-    }
-}
-
-// The same NV packed bf16 values into an LDS out tile instead (kernel 6: the wave's own strip buffer, stored to memory afterwards as whole
-// kilobytes per instruction).  dst is 8-byte aligned; 16-byte pieces only when a lane's run is a multiple of 16 bytes.
-template <int NV, bool PK_RELU>
-__device__ __forceinline__ void lds_store_row_bf16(char* dst, const float* v) {
-    unsigned w[NV / 2];
-#pragma unroll
-    for (int i = 0; i < NV / 2; ++i) {
-        w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-        if constexpr (PK_RELU) {
-            typedef short s16x2 __attribute__((ext_vector_type(2)));
-            const s16x2 z = {0, 0};
-            w[i] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, w[i]), z));
-        }
-    }
-    if constexpr (NV % 8 == 0) {
-#pragma unroll
-        for (int i = 0; i < NV / 8; ++i) *reinterpret_cast<uint4*>(dst + 16 * i) = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < NV / 4; ++i) *reinterpret_cast<uint2*>(dst + 8 * i) = make_uint2(w[2 * i], w[2 * i + 1]);
     }
 }
 
@@ -619,70 +596,6 @@ struct ConvDev {
         }
     }
 
-    // ---- narrow wave tile (kernel 7): 2 pixel tiles (rows 0 and 1 of a 2 x 16 sub-strip) x NT cout tiles ------------------------------
-    // Same steps, same unit map, same order as mma_steps: a pixel's accumulation chain is identical, only half as many pixels per wave.
-    static constexpr int FR2 = NT + 2, FM2 = 2 * NT;
-    template <int I>
-    __device__ static __forceinline__ void load_frag_item2(int s, const char* s_in, const char* s_w, int lane_x, int lane_w, const LaneOff& lo,
-                                                           uint4 (&wf)[NT], uint4 (&xf)[2]) {
-        if constexpr (I < NT) wf[I] = *reinterpret_cast<const uint4*>(s_w + (s * NT + I) * 1024 + lane_w);
-        else xf[I - NT] = *reinterpret_cast<const uint4*>(s_in + lane_x + step_off(s, lo) + (I - NT) * TWH * SPIX);
-    }
-    __device__ static __forceinline__ void zero_pad_frags2(int s, int q, uint4 (&xf)[2]) {
-        if (step_has_pad(s)) {
-            if (lane_is_pad(s, q)) { xf[0] = make_uint4(0u, 0u, 0u, 0u); xf[1] = make_uint4(0u, 0u, 0u, 0u); }
-        }
-    }
-    template <int I, bool NEXT>
-    __device__ static __forceinline__ void step_interleaved2(int s, const char* s_in, const char* s_w, int lane_x, int lane_w, const LaneOff& lo,
-                                                             const uint4 (&wf)[NT], const uint4 (&xf)[2], uint4 (&wfn)[NT], uint4 (&xfn)[2], f32x4 (&acc)[2][NT]) {
-        if constexpr (I < FR2) {
-            if constexpr (NEXT) load_frag_item2<I>(s + 1, s_in, s_w, lane_x, lane_w, lo, wfn, xfn);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int m = (I * FM2) / FR2; m < ((I + 1) * FM2) / FR2; ++m) Mma<T>::run(wf[m % NT], xf[m / NT], acc[m / NT][m % NT]);
-            __builtin_amdgcn_sched_barrier(0);
-            step_interleaved2<I + 1, NEXT>(s, s_in, s_w, lane_x, lane_w, lo, wf, xf, wfn, xfn, acc);
-        }
-    }
-    template <bool DBUF>
-    __device__ static __forceinline__ void mma_steps2(const char* s_in, const char* s_w, int lane_x, int lane_w, int q, const LaneOff& lo, f32x4 (&acc)[2][NT]) {
-        static_assert(ES == 2, "bf16 form");
-        if constexpr (!DBUF) {                 // one fragment set, compiler-scheduled: four waves per SIMD cover the LDS latency, 20 registers fewer
-#pragma unroll
-            for (int s = 0; s < STEPS; ++s) {
-                uint4 wf[NT], xf[2];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const uint4*>(s_w + (s * NT + nt) * 1024 + lane_w);
-                xf[0] = *reinterpret_cast<const uint4*>(s_in + lane_x + step_off(s, lo));
-                xf[1] = *reinterpret_cast<const uint4*>(s_in + lane_x + step_off(s, lo) + TWH * SPIX);
-                zero_pad_frags2(s, q, xf);
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) Mma<T>::run(wf[nt], xf[p], acc[p][nt]);
-            }
-            return;
-        }
-        uint4 wfa[NT], xfa[2], wfb[NT], xfb[2];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wfa[nt] = *reinterpret_cast<const uint4*>(s_w + nt * 1024 + lane_w);
-        xfa[0] = *reinterpret_cast<const uint4*>(s_in + lane_x + step_off(0, lo));
-        xfa[1] = *reinterpret_cast<const uint4*>(s_in + lane_x + step_off(0, lo) + TWH * SPIX);
-        zero_pad_frags2(0, q, xfa);
-#pragma unroll
-        for (int s = 0; s < STEPS; s += 2) {
-            if (s + 1 < STEPS) step_interleaved2<0, true>(s, s_in, s_w, lane_x, lane_w, lo, wfa, xfa, wfb, xfb, acc);
-            else step_interleaved2<0, false>(s, s_in, s_w, lane_x, lane_w, lo, wfa, xfa, wfb, xfb, acc);
-            if (s + 1 < STEPS) {
-                zero_pad_frags2(s + 1, q, xfb);
-                if (s + 2 < STEPS) step_interleaved2<0, true>(s + 1, s_in, s_w, lane_x, lane_w, lo, wfb, xfb, wfa, xfa, acc);
-                else step_interleaved2<0, false>(s + 1, s_in, s_w, lane_x, lane_w, lo, wfb, xfb, wfa, xfa, acc);
-                if (s + 2 < STEPS) zero_pad_frags2(s + 2, q, xfa);
-            }
-        }
-    }
-
     // ---- epilogue ---------------------------------------------------------------------------------------
     // lane (q, n) holds, per pixel tile pt, packed couts jbase .. jbase+NV-1 of pixel (row, col0+n).
     // The accumulators already contain the bias (it is the MFMA chain's initial C operand).
@@ -696,21 +609,21 @@ struct ConvDev {
 
     template <bool FAST>
     __device__ static __forceinline__ void epilogue(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
-                                                    f32x4 (&acc)[4][NT], char* lds_out = nullptr) {
+                                                    f32x4 (&acc)[4][NT]) {
         // fp32 always takes the generic form: with the seven-way switch hipcc keeps the fp32 accumulators in scratch
         // (224 B/lane, measured 92 -> 74 TF/s), and its MFMA loop is 4x longer per tile anyway
         if constexpr (!FAST || ES == 4) return epilogue_generic(a, b, y0, x0, sp, ct, tid, acc);
         else switch (a.ep_key) {                  // uniform; set by the host, >= 0 in FAST kernels
-            case 0: return epilogue_fast<0>(a, b, y0, x0, sp, ct, tid, acc, lds_out);
-            case EP_RELU: return epilogue_fast<EP_RELU>(a, b, y0, x0, sp, ct, tid, acc, lds_out);
-            case EP_LEAKY: return epilogue_fast<EP_LEAKY>(a, b, y0, x0, sp, ct, tid, acc, lds_out);
-            case EP_RES: return epilogue_fast<EP_RES>(a, b, y0, x0, sp, ct, tid, acc, lds_out);
-            case EP_SUMS: return epilogue_fast<EP_SUMS>(a, b, y0, x0, sp, ct, tid, acc, lds_out);
-            case EP_MUL: return epilogue_fast<EP_MUL>(a, b, y0, x0, sp, ct, tid, acc, lds_out);
-            case EP_FILM | EP_LEAKY: return epilogue_fast<EP_FILM | EP_LEAKY>(a, b, y0, x0, sp, ct, tid, acc, lds_out);
-            case EP_RELU | EP_SUMS: return epilogue_fast<EP_RELU | EP_SUMS>(a, b, y0, x0, sp, ct, tid, acc, lds_out);       // RCAB conv1 of the early-gate schedule
-            case EP_LEAKY | EP_SUMS: return epilogue_fast<EP_LEAKY | EP_SUMS>(a, b, y0, x0, sp, ct, tid, acc, lds_out);     // ... of the codec's ResidualBlockWithCA
-            case EP_GATE | EP_RES: return epilogue_fast<EP_GATE | EP_RES>(a, b, y0, x0, sp, ct, tid, acc, lds_out);         // RCAB conv2: conv * gate + x
+            case 0: return epilogue_fast<0>(a, b, y0, x0, sp, ct, tid, acc);
+            case EP_RELU: return epilogue_fast<EP_RELU>(a, b, y0, x0, sp, ct, tid, acc);
+            case EP_LEAKY: return epilogue_fast<EP_LEAKY>(a, b, y0, x0, sp, ct, tid, acc);
+            case EP_RES: return epilogue_fast<EP_RES>(a, b, y0, x0, sp, ct, tid, acc);
+            case EP_SUMS: return epilogue_fast<EP_SUMS>(a, b, y0, x0, sp, ct, tid, acc);
+            case EP_MUL: return epilogue_fast<EP_MUL>(a, b, y0, x0, sp, ct, tid, acc);
+            case EP_FILM | EP_LEAKY: return epilogue_fast<EP_FILM | EP_LEAKY>(a, b, y0, x0, sp, ct, tid, acc);
+            case EP_RELU | EP_SUMS: return epilogue_fast<EP_RELU | EP_SUMS>(a, b, y0, x0, sp, ct, tid, acc);       // RCAB conv1 of the early-gate schedule
+            case EP_LEAKY | EP_SUMS: return epilogue_fast<EP_LEAKY | EP_SUMS>(a, b, y0, x0, sp, ct, tid, acc);     // ... of the codec's ResidualBlockWithCA
+            case EP_GATE | EP_RES: return epilogue_fast<EP_GATE | EP_RES>(a, b, y0, x0, sp, ct, tid, acc);         // RCAB conv2: conv * gate + x
             default: return;                      // unreachable: the host launches the !FAST kernel for other masks
         }
     }
@@ -751,18 +664,17 @@ struct ConvDev {
 
     template <int F>
     __device__ static __forceinline__ void epilogue_fast(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
-                                                         f32x4 (&acc)[4][NT], char* lds_out = nullptr) {
+                                                         f32x4 (&acc)[4][NT]) {
         float none[NV];
-        epilogue_fast_impl<F, false>(a, b, y0, x0, sp, ct, tid, acc, none, true, lds_out);
+        epilogue_fast_impl<F, false>(a, b, y0, x0, sp, ct, tid, acc, none, true);
     }
     // RUN (CALayer sums in a persistent kernel): `run` carries this lane's channel sums from tile to tile; only when
     // `flush` is set (the block's next tile belongs to another image, or there is none) are they reduced over the 16-lane
     // rows and written, to the current tile's slot -- the other tiles' slots get zeros, so rc_ca_gate's fixed-order fold
     // over all slots is unchanged.  Per tile this leaves NV adds per pixel tile instead of a 4-step DPP reduction of NV values.
-    // lds_out (kernel 6, NHWC, one cout tile): instead of storing, leave the packed tile in LDS as [2 rows][32 pixels][COUT_TILE] (strip_store_linear writes it out)
     template <int F, bool RUN>
     __device__ static __forceinline__ void epilogue_fast_impl(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
-                                                              f32x4 (&acc)[4][NT], float (&run)[NV], bool flush, char* lds_out = nullptr) {
+                                                              f32x4 (&acc)[4][NT], float (&run)[NV], bool flush) {
         const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
         const int jbase = ct * Cfg::COUT_TILE + q * NV;
         const size_t img_out = (size_t)a.H * a.W * a.cout;    // output / residual / mul image (elements)
@@ -855,13 +767,9 @@ struct ConvDev {
                     for (int e = 0; e < NV; ++e) csum[e] += valid ? v[e] : 0.f;
                 }
             }
-            if (lds_out != nullptr) {
-                if constexpr (ES == 2) lds_store_row_bf16<NV, PK_RELU>(lds_out + ((dy * kTW + dx * 16 + n) * Cfg::COUT_TILE + q * NV) * 2, v);
-            } else {
-                int oo = (valid && !(a.dbg_flags & 1)) ? o_off0 + dy * o_row + dx * o_col : kOOB;
-                if ((a.dbg_flags & 8) && oo != kOOB) oo &= 0x3fffff;      // knock-out: every store lands in one 4 MB window (L2-resident: no HBM write stream)
-                buf_store_row<T, NV, PK_RELU>(r_out, oo, v);
-            }
+            int oo = (valid && !(a.dbg_flags & 1)) ? o_off0 + dy * o_row + dx * o_col : kOOB;
+            if ((a.dbg_flags & 8) && oo != kOOB) oo &= 0x3fffff;      // knock-out: every store lands in one 4 MB window (L2-resident: no HBM write stream)
+            buf_store_row<T, NV, PK_RELU>(r_out, oo, v);
         }
         if constexpr ((F & EP_SUMS) != 0) {
             if (!RUN || flush) {
@@ -909,7 +817,7 @@ struct ConvDev {
     // gate_row: image b's row of out_scale (key EP_GATE | EP_RES), or NULL.  Kernel 6 passes a row of its LDS copy: a GLOBAL load issued here
     // is younger than the next tile's prefetch, and waiting for it (vmcnt counts in order) drains the prefetch.
     __device__ static __forceinline__ void epilogue_res_pre(const ConvArgs& a, int b, int y0, int x0, int ct, int tid, f32x4 (&acc)[4][NT],
-                                                            const unsigned (&rp)[4][NRH], const float* gate_row, char* lds_out = nullptr) {
+                                                            const unsigned (&rp)[4][NRH], const float* gate_row) {
         const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
         const int jbase = ct * Cfg::COUT_TILE + q * NV;
         // key EP_GATE | EP_RES (uniform): v * out_scale[b][c] first.  ONE copy of this epilogue with a uniform branch: a second instantiation
@@ -945,121 +853,8 @@ struct ConvDev {
                 v[2 * i] += __uint_as_float(rp[pt][i] << 16);
                 v[2 * i + 1] += __uint_as_float(rp[pt][i] & 0xffff0000u);
             }
-            if (lds_out != nullptr) {
-                if constexpr (ES == 2) lds_store_row_bf16<NV, false>(lds_out + ((dy * kTW + dx * 16 + n) * Cfg::COUT_TILE + q * NV) * 2, v);
-            } else {
-                const int oo = (valid && !(a.dbg_flags & 1)) ? off0 + dy * row_b + dx * col_b : kOOB;
-                buf_store_row<T, NV, false>(r_out, oo, v);
-            }
-        }
-    }
-
-    // Kernel 6: the packed [2 rows][32 pixels][COUT_TILE] bf16 tile a wave left in its own LDS strip -> NHWC output, one KILOBYTE of consecutive
-    // addresses per store instruction (a row of the tile is 32 * COUT_TILE * 2 bytes = a whole number of KB).  The MFMA D layout gives a lane
-    // NV channels of one pixel: stored directly that is 2 instructions per pixel tile of 16- and 8-byte pieces at a 96-byte pitch, and store
-    // ISSUE is what the epilogue costs (~190-250 cycles per scattered buffer_store_dwordx4 per wave, 2-3x less for whole runs).
-    __device__ static __forceinline__ void strip_store_linear(const ConvArgs& a, int b, int gy, int x0, const char* lds_out, int lane) {
-        constexpr int PXB = Cfg::COUT_TILE * 2, ROWB = kTW * PXB, NS = 2 * ROWB / 1024, SPR = ROWB / 1024;
-        static_assert(ROWB % 1024 == 0, "a tile row is a whole number of KB");
-        const size_t img_out = (size_t)a.H * a.W * a.cout;
-        const __amdgpu_buffer_rsrc_t r_out = make_rsrc(static_cast<T*>(a.out) + (size_t)b * img_out, (unsigned)(img_out * ES));
-        const bool full = gy + 2 <= a.H && x0 + kTW <= a.W && !(a.dbg_flags & 1);     // uniform
-        const int base = (gy * a.W + x0) * PXB + lane * 16, row_b = a.W * PXB;
-        uint4 v[NS];
-#pragma unroll
-        for (int j = 0; j < NS; ++j) v[j] = *reinterpret_cast<const uint4*>(lds_out + j * 1024 + lane * 16);
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            const int row = j / SPR, inrow = (j % SPR) * 1024;
-            int off = base + row * row_b + inrow;
-            if (!full) {
-                const int px = (inrow + lane * 16) / PXB;
-                if (gy + row >= a.H || x0 + px >= a.W || (a.dbg_flags & 1)) off = kOOB;
-            }
-            buf_store16(r_out, off, 0, v[j]);
-        }
-    }
-
-    // ---- kernel 7: epilogue of a 2-row x 16-pixel sub-strip (lane (n, q): pixel (gy + p, gx0 + n), channels q NV .. q NV + NV - 1) ------------
-    // NHWC, one cout tile, bf16.  F: EP_RELU / EP_LEAKY / EP_SUMS (carried: `run`, written to slot (sp, wv) when `flush`) / EP_RES (+ EP_GATE),
-    // the residual prefetched into rp by sub_res_prefetch.  Same arithmetic, same order as epilogue_fast_impl / epilogue_res_pre.
-    __device__ static __forceinline__ void sub_res_prefetch(const ConvArgs& a, int b, int gy, int gx0, int lane, unsigned (&rp)[2][NRH]) {
-        const int q = lane >> 4, n = lane & 15;
-        const size_t img_out = (size_t)a.H * a.W * a.cout;
-        const __amdgpu_buffer_rsrc_t r_res = make_rsrc(static_cast<const T*>(a.residual) + (size_t)b * img_out, (unsigned)(img_out * ES));
-        const int gx = gx0 + n;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int po = (gy + p < a.H && gx < a.W) ? (((gy + p) * a.W + gx) * a.cout + q * NV) * ES : kOOB;
-#pragma unroll
-            for (int i = 0; i < NRH / 4; ++i) {
-                const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r_res, po + 16 * i, 0, 0);
-                rp[p][4 * i] = t.x; rp[p][4 * i + 1] = t.y; rp[p][4 * i + 2] = t.z; rp[p][4 * i + 3] = t.w;
-            }
-            if constexpr (NRH % 4 != 0) {
-                const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(r_res, po + 16 * (NRH / 4), 0, 0);
-                rp[p][4 * (NRH / 4)] = t.x; rp[p][4 * (NRH / 4) + 1] = t.y;
-            }
-        }
-    }
-    template <int F, int NRP>
-    __device__ static __forceinline__ void epilogue_sub(const ConvArgs& a, int b, int gy, int gx0, int sp, int wv, int lane, f32x4 (&acc)[2][NT],
-                                                        float (&run)[(F & EP_SUMS) ? NV : 1], bool flush, const unsigned (&rp)[NRP][(F & EP_RES) ? NRH : 1],
-                                                        const float* gate_row) {
-        const int q = lane >> 4, n = lane & 15, jbase = q * NV;
-        const size_t img_out = (size_t)a.H * a.W * a.cout;
-        const __amdgpu_buffer_rsrc_t r_out = make_rsrc(static_cast<T*>(a.out) + (size_t)b * img_out, (unsigned)(img_out * ES));
-        const int gx = gx0 + n;
-        float gs[(F & EP_GATE) ? NV : 1];
-        if constexpr ((F & EP_GATE) != 0) {
-#pragma unroll
-            for (int e = 0; e < NV; e += 4) {
-                const float4 g4 = *reinterpret_cast<const float4*>(gate_row + jbase + e);
-                gs[e] = g4.x; gs[e + 1] = g4.y; gs[e + 2] = g4.z; gs[e + 3] = g4.w;
-            }
-        }
-        const float inf = __builtin_inff();
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const bool valid = gy + p < a.H && gx < a.W;
-            float v[NV];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[p][nt][r];
-            constexpr bool PK_RELU = F == EP_RELU;
-            if constexpr ((F & EP_RELU) != 0 && !PK_RELU) {
-#pragma unroll
-                for (int e = 0; e < NV; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.f, inf);
-            }
-            if constexpr ((F & EP_LEAKY) != 0) {
-#pragma unroll
-                for (int e = 0; e < NV; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], v[e] * a.act_slope, inf);
-            }
-            if constexpr ((F & EP_GATE) != 0) {
-#pragma unroll
-                for (int e = 0; e < NV; ++e) v[e] *= gs[e];
-            }
-            if constexpr ((F & EP_RES) != 0) {
-#pragma unroll
-                for (int i = 0; i < NRH; ++i) {
-                    v[2 * i] += __uint_as_float(rp[p][i] << 16);
-                    v[2 * i + 1] += __uint_as_float(rp[p][i] & 0xffff0000u);
-                }
-            }
-            if constexpr ((F & EP_SUMS) != 0) {
-#pragma unroll
-                for (int e = 0; e < NV; ++e) run[e] += valid ? v[e] : 0.f;
-            }
-            const int oo = (valid && !(a.dbg_flags & 1)) ? (((gy + p) * a.W + gx) * a.cout + jbase) * ES : kOOB;
-            buf_store_row<T, NV, PK_RELU>(r_out, oo, v);
-        }
-        if constexpr ((F & EP_SUMS) != 0) {
-            if (flush) {
-                write_chan_sums(a, b, sp, wv, n, jbase, run, false);
-#pragma unroll
-                for (int e = 0; e < NV; ++e) run[e] = 0.f;
-            }
+            const int oo = (valid && !(a.dbg_flags & 1)) ? off0 + dy * row_b + dx * col_b : kOOB;
+            buf_store_row<T, NV, false>(r_out, oo, v);
         }
     }
 
@@ -1368,12 +1163,16 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
         else D::stage_tile_scalar(a, b, y0, x0, 0, tid, s_in, static_cast<typename Cfg::elem*>(a.in_store));
         constexpr bool RUN_SUMS = FAST && sizeof(typename Cfg::elem) == 2 && NT >= 3;   // sums carried across the block's tiles (narrow tiles: per-tile sums; their
                                                                                         // 168-register instantiations have no room for the carried values)
-        if constexpr (RUN_SUMS) {
-            if ((a.ep_key == D::EP_SUMS || a.ep_key == (D::EP_RELU | D::EP_SUMS)) && n_ct == 1) D::zero_sum_slots(a, b, sp, tid);   // uniform; RUN form below
-        }
         const int cb = b, csp = sp, cy0 = y0, cx0 = x0;
         const int next = tile + (int)gridDim.x;
         tile = next < n_tiles ? next : -1;
+        if constexpr (RUN_SUMS) {
+            // RUN form below: a tile whose sums are CARRIED on leaves zeros in its slots.  A tile that flushes (the block's next tile is another image's, or
+            // there is none) writes its slots itself in the epilogue: no zero store for it -- nothing then depends on a zero store and a flush store to the
+            // same address being ordered (they were, through the fences of the two __syncthreads() between them, but only by that).
+            const bool will_flush = tile < 0 || magic_div(tile, a.td.sp_total) != cb;                                             // uniform
+            if ((a.ep_key == D::EP_SUMS || a.ep_key == (D::EP_RELU | D::EP_SUMS)) && n_ct == 1 && !will_flush) D::zero_sum_slots(a, cb, csp, tid);
+        }
 
         for (int ct = 0; ct < n_ct; ++ct) {
             if (n_ct > 1) {
@@ -1964,8 +1763,7 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_pss_kernel(const ConvAr
 // ==================================================================================================
 // Kernel 6: wave-AUTONOMOUS persistent form for single-chunk, single-cout-tile bf16 layers (the 48 -> 48 convolutions: half of the step).
 // Kernel 2 keeps two 4-wave blocks per CU, each with its own copy of the packed weights (43 KB) and ONE halo tile; the waves of a block
-// meet at two workgroup barriers per tile, so a CU has at most two tiles' loads in flight and every wave waits for its block's slowest
-// (measured: loads 0.29, stores 0.37, MFMA + epilogue 0.51 ms of a 0.76 ms layer -- the phases of the two blocks overlap 70 %).
+// meet at two workgroup barriers per tile, so a CU has at most two tiles' loads in flight and every wave waits for its block's slowest.
 // gfx950 has no sub-group barrier, so three tiles in flight cannot be three teams of one block.  Here a CU runs ONE block of 8 waves
 // that share the weights and nothing else: wave w owns a 2-row x 32-pixel STRIP (the wave tile of every other form: 4 pixel tiles x NT
 // cout tiles) with a PRIVATE 4 x 34 halo strip in LDS (13 KB; 8 x 13 + 43 KB of weights), loads it itself (13 x 16 B per lane,
@@ -1975,8 +1773,13 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_pss_kernel(const ConvAr
 // with the neighbouring strips are read by sibling waves of the same CU at about the same time (L2 hits; HBM traffic unchanged).
 // Same unit map, same MFMA chain, same epilogues (a strip IS wave j & 3 of an ordinary 8 x 32 tile) -> bit-identical to kernels 1-4.
 // Every load of the loop is issued unconditionally (out-of-range strips load from offset kOOB = no memory access), so hipcc can count
-// them: the epilogue's wait for the prefetched residual leaves the next strip's 13 loads in flight (a conditional issue makes it
-// wait vmcnt(0), section 4.8 of DESIGN.md).
+// them; per-image vectors an epilogue needs (the CALayer gate of key EP_GATE | EP_RES) are copied to LDS once per block: a global load
+// issued after the MFMA loop is younger than the next strip's prefetch and its wait (vmcnt counts in order) would drain it.
+// MEASURED (profiles/r05_power_wall.md): 0.756-0.78 ms on the level-0 plain layer against kernel 2's 0.76-0.785 -- and the same again with
+// whole-kilobyte stores staged through the strip buffer, and with half the wave tile at 3 or 4 waves per SIMD ("kernel 7", removed).
+// All of them run the socket at its 1400 W cap with the shader clock throttled to 1.6-1.9 GHz: time = joules per launch / 1.1 kW, and
+// none of this changes the joules.  Kept for the forms where it is 1-5 % faster (plain, ReLU, + channel sums: `persist_auto` 1);
+// the residual forms stay on kernel 2.
 // ==================================================================================================
 constexpr int kAutoWaves = 8, kAutoThreads = 64 * kAutoWaves, kAutoBias = 64, kAutoGate = 1024;   // LDS floats: bias; the (batch, cout) CALayer gates of key EP_GATE | EP_RES
 template <class Cfg>
@@ -2119,177 +1922,20 @@ __global__ __launch_bounds__(kAutoThreads) void conv_mfma_auto_kernel(const Conv
         }
         if (!(a.dbg_flags & 2)) D::template mma_steps<0, STEPS, 0, true>(s_my, s_w, lane_x, lane_w, q, lo, acc);
 
-        char* const s_out = (a.dbg_flags & 32) ? nullptr : s_my;     // conv_flags 32 (A/B): store straight from the MFMA layout like kernels 1-5
         if constexpr (MODE == 1) {
             const bool flush = nu < 0 || nb != cb;                   // uniform: this wave's next strip belongs to another image (or there is none)
             if (!flush) {                                            // a strip whose sums are carried on leaves ZEROS in its slot (rc_ca_gate's fixed-order fold reads every slot)
                 float* dst = a.chan_sums + (((size_t)cb * (a.tiles_x * a.tiles_y) + sp) * 4 + (wave & 3)) * a.cout;
                 if (4 * lane < a.cout) *reinterpret_cast<float4*>(dst + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            if (a.ep_key == D8::EP_SUMS) D8::template epilogue_fast_impl<D8::EP_SUMS, true>(a, cb, y0, x0, sp, 0, ftid, acc, run, flush, s_out);
-            else D8::template epilogue_fast_impl<D8::EP_RELU | D8::EP_SUMS, true>(a, cb, y0, x0, sp, 0, ftid, acc, run, flush, s_out);
+            if (a.ep_key == D8::EP_SUMS) D8::template epilogue_fast_impl<D8::EP_SUMS, true>(a, cb, y0, x0, sp, 0, ftid, acc, run, flush);
+            else D8::template epilogue_fast_impl<D8::EP_RELU | D8::EP_SUMS, true>(a, cb, y0, x0, sp, 0, ftid, acc, run, flush);
         } else if constexpr (MODE == 2) {
-            D8::epilogue_res_pre(a, cb, y0, x0, 0, ftid, acc, rpre, gated_out ? s_gate + cb * a.cout : nullptr, s_out);
+            D8::epilogue_res_pre(a, cb, y0, x0, 0, ftid, acc, rpre, gated_out ? s_gate + cb * a.cout : nullptr);
         } else {
-            D8::template epilogue<true>(a, cb, y0, x0, sp, 0, ftid, acc, s_out);
+            D8::template epilogue<true>(a, cb, y0, x0, sp, 0, ftid, acc);
         }
-        // the tile is in this wave's strip buffer (dead since the MFMA loop; pixel tile pt of wave j & 3 sits at row pt >> 1): out as whole kilobytes
-        if (s_out != nullptr) D8::strip_store_linear(a, cb, y0 + 2 * (wave & 3), x0, s_out, lane);
         cu = nu; cb = nb; cty8 = nty8; ctx = ntx;
-    }
-}
-
-// ==================================================================================================
-// Kernel 7: kernel 6 with HALF the wave tile and twice the waves.  Kernels 2 and 6 tie (0.76 ms on the level-0 48 -> 48 layer whether the
-// waves meet at barriers or not, whether the stores leave as 16-byte pieces or whole kilobytes: tools/auto_probe.py): what they share is TWO
-// waves per SIMD (256 registers each), each of which spends about half of a strip's time waiting for its own loads, its own LDS fragments or a
-// store-issue slot -- with two such waves a SIMD idles whenever both wait.  Here a wave's unit of work is a 2-row x 16-pixel SUB-strip:
-// 2 pixel tiles x NT cout tiles = 24 accumulator registers instead of 48, 7 prefetch registers x 4 instead of 13 x 4, 12 residual registers
-// instead of 24 -> 128 registers, FOUR waves per SIMD, 16 autonomous waves per CU (private 4 x 18 halo sub-strips: 16 x 6.75 KB + the
-// shared 42 KB of weights).  A wave still owns whole 2 x 32 strips (left half, then right half), so the CALayer partial-sum slots and the
-// tile walk are those of kernel 6.  Price: 5 fragment reads per 6 MFMAs instead of 7 per 12 (LDS read traffic x1.43, still under half the
-// pipe) and 2.25x instead of 2.1x halo reads through L2.  Same chain per pixel -> bit-identical results.
-// ==================================================================================================
-template <class Cfg, int NW>
-constexpr int auto16_lds_bytes() { return (int)Cfg::CHUNK_W_BYTES + (kAutoBias + kAutoGate) * 4 + NW * ConvCfg<typename Cfg::elem, Cfg::CK, Cfg::NT, Cfg::KS, 2, 16>::IN_BYTES; }
-
-template <class Cfg8, int MODE, int NW, bool DBUF>
-__global__ __launch_bounds__(64 * NW) void conv_mfma_auto16_kernel(const ConvArgs a) {
-    using T = typename Cfg8::elem;
-    using Cfg = ConvCfg<T, Cfg8::CK, Cfg8::NT, Cfg8::KS, 2, 16>;
-    using D = ConvDev<Cfg>;
-    constexpr int NT = Cfg::NT, STEPS = Cfg::STEPS, NV = 4 * NT, UPT = Cfg::UPT, UNIT = Cfg::UNIT, TWH = Cfg::TWH, SPIX = Cfg::SPIX, ES = 2;
-    constexpr int NPIX = Cfg::THH * TWH, NU = NPIX * UPT, NI = (NU + 63) / 64, RU = TWH * UPT, NG = NW / 4;
-    constexpr bool LINEAR = SPIX == UPT * 16;
-    static_assert(Cfg::HALO == 1 && Cfg::THH == 4 && RU >= 64 && NW % 4 == 0, "3x3, 2 x 16 sub-strips, groups of 4 waves");
-    constexpr int EP_RELU = D::EP_RELU, EP_LEAKY = D::EP_LEAKY, EP_RES = D::EP_RES, EP_SUMS = D::EP_SUMS, EP_GATE = D::EP_GATE;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_w = smem;
-    float* s_bias = reinterpret_cast<float*>(smem + Cfg::CHUNK_W_BYTES);
-    float* s_gate = s_bias + kAutoBias;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    char* s_my = smem + Cfg::CHUNK_W_BYTES + (kAutoBias + kAutoGate) * 4 + wave * Cfg::IN_BYTES;
-    const int q = lane >> 4, n = lane & 15;
-    const int wv = wave & 3;                                         // strip of its group's 8 x 32 tile (= the wave index the other kernels' epilogues use)
-
-    for (int kb = wave; kb < STEPS * NT; kb += NW)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.wpacked) + kb * 1024 + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(s_w + kb * 1024), 16, 0, 0);
-    for (int i = tid; i < kAutoBias; i += 64 * NW) s_bias[i] = (a.bias && i < a.cout_packed) ? a.bias[i] : 0.f;
-    [[maybe_unused]] const bool gated_out = a.ep_key == (EP_GATE | EP_RES);
-    if constexpr (MODE == 2) {
-        if (gated_out)
-            for (int i = tid; i < a.batch * a.cout; i += 64 * NW) s_gate[i] = a.out_scale[i];
-    }
-
-    const int sp_total = a.tiles_x * a.tiles_y;
-    const int n_units = sp_total * a.batch;
-    // a block is NG groups of 4 waves, each walking its own list of 8 x 32 tiles (band-major); XCD x (blockIdx % 8) takes a run of consecutive tiles
-    const int slots = (int)(gridDim.x >> 3) * NG;
-    const int pos = (blockIdx.x & 7) * slots + (blockIdx.x >> 3) * NG + (wave >> 2);
-    const int stride = (int)gridDim.x * NG;
-    const size_t img = (size_t)a.H * a.W * a.cin;
-    const unsigned img_bytes = (unsigned)(img * ES);
-
-    auto next_strip = [&](int from, int& b, int& ty8, int& tx) -> int {
-        if (from >= n_units) return -1;
-        b = magic_div(from, a.td.sp_total);
-        band_decode(from - b * sp_total, a.tiles_x, a.tiles_y, a.td, ty8, tx);
-        return from;
-    };
-
-    const int rdelta = (a.W * a.cin - RU * UNIT) * ES;
-    uint4 r[NI];
-    auto issue = [&](bool valid, int b, int ty8, int tx, int half) {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(static_cast<const T*>(a.in0) + (size_t)b * img, img_bytes);
-        const int gy0 = ty8 * kTH + 2 * wv - 1, gx0 = tx * kTW + 16 * half - 1;
-        const bool interior = valid && gy0 >= 0 && gx0 >= 0 && gy0 + Cfg::THH <= a.H && gx0 + TWH <= a.W && a.cin_chunk_ok;   // uniform
-        if (interior) {
-            const int soff = (gy0 * a.W + gx0) * a.cin * ES;
-            const int l16 = lane * 16;
-#pragma unroll
-            for (int k = 0; k < NI; ++k) {
-                const int row0 = (64 * k) / RU, t = (row0 + 1) * RU - 64 * k;
-                int voff = l16;
-                if (t < 64) voff = lane >= t ? l16 + rdelta : l16;
-                if (64 * k + 63 >= NU) voff = lane + 64 * k < NU ? voff : kOOB;
-                r[k] = buf_load16(rs, voff, soff + 1024 * k + row0 * rdelta);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NI; ++k) {
-                const int u = lane + 64 * k, pix = u / UPT, v = u - pix * UPT, py = pix / TWH, px = pix - py * TWH;
-                const int gy = gy0 + py, gx = gx0 + px;
-                const bool ok = valid && u < NU && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && v * UNIT < a.cin;
-                r[k] = buf_load16(rs, ok ? ((gy * a.W + gx) * a.cin + v * UNIT) * ES : kOOB, 0);
-            }
-        }
-    };
-
-    typename D::LaneOff lo;
-    D::lane_offsets(q, lo);
-    const int lane_x = n * SPIX, lane_w = lane * 16;
-
-    int cb = 0, cty8 = 0, ctx = 0, chalf = 0;
-    int cu = next_strip(pos, cb, cty8, ctx);
-    issue(cu >= 0, cb, cty8, ctx, 0);
-    __syncthreads();
-
-    float run[MODE == 1 ? NV : 1];
-#pragma unroll
-    for (int e = 0; e < (MODE == 1 ? NV : 1); ++e) run[e] = 0.f;
-
-    while (cu >= 0) {
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            if (64 * k + 63 < NU || lane + 64 * k < NU) {
-                const int u = lane + 64 * k;
-                if constexpr (LINEAR) *reinterpret_cast<uint4*>(s_my + u * 16) = r[k];
-                else *reinterpret_cast<uint4*>(s_my + (u / UPT) * SPIX + (u % UPT) * 16) = r[k];
-            }
-        }
-        const int gy = cty8 * kTH + 2 * wv, gx0 = ctx * kTW + 16 * chalf, sp = cty8 * a.tiles_x + ctx;
-        // the sub-strip after this one: the right half of the same strip, or the left half of this wave's next strip
-        int nb = cb, nty8 = cty8, ntx = ctx, nu = cu;
-        const int nhalf = chalf ^ 1;
-        if (chalf == 1) nu = next_strip(cu + stride, nb, nty8, ntx);
-        unsigned rpre[MODE == 2 ? 2 : 1][MODE == 2 ? D::NRH : 1];
-        if constexpr (MODE == 2) D::sub_res_prefetch(a, cb, gy, gx0, lane, rpre);
-        issue(nu >= 0, nb, nty8, ntx, nhalf);
-
-        f32x4 acc[2][NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float4 t4 = *reinterpret_cast<const float4*>(s_bias + q * NV + nt * 4);
-            acc[0][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
-            acc[1][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
-        }
-        if (!(a.dbg_flags & 2)) D::template mma_steps2<DBUF>(s_my, s_w, lane_x, lane_w, q, lo, acc);
-
-        if constexpr (MODE == 1) {
-            const bool last = chalf == 1;
-            const bool flush = last && (nu < 0 || nb != cb);         // uniform: the strip's sums leave with its right half, if the wave's next strip is another image's
-            if (last && !flush) {
-                float* dst = a.chan_sums + (((size_t)cb * (a.tiles_x * a.tiles_y) + sp) * 4 + wv) * a.cout;
-                if (4 * lane < a.cout) *reinterpret_cast<float4*>(dst + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            const unsigned none[1][1] = {{0u}};
-            if (a.ep_key == EP_SUMS) D::template epilogue_sub<EP_SUMS, 1>(a, cb, gy, gx0, sp, wv, lane, acc, run, flush, none, nullptr);
-            else D::template epilogue_sub<EP_RELU | EP_SUMS, 1>(a, cb, gy, gx0, sp, wv, lane, acc, run, flush, none, nullptr);
-        } else if constexpr (MODE == 2) {
-            float none[1] = {0.f};
-            if (gated_out) D::template epilogue_sub<EP_GATE | EP_RES, 2>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, rpre, s_gate + cb * a.cout);
-            else D::template epilogue_sub<EP_RES, 2>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, rpre, nullptr);
-        } else {
-            float none[1] = {0.f};
-            const unsigned nonr[1][1] = {{0u}};
-            if (a.ep_key == EP_RELU) D::template epilogue_sub<EP_RELU, 1>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, nonr, nullptr);
-            else if (a.ep_key == EP_LEAKY) D::template epilogue_sub<EP_LEAKY, 1>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, nonr, nullptr);
-            else D::template epilogue_sub<0, 1>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, nonr, nullptr);
-        }
-        cu = nu; cb = nb; cty8 = nty8; ctx = ntx; chalf = nhalf;
     }
 }
 
@@ -2368,45 +2014,14 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
         }
     }
     if constexpr (!GATED && FAST && auto_eligible<Cfg>()) {
-        // wave-autonomous persistent form (kernel 6): rc_debug_set("persist_auto", 1)
+        // wave-autonomous persistent form (kernel 6): rc_debug_set("persist_auto", 0 / 1 / 2)
         using DD = ConvDev<Cfg>;
         // keys whose epilogue would load per-image vectors or a second map from global memory after the MFMA loop (FiLM, x (lsc + 1)) stay on kernel 2
         const bool key_ok = a.ep_key >= 0 && (a.ep_key & (DD::EP_FILM | DD::EP_MUL)) == 0 && (a.ep_key != (DD::EP_GATE | DD::EP_RES) || a.batch * a.cout <= kAutoGate);
-        const bool mode_ok = a.auto_impl != 5 || (a.ep_key & DD::EP_RES) == 0;      // persist_auto 5: the residual forms stay on kernel 2
+        const bool mode_ok = a.auto_impl == 2 || (a.ep_key & DD::EP_RES) == 0;      // persist_auto 1 (default): the residual forms stay on kernel 2 (4-5 % faster there); 2: every eligible form
         if (a.auto_impl && key_ok && mode_ok && a.n_chunks == 1 && a.n_ct == 1 && a.cin_vec_ok && a.persist_ok && a.out_mode == RC_OUT_NHWC && n_tiles < (1 << 24)) {
             constexpr int A_LDS = auto_lds_bytes<Cfg>();
             const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch;
-            if (a.auto_impl >= 2 && a.auto_impl <= 4) {                // kernel 7: 2 x 16 sub-strips; persist_auto 2: 16 waves per CU (128 registers), 3: 12 waves (168), 4: 16 waves, double-buffered fragments
-                const int k7 = a.ep_key;
-                if (k7 == 0 || k7 == DD::EP_RELU || k7 == DD::EP_LEAKY || k7 == DD::EP_SUMS || k7 == (DD::EP_RELU | DD::EP_SUMS) || k7 == DD::EP_RES || k7 == (DD::EP_GATE | DD::EP_RES)) {
-                    const int mode = (k7 & DD::EP_SUMS) ? 1 : (k7 & DD::EP_RES) ? 2 : 0;
-                    const int ng = a.auto_impl == 3 ? 3 : 4;         // groups of 4 waves per block
-                    int grid = a.num_cus;
-                    if (grid * ng > n_tiles) grid = (n_tiles + ng - 1) / ng;
-                    grid = (grid + 7) / 8 * 8;
-                    auto go = [&](auto kern, int lds, int threads) -> int {
-                        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-                        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads), lds, stream, a);
-                        RC_HIP_CHECK(hipGetLastError());
-                        return RC_OK;
-                    };
-                    constexpr int L16 = auto16_lds_bytes<Cfg, 16>(), L12 = auto16_lds_bytes<Cfg, 12>();
-                    static_assert(L16 <= 160 * 1024, "kernel 7 LDS");
-                    if (a.auto_impl == 2) {
-                        if (mode == 1) return go(&conv_mfma_auto16_kernel<Cfg, 1, 16, false>, L16, 1024);
-                        if (mode == 2) return go(&conv_mfma_auto16_kernel<Cfg, 2, 16, false>, L16, 1024);
-                        return go(&conv_mfma_auto16_kernel<Cfg, 0, 16, false>, L16, 1024);
-                    } else if (a.auto_impl == 3) {
-                        if (mode == 1) return go(&conv_mfma_auto16_kernel<Cfg, 1, 12, true>, L12, 768);
-                        if (mode == 2) return go(&conv_mfma_auto16_kernel<Cfg, 2, 12, true>, L12, 768);
-                        return go(&conv_mfma_auto16_kernel<Cfg, 0, 12, true>, L12, 768);
-                    } else {
-                        if (mode == 1) return go(&conv_mfma_auto16_kernel<Cfg, 1, 16, true>, L16, 1024);
-                        if (mode == 2) return go(&conv_mfma_auto16_kernel<Cfg, 2, 16, true>, L16, 1024);
-                        return go(&conv_mfma_auto16_kernel<Cfg, 0, 16, true>, L16, 1024);
-                    }
-                }
-            }
             static PerDeviceFlag attr_set;
             if (!attr_set.test_and_set()) {
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_auto_kernel<Cfg, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));

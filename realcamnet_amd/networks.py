@@ -287,7 +287,7 @@ class RCABlock(HipModule):
     def _early(self, a) -> bool:
         mods = list(self.res)
         return (ops.EARLY_GATE and len(mods) == 3 and isinstance(mods[0], Conv2d) and _is_act(mods[1]) and isinstance(mods[2], Conv2d) and
-                tuple(mods[2].weight.shape[2:]) == (3, 3) and mods[2].weight.shape[0] == mods[2].weight.shape[1] and
+                ops.gate_ahead_ok(mods[0], mods[2], self.ca) and           # stride 1, zero padding 1, C -> C, squeeze -> ReLU -> excite -> Sigmoid: else the closed form is wrong
                 not (isinstance(mods[1], nn.ReLU) and ops.conv_pair_ok(a, mods[0], mods[2])))
 
     def _nhwc_early(self, a):

@@ -109,7 +109,7 @@ def packed_conv(mod, act_dtype: torch.dtype, out_mode: int) -> PackedConv:
     w, b = mod.weight, mod.bias
     c = _cache(mod)
     k = ("conv", act_dtype, out_mode)
-    key = (_key(w, b), _lib.load().rc_debug_get(b"conv32"))      # the 32x32x16 layers' packed order depends on that knob (and on nothing else)
+    key = (_key(w, b), _lib.knob(b"conv32"))      # the 32x32x16 layers' packed order depends on that knob (and on nothing else); mirrored host-side, no C call per conv
     hit = c.get(k)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -764,6 +764,26 @@ def ca_gate(sums: torch.Tensor, hw: int, ca) -> torch.Tensor:
 # linear in its input, so conv1's channel sums + t's four border lines give it), and conv2's epilogue writes x_new = conv2(t) * gate + x directly.
 # Per block 5 map passes instead of 6 (the gated staging form read r and skip and wrote x and t); False: gate folded into the NEXT conv's staging.
 EARLY_GATE = True
+
+
+def gate_ahead_ok(conv1, conv2, ca) -> bool:
+    """Is the closed form of ca_gate_ahead valid for this block?  It assumes conv2 = 3x3, C -> C, stride 1, zero padding 1, dilation 1, groups 1 fed by
+    conv1's C channels, and a channel attention of the shape squeeze (1x1 conv / Linear) -> ReLU -> excite -> Sigmoid.  Anything else (another
+    checkpoint-compatible conv2 configuration or activation) must take the schedule that reduces conv2's real output."""
+    w = getattr(conv2, "weight", None)
+    if w is None or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3) or w.shape[0] != w.shape[1]:
+        return False
+    one = lambda v, k: tuple(v) == (k, k) if isinstance(v, (tuple, list)) else v == k
+    if not (one(conv2.stride, 1) and one(conv2.padding, 1) and one(conv2.dilation, 1) and conv2.groups == 1 and getattr(conv2, "padding_mode", "zeros") == "zeros"):
+        return False
+    if getattr(conv1, "weight", None) is None or conv1.weight.shape[0] != w.shape[1]:
+        return False
+    seq = getattr(ca, "conv_du", None) or getattr(ca, "fc", None)
+    if seq is None or len(seq) != 4 or not isinstance(seq[1], torch.nn.ReLU) or not isinstance(seq[3], torch.nn.Sigmoid):
+        return False
+    c0, c1 = seq[0], seq[2]
+    ok_layer = lambda m: isinstance(m, torch.nn.Linear) or (isinstance(m, torch.nn.Conv2d) and tuple(m.weight.shape[2:]) == (1, 1) and m.groups == 1 and one(m.stride, 1))
+    return ok_layer(c0) and ok_layer(c1) and c0.weight.shape[1] == w.shape[0] and c1.weight.shape[0] == w.shape[0] and c1.weight.shape[1] == c0.weight.shape[0]
 
 
 def ca_gate_ahead(sums_t: torch.Tensor, t: torch.Tensor, conv2, ca) -> torch.Tensor:

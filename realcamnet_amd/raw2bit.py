@@ -45,7 +45,7 @@ class ResidualBlockWithCA(nn.Module):
 
     def _nhwc(self, a):
         identity = a if self.skip is None else self.skip._nhwc(a)
-        if ops.EARLY_GATE and tuple(self.conv2.weight.shape[2:]) == (3, 3) and self.conv2.weight.shape[0] == self.conv2.weight.shape[1]:
+        if ops.EARLY_GATE and ops.gate_ahead_ok(self.conv1, self.conv2, self.ca):
             # the gate of conv2's output from conv1's channel sums, ahead of conv2 (ops.ca_gate_ahead); conv2's epilogue writes conv2(t) * gate + skip
             t, sums = self.conv1._nhwc(a, act="leaky", slope=float(self.leaky_relu.negative_slope), want_sums=True)
             return self.conv2._nhwc(t, out_scale=ops.ca_gate_ahead(sums, t, self.conv2, self.ca), residual=identity)

@@ -44,6 +44,30 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local_rank
 
 
+def torchrun_command(script: str, argv, nproc: int, port: Optional[int] = None):
+    """The command that runs `script argv...` as `nproc` ranks of one node under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1:
+    the container hostname may not resolve).  `port` None = a free port picked here."""
+    import socket
+    import sys
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(nproc)}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script, *argv]
+
+
+def relaunch_under_torchrun(script: str, argv, nproc: int) -> None:
+    """`python bench.py --gpus N` with N > 1 and no launcher in the environment: replace this process by the N-rank torchrun job (never returns).
+    The reference's only multi-GPU hook is a one-process nn.DataParallel (upstream models/networks.py:99-106): one command, no launcher -- this keeps that
+    calling convention for the one-process-per-GPU path.  Under a launcher (WORLD_SIZE set) this must not be called."""
+    if "WORLD_SIZE" in os.environ:
+        raise RuntimeError("relaunch_under_torchrun: already under a launcher")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = torchrun_command(script, list(argv), nproc)
+    os.execv(cmd[0], cmd)
+
+
 def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
     """All-reduce(MAX) of a host scalar (the reported wall time is the slowest rank's)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

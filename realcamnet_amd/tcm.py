@@ -429,23 +429,35 @@ class _Fp32Masters:
         m = self.__dict__.get("_f32_masters", {}).get(name)
         if live.dtype == torch.float32 or m is None or m.shape != live.shape:
             return live.detach().float()
-        return m.to(live.device)
+        m = m.to(live.device)
+        if not torch.equal(m.to(live.dtype), live.detach()):          # the low-precision tensor was written after the cast: it is the truth, the master is stale
+            return live.detach().float()
+        return m
 
     def _apply(self, fn, recurse=True):
         masters = self.__dict__.setdefault("_f32_masters", {})
         # snapshot first: nn.Module._apply swaps a Parameter's .data in place, so the "old" object would show the new dtype afterwards
         pre = {n: getattr(self, n).detach().clone() for n in self._MASTER_NAMES
                if getattr(self, n).dtype == torch.float32 and getattr(self, n).numel() > 0}
+        # a master is authoritative only while the live low-precision tensor is still ITS rounding: a value written while the module was bf16
+        # (optimizer step, p.data = ..., copy_) must survive the cast back, not be reverted to the stale master
+        stale = set()
+        for n, m in masters.items():
+            live = getattr(self, n, None)
+            if live is not None and live.dtype != torch.float32 and m.shape == live.shape and not torch.equal(m.to(live.device).to(live.dtype), live.detach()):
+                stale.add(n)
         out = super()._apply(fn, recurse) if _APPLY_TAKES_RECURSE else super()._apply(fn)
         for n in self._MASTER_NAMES:
             new = getattr(self, n)
             if new.dtype == torch.float32:
                 m = masters.pop(n, None)
-                if m is not None and m.shape == new.shape:            # back to fp32 after a rounding cast: restore what the cast rounded, so
-                    with torch.no_grad():                             # .to(bf16).float() leaves the coder's tensors exact (tables stay identical)
+                if m is not None and m.shape == new.shape and n not in stale:   # back to fp32 after a rounding cast: restore what the cast rounded, so
+                    with torch.no_grad():                                       # .to(bf16).float() leaves the coder's tensors exact (tables stay identical)
                         new.copy_(m.to(new.device))
             elif n in pre:
                 masters[n] = pre[n]                                   # this cast rounded an fp32 tensor: keep what it rounded
+            elif n in stale:
+                masters.pop(n, None)                                  # the live values were changed under the master: they are the truth now
             if n in masters:
                 masters[n] = masters[n].to(new.device)
                 if n in self._buffers:                                # a buffer (scale_table) simply stays fp32: the state_dict keeps exact values

@@ -120,6 +120,26 @@ def test_coder_tables_do_not_depend_on_the_order_of_cast_and_update():
     assert not torch.equal(a.quantiles[:, 0, 1].float(), med)                                   # (the live bf16 parameter IS rounded)
 
 
+def test_values_written_while_bf16_survive_the_cast_back_to_fp32():
+    """the saved fp32 master used to be copied over the live tensor on every cast back to fp32, silently reverting a coder parameter that was
+    changed while the module was bf16 (optimizer step, p.data = ..., copy_).  A master is authoritative only while the live tensor is still its rounding."""
+    from realcamnet_amd import tcm
+    torch.manual_seed(5)
+    eb = tcm.EntropyBottleneck(4)
+    exact = eb.quantiles.detach().clone() + 0.123456789
+    with torch.no_grad():
+        eb.quantiles.copy_(exact)
+    eb = eb.to(torch.bfloat16)
+    assert torch.equal(eb._master("quantiles"), exact)                       # untouched: the master (exact fp32) is what the coder reads
+    assert torch.equal(eb.float().quantiles, exact)                          # ... and what a cast back restores
+    eb = eb.to(torch.bfloat16)
+    with torch.no_grad():
+        eb.quantiles.add_(1.0)                                               # written while bf16
+    live = eb.quantiles.detach().float().clone()
+    assert torch.equal(eb._master("quantiles"), live)                        # the coder sees the new values, not the stale master
+    assert torch.equal(eb.float().quantiles, live) and not torch.equal(live, exact)
+
+
 def test_bad_index_is_an_error():
     t, tables = _tables()
     with pytest.raises(Exception):

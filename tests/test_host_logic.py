@@ -127,3 +127,62 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
                        capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_bench_launches_itself_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` with no launcher in the environment (the driver's N = 1 command form at N > 1) re-executes itself under
+    torch.distributed.run with one rank per GPU; --launcher-selftest swaps the GPU step for a trivial CPU step over gloo, so the whole
+    launch / rendezvous / shard / overlapped gather / barrier / max-over-ranks skeleton runs here.  The torchrun form keeps working."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3", "--frames", "2", "--launcher-selftest"], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["gathered_ok"] is True and line["launched_by"].startswith("self") and "not a measurement" in line["metric"]
+    # one GPU: no launcher, no process group
+    r1 = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "2", "--launcher-selftest"], capture_output=True, text=True, timeout=120, env=env)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    assert json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])["launched_by"] == "single process"
+    # the driver's multi-GPU form: already under torch.distributed.run -> no second launch; a rank count that contradicts --gpus is an error
+    cmd = shard.torchrun_command(bench, ["--gpus", "2", "--steps", "2", "--frames", "2", "--launcher-selftest"], 2)
+    r2 = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert r2.returncode == 0 and json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 2, r2.stdout + r2.stderr
+    bad = subprocess.run(shard.torchrun_command(bench, ["--gpus", "3", "--launcher-selftest"], 2), capture_output=True, text=True, timeout=240, env=env)
+    assert bad.returncode != 0 and "--nproc-per-node must equal --gpus" in (bad.stdout + bad.stderr)
+
+
+def test_early_gate_is_taken_only_where_its_closed_form_holds():
+    """ca_gate_ahead's closed form (the mean of conv2's output from conv1's channel sums and border lines) holds for a 3x3, C -> C, stride 1,
+    zero padding 1, dilation 1, groups 1 convolution and a squeeze -> ReLU -> excite -> Sigmoid attention only; any other checkpoint-compatible
+    configuration must take the schedule that reduces conv2's real output instead of silently computing a wrong gate."""
+    import torch.nn as nn
+    from realcamnet_amd import networks as N, ops, raw2bit as RB
+    blk = N.RCABlock(32, 32, 3, 1, 1, True, "CRC", 16)
+    c1, c2 = blk.res[0], blk.res[2]
+    assert ops.gate_ahead_ok(c1, c2, blk.ca)
+    rb = RB.ResidualBlockWithCA(32, 32)
+    assert ops.gate_ahead_ok(rb.conv1, rb.conv2, rb.ca)
+    for bad in (nn.Conv2d(32, 32, 3, 2, 1), nn.Conv2d(32, 32, 3, 1, 2, dilation=2), nn.Conv2d(32, 32, 3, 1, 1, groups=2), nn.Conv2d(32, 32, 3, 1, 1, padding_mode="reflect"),
+                nn.Conv2d(32, 32, 3, 1, 0), nn.Conv2d(32, 32, 5, 1, 2), nn.Conv2d(32, 48, 3, 1, 1), nn.Conv2d(16, 32, 3, 1, 1)):
+        assert not ops.gate_ahead_ok(c1, bad, blk.ca), bad
+    ca = N.CALayer(32, 16)
+    ca.conv_du[1] = nn.LeakyReLU(0.1)
+    assert not ops.gate_ahead_ok(c1, c2, ca)
+    ca = N.CALayer(32, 16)
+    ca.conv_du[3] = nn.Tanh()
+    assert not ops.gate_ahead_ok(c1, c2, ca)
+    assert not ops.gate_ahead_ok(nn.Conv2d(32, 16, 3, 1, 1), c2, blk.ca)           # conv1 must produce conv2's C channels
+    blk.ca.conv_du[1] = nn.LeakyReLU(0.1)
+    assert not blk._early(None)                                                     # the block itself falls back to the staged schedule
+
+
+def test_debug_knobs_are_mirrored_host_side():
+    """packed_conv asked the library for the `conv32` knob on every conv of every forward; the binding now mirrors knobs and drops the
+    mirrored value whenever one is set through it."""
+    from realcamnet_amd import _lib
+    L = _lib.load()
+    assert L.rc_debug_set(b"conv32", 0) == 0 and _lib.knob(b"conv32") == 0 and _lib._knobs.get(b"conv32") == 0
+    assert L.rc_debug_set(b"conv32", 4) == 0 and b"conv32" not in _lib._knobs and _lib.knob(b"conv32") == 4
+    assert L.rc_debug_set(b"conv32", 0) == 0 and _lib.knob(b"conv32") == 0
+    assert L.rc_debug_get(b"persist_auto") == 1                                     # default: kernel 6 for the plain / +sums forms

@@ -11,7 +11,7 @@ L = _lib.load()
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 
 
-VARIANTS = (("k2", 0, 0), ("k6", 1, 0), ("k7 16w", 2, 0), ("k7 12w", 3, 0), ("k7 16w dbuf", 4, 0))
+VARIANTS = (("kernel 2", 0, 0), ("kernel 6", 2, 0))
 
 
 def knob(v, flags=0):

@@ -42,31 +42,32 @@ def knobs(auto, flags):
 
 print("idle:", smi())
 with torch.no_grad():
-    for tag, auto, flags in (("kernel 2", 0, 0), ("kernel 6", 1, 0), ("kernel 6, no stores", 1, 1), ("kernel 6, no MFMA", 1, 2), ("kernel 6, no tile loads", 1, 4),
-                             ("kernel 6, no loads, no stores", 1, 5), ("kernel 6, no MFMA no loads", 1, 6), ("kernel 7 (16 waves)", 2, 0), ("kernel 7, no MFMA", 2, 2)):
+    for tag, auto, flags in (("kernel 2", 0, 0), ("kernel 6", 2, 0), ("kernel 6, no stores", 2, 1), ("kernel 6, no MFMA", 2, 2), ("kernel 6, no tile loads", 2, 4),
+                             ("kernel 6, no loads, no stores", 2, 5), ("kernel 6, no MFMA no loads", 2, 6)):
         knobs(auto, flags)
         run(tag, lambda: ops.conv2d(x, c, act="relu"))
-    knobs(0, 0)
+    knobs(1, 0)
     # the multi-chunk kernel (wsm) on the two layer shapes that carry its time
     for cin, H, W in ((192, 544, 960), (512, 136, 240), (128, 272, 480)):
         cm = N.Conv2d(cin, cin, 3, 1, 1).to("cuda", torch.bfloat16)
         xm = torch.rand(8, H, W, cin, device="cuda").to(torch.bfloat16)
         fl = 2 * 8 * H * W * cin * cin * 9
         for tag, flags in (("", 0), (", no MFMA", 2), (", no stores", 1)):
-            knobs(0, flags)
+            knobs(1, flags)
             run(f"wsm {cin}->{cin} {H}x{W}{tag}", lambda: ops.conv2d(xm, cm, act="relu"))
         print(f"    ({fl / 1e12:.3f} TFLOP per launch)")
-    knobs(0, 0)
+    knobs(1, 0)
     import ctypes as C
     for name, fn, wps in (("16x16x32 const", L.rc_debug_mfma_peak, 2), ("16x16x32 random", L.rc_debug_mfma_peak, 12), ("32x32x16 const", L.rc_debug_mfma_peak32, 2),
                           ("32x32x16 random", L.rc_debug_mfma_peak32, 12), ("32x32x16 random, 1 wave/SIMD", L.rc_debug_mfma_peak32, 11)):
         tf, tk = C.c_double(), C.c_double()
         out = {}
-        th = threading.Thread(target=lambda: (time.sleep(1.6), out.setdefault("smi", smi())))
+        out = []
+        th = threading.Thread(target=lambda: [out.append((time.sleep(0.7), smi())[1]) for _ in range(3)])
         th.start()
-        assert fn(wps, 1600000 if "16x16" in name else 1600000, C.byref(tf), C.byref(tk)) == 0      # three launches of ~1 s each: the sample falls inside the second
+        assert fn(wps, 1600000, C.byref(tf), C.byref(tk)) == 0      # three launches of ~0.7-1 s each: the first samples fall inside them
         th.join()
-        print(f"pure MFMA {name:30s} {tf.value:7.1f} TF/s   {out.get('smi')}", flush=True)
+        print(f"pure MFMA {name:30s} {tf.value:7.1f} TF/s   {out}", flush=True)
     run("torch copy 1.6 -> 1.6 GB", lambda: y.copy_(x))
     a = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16); b = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
     run("torch.matmul 8192^3 bf16", lambda: torch.matmul(a, b))
