@@ -80,6 +80,58 @@ def cpu_baseline(name, sd, frame_hw=(2160, 3840), budget_s=20.0):
     return info, (mosaic, cond, coord, out)
 
 
+# algorithmic FLOPs per padded output pixel (2 MAC of every conv / linear of the REFERENCE net, hook-counted there), and the GroupMix block's
+# 25.3 C^2 + 176 C FLOP per token (C = 80) plus the build's two 1x1 projections 192 -> 80 -> 192 around it.  `flops_per_step` (executed) is lower where a fold
+# removed work (the tail as one 5x5 convolution): both are reported so that the fold's credit is visible and the denominator is not silently moving.
+ALGO_FLOP_PER_PX = {"LiteISPNet": 716896.0, "LiteISPNet_GFM_LSC": 622084.0, "LiteISPNet_GFM_LSC_GMA": 622084.0, "ISPUNet_GFM_LSC": 378922.0}
+GMA_FLOP_PER_TOKEN = 25.3 * 80 * 80 + 176 * 80 + 2 * 2 * 192 * 80
+
+
+def flops_algorithmic(model, frames, H2, W2):
+    if model not in ALGO_FLOP_PER_PX:
+        return None
+    pad = 16                                              # packed RAW padded to a multiple of 16 (pad_to_multiple_of_16, LiteISP.py:84-128)
+    hp, wp = -(-(H2 // 2) // pad) * pad, -(-(W2 // 2) // pad) * pad
+    fl = ALGO_FLOP_PER_PX[model] * (2 * hp) * (2 * wp)
+    if model.endswith("_GMA"):
+        fl += GMA_FLOP_PER_TOKEN * (hp // 2) * (wp // 2)
+    return frames * fl
+
+
+class PowerSampler:
+    """One rocm-smi sample (socket power, shader clock) taken INSIDE the timed region, from a side thread: the conv kernels run this part at its board power
+    cap with the clock throttled (profiles/r05_power_wall.md), which is what bounds roofline.frac.  Diagnostics only: never fails the run."""
+
+    def __init__(self, delay_s):
+        import subprocess, threading
+        self.out, self.t_done = {}, None
+
+        def work():
+            try:
+                time.sleep(max(0.0, delay_s))
+                r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True, timeout=20)
+                self.t_done = time.perf_counter()
+                for l in r.stdout.splitlines():
+                    v = l.split(":")[-1].strip()
+                    if "Max Graphics Package Power" in l:
+                        self.out["cap_W"] = float(v)
+                    elif "Graphics Package Power" in l and "Max" not in l:
+                        self.out["socket_W"] = float(v)
+                    elif "sclk" in l and "(" in l:
+                        self.out["sclk_MHz"] = int(l.split("(")[-1].split("Mhz")[0])
+            except Exception as e:                        # noqa: BLE001 -- diagnostics only
+                self.out["error"] = str(e)[:60]
+        self.th = threading.Thread(target=work, daemon=True)
+        self.th.start()
+
+    def result(self, t_region_end):
+        self.th.join(timeout=25)
+        if not self.out or "error" in self.out:
+            return None
+        self.out["sampled_inside_timed_region"] = bool(self.t_done is not None and self.t_done <= t_region_end)
+        return self.out
+
+
 def load_pmc_summary():
     """The newest profiles/rNN_pmc_bench.json whose `source_digest` equals this build's kernel-source digest, else None."""
     from realcamnet_amd import build as rb
@@ -251,6 +303,12 @@ def main():
     torch.cuda.synchronize()
     shard.barrier()
     torch.cuda.synchronize()
+    tw = time.perf_counter()                               # one untimed step to size the power sample's delay
+    step(); torch.cuda.synchronize()
+    est = (time.perf_counter() - tw) * args.steps
+    shard.barrier()
+    torch.cuda.synchronize()
+    sampler = PowerSampler(0.3 * est) if (rank == 0 and est > 0.6) else None      # rocm-smi itself takes ~0.2 s: only runs long enough to contain it
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -260,7 +318,9 @@ def main():
     torch.cuda.synchronize()
     shard.barrier()
     torch.cuda.synchronize()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dev)
+    t_end = time.perf_counter()
+    elapsed = shard.max_over_ranks(t_end - t0, dev)
+    power = sampler.result(t_end) if sampler is not None else None
     assert out.shape == (B, 3, H2, W2) and gathered.shape == (total_frames if gather is not None else B, 3, H2, W2)
     if gather is not None:                                 # the gathered payload is this rank's own frames where they belong
         assert torch.equal(gathered[s:e], out)
@@ -269,6 +329,7 @@ def main():
     ops.prof_enable(True)
     step()
     n_launch, conv_ms, conv_flops = ops.prof_collect()
+    rows = ops.prof_rows()
     ops.prof_enable(False)
 
     if rank != 0:
@@ -297,6 +358,30 @@ def main():
                      "kernel": "conv_mfma_kernel (all instantiations)", "launches_per_step": int(n_launch),
                      "kernel_ms_per_step": round(conv_ms, 3), "flops_per_step": conv_flops},
     }
+    # what bounds what: the family's frac above is priced against the MFMA peak, but the layer shape with the most time is HBM-paced -- name it, with both
+    # of its fractions (flat scalar keys: the driver's parser keeps those)
+    rf = res["roofline"]
+    fa = flops_algorithmic(args.model, B, H2, W2)
+    if fa is not None:
+        rf["flops_algorithmic"] = fa
+        rf["frac_algorithmic_whole_step"] = round(fa / (elapsed / args.steps) / 1e12 / peak, 4)
+        rf["flops_note"] = "flops_per_step = executed by the conv launches (the folded 5x5 tail executes 4.6x fewer than the two convolutions it replaces); flops_algorithmic = SURVEY 8(d): reference net at the padded size + GroupMix block"
+    if rows:
+        d0 = rows[0]
+        es = 2 if args.dtype == "bf16" else 4
+        rf["dominant_kernel"] = f"conv {d0['ksize']}x{d0['ksize']} {d0['cin']}->{d0['cout']} ({d0['launches']} launches per step)"
+        rf["dominant_ms_per_step"] = round(d0["ms"], 3)
+        rf["dominant_tflops"] = round(d0["flops"] / (d0["ms"] * 1e-3) / 1e12, 1)
+        rf["dominant_mfma_frac"] = round(d0["flops"] / (d0["ms"] * 1e-3) / 1e12 / peak, 4)
+        rf["dominant_hbm_TBps"] = round(d0["bytes"] / (d0["ms"] * 1e-3) / 1e12, 2)
+        rf["dominant_hbm_frac_of_8TBps"] = round(d0["bytes"] / (d0["ms"] * 1e-3) / 8e12, 4)
+        rf["dominant_bound"] = "hbm" if rf["dominant_hbm_frac_of_8TBps"] > rf["dominant_mfma_frac"] else "mfma"
+        rf["by_shape_top4"] = "; ".join(f"{r['cin']}->{r['cout']} k{r['ksize']}: {r['ms']:.2f} ms, {r['flops'] / (r['ms'] * 1e-3) / 1e12:.0f} TF/s, "
+                                        f"{r['bytes'] / (r['ms'] * 1e-3) / 1e12:.2f} TB/s" for r in rows[:4])
+    if power is not None:
+        res["power"] = power
+        rf["power_note"] = (f"socket {power.get('socket_W')} W of a {power.get('cap_W')} W cap at sclk {power.get('sclk_MHz')} MHz mid-run: the conv kernels are "
+                            "power-capped, not pipe- or HBM-capped (profiles/r05_power_wall.md)")
     # HBM traffic comes from PMC counters, which cannot be read inside a timed run: tools/pmc_bench.sh collects them in separate
     # rocprofv3 --pmc passes of this same default command and commits the summary under profiles/.  The summary carries the digest of
     # the kernel sources it was measured on; a file taken on other sources is ignored (traffic stays null) rather than replayed.
@@ -311,6 +396,7 @@ def main():
                      key=lambda t: -t[1] * t[2])[:3]
         res["roofline"]["traffic_by_kernel"] = [{"kernel": k.split("(")[0][-70:], "launches_per_forward": round(n / fw, 1), "hbm_bytes_per_launch": round(bpl),
                                                  "hbm_GB_per_forward": round(n * bpl / fw / 1e9, 1)} for k, n, bpl in top]
+        res["roofline"]["traffic_top3"] = "; ".join(f"{k.split('(')[0].split('::')[-1][:40]} x{n / fw:.0f}: {n * bpl / fw / 1e9:.1f} GB per forward" for k, n, bpl in top)
         step_bytes = (pmc["all_kernels_total_bytes"]["fetch"] + pmc["all_kernels_total_bytes"]["write"]) / pmc.get("forwards", 3)
         res["hbm_whole_step"] = {"bytes_per_step": round(step_bytes), "achieved_TBps": round(step_bytes / (elapsed / args.steps) / 1e12, 2),
                                  "copy_rate_TBps": pmc.get("copy_rate_TBps", 5.9), "peak_TBps": 8.0}

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 9
+#define RC_ABI_VERSION 10
 
 typedef enum rc_status {
     RC_OK = 0,
@@ -543,6 +543,11 @@ int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* me
 int rc_debug_mfma_peak32(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma);
 int rc_prof_enable(int on);
 int rc_prof_collect(int64_t* n_launches, double* total_ms, double* total_flops);
+/* The same records grouped by layer shape (cin, cout, ksize): launches, summed HIP-event ms, algorithmic FLOPs and algorithmic BYTES (every map
+ * the launch has to touch once: input, output, residual / multiplier operand, the gated form's skip and materialised input) -- what bench.py's
+ * roofline line names its dominant kernel from.  Does not clear the records (rc_prof_enable does). */
+typedef struct rc_prof_row { int cin, cout, ksize, launches; double ms, flops, bytes; } rc_prof_row;
+int rc_prof_collect_rows(rc_prof_row* rows, int max_rows, int* n_rows);
 
 /* ---- f3: on-device entropy coding (csrc/rans.hip) ----------------------------------------------------------
  * Replaces the `.tolist()` symbol dumps + CompressAI `BufferedRansEncoder` / `RansDecoder` calls of compress() / decompress()

@@ -17,7 +17,7 @@ HEADER = PKG.parent / "include" / "realcam_hip.h"
 RC_F32, RC_BF16, RC_U16 = 0, 1, 2
 RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY, RC_ACT_GELU, RC_ACT_RELU_POST = 0, 1, 2, 3, 4
 RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW = 0, 1, 2, 3
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class ConvDesc(C.Structure):
@@ -160,6 +160,7 @@ _SIGS = {
     "rc_debug_set_ptr": (C.c_int, [C.c_char_p, _P]),
     "rc_prof_enable": (C.c_int, [_I]),
     "rc_prof_collect": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rc_prof_collect_rows": (C.c_int, [_P, _I, C.POINTER(C.c_int)]),
 }
 
 _lib = None

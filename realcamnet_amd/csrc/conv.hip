@@ -15,6 +15,7 @@ struct ConvPlan {
 static int g_persist_on = 1;       // rc_debug_set("persist", v): 0 general kernel only, 1 automatic (default), 2 producer/consumer wherever eligible, 3 persistent only
 extern int g_dw3_seg16;            // gma.hip
 extern int g_dec_lds;              // rans.hip
+extern int g_gate_fused;           // cond.hip
 static int g_pss = 0;              // rc_debug_set("pss", v): 1: single-chunk pixel-shuffle layers (the tail 48 -> 192) take kernel 5 (output staged through LDS, stored by the
                                    // loader waves); 0 (default): kernel 4.  Measured on MI355X at 8 x 1088 x 1920: 3.16-3.29 vs 3.24-3.27 ms (conv_kernel.hpp, kernel 5)
 static int g_auto = 1;             // rc_debug_set("persist_auto", v): single-chunk, single-cout-tile bf16 3x3 layers (48 -> 48, 32 -> 32) on kernel 6 (wave-autonomous strips):
@@ -113,18 +114,18 @@ static int g_pair_impl = 0;         // rc_debug_set("pair_impl", v): 0 = the fas
 static long long* g_dbg_ptr = nullptr;   // rc_debug_set_ptr("conv_phase_timing", device buffer of >= 512 int64)
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
-struct ProfRec { hipEvent_t e0, e1; double flops; };
+struct ProfRec { hipEvent_t e0, e1; double flops, bytes; int cin, cout, ksize; };
 static std::vector<ProfRec> g_prof;
 
 long long* conv_dbg_ptr() { return g_dbg_ptr; }
 int conv_pair_impl() { return g_pair_impl; }
 
 // HIP-event bracket around one conv launch on its own stream (rc_prof_enable); shared with conv_pair.hip
-void conv_prof_begin(double flops, hipStream_t stream, void** token) {
+void conv_prof_begin(double flops, hipStream_t stream, void** token, double bytes, int cin, int cout, int ksize) {
     *token = nullptr;
     { std::lock_guard<std::mutex> lk(g_prof_mu); if (!g_prof_on) return; }
     ProfRec* rec = new ProfRec{};
-    rec->flops = flops;
+    rec->flops = flops; rec->bytes = bytes; rec->cin = cin; rec->cout = cout; rec->ksize = ksize;
     if (hipEventCreate(&rec->e0) != hipSuccess || hipEventCreate(&rec->e1) != hipSuccess) { delete rec; return; }
     (void)hipEventRecord(rec->e0, stream);
     *token = rec;
@@ -264,6 +265,7 @@ int rc_debug_set(const char* key, int value) {
     if (std::string(key) == "dec_lds") { g_dec_lds = value != 0; return RC_OK; }
     if (std::string(key) == "dw3_seg16") { g_dw3_seg16 = value != 0; return RC_OK; }
     if (std::string(key) == "pss") { g_pss = value != 0; return RC_OK; }
+    if (std::string(key) == "gate_fused") { g_gate_fused = value != 0; return RC_OK; }
     if (std::string(key) == "persist_auto") { g_auto = value < 0 ? 0 : (value > 2 ? 2 : value); return RC_OK; }
     if (std::string(key) == "conv32") { g_conv32 = value < 0 ? 0 : (value > 4 ? 4 : value); return RC_OK; }
     return fail(RC_ERR_INVALID, std::string("rc_debug_set: unknown key ") + key);
@@ -275,6 +277,7 @@ int rc_debug_get(const char* key) {
     if (std::string(key) == "conv32") return g_conv32;
     if (std::string(key) == "conv_flags") return g_dbg_flags;
     if (std::string(key) == "pss") return g_pss;
+    if (std::string(key) == "gate_fused") return g_gate_fused;
     if (std::string(key) == "persist_auto") return g_auto;
     return -1;
 }
@@ -305,6 +308,27 @@ int rc_prof_collect(int64_t* n_launches, double* total_ms, double* total_flops) 
     if (n_launches) *n_launches = (int64_t)g_prof.size();
     if (total_ms) *total_ms = ms;
     if (total_flops) *total_flops = fl;
+    return RC_OK;
+}
+
+int rc_prof_collect_rows(rc_prof_row* rows, int max_rows, int* n_rows) {
+    RC_REQUIRE(rows != nullptr && n_rows != nullptr && max_rows >= 1, "rc_prof_collect_rows: bad arguments");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    for (auto& r : g_prof) {
+        RC_HIP_CHECK(hipEventSynchronize(r.e1));
+        float t = 0.f;
+        RC_HIP_CHECK(hipEventElapsedTime(&t, r.e0, r.e1));
+        int i = 0;
+        while (i < n && !(rows[i].cin == r.cin && rows[i].cout == r.cout && rows[i].ksize == r.ksize)) ++i;
+        if (i == n) {
+            if (n == max_rows) continue;                    // table full: the launch is still in rc_prof_collect's totals
+            rows[n] = rc_prof_row{r.cin, r.cout, r.ksize, 0, 0.0, 0.0, 0.0};
+            ++n;
+        }
+        rows[i].launches += 1; rows[i].ms += t; rows[i].flops += r.flops; rows[i].bytes += r.bytes;
+    }
+    *n_rows = n;
     return RC_OK;
 }
 
@@ -414,7 +438,12 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     void* tok = nullptr;
     // algorithmic FLOPs: a ksize-2 launch is a stride-2 3x3 convolution over its space-to-depth map -- 9 of its 16 (tap, phase) blocks are real
     const double taps = d->ksize == 2 ? 9.0 / 4.0 : (double)d->ksize * d->ksize;
-    conv_prof_begin(2.0 * d->batch * d->height * d->width * (double)d->cin * d->cout * taps, stream, &tok);
+    // algorithmic bytes: every map the launch must touch once (input, output, residual / x(lsc+1) operand, the gated form's skip and materialised input)
+    const double px = (double)d->batch * d->height * d->width;
+    const double osz = (d->out_mode == RC_OUT_NCHW || d->out_mode == RC_OUT_PIXEL_SHUFFLE2_NCHW) ? (d->out_dtype == RC_F32 ? 4.0 : 2.0) : (double)es;
+    const double bytes = px * d->cin * es * (1.0 + (d->in1 ? 1.0 : 0.0) + (d->in_store ? 1.0 : 0.0)) + px * d->cout * osz +
+                         px * d->cout * es * ((d->residual ? 1.0 : 0.0) + (d->mul_plus1 ? 1.0 : 0.0));
+    conv_prof_begin(2.0 * px * (double)d->cin * d->cout * taps, stream, &tok, bytes, d->cin, d->cout, d->ksize);
     const int rcode = p.m32 ? (p.ck == 16 ? conv32_ck16(0, a, stream) : p.ck == 32 ? conv32_ck32(g_conv32 == 3 ? 1 : 0, a, stream) : conv32_ck48(0, a, stream))
                             : dispatch_conv(d->dtype == RC_BF16, d->ksize, p.ck, p.nt, a, stream);
     conv_prof_end(tok, stream);

@@ -1418,7 +1418,7 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
         // gated inputs: two tile operands already fill the loader's 168 VGPRs, so the weight halves go by LDS-DMA instead
         // of through registers -- issued at the start of the half in which their LDS region is free, landed by the barrier
         // that ends it (the barrier's vmcnt(0) also waits for this half's tile loads; they had the same half to arrive)
-        constexpr bool WDMA = GATED;
+        constexpr bool WDMA = GATED || (Cfg::CK == 48 && Cfg::NT == 3);   // one-chunk 48 -> 48k: the 60-register halo tile + 48 weight registers spilled 8-10 of the 168
         uint4 r0[D::NI], r1[GATED ? D::NI : 1], wra[WDMA ? 1 : NWA], wrb[WDMA ? 1 : NWB];
         float gv[GATED ? D::UNIT : 1];
         typename D::TileSrc ts;
@@ -1992,7 +1992,10 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
     // multi-chunk producer/consumer form
     // bf16 only: in fp32 the MFMAs are 4x longer, the layers are MFMA-bound either way and the general kernel's many
     // small blocks balance the B = 1 configurations better (measured 99 vs 88 TF/s on 64 -> 64 at 1080p)
-    if constexpr (WSM_LDS <= 160 * 1024 && Cfg::KS >= 2 && Cfg::STEPS >= 2 && sizeof(typename Cfg::elem) == 2) {
+    // (kernels 2 and 4 are instantiated for plain inputs only: their gated forms -- the round-3 schedule that folded the CALayer gate into the next conv's
+    // staging -- spilled 5-77 registers each, 14 instantiations, and nothing on the default path has dispatched to them since the early gate.
+    // A gated input takes kernel 3 (single chunk) or kernel 1 (several chunks): the same bits, tested in every persist mode.)
+    if constexpr (!GATED && WSM_LDS <= 160 * 1024 && Cfg::KS >= 2 && Cfg::STEPS >= 2 && sizeof(typename Cfg::elem) == 2) {
         // one-chunk layers with several cout tiles AND a residual (the U-Net's 48 -> 192 + skip at level 1) stay on the persistent kernel: input tile
         // resident, weights per cout tile, the residual's loads issued before the MFMA loop (1.13 vs 1.31 ms here, 1.25 in the 32x32x16 form);
         // persist_ok 3 ("persistent only") sends every one-chunk layer there
@@ -2041,7 +2044,7 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
             return RC_OK;
         }
     }
-    if constexpr (P_OK) {
+    if constexpr (P_OK && !GATED) {
         if (a.n_chunks == 1 && a.cout_packed <= persist_bias_slots<Cfg>() && a.persist_ok && n_tiles < (1 << 24)) {
             static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
             if (!attr_set.test_and_set()) {

@@ -906,7 +906,7 @@ int launch(const PairArgs& a, int num_cus, hipStream_t stream) {
 }  // namespace pair2
 long long* conv_dbg_ptr();
 int conv_pair_impl();
-void conv_prof_begin(double flops, hipStream_t stream, void** token);
+void conv_prof_begin(double flops, hipStream_t stream, void** token, double bytes, int cin, int cout, int ksize);
 void conv_prof_end(void* token, hipStream_t stream);
 }  // namespace rc
 
@@ -953,7 +953,7 @@ int rc_conv_pair(const rc_conv_pair_desc* d, void* stream_) {
     const int num_cus = device_cu_count();          // per device (common.hpp)
     hipStream_t stream = as_stream(stream_);
     void* tok = nullptr;
-    conv_prof_begin(2.0 * 2.0 * d->batch * d->height * d->width * 9.0 * pair::C * pair::C, stream, &tok);
+    conv_prof_begin(2.0 * 2.0 * d->batch * d->height * d->width * 9.0 * pair::C * pair::C, stream, &tok, 2.0 * 2.0 * d->batch * d->height * d->width * pair::C, pair::C, pair::C, 3);
     int rcode;
     const bool gated = d->in_gate != nullptr;
 #define RC_PAIR_DISPATCH(NS)                                                                                                                        \

@@ -1316,6 +1316,7 @@ extern "C" int rc_lsc_chain(const void* d_x, int cin0, const void* d_blob, int c
     RC_REQUIRE(d_x && d_blob && d_out, "rc_lsc_chain: null pointer");
     RC_REQUIRE((c == 32 || c == 48 || c == 64 || c == 128) && n_mid >= 1 && n_mid <= 4 && cin0 >= 1 && cin0 <= 4, "rc_lsc_chain: width 32, 48, 64 or 128, 1..4 mid layers, cin0 <= 4");
     RC_REQUIRE(!d_raw || (raw_c >= 1 && raw_c <= 4), "rc_lsc_chain: the head's input has 1..4 channels");
+    RC_REQUIRE(!(d_raw && c == 128), "rc_lsc_chain: the fused head exists at widths 32 / 48 / 64 (at 128 it spilled 29 registers and the codec needs the lens-shading map itself)");
     RC_REQUIRE(batch >= 1 && H >= 1 && W >= 1 && (long long)batch * H * W * 8 < (1LL << 31), "rc_lsc_chain: bad shape (inputs must stay below 2 GiB)");
     RC_REQUIRE(slope >= 0.f && slope <= 1.f, "rc_lsc_chain: slope must be in [0, 1]");
     RC_REQUIRE(reinterpret_cast<uintptr_t>(d_out) % 16 == 0 && reinterpret_cast<uintptr_t>(d_blob) % 16 == 0, "rc_lsc_chain: misaligned pointer");
@@ -1341,7 +1342,7 @@ extern "C" int rc_lsc_chain(const void* d_x, int cin0, const void* d_blob, int c
     if (c == 32) { if (d_raw) RC_LSC(32, true); else RC_LSC(32, false); }            // the ISPUNet family's width
     else if (c == 48) { if (d_raw) RC_LSC(48, true); else RC_LSC(48, false); }
     else if (c == 64) { if (d_raw) RC_LSC(64, true); else RC_LSC(64, false); }
-    else { if (d_raw) RC_LSC(128, true); else RC_LSC(128, false); }
+    else RC_LSC(128, false);
 #undef RC_LSC
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;

@@ -463,7 +463,7 @@ __global__ void dwt_forward_kernel(const T* __restrict__ x, T* __restrict__ y, c
 // inverse: x (B,h,w,4C) -> y (B,2h,2w,C): y[2y+i][2x+j][c] = sum_k taps[4c+k][i][j] * x[y][x][4c+k]
 // One thread per (input pixel, 16-byte group of OUTPUT channels) = 4 input vectors -> 4 output vectors.
 template <typename T, bool UNIFORM>
-__global__ void dwt_inverse_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ taps,
+__global__ __launch_bounds__(kPwThreads) void dwt_inverse_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ taps,
                                    int batch, int h, int w, int c4) {
     constexpr int U = Vec16<T>::N;
     float ut[16];

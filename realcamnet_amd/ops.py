@@ -737,6 +737,8 @@ def lsc_chain(lsc, coord: torch.Tensor, head=None, raw: Optional[torch.Tensor] =
         if not (raw is not None and raw.dtype == torch.bfloat16 and tuple(hw.shape[2:]) == (3, 3) and hw.shape[0] == c and hw.shape[1] == raw.shape[-1] <= 4 and
                 tuple(head.stride) == (1, 1) and tuple(head.padding) == (1, 1) and raw.shape[:3] == coord.shape[:3]):
             return None
+        if c == 128:                   # no fused head at that width (rc_lsc_chain): the caller runs lsc and the head conv as two launches
+            return None
         raw = _req(raw, "raw")
     coord = _req(coord, "coord")
     params = [p for m in convs for p in (m.weight, m.bias)] + ([head.weight, head.bias] if head is not None else [])
@@ -945,6 +947,20 @@ def gfm_vector(vec: torch.Tensor, lin0, lin1) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------------
 def prof_enable(on: bool) -> None:
     check(lib().rc_prof_enable(1 if on else 0), "rc_prof_enable")
+
+
+class ProfRow(C.Structure):
+    """Mirror of `struct rc_prof_row` (include/realcam_hip.h)."""
+    _fields_ = [("cin", C.c_int), ("cout", C.c_int), ("ksize", C.c_int), ("launches", C.c_int), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+def prof_rows(max_rows: int = 64):
+    """The profiled conv launches grouped by layer shape: [{cin, cout, ksize, launches, ms, flops, bytes}], most time first (rc_prof_collect_rows)."""
+    rows = (ProfRow * max_rows)()
+    n = C.c_int(0)
+    check(lib().rc_prof_collect_rows(C.cast(rows, C.c_void_p), max_rows, C.byref(n)), "rc_prof_collect_rows")
+    out = [{f: getattr(rows[i], f) for f, _ in ProfRow._fields_} for i in range(n.value)]
+    return sorted(out, key=lambda r: -r["ms"])
 
 
 def prof_collect():

@@ -370,12 +370,12 @@ class raw_compression_tcm_final(nn.Module):
         dt = self._act_dtype()
         return self._analysis(ops.to_nhwc(raw, dtype=dt), cond, ops.to_nhwc(coord, dtype=dt))[0]
 
-    def compress(self, x, fmt: str = "chunked"):
+    def compress(self, x, fmt: str = "chunked", chunk: int = T.bitstream.DEFAULT_CHUNK):
         """upstream models/raw2bit.py:1876-1944: x = [raw, cond, coord] -> {"strings": [y_strings, z_strings], "shape"} (one string per
         image; fmt "chunked": GPU coder, "compressai": one CompressAI-layout stream per image)."""
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
-        return T._codec_compress(self, self._latent(x), fmt)
+        return T._codec_compress(self, self._latent(x), fmt, chunk)
 
     def decompress(self, strings, shape, fmt: str = "chunked"):
         """upstream models/raw2bit.py:1961-2027: -> {"x_hat": (B,3,2H,2W) clamped to [0, 1]}."""

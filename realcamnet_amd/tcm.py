@@ -688,12 +688,14 @@ class TCM(nn.Module):
     update = _codec_update
     load_state_dict = _codec_load_state_dict
 
-    def compress(self, x, fmt: str = "chunked"):
+    def compress(self, x, fmt: str = "chunked", chunk: int = bitstream.DEFAULT_CHUNK):
         """upstream models/tcm.py:511-570: x (B,3,H,W) -> {"strings": [y_strings, z_strings], "shape": z spatial size}; one string per
-        image in each list.  fmt "chunked" (GPU coder) or "compressai" (one stream per image in CompressAI's layout, host coder)."""
+        image in each list.  fmt "chunked" (GPU coder) or "compressai" (one stream per image in CompressAI's layout, host coder).
+        chunk: symbols per independent rANS stream of the chunked format -- a field of every container's header, so decompress() needs no argument;
+        shorter chunks decode faster (more parallel lanes) and cost a 64-bit state flush + a 4-byte size each."""
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
-        return _codec_compress(self, self.g_a._nhwc(ops.to_nhwc(x, dtype=self._act_dtype())), fmt)
+        return _codec_compress(self, self.g_a._nhwc(ops.to_nhwc(x, dtype=self._act_dtype())), fmt, chunk)
 
     def decompress(self, strings, shape, fmt: str = "chunked"):
         """upstream models/tcm.py:592-637: -> {"x_hat": (B,3,H,W) clamped to [0, 1]}."""
@@ -746,14 +748,17 @@ def _refine(m, i, mean_support, y_hat_slice):
     return ops.tanh_half_add(y_hat_slice, m.lrp_transforms[i]._nhwc(ops.channel_concat([mean_support, y_hat_slice])))
 
 
-def _codec_compress(m, y, fmt):
+def _codec_compress(m, y, fmt, chunk=bitstream.DEFAULT_CHUNK):
     """Shared by TCM.compress and raw_compression_tcm_final.compress (models/tcm.py:515-570, raw2bit.py:1901-1944): y NHWC latent ->
     strings.  The symbols and CDF indexes of every slice are produced on the device (realcam::gc_symbols); "chunked": every slice
     becomes one container of GPU-coded chunk streams, an image's y string is the concatenation of its slices' containers;
     "compressai": the slices' symbols are concatenated and coded as ONE stream per image, as upstream's single BufferedRansEncoder."""
     gc = m.gaussian_conditional
     z = m.h_a._nhwc(y)
-    z_strings, z_hat = m.entropy_bottleneck._compress_nhwc(z, fmt)
+    chunk = int(chunk)
+    if not 1 <= chunk <= (1 << 24):
+        raise ValueError("chunk: symbols per independent rANS stream, 1 .. 2^24")
+    z_strings, z_hat = m.entropy_bottleneck._compress_nhwc(z, fmt, chunk)
     latent_scales, latent_means = _hyper_synthesis(m, z_hat)
     if latent_means.shape[1:3] != y.shape[1:3]:
         raise NotImplementedError("latent size must be a multiple of 4; upstream crops here")
@@ -766,7 +771,7 @@ def _codec_compress(m, y, fmt):
         sym, idx, y_hat_slice = torch.ops.realcam.gc_symbols(ops.channel_slice(y, i * per, per), mu, scale, table, gc.scale_bound_value)
         if fmt == "chunked":
             for k in range(b):
-                pieces[k].append(bitstream.encode(sym[k], idx[k], tables, fmt))
+                pieces[k].append(bitstream.encode(sym[k], idx[k], tables, fmt, chunk))
         else:
             syms.append(sym); idxs.append(idx)
         y_hat_slices.append(_refine(m, i, mean_support, y_hat_slice))

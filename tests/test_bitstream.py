@@ -4,6 +4,8 @@ Integer work: the bar is BIT-EXACT against the oracle (oracle/rans_oracle.c, ora
 algorithms restated; the package is absent and unpinned upstream, so the wire format is parity-unpinned against CompressAI itself).
 CPU: host-side functions of the library (table quantiser, the single-stream "compressai" coder) and the mirror's update() /
 strict load.  GPU: symbol kernels, the chunked coder byte for byte, escapes, and compress -> decompress round trips of both codecs."""
+import struct
+
 import numpy as np
 import pytest
 import torch
@@ -322,6 +324,38 @@ def test_raw_codec_compress_decompress_round_trip(hip):
         out = m.decompress(enc["strings"], enc["shape"])["x_hat"]
         fwd = m(x)
     assert out.shape == (1, 3, 512, 512) and _psnr(out, fwd["x_hat"].clamp(0, 1)) >= 45.0
+
+
+@pytest.mark.gpu
+def test_chunk_length_is_a_container_field_of_the_codec(hip):
+    """compress(x, chunk=...) writes the chunk length into every container's header; decompress() takes no argument and reproduces the SAME x_hat bit for
+    bit for every chunk length (the symbols are the same, only their grouping into independent rANS streams changes); shorter chunks cost bytes (a 64-bit
+    state flush + a 4-byte size each).  A header whose chunk field was altered no longer matches its size table and is rejected, never decoded."""
+    import liteisp_oracle as O
+    import realcamnet_amd.raw2bit as RB
+    m = RB.raw_compression_tcm_final(N=32).eval()
+    det_fill_(m.state_dict())
+    m = m.to("cuda", torch.bfloat16)
+    m.update()
+    g = torch.Generator().manual_seed(12)
+    x = [torch.rand(1, 4, 256, 256, generator=g).cuda(), torch.rand(1, 4, 64, 64, generator=g).cuda(), O.make_coord(1, 256, 256).cuda()]
+    outs, sizes = {}, {}
+    with torch.no_grad():
+        for chunk in (2048, 512, 100, 1 << 20):
+            enc = m.compress(x, chunk=chunk)
+            y0 = enc["strings"][0][0]
+            assert struct.unpack_from("<4sIII", y0, 0)[2] == chunk
+            outs[chunk] = m.decompress(enc["strings"], enc["shape"])["x_hat"]
+            sizes[chunk] = sum(len(s) for grp in enc["strings"] for s in grp)
+        for chunk in (512, 100, 1 << 20):
+            assert torch.equal(outs[chunk], outs[2048]), chunk
+        assert sizes[100] > sizes[512] > sizes[2048] >= sizes[1 << 20]
+        enc = m.compress(x, chunk=512)
+        bad = bytearray(enc["strings"][0][0]); bad[8:12] = (256).to_bytes(4, "little")          # chunk 512 -> 256: the size table no longer fits
+        with pytest.raises(ValueError):
+            m.decompress([[bytes(bad)], enc["strings"][1]], enc["shape"])
+        with pytest.raises(ValueError):
+            m.compress(x, chunk=0)
 
 
 def test_state_dict_contract_equals_the_reference_classes():

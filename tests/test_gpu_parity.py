@@ -278,6 +278,26 @@ def test_tail_pixel_shuffle_vs_reference(hip, dt):
     assert rel_err(y.float().cpu(), g["y"]) <= tol(dt)
 
 
+def test_tail_fold_vs_the_reference_tail_output(hip):
+    """The reference's own tail output (block_tail_16: conv(16, 64) -> PixelShuffle(2) -> conv(16, 3), upstream models/LiteISP.py:2379-2383) against the
+    FOLDED form (ops.tail_fold: one 5x5 convolution 16 -> 12 + the exact border ring) in fp32, where C = 16 has a 5x5 instantiation: the fold differs from
+    the two convolutions by the fp32 rounding of the composed weights only."""
+    g = load_golden("block_tail_16")
+    tail = N.seq(N.conv(16, 64, mode="C"), torch.nn.PixelShuffle(2), N.conv(16, 3, mode="C"))
+    tail = put(tail, g["sd"], torch.float32)
+    with torch.no_grad():
+        a = ops.to_nhwc(g["x"].to(DEV))
+        assert ops.tail_fold_ok(a, tail[0], tail[2])
+        y = ops.tail_fold(a, tail[0], tail[2])
+        two = tail[2]._nhwc(tail[0]._nhwc(a, out_mode=ops.RC_OUT_PIXEL_SHUFFLE2), out_mode=ops.RC_OUT_NCHW)
+    assert y.shape == g["y"].shape
+    assert rel_err(y.cpu(), g["y"]) <= tol(torch.float32)
+    assert rel_err(y.cpu(), two.cpu()) <= tol(torch.float32)
+    ring = torch.ones_like(y, dtype=torch.bool)
+    ring[..., 1:-1, 1:-1] = False
+    assert rel_err(y[ring].cpu(), two[ring].cpu()) <= 2e-6   # the outermost ring IS the two convolutions, recomputed on four strips (the side strips transposed: another fp32 summation order)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_dwt_any_channel_count_pair_vs_reference(hip, dt):
     """networks.DWTForward_ / DWTInverse_ (upstream models/networks.py:9-47) on the reference's fixtures; the state_dict is the single (4,1,2,2) tap set."""

@@ -39,3 +39,12 @@ with torch.no_grad():
         print(json.dumps({"format": fmt, "frames": a.frames, "packed_hw": [H, W], "forward_ms": round(t_fwd, 2), "compress_ms": round(t_enc, 2),
                           "decompress_ms": round(t_dec, 2), "stream_bytes": nbytes, "bpp_mosaic": round(8 * nbytes / (a.frames * 4 * H * W), 4),
                           "y_symbols": a.frames * 320 * (H // 16) * (W // 16)}))
+        if fmt == "compressai":
+            one_stream = nbytes
+    # the chunk length is a field of the container: shorter chunks = more independent rANS streams = more decoder lanes, at a 64-bit flush + 4-byte size each
+    for chunk in (4096, 2048, 1024, 512, 256):
+        enc, t_enc = timed(lambda: m.compress(x, fmt="chunked", chunk=chunk))
+        dec, t_dec = timed(lambda: m.decompress(enc["strings"], enc["shape"]))
+        nbytes = sum(len(s) for group in enc["strings"] for s in group)
+        print(json.dumps({"format": "chunked", "chunk": chunk, "compress_ms": round(t_enc, 2), "decompress_ms": round(t_dec, 2), "stream_bytes": nbytes,
+                          "bytes_vs_one_stream": round(nbytes / one_stream, 4)}))
