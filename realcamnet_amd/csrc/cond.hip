@@ -9,16 +9,7 @@ namespace rc {
 // ---- CALayer gate: fixed-order reduction of the conv's per-tile channel sums + 2-layer MLP -------
 // Stage 1 (large images): block (k, b) folds tiles [k*L, (k+1)*L) of image b into slot k*L, in place
 // (a block only ever writes inside its own range, so there is no cross-block hazard).  Fixed order.
-// SYS: the value crosses to another CU INSIDE a launch (the one-launch gate below): system-scope relaxed atomics = `sc0 sc1` write-through stores and
-// cache-bypassing loads on gfx950 -- visible without an agent-scope fence, whose buffer_wbl2 would write back the whole L2 (full of the conv's output)
-template <bool SYS> __device__ __forceinline__ void st_f(float* p, float v) {
-    if constexpr (SYS) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else *p = v;
-}
-template <bool SYS> __device__ __forceinline__ float ld_f(const float* p) {
-    if constexpr (SYS) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else return *p;
-}
-template <bool SYS = false>
-__device__ __forceinline__ void ca_reduce_body(float* __restrict__ sums, int n_tiles, int c, int L, int k, int b, int tid, float* part, bool act = true) {   // act: threads >= 256 of a wider block only keep the barriers company
+__device__ __forceinline__ void ca_reduce_body(float* __restrict__ sums, int n_tiles, int c, int L, int k, int b, int tid, float* part) {
     float* s = sums + (size_t)b * n_tiles * c;
     const int t0 = k * L, t1 = (t0 + L) < n_tiles ? (t0 + L) : n_tiles;
     for (int c0 = 0; c0 < c; c0 += 256) {
@@ -26,14 +17,14 @@ __device__ __forceinline__ void ca_reduce_body(float* __restrict__ sums, int n_t
         const int nparts = 256 / cw;
         const int ch = tid % cw, pt = tid / cw;
         float acc = 0.f;
-        if (act && pt < nparts)
+        if (pt < nparts)
             for (int t = t0 + pt; t < t1; t += nparts) acc += s[(size_t)t * c + c0 + ch];
-        if (act) part[tid] = acc;
+        part[tid] = acc;
         __syncthreads();
-        if (act && tid < cw) {
+        if (tid < cw) {
             float tot = 0.f;
             for (int p = 0; p < nparts; ++p) tot += part[p * cw + tid];
-            st_f<SYS>(&s[(size_t)t0 * c + c0 + tid], tot);
+            s[(size_t)t0 * c + c0 + tid] = tot;
         }
         __syncthreads();
     }
@@ -103,9 +94,9 @@ __global__ __launch_bounds__(kGateThreads) void ca_gate_kernel(const float* __re
 // runs, whose epilogue can then write x_new = conv2(t) * gate + x directly (rc_conv_desc.out_scale + residual).
 constexpr int kEdgeSegs = 8;
 // grid (4 * kEdgeSegs, B): fixed-order partial sums of row 0 / row H-1 / column 0 / column W-1 of an NHWC map, and its four corner pixels
-template <typename T, bool SYS = false>
+template <typename T>
 __device__ __forceinline__ void ca_border_body(const T* __restrict__ t, float* __restrict__ edge, float* __restrict__ corner,
-                                               int H, int W, int c, int idx, int b, int tid, float* part, bool act = true) {
+                                               int H, int W, int c, int idx, int b, int tid, float* part) {
     const int e = idx / kEdgeSegs, seg = idx % kEdgeSegs;
     const T* img = t + (size_t)b * H * W * c;
     const int n = e < 2 ? W : H, per = (n + kEdgeSegs - 1) / kEdgeSegs;
@@ -115,21 +106,21 @@ __device__ __forceinline__ void ca_border_body(const T* __restrict__ t, float* _
     for (int c0 = 0; c0 < c; c0 += 64) {
         const int ch = c0 + (tid & 63), sub = tid >> 6;
         float acc = 0.f;
-        if (act && ch < c) {
+        if (ch < c) {
 #pragma unroll 4
             for (int i = i0 + sub; i < i1; i += 4) acc += to_f32(img[base + (size_t)i * step + ch]);
         }
-        if (act) part[tid] = acc;
+        part[tid] = acc;
         __syncthreads();
-        if (tid < 64 && ch < c) st_f<SYS>(&edge[(((size_t)b * 4 + e) * kEdgeSegs + seg) * c + ch], (part[tid] + part[tid + 64]) + (part[tid + 128] + part[tid + 192]));
+        if (tid < 64 && ch < c) edge[(((size_t)b * 4 + e) * kEdgeSegs + seg) * c + ch] = (part[tid] + part[tid + 64]) + (part[tid + 128] + part[tid + 192]);
         __syncthreads();
     }
-    if (idx == 0 && act)
+    if (idx == 0)
         for (int ch = tid; ch < c; ch += 256) {
-            st_f<SYS>(&corner[((size_t)b * 4 + 0) * c + ch], to_f32(img[ch]));
-            st_f<SYS>(&corner[((size_t)b * 4 + 1) * c + ch], to_f32(img[(size_t)(W - 1) * c + ch]));
-            st_f<SYS>(&corner[((size_t)b * 4 + 2) * c + ch], to_f32(img[(size_t)(H - 1) * W * c + ch]));
-            st_f<SYS>(&corner[((size_t)b * 4 + 3) * c + ch], to_f32(img[((size_t)(H - 1) * W + (W - 1)) * c + ch]));
+            corner[((size_t)b * 4 + 0) * c + ch] = to_f32(img[ch]);
+            corner[((size_t)b * 4 + 1) * c + ch] = to_f32(img[(size_t)(W - 1) * c + ch]);
+            corner[((size_t)b * 4 + 2) * c + ch] = to_f32(img[(size_t)(H - 1) * W * c + ch]);
+            corner[((size_t)b * 4 + 3) * c + ch] = to_f32(img[((size_t)(H - 1) * W + (W - 1)) * c + ch]);
         }
 }
 
@@ -143,7 +134,6 @@ __global__ __launch_bounds__(256) void ca_reduce_border_kernel(float* __restrict
 }
 
 // sm: [kGateThreads] partials | S[c] | E[4][c] | K[4][c] | mean[c] | hid[cr]; one 1024-thread block per image
-template <bool SYS = false>
 __device__ __forceinline__ void ca_gate_ahead_body(const float* __restrict__ sums, int n_tiles, int tile_stride, size_t image_stride,
                                                    const float* __restrict__ edge, const float* __restrict__ corner,
                                                    const float* __restrict__ w2t, const float* __restrict__ b2,
@@ -167,11 +157,11 @@ __device__ __forceinline__ void ca_gate_ahead_body(const float* __restrict__ sum
             const float* q = s + c0 + ch;
             int t = pt;
             for (; t + 3 * nparts < n_tiles; t += 4 * nparts) {
-                const float v0 = ld_f<SYS>(q + (size_t)t * step), v1 = ld_f<SYS>(q + (size_t)(t + nparts) * step);
-                const float v2 = ld_f<SYS>(q + (size_t)(t + 2 * nparts) * step), v3 = ld_f<SYS>(q + (size_t)(t + 3 * nparts) * step);
+                const float v0 = q[(size_t)t * step], v1 = q[(size_t)(t + nparts) * step];
+                const float v2 = q[(size_t)(t + 2 * nparts) * step], v3 = q[(size_t)(t + 3 * nparts) * step];
                 a0 += v0; a1 += v1; a2 += v2; a3 += v3;
             }
-            for (; t < n_tiles; t += nparts) a0 += ld_f<SYS>(q + (size_t)t * step);
+            for (; t < n_tiles; t += nparts) a0 += q[(size_t)t * step];
         }
         part[tid] = (a0 + a1) + (a2 + a3);
         __syncthreads();
@@ -185,9 +175,9 @@ __device__ __forceinline__ void ca_gate_ahead_body(const float* __restrict__ sum
     for (int i = tid; i < 4 * c; i += kGateThreads) {          // border lines: fold the segments in order; corners as they are
         const int e = i / c, ch = i - e * c;
         float tot = 0.f;
-        for (int g = 0; g < kEdgeSegs; ++g) tot += ld_f<SYS>(&edge[(((size_t)b * 4 + e) * kEdgeSegs + g) * c + ch]);
+        for (int g = 0; g < kEdgeSegs; ++g) tot += edge[(((size_t)b * 4 + e) * kEdgeSegs + g) * c + ch];
         E[i] = tot;
-        K[i] = ld_f<SYS>(&corner[(size_t)b * 4 * c + i]);
+        K[i] = corner[(size_t)b * 4 * c + i];
     }
     __syncthreads();
     // mean_HW(conv2(t))[o]: thread (o, pt) takes every nparts-th input channel; fixed-order fold over pt
@@ -238,36 +228,10 @@ __global__ __launch_bounds__(kGateThreads) void ca_gate_ahead_kernel(const float
     ca_gate_ahead_body(sums, n_tiles, tile_stride, image_stride, edge, corner, w2t, b2, c, cr, inv_hw, w0, b0, w1, b1, gate, blockIdx.x, threadIdx.x, sm);
 }
 
-// ---- the same in ONE launch (round 5): fold + border blocks, and the block that arrives LAST at an image's counter computes its gate ----------
-// The two launches above cost 13.5 + 16 us per RCAB (32 RCABs per forward: 0.95 ms), most of it the dependent launch boundary and a 1024-thread
-// block per image waiting for its own loads.  Here grid = (n_red + 4 * kEdgeSegs, B) blocks do the slot fold / the border segments as before (on their first four waves; the blocks are 1024 threads for the gate stage);
-// each then publishes (its results as write-through `sc0 sc1` stores, drained, then a device-scope atomic on counter[b]); the block that finds itself last runs the gate
-// stage for image b from the folded slots and the edge / corner scratch -- the same sums in the same fixed order, so the gate is bit-identical to the
-// two-launch form whichever block happens to be last.  The last block resets the counter (stream order makes that visible to the next launch); concurrent
-// streams take different counter slices.
-template <typename T>
-__global__ __launch_bounds__(kGateThreads) void ca_gate_ahead_fused_kernel(float* __restrict__ sums, int n_tiles, int L, int n_red, const T* __restrict__ t,
-                                                                           float* __restrict__ edge, float* __restrict__ corner, int H, int W,
-                                                                           const float* __restrict__ w2t, const float* __restrict__ b2, int c, int cr, float inv_hw,
-                                                                           const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ w1,
-                                                                           const float* __restrict__ b1, float* __restrict__ gate, int* __restrict__ counter) {
-    extern __shared__ float sm[];          // phase 1: [256] partials; phase 2: ca_gate_ahead_body's layout
-    __shared__ int s_last;
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const bool act = tid < 256;            // the fold / border bodies are 256-thread code; the other 12 waves wait for the gate stage
-    // what another CU will read (the folded slots, the edge / corner sums) leaves as write-through `sc0 sc1` stores ...
-    if ((int)blockIdx.x < n_red) ca_reduce_body<true>(sums, n_tiles, c, L, blockIdx.x, b, tid, sm, act);
-    else ca_border_body<T, true>(t, edge, corner, H, W, c, (int)blockIdx.x - n_red, b, tid, sm, act);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // ... drained by every thread before the block's arrival is published
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&counter[b], 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    if (tid == 0) counter[b] = 0;                                  // ready for the next launch on this stream
-    // the gate stage exactly as the second launch ran it (same 1024 threads, same fold order; its reads of the other blocks' results bypass the caches):
-    // bit-identical whichever block arrived last
-    ca_gate_ahead_body<true>(sums, n_red > 0 ? n_red : n_tiles, n_red > 0 ? L : 1, (size_t)n_tiles * c, edge, corner, w2t, b2, c, cr, inv_hw, w0, b0, w1, b1, gate, b, tid, sm);
-}
+// (Round 5 tried rc_ca_gate_ahead as ONE launch: the fold / border blocks publish their results, the block that arrives last at a per-image counter runs
+// the gate stage -- bit-identical to the two launches.  With agent-scope release / acquire fences it took 85 us per call at level 0 against 35 us for
+// the two launches (every block's release writes back an L2 full of the conv's output); with write-through `sc0 sc1` stores and cache-bypassing loads 52 us;
+// the whole step 52.4 vs 51.9 ms.  A dependent launch boundary (~2 us) is cheaper than any cross-CU hand-off inside a launch here.  Removed.)
 
 // ---- color_block: conv1x1 -> avgpool(3, s2, p1, count_include_pad) -> LeakyReLU(0.2) -------------
 // x NCHW (B,cin,h,w), optionally instance-normalised on load; y fp32 NCHW (B,cout,ho,wo).
@@ -438,9 +402,6 @@ __global__ __launch_bounds__(256) void channel_sums_kernel(const T* __restrict__
     }
 }
 
-int g_gate_fused = 1;              // rc_debug_set("gate_fused", v): 1 (default) rc_ca_gate_ahead as ONE launch (last-block-done counter), 0 the two launches of round 4
-constexpr int kGateSlices = 64, kGateCounters = 4096;
-
 }  // namespace rc
 
 using namespace rc;
@@ -511,35 +472,6 @@ int rc_ca_gate_ahead(float* d_sums, int batch, int n_tiles, int c, int cr, const
         slots = ceil_div(n_tiles, L);
         stride = L;
         n_red = slots;
-    }
-    // ONE launch (the last block to arrive computes the image's gate) when the arrival counters exist: kGateSlices slices of kGateCounters ints per device,
-    // zero at allocation, returned to zero by every launch, one slice per call in turn (calls in flight on different streams never share a slice).
-    // They are allocated on the first call outside a stream capture; until then (and for batch > kGateCounters) the two launches below run.
-    if (g_gate_fused && batch <= kGateCounters) {
-        static int* counters[64] = {};
-        static unsigned turn[64] = {};
-        const int dev = current_device();
-        if (counters[dev] == nullptr) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(as_stream(stream), &cs);
-            if (cs == hipStreamCaptureStatusNone) {
-                int* p = nullptr;
-                if (hipMalloc(&p, sizeof(int) * kGateSlices * kGateCounters) == hipSuccess && hipMemset(p, 0, sizeof(int) * kGateSlices * kGateCounters) == hipSuccess) counters[dev] = p;
-                else (void)hipGetLastError();
-            }
-        }
-        if (counters[dev] != nullptr) {
-            int* ctr = counters[dev] + (size_t)(turn[dev]++ % kGateSlices) * kGateCounters;
-            const float inv_hw = 1.0f / ((float)H * (float)W);
-            if (dtype == RC_F32)
-                hipLaunchKernelGGL(ca_gate_ahead_fused_kernel<float>, dim3(n_red + 4 * kEdgeSegs, batch), dim3(kGateThreads), lds, as_stream(stream), d_sums, n_tiles, L, n_red,
-                                   static_cast<const float*>(d_t), edge, corner, H, W, d_w2t, d_b2, c, cr, inv_hw, d_w0, d_b0, d_w1, d_b1, d_gate, ctr);
-            else
-                hipLaunchKernelGGL(ca_gate_ahead_fused_kernel<bf16_t>, dim3(n_red + 4 * kEdgeSegs, batch), dim3(kGateThreads), lds, as_stream(stream), d_sums, n_tiles, L, n_red,
-                                   static_cast<const bf16_t*>(d_t), edge, corner, H, W, d_w2t, d_b2, c, cr, inv_hw, d_w0, d_b0, d_w1, d_b1, d_gate, ctr);
-            RC_HIP_CHECK(hipGetLastError());
-            return RC_OK;
-        }
     }
     if (dtype == RC_F32)
         hipLaunchKernelGGL(ca_reduce_border_kernel<float>, dim3(n_red + 4 * kEdgeSegs, batch), dim3(256), 0, as_stream(stream), d_sums, n_tiles, c, L, n_red,

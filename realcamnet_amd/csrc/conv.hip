@@ -15,7 +15,6 @@ struct ConvPlan {
 static int g_persist_on = 1;       // rc_debug_set("persist", v): 0 general kernel only, 1 automatic (default), 2 producer/consumer wherever eligible, 3 persistent only
 extern int g_dw3_seg16;            // gma.hip
 extern int g_dec_lds;              // rans.hip
-extern int g_gate_fused;           // cond.hip
 static int g_pss = 0;              // rc_debug_set("pss", v): 1: single-chunk pixel-shuffle layers (the tail 48 -> 192) take kernel 5 (output staged through LDS, stored by the
                                    // loader waves); 0 (default): kernel 4.  Measured on MI355X at 8 x 1088 x 1920: 3.16-3.29 vs 3.24-3.27 ms (conv_kernel.hpp, kernel 5)
 static int g_auto = 1;             // rc_debug_set("persist_auto", v): single-chunk, single-cout-tile bf16 3x3 layers (48 -> 48, 32 -> 32) on kernel 6 (wave-autonomous strips):
@@ -265,7 +264,6 @@ int rc_debug_set(const char* key, int value) {
     if (std::string(key) == "dec_lds") { g_dec_lds = value != 0; return RC_OK; }
     if (std::string(key) == "dw3_seg16") { g_dw3_seg16 = value != 0; return RC_OK; }
     if (std::string(key) == "pss") { g_pss = value != 0; return RC_OK; }
-    if (std::string(key) == "gate_fused") { g_gate_fused = value != 0; return RC_OK; }
     if (std::string(key) == "persist_auto") { g_auto = value < 0 ? 0 : (value > 2 ? 2 : value); return RC_OK; }
     if (std::string(key) == "conv32") { g_conv32 = value < 0 ? 0 : (value > 4 ? 4 : value); return RC_OK; }
     return fail(RC_ERR_INVALID, std::string("rc_debug_set: unknown key ") + key);
@@ -277,7 +275,6 @@ int rc_debug_get(const char* key) {
     if (std::string(key) == "conv32") return g_conv32;
     if (std::string(key) == "conv_flags") return g_dbg_flags;
     if (std::string(key) == "pss") return g_pss;
-    if (std::string(key) == "gate_fused") return g_gate_fused;
     if (std::string(key) == "persist_auto") return g_auto;
     return -1;
 }

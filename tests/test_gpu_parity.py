@@ -759,9 +759,13 @@ def test_lsc_chain_in_registers_vs_layer_by_layer(hip, shape, width):
             two = head._nhwc(a, mul_plus1=layered)
         finally:
             ops.FUSE_CHAIN = old
-    assert chain is not None and fused is not None and chain.shape == fused.shape == two.shape == (b, H, W, width)
+    assert chain is not None and chain.shape == two.shape == (b, H, W, width)
     f = lambda v: ops.to_nchw(v).float().cpu()
     assert rel_err(f(chain), f(layered)) < 2e-2 and rel_err(f(chain), t) < 3e-2
+    if width == 128:        # no fused head at the codec's width (it spilled 29 registers, and the codec returns the lens-shading map itself): two launches
+        assert fused is None
+        return
+    assert fused is not None and fused.shape == (b, H, W, width)
     assert rel_err(f(fused), f(two)) < 2e-2 and rel_err(f(fused), ref) < 3e-2
 
 
