@@ -858,6 +858,89 @@ struct ConvDev {
         }
     }
 
+    // ---- kernel 7: epilogue of a 2-row x 16-pixel sub-strip (lane (n, q): pixel (gy + p, gx0 + n), channels q NV .. q NV + NV - 1) ------------
+    // NHWC, one cout tile, bf16.  F: EP_RELU / EP_LEAKY / EP_SUMS (carried: `run`, written to slot (sp, wv) when `flush`) / EP_RES (+ EP_GATE),
+    // the residual prefetched into rp by sub_res_prefetch.  Same arithmetic, same order as epilogue_fast_impl / epilogue_res_pre.
+    __device__ static __forceinline__ void sub_res_prefetch(const ConvArgs& a, int b, int gy, int gx0, int lane, unsigned (&rp)[2][NRH]) {
+        const int q = lane >> 4, n = lane & 15;
+        const size_t img_out = (size_t)a.H * a.W * a.cout;
+        const __amdgpu_buffer_rsrc_t r_res = make_rsrc(static_cast<const T*>(a.residual) + (size_t)b * img_out, (unsigned)(img_out * ES));
+        const int gx = gx0 + n;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int po = (gy + p < a.H && gx < a.W) ? (((gy + p) * a.W + gx) * a.cout + q * NV) * ES : kOOB;
+#pragma unroll
+            for (int i = 0; i < NRH / 4; ++i) {
+                const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r_res, po + 16 * i, 0, 0);
+                rp[p][4 * i] = t.x; rp[p][4 * i + 1] = t.y; rp[p][4 * i + 2] = t.z; rp[p][4 * i + 3] = t.w;
+            }
+            if constexpr (NRH % 4 != 0) {
+                const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(r_res, po + 16 * (NRH / 4), 0, 0);
+                rp[p][4 * (NRH / 4)] = t.x; rp[p][4 * (NRH / 4) + 1] = t.y;
+            }
+        }
+    }
+    template <int F, int NRP>
+    __device__ static __forceinline__ void epilogue_sub(const ConvArgs& a, int b, int gy, int gx0, int sp, int wv, int lane, f32x4 (&acc)[2][NT],
+                                                        float (&run)[(F & EP_SUMS) ? NV : 1], bool flush, const unsigned (&rp)[NRP][(F & EP_RES) ? NRH : 1],
+                                                        const float* gate_row) {
+        const int q = lane >> 4, n = lane & 15, jbase = q * NV;
+        const size_t img_out = (size_t)a.H * a.W * a.cout;
+        const __amdgpu_buffer_rsrc_t r_out = make_rsrc(static_cast<T*>(a.out) + (size_t)b * img_out, (unsigned)(img_out * ES));
+        const int gx = gx0 + n;
+        float gs[(F & EP_GATE) ? NV : 1];
+        if constexpr ((F & EP_GATE) != 0) {
+#pragma unroll
+            for (int e = 0; e < NV; e += 4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gate_row + jbase + e);
+                gs[e] = g4.x; gs[e + 1] = g4.y; gs[e + 2] = g4.z; gs[e + 3] = g4.w;
+            }
+        }
+        const float inf = __builtin_inff();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const bool valid = gy + p < a.H && gx < a.W;
+            float v[NV];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[p][nt][r];
+            constexpr bool PK_RELU = F == EP_RELU;
+            if constexpr ((F & EP_RELU) != 0 && !PK_RELU) {
+#pragma unroll
+                for (int e = 0; e < NV; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.f, inf);
+            }
+            if constexpr ((F & EP_LEAKY) != 0) {
+#pragma unroll
+                for (int e = 0; e < NV; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], v[e] * a.act_slope, inf);
+            }
+            if constexpr ((F & EP_GATE) != 0) {
+#pragma unroll
+                for (int e = 0; e < NV; ++e) v[e] *= gs[e];
+            }
+            if constexpr ((F & EP_RES) != 0) {
+#pragma unroll
+                for (int i = 0; i < NRH; ++i) {
+                    v[2 * i] += __uint_as_float(rp[p][i] << 16);
+                    v[2 * i + 1] += __uint_as_float(rp[p][i] & 0xffff0000u);
+                }
+            }
+            if constexpr ((F & EP_SUMS) != 0) {
+#pragma unroll
+                for (int e = 0; e < NV; ++e) run[e] += valid ? v[e] : 0.f;
+            }
+            const int oo = (valid && !(a.dbg_flags & 1)) ? (((gy + p) * a.W + gx) * a.cout + jbase) * ES : kOOB;
+            buf_store_row<T, NV, PK_RELU>(r_out, oo, v);
+        }
+        if constexpr ((F & EP_SUMS) != 0) {
+            if (flush) {
+                write_chan_sums(a, b, sp, wv, n, jbase, run, false);
+#pragma unroll
+                for (int e = 0; e < NV; ++e) run[e] = 0.f;
+            }
+        }
+    }
+
     __device__ static __forceinline__ void epilogue_generic(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
                                                             f32x4 (&acc)[4][NT]) {
         const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
@@ -1939,6 +2022,200 @@ __global__ __launch_bounds__(kAutoThreads) void conv_mfma_auto_kernel(const Conv
     }
 }
 
+// ==================================================================================================
+// Kernel 7: the wave-autonomous form for the 64-CHANNEL layers (64 -> 64: the trunk of LiteISPNet / LiteISPNet_GFM, the codec's ResidualBlocks).
+// Those layers had no kernel configuration of their own: 72 KB of packed weights + a 54 KB halo tile do not fit twice per CU, so they ran on the
+// general kernel, which re-stages the weights for every 8 x 32 tile in three sub-stages (8 GB of L2 -> LDS traffic per level-0 layer; 2.0 ms per
+// layer at 1.34 kW, twice the energy of the 48-channel layers per FLOP).  Here the weights stay resident (one copy per CU) and 8 autonomous waves
+// (kernel 6's scheme: private halo strips, loads prefetched one strip ahead, no barrier in the loop) each own 2-row x 32-pixel strips, processed as
+// two 2 x 16 SUB-strips so that a private 4 x 18 halo sub-strip is 9 KB: 72 + 8 x 9 KB of LDS.  A wave tile is 2 pixel tiles x 4 cout tiles (32
+// accumulator registers, 6 fragment reads per 8 MFMAs).
+// LDS layout: a pixel is 8 units of 16 bytes = 128 bytes, which maps every second pixel onto the same banks; padding the slot to 160 bytes (the other
+// kernels' remedy) would not fit, so unit u of the pixel in halo column c sits in slot u ^ (c & 7): with that XOR every 16-lane group of a
+// ds_read_b128 covers 16 distinct 4-bank groups for all three kx and both channel halves (checked exhaustively: tools/swizzle_check.py).
+// Same unit map, same step order, same MFMA chain per pixel as kernels 1-4 -> bit-identical results (tested).
+// ==================================================================================================
+template <class Cfg>
+constexpr bool auto64_eligible() { return sizeof(typename Cfg::elem) == 2 && Cfg::KS == 3 && Cfg::CK == 64 && Cfg::NT == 4; }
+constexpr int kA64TWH = 18, kA64PXB = 128, kA64ROWB = kA64TWH * kA64PXB, kA64STRIP = 4 * kA64ROWB;
+template <class Cfg>
+constexpr int auto64_lds_bytes() { return (int)Cfg::CHUNK_W_BYTES + (kAutoBias + kAutoGate) * 4 + kAutoWaves * kA64STRIP; }
+
+// one MFMA step with the next step's fragment reads interleaved (kernel 7): 4 weight + 2 pixel fragments, 8 MFMAs
+template <int I, bool NEXT, int NT>
+__device__ __forceinline__ void a64_step(int s, const char* s_my, const char* s_w, int lane_w, const int (&xo)[3][2], const uint4 (&wf)[NT], const uint4 (&xf)[2],
+                                         uint4 (&wfn)[NT], uint4 (&xfn)[2], f32x4 (&acc)[2][NT]) {
+    constexpr int FR = NT + 2, FM = 2 * NT;
+    if constexpr (I < FR) {
+        if constexpr (NEXT) {
+            const int sn = s + 1, tap = sn >> 1, ky = tap / 3, kx = tap - 3 * ky, h = sn & 1;
+            if constexpr (I < NT) wfn[I] = *reinterpret_cast<const uint4*>(s_w + (sn * NT + I) * 1024 + lane_w);
+            else xfn[I - NT] = *reinterpret_cast<const uint4*>(s_my + xo[kx][h] + (ky + (I - NT)) * kA64ROWB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = (I * FM) / FR; m < ((I + 1) * FM) / FR; ++m) Mma<bf16_t>::run(wf[m % NT], xf[m / NT], acc[m / NT][m % NT]);
+        __builtin_amdgcn_sched_barrier(0);
+        a64_step<I + 1, NEXT, NT>(s, s_my, s_w, lane_w, xo, wf, xf, wfn, xfn, acc);
+    }
+}
+
+template <class Cfg8, int MODE>
+__global__ __launch_bounds__(kAutoThreads) void conv_mfma_auto64_kernel(const ConvArgs a) {
+    using D = ConvDev<Cfg8>;
+    using T = typename Cfg8::elem;
+    constexpr int NT = Cfg8::NT, STEPS = Cfg8::STEPS, NV = 4 * NT, UPT = 8, UNIT = 8, ES = 2, TWH = kA64TWH;
+    constexpr int NU = 4 * TWH * UPT, NI = NU / 64, RU = TWH * UPT;                 // 576 units = 9 loads per lane, 144 units per halo row
+    static_assert(auto64_eligible<Cfg8>() && NU % 64 == 0 && STEPS == 18, "64-channel 3x3 bf16 form");
+    constexpr int EP_RELU = D::EP_RELU, EP_LEAKY = D::EP_LEAKY, EP_RES = D::EP_RES, EP_SUMS = D::EP_SUMS, EP_GATE = D::EP_GATE;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_w = smem;
+    float* s_bias = reinterpret_cast<float*>(smem + Cfg8::CHUNK_W_BYTES);
+    float* s_gate = s_bias + kAutoBias;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* s_my = smem + Cfg8::CHUNK_W_BYTES + (kAutoBias + kAutoGate) * 4 + wave * kA64STRIP;
+    const int q = lane >> 4, n = lane & 15;
+    const int wv = wave & 3;                                         // strip of its group's 8 x 32 tile (= the wave index the other kernels' epilogues use)
+
+    for (int kb = wave; kb < STEPS * NT; kb += kAutoWaves)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.wpacked) + kb * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(s_w + kb * 1024), 16, 0, 0);
+    for (int i = tid; i < kAutoBias; i += kAutoThreads) s_bias[i] = (a.bias && i < a.cout_packed) ? a.bias[i] : 0.f;
+    [[maybe_unused]] const bool gated_out = a.ep_key == (EP_GATE | EP_RES);
+    if constexpr (MODE == 2) {
+        if (gated_out)
+            for (int i = tid; i < a.batch * a.cout; i += kAutoThreads) s_gate[i] = a.out_scale[i];
+    }
+
+    // a block is two groups of 4 waves, each walking its own list of 8 x 32 tiles (band-major); XCD x (blockIdx % 8) takes a run of consecutive tiles
+    constexpr int NG = kAutoWaves / 4;
+    const int sp_total = a.tiles_x * a.tiles_y;
+    const int n_units = sp_total * a.batch;
+    const int slots = (int)(gridDim.x >> 3) * NG;
+    const int pos = (blockIdx.x & 7) * slots + (blockIdx.x >> 3) * NG + (wave >> 2);
+    const int stride = (int)gridDim.x * NG;
+    const size_t img = (size_t)a.H * a.W * a.cin;
+    const unsigned img_bytes = (unsigned)(img * ES);
+
+    auto decode = [&](int u, int& b, int& ty8, int& tx) -> int {
+        if (u >= n_units) return -1;
+        b = magic_div(u, a.td.sp_total);
+        band_decode(u - b * sp_total, a.tiles_x, a.tiles_y, a.td, ty8, tx);
+        return u;
+    };
+
+    // Load k of a sub-strip covers units u = lane + 64 k: halo pixel u / 8 (row-major in the 4 x 18 sub-strip), 16-byte piece u % 8 = lane & 7.
+    const int rdelta = (a.W * a.cin - RU * UNIT) * ES;               // image row pitch - sub-strip row bytes (uniform)
+    const int j8 = lane >> 3, cu = lane & 7;
+    uint4 r[NI];
+    auto issue = [&](bool valid, int b, int ty8, int tx, int half) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(static_cast<const T*>(a.in0) + (size_t)b * img, img_bytes);
+        const int gy0 = ty8 * kTH + 2 * wv - 1, gx0 = tx * kTW + 16 * half - 1;
+        if (a.dbg_flags & 4) valid = false;
+        const bool interior = valid && gy0 >= 0 && gx0 >= 0 && gy0 + 4 <= a.H && gx0 + TWH <= a.W && a.cin_chunk_ok;   // uniform
+        if (interior) {
+            const int soff = (gy0 * a.W + gx0) * a.cin * ES;
+            const int l16 = lane * 16;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int row0 = (64 * k) / RU, t = (row0 + 1) * RU - 64 * k;        // lanes >= t of this load are in the next halo row
+                const int voff = t < 64 ? (lane >= t ? l16 + rdelta : l16) : l16;
+                r[k] = buf_load16(rs, voff, soff + 1024 * k + row0 * rdelta);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NI; ++k) {
+                const int pix = 8 * k + j8, py = pix / TWH, px = pix - py * TWH;
+                const int gy = gy0 + py, gx = gx0 + px;
+                const bool ok = valid && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W && cu * UNIT < a.cin;
+                r[k] = buf_load16(rs, ok ? ((gy * a.W + gx) * a.cin + cu * UNIT) * ES : kOOB, 0);
+            }
+        }
+    };
+
+    // per-lane operand offsets: pixel column n + kx of a halo row, unit 4 h + q in its swizzled slot
+    int xo[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) xo[kx][h] = (n + kx) * kA64PXB + (((4 * h + q) ^ ((n + kx) & 7)) * 16);
+    const int lane_w = lane * 16;
+
+    int cb = 0, cty8 = 0, ctx = 0, chalf = 0;
+    int cu_ = decode(pos, cb, cty8, ctx);
+    issue(cu_ >= 0, cb, cty8, ctx, 0);
+    __syncthreads();
+
+    float run[MODE == 1 ? NV : 1];
+#pragma unroll
+    for (int e = 0; e < (MODE == 1 ? NV : 1); ++e) run[e] = 0.f;
+
+    while (cu_ >= 0) {
+        // ---- commit: unit (pixel 8 k + lane / 8, piece lane % 8) -> slot piece ^ (column & 7) of the pixel's 128 bytes
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int row0 = (8 * k) / TWH, thr = (row0 + 1) * TWH - 8 * k;
+            const int pix = 8 * k + j8;
+            const int px = pix - TWH * (row0 + ((thr < 8 && j8 >= thr) ? 1 : 0));
+            *reinterpret_cast<uint4*>(s_my + pix * kA64PXB + ((cu ^ (px & 7)) * 16)) = r[k];
+        }
+        const int gy = cty8 * kTH + 2 * wv, gx0 = ctx * kTW + 16 * chalf, sp = cty8 * a.tiles_x + ctx;
+        int nb = cb, nty8 = cty8, ntx = ctx, nu = cu_;
+        const int nhalf = chalf ^ 1;
+        if (chalf == 1) nu = decode(cu_ + stride, nb, nty8, ntx);
+        unsigned rpre[MODE == 2 ? 2 : 1][MODE == 2 ? D::NRH : 1];
+        if constexpr (MODE == 2) D::sub_res_prefetch(a, cb, gy, gx0, lane, rpre);
+        issue(nu >= 0, nb, nty8, ntx, nhalf);
+
+        f32x4 acc[2][NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float4 t4 = *reinterpret_cast<const float4*>(s_bias + q * NV + nt * 4);
+            acc[0][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
+            acc[1][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
+        }
+        if (!(a.dbg_flags & 2)) {
+            uint4 wfa[NT], xfa[2], wfb[NT], xfb[2];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wfa[nt] = *reinterpret_cast<const uint4*>(s_w + nt * 1024 + lane_w);
+            xfa[0] = *reinterpret_cast<const uint4*>(s_my + xo[0][0]);
+            xfa[1] = *reinterpret_cast<const uint4*>(s_my + xo[0][0] + kA64ROWB);
+#pragma unroll
+            for (int s = 0; s < STEPS; s += 2) {
+                a64_step<0, true, NT>(s, s_my, s_w, lane_w, xo, wfa, xfa, wfb, xfb, acc);
+                if (s + 2 < STEPS) a64_step<0, true, NT>(s + 1, s_my, s_w, lane_w, xo, wfb, xfb, wfa, xfa, acc);
+                else a64_step<0, false, NT>(s + 1, s_my, s_w, lane_w, xo, wfb, xfb, wfa, xfa, acc);
+            }
+        }
+
+        if constexpr (MODE == 1) {
+            const bool last = chalf == 1;
+            const bool flush = last && (nu < 0 || nb != cb);         // uniform: the strip's sums leave with its right half, if the wave's next strip is another image's
+            if (last && !flush) {
+                float* dst = a.chan_sums + (((size_t)cb * (a.tiles_x * a.tiles_y) + sp) * 4 + wv) * a.cout;
+                if (4 * lane < a.cout) *reinterpret_cast<float4*>(dst + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const unsigned none[1][1] = {{0u}};
+            if (a.ep_key == EP_SUMS) D::template epilogue_sub<EP_SUMS, 1>(a, cb, gy, gx0, sp, wv, lane, acc, run, flush, none, nullptr);
+            else if (a.ep_key == (EP_RELU | EP_SUMS)) D::template epilogue_sub<EP_RELU | EP_SUMS, 1>(a, cb, gy, gx0, sp, wv, lane, acc, run, flush, none, nullptr);
+            else D::template epilogue_sub<EP_LEAKY | EP_SUMS, 1>(a, cb, gy, gx0, sp, wv, lane, acc, run, flush, none, nullptr);
+        } else if constexpr (MODE == 2) {
+            float none[1] = {0.f};
+            if (gated_out) D::template epilogue_sub<EP_GATE | EP_RES, 2>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, rpre, s_gate + cb * a.cout);
+            else D::template epilogue_sub<EP_RES, 2>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, rpre, nullptr);
+        } else {
+            float none[1] = {0.f};
+            const unsigned nonr[1][1] = {{0u}};
+            if (a.ep_key == EP_RELU) D::template epilogue_sub<EP_RELU, 1>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, nonr, nullptr);
+            else if (a.ep_key == EP_LEAKY) D::template epilogue_sub<EP_LEAKY, 1>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, nonr, nullptr);
+            else D::template epilogue_sub<0, 1>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, nonr, nullptr);
+        }
+        cu_ = nu; cb = nb; cty8 = nty8; ctx = ntx; chalf = nhalf;
+    }
+}
+
 template <class Cfg>
 constexpr int ws_lds_bytes() { return 2 * Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTES + 16 * Cfg::NT * 4; }
 
@@ -2012,6 +2289,31 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
             if (grid > n_items) grid = n_items;
             grid = (grid + 7) / 8 * 8;
             hipLaunchKernelGGL((conv_mfma_wsm_kernel<Cfg, GATED, FAST>), dim3((unsigned)grid), dim3(kWsmThreads), WSM_LDS, stream, a);
+            RC_HIP_CHECK(hipGetLastError());
+            return RC_OK;
+        }
+    }
+    if constexpr (!GATED && FAST && auto64_eligible<Cfg>()) {
+        // the 64-channel wave-autonomous form (kernel 7): 64 -> 64, one cout tile, rc_debug_set("persist_auto", != 0)
+        using DD = ConvDev<Cfg>;
+        const int k7 = a.ep_key;
+        const bool key_ok = k7 == 0 || k7 == DD::EP_RELU || k7 == DD::EP_LEAKY || k7 == DD::EP_SUMS || k7 == (DD::EP_RELU | DD::EP_SUMS) || k7 == (DD::EP_LEAKY | DD::EP_SUMS) ||
+                            k7 == DD::EP_RES || (k7 == (DD::EP_GATE | DD::EP_RES) && a.batch * a.cout <= kAutoGate);
+        if (a.auto_impl && key_ok && a.n_chunks == 1 && a.n_ct == 1 && a.cout == Cfg::COUT_TILE && a.cin_vec_ok && a.persist_ok && a.out_mode == RC_OUT_NHWC && n_tiles < (1 << 24)) {
+            constexpr int A_LDS = auto64_lds_bytes<Cfg>();
+            static_assert(A_LDS <= 160 * 1024, "kernel 7 LDS");
+            static PerDeviceFlag attr_set;
+            if (!attr_set.test_and_set()) {
+                RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_auto64_kernel<Cfg, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
+                RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_auto64_kernel<Cfg, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
+                RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_auto64_kernel<Cfg, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
+            }
+            int grid = a.num_cus;
+            if (grid * 2 > n_tiles) grid = (n_tiles + 1) / 2;      // two groups of four waves per block, one 8 x 32 tile each
+            grid = (grid + 7) / 8 * 8;
+            if (k7 & DD::EP_SUMS) hipLaunchKernelGGL((conv_mfma_auto64_kernel<Cfg, 1>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, a);
+            else if (k7 & DD::EP_RES) hipLaunchKernelGGL((conv_mfma_auto64_kernel<Cfg, 2>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, a);
+            else hipLaunchKernelGGL((conv_mfma_auto64_kernel<Cfg, 0>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, a);
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Kernel 6 (wave-autonomous strips, rc_debug_set("persist_auto", 1)) against kernel 2 (two 4-wave persistent blocks per CU) on the 48 -> 48 layers
-of cfg3: bit-equality of every operand form, then ms per layer (>= 50 warm-up launches: the GPU idles at low clocks) and the RCAGroup."""
+"""The wave-autonomous kernels (6: 48 / 32 channels, 7: 64 channels; rc_debug_set("persist_auto", ...)) against the kernels they replace, on C -> C layers
+(argv[1] = C, default 48) at the cfg3 sizes: bit-equality of every operand form, then ms per layer (>= 50 warm-up launches: the GPU idles at low clocks) and the RCAGroup."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
@@ -11,7 +11,7 @@ L = _lib.load()
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 
 
-VARIANTS = (("kernel 2", 0, 0), ("kernel 6", 2, 0))
+VARIANTS = (("persist_auto 0", 0, 0), ("persist_auto 2", 2, 0))     # 48 / 32 channels: kernel 2 vs kernel 6; 64 channels: the general kernel vs kernel 7
 
 
 def knob(v, flags=0):
@@ -37,6 +37,7 @@ with torch.no_grad():
         res = torch.randn(B, H, W, C, device=dev, dtype=bf)
         g = torch.rand(B, C, device=dev, dtype=torch.float32)
         forms = {"plain": dict(), "relu": dict(act="relu"), "leaky": dict(act="leaky", slope=0.2), "sums": dict(want_sums=True), "relu+sums": dict(act="relu", want_sums=True),
+                 "leaky+sums": dict(act="leaky", slope=0.01, want_sums=True),
                  "res": dict(residual=res), "gate+res": dict(residual=res, out_scale=g)}
         for name, kw in forms.items():
             outs = []
