@@ -294,21 +294,22 @@ def main():
 
     import torch.distributed as dist
     gather = shard.OverlappedGather(total_frames) if (dist.is_available() and dist.is_initialized() and not args.no_gather) else None
-    for _ in range(args.warmup):
+    est = 0.0
+    for i in range(args.warmup):
+        if i == args.warmup - 1:                           # the last warm-up step is timed on its own: it sizes the power sample's delay (no extra forward)
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
         out = step()
         if gather is not None:
             gather.submit(out)
     if gather is not None:
         gather.wait()
     torch.cuda.synchronize()
+    if args.warmup > 0:
+        est = (time.perf_counter() - tw) * args.steps
     shard.barrier()
     torch.cuda.synchronize()
-    tw = time.perf_counter()                               # one untimed step to size the power sample's delay
-    step(); torch.cuda.synchronize()
-    est = (time.perf_counter() - tw) * args.steps
-    shard.barrier()
-    torch.cuda.synchronize()
-    sampler = PowerSampler(0.3 * est) if (rank == 0 and est > 0.6) else None      # rocm-smi itself takes ~0.2 s: only runs long enough to contain it
+    sampler = PowerSampler(0.1 * est) if (rank == 0 and est > 0.25) else None     # rocm-smi itself takes ~0.2 s: only runs long enough to contain it (the result says whether it did)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()

@@ -2,7 +2,7 @@
 # Round-end evidence: PMC traffic passes, kernel-trace of the bench command, default bench line (with CPU baseline),
 # the other table rows, MFMA calibration.  usage: tools/final_profiles.sh TAG [ROUND]   (outputs under gpurun_out/)
 TAG=${1:-fin}
-ROUND=${2:-r04}
+ROUND=${2:-r05}
 mkdir -p gpurun_out
 bash tools/pmc_bench.sh $TAG > gpurun_out/pmc_${TAG}.log 2>&1
 
@@ -18,6 +18,10 @@ timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_codec_$TAG -o tr
 timeout 300 python tools/gma_stage_bench.py > gpurun_out/gma_stages_$TAG.txt 2>&1
 timeout 300 python tools/codec_stream_bench.py > gpurun_out/codec_stream_$TAG.txt 2>&1
 timeout 120 python tools/mfma_peak.py > gpurun_out/mfma_peak_$TAG.txt 2>/dev/null
+# round 5 evidence: power / clock per kernel variant (the conv kernels sit at the board's power cap), kernels 6 / 7 against the kernels they replace
+timeout 200 python tools/power_probe.py > gpurun_out/power_probe_$TAG.txt 2>&1
+( timeout 150 python tools/auto_probe.py 48; timeout 150 python tools/auto_probe.py 64 ) > gpurun_out/auto_probe_$TAG.txt 2>&1
+timeout 300 python bench.py --model LiteISPNet --no-cpu-baseline > gpurun_out/bench_liteisp_bf16_$TAG.json 2>/dev/null
 # round 4 evidence: the folded tail against the two launches it replaces, the early-gate RCAGroup, the codec's per-launch breakdown
 ( timeout 200 python tools/tail_fold_probe.py; timeout 200 python tools/rcag_probe.py ) > gpurun_out/tail_fold_$TAG.txt 2>&1
 timeout 200 python tools/codec_conv_breakdown.py > gpurun_out/codec_probes_$TAG.txt 2>&1
@@ -29,7 +33,7 @@ tail -c 400 gpurun_out/bench_default_$TAG.json; echo; cut -c1-160 gpurun_out/ben
 
 # summaries are written ON the box (gpurun_out/ is capped at 64 MiB on the way back): keep them, the bench trace database and the small logs
 mkdir -p gpurun_out/profiles_$TAG
-cp gpurun_out/tail_fold_$TAG.txt gpurun_out/codec_probes_$TAG.txt gpurun_out/profiles_$TAG/ 2>/dev/null
+cp gpurun_out/tail_fold_$TAG.txt gpurun_out/codec_probes_$TAG.txt gpurun_out/power_probe_$TAG.txt gpurun_out/auto_probe_$TAG.txt gpurun_out/profiles_$TAG/ 2>/dev/null
 python tools/write_profiles.py $TAG $ROUND gpurun_out/profiles_$TAG > gpurun_out/profiles_$TAG/summary.json 2> gpurun_out/write_profiles_$TAG.err
 mkdir -p gpurun_out/keep_$TAG && cp gpurun_out/prof_$TAG/trace_results.db gpurun_out/keep_$TAG/bench_trace_results.db 2>/dev/null
 cp gpurun_out/prof_codec_$TAG/trace_results.db gpurun_out/keep_$TAG/codec_trace_results.db 2>/dev/null

@@ -83,7 +83,7 @@ Default run (steps 5, warm-up 2, CPU baseline leg on):
 ```
 
 Kernel trace: `rocprofv3 --kernel-trace --stats -- python bench.py --model raw_compression_tcm_final --frames 8 --steps 2 --warmup 1 --no-cpu-baseline`
-(3 forwards of 4 frames in the trace; the table counts the LAST TWO -- steady state, weight packing and its copies are out), summarised with
+(3 forwards of 8 frames in the trace; the table counts the LAST TWO -- steady state, weight packing and its copies are out), summarised with
 `tools/rocpd_summary.py --last-forwards 2`:
 
 {csumm}
@@ -114,6 +114,25 @@ open(f"{OUT}/{RND}_tail_fold_rcag.md", "w").write(f"""# {RND} — the folded tai
 `RCAGroup shipped` = the early-gate schedule (default); `proxy kernels` = the same schedule timed with round 3's kernels before the new epilogues existed
 (conv + sums, conv + residual) -- the estimate the work was started on.  Round 3's schedule (gate folded into the next conv's staging) measured 9.16 / 2.36 ms
 at the two sizes on the same tool.
+""")
+open(f"{OUT}/{RND}_power_and_autonomous_kernels.md", "w").write(f"""# {RND} — power / clock per kernel variant and the wave-autonomous kernels at the final sources (`tools/power_probe.py`, `tools/auto_probe.py 48`, `tools/auto_probe.py 64`), 1x MI355X
+
+`rocm-smi` sampled in the middle of a ~1.2 s back-to-back run of each variant (ms per launch | shader clock | socket power).  The analysis is in
+`profiles/r05_power_wall.md`; this is the same probe on the round's final build.
+
+```
+{rd('power_probe')}
+```
+
+Kernel 6 (48 channels; `persist_auto` 2 = every eligible form, the default 1 keeps the residual forms on kernel 2) and kernel 7 (64 channels) against the kernels
+they replace, bit-equality of every operand form first:
+
+```
+{rd('auto_probe')}
+```
+
+`LiteISPNet`, 4K, 8 frames, bf16 (the 64-channel trunk; round 4: 58.6 ms):
+{last(f'{G}/bench_liteisp_bf16_{tag}.json') if os.path.exists(f'{G}/bench_liteisp_bf16_{tag}.json') else '(not collected)'}
 """)
 mf = f"{G}/pmc_mfma_{tag}.md"
 if os.path.exists(mf):
