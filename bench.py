@@ -381,8 +381,8 @@ def main():
                                         f"{r['bytes'] / (r['ms'] * 1e-3) / 1e12:.2f} TB/s" for r in rows[:4])
     if power is not None:
         res["power"] = power
-        rf["power_note"] = (f"socket {power.get('socket_W')} W of a {power.get('cap_W')} W cap at sclk {power.get('sclk_MHz')} MHz mid-run: the conv kernels are "
-                            "power-capped, not pipe- or HBM-capped (profiles/r05_power_wall.md)")
+        rf["power_note"] = (f"rocm-smi mid-run: socket {power.get('socket_W')} W (its reading averages over a window that includes the non-conv kernels) of a "
+                            f"{power.get('cap_W')} W cap, sclk {power.get('sclk_MHz')} MHz of 2400; the conv kernels alone sit AT the cap (profiles/r05_power_wall.md)")
     # HBM traffic comes from PMC counters, which cannot be read inside a timed run: tools/pmc_bench.sh collects them in separate
     # rocprofv3 --pmc passes of this same default command and commits the summary under profiles/.  The summary carries the digest of
     # the kernel sources it was measured on; a file taken on other sources is ignored (traffic stays null) rather than replayed.

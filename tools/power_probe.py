@@ -12,12 +12,15 @@ y = torch.empty_like(x)
 
 
 def smi():
+    """'sclk <MHz>, <W>' from one rocm-smi call (socket graphics package power; the reading averages over the tool's own window)."""
     r = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True)
-    keep = []
+    sclk = power = "?"
     for l in r.stdout.splitlines():
-        if "sclk" in l or "mclk" in l or "fclk" in l or "Power" in l:
-            keep.append(l.split(":", 1)[-1].strip() if "Power" not in l else "P " + l.split(":")[-1].strip())
-    return " | ".join(keep)
+        if "sclk" in l and "(" in l:
+            sclk = l.split("(")[-1].split("Mhz")[0]
+        elif "Power" in l and "===" not in l:
+            power = l.split(":")[-1].strip()
+    return f"sclk {sclk} MHz, {power} W"
 
 
 def run(tag, fn, secs=1.2):
