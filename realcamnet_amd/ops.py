@@ -644,26 +644,41 @@ BRANCH_STREAMS = True        # run independent small sub-graphs (the codec's mea
 _SIDE_STREAMS = {}
 
 
+FORK_DEPTH = 1       # nesting depth of fork_join: 1 = one fork at a time (the slice loop's mean || scale); 3 also runs conv_a || conv_b inside each attention
+                     # block on streams of their own -- measured +0.5 % at 8 frames, -3 % at 1 frame (host-bound): profiles/r05_small_things.md
+_FORK_PATH = __import__("threading").local()     # where in a tree of nested fork_join calls the running code is: "" / "s" / "m" / "sm" ...
+
+
 def fork_join(side_fn, main_fn, inputs):
     """(side_fn(), main_fn()) for two independent sub-graphs.  At the latent's size (1/16 of the packed frame) one launch covers about
-    half of the 256 CUs, so the two branches are enqueued on two streams and overlap: side_fn on a per-device side stream ordered behind the
+    half of the 256 CUs, so the two branches are enqueued on two streams and overlap: side_fn on a side stream ordered behind the
     current stream, main_fn on the current stream, which then waits for the side stream.  `inputs`: tensors side_fn reads (the caching
-    allocator is told about the second stream; the side branch's outputs likewise).  One stream under graph capture, fake tensors or
-    BRANCH_STREAMS = False."""
+    allocator is told about the second stream; the side branch's outputs likewise).  Calls NEST: a fork inside either branch of another gets a
+    side stream of its own (one per position in the call tree), so the codec's slice loop runs mean || scale and, inside each, conv_a || conv_b
+    as four concurrent chains of small launches.  One stream under graph capture, fake tensors or BRANCH_STREAMS = False."""
     from torch._subclasses.fake_tensor import FakeTensor
     probe = inputs[0]
     if not BRANCH_STREAMS or not probe.is_cuda or isinstance(probe, FakeTensor) or torch.cuda.is_current_stream_capturing():
         return side_fn(), main_fn()
+    path = getattr(_FORK_PATH, "p", "")
+    if len(path) >= FORK_DEPTH:                          # depth cap: 8 streams are plenty for 256 CUs (1 = round 4's single fork)
+        return side_fn(), main_fn()
     main = torch.cuda.current_stream(probe.device)
-    side = _SIDE_STREAMS.get(probe.device.index)
+    key = (probe.device.index, path)
+    side = _SIDE_STREAMS.get(key)
     if side is None:
-        side = _SIDE_STREAMS[probe.device.index] = torch.cuda.Stream(device=probe.device)
+        side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=probe.device)
     side.wait_stream(main)
     for t in inputs:
         t.record_stream(side)
-    with torch.cuda.stream(side):
-        a = side_fn()
-    b = main_fn()
+    try:
+        _FORK_PATH.p = path + "s"
+        with torch.cuda.stream(side):
+            a = side_fn()
+        _FORK_PATH.p = path + "m"
+        b = main_fn()
+    finally:
+        _FORK_PATH.p = path
     main.wait_stream(side)
     for t in (a if isinstance(a, (tuple, list)) else (a,)):
         t.record_stream(main)

@@ -226,7 +226,9 @@ class AttentionBlock(nn.Module):
         return self.conv_b[3]._nhwc(b)
 
     def _nhwc(self, a):
-        return ops.sigmoid_gate_add(self._branch_a(a), self._branch_b(a), a)
+        # conv_a || conv_b: two independent chains of 9 / 10 small launches (ops.fork_join: two streams outside graph capture)
+        ya, yb = ops.fork_join(lambda: self._branch_a(a), lambda: self._branch_b(a), [a])
+        return ops.sigmoid_gate_add(ya, yb, a)
 
     def forward(self, x):
         return ops.to_nchw(self._nhwc(ops.to_nhwc(x)))
@@ -254,8 +256,9 @@ class SWAtten(AttentionBlock):
         x = self.in_conv._nhwc(a)
         if x.shape[1] <= self.non_local_block.window_size or x.shape[2] <= self.non_local_block.window_size:
             raise ValueError("SWAtten: the map must be larger than the window")
-        z = self.non_local_block.block_2(self.non_local_block.block_1(x))
-        out = ops.sigmoid_gate_add(self._branch_a(x), self._branch_b(z), x)
+        # conv_a(x) on a side stream beside [SwinBlock -> conv_b] (the longer chain) on this one: nested inside the slice loop's mean || scale fork
+        ya, yb = ops.fork_join(lambda: self._branch_a(x), lambda: self._branch_b(self.non_local_block.block_2(self.non_local_block.block_1(x))), [x])
+        out = ops.sigmoid_gate_add(ya, yb, x)
         return self.out_conv._nhwc(out)
 
     def forward(self, x):
