@@ -144,6 +144,11 @@ typedef struct rc_conv_desc {
      * conv's own output when it is known ahead of the launch (rc_ca_gate_ahead): RCABlock's x + CA(conv(...)) (networks.py:311, 270) leaves
      * the second conv as ONE map, x_new = conv2(t) * gate + x, instead of r = conv2(t) followed by r * gate + x in the next layer's staging. */
     const float* out_scale;
+    /* ABI 10: partial-sum slots per image the caller allocated for chan_sums: rc_conv_sum_slots(desc) (what this launch fills -- the carried-sums
+     * kernels write one slot per (residue class of their tile walk, wave): 2 048 per image at 4K instead of 32 640) or 0 / rc_conv_sum_tiles() = the
+     * per-tile layout every kernel can write.  Any other value is an error. */
+    int32_t chan_sums_slots;
+    int32_t reserved0;
 } rc_conv_desc;
 
 /* Size in bytes of the packed weight buffer for (cin,cout,ksize,dtype,out_mode); 0 on error. */
@@ -159,6 +164,10 @@ int rc_conv_pack_bias(const float* bias_host, int cin, int cout, int ksize, int 
                       float* dst_host);
 /* Number of partial-sum slots per image the conv kernel writes to chan_sums (4 waves per 8x32 tile; depends only on H,W). */
 int rc_conv_sum_tiles(int height, int width);
+/* Slots per image the launch described by `d` fills in chan_sums (pointers are only tested for NULL; d->chan_sums_slots is ignored): the answer comes from
+ * the launcher itself, so an allocation sized by it cannot drift from the dispatch.  Either rc_conv_sum_tiles() (per (8x32 tile, wave)) or, for the
+ * carried-sums kernels, grid x waves.  Consumers (rc_ca_gate, rc_ca_gate_ahead) fold whatever count they are given, in fixed order.  -1 on a bad desc. */
+int rc_conv_sum_slots(const rc_conv_desc* d);
 int rc_conv2d(const rc_conv_desc* desc, void* stream);
 /* sizeof(rc_conv_desc) as compiled into the library: lets an FFI binding verify its struct mirror. */
 size_t rc_conv_desc_size(void);

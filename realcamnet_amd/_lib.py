@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("chan_sums", C.c_void_p),
         ("src_h", C.c_int32), ("src_w", C.c_int32),
         ("out_scale", C.c_void_p),
+        ("chan_sums_slots", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -75,6 +76,7 @@ _SIGS = {
     "rc_conv_packed_cout": (C.c_int, [_I, _I, _I, _I, _I]),
     "rc_conv_pack_bias": (C.c_int, [_P, _I, _I, _I, _I, _I, _P]),
     "rc_conv_sum_tiles": (C.c_int, [_I, _I]),
+    "rc_conv_sum_slots": (C.c_int, [_P]),
     "rc_conv2d": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "rc_conv_desc_size": (_SZ, []),
     "rc_tail_fold_weights": (C.c_int, [_P, _P, _P, _P, _I, _I, _P, _P]),

@@ -19,6 +19,7 @@ static int g_pss = 0;              // rc_debug_set("pss", v): 1: single-chunk pi
                                    // loader waves); 0 (default): kernel 4.  Measured on MI355X at 8 x 1088 x 1920: 3.16-3.29 vs 3.24-3.27 ms (conv_kernel.hpp, kernel 5)
 static int g_auto = 1;             // rc_debug_set("persist_auto", v): single-chunk, single-cout-tile bf16 3x3 layers (48 -> 48, 32 -> 32) on kernel 6 (wave-autonomous strips):
                                    // 0 never, 1 (default) the plain / ReLU / LeakyReLU / +sums forms (1-5 % faster than kernel 2; profiles/r05_power_wall.md), 2 also the residual forms (4-5 % slower)
+static int g_sums_compact = 1;     // rc_debug_set("sums_compact", v): 0 = the carried-sums kernels keep the per-tile slot layout (A/B and tests)
 static int g_conv32 = 0;           // rc_debug_set("conv32", v): which layers take the 32x32x16 forms (conv32_kernel.hpp).  0 (default) none: the one layer they were
                                    // faster on (48 -> 192 + residual at 544x960x8: 1.25 vs 1.31 ms) now runs on the persistent kernel with the residual prefetched
                                    // (1.13 ms); 4 = that layer family (one-chunk 48 -> 96k NHWC) only; 1 all eligible layers, multi-chunk
@@ -264,6 +265,7 @@ int rc_debug_set(const char* key, int value) {
     if (std::string(key) == "dec_lds") { g_dec_lds = value != 0; return RC_OK; }
     if (std::string(key) == "dw3_seg16") { g_dw3_seg16 = value != 0; return RC_OK; }
     if (std::string(key) == "pss") { g_pss = value != 0; return RC_OK; }
+    if (std::string(key) == "sums_compact") { g_sums_compact = value != 0; return RC_OK; }
     if (std::string(key) == "persist_auto") { g_auto = value < 0 ? 0 : (value > 2 ? 2 : value); return RC_OK; }
     if (std::string(key) == "conv32") { g_conv32 = value < 0 ? 0 : (value > 4 ? 4 : value); return RC_OK; }
     return fail(RC_ERR_INVALID, std::string("rc_debug_set: unknown key ") + key);
@@ -275,6 +277,7 @@ int rc_debug_get(const char* key) {
     if (std::string(key) == "conv32") return g_conv32;
     if (std::string(key) == "conv_flags") return g_dbg_flags;
     if (std::string(key) == "pss") return g_pss;
+    if (std::string(key) == "sums_compact") return g_sums_compact;
     if (std::string(key) == "persist_auto") return g_auto;
     return -1;
 }
@@ -329,9 +332,9 @@ int rc_prof_collect_rows(rc_prof_row* rows, int max_rows, int* n_rows) {
     return RC_OK;
 }
 
-int rc_conv2d(const rc_conv_desc* d, void* stream_) {
+// Validation + launch arguments of one rc_conv2d call; shared with rc_conv_sum_slots (which asks the launcher what it WOULD do with them).
+static int conv_build_args(const rc_conv_desc* d, ConvPlan& p, ConvArgs& a, size_t& es_out) {
     RC_REQUIRE(d != nullptr, "rc_conv2d: null desc");
-    ConvPlan p;
     RC_REQUIRE(make_plan(d->cin, d->cout, d->ksize, d->dtype, d->out_mode, &p), "rc_conv2d: unsupported cin/cout/ksize/dtype");
     RC_REQUIRE(d->batch >= 1 && d->height >= 1 && d->width >= 1, "rc_conv2d: empty tensor");
     RC_REQUIRE(d->batch <= 65535, "rc_conv2d: batch > 65535");
@@ -387,7 +390,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     if (d->residual) RC_REQUIRE(reinterpret_cast<uintptr_t>(d->residual) % 16 == 0, "rc_conv2d: residual must be 16-byte aligned");
     if (d->mul_plus1) RC_REQUIRE(reinterpret_cast<uintptr_t>(d->mul_plus1) % 16 == 0, "rc_conv2d: mul_plus1 must be 16-byte aligned");
 
-    ConvArgs a{};
+    a = ConvArgs{};
     a.batch = d->batch; a.H = d->height; a.W = d->width; a.cin = d->cin; a.cout = d->cout;
     a.n_chunks = p.n_chunks; a.n_ct = p.n_ct;
     a.tiles_x = ceil_div(d->width, kTW); a.tiles_y = ceil_div(d->height, kTH);
@@ -405,6 +408,8 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
     a.mul_plus1 = d->mul_plus1; a.residual = d->residual; a.out_scale = d->out_scale;
     a.out = d->out; a.out_mode = d->out_mode; a.out_dtype = d->out_dtype; a.out_h = d->out_h; a.out_w = d->out_w;
     a.chan_sums = d->chan_sums; a.cout_packed = p.cout_packed;
+    a.sum_slots = d->chan_sums_slots > 0 ? d->chan_sums_slots : 4 * ceil_div(d->height, kTH) * ceil_div(d->width, kTW);   // 0: the legacy count (rc_conv_sum_tiles)
+    a.sums_compact = 0; a.query = nullptr; a.sums_compact_ok = g_sums_compact;
     {   // epilogue feature mask (ConvDev::EP_*); anything outside the compiled set takes the generic epilogue
         int key = (d->act == RC_ACT_RELU ? 1 : 0) | (d->act == RC_ACT_LEAKY ? 2 : 0) | (d->film_scale ? 4 : 0) |
                   (d->mul_plus1 ? 8 : 0) | (d->residual ? 16 : 0) | (d->chan_sums ? 32 : 0) | (d->out_scale ? 64 : 0);
@@ -430,7 +435,15 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
         a.td_wsm = make_tile_decode(a.tiles_x, (a.H + kWsmTH - 1) / kWsmTH, kBandRows);
         a.div_n_ct = make_magic(a.n_ct);
     }
+    es_out = es;
+    return RC_OK;
+}
 
+int rc_conv2d(const rc_conv_desc* d, void* stream_) {
+    ConvPlan p;
+    ConvArgs a;
+    size_t es = 0;
+    if (int e = conv_build_args(d, p, a, es)) return e;
     hipStream_t stream = as_stream(stream_);
     void* tok = nullptr;
     // algorithmic FLOPs: a ksize-2 launch is a stride-2 3x3 convolution over its space-to-depth map -- 9 of its 16 (tap, phase) blocks are real
@@ -445,6 +458,19 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
                             : dispatch_conv(d->dtype == RC_BF16, d->ksize, p.ck, p.nt, a, stream);
     conv_prof_end(tok, stream);
     return rcode;
+}
+
+int rc_conv_sum_slots(const rc_conv_desc* d) {
+    ConvPlan p;
+    ConvArgs a;
+    size_t es = 0;
+    if (conv_build_args(d, p, a, es) != RC_OK) return -1;
+    const int legacy = 4 * ceil_div(d->height, kTH) * ceil_div(d->width, kTW);
+    if (p.m32) return legacy;                                  // the 32x32x16 forms write the per-tile layout
+    int q[2] = {0, legacy};
+    a.query = q;                                               // the launcher reports the branch it would take and launches nothing
+    if (dispatch_conv(d->dtype == RC_BF16, d->ksize, p.ck, p.nt, a, nullptr) != RC_OK) return -1;
+    return q[1];
 }
 
 }  // extern "C"

@@ -59,6 +59,10 @@ struct ConvArgs {
     const float* out_scale;            // (B, cout) fp32 or NULL: v *= out_scale[b][c] after act / mul_plus1, before the residual (CALayer gate applied by the producing conv)
     void* out; int out_mode; int out_dtype; int out_h, out_w;
     float* chan_sums; int cout_packed;
+    int sum_slots;                     // partial-sum slots per image in chan_sums as the caller allocated them (rc_conv_desc.chan_sums_slots; 0 there = 4 per 8x32 tile)
+    int sums_compact_ok;               // rc_debug_set("sums_compact"): 0 keeps the per-tile layout everywhere
+    int sums_compact;                  // set by the launcher: the carried-sums kernels (2 / 6 / 7) write ONE slot per (residue class of the tile walk, wave) -- see compact_slot()
+    int* query;                        // rc_conv_sum_slots(): the launcher reports {kind, slots per image} of the branch it WOULD take and launches nothing
     int num_cus; int persist_ok;
     int ep_key;                        // epilogue_fast feature mask, or -1 for the generic epilogue (ep_key_for)
     TileDecode td, td_wsm;             // division constants of the persistent kernels' tile decode (8- and 16-row tiles)
@@ -632,8 +636,26 @@ struct ConvDev {
     // per lane of wave 0 covers them (4 waves x cout floats) -- per-wave element stores cost 12 store instructions per wave and tile, more than the tile's own output.
     // Issued between the tile's two workgroup barriers, so a later flush store of any wave to the same slot is ordered behind it.
     __device__ static __forceinline__ void zero_sum_slots(const ConvArgs& a, int b, int sp, int tid) {
-        float* dst = a.chan_sums + ((size_t)b * (a.tiles_x * a.tiles_y) + sp) * 4 * a.cout;     // 4 * cout floats, 16-byte aligned (cout % 4 == 0 in FAST kernels)
+        zero_slots4(a, b, 4 * sp, tid);
+    }
+    // zeros into the 4 consecutive slots [slot0, slot0 + 4) of image b (4 * cout floats, 16-byte aligned: cout % 4 == 0 in FAST kernels), by a 256-thread block
+    __device__ static __forceinline__ void zero_slots4(const ConvArgs& a, int b, int slot0, int tid) {
+        float* dst = a.chan_sums + ((size_t)b * a.sum_slots + slot0) * a.cout;
         for (int i = tid; i < a.cout; i += kThreads) *reinterpret_cast<float4*>(dst + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // ... and into ONE slot, by one wave (kernels 6 / 7)
+    __device__ static __forceinline__ void zero_slot1(const ConvArgs& a, int b, int slot, int lane) {
+        float* dst = a.chan_sums + ((size_t)b * a.sum_slots + slot) * a.cout;
+        if (4 * lane < a.cout) *reinterpret_cast<float4*>(dst + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // COMPACT layout of the carried sums (kernels 2 / 6 / 7, a.sums_compact): a block (wave group) walks units pos, pos + stride, ...; the units of image b it
+    // visits are one residue class r = (pos - b * units_per_image) mod stride of the image's own unit index, so its run total for that image goes to slot
+    // r * waves + wave -- `stride * waves` slots per image instead of 4 per tile (2 048 instead of 32 640 at 4K), no zero stores per tile, and a function of the
+    // image's own tile indices only: frame i of a batch and frame i alone produce the same partial sums in the same slots (bitwise batch invariance).
+    // A residue class without a unit in image b (small images, kernel 6's skipped strips) gets zeros: cover_until().
+    __device__ static __forceinline__ int compact_residue(int pos, int b, int units_per_image, int stride) {
+        int r = (pos - b * units_per_image) % stride;
+        return r < 0 ? r + stride : r;
     }
 
     template <int CTRL>
@@ -649,13 +671,13 @@ struct ConvDev {
         s = dpp_add<0x140>(s);   // row_mirror
         return s;
     }
-    __device__ static __forceinline__ void write_chan_sums(const ConvArgs& a, int b, int sp, int wave, int n, int jbase,
+    __device__ static __forceinline__ void write_chan_sums(const ConvArgs& a, int b, int slot, int n, int jbase,
                                                            float (&csum)[NV], bool ragged) {
-        // every wave writes its own partial (slot = 4*tile + wave); rc_ca_gate folds them in fixed order
+        // every wave writes its own partial (legacy layout: slot = 4*tile + wave); rc_ca_gate folds them in fixed order
 #pragma unroll
         for (int e = 0; e < NV; ++e) csum[e] = row_sum16(csum[e]);
         if (n == 0) {
-            float* dst = a.chan_sums + (((size_t)b * (a.tiles_x * a.tiles_y) + sp) * 4 + wave) * a.cout;
+            float* dst = a.chan_sums + ((size_t)b * a.sum_slots + slot) * a.cout;
 #pragma unroll
             for (int e = 0; e < NV; ++e)
                 if (!ragged || jbase + e < a.cout) dst[jbase + e] = csum[e];
@@ -672,9 +694,10 @@ struct ConvDev {
     // `flush` is set (the block's next tile belongs to another image, or there is none) are they reduced over the 16-lane
     // rows and written, to the current tile's slot -- the other tiles' slots get zeros, so rc_ca_gate's fixed-order fold
     // over all slots is unchanged.  Per tile this leaves NV adds per pixel tile instead of a 4-step DPP reduction of NV values.
+    // run_slot0 >= 0 (compact layout): the run total goes to slot run_slot0 + (tid >> 6) instead of 4 * sp + (tid >> 6)
     template <int F, bool RUN>
     __device__ static __forceinline__ void epilogue_fast_impl(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
-                                                              f32x4 (&acc)[4][NT], float (&run)[NV], bool flush) {
+                                                              f32x4 (&acc)[4][NT], float (&run)[NV], bool flush, int run_slot0 = -1) {
         const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
         const int jbase = ct * Cfg::COUT_TILE + q * NV;
         const size_t img_out = (size_t)a.H * a.W * a.cout;    // output / residual / mul image (elements)
@@ -773,7 +796,7 @@ struct ConvDev {
         }
         if constexpr ((F & EP_SUMS) != 0) {
             if (!RUN || flush) {
-                write_chan_sums(a, b, sp, wave, n, jbase, csum, false);
+                write_chan_sums(a, b, (run_slot0 >= 0 ? run_slot0 : 4 * sp) + wave, n, jbase, csum, false);
                 if constexpr (RUN) {
 #pragma unroll
                     for (int e = 0; e < NV; ++e) run[e] = 0.f;
@@ -881,7 +904,7 @@ struct ConvDev {
         }
     }
     template <int F, int NRP>
-    __device__ static __forceinline__ void epilogue_sub(const ConvArgs& a, int b, int gy, int gx0, int sp, int wv, int lane, f32x4 (&acc)[2][NT],
+    __device__ static __forceinline__ void epilogue_sub(const ConvArgs& a, int b, int gy, int gx0, int slot, int lane, f32x4 (&acc)[2][NT],
                                                         float (&run)[(F & EP_SUMS) ? NV : 1], bool flush, const unsigned (&rp)[NRP][(F & EP_RES) ? NRH : 1],
                                                         const float* gate_row) {
         const int q = lane >> 4, n = lane & 15, jbase = q * NV;
@@ -934,7 +957,7 @@ struct ConvDev {
         }
         if constexpr ((F & EP_SUMS) != 0) {
             if (flush) {
-                write_chan_sums(a, b, sp, wv, n, jbase, run, false);
+                write_chan_sums(a, b, slot, n, jbase, run, false);
 #pragma unroll
                 for (int e = 0; e < NV; ++e) run[e] = 0.f;
             }
@@ -1081,7 +1104,7 @@ struct ConvDev {
                 }
             }
         }
-        if (a.chan_sums != nullptr) write_chan_sums(a, b, sp, wave, n, jbase, csum, true);
+        if (a.chan_sums != nullptr) write_chan_sums(a, b, 4 * sp + wave, n, jbase, csum, true);
     }
 };
 
@@ -1233,6 +1256,7 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
     float run[NV];                                     // CALayer channel sums carried across this block's tiles
 #pragma unroll
     for (int e = 0; e < NV; ++e) run[e] = 0.f;
+    int covered = 0;                                   // compact sums: images [0, covered) have this block's 4 slots written (a run total or zeros)
     // the 3x3 kernels with 3-4 cout tiles (256-register budget) prefetch border tiles too; elsewhere the bounds-checked addressing spills
     constexpr bool BORDER_PRE = !GATED && Cfg::KS == 3 && (NT == 3 || NT == 4) && sizeof(typename Cfg::elem) == 2;
     bool first_tile = true;                            // the first tile's border loads are never prefetched
@@ -1254,7 +1278,13 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
             // there is none) writes its slots itself in the epilogue: no zero store for it -- nothing then depends on a zero store and a flush store to the
             // same address being ordered (they were, through the fences of the two __syncthreads() between them, but only by that).
             const bool will_flush = tile < 0 || magic_div(tile, a.td.sp_total) != cb;                                             // uniform
-            if ((a.ep_key == D::EP_SUMS || a.ep_key == (D::EP_RELU | D::EP_SUMS)) && n_ct == 1 && !will_flush) D::zero_sum_slots(a, cb, csp, tid);
+            if ((a.ep_key == D::EP_SUMS || a.ep_key == (D::EP_RELU | D::EP_SUMS)) && n_ct == 1) {
+                if (!a.sums_compact) { if (!will_flush) D::zero_sum_slots(a, cb, csp, tid); }
+                else if (will_flush) {                 // compact layout: residue classes this block has no tile of, in the images it skipped, get zeros
+                    for (int bb = covered; bb < cb; ++bb) D::zero_slots4(a, bb, 4 * D::compact_residue(pos, bb, sp_total, (int)gridDim.x), tid);
+                    covered = cb + 1;
+                }
+            }
         }
 
         for (int ct = 0; ct < n_ct; ++ct) {
@@ -1293,10 +1323,11 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
             }
             D::template mma_steps<0, STEPS, 0, (!GATED && NT < 5)>(s_in, s_w, lane_x, lane_w, q, lo, acc);
             if constexpr (FAST && sizeof(typename Cfg::elem) == 2) {
+                const int rslot = a.sums_compact ? 4 * D::compact_residue(pos, cb, sp_total, (int)gridDim.x) : -1;                 // uniform
                 if (RUN_SUMS && a.ep_key == D::EP_SUMS && n_ct == 1)    // uniform
-                    D::template epilogue_fast_impl<D::EP_SUMS, RUN_SUMS>(a, cb, cy0, cx0, csp, ct, tid, acc, run, tile < 0 || b != cb);
+                    D::template epilogue_fast_impl<D::EP_SUMS, RUN_SUMS>(a, cb, cy0, cx0, csp, ct, tid, acc, run, tile < 0 || b != cb, rslot);
                 else if (RUN_SUMS && a.ep_key == (D::EP_RELU | D::EP_SUMS) && n_ct == 1)
-                    D::template epilogue_fast_impl<D::EP_RELU | D::EP_SUMS, RUN_SUMS>(a, cb, cy0, cx0, csp, ct, tid, acc, run, tile < 0 || b != cb);
+                    D::template epilogue_fast_impl<D::EP_RELU | D::EP_SUMS, RUN_SUMS>(a, cb, cy0, cx0, csp, ct, tid, acc, run, tile < 0 || b != cb, rslot);
                 else if (res_pre) {
                     if constexpr (RESPRE) {
                         D::epilogue_res_pre(a, cb, cy0, cx0, ct, tid, acc, rpre, a.ep_key == (D::EP_GATE | D::EP_RES) ? a.out_scale + (size_t)cb * a.cout : nullptr);
@@ -1304,6 +1335,11 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
                 } else D::template epilogue<FAST>(a, cb, cy0, cx0, csp, ct, tid, acc);
             } else D::template epilogue<FAST>(a, cb, cy0, cx0, csp, ct, tid, acc);
         }
+    }
+    if constexpr (FAST && sizeof(typename Cfg::elem) == 2 && NT >= 3) {
+        // compact sums: the images after this block's last one (and all of them, for a block without tiles) still need their 4 slots
+        if (a.sums_compact && (a.ep_key == D::EP_SUMS || a.ep_key == (D::EP_RELU | D::EP_SUMS)) && n_ct == 1)
+            for (int bb = covered; bb < a.batch; ++bb) D::zero_slots4(a, bb, 4 * D::compact_residue(pos, bb, sp_total, (int)gridDim.x), tid);
     }
 }
 
@@ -1977,6 +2013,7 @@ __global__ __launch_bounds__(kAutoThreads) void conv_mfma_auto_kernel(const Conv
     [[maybe_unused]] float run[MODE == 1 ? NV : 1];                  // CALayer channel sums carried across this wave's strips
 #pragma unroll
     for (int e = 0; e < (MODE == 1 ? NV : 1); ++e) run[e] = 0.f;
+    [[maybe_unused]] int covered = 0;                                // compact sums: images [0, covered) have this wave's slot written (a run total or zeros)
 
     while (cu >= 0) {
         // ---- commit: the strip's units, registers -> this wave's LDS strip (the same wave reads them back: program order, no barrier)
@@ -2007,18 +2044,26 @@ __global__ __launch_bounds__(kAutoThreads) void conv_mfma_auto_kernel(const Conv
 
         if constexpr (MODE == 1) {
             const bool flush = nu < 0 || nb != cb;                   // uniform: this wave's next strip belongs to another image (or there is none)
-            if (!flush) {                                            // a strip whose sums are carried on leaves ZEROS in its slot (rc_ca_gate's fixed-order fold reads every slot)
-                float* dst = a.chan_sums + (((size_t)cb * (a.tiles_x * a.tiles_y) + sp) * 4 + (wave & 3)) * a.cout;
-                if (4 * lane < a.cout) *reinterpret_cast<float4*>(dst + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+            int rslot = -1;
+            if (!a.sums_compact) {
+                if (!flush) D8::zero_slot1(a, cb, 4 * sp + (wave & 3), lane);   // legacy layout: a strip whose sums are carried on leaves ZEROS in its (tile, wave) slot
+            } else if (flush) {                                      // compact layout: slot (residue class of the region walk) * 8 + wave; skipped images get zeros
+                for (int bb = covered; bb < cb; ++bb) D8::zero_slot1(a, bb, 8 * D8::compact_residue(pos, bb, sp_total, stride) + wave, lane);
+                covered = cb + 1;
+                rslot = 8 * D8::compact_residue(pos, cb, sp_total, stride) + (wave & 4);        // + (ftid >> 6) = wave & 3 inside the epilogue
             }
-            if (a.ep_key == D8::EP_SUMS) D8::template epilogue_fast_impl<D8::EP_SUMS, true>(a, cb, y0, x0, sp, 0, ftid, acc, run, flush);
-            else D8::template epilogue_fast_impl<D8::EP_RELU | D8::EP_SUMS, true>(a, cb, y0, x0, sp, 0, ftid, acc, run, flush);
+            if (a.ep_key == D8::EP_SUMS) D8::template epilogue_fast_impl<D8::EP_SUMS, true>(a, cb, y0, x0, sp, 0, ftid, acc, run, flush, rslot);
+            else D8::template epilogue_fast_impl<D8::EP_RELU | D8::EP_SUMS, true>(a, cb, y0, x0, sp, 0, ftid, acc, run, flush, rslot);
         } else if constexpr (MODE == 2) {
             D8::epilogue_res_pre(a, cb, y0, x0, 0, ftid, acc, rpre, gated_out ? s_gate + cb * a.cout : nullptr);
         } else {
             D8::template epilogue<true>(a, cb, y0, x0, sp, 0, ftid, acc);
         }
         cu = nu; cb = nb; cty8 = nty8; ctx = ntx;
+    }
+    if constexpr (MODE == 1) {
+        if (a.sums_compact)                                          // the images after this wave's last one (all of them for a wave without strips)
+            for (int bb = covered; bb < a.batch; ++bb) D8::zero_slot1(a, bb, 8 * D8::compact_residue(pos, bb, sp_total, stride) + wave, lane);
     }
 }
 
@@ -2151,6 +2196,7 @@ __global__ __launch_bounds__(kAutoThreads) void conv_mfma_auto64_kernel(const Co
     float run[MODE == 1 ? NV : 1];
 #pragma unroll
     for (int e = 0; e < (MODE == 1 ? NV : 1); ++e) run[e] = 0.f;
+    [[maybe_unused]] int covered = 0;                                // compact sums: images [0, covered) have this wave's slot written
 
     while (cu_ >= 0) {
         // ---- commit: unit (pixel 8 k + lane / 8, piece lane % 8) -> slot piece ^ (column & 7) of the pixel's 128 bytes
@@ -2193,26 +2239,34 @@ __global__ __launch_bounds__(kAutoThreads) void conv_mfma_auto64_kernel(const Co
         if constexpr (MODE == 1) {
             const bool last = chalf == 1;
             const bool flush = last && (nu < 0 || nb != cb);         // uniform: the strip's sums leave with its right half, if the wave's next strip is another image's
-            if (last && !flush) {
-                float* dst = a.chan_sums + (((size_t)cb * (a.tiles_x * a.tiles_y) + sp) * 4 + wv) * a.cout;
-                if (4 * lane < a.cout) *reinterpret_cast<float4*>(dst + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+            int slot = 4 * sp + wv;                                  // legacy layout: (tile, wave); a strip whose sums are carried on leaves zeros there
+            if (!a.sums_compact) {
+                if (last && !flush) D::zero_slot1(a, cb, slot, lane);
+            } else if (flush) {                                      // compact layout: slot (residue class of this group's tile walk) * 4 + wave
+                for (int bb = covered; bb < cb; ++bb) D::zero_slot1(a, bb, 4 * D::compact_residue(pos, bb, sp_total, stride) + wv, lane);
+                covered = cb + 1;
+                slot = 4 * D::compact_residue(pos, cb, sp_total, stride) + wv;
             }
             const unsigned none[1][1] = {{0u}};
-            if (a.ep_key == EP_SUMS) D::template epilogue_sub<EP_SUMS, 1>(a, cb, gy, gx0, sp, wv, lane, acc, run, flush, none, nullptr);
-            else if (a.ep_key == (EP_RELU | EP_SUMS)) D::template epilogue_sub<EP_RELU | EP_SUMS, 1>(a, cb, gy, gx0, sp, wv, lane, acc, run, flush, none, nullptr);
-            else D::template epilogue_sub<EP_LEAKY | EP_SUMS, 1>(a, cb, gy, gx0, sp, wv, lane, acc, run, flush, none, nullptr);
+            if (a.ep_key == EP_SUMS) D::template epilogue_sub<EP_SUMS, 1>(a, cb, gy, gx0, slot, lane, acc, run, flush, none, nullptr);
+            else if (a.ep_key == (EP_RELU | EP_SUMS)) D::template epilogue_sub<EP_RELU | EP_SUMS, 1>(a, cb, gy, gx0, slot, lane, acc, run, flush, none, nullptr);
+            else D::template epilogue_sub<EP_LEAKY | EP_SUMS, 1>(a, cb, gy, gx0, slot, lane, acc, run, flush, none, nullptr);
         } else if constexpr (MODE == 2) {
             float none[1] = {0.f};
-            if (gated_out) D::template epilogue_sub<EP_GATE | EP_RES, 2>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, rpre, s_gate + cb * a.cout);
-            else D::template epilogue_sub<EP_RES, 2>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, rpre, nullptr);
+            if (gated_out) D::template epilogue_sub<EP_GATE | EP_RES, 2>(a, cb, gy, gx0, 0, lane, acc, none, false, rpre, s_gate + cb * a.cout);
+            else D::template epilogue_sub<EP_RES, 2>(a, cb, gy, gx0, 0, lane, acc, none, false, rpre, nullptr);
         } else {
             float none[1] = {0.f};
             const unsigned nonr[1][1] = {{0u}};
-            if (a.ep_key == EP_RELU) D::template epilogue_sub<EP_RELU, 1>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, nonr, nullptr);
-            else if (a.ep_key == EP_LEAKY) D::template epilogue_sub<EP_LEAKY, 1>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, nonr, nullptr);
-            else D::template epilogue_sub<0, 1>(a, cb, gy, gx0, sp, wv, lane, acc, none, false, nonr, nullptr);
+            if (a.ep_key == EP_RELU) D::template epilogue_sub<EP_RELU, 1>(a, cb, gy, gx0, 0, lane, acc, none, false, nonr, nullptr);
+            else if (a.ep_key == EP_LEAKY) D::template epilogue_sub<EP_LEAKY, 1>(a, cb, gy, gx0, 0, lane, acc, none, false, nonr, nullptr);
+            else D::template epilogue_sub<0, 1>(a, cb, gy, gx0, 0, lane, acc, none, false, nonr, nullptr);
         }
         cu_ = nu; cb = nb; cty8 = nty8; ctx = ntx; chalf = nhalf;
+    }
+    if constexpr (MODE == 1) {
+        if (a.sums_compact)
+            for (int bb = covered; bb < a.batch; ++bb) D::zero_slot1(a, bb, 4 * D::compact_residue(pos, bb, sp_total, stride) + wv, lane);
     }
 }
 
@@ -2228,12 +2282,29 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
     constexpr int P_LDS = persist_lds_bytes<Cfg>();
     constexpr bool P_OK = P_LDS <= 80 * 1024;          // two persistent blocks per CU
     const int n_tiles = a.tiles_x * a.tiles_y * a.batch;
+    // Channel-sum slots.  Every kernel writes the LEGACY layout (one slot per (8 x 32 tile, wave): 4 x tiles per image); the carried-sums kernels (2, 6, 7) also have the
+    // COMPACT one (compact_residue(): grid-many residue classes x waves).  rc_conv_sum_slots() asks THIS function (a.query) which branch a launch will take and how many
+    // slots it fills, so the host's allocation cannot drift from the dispatch; a launch whose chan_sums_slots is neither count is an error, never a guess.
+    const int legacy_slots = 4 * a.tiles_x * a.tiles_y;
+    auto report = [&](int kind, int slots) -> bool {         // query mode: {kind (0 legacy-only kernel, 2 / 6 / 7), slots per image}; nothing is launched
+        if (a.query == nullptr) return false;
+        a.query[0] = kind; a.query[1] = slots;
+        return true;
+    };
+    auto sums_mode = [&](int compact_slots, int& compact) -> int {    // which layout did the caller allocate?
+        compact = 0;
+        if (a.chan_sums == nullptr || a.sum_slots == legacy_slots) return RC_OK;
+        if (compact_slots > 0 && a.sum_slots == compact_slots) { compact = 1; return RC_OK; }
+        return fail(RC_ERR_INVALID, "rc_conv2d: chan_sums_slots matches neither layout of the kernel this launch takes (ask rc_conv_sum_slots)");
+    };
     constexpr int WS_LDS = ws_lds_bytes<Cfg>();
     if constexpr (WS_LDS <= 150 * 1024) {              // one 8-wave producer/consumer block per CU
         // persist_ok: 1 = automatic (producer/consumer form for the register-starved variants: gated input or 80-wide
         // cout tiles, whose prefetch registers would otherwise spill), 2 = wherever eligible, 3 = never
         const bool ws_auto = GATED || Cfg::NT == 5 || Cfg::CK == 80;
         if (a.n_chunks == 1 && a.n_ct == 1 && a.cin_vec_ok && (a.persist_ok == 2 || (a.persist_ok == 1 && ws_auto)) && n_tiles < (1 << 24)) {
+            if (report(0, legacy_slots)) return RC_OK;
+            { int c_; if (int e_ = sums_mode(0, c_)) return e_; }
             static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
             if (!attr_set.test_and_set()) {
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_ws_kernel<Cfg, GATED, FAST>),
@@ -2251,6 +2322,7 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
                   (kWsmTH * kTW * Cfg::COUT_TILE * 2) % (16 * kThreads * 2) == 0) {
         // single-chunk pixel-shuffle layers: output staged through LDS, stored by the loader waves (kernel 5)
         if (a.pss && a.n_chunks == 1 && a.n_ct == 4 && a.cin_vec_ok && a.cin_chunk_ok && a.persist_ok && n_tiles < (1 << 24)) {
+            if (report(0, legacy_slots)) return RC_OK;
             constexpr int PSS_LDS = pss_lds_bytes<Cfg>();
             const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch;
             static PerDeviceFlag attr_set;
@@ -2279,6 +2351,8 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
         const bool res_pre_form = FAST && !GATED && sizeof(typename Cfg::elem) == 2 && Cfg::NT <= 3 && a.ep_key == ConvDev<Cfg>::EP_RES && a.out_mode == RC_OUT_NHWC;
         if ((a.n_chunks > 1 || (a.n_ct > 1 && a.persist_ok != 3 && !(P_OK && res_pre_form))) && a.cin_vec_ok && a.cin_chunk_ok && a.persist_ok && a.cout_packed <= kPersistMaxCout &&
             n_tiles < (1 << 24)) {
+            if (report(0, legacy_slots)) return RC_OK;
+            { int c_; if (int e_ = sums_mode(0, c_)) return e_; }
             const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch * (a.n_chunks > 1 ? a.n_ct : 1);
             static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
             if (!attr_set.test_and_set()) {
@@ -2302,18 +2376,22 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
         if (a.auto_impl && key_ok && a.n_chunks == 1 && a.n_ct == 1 && a.cout == Cfg::COUT_TILE && a.cin_vec_ok && a.persist_ok && a.out_mode == RC_OUT_NHWC && n_tiles < (1 << 24)) {
             constexpr int A_LDS = auto64_lds_bytes<Cfg>();
             static_assert(A_LDS <= 160 * 1024, "kernel 7 LDS");
+            int grid = a.num_cus;
+            if (grid * 2 > n_tiles) grid = (n_tiles + 1) / 2;      // two groups of four waves per block, one 8 x 32 tile each
+            grid = (grid + 7) / 8 * 8;
+            const int cslots = ((k7 & DD::EP_SUMS) && a.sums_compact_ok && grid * 8 < legacy_slots) ? grid * 8 : 0;   // compact sums: (grid x 2 groups) residue classes x 4 waves (small images: the per-tile layout is smaller)
+            if (report(7, cslots ? cslots : legacy_slots)) return RC_OK;
+            ConvArgs aa = a;
+            if (int e_ = sums_mode(cslots, aa.sums_compact)) return e_;
             static PerDeviceFlag attr_set;
             if (!attr_set.test_and_set()) {
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_auto64_kernel<Cfg, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_auto64_kernel<Cfg, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_auto64_kernel<Cfg, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
             }
-            int grid = a.num_cus;
-            if (grid * 2 > n_tiles) grid = (n_tiles + 1) / 2;      // two groups of four waves per block, one 8 x 32 tile each
-            grid = (grid + 7) / 8 * 8;
-            if (k7 & DD::EP_SUMS) hipLaunchKernelGGL((conv_mfma_auto64_kernel<Cfg, 1>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, a);
-            else if (k7 & DD::EP_RES) hipLaunchKernelGGL((conv_mfma_auto64_kernel<Cfg, 2>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, a);
-            else hipLaunchKernelGGL((conv_mfma_auto64_kernel<Cfg, 0>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, a);
+            if (k7 & DD::EP_SUMS) hipLaunchKernelGGL((conv_mfma_auto64_kernel<Cfg, 1>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, aa);
+            else if (k7 & DD::EP_RES) hipLaunchKernelGGL((conv_mfma_auto64_kernel<Cfg, 2>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, aa);
+            else hipLaunchKernelGGL((conv_mfma_auto64_kernel<Cfg, 0>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, aa);
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }
@@ -2327,42 +2405,56 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
         if (a.auto_impl && key_ok && mode_ok && a.n_chunks == 1 && a.n_ct == 1 && a.cin_vec_ok && a.persist_ok && a.out_mode == RC_OUT_NHWC && n_tiles < (1 << 24)) {
             constexpr int A_LDS = auto_lds_bytes<Cfg>();
             const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch;
+            int grid = a.num_cus;
+            if (grid > n_items) grid = n_items;
+            grid = (grid + 7) / 8 * 8;
+            const bool run_sums = a.ep_key == DD::EP_SUMS || a.ep_key == (DD::EP_RELU | DD::EP_SUMS);
+            const int cslots = (run_sums && a.sums_compact_ok && grid * 8 < legacy_slots) ? grid * 8 : 0;             // compact sums: grid residue classes of the region walk x 8 waves
+            if (report(6, cslots ? cslots : legacy_slots)) return RC_OK;
+            ConvArgs aa = a;
+            if (int e_ = sums_mode(cslots, aa.sums_compact)) return e_;
             static PerDeviceFlag attr_set;
             if (!attr_set.test_and_set()) {
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_auto_kernel<Cfg, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_auto_kernel<Cfg, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_auto_kernel<Cfg, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
             }
-            int grid = a.num_cus;
-            if (grid > n_items) grid = n_items;
-            grid = (grid + 7) / 8 * 8;
-            if (a.ep_key == DD::EP_SUMS || a.ep_key == (DD::EP_RELU | DD::EP_SUMS))
-                hipLaunchKernelGGL((conv_mfma_auto_kernel<Cfg, 1>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, a);
+            if (run_sums)
+                hipLaunchKernelGGL((conv_mfma_auto_kernel<Cfg, 1>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, aa);
             else if (a.ep_key == DD::EP_RES || a.ep_key == (DD::EP_GATE | DD::EP_RES))
-                hipLaunchKernelGGL((conv_mfma_auto_kernel<Cfg, 2>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, a);
+                hipLaunchKernelGGL((conv_mfma_auto_kernel<Cfg, 2>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, aa);
             else
-                hipLaunchKernelGGL((conv_mfma_auto_kernel<Cfg, 0>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, a);
+                hipLaunchKernelGGL((conv_mfma_auto_kernel<Cfg, 0>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, aa);
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }
     }
     if constexpr (P_OK && !GATED) {
         if (a.n_chunks == 1 && a.cout_packed <= persist_bias_slots<Cfg>() && a.persist_ok && n_tiles < (1 << 24)) {
-            static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
-            if (!attr_set.test_and_set()) {
-                RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_persist_kernel<Cfg, GATED, FAST>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS > 100 * 1024 ? P_LDS : 100 * 1024));
-            }
             int grid = persist_blocks_per_cu<Cfg>() * a.num_cus;
             const bool one_per_cu = (a.dbg_flags & 64) != 0 && P_LDS <= 80 * 1024;      // occupancy experiment: LDS padded so that ONE block fits a CU
             if (one_per_cu) grid = a.num_cus;
             if (grid > n_tiles) grid = n_tiles;
             grid = (grid + 7) / 8 * 8;
-            hipLaunchKernelGGL((conv_mfma_persist_kernel<Cfg, GATED, FAST>), dim3((unsigned)grid), dim3(kThreads), one_per_cu ? 100 * 1024 : P_LDS, stream, a);
+            // the carried-sums (RUN) form of this kernel: fast epilogue, bf16, >= 3 cout tiles per block, one cout tile per layer
+            const bool run_sums = FAST && sizeof(typename Cfg::elem) == 2 && Cfg::NT >= 3 && a.n_ct == 1 &&
+                                  (a.ep_key == ConvDev<Cfg>::EP_SUMS || a.ep_key == (ConvDev<Cfg>::EP_RELU | ConvDev<Cfg>::EP_SUMS));
+            const int cslots = (run_sums && a.sums_compact_ok && grid * 4 < legacy_slots) ? grid * 4 : 0;             // compact sums: grid residue classes of the tile walk x 4 waves
+            if (report(2, cslots ? cslots : legacy_slots)) return RC_OK;
+            ConvArgs aa = a;
+            if (int e_ = sums_mode(cslots, aa.sums_compact)) return e_;
+            static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
+            if (!attr_set.test_and_set()) {
+                RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_persist_kernel<Cfg, GATED, FAST>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS > 100 * 1024 ? P_LDS : 100 * 1024));
+            }
+            hipLaunchKernelGGL((conv_mfma_persist_kernel<Cfg, GATED, FAST>), dim3((unsigned)grid), dim3(kThreads), one_per_cu ? 100 * 1024 : P_LDS, stream, aa);
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }
     }
+    if (report(0, legacy_slots)) return RC_OK;
+    { int c_; if (int e_ = sums_mode(0, c_)) return e_; }
     static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
     if (!attr_set.test_and_set()) {
         RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<Cfg, GATED, FAST>),

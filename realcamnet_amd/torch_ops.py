@@ -164,7 +164,28 @@ def _conv_alloc(x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, 
     else:
         out = x.new_empty((b, cout, crop_h if crop_h > 0 else H, crop_w if crop_w > 0 else W), dtype=out_dtype or x.dtype)
     stored = torch.empty_like(x) if (store_input and gate is not None) else _none(x)
-    sums = x.new_empty((b, lib().rc_conv_sum_tiles(H, W), cout), dtype=torch.float32) if want_sums else x.new_empty((0,), dtype=torch.float32)
+    sums = x.new_empty((0,), dtype=torch.float32)
+    if want_sums:
+        # how many partial-sum slots per image will THIS launch fill?  Asked of the launcher itself (rc_conv_sum_slots: the kernels that carry their sums
+        # across tiles write grid x waves slots, the others 4 per 8 x 32 tile); only the NULL-ness of the pointers matters for the question.
+        d = ConvDesc()
+        d.batch, d.height, d.width, d.cin, d.cout, d.ksize, d.dtype = b, H, W, x.shape[-1], cout, ksize, _DT[x.dtype]
+        dummy = 4096                                                   # non-NULL, 16-byte aligned
+        d.in0 = d.wpacked = d.out = d.chan_sums = dummy
+        if gate is not None:
+            d.in1 = d.in_gate = dummy
+            if store_input:
+                d.in_store = dummy
+        for name, t in (("bias", bias), ("film_scale", film_scale), ("film_shift", film_shift), ("mul_plus1", mul_plus1), ("residual", residual), ("out_scale", out_scale)):
+            if t is not None:
+                setattr(d, name, dummy)
+        d.act, d.act_slope, d.out_mode, d.out_dtype = act, float(slope), out_mode, _DT[out.dtype]
+        if out_mode in (RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW):
+            d.out_h, d.out_w = out.shape[2], out.shape[3]
+        n = lib().rc_conv_sum_slots(C.byref(d))
+        if n <= 0:                                                     # an invalid description: the launch reports it (with its own message); allocate the per-tile count
+            n = lib().rc_conv_sum_tiles(H, W)
+        sums = x.new_empty((b, n, cout), dtype=torch.float32)
     return out, stored, sums
 
 
@@ -189,6 +210,7 @@ def _conv_launch(outs, x, wpacked, bias, cout, ksize, act, slope, residual, mul_
         d.out_h, d.out_w = out.shape[2], out.shape[3]
     if want_sums:
         d.chan_sums = sums.data_ptr()
+        d.chan_sums_slots = sums.shape[1]
     check(lib().rc_conv2d(C.byref(d), _stream()), "rc_conv2d")
 
 

@@ -290,3 +290,34 @@ def test_bench_path_kernels_do_not_spill_and_the_count_cannot_grow():
     bad = sorted(k for p in bench_path for k in hits[p] if k in spilled)
     assert not bad, [(k, spilled[k]) for k in bad]
     assert len(spilled) <= 30, sorted((v["tu"], v["vgpr_spill"], k[:90]) for k, v in spilled.items())
+
+
+def test_sum_slot_query_follows_the_dispatch():
+    """rc_conv_sum_slots asks the launcher itself which kernel a launch will take (nothing is launched: works without a GPU): the carried-sums kernels report
+    grid x waves slots per image, everything else -- and every kernel when the per-tile layout is smaller -- rc_conv_sum_tiles()."""
+    lib = _lib.load()
+
+    def q(cin, cout, H, W, B=8, act=1, dtype=RC_BF16, residual=False):
+        d = _lib.ConvDesc()
+        d.batch, d.height, d.width, d.cin, d.cout, d.ksize, d.dtype = B, H, W, cin, cout, 3, dtype
+        d.in0 = d.wpacked = d.out = d.chan_sums = 4096
+        if residual:
+            d.residual = 4096
+        d.act, d.out_dtype = act, dtype
+        return lib.rc_conv_sum_slots(C.byref(d))
+    legacy = lib.rc_conv_sum_tiles(1088, 1920)
+    try:
+        assert q(48, 48, 1088, 1920) == 2048 and q(64, 64, 1088, 1920) == 2048 and legacy == 32640      # kernels 6 / 7 at 256 CUs: 256 x 8
+        assert q(48, 48, 16, 40, B=2) == lib.rc_conv_sum_tiles(16, 40)                                  # small image: the per-tile layout is the smaller one
+        assert q(128, 128, 272, 480) == lib.rc_conv_sum_tiles(272, 480)                                  # multi-chunk kernel: per tile
+        assert q(32, 32, 64, 64, dtype=RC_F32) == lib.rc_conv_sum_tiles(64, 64)                          # fp32: per tile
+        assert lib.rc_debug_set(b"persist_auto", 0) == 0
+        assert q(48, 48, 1088, 1920) == 2048 and q(64, 64, 1088, 1920) == legacy                        # kernel 2: 512 blocks x 4 waves; 64 channels: general kernel
+        assert lib.rc_debug_set(b"persist", 0) == 0
+        assert q(48, 48, 1088, 1920) == legacy                                                           # general kernel only
+        assert lib.rc_debug_set(b"persist", 1) == 0 and lib.rc_debug_set(b"sums_compact", 0) == 0
+        assert q(48, 48, 1088, 1920) == legacy
+    finally:
+        lib.rc_debug_set(b"persist", 1); lib.rc_debug_set(b"persist_auto", 1); lib.rc_debug_set(b"sums_compact", 1)
+    d = _lib.ConvDesc()
+    assert lib.rc_conv_sum_slots(C.byref(d)) == -1 and lib.rc_conv_sum_slots(None) == -1

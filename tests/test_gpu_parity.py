@@ -171,6 +171,40 @@ def test_gate_ahead_equals_gate_of_the_conv_output(hip, dt, c, H, W):
     assert ref.std().item() > 1e-3
 
 
+@pytest.mark.parametrize("c,B,H,W,auto", [(48, 2, 632, 256, 1), (48, 2, 632, 256, 0), (48, 3, 256, 1024, 1), (64, 2, 632, 256, 1), (32, 2, 256, 1024, 1)])
+def test_compact_channel_sum_slots_equal_the_per_tile_layout(hip, c, B, H, W, auto):
+    """The carried-sums kernels (2, 6, 7) write ONE partial-sum slot per (residue class of their tile walk, wave) instead of 4 per 8 x 32 tile
+    (rc_conv_sum_slots; 2 048 instead of 32 640 per image at 4K, no zero stores per tile).  On integer data every partial sum is exact, so the totals of the
+    two layouts are EQUAL; 632 rows = 79 tile rows: kernel 6's waves 4-7 have no strip in the last 16-row band, so some of their residue classes are empty in
+    an image and must be zero-filled.  The gate computed from either layout is the same, and frame 1 of a batch gives the slots of frame 1 alone, bitwise."""
+    lib = hip
+    g = torch.Generator().manual_seed(c + H)
+    conv = N.Conv2d(c, c, 3, 1, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randint(-2, 3, conv.weight.shape, generator=g).float() / 2)
+        conv.bias.copy_(torch.randint(-2, 3, conv.bias.shape, generator=g).float())
+    x = (torch.randint(-2, 3, (B, H, W, c), generator=g).float() / 2).to(DEV, torch.bfloat16)
+    conv = conv.to(DEV, torch.bfloat16).eval()
+    res = {}
+    try:
+        assert lib.rc_debug_set(b"persist_auto", auto) == 0
+        for compact in (1, 0):
+            assert lib.rc_debug_set(b"sums_compact", compact) == 0
+            with torch.no_grad():
+                y, sums = ops.conv2d(x, conv, act="relu", want_sums=True)
+                y1, sums1 = ops.conv2d(x[1:2].contiguous(), conv, act="relu", want_sums=True)
+            torch.cuda.synchronize()
+            res[compact] = (y, sums, sums1)
+    finally:
+        lib.rc_debug_set(b"sums_compact", 1); lib.rc_debug_set(b"persist_auto", 1)
+    legacy_n = lib.rc_conv_sum_tiles(H, W)
+    assert res[0][1].shape[1] == legacy_n and res[1][1].shape[1] < legacy_n            # the compact layout really is in use, and smaller
+    assert torch.equal(res[0][0], res[1][0])
+    ref = res[1][0].float().sum(dim=(1, 2))
+    assert torch.equal(res[1][1].sum(1), ref) and torch.equal(res[0][1].sum(1), ref)      # integers: exact, whatever the split
+    assert torch.equal(res[1][2][0], res[1][1][1])                                        # frame 1 alone == frame 1 of the batch, slot for slot
+
+
 @pytest.mark.parametrize("persist", [1, 2, 3, 0])
 @pytest.mark.parametrize("dt,cin,H,W", [(torch.bfloat16, 48, 16, 40), (torch.bfloat16, 48, 9, 33), (torch.bfloat16, 128, 21, 70), (torch.float32, 32, 9, 33),
                                         (torch.bfloat16, 32, 21, 70), (torch.bfloat16, 64, 9, 33)])
