@@ -171,6 +171,39 @@ def test_gate_ahead_equals_gate_of_the_conv_output(hip, dt, c, H, W):
     assert ref.std().item() > 1e-3
 
 
+@pytest.mark.parametrize("c", [32, 48, 64])
+def test_wave_autonomous_kernels_equal_the_kernels_they_replace(hip, c):
+    """Kernels 6 (32 / 48 channels) and 7 (64 channels) -- barrier-free waves with private halo strips, DESIGN 4.11 -- against the kernels they replace
+    (`persist_auto` 0: kernel 2 / the general kernel): same unit map, same MFMA chain per pixel, so every operand form must match BIT FOR BIT on real-valued
+    data, on ragged, multi-image and single-tile shapes (border strips take the bounds-checked load path; 130 x 260 has interior strips too).  The channel
+    partial sums are split differently between the kernels (which tiles a wave carries): their totals agree to fp32 summation order."""
+    lib = hip
+    g = torch.Generator().manual_seed(7 * c)
+    conv = N.Conv2d(c, c, 3, 1, 1).to(DEV, torch.bfloat16).eval()
+    try:
+        for (B, H, W) in ((1, 8, 32), (2, 23, 70), (3, 40, 97), (9, 17, 33), (1, 130, 260)):
+            x = torch.randn(B, H, W, c, generator=g).to(DEV, torch.bfloat16)
+            res = torch.randn(B, H, W, c, generator=g).to(DEV, torch.bfloat16)
+            gate = torch.rand(B, c, generator=g).to(DEV)
+            forms = {"plain": dict(), "relu": dict(act="relu"), "leaky": dict(act="leaky", slope=0.2), "sums": dict(want_sums=True),
+                     "relu+sums": dict(act="relu", want_sums=True), "res": dict(residual=res), "gate+res": dict(residual=res, out_scale=gate)}
+            if c == 64:
+                forms["leaky+sums"] = dict(act="leaky", slope=0.01, want_sums=True)
+            for name, kw in forms.items():
+                outs = []
+                for auto in (0, 2):
+                    assert lib.rc_debug_set(b"persist_auto", auto) == 0
+                    with torch.no_grad():
+                        o = ops.conv2d(x, conv, **kw)
+                    outs.append(o if isinstance(o, tuple) else (o,))
+                torch.cuda.synchronize()
+                assert torch.equal(outs[0][0], outs[1][0]), (c, B, H, W, name)
+                if "sums" in name:
+                    assert torch.allclose(outs[0][1].sum(1), outs[1][1].sum(1), rtol=1e-5, atol=1e-3), (c, B, H, W, name)
+    finally:
+        lib.rc_debug_set(b"persist_auto", 1)
+
+
 @pytest.mark.parametrize("c,B,H,W,auto", [(48, 2, 632, 256, 1), (48, 2, 632, 256, 0), (48, 3, 256, 1024, 1), (64, 2, 632, 256, 1), (32, 2, 256, 1024, 1)])
 def test_compact_channel_sum_slots_equal_the_per_tile_layout(hip, c, B, H, W, auto):
     """The carried-sums kernels (2, 6, 7) write ONE partial-sum slot per (residue class of their tile walk, wave) instead of 4 per 8 x 32 tile
