@@ -855,7 +855,15 @@ def test_bench_prints_one_contract_json_line(hip):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "MP/s" and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and "workload" in d["config"] and d["value"] > 0
-    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    rf = d["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rf)
+    # what bounds what: the layer shape with the most time, with both of its fractions, and SURVEY 8(d)'s algorithmic FLOPs beside the executed ones
+    assert set(("dominant_kernel", "dominant_ms_per_step", "dominant_tflops", "dominant_mfma_frac", "dominant_hbm_TBps", "dominant_hbm_frac_of_8TBps",
+                "dominant_bound", "by_shape_top4", "flops_algorithmic", "frac_algorithmic_whole_step")) <= set(rf)
+    assert rf["dominant_bound"] in ("hbm", "mfma") and 0 < rf["dominant_mfma_frac"] < 1 and 0 < rf["dominant_hbm_frac_of_8TBps"] < 1
+    hp, wp = -(-64 // 16) * 16, -(-96 // 16) * 16                       # the 128 x 192 mosaic's packed RAW padded to multiples of 16
+    assert rf["flops_algorithmic"] == 622084.0 * (2 * hp) * (2 * wp) and rf["flops_per_step"] < rf["flops_algorithmic"]      # the folded tail executes fewer
+    assert all(not isinstance(v, (list, dict)) for k, v in rf.items() if k.startswith("dominant") or k in ("by_shape_top4", "flops_algorithmic"))   # flat: the driver's parser keeps them
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert d["psnr_db_vs_cpu_fp32"] >= 55.0
 
