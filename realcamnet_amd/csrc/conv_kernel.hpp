@@ -1537,7 +1537,12 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
         // gated inputs: two tile operands already fill the loader's 168 VGPRs, so the weight halves go by LDS-DMA instead
         // of through registers -- issued at the start of the half in which their LDS region is free, landed by the barrier
         // that ends it (the barrier's vmcnt(0) also waits for this half's tile loads; they had the same half to arrive)
-        constexpr bool WDMA = GATED || (Cfg::CK == 48 && Cfg::NT == 3);   // one-chunk 48 -> 48k: the 60-register halo tile + 48 weight registers spilled 8-10 of the 168
+        // The packed weights go global -> LDS by LDS-DMA in EVERY form (round 5; rounds 2-4: through registers except in the gated form): a half's DMA is issued at the start of
+        // the half-stage in which its LDS region is free and landed by the barrier that ends it.  Rounds 2-4 avoided that because the barrier's vmcnt(0) then also waits
+        // for the tile loads of the same half -- a cycle cost -- but these kernels run at the board's power cap with cycles to spare, and not moving 36 KB per
+        // stage through VGPRs and ds_write_b128 saves joules: the multi-chunk layers of cfg3 18.04 -> 17.83 ms (tools/wsm_probe.py, two runs each), and the loaders'
+        // 48 weight registers (8-10 spilled in the one-chunk 48-channel form) are gone.
+        constexpr bool WDMA = true;
         uint4 r0[D::NI], r1[GATED ? D::NI : 1], wra[WDMA ? 1 : NWA], wrb[WDMA ? 1 : NWB];
         float gv[GATED ? D::UNIT : 1];
         typename D::TileSrc ts;

@@ -267,7 +267,7 @@ def test_bench_path_kernels_do_not_spill_and_the_count_cannot_grow():
     """hipcc's per-kernel resource remarks of the built library (realcamnet_amd/_build/resources.json, written by build()): a kernel whose accumulators or
     staging registers land in scratch passes every parity test and silently runs 20-50 % slower (round 1: the fp32 fast-epilogue switch; round 3: the first
     GDN chain), and the count of such instantiations drifted 62 -> 71 -> 82 over rounds 2-4.  Round 5: the gated forms of kernels 2 / 4 and two unused
-    instantiations are gone (81 -> 30); every kernel the cfg3 / cfg5 bench paths launch must be spill-free, and the total may only go down."""
+    instantiations are gone (81 -> 25); every kernel the cfg3 / cfg5 bench paths launch must be spill-free, and the total may only go down."""
     from realcamnet_amd import build
     res = build.kernel_resources()
     assert len(res) > 500
@@ -289,7 +289,7 @@ def test_bench_path_kernels_do_not_spill_and_the_count_cannot_grow():
     assert all(hits[p] for p in bench_path), [p for p in bench_path if not hits[p]]            # the patterns still name real kernels
     bad = sorted(k for p in bench_path for k in hits[p] if k in spilled)
     assert not bad, [(k, spilled[k]) for k in bad]
-    assert len(spilled) <= 30, sorted((v["tu"], v["vgpr_spill"], k[:90]) for k, v in spilled.items())
+    assert len(spilled) <= 25, sorted((v["tu"], v["vgpr_spill"], k[:90]) for k, v in spilled.items())
 
 
 def test_sum_slot_query_follows_the_dispatch():
