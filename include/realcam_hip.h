@@ -138,7 +138,9 @@ typedef struct rc_conv_desc {
     /* ksize 2 only, 0 = unused: in0 is the stride-2 convolution's OWN input (B, src_h, src_w, cin / 4) and the kernel gathers the
      * space-to-depth channels while staging (channel p*(cin/4) + k of map pixel (y, x) = channel k of source pixel (2y + (p >> 1),
      * 2x + (p & 1)), zero beyond the source edge -- rc_space_to_depth2's order), so no space-to-depth pass is launched.  Needs
-     * height = ceil(src_h / 2), width = ceil(src_w / 2), cin / 4 a multiple of 64, no gated input.                                     */
+     * height = ceil(src_h / 2), width = ceil(src_w / 2), cin / 4 a multiple of 64, no gated input.
+     * With src_h set the layer IS a stride-2 3x3 convolution: the 7 of 16 (tap, phase) weight blocks such a convolution never touches (tap row -1 with
+     * phase row 0, tap column -1 with phase column 0) are taken as zero and their multiplications are not issued, whatever the weight tensor holds there. */
     int32_t src_h, src_w;
     /* optional (B, cout) fp32: v = v * out_scale[b][c], applied after act / mul_plus1 and BEFORE the residual add -- the CALayer gate of this
      * conv's own output when it is known ahead of the launch (rc_ca_gate_ahead): RCABlock's x + CA(conv(...)) (networks.py:311, 270) leaves
@@ -550,6 +552,9 @@ int rc_debug_hbm_probe(const void* src, void* dst, size_t bytes, int mode, int n
 int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma);
 /* The same calibration on v_mfma_f32_32x32x16_bf16 (8 independent accumulators per wave). */
 int rc_debug_mfma_peak32(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma);
+/* Test aid: fill the whole LDS allocation of every CU with `pattern` (e.g. 0x7FC07FC0: bf16 / fp32 NaNs) on `stream`, so that a kernel reading LDS it has not
+ * written, or before the write has landed, fails the parity tests whatever ran before it (LDS contents survive from one kernel to the next). */
+int rc_debug_poison_lds(unsigned pattern, void* stream);
 int rc_prof_enable(int on);
 int rc_prof_collect(int64_t* n_launches, double* total_ms, double* total_flops);
 /* The same records grouped by layer shape (cin, cout, ksize): launches, summed HIP-event ms, algorithmic FLOPs and algorithmic BYTES (every map

@@ -86,6 +86,7 @@ _SIGS = {
     "rc_debug_hbm_probe": (C.c_int, [_P, _P, C.c_size_t, _I, _I, _I, _I, _I, C.POINTER(C.c_double)]),
     "rc_debug_mfma_peak": (C.c_int, [_I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rc_debug_mfma_peak32": (C.c_int, [_I, _I, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "rc_debug_poison_lds": (C.c_int, [C.c_uint, _P]),
     "rc_pointwise_chain48": (C.c_int, [_P, _I, _P, _P, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _F, _P, _I, C.c_longlong, _P]),
     "rc_lsc_packed_bytes": (C.c_size_t, [_I, _I, _I]),
     "rc_lsc_pack": (C.c_int, [_P, _P, _I, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _I, _P, _P, _I, _I, _P]),

@@ -69,6 +69,7 @@ struct ConvArgs {
     MagicDiv div_n_ct;
     int pss;                           // single-chunk pixel-shuffle layer: kernel 5 (output staged through LDS)
     int auto_impl;                     // single-chunk, single-cout-tile bf16 3x3 layers: kernel 6 (wave-autonomous strips)
+    int thin;                          // kernel 4b (one barrier per stage) where kernel 4 would run a layer with thin stages
     int fold2, src_H, src_W, cfold;    // ksize 2 over the UN-shuffled input: in0 is (B, src_H, src_W, cfold = cin / 4), see ConvDev::fold_*
     long long* dbg;                    // optional phase-timing buffer (rc_debug_set_ptr), normally NULL
     int dbg_flags;                     // knock-out experiments (rc_debug_set "conv_flags"): 1 no stores, 2 no MFMA, 4 no tile loads
@@ -1494,6 +1495,7 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
     constexpr int WA = SA * NT * 1024, WB = (STEPS - SA) * NT * 1024, WALL = (int)Cfg::CHUNK_W_BYTES;
     constexpr int NWA = (WA / 16 + kThreads - 1) / kThreads, NWB = (WB / 16 + kThreads - 1) / kThreads;
     static_assert(STEPS >= 2 && WA + WB == WALL, "weight halves");
+    constexpr bool FOLD_SKIP = Cfg::KS == 2 && Cfg::UPT == 4 && STEPS == 4 && sizeof(typename Cfg::elem) == 2;   // a tap = one MFMA step (CK = 32, the form cfold % 64 == 0 layers take)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_w = smem;                                                // weights first: ds_read immediates < 64 KiB
@@ -1600,6 +1602,8 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
                     if (woa[k] != kOOB) *reinterpret_cast<uint4*>(s_w + woa[k]) = wra[k];
             }
         };
+        // folded stride-2 layers: the chunks of phases 0 and 1 (source row 2y) have no weights in half a = the taps of map row y - 1 (see the compute waves)
+        auto need_wa = [&]() { if constexpr (FOLD_SKIP) return !(D::folded(a) && D::fold_phase(a, c_chunk * Cfg::CK) < 2); else return true; };
         auto commit_b = [&]() {
             if constexpr (!WDMA) {
 #pragma unroll
@@ -1610,7 +1614,7 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
 
         if (my_stages > 0) {
             issue_a(); commit_a(); issue_b();
-            if constexpr (WDMA) dma(0, WA, wsoff);                   // Wa(0)
+            if (need_wa()) dma(0, WA, wsoff);                        // Wa(0)
         }
         __syncthreads();                                             // barrier 0: bias, Wa(0), tile(0) visible
         for (int g = 0; g < my_stages; ++g) {
@@ -1624,7 +1628,7 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
             if (g + 1 < my_stages) issue_a();                        //         ... and fetch Wa(g+1) (+ tile)
             __syncthreads();
             if (g + 1 < my_stages) {                                 // half b: write Wa(g+1) (+ tile); fetch Wb(g+1)
-                if constexpr (WDMA) dma(0, WA, wsoff);
+                if (need_wa()) dma(0, WA, wsoff);
                 commit_a(); issue_b();
             }
             __syncthreads();
@@ -1650,12 +1654,32 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
 #pragma unroll
                     for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
                 }
-                for (int c = 0; c < n_chunks; ++c, ++g) {
-                    const char* s_in = s_in0 + (one_chunk ? (k & 1) : (g & 1)) * Cfg::IN_BYTES;
-                    if (!(a.dbg_flags & 2)) D::template mma_steps<0, SA, 0, true>(s_in, s_w, lane_x, lane_w, q, lo, acc);
-                    __syncthreads();
-                    if (!(a.dbg_flags & 2)) D::template mma_steps<SA, STEPS - SA, 0, true>(s_in, s_w, lane_x, lane_w, q, lo, acc);
-                    if (c + 1 < n_chunks) __syncthreads();
+                // chunks [c0, c1) of the item, all of fold phase PH (3 = every tap carries weights: the un-folded layers)
+                auto run_chunks = [&](auto PH, int c0, int c1) {
+                    constexpr int ph = decltype(PH)::value;
+                    for (int c = c0; c < c1; ++c, ++g) {
+                        const char* s_in = s_in0 + (one_chunk ? (k & 1) : (g & 1)) * Cfg::IN_BYTES;
+                        if constexpr (ph == 3) { if (!(a.dbg_flags & 2)) D::template mma_steps<0, SA, 0, true>(s_in, s_w, lane_x, lane_w, q, lo, acc); }
+                        else if constexpr (ph == 2) D::template mma_steps<1, 1, 0, false>(s_in, s_w, lane_x, lane_w, q, lo, acc);
+                        __syncthreads();
+                        if constexpr ((ph & 1) != 0) { if (!(a.dbg_flags & 2)) D::template mma_steps<SA, STEPS - SA, 0, true>(s_in, s_w, lane_x, lane_w, q, lo, acc); }
+                        else D::template mma_steps<3, 1, 0, false>(s_in, s_w, lane_x, lane_w, q, lo, acc);
+                        if (c + 1 < n_chunks) __syncthreads();
+                    }
+                };
+                if constexpr (FOLD_SKIP) {
+                    // Folded stride-2 3x3 layer (a.fold2): the chunks come phase by phase of the 2x2 un-shuffle (cfold % CK == 0), and of the {-1, 0}^2 window only the
+                    // taps with (ty == 1 || i == 1) && (tx == 1 || j == 1) carry weights for phase (i, j) -- 1 / 2 / 2 / 4 of the 4 taps, 9 of 16 over a pixel; the others
+                    // would multiply by the zeros _stride2_view packs, so they are not issued (a tap = one step here: half a = taps (0,0) (0,1), half b = (1,0) (1,1)).
+                    // Four loops with a fixed instruction stream each, not one loop with a branch per chunk: with alternative MFMA streams under if / else inside the
+                    // loop hipcc spilled 33-135 registers of the 168 this 768-thread kernel has.
+                    const int cpp = D::folded(a) ? n_chunks >> 2 : 0;
+                    run_chunks(std::integral_constant<int, 0>{}, 0, cpp);
+                    run_chunks(std::integral_constant<int, 1>{}, cpp, 2 * cpp);
+                    run_chunks(std::integral_constant<int, 2>{}, 2 * cpp, 3 * cpp);
+                    run_chunks(std::integral_constant<int, 3>{}, 3 * cpp, n_chunks);
+                } else {
+                    run_chunks(std::integral_constant<int, 3>{}, 0, n_chunks);
                 }
                 if (ty8 < a.tiles_y)
                     D8::template epilogue<FAST>(a, b, ty8 * kTH, tx * kTW, ty8 * a.tiles_x + tx, ct, tid & 255, acc);
@@ -1663,6 +1687,233 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
             }
         }
     }
+}
+
+// ==================================================================================================
+// Kernel 4b: kernel 4 for THIN stages -- layers whose per-chunk weights are small enough (<= 20 KB) that the weights can be double-buffered whole
+// and the input tile triple-buffered: the folded stride-2 layers (ksize 2, 32-channel chunks: 64 MFMAs per wave and stage), the 16/32-wide cout tiles
+// (128 -> 12, 32 -> 16) and the 16-channel chunks.  Kernel 4's stage is two halves, each ended by a barrier that waits for an LDS-DMA of weights
+// issued at its start, with the tile's loads issued at the start of half a and written to LDS in half b: a stage cannot be shorter than two memory
+// latencies in series (measured 2.3 us per stage on the codec's folded 128 -> 128 layer, whose MFMAs need 0.85 us: 2.5 TB/s and half the matrix rate).
+// Here a stage is ONE barrier and nothing waits for a load younger than a stage:
+//
+//            compute waves 0-7                                          tile waves 8-11
+//   stage g  MFMA steps of stage g   (W[g&1], in[g % 3])                LDS-DMA W(g+1) -> W[(g+1)&1], then tile(g+2) -> in[(g+2) % 3]  (NDW instructions a wave);
+//            (+ epilogue on an item's last chunk)                       s_waitcnt vmcnt(NDW): everything older -- W(g+1), tile(g+1) -- has landed
+//   barrier                                                             barrier (raw s_barrier: the newest tile stays in flight across it)
+//
+// (The compute waves issue no LDS-DMA: with one in flight hipcc puts vmcnt(0) in front of their next LDS read -- it cannot tell the regions apart.)
+//
+// The tile goes global -> LDS by `buffer_load ... lds` (out-of-range pieces land zeros = the zero padding), which writes 64 consecutive 16-byte
+// pieces per instruction: the pixels sit DENSE in LDS here (WstCfg::SPIX = the chunk's bytes; conflict-free for the 2- and 4-unit chunks this
+// kernel takes: the four lane groups of a fragment read the four pieces of one pixel or of two neighbouring ones).  No staging registers, no
+// ds_write, and the wait is an instruction COUNT the code states itself (the pieces an interior tile's wave has just issued; zero after a border
+// tile or a stage that fetches none) -- left to hipcc's own waitcnt insertion a two-deep register pipeline collapsed to vmcnt(0..1) at the first
+// uncountable branch.  Work decomposition, tile order, accumulation order and epilogue are kernel 4's: same bits.
+// ==================================================================================================
+template <class Cfg8>
+struct WstCfg : WsmCfg<Cfg8> {
+    using B = WsmCfg<Cfg8>;
+    static constexpr int SPIX = B::CK * (int)sizeof(typename B::elem);              // dense pixels
+    static constexpr int N_PIECES = B::THH * B::TWH * B::UPT;                       // 16-byte pieces of a halo tile
+    static constexpr int N_DMA = (N_PIECES + 63) / 64;                              // wave-instructions per tile
+    static constexpr int IN_BYTES = N_DMA * 1024;
+};
+template <class Cfg>
+constexpr int wst_lds_bytes() { return 2 * (int)Cfg::CHUNK_W_BYTES + kPersistMaxCout * 4 + 3 * WstCfg<Cfg>::IN_BYTES; }
+template <class Cfg>
+constexpr bool wst_eligible() {
+    return sizeof(typename Cfg::elem) == 2 && (Cfg::KS == 2 || Cfg::KS == 3) && (Cfg::UPT == 2 || Cfg::UPT == 4) && Cfg::STEPS >= 2 &&
+           (int)Cfg::CHUNK_W_BYTES <= 20 * 1024 && wst_lds_bytes<Cfg>() <= 160 * 1024;
+}
+constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }   // s_waitcnt vmcnt(n), lgkmcnt / expcnt untouched (gfx9 encoding)
+
+template <class Cfg8, bool FAST>
+__global__ __launch_bounds__(kWsmThreads) void conv_mfma_wst_kernel(const ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the stub: with the body visible to it, it silently dropped the stub of every instantiation (undefined symbol at load)
+    using Cfg = WstCfg<Cfg8>;
+    using D = ConvDev<Cfg>;
+    using D8 = ConvDev<Cfg8>;
+    constexpr int NT = Cfg::NT, STEPS = Cfg::STEPS, NV = 4 * NT, WALL = (int)Cfg::CHUNK_W_BYTES, UPT = Cfg::UPT, TWH = Cfg::TWH, ES = 2;
+    constexpr int N_DMA = Cfg::N_DMA, NDW = (N_DMA + 3) / 4;         // tile pieces: wave-instructions per tile / per tile wave
+    constexpr bool FOLD_SKIP = Cfg::KS == 2 && UPT == 4 && STEPS == 4;   // a tap = one MFMA step (see kernel 4)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_w = smem;                                                // W[2]
+    float* s_bias = reinterpret_cast<float*>(smem + 2 * WALL);
+    char* s_in0 = smem + 2 * WALL + kPersistMaxCout * 4;             // in[3]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave12 >= 8;
+    const int q = lane >> 4, n = lane & 15;
+
+    const int tiles_y = (a.H + kWsmTH - 1) / kWsmTH;
+    const int sp_total = a.tiles_x * tiles_y;
+    const int n_tiles = sp_total * a.batch;
+    const int n_chunks = a.n_chunks, n_ct = a.n_ct;
+    const bool one_chunk = n_chunks == 1;                            // unit = tile (fetched once for all its cout tiles); else unit = (tile, cout tile)
+    const int n_units = one_chunk ? n_tiles : n_tiles * n_ct;
+    const int cts_per_unit = one_chunk ? n_ct : 1;
+    const int slots = gridDim.x >> 3;
+    const int pos = (blockIdx.x & 7) * slots + (blockIdx.x >> 3);
+    const int stride = (int)gridDim.x;
+    const int my_units = pos < n_units ? (n_units - pos + stride - 1) / stride : 0;
+    const int my_stages = my_units * cts_per_unit * n_chunks;
+
+    for (int i = tid; i < a.cout_packed; i += kWsmThreads) s_bias[i] = a.bias ? a.bias[i] : 0.f;
+
+    auto decode = [&](int unit, int& b, int& ty, int& tx, int& ct0) {
+        int tile = unit;
+        ct0 = 0;
+        if (!one_chunk) { tile = magic_div(unit, a.div_n_ct); ct0 = unit - tile * n_ct; }
+        b = magic_div(tile, a.td_wsm.sp_total);
+        band_decode(tile - b * sp_total, a.tiles_x, tiles_y, a.td_wsm, ty, tx);
+    };
+
+    if (loader) {
+        // ---------------------------------------------------------------- tile waves
+        const int w4 = wave12 - 8;
+        // piece r of this wave = wave-instruction w4 + 4 r of the tile: 16-byte piece P = 64 inst + lane = (halo pixel P / UPT, unit P % UPT).  Interior
+        // tiles (95 % at 4K): its offset is this per-lane launch constant + the tile's scalar offset in the instruction's soffset
+        int lc[NDW];
+#pragma unroll
+        for (int r = 0; r < NDW; ++r) {
+            const int P = (w4 + 4 * r) * 64 + lane, pix = P / UPT, v = P - pix * UPT, py = pix / TWH, px = pix - py * TWH;
+            const int o = D::folded(a) ? ((2 * py * a.src_W + 2 * px) * a.cfold + v * Cfg::UNIT) * ES : ((py * a.W + px) * a.cin + v * Cfg::UNIT) * ES;
+            lc[r] = P < Cfg::N_PIECES ? o : kOOB;
+        }
+        typename D::TileSrc ts;
+        int k_unit = 0, cti = 0, chunk = 0, gi = 0, gb3 = 0, kb3 = 0;   // the stage whose tile is fetched next (+ stage / unit index mod 3)
+        int b = 0, ty = 0, tx = 0, ct0 = 0;
+        const int n_mine = (N_DMA - w4 + 3) / 4;                     // pieces of a tile this wave issues: NDW or NDW - 1
+        // Fetch the tile of the next stage in line; returns how many of its pieces may stay in flight across the coming barrier.  Only an INTERIOR tile's do:
+        // the count wait needs the counter to retire in issue order, and an instruction whose lanes are all out of range (border tiles have them; a round-5
+        // form that padded tile-less stages with zero-record pieces to keep the count constant) completes without a memory access -- the rare stale tile that
+        // form produced on a cold GPU (1 launch in ~1 000, tools/thin_ab.py) is why border and tile-less stages now wait for everything.
+        auto issue = [&]() -> int {
+            const bool tile = gi < my_stages && (!one_chunk || cti == 0);
+            char* dst = s_in0 + (one_chunk ? kb3 : gb3) * Cfg::IN_BYTES;
+            int in_flight = 0;
+            if (tile && chunk == 0) {
+                decode(pos + k_unit * stride, b, ty, tx, ct0);
+                ts = D::tile_src(a, b, ty * kWsmTH, tx * kTW);
+            }
+            if (tile && ts.interior) {
+                const int soff = ts.soff + D::chunk_soff(a, chunk);
+#pragma unroll
+                for (int r = 0; r < NDW; ++r) {
+                    const int inst = w4 + 4 * r;                     // wave-uniform
+                    if (inst < N_DMA)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(ts.r0, (__attribute__((address_space(3))) void*)(dst + inst * 1024), 16, lc[r], soff, 0, 0);
+                }
+                in_flight = n_mine;
+            } else if (tile) {                                       // border tiles: bounds-checked geometry per piece
+                int ln = lane;
+                asm volatile("" : "+v"(ln));                         // keep it here: hoisted out of the stage loop it would be spilled
+#pragma unroll
+                for (int r = 0; r < NDW; ++r) {
+                    const int inst = w4 + 4 * r, P = inst * 64 + ln, pix = P / UPT, v = P - pix * UPT;
+                    if (inst < N_DMA) {
+                        bool center;
+                        const int off = P < Cfg::N_PIECES ? D::vec_off(a, ts, chunk, pix, v, true, center) : kOOB;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(ts.r0, (__attribute__((address_space(3))) void*)(dst + inst * 1024), 16, off, 0, 0, 0);
+                    }
+                }
+            }
+            ++gi; gb3 = gb3 == 2 ? 0 : gb3 + 1;
+            if (++chunk == n_chunks) { chunk = 0; if (++cti == cts_per_unit) { cti = 0; ++k_unit; kb3 = kb3 == 2 ? 0 : kb3 + 1; } }
+            return in_flight;
+        };
+        // the packed weights of the stage after the current one, global -> W[stage & 1] (1 KiB per wave-instruction; only the steps -- taps -- the chunk's
+        // fold phase multiplies by, see run_chunks).  Issued BEFORE the stage's tile pieces: older in the in-order counter, so the count wait lands them
+        int wi = 0, wk = 0, wcti = 0, wchunk = 0, wct0 = 0;
+        auto issue_w = [&]() {
+            if (wi < my_stages) {
+                if (wchunk == 0 && wcti == 0) { int b_, ty_, tx_; decode(pos + wk * stride, b_, ty_, tx_, wct0); }
+                const int goff = ((wct0 + wcti) * n_chunks + wchunk) * WALL;
+                int ph = 3;
+                if constexpr (FOLD_SKIP) ph = D::folded(a) ? D::fold_phase(a, wchunk * Cfg::CK) : 3;
+                for (int kb = w4; kb < WALL / 1024; kb += 4) {
+                    if constexpr (FOLD_SKIP) {
+                        const int st = kb / NT;
+                        if (!(st == 3 || ph == 3 || (ph == 1 && st == 2) || (ph == 2 && st == 1))) continue;
+                    }
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.wpacked) + goff + kb * 1024 + lane * 16),
+                                                     (__attribute__((address_space(3))) void*)(s_w + (wi & 1) * WALL + kb * 1024), 16, 0, 0);
+                }
+            }
+            ++wi;
+            if (++wchunk == n_chunks) { wchunk = 0; if (++wcti == cts_per_unit) { wcti = 0; ++wk; } }
+        };
+        issue_w();                                                   // W(0)
+        issue();                                                     // tile(0)
+        issue();                                                     // tile(1)
+        __syncthreads();                                             // barrier 0 (vmcnt(0): all three landed): bias, W(0), tile(0) visible
+        for (int g = 0; g < my_stages; ++g) {
+            issue_w();                                               // W(g+1): its buffer was last read in stage g-1
+            const int nfl = issue();                                 // tile(g+2)
+            // everything older than the pieces just issued -- W(g+1), tile(g+1) -- is in LDS (the count is an immediate: one branch per value)
+            if (nfl == NDW) __builtin_amdgcn_s_waitcnt(waitcnt_vm(NDW));
+            else if (NDW > 1 && nfl == NDW - 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(NDW > 1 ? NDW - 1 : 0));
+            else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    } else {
+        // ---------------------------------------------------------------- compute waves (two per SIMD)
+        const int wave = wave12;
+        typename D::LaneOff lo;
+        D::lane_offsets(q, lo);
+        const int lane_x = ((2 * wave) * D::TWH + n) * D::SPIX;
+        const int lane_w = lane * 16;
+        __syncthreads();                                             // barrier 0
+        int g = 0, gb3 = 0, kb3 = 0;
+        for (int k = 0; k < my_units; ++k) {
+            int b, ty, tx, ct0;
+            decode(pos + k * stride, b, ty, tx, ct0);
+            const int ty8 = 2 * ty + (wave >> 2);                    // each half of the block stores as an ordinary 8 x 32 tile
+            for (int ct = ct0; ct < ct0 + cts_per_unit; ++ct) {
+                f32x4 acc[4][NT];                                    // initial C operand = bias
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(s_bias + ct * Cfg::COUT_TILE + q * NV + nt * 4);
+#pragma unroll
+                    for (int pt = 0; pt < 4; ++pt) acc[pt][nt] = f32x4{t4.x, t4.y, t4.z, t4.w};
+                }
+                // chunks [c0, c1) of the item, all of fold phase PH (3 = every tap carries weights: the un-folded layers; see kernel 4)
+                auto run_chunks = [&](auto PH, int c0, int c1) {
+                    constexpr int ph = decltype(PH)::value;
+                    for (int c = c0; c < c1; ++c, ++g) {
+                        const char* s_in = s_in0 + (one_chunk ? kb3 : gb3) * Cfg::IN_BYTES;
+                        const char* s_wg = s_w + (g & 1) * WALL;
+                        if constexpr (ph == 3) D::template mma_steps<0, STEPS, 0, true>(s_in, s_wg, lane_x, lane_w, q, lo, acc);
+                        else if constexpr (ph == 1) D::template mma_steps<2, 2, 0, true>(s_in, s_wg, lane_x, lane_w, q, lo, acc);
+                        else {
+                            if constexpr (ph == 2) D::template mma_steps<1, 1, 0, false>(s_in, s_wg, lane_x, lane_w, q, lo, acc);
+                            D::template mma_steps<3, 1, 0, false>(s_in, s_wg, lane_x, lane_w, q, lo, acc);
+                        }
+                        gb3 = gb3 == 2 ? 0 : gb3 + 1;
+                        if (c + 1 < n_chunks) __syncthreads();
+                    }
+                };
+                if constexpr (FOLD_SKIP) {
+                    const int cpp = D::folded(a) ? n_chunks >> 2 : 0;
+                    run_chunks(std::integral_constant<int, 0>{}, 0, cpp);
+                    run_chunks(std::integral_constant<int, 1>{}, cpp, 2 * cpp);
+                    run_chunks(std::integral_constant<int, 2>{}, 2 * cpp, 3 * cpp);
+                    run_chunks(std::integral_constant<int, 3>{}, 3 * cpp, n_chunks);
+                } else {
+                    run_chunks(std::integral_constant<int, 3>{}, 0, n_chunks);
+                }
+                if (ty8 < a.tiles_y)
+                    D8::template epilogue<FAST>(a, b, ty8 * kTH, tx * kTW, ty8 * a.tiles_x + tx, ct, tid & 255, acc);
+                __syncthreads();
+            }
+            kb3 = kb3 == 2 ? 0 : kb3 + 1;
+        }
+    }
+#endif
 }
 
 // ==================================================================================================
@@ -2282,6 +2533,17 @@ constexpr int ws_lds_bytes() { return 2 * Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTE
 template <class Cfg>
 constexpr int persist_lds_bytes() { return persist_lds_bytes_c<Cfg>(); }
 
+template <class Cfg>
+int launch_wst(const ConvArgs& a, int grid, hipStream_t stream) {
+    constexpr int WST_LDS = wst_lds_bytes<Cfg>();
+    static PerDeviceFlag attr_thin;                      // function attributes are per device (common.hpp)
+    if (!attr_thin.test_and_set())
+        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_wst_kernel<Cfg, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WST_LDS));
+    hipLaunchKernelGGL((conv_mfma_wst_kernel<Cfg, true>), dim3((unsigned)grid), dim3(kWsmThreads), WST_LDS, stream, a);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
 template <class Cfg, bool GATED, bool FAST>
 int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
     constexpr int P_LDS = persist_lds_bytes<Cfg>();
@@ -2359,14 +2621,17 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
             if (report(0, legacy_slots)) return RC_OK;
             { int c_; if (int e_ = sums_mode(0, c_)) return e_; }
             const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch * (a.n_chunks > 1 ? a.n_ct : 1);
+            int grid = a.num_cus;
+            if (grid > n_items) grid = n_items;
+            grid = (grid + 7) / 8 * 8;
+            if constexpr (FAST && wst_eligible<Cfg>()) {         // (compile-time epilogue forms only: the generic one spilled in three of these instantiations)
+                if (a.thin) return launch_wst<Cfg>(a, grid, stream);   // thin stages: one barrier per stage (kernel 4b), rc_debug_set("thin", 0) for kernel 4
+            }
             static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
             if (!attr_set.test_and_set()) {
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_wsm_kernel<Cfg, GATED, FAST>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, WSM_LDS));
             }
-            int grid = a.num_cus;
-            if (grid > n_items) grid = n_items;
-            grid = (grid + 7) / 8 * 8;
             hipLaunchKernelGGL((conv_mfma_wsm_kernel<Cfg, GATED, FAST>), dim3((unsigned)grid), dim3(kWsmThreads), WSM_LDS, stream, a);
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;

@@ -148,6 +148,17 @@ __global__ void __launch_bounds__(256) hbm_probe_kernel(const f4_t* __restrict__
 }
 }  // namespace rc
 
+namespace rc {
+// fills the whole LDS allocation of every CU with a signalling pattern (bf16 / fp32 NaNs): a kernel that reads LDS it has not written -- or
+// before the write has landed -- then shows up in the parity tests whatever ran before it
+__global__ __launch_bounds__(256) void lds_poison_kernel(unsigned pattern, int words) {
+    extern __shared__ unsigned pz[];
+    for (int i = threadIdx.x; i < words; i += 256) pz[i] = pattern;
+    __syncthreads();
+    if (pz[(threadIdx.x * 97) % words] != pattern) __builtin_trap();      // keeps the stores
+}
+}  // namespace rc
+
 extern "C" {
 
 int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* memtime_ticks_per_mfma) {
@@ -176,6 +187,16 @@ int rc_debug_mfma_peak(int waves_per_simd, int iters, double* tflops, double* me
     *tflops = (double)grid * 4 * iters * 16 * 16384.0 / (ms * 1e-3) / 1e12;
     if (memtime_ticks_per_mfma) *memtime_ticks_per_mfma = (double)h / ((double)iters * 16 * waves_per_simd);
     (void)hipFree(sink); (void)hipFree(cyc); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return RC_OK;
+}
+
+int rc_debug_poison_lds(unsigned pattern, void* stream) {
+    constexpr int kBytes = 160 * 1024;
+    static rc::PerDeviceFlag attr;
+    if (!attr.test_and_set())
+        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rc::lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes));
+    hipLaunchKernelGGL(rc::lds_poison_kernel, dim3((unsigned)(rc::device_cu_count() * 4)), dim3(256), kBytes, static_cast<hipStream_t>(stream), pattern, kBytes / 4);
+    RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
 

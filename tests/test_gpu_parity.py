@@ -204,6 +204,43 @@ def test_wave_autonomous_kernels_equal_the_kernels_they_replace(hip, c):
         lib.rc_debug_set(b"persist_auto", 1)
 
 
+def test_thin_stage_kernel_equals_kernel_4(hip):
+    """Kernel 4b (one barrier per stage, weights and tile by LDS-DMA two stages ahead, dense LDS pixels) against kernel 4 (`thin` 0) on the
+    layers it takes over: folded stride-2 3x3 (its structurally-zero taps skipped in both), 3x3 with a 16-wide cout tile over several chunks, 16-channel
+    chunks, the un-folded 2x2 window.  Same work decomposition and accumulation order: BIT FOR BIT, on border-only, ragged and interior-tile shapes,
+    several images, with activation / residual / channel sums."""
+    lib = hip
+    assert lib.rc_debug_set(b"lds_poison", 1) == 0            # every launch starts from LDS full of NaNs: nothing may depend on what an earlier kernel left there
+    g = torch.Generator().manual_seed(411)
+    cases = []
+    for (cin, cout) in ((64, 64), (128, 128), (128, 192)):
+        conv = N.Conv2d(cin, cout, 3, 2, 1).to(DEV, torch.bfloat16).eval()
+        cases.append((f"fold {cin}->{cout}", cin, lambda x, conv=conv: (ops.conv_stride2(x, conv), ops.conv_stride2(x, conv, act="leaky", slope=0.1))))
+    for (cin, cout) in ((128, 12), (64, 16), (112, 64), (96, 32), (16, 128), (144, 16), (48, 32), (16, 200)):   # (16, 128) / (16, 200): one chunk, several cout tiles
+        conv = N.Conv2d(cin, cout, 3, 1, 1).to(DEV, torch.bfloat16).eval()
+        def run(x, conv=conv, cout=cout):
+            res = torch.randn(*x.shape[:3], cout, generator=torch.Generator().manual_seed(5)).to(DEV, torch.bfloat16)
+            y, sums = ops.conv2d(x, conv, act="relu", want_sums=True)
+            return (ops.conv2d(x, conv), y, sums.sum(1), ops.conv2d(x, conv, residual=res))
+        cases.append((f"3x3 {cin}->{cout}", cin, run))
+    w2 = ops._ConvView((torch.randn(32, 64, 2, 2, generator=g) * 0.1).to(DEV, torch.bfloat16), torch.randn(32, generator=g).to(DEV, torch.bfloat16))
+    cases.append(("2x2 64->32", 64, lambda x: (ops.conv2d(x, w2), ops.conv2d(x, w2, act="relu"))))
+    try:
+        for name, cin, fn in cases:
+            for (B, H, W) in ((1, 9, 20), (2, 37, 71), (3, 64, 96), (1, 150, 230)):
+                x = torch.randn(B, H, W, cin, generator=g).to(DEV, torch.bfloat16)
+                outs = []
+                for thin in (1, 0):
+                    assert lib.rc_debug_set(b"thin", thin) == 0
+                    with torch.no_grad():
+                        outs.append(fn(x))
+                torch.cuda.synchronize()
+                for a, b in zip(*outs):
+                    assert torch.equal(a, b), (name, B, H, W)
+    finally:
+        lib.rc_debug_set(b"thin", 1); lib.rc_debug_set(b"lds_poison", 0)
+
+
 @pytest.mark.parametrize("c,B,H,W,auto", [(48, 2, 632, 256, 1), (48, 2, 632, 256, 0), (48, 3, 256, 1024, 1), (64, 2, 632, 256, 1), (32, 2, 256, 1024, 1)])
 def test_compact_channel_sum_slots_equal_the_per_tile_layout(hip, c, B, H, W, auto):
     """The carried-sums kernels (2, 6, 7) write ONE partial-sum slot per (residue class of their tile walk, wave) instead of 4 per 8 x 32 tile

@@ -39,7 +39,7 @@ print(f"{len(recs)} launches, {tot:.1f} ms serialized")
 agg = collections.defaultdict(lambda: [0, 0.0])
 for n, s, e, t in recs:
     agg[(n, s, e)][0] += 1; agg[(n, s, e)][1] += t
-for (n, s, e), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+for (n, s, e), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("TOP", "45"))]:
     fl = ""
     if n == "conv2d_fold2":
         cout = int(e.split()[0][5:]); b, h, w, cin = s
