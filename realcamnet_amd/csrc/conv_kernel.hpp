@@ -2533,13 +2533,13 @@ constexpr int ws_lds_bytes() { return 2 * Cfg::IN_BYTES + (int)Cfg::CHUNK_W_BYTE
 template <class Cfg>
 constexpr int persist_lds_bytes() { return persist_lds_bytes_c<Cfg>(); }
 
-template <class Cfg>
+template <class Cfg, bool FAST>
 int launch_wst(const ConvArgs& a, int grid, hipStream_t stream) {
     constexpr int WST_LDS = wst_lds_bytes<Cfg>();
     static PerDeviceFlag attr_thin;                      // function attributes are per device (common.hpp)
     if (!attr_thin.test_and_set())
-        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_wst_kernel<Cfg, true>), hipFuncAttributeMaxDynamicSharedMemorySize, WST_LDS));
-    hipLaunchKernelGGL((conv_mfma_wst_kernel<Cfg, true>), dim3((unsigned)grid), dim3(kWsmThreads), WST_LDS, stream, a);
+        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_wst_kernel<Cfg, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, WST_LDS));
+    hipLaunchKernelGGL((conv_mfma_wst_kernel<Cfg, FAST>), dim3((unsigned)grid), dim3(kWsmThreads), WST_LDS, stream, a);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
@@ -2624,8 +2624,8 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
             int grid = a.num_cus;
             if (grid > n_items) grid = n_items;
             grid = (grid + 7) / 8 * 8;
-            if constexpr (FAST && wst_eligible<Cfg>()) {         // (compile-time epilogue forms only: the generic one spilled in three of these instantiations)
-                if (a.thin) return launch_wst<Cfg>(a, grid, stream);   // thin stages: one barrier per stage (kernel 4b), rc_debug_set("thin", 0) for kernel 4
+            if constexpr ((FAST || Cfg::NT <= 3) && wst_eligible<Cfg>()) {   // (with the generic epilogue the 64-wide cout tiles spilled 1-22 registers: those stay on kernel 4)
+                if (a.thin) return launch_wst<Cfg, FAST>(a, grid, stream);   // thin stages: one barrier per stage (kernel 4b), rc_debug_set("thin", 0) for kernel 4
             }
             static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
             if (!attr_set.test_and_set()) {

@@ -221,7 +221,7 @@ def test_thin_stage_kernel_equals_kernel_4(hip):
         def run(x, conv=conv, cout=cout):
             res = torch.randn(*x.shape[:3], cout, generator=torch.Generator().manual_seed(5)).to(DEV, torch.bfloat16)
             y, sums = ops.conv2d(x, conv, act="relu", want_sums=True)
-            return (ops.conv2d(x, conv), y, sums.sum(1), ops.conv2d(x, conv, residual=res))
+            return (ops.conv2d(x, conv), y, sums.sum(1), ops.conv2d(x, conv, residual=res), ops.conv2d(x, conv, act="gelu"))      # GELU: the generic epilogue
         cases.append((f"3x3 {cin}->{cout}", cin, run))
     w2 = ops._ConvView((torch.randn(32, 64, 2, 2, generator=g) * 0.1).to(DEV, torch.bfloat16), torch.randn(32, generator=g).to(DEV, torch.bfloat16))
     cases.append(("2x2 64->32", 64, lambda x: (ops.conv2d(x, w2), ops.conv2d(x, w2, act="relu"))))
