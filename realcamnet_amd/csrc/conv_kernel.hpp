@@ -1466,16 +1466,17 @@ __global__ __launch_bounds__(kWsThreads) void conv_mfma_ws_kernel(const ConvArgs
 // from this XCD's L2 after the first touch; every stage has two halves separated by a barrier:
 //
 //            compute waves 0-7                          loader waves 8-11
-//   half a   MFMA steps [0, SA) of stage g   (Wa, in[g&1])     issue loads Wa(g+1), tile(g+1);  Wb(g) registers -> LDS
+//   half a   MFMA steps [0, SA) of stage g   (Wa, in[g&1])     LDS-DMA Wb(g) -> its half; issue the loads of tile(g+1)
 //   barrier
-//   half b   MFMA steps [SA, STEPS)          (Wb, in[g&1])     issue loads Wb(g+1);  Wa(g+1), tile(g+1) -> LDS in[(g+1)&1]
+//   half b   MFMA steps [SA, STEPS)          (Wb, in[g&1])     LDS-DMA Wa(g+1) -> its half; tile(g+1) registers -> LDS in[(g+1)&1]
 //            (+ epilogue on an item's last chunk)
 //   barrier
 //
 // so the packed weights are single-buffered BY HALVES (each half is rewritten while the other is being read) and
-// only the input tile is double-buffered: 36 + 2 x 57 KB of LDS.  Everything the loaders fetch is a plain buffer load
-// issued one half-stage before it is needed (with an LDS-DMA in flight hipcc's barrier would wait vmcnt(0) and drain
-// the prefetch; plain loads survive a __syncthreads()).  The general kernel (one block per (tile, cout tile), loads
+// only the input tile is double-buffered: 36 + 2 x 57 KB of LDS.  (Rounds 2-4 moved the weights through the loaders' registers,
+// issued one half-stage ahead, because hipcc's barrier waits vmcnt(0) with an LDS-DMA in flight and then also drains the tile's loads;
+// round 5 made them DMA everywhere -- at the power cap the register trip costs more than the wait, see the loader -- and gave the
+// layers whose stages are too thin for this scheme kernel 4b.)  The general kernel (one block per (tile, cout tile), loads
 // in front of the MFMAs, weights by LDS-DMA in sub-stages) left the matrix pipe at ~50 % on these layers.
 // For the epilogue each half of the block is an ordinary 8 x 32 tile: same code, same CALayer partial-sum slots.
 // ==================================================================================================
@@ -1493,7 +1494,6 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
     constexpr int NT = Cfg::NT, STEPS = Cfg::STEPS, NV = 4 * NT;
     constexpr int SA = (STEPS + 1) / 2;                              // steps in half a
     constexpr int WA = SA * NT * 1024, WB = (STEPS - SA) * NT * 1024, WALL = (int)Cfg::CHUNK_W_BYTES;
-    constexpr int NWA = (WA / 16 + kThreads - 1) / kThreads, NWB = (WB / 16 + kThreads - 1) / kThreads;
     static_assert(STEPS >= 2 && WA + WB == WALL, "weight halves");
     constexpr bool FOLD_SKIP = Cfg::KS == 2 && Cfg::UPT == 4 && STEPS == 4 && sizeof(typename Cfg::elem) == 2;   // a tap = one MFMA step (CK = 32, the form cfold % 64 == 0 layers take)
 
@@ -1536,40 +1536,28 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
     if (loader) {
         // ---------------------------------------------------------------- producer waves
         const int rtid = tid - kWsmCompute;                          // 0..255
-        // gated inputs: two tile operands already fill the loader's 168 VGPRs, so the weight halves go by LDS-DMA instead
-        // of through registers -- issued at the start of the half in which their LDS region is free, landed by the barrier
-        // that ends it (the barrier's vmcnt(0) also waits for this half's tile loads; they had the same half to arrive)
-        // The packed weights go global -> LDS by LDS-DMA in EVERY form (round 5; rounds 2-4: through registers except in the gated form): a half's DMA is issued at the start of
-        // the half-stage in which its LDS region is free and landed by the barrier that ends it.  Rounds 2-4 avoided that because the barrier's vmcnt(0) then also waits
-        // for the tile loads of the same half -- a cycle cost -- but these kernels run at the board's power cap with cycles to spare, and not moving 36 KB per
-        // stage through VGPRs and ds_write_b128 saves joules: the multi-chunk layers of cfg3 18.04 -> 17.83 ms (tools/wsm_probe.py, two runs each), and the loaders'
-        // 48 weight registers (8-10 spilled in the one-chunk 48-channel form) are gone.
-        constexpr bool WDMA = true;
-        uint4 r0[D::NI], r1[GATED ? D::NI : 1], wra[WDMA ? 1 : NWA], wrb[WDMA ? 1 : NWB];
+        // The packed weights go global -> LDS by LDS-DMA in EVERY form (round 5; rounds 2-4: through the loaders' registers except in the gated form): a half's DMA is
+        // issued at the start of the half-stage in which its LDS region is free and landed by the barrier that ends it.  Rounds 2-4 avoided that because the barrier's
+        // vmcnt(0) then also waits for the tile loads of the same half -- a cycle cost -- but these kernels run at the board's power cap with cycles to spare,
+        // and not moving 36 KB per stage through VGPRs and ds_write_b128 saves joules: the multi-chunk layers of cfg3 18.04 -> 17.83 ms (tools/wsm_probe.py, two runs each),
+        // and the loaders' 48 weight registers (8-10 spilled in the one-chunk 48-channel form) are gone.
+        uint4 r0[D::NI], r1[GATED ? D::NI : 1];
         float gv[GATED ? D::UNIT : 1];
         typename D::TileSrc ts;
         typename D::TileOffs to;
         D::tile_offsets(a, rtid, to);
-        int woa[WDMA ? 1 : NWA], wob[WDMA ? 1 : NWB];                // this thread's 16-byte pieces of the two weight halves
-        if constexpr (!WDMA) {
-#pragma unroll
-            for (int k = 0; k < NWA; ++k) woa[k] = (k * kThreads + rtid) * 16 < WA ? (k * kThreads + rtid) * 16 : kOOB;
-#pragma unroll
-            for (int k = 0; k < NWB; ++k) wob[k] = (k * kThreads + rtid) * 16 < WB ? WA + (k * kThreads + rtid) * 16 : kOOB;
-        }
         auto dma = [&](int lds_off, int bytes, int goff) {           // packed weights, global -> LDS, 1 KiB per wave-instruction
             for (int kb = wave12 - 8; kb < bytes / 1024; kb += 4)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.wpacked) + goff + lds_off + kb * 1024 + lane * 16),
                                                  (__attribute__((address_space(3))) void*)(s_w + lds_off + kb * 1024), 16, 0, 0);
         };
-        const __amdgpu_buffer_rsrc_t r_w = make_rsrc(a.wpacked, (unsigned)((size_t)n_ct * n_chunks * WALL));
         ConvArgs aa = a;                                             // per-item view: only ct == 0 materialises a gated input
 
-        int k_unit = 0, cti = 0, ct = 0, chunk = 0, gi = 0;          // the stage whose Wa / tile loads are issued next
+        int k_unit = 0, cti = 0, ct = 0, chunk = 0, gi = 0;          // the stage whose tile loads are issued next
         int b = 0, ty = 0, tx = 0, ct0 = 0;
         int wsoff = 0, c_chunk = 0, c_buf = 0;                       // of the stage held in registers
         bool c_tile = false;
-        auto issue_a = [&]() {                                       // Wa (+ input tile) of the next stage -> registers
+        auto issue_a = [&]() {                                       // input tile of the next stage -> registers
             if (chunk == 0) {
                 if (cti == 0) decode(pos + k_unit * stride, b, ty, tx, ct0);
                 ct = ct0 + cti;
@@ -1581,55 +1569,29 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
             c_chunk = chunk;
             if (c_tile) D::template load_tile<GATED>(aa, ts, to, b, chunk, rtid, r0, r1, gv);
             wsoff = (ct * n_chunks + chunk) * WALL;
-            if constexpr (!WDMA) {
-#pragma unroll
-                for (int k = 0; k < NWA; ++k) wra[k] = buf_load16(r_w, woa[k], wsoff);
-            }
             ++gi;
             if (++chunk == n_chunks) { chunk = 0; if (++cti == cts_per_unit) { cti = 0; ++k_unit; } }
         };
-        auto issue_b = [&]() {                                       // Wb of the stage issue_a fetched last
-            if constexpr (!WDMA) {
-#pragma unroll
-                for (int k = 0; k < NWB; ++k) wrb[k] = buf_load16(r_w, wob[k], wsoff);
-            }
-        };
         auto commit_a = [&]() {
             if (c_tile) D::template commit_tile<GATED>(aa, ts, to, c_chunk, rtid, r0, r1, gv, s_in0 + c_buf * Cfg::IN_BYTES);
-            if constexpr (!WDMA) {
-#pragma unroll
-                for (int k = 0; k < NWA; ++k)
-                    if (woa[k] != kOOB) *reinterpret_cast<uint4*>(s_w + woa[k]) = wra[k];
-            }
         };
         // folded stride-2 layers: the chunks of phases 0 and 1 (source row 2y) have no weights in half a = the taps of map row y - 1 (see the compute waves)
         auto need_wa = [&]() { if constexpr (FOLD_SKIP) return !(D::folded(a) && D::fold_phase(a, c_chunk * Cfg::CK) < 2); else return true; };
-        auto commit_b = [&]() {
-            if constexpr (!WDMA) {
-#pragma unroll
-                for (int k = 0; k < NWB; ++k)
-                    if (wob[k] != kOOB) *reinterpret_cast<uint4*>(s_w + wob[k]) = wrb[k];
-            }
-        };
 
         if (my_stages > 0) {
-            issue_a(); commit_a(); issue_b();
+            issue_a(); commit_a();
             if (need_wa()) dma(0, WA, wsoff);                        // Wa(0)
         }
         __syncthreads();                                             // barrier 0: bias, Wa(0), tile(0) visible
         for (int g = 0; g < my_stages; ++g) {
-            // every load is issued at the START of a half and consumed one half later: a whole half of latency budget
-            // In both halves the commit comes BEFORE the issue: hipcc cannot count the conditionally issued younger loads, so a commit
-            // placed after them waits vmcnt(0) -- i.e. for the loads of its own half (round 3, tools/conv32_phases.py: 2650 + 1660
-            // loader cycles per stage became 1660 + 1630).  This way its wait covers only loads that have had a whole half-stage.
+            // the tile's loads are issued in half a and written to LDS in half b; each half's weights land during the half before the one that reads them
             const int wsoff_g = wsoff;                               // stage g's weights (issue_a moves wsoff on to g+1)
-            if constexpr (WDMA) dma(WA, WB, wsoff_g);                // half a: Wb(g) straight into its (free) LDS half
-            commit_b();                                              //         write Wb(g); the computers read Wa(g) ...
-            if (g + 1 < my_stages) issue_a();                        //         ... and fetch Wa(g+1) (+ tile)
+            dma(WA, WB, wsoff_g);                                    // half a: Wb(g) straight into its (free) LDS half; the computers read Wa(g) ...
+            if (g + 1 < my_stages) issue_a();                        //         ... and the loads of tile(g+1) go out
             __syncthreads();
-            if (g + 1 < my_stages) {                                 // half b: write Wa(g+1) (+ tile); fetch Wb(g+1)
+            if (g + 1 < my_stages) {                                 // half b: Wa(g+1) into its half, tile(g+1) -> LDS
                 if (need_wa()) dma(0, WA, wsoff);
-                commit_a(); issue_b();
+                commit_a();
             }
             __syncthreads();
         }

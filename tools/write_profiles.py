@@ -134,6 +134,17 @@ they replace, bit-equality of every operand form first:
 `LiteISPNet`, 4K, 8 frames, bf16 (the 64-channel trunk; round 4: 58.6 ms):
 {last(f'{G}/bench_liteisp_bf16_{tag}.json') if os.path.exists(f'{G}/bench_liteisp_bf16_{tag}.json') else '(not collected)'}
 """)
+open(f"{OUT}/{RND}_thin_stage_kernel.md", "w").write(f"""# {RND} — kernel 4b (thin stages of the multi-chunk conv kernel, DESIGN 4.12) against kernel 4 at the final sources, 1x MI355X
+
+In order: the codec bench line (`bench.py --model raw_compression_tcm_final --frames 8 --steps 5 --warmup 2`) with `RC_DEBUG=thin=1 / 0 / 1 / 0` (kernel 4b / kernel 4,
+one process each, same box); the per-launch table of one codec forward at 8 frames (`tools/codec_conv_breakdown.py 8`) with kernel 4b, then the rows kernel 4b serves
+re-measured with kernel 4; cfg3's multi-chunk layers (`tools/wsm_probe.py`: weights by LDS-DMA in every form); the back-to-back stress loop (`tools/thin_stress.py`) and the
+per-launch A/B inside the small RAW codec's compress / decompress / forward after the TCM round trips (`tools/thin_ab.py --after-tcm`: the order that exposed the stale tile).
+
+```
+{rd('thin')}
+```
+""")
 mf = f"{G}/pmc_mfma_{tag}.md"
 if os.path.exists(mf):
     open(f"{OUT}/{RND}_pmc_mfma_lds.md", "w").write(f"""# {RND} — matrix-pipe and LDS counters of the bench command (cfg3), `tools/pmc_mfma.sh`
