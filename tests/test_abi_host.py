@@ -282,6 +282,8 @@ def test_bench_path_kernels_do_not_spill_and_the_count_cannot_grow():
         "conv_mfma_persist_kernelINS_7ConvCfgIDF16bLi48ELi1ELi5ELi8EEELb0ELb0E",
         "conv_mfma_persist_kernelINS_7ConvCfgIDF16bLi48ELi1ELi3ELi8EEELb0ELb0E",    # 48 -> 3 on the ring strips
         "conv_mfma_kernelINS_7ConvCfgIDF16bLi64ELi5ELi1ELi8EEELb0E",                 # GroupMix in-projection 192 -> 80
+        "conv_mfma_wst_kernel",                                                       # kernel 4b, every instantiation (the codec's folded stride-2 layers, 16-wide cout tiles, 16-channel chunks)
+        "conv_mfma_wsm_kernelINS_7ConvCfgIDF16bLi32ELi4ELi2ELi8EEELb0ELb1E",        # ... and kernel 4 on the same folded layers (`thin` 0)
         "2gf", "ca_gate", "ca_reduce", "color_", "instance_stats", "gfm_vector", "dwt_", "raw_ingest", "tail_ring", "nchw_to_nhwc", "nhwc_to_nchw",
         "wmsa", "3ans", "entropy_bottleneck", "gaussian_conditional", "channel_concat", "pointwise_chain",
     ]
@@ -290,6 +292,21 @@ def test_bench_path_kernels_do_not_spill_and_the_count_cannot_grow():
     bad = sorted(k for p in bench_path for k in hits[p] if k in spilled)
     assert not bad, [(k, spilled[k]) for k in bad]
     assert len(spilled) <= 25, sorted((v["tu"], v["vgpr_spill"], k[:90]) for k, v in spilled.items())
+
+
+def test_debug_knobs_have_their_documented_defaults():
+    """The A/B switches the header documents (include/realcam_hip.h, rc_debug_set) read back their defaults, round-trip, and reject unknown keys: a default that
+    drifted would silently change which kernel the parity tests and the bench exercise."""
+    lib = _lib.load()
+    for key, default in ((b"persist", 1), (b"conv32", 0), (b"pss", 0), (b"persist_auto", 1), (b"sums_compact", 1), (b"thin", 1), (b"lds_poison", 0), (b"conv_flags", 0)):
+        assert lib.rc_debug_get(key) == default, key
+    for key, v in ((b"thin", 0), (b"lds_poison", 1), (b"persist_auto", 2)):
+        old = lib.rc_debug_get(key)
+        try:
+            assert lib.rc_debug_set(key, v) == 0 and lib.rc_debug_get(key) == v
+        finally:
+            lib.rc_debug_set(key, old)
+    assert lib.rc_debug_get(b"no_such_knob") == -1 and lib.rc_debug_set(b"no_such_knob", 1) != 0
 
 
 def test_sum_slot_query_follows_the_dispatch():
