@@ -18,7 +18,7 @@ extern int g_dec_lds;              // rans.hip
 static int g_pss = 0;              // rc_debug_set("pss", v): 1: single-chunk pixel-shuffle layers (the tail 48 -> 192) take kernel 5 (output staged through LDS, stored by the
                                    // loader waves); 0 (default): kernel 4.  Measured on MI355X at 8 x 1088 x 1920: 3.16-3.29 vs 3.24-3.27 ms (conv_kernel.hpp, kernel 5)
 static int g_poison = 0;           // rc_debug_set("lds_poison", 1): every rc_conv2d launch is preceded by rc_debug_poison_lds (bf16 NaNs in all LDS) -- test aid
-static int g_thin = 1;             // rc_debug_set("thin", v): layers kernel 4 would run with thin stages (per-chunk weights <= 20 KB) take kernel 4b (one barrier per stage, tiles fetched two stages ahead); 0: kernel 4
+static int g_thin = 2;             // rc_debug_set("thin", v): kernel 4b where kernel 4 would run -- 1: the layers with thin stages (per-chunk weights <= 20 KB: tiles by LDS-DMA two stages ahead); 2 (default): also the 3x3 layers with <= 36 KB of weights a chunk (one barrier per stage, tile through registers one stage ahead); 0: kernel 4
 static int g_auto = 1;             // rc_debug_set("persist_auto", v): single-chunk, single-cout-tile bf16 3x3 layers (48 -> 48, 32 -> 32) on kernel 6 (wave-autonomous strips):
                                    // 0 never, 1 (default) the plain / ReLU / LeakyReLU / +sums forms (1-5 % faster than kernel 2; profiles/r05_power_wall.md), 2 also the residual forms (4-5 % slower)
 static int g_sums_compact = 1;     // rc_debug_set("sums_compact", v): 0 = the carried-sums kernels keep the per-tile slot layout (A/B and tests)
@@ -269,7 +269,7 @@ int rc_debug_set(const char* key, int value) {
     if (std::string(key) == "pss") { g_pss = value != 0; return RC_OK; }
     if (std::string(key) == "sums_compact") { g_sums_compact = value != 0; return RC_OK; }
     if (std::string(key) == "persist_auto") { g_auto = value < 0 ? 0 : (value > 2 ? 2 : value); return RC_OK; }
-    if (std::string(key) == "thin") { g_thin = value != 0; return RC_OK; }
+    if (std::string(key) == "thin") { g_thin = value < 0 ? 0 : (value > 2 ? 2 : value); return RC_OK; }
     if (std::string(key) == "lds_poison") { g_poison = value != 0; return RC_OK; }
     if (std::string(key) == "conv32") { g_conv32 = value < 0 ? 0 : (value > 4 ? 4 : value); return RC_OK; }
     return fail(RC_ERR_INVALID, std::string("rc_debug_set: unknown key ") + key);

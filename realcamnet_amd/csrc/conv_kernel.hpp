@@ -1681,13 +1681,20 @@ struct WstCfg : WsmCfg<Cfg8> {
     static constexpr int N_DMA = (N_PIECES + 63) / 64;                              // wave-instructions per tile
     static constexpr int IN_BYTES = N_DMA * 1024;
 };
+// form 3: weights <= 20 KB a chunk, THREE tile buffers filled by LDS-DMA two stages ahead;  form 2: weights <= 36 KB a chunk (the 64-wide cout tiles of the 3x3
+// layers over 32-channel chunks: cfg3's 128 / 192 / 512-channel levels), TWO tile buffers, the tile through the loaders' registers one stage ahead;  0: kernel 4 only
 template <class Cfg>
-constexpr int wst_lds_bytes() { return 2 * (int)Cfg::CHUNK_W_BYTES + kPersistMaxCout * 4 + 3 * WstCfg<Cfg>::IN_BYTES; }
-template <class Cfg>
-constexpr bool wst_eligible() {
-    return sizeof(typename Cfg::elem) == 2 && (Cfg::KS == 2 || Cfg::KS == 3) && (Cfg::UPT == 2 || Cfg::UPT == 4) && Cfg::STEPS >= 2 &&
-           (int)Cfg::CHUNK_W_BYTES <= 20 * 1024 && wst_lds_bytes<Cfg>() <= 160 * 1024;
+constexpr int wst_form() {
+    if (!(sizeof(typename Cfg::elem) == 2 && (Cfg::KS == 2 || Cfg::KS == 3) && (Cfg::UPT == 2 || Cfg::UPT == 4) && Cfg::STEPS >= 2)) return 0;
+    const int w = (int)Cfg::CHUNK_W_BYTES, in = WstCfg<Cfg>::IN_BYTES, fixed = 2 * w + kPersistMaxCout * 4;
+    if (w <= 20 * 1024 && fixed + 3 * in <= 160 * 1024) return 3;
+    if (w <= 36 * 1024 && fixed + 2 * in <= 160 * 1024) return 2;
+    return 0;
 }
+template <class Cfg>
+constexpr int wst_lds_bytes() { return 2 * (int)Cfg::CHUNK_W_BYTES + kPersistMaxCout * 4 + (wst_form<Cfg>() == 3 ? 3 : 2) * WstCfg<Cfg>::IN_BYTES; }
+template <class Cfg>
+constexpr bool wst_eligible() { return wst_form<Cfg>() != 0; }
 constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }   // s_waitcnt vmcnt(n), lgkmcnt / expcnt untouched (gfx9 encoding)
 
 template <class Cfg8, bool FAST>
@@ -1698,12 +1705,13 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wst_kernel(const ConvAr
     using D8 = ConvDev<Cfg8>;
     constexpr int NT = Cfg::NT, STEPS = Cfg::STEPS, NV = 4 * NT, WALL = (int)Cfg::CHUNK_W_BYTES, UPT = Cfg::UPT, TWH = Cfg::TWH, ES = 2;
     constexpr int N_DMA = Cfg::N_DMA, NDW = (N_DMA + 3) / 4;         // tile pieces: wave-instructions per tile / per tile wave
+    constexpr int NBUF = wst_form<Cfg8>() == 3 ? 3 : 2;              // tile buffers (form 3: by LDS-DMA two stages ahead; form 2: through registers one stage ahead)
     constexpr bool FOLD_SKIP = Cfg::KS == 2 && UPT == 4 && STEPS == 4;   // a tap = one MFMA step (see kernel 4)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_w = smem;                                                // W[2]
     float* s_bias = reinterpret_cast<float*>(smem + 2 * WALL);
-    char* s_in0 = smem + 2 * WALL + kPersistMaxCout * 4;             // in[3]
+    char* s_in0 = smem + 2 * WALL + kPersistMaxCout * 4;             // in[NBUF]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1733,7 +1741,45 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wst_kernel(const ConvAr
         band_decode(tile - b * sp_total, a.tiles_x, tiles_y, a.td_wsm, ty, tx);
     };
 
-    if (loader) {
+    if (loader && NBUF == 2) {
+        // ---------------------------------------------------------------- loader waves, form 2: during stage g, W(g+1) by LDS-DMA and tile(g+1) through registers,
+        // both issued at the start of the stage and waited for ONCE (kernel 4 waits for the tile in half a and for a weight half in half b: two latencies in series)
+        if constexpr (NBUF == 2) {
+            const int rtid = tid - kWsmCompute, w4 = wave12 - 8;
+            uint4 r0[D::NI], r1[1];
+            float gv[1];
+            typename D::TileSrc ts;
+            typename D::TileOffs to;
+            D::tile_offsets(a, rtid, to);
+            int k_unit = 0, cti = 0, chunk = 0, gi = 0, ct = 0;
+            int b = 0, ty = 0, tx = 0, ct0 = 0;
+            auto fetch = [&]() {                                     // everything stage gi reads
+                if (gi < my_stages) {
+                    if (chunk == 0) {
+                        if (cti == 0) decode(pos + k_unit * stride, b, ty, tx, ct0);
+                        ct = ct0 + cti;
+                        ts = D::tile_src(a, b, ty * kWsmTH, tx * kTW);
+                    }
+                    const int goff = (ct * n_chunks + chunk) * WALL;
+                    for (int kb = w4; kb < WALL / 1024; kb += 4)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(static_cast<const char*>(a.wpacked) + goff + kb * 1024 + lane * 16),
+                                                         (__attribute__((address_space(3))) void*)(s_w + (gi & 1) * WALL + kb * 1024), 16, 0, 0);
+                    if (!one_chunk || cti == 0) {
+                        D::template load_tile<false>(a, ts, to, b, chunk, rtid, r0, r1, gv);
+                        D::template commit_tile<false>(a, ts, to, chunk, rtid, r0, r1, gv, s_in0 + (one_chunk ? (k_unit & 1) : (gi & 1)) * Cfg::IN_BYTES);
+                    }
+                }
+                ++gi;
+                if (++chunk == n_chunks) { chunk = 0; if (++cti == cts_per_unit) { cti = 0; ++k_unit; } }
+            };
+            fetch();                                                 // stage 0
+            __syncthreads();                                         // barrier 0
+            for (int g = 0; g < my_stages; ++g) {
+                fetch();                                             // stage g + 1: its buffers were last read in stage g - 1
+                __syncthreads();
+            }
+        }
+    } else if (loader) {
         // ---------------------------------------------------------------- tile waves
         const int w4 = wave12 - 8;
         // piece r of this wave = wave-instruction w4 + 4 r of the tile: 16-byte piece P = 64 inst + lane = (halo pixel P / UPT, unit P % UPT).  Interior
@@ -1855,7 +1901,7 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wst_kernel(const ConvAr
                             if constexpr (ph == 2) D::template mma_steps<1, 1, 0, false>(s_in, s_wg, lane_x, lane_w, q, lo, acc);
                             D::template mma_steps<3, 1, 0, false>(s_in, s_wg, lane_x, lane_w, q, lo, acc);
                         }
-                        gb3 = gb3 == 2 ? 0 : gb3 + 1;
+                        gb3 = gb3 == NBUF - 1 ? 0 : gb3 + 1;
                         if (c + 1 < n_chunks) __syncthreads();
                     }
                 };
@@ -1872,7 +1918,7 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wst_kernel(const ConvAr
                     D8::template epilogue<FAST>(a, b, ty8 * kTH, tx * kTW, ty8 * a.tiles_x + tx, ct, tid & 255, acc);
                 __syncthreads();
             }
-            kb3 = kb3 == 2 ? 0 : kb3 + 1;
+            kb3 = kb3 == NBUF - 1 ? 0 : kb3 + 1;
         }
     }
 #endif
@@ -2587,7 +2633,7 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
             if (grid > n_items) grid = n_items;
             grid = (grid + 7) / 8 * 8;
             if constexpr ((FAST || Cfg::NT <= 3) && wst_eligible<Cfg>()) {   // (with the generic epilogue the 64-wide cout tiles spilled 1-22 registers: those stay on kernel 4)
-                if (a.thin) return launch_wst<Cfg, FAST>(a, grid, stream);   // thin stages: one barrier per stage (kernel 4b), rc_debug_set("thin", 0) for kernel 4
+                if (a.thin >= (wst_form<Cfg>() == 3 ? 1 : 2)) return launch_wst<Cfg, FAST>(a, grid, stream);   // thin stages: one barrier per stage (kernel 4b), rc_debug_set("thin", 0) for kernel 4
             }
             static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
             if (!attr_set.test_and_set()) {

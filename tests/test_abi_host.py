@@ -298,7 +298,7 @@ def test_debug_knobs_have_their_documented_defaults():
     """The A/B switches the header documents (include/realcam_hip.h, rc_debug_set) read back their defaults, round-trip, and reject unknown keys: a default that
     drifted would silently change which kernel the parity tests and the bench exercise."""
     lib = _lib.load()
-    for key, default in ((b"persist", 1), (b"conv32", 0), (b"pss", 0), (b"persist_auto", 1), (b"sums_compact", 1), (b"thin", 1), (b"lds_poison", 0), (b"conv_flags", 0)):
+    for key, default in ((b"persist", 1), (b"conv32", 0), (b"pss", 0), (b"persist_auto", 1), (b"sums_compact", 1), (b"thin", 2), (b"lds_poison", 0), (b"conv_flags", 0)):
         assert lib.rc_debug_get(key) == default, key
     for key, v in ((b"thin", 0), (b"lds_poison", 1), (b"persist_auto", 2)):
         old = lib.rc_debug_get(key)

@@ -216,7 +216,8 @@ def test_thin_stage_kernel_equals_kernel_4(hip):
     for (cin, cout) in ((64, 64), (128, 128), (128, 192)):
         conv = N.Conv2d(cin, cout, 3, 2, 1).to(DEV, torch.bfloat16).eval()
         cases.append((f"fold {cin}->{cout}", cin, lambda x, conv=conv: (ops.conv_stride2(x, conv), ops.conv_stride2(x, conv, act="leaky", slope=0.1))))
-    for (cin, cout) in ((128, 12), (64, 16), (112, 64), (96, 32), (16, 128), (144, 16), (48, 32), (16, 200)):   # (16, 128) / (16, 200): one chunk, several cout tiles
+    # (16, 128) / (16, 200): one chunk, several cout tiles;  (128, 128) .. (192, 48): form 2 (64- and 48-wide cout tiles over 32-channel chunks: `thin` 2)
+    for (cin, cout) in ((128, 12), (64, 16), (112, 64), (96, 32), (16, 128), (144, 16), (48, 32), (16, 200), (128, 128), (192, 192), (128, 64), (192, 48), (32, 128)):
         conv = N.Conv2d(cin, cout, 3, 1, 1).to(DEV, torch.bfloat16).eval()
         def run(x, conv=conv, cout=cout):
             res = torch.randn(*x.shape[:3], cout, generator=torch.Generator().manual_seed(5)).to(DEV, torch.bfloat16)
@@ -230,7 +231,7 @@ def test_thin_stage_kernel_equals_kernel_4(hip):
             for (B, H, W) in ((1, 9, 20), (2, 37, 71), (3, 64, 96), (1, 150, 230)):
                 x = torch.randn(B, H, W, cin, generator=g).to(DEV, torch.bfloat16)
                 outs = []
-                for thin in (1, 0):
+                for thin in (2, 0):
                     assert lib.rc_debug_set(b"thin", thin) == 0
                     with torch.no_grad():
                         outs.append(fn(x))
@@ -238,7 +239,7 @@ def test_thin_stage_kernel_equals_kernel_4(hip):
                 for a, b in zip(*outs):
                     assert torch.equal(a, b), (name, B, H, W)
     finally:
-        lib.rc_debug_set(b"thin", 1); lib.rc_debug_set(b"lds_poison", 0)
+        lib.rc_debug_set(b"thin", 2); lib.rc_debug_set(b"lds_poison", 0)
 
 
 @pytest.mark.parametrize("c,B,H,W,auto", [(48, 2, 632, 256, 1), (48, 2, 632, 256, 0), (48, 3, 256, 1024, 1), (64, 2, 632, 256, 1), (32, 2, 256, 1024, 1)])

@@ -26,9 +26,11 @@ timeout 300 python bench.py --model LiteISPNet --no-cpu-baseline > gpurun_out/be
 ( timeout 200 python tools/tail_fold_probe.py; timeout 200 python tools/rcag_probe.py ) > gpurun_out/tail_fold_$TAG.txt 2>&1
 timeout 200 python tools/codec_conv_breakdown.py > gpurun_out/codec_probes_$TAG.txt 2>&1
 # round 5, later: kernel 4b (thin stages) against kernel 4 in one process each, same box; the per-launch table at the bench's 8 frames; cfg3's multi-chunk layers
-( for t in 1 0 1 0; do echo "thin=$t"; RC_DEBUG=thin=$t timeout 200 python bench.py --model raw_compression_tcm_final --frames 8 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | cut -c1-260; done;
+( for t in 2 1 0 2 1 0; do echo "codec thin=$t"; RC_DEBUG=thin=$t timeout 200 python bench.py --model raw_compression_tcm_final --frames 8 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | cut -c1-260; done;
+  for t in 2 1 0 2 1 0; do echo "cfg3 thin=$t"; RC_DEBUG=thin=$t timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-codec-leg 2>/dev/null | cut -c1-200; done;
+  for t in 2 1 0; do echo "multi-chunk layers of cfg3, thin=$t"; RC_DEBUG=thin=$t timeout 200 python tools/wsm_probe.py; done;
   TOP=60 timeout 200 python tools/codec_conv_breakdown.py 8; RC_DEBUG=thin=0 TOP=60 timeout 200 python tools/codec_conv_breakdown.py 8 | grep -i "fold2\|cout=12 \|launches";
-  timeout 200 python tools/wsm_probe.py; timeout 200 python tools/thin_stress.py; timeout 300 python tools/thin_ab.py --after-tcm | tail -8 ) > gpurun_out/thin_$TAG.txt 2>&1
+  timeout 200 python tools/thin_stress.py; timeout 200 python tools/thin_stress.py 192 192 3 2 200 300; timeout 300 python tools/thin_ab.py --after-tcm | tail -8 ) > gpurun_out/thin_$TAG.txt 2>&1
 bash tools/pmc_mfma.sh $TAG > gpurun_out/pmc_mfma_${TAG}.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_cmp_$TAG -o trace -- python tools/compress_trace.py > gpurun_out/compress_$TAG.txt 2>&1
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_torchrun_$TAG.json 2>/dev/null

@@ -17,7 +17,7 @@ class AB(TorchDispatchMode):
         if "realcam.conv2d" not in name:
             return func(*args, **(kwargs or {}))
         lib.rc_debug_set(b"thin", 0); ref = func(*args, **(kwargs or {}))
-        lib.rc_debug_set(b"thin", 1); out = func(*args, **(kwargs or {}))
+        lib.rc_debug_set(b"thin", 2); out = func(*args, **(kwargs or {}))
         torch.cuda.synchronize()
         self.n += 1
         ro = ref if isinstance(ref, (tuple, list)) else (ref,)
@@ -75,7 +75,7 @@ class Rec(TorchDispatchMode):
             self.rows.append((name, tuple(args[0].shape) if torch.is_tensor(args[0]) else None, [a for a in args[1:] if not torch.is_tensor(a)], ins, sig))
         return out
 runs = {}
-for thin in (0, 1):
+for thin in (0, 2):
     lib.rc_debug_set(b"thin", thin)
     rec = Rec()
     with torch.no_grad(), rec:
@@ -92,7 +92,7 @@ for i, (r0, r1) in enumerate(zip(runs[0], runs[1])):
 # third pass: exactly the test's flow, no synchronisation between launches
 def psnr(a, b): return float(10 * torch.log10(1.0 / ((a.float() - b.float()) ** 2).mean().clamp_min(1e-12)))
 res = {}
-for thin in (0, 1, 0, 1):
+for thin in (0, 2, 0, 2):
     lib.rc_debug_set(b"thin", thin)
     with torch.no_grad():
         enc = m.compress(x)

@@ -20,7 +20,7 @@ xb = torch.randn(1, 256, 256, 128, generator=g).to(DEV, torch.bfloat16)
 x = torch.randn(B, H, W, cin, generator=g).to(DEV, torch.bfloat16)
 with torch.no_grad():
     lib.rc_debug_set(b"thin", 0); ref = ops.conv2d(x, conv, act="leaky", slope=0.1); torch.cuda.synchronize()
-    lib.rc_debug_set(b"thin", 1)
+    lib.rc_debug_set(b"thin", 2)
     outs = []
     for it in range(int(os.environ.get("ITERS", "300"))):
         if it % 3 == 0: ops.conv2d(xo, other)

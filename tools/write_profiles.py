@@ -136,9 +136,10 @@ they replace, bit-equality of every operand form first:
 """)
 open(f"{OUT}/{RND}_thin_stage_kernel.md", "w").write(f"""# {RND} — kernel 4b (thin stages of the multi-chunk conv kernel, DESIGN 4.12) against kernel 4 at the final sources, 1x MI355X
 
-In order: the codec bench line (`bench.py --model raw_compression_tcm_final --frames 8 --steps 5 --warmup 2`) with `RC_DEBUG=thin=1 / 0 / 1 / 0` (kernel 4b / kernel 4,
-one process each, same box); the per-launch table of one codec forward at 8 frames (`tools/codec_conv_breakdown.py 8`) with kernel 4b, then the rows kernel 4b serves
-re-measured with kernel 4; cfg3's multi-chunk layers (`tools/wsm_probe.py`: weights by LDS-DMA in every form); the back-to-back stress loop (`tools/thin_stress.py`) and the
+In order: the codec bench line (`bench.py --model raw_compression_tcm_final --frames 8 --steps 5 --warmup 2`) with `RC_DEBUG=thin=2 / 1 / 0` twice (2 = default: kernel 4b
+in both of its forms; 1 = only the LDS-DMA form for thin stages; 0 = kernel 4 everywhere; one process each, same box); the cfg3 headline (`bench.py --steps 10 --warmup 3`)
+the same way; cfg3's multi-chunk layers one by one (`tools/wsm_probe.py`) under the three settings; the per-launch table of one codec forward at 8 frames
+(`tools/codec_conv_breakdown.py 8`), then the rows kernel 4b's DMA form serves re-measured with kernel 4; the back-to-back stress loops (`tools/thin_stress.py`) and the
 per-launch A/B inside the small RAW codec's compress / decompress / forward after the TCM round trips (`tools/thin_ab.py --after-tcm`: the order that exposed the stale tile).
 
 ```
