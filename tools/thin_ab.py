@@ -82,10 +82,10 @@ for thin in (0, 2):
         enc = m.compress(x)
         out = m.decompress(enc["strings"], enc["shape"])["x_hat"]
     runs[thin] = rec.rows
-print(len(runs[0]), len(runs[1]))
+print(len(runs[0]), len(runs[2]))
 shown = 0
-for i, (r0, r1) in enumerate(zip(runs[0], runs[1])):
-    if r0[3] == r1[3] and r0[4] != r1[4]:                 # same inputs, different outputs
+for i, (r0, r1) in enumerate(zip(runs[0], runs[2])):
+    if r0[0].startswith("realcam.conv2d") and r0[3] == r1[3] and r0[4] != r1[4]:                 # a conv launch with the same inputs and different outputs
         print("DIVERGE", i, r0[0], r0[1], r0[2], r0[4], r1[4]); shown += 1
         if shown > 6: break
 
