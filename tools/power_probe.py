@@ -55,9 +55,11 @@ with torch.no_grad():
         cm = N.Conv2d(cin, cin, 3, 1, 1).to("cuda", torch.bfloat16)
         xm = torch.rand(8, H, W, cin, device="cuda").to(torch.bfloat16)
         fl = 2 * 8 * H * W * cin * cin * 9
-        for tag, flags in (("", 0), (", no MFMA", 2), (", no stores", 1)):
+        for tag, flags, thin in ((" kernel 4b", 0, 2), (" kernel 4", 0, 0), (" kernel 4, no MFMA", 2, 0), (" kernel 4, no stores", 1, 0)):     # the knock-outs exist in kernel 4 only
             knobs(1, flags)
-            run(f"wsm {cin}->{cin} {H}x{W}{tag}", lambda: ops.conv2d(xm, cm, act="relu"))
+            assert L.rc_debug_set(b"thin", thin) == 0
+            run(f"{cin}->{cin} {H}x{W}{tag}", lambda: ops.conv2d(xm, cm, act="relu"))
+        L.rc_debug_set(b"thin", 2)
         print(f"    ({fl / 1e12:.3f} TFLOP per launch)")
     knobs(1, 0)
     import ctypes as C
