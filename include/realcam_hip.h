@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 10
+#define RC_ABI_VERSION 11
 
 typedef enum rc_status {
     RC_OK = 0,
@@ -150,7 +150,10 @@ typedef struct rc_conv_desc {
      * kernels write one slot per (residue class of their tile walk, wave): 2 048 per image at 4K instead of 32 640) or 0 / rc_conv_sum_tiles() = the
      * per-tile layout every kernel can write.  Any other value is an error. */
     int32_t chan_sums_slots;
-    int32_t reserved0;
+    /* ABI 11 (the slot was reserved0): cout tile width in channels, 0 = automatic (64 / 48 / 80 / 16 by shape).  A multiple of 16 <= 80: narrower tiles give the
+     * general kernel more blocks on maps too small to fill the chip (fp32 128 -> 128 at 135 x 240, B = 1: 272 blocks of 64 couts for 256 CUs; 16-wide tiles: 1 088).
+     * The packed order depends on it: pack weights and bias with rc_conv_pack_weights_ct / rc_conv_pack_bias_ct and the SAME value.  Plain NHWC / NCHW stores, ksize 1 / 3. */
+    int32_t cout_tile;
 } rc_conv_desc;
 
 /* Size in bytes of the packed weight buffer for (cin,cout,ksize,dtype,out_mode); 0 on error. */
@@ -164,6 +167,11 @@ int rc_conv_pack_weights(const float* w_oihw_host, int cin, int cout, int ksize,
 int rc_conv_packed_cout(int cin, int cout, int ksize, int dtype, int out_mode);
 int rc_conv_pack_bias(const float* bias_host, int cin, int cout, int ksize, int dtype, int out_mode,
                       float* dst_host);
+/* The same three with a caller-chosen cout tile width (rc_conv_desc.cout_tile; 0 = the functions above). */
+size_t rc_conv_packed_bytes_ct(int cin, int cout, int ksize, int dtype, int out_mode, int cout_tile);
+int rc_conv_packed_cout_ct(int cin, int cout, int ksize, int dtype, int out_mode, int cout_tile);
+int rc_conv_pack_weights_ct(const float* w_oihw_host, int cin, int cout, int ksize, int dtype, int out_mode, int cout_tile, void* dst_host);
+int rc_conv_pack_bias_ct(const float* bias_host, int cin, int cout, int ksize, int dtype, int out_mode, int cout_tile, float* dst_host);
 /* Number of partial-sum slots per image the conv kernel writes to chan_sums (4 waves per 8x32 tile; depends only on H,W). */
 int rc_conv_sum_tiles(int height, int width);
 /* Slots per image the launch described by `d` fills in chan_sums (pointers are only tested for NULL; d->chan_sums_slots is ignored): the answer comes from

@@ -28,7 +28,7 @@ static int g_conv32 = 0;           // rc_debug_set("conv32", v): which layers ta
                                    // NHWC ones in the staged-output form; 2 / 3 multi-chunk layers in the two-barrier form with 4 / 8 compute waves (A/B experiments)
 
 // Must mirror ConvCfg<> (static_asserts in check_plan_consistency below keep them in lock-step).
-static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, ConvPlan* p) {
+static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, ConvPlan* p, int cout_tile = 0) {
     if (cin < 1 || cout < 1 || (ksize != 1 && ksize != 3 && ksize != 2 && ksize != 5)) return false;
     if (dtype != RC_F32 && dtype != RC_BF16) return false;
     // ksize 5: the folded tail (rc_tail_fold_weights): one 16-wide cout tile; bf16 with 48 k or 32 k input channels, fp32 with 16 k
@@ -68,12 +68,19 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
     else if (cout % 64 == 0) p->nt = 4;
     else if (cout % 48 == 0) p->nt = 3;
     else p->nt = 1;
+    // Caller-chosen cout tile width (rc_conv_desc.cout_tile, the *_ct packers): narrower tiles = more blocks for the general kernel on maps too small to fill the chip
+    // with the automatic width (fp32 at 1080p, B = 1: 72-272 blocks of 64 couts for 256 CUs at the 128-channel levels).  Plain stores only; the packed order depends on
+    // it, so weights, bias and launch must be given the same value (a width without a kernel instantiation fails at the launch, RC_ERR_UNSUPPORTED).
+    if (cout_tile != 0) {
+        if (cout_tile < 16 || cout_tile > 80 || cout_tile % 16 != 0 || ksize == 5 || ksize == 2 || out_mode == RC_OUT_PIXEL_SHUFFLE2 || out_mode == RC_OUT_PIXEL_SHUFFLE2_NCHW) return false;
+        p->nt = cout_tile / 16;
+    }
     // 32x32x16 form: 3x3 bf16 layers whose weights are streamed (several 32-channel chunks, or the one-chunk 48 -> 192 layers) and whose
     // couts fill whole 32-row tiles.  The packed order differs, so the choice depends on the shape and on the `conv32` knob ONLY (not on `persist`:
     // a 32x32x16 layer runs its own kernel in every persist mode) -- weights packed under one conv32 setting must not be used under another
     // (rc_debug_get("conv32") is part of the host mirror's pack-cache key).
     p->m32 = 0;
-    if (dtype == RC_BF16 && ksize == 3 && g_conv32 != 0 && cout <= kPersistMaxCout && out_mode != RC_OUT_NCHW && out_mode != RC_OUT_PIXEL_SHUFFLE2_NCHW) {
+    if (cout_tile == 0 && dtype == RC_BF16 && ksize == 3 && g_conv32 != 0 && cout <= kPersistMaxCout && out_mode != RC_OUT_NCHW && out_mode != RC_OUT_PIXEL_SHUFFLE2_NCHW) {
         const int cw = out_mode == RC_OUT_PIXEL_SHUFFLE2 ? cout / 4 : cout;          // channels a lane's 16-value run must tile
         const bool all = g_conv32 != 4;
         if (all && p->ck == 32 && cin % 32 == 0 && (out_mode == RC_OUT_PIXEL_SHUFFLE2 ? cw % 32 == 0 : cw % 64 == 0)) { p->m32 = 1; p->nt = 2; p->ck = (g_conv32 == 1 && out_mode == RC_OUT_NHWC) ? 16 : 32; }
@@ -147,22 +154,31 @@ using namespace rc;
 
 extern "C" {
 
-size_t rc_conv_packed_bytes(int cin, int cout, int ksize, int dtype, int out_mode) {
+size_t rc_conv_packed_bytes_ct(int cin, int cout, int ksize, int dtype, int out_mode, int cout_tile) {
     ConvPlan p;
-    if (!make_plan(cin, cout, ksize, dtype, out_mode, &p)) { set_error("rc_conv_packed_bytes: bad shape"); return 0; }
+    if (!make_plan(cin, cout, ksize, dtype, out_mode, &p, cout_tile)) { set_error("rc_conv_packed_bytes: bad shape"); return 0; }
     return (size_t)p.n_ct * p.n_chunks * p.steps * p.nt * 1024;
 }
+size_t rc_conv_packed_bytes(int cin, int cout, int ksize, int dtype, int out_mode) { return rc_conv_packed_bytes_ct(cin, cout, ksize, dtype, out_mode, 0); }
 
-int rc_conv_packed_cout(int cin, int cout, int ksize, int dtype, int out_mode) {
+int rc_conv_packed_cout_ct(int cin, int cout, int ksize, int dtype, int out_mode, int cout_tile) {
     ConvPlan p;
-    if (!make_plan(cin, cout, ksize, dtype, out_mode, &p)) return fail(RC_ERR_INVALID, "rc_conv_packed_cout: bad shape");
+    if (!make_plan(cin, cout, ksize, dtype, out_mode, &p, cout_tile)) return fail(RC_ERR_INVALID, "rc_conv_packed_cout: bad shape");
     return p.cout_packed;
 }
+int rc_conv_packed_cout(int cin, int cout, int ksize, int dtype, int out_mode) { return rc_conv_packed_cout_ct(cin, cout, ksize, dtype, out_mode, 0); }
 
 int rc_conv_pack_weights(const float* w, int cin, int cout, int ksize, int dtype, int out_mode, void* dst) {
+    return rc_conv_pack_weights_ct(w, cin, cout, ksize, dtype, out_mode, 0, dst);
+}
+int rc_conv_pack_bias(const float* bias, int cin, int cout, int ksize, int dtype, int out_mode, float* dst) {
+    return rc_conv_pack_bias_ct(bias, cin, cout, ksize, dtype, out_mode, 0, dst);
+}
+
+int rc_conv_pack_weights_ct(const float* w, int cin, int cout, int ksize, int dtype, int out_mode, int cout_tile, void* dst) {
     ConvPlan p;
     RC_REQUIRE(w && dst, "rc_conv_pack_weights: null pointer");
-    RC_REQUIRE(make_plan(cin, cout, ksize, dtype, out_mode, &p), "rc_conv_pack_weights: bad shape");
+    RC_REQUIRE(make_plan(cin, cout, ksize, dtype, out_mode, &p, cout_tile), "rc_conv_pack_weights: bad shape");
     const int kk = ksize * ksize;
     char* out = static_cast<char*>(dst);
     if (p.m32) {
@@ -214,10 +230,10 @@ int rc_conv_pack_weights(const float* w, int cin, int cout, int ksize, int dtype
     return RC_OK;
 }
 
-int rc_conv_pack_bias(const float* bias, int cin, int cout, int ksize, int dtype, int out_mode, float* dst) {
+int rc_conv_pack_bias_ct(const float* bias, int cin, int cout, int ksize, int dtype, int out_mode, int cout_tile, float* dst) {
     ConvPlan p;
     RC_REQUIRE(dst, "rc_conv_pack_bias: null pointer");
-    RC_REQUIRE(make_plan(cin, cout, ksize, dtype, out_mode, &p), "rc_conv_pack_bias: bad shape");
+    RC_REQUIRE(make_plan(cin, cout, ksize, dtype, out_mode, &p, cout_tile), "rc_conv_pack_bias: bad shape");
     for (int j = 0; j < p.cout_packed; ++j) {
         const int co = packed_to_cout(p, cout, out_mode, j);
         dst[j] = (bias && co >= 0 && co < cout) ? bias[co] : 0.f;
@@ -341,7 +357,7 @@ int rc_prof_collect_rows(rc_prof_row* rows, int max_rows, int* n_rows) {
 // Validation + launch arguments of one rc_conv2d call; shared with rc_conv_sum_slots (which asks the launcher what it WOULD do with them).
 static int conv_build_args(const rc_conv_desc* d, ConvPlan& p, ConvArgs& a, size_t& es_out) {
     RC_REQUIRE(d != nullptr, "rc_conv2d: null desc");
-    RC_REQUIRE(make_plan(d->cin, d->cout, d->ksize, d->dtype, d->out_mode, &p), "rc_conv2d: unsupported cin/cout/ksize/dtype");
+    RC_REQUIRE(make_plan(d->cin, d->cout, d->ksize, d->dtype, d->out_mode, &p, d->cout_tile), "rc_conv2d: unsupported cin/cout/ksize/dtype/cout_tile");
     RC_REQUIRE(d->batch >= 1 && d->height >= 1 && d->width >= 1, "rc_conv2d: empty tensor");
     RC_REQUIRE(d->batch <= 65535, "rc_conv2d: batch > 65535");
     RC_REQUIRE(d->in0 && d->wpacked && d->out, "rc_conv2d: null in0/wpacked/out");

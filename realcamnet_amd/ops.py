@@ -10,6 +10,7 @@ import ctypes as C
 from typing import Optional, Tuple
 
 import numpy as np
+import os
 import torch
 
 from . import _lib
@@ -104,11 +105,11 @@ class PackedConv:
     __slots__ = ("wpacked", "bias", "cin", "cout", "ksize", "dtype", "out_mode")
 
 
-def packed_conv(mod, act_dtype: torch.dtype, out_mode: int) -> PackedConv:
-    """MFMA-fragment-ordered copy of a conv's weights (realcam::conv_pack_weights), cached on the module."""
+def packed_conv(mod, act_dtype: torch.dtype, out_mode: int, cout_tile: int = 0) -> PackedConv:
+    """MFMA-fragment-ordered copy of a conv's weights (realcam::conv_pack_weights), cached on the module (one copy per cout tile width in use)."""
     w, b = mod.weight, mod.bias
     c = _cache(mod)
-    k = ("conv", act_dtype, out_mode)
+    k = ("conv", act_dtype, out_mode, cout_tile)
     key = (_key(w, b), _lib.knob(b"conv32"))      # the 32x32x16 layers' packed order depends on that knob (and on nothing else); mirrored host-side, no C call per conv
     hit = c.get(k)
     if hit is not None and hit[0] == key:
@@ -122,7 +123,7 @@ def packed_conv(mod, act_dtype: torch.dtype, out_mode: int) -> PackedConv:
         cout, cin, kh, kw = w.shape
     if kh != kw or kh not in (1, 2, 3, 5):                 # 2: the {-1, 0}^2 window of a stride-2 3x3 conv over its space-to-depth map; 5: the folded tail
         raise NotImplementedError(f"HIP conv supports 1x1 and 3x3 kernels, got {kh}x{kw}")
-    wp, bp = _R.conv_pack_weights(w.detach(), b.detach() if b is not None else None, act_dtype, out_mode)
+    wp, bp = _R.conv_pack_weights(w.detach(), b.detach() if b is not None else None, act_dtype, out_mode, cout_tile)
     pc = PackedConv()
     pc.wpacked = wp
     pc.bias = bp if b is not None else None
@@ -467,6 +468,32 @@ def make_coord(b: int, h: int, w: int, device=None, dtype: torch.dtype = torch.f
 _ACT = {None: RC_ACT_NONE, "relu": RC_ACT_RELU, "leaky": RC_ACT_LEAKY, "gelu": RC_ACT_GELU, "relu_post": RC_ACT_RELU_POST}
 
 
+# fp32 3x3 layers with 64 | cout on maps too small to fill the chip with 64-wide cout tiles take 16-wide ones (rc_conv_desc.cout_tile): the general kernel launches one
+# block per (8 x 32 tile, cout tile), and cfg2's 128 -> 128 levels are 272 / 72 such blocks for 256 CUs at 1080p, B = 1 (52 TF/s against the 64 -> 64 level's 115)
+SMALL_MAP_COUT_TILE = os.environ.get("RC_SMALL_MAP_COUT_TILE", "1") != "0"        # (the env switch is for A/B runs of bench.py)
+_CU_COUNT = {}
+_SMALL_MAP_FACTOR = int(os.environ.get("RC_SMALL_MAP_FACTOR", "2"))           # blocks of 64 couts below this many per CU -> 16-wide tiles
+
+
+def small_map_cout_tile(x: torch.Tensor, mod, out_mode: int) -> int:
+    w = mod.weight
+    if not SMALL_MAP_COUT_TILE or x.dtype != torch.float32 or w.dim() != 4 or w.shape[-1] != 3 or w.shape[0] % 64 != 0 or w.shape[1] % 16 != 0:
+        return 0
+    if out_mode not in (RC_OUT_NHWC, RC_OUT_NCHW):
+        return 0
+    dev = x.device.index if x.device.index is not None else 0
+    cus = _CU_COUNT.get(dev)
+    if cus is None:
+        try:
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count if x.is_cuda else 256
+        except (RuntimeError, AssertionError):       # FakeTensor traces on a machine without a GPU
+            cus = 256
+        _CU_COUNT[dev] = cus
+    b, H, W, _ = x.shape
+    blocks = b * ((H + 7) // 8) * ((W + 31) // 32) * (w.shape[0] // 64)
+    return 16 if blocks < _SMALL_MAP_FACTOR * cus else 0
+
+
 def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.0,
            residual: Optional[torch.Tensor] = None, mul_plus1: Optional[torch.Tensor] = None,
            film: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
@@ -485,7 +512,8 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
         check_conv_module(mod)
     x = _req(x, "conv input")
     b, H, W, cin = x.shape
-    pc = packed_conv(mod, x.dtype, out_mode)
+    ct = small_map_cout_tile(x, mod, out_mode)
+    pc = packed_conv(mod, x.dtype, out_mode, ct)
     if cin != pc.cin:
         raise ValueError(f"conv expects {pc.cin} input channels, got {cin}")
     if gate is not None:
@@ -517,7 +545,7 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
         _DT[out_dtype]
     out, stored, sums = _R.conv2d(x, pc.wpacked, pc.bias, pc.cout, pc.ksize, _ACT[act], float(slope), residual, mul_plus1, fs, ft, gate, skip,
                                   bool(store_input), int(out_mode), bool(want_sums), int(ch), int(cw),
-                                  out_dtype if planar else None, out_scale)
+                                  out_dtype if planar else None, out_scale, ct)
     extras = [t for t in (_opt(stored), _opt(sums)) if t is not None]
     return (out, *extras) if extras else out
 

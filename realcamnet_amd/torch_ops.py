@@ -120,19 +120,19 @@ def _wshape(weight):
     return weight.shape[0], weight.shape[1], weight.shape[2]
 
 
-def _pack_alloc(weight, bias, act_dtype, out_mode):
+def _pack_alloc(weight, bias, act_dtype, out_mode, cout_tile=0):
     cout, cin, k = _wshape(weight)
     L = lib()
     dt = _DT[act_dtype]
-    nbytes = L.rc_conv_packed_bytes(cin, cout, k, dt, out_mode)
+    nbytes = L.rc_conv_packed_bytes_ct(cin, cout, k, dt, out_mode, cout_tile)
     if nbytes == 0:
         raise _lib.HipError(f"rc_conv_packed_bytes: {L.rc_last_error().decode()}")
-    n_packed = L.rc_conv_packed_cout(cin, cout, k, dt, out_mode)
+    n_packed = L.rc_conv_packed_cout_ct(cin, cout, k, dt, out_mode, cout_tile)
     return (weight.new_empty((nbytes,), dtype=torch.uint8),
             weight.new_empty((n_packed if bias is not None else 0,), dtype=torch.float32))
 
 
-def _pack_launch(outs, weight, bias, act_dtype, out_mode):
+def _pack_launch(outs, weight, bias, act_dtype, out_mode, cout_tile=0):
     # one-time host-side re-ordering into MFMA fragment order (rc_conv_pack_weights is a host function)
     wp, bp = outs
     cout, cin, k = _wshape(weight)
@@ -140,20 +140,21 @@ def _pack_launch(outs, weight, bias, act_dtype, out_mode):
     dt = _DT[act_dtype]
     w_host = np.ascontiguousarray(weight.detach().float().cpu().numpy())
     dst = np.empty(wp.numel(), dtype=np.uint8)
-    check(L.rc_conv_pack_weights(w_host.ctypes.data, cin, cout, k, dt, out_mode, dst.ctypes.data), "rc_conv_pack_weights")
+    check(L.rc_conv_pack_weights_ct(w_host.ctypes.data, cin, cout, k, dt, out_mode, cout_tile, dst.ctypes.data), "rc_conv_pack_weights")
     wp.copy_(torch.from_numpy(dst))
     if bias is not None:
         b_host = np.ascontiguousarray(bias.detach().float().cpu().numpy())
         bdst = np.zeros(bp.numel(), dtype=np.float32)
-        check(L.rc_conv_pack_bias(b_host.ctypes.data, cin, cout, k, dt, out_mode, bdst.ctypes.data), "rc_conv_pack_bias")
+        check(L.rc_conv_pack_bias_ct(b_host.ctypes.data, cin, cout, k, dt, out_mode, cout_tile, bdst.ctypes.data), "rc_conv_pack_bias")
         bp.copy_(torch.from_numpy(bdst))
 
 
-define("conv_pack_weights(Tensor weight, Tensor? bias, ScalarType act_dtype, int out_mode) -> (Tensor, Tensor)", _pack_alloc, _pack_launch)
+# cout_tile: cout tile width in channels (rc_conv_desc.cout_tile), 0 = automatic; the conv launch must be given the same value
+define("conv_pack_weights(Tensor weight, Tensor? bias, ScalarType act_dtype, int out_mode, int cout_tile=0) -> (Tensor, Tensor)", _pack_alloc, _pack_launch)
 
 
 def _conv_alloc(x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, film_scale, film_shift, gate, skip, store_input, out_mode,
-                want_sums, crop_h, crop_w, out_dtype, out_scale=None):
+                want_sums, crop_h, crop_w, out_dtype, out_scale=None, cout_tile=0):
     b, H, W, _ = x.shape
     if out_mode == RC_OUT_NHWC:
         out = x.new_empty((b, H, W, cout))
@@ -180,6 +181,7 @@ def _conv_alloc(x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, 
             if t is not None:
                 setattr(d, name, dummy)
         d.act, d.act_slope, d.out_mode, d.out_dtype = act, float(slope), out_mode, _DT[out.dtype]
+        d.cout_tile = cout_tile
         if out_mode in (RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW):
             d.out_h, d.out_w = out.shape[2], out.shape[3]
         n = lib().rc_conv_sum_slots(C.byref(d))
@@ -190,7 +192,7 @@ def _conv_alloc(x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, 
 
 
 def _conv_launch(outs, x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, film_scale, film_shift, gate, skip, store_input,
-                 out_mode, want_sums, crop_h, crop_w, out_dtype, out_scale=None):
+                 out_mode, want_sums, crop_h, crop_w, out_dtype, out_scale=None, cout_tile=0):
     out, stored, sums = outs
     b, H, W, cin = x.shape
     d = ConvDesc()
@@ -206,6 +208,7 @@ def _conv_launch(outs, x, wpacked, bias, cout, ksize, act, slope, residual, mul_
     d.mul_plus1, d.residual, d.out_scale = _p(mul_plus1), _p(residual), _p(out_scale)
     d.out, d.out_mode = out.data_ptr(), out_mode
     d.out_dtype = _dt(out)
+    d.cout_tile = cout_tile
     if out_mode in (RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW):
         d.out_h, d.out_w = out.shape[2], out.shape[3]
     if want_sums:
@@ -216,7 +219,7 @@ def _conv_launch(outs, x, wpacked, bias, cout, ksize, act, slope, residual, mul_
 
 define("conv2d(Tensor x, Tensor wpacked, Tensor? bias, int cout, int ksize, int act, float slope, Tensor? residual, Tensor? mul_plus1, "
        "Tensor? film_scale, Tensor? film_shift, Tensor? gate, Tensor? skip, bool store_input, int out_mode, bool want_sums, "
-       "int crop_h, int crop_w, ScalarType? out_dtype, Tensor? out_scale=None) -> (Tensor, Tensor, Tensor)", _conv_alloc, _conv_launch)
+       "int crop_h, int crop_w, ScalarType? out_dtype, Tensor? out_scale=None, int cout_tile=0) -> (Tensor, Tensor, Tensor)", _conv_alloc, _conv_launch)
 
 
 def _conv_fold2_launch(out, x, wpacked, bias, cout, act, slope):

@@ -294,6 +294,27 @@ def test_bench_path_kernels_do_not_spill_and_the_count_cannot_grow():
     assert len(spilled) <= 25, sorted((v["tu"], v["vgpr_spill"], k[:90]) for k, v in spilled.items())
 
 
+def test_cout_tile_override_packs_the_same_bytes_in_another_order():
+    """rc_conv_desc.cout_tile (ABI 11) / the *_ct packers: a caller-chosen cout tile width changes the packed ORDER ([ct][chunk][step][nt]), not the content -- same
+    byte count and the same multiset of values when the automatic width divides cout; widths the layout cannot express and the pixel-shuffle stores are rejected."""
+    lib = _lib.load()
+    cin, cout = 128, 128
+    w = np.random.default_rng(5).standard_normal((cout, cin, 3, 3)).astype(np.float32)
+    n0 = lib.rc_conv_packed_bytes(cin, cout, 3, RC_F32, RC_OUT_NHWC)
+    assert n0 == lib.rc_conv_packed_bytes_ct(cin, cout, 3, RC_F32, RC_OUT_NHWC, 0) == lib.rc_conv_packed_bytes_ct(cin, cout, 3, RC_F32, RC_OUT_NHWC, 16) > 0
+    a, b = np.empty(n0, np.uint8), np.empty(n0, np.uint8)
+    assert lib.rc_conv_pack_weights(w.ctypes.data, cin, cout, 3, RC_F32, RC_OUT_NHWC, a.ctypes.data) == 0
+    assert lib.rc_conv_pack_weights_ct(w.ctypes.data, cin, cout, 3, RC_F32, RC_OUT_NHWC, 16, b.ctypes.data) == 0
+    fa, fb = a.view(np.float32), b.view(np.float32)
+    assert not np.array_equal(fa, fb) and np.array_equal(np.sort(fa), np.sort(fb))
+    assert lib.rc_conv_packed_cout_ct(cin, cout, 3, RC_F32, RC_OUT_NHWC, 16) == cout
+    bias = np.arange(cout, dtype=np.float32)
+    pb = np.empty(cout, np.float32)
+    assert lib.rc_conv_pack_bias_ct(bias.ctypes.data, cin, cout, 3, RC_F32, RC_OUT_NHWC, 16, pb.ctypes.data) == 0 and np.array_equal(pb, bias)
+    for bad_tile, mode in ((24, RC_OUT_NHWC), (96, RC_OUT_NHWC), (16, RC_OUT_PIXEL_SHUFFLE2)):
+        assert lib.rc_conv_packed_bytes_ct(cin, cout, 3, RC_F32, mode, bad_tile) == 0
+
+
 def test_debug_knobs_have_their_documented_defaults():
     """The A/B switches the header documents (include/realcam_hip.h, rc_debug_set) read back their defaults, round-trip, and reject unknown keys: a default that
     drifted would silently change which kernel the parity tests and the bench exercise."""

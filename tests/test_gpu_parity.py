@@ -204,6 +204,40 @@ def test_wave_autonomous_kernels_equal_the_kernels_they_replace(hip, c):
         lib.rc_debug_set(b"persist_auto", 1)
 
 
+@pytest.mark.parametrize("cin,cout,shape", [(128, 128, (1, 135, 240)), (128, 128, (1, 68, 120)), (64, 128, (2, 40, 70)), (128, 256, (1, 33, 65)), (512, 128, (1, 17, 30))])
+def test_fp32_small_maps_take_narrow_cout_tiles_with_the_same_bits(hip, cin, cout, shape):
+    """fp32 3x3 layers on maps too small to fill the chip with 64-wide cout tiles run with 16-wide ones (rc_conv_desc.cout_tile, ops.small_map_cout_tile: cfg2's 128-channel
+    levels at 1080p, B = 1).  The tile width changes which block computes a channel, not the order its products are summed in: BIT-identical to the automatic width, in every
+    operand form the fp32 nets use, exact against F.conv2d on integer data, planar store included."""
+    b, H, W = shape
+    g = torch.Generator().manual_seed(cin + cout + H)
+    conv = N.Conv2d(cin, cout, 3, 1, 1).to(DEV).eval()
+    x = torch.randn(b, H, W, cin, generator=g).to(DEV)
+    res = torch.randn(b, H, W, cout, generator=g).to(DEV)
+    assert ops.SMALL_MAP_COUT_TILE and ops.small_map_cout_tile(x, conv, ops.RC_OUT_NHWC) == 16
+    def run():
+        with torch.no_grad():
+            y, sums = ops.conv2d(x, conv, act="relu", want_sums=True)
+            return (ops.conv2d(x, conv), y, sums.sum(1), ops.conv2d(x, conv, residual=res, act="leaky", slope=0.2), ops.conv2d(x, conv, out_mode=ops.RC_OUT_NCHW))
+    narrow = run()
+    ops.SMALL_MAP_COUT_TILE = False
+    try:
+        assert ops.small_map_cout_tile(x, conv, ops.RC_OUT_NHWC) == 0
+        wide = run()
+    finally:
+        ops.SMALL_MAP_COUT_TILE = True
+    for a, c in zip(narrow, wide):
+        assert torch.equal(a, c)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randint(-2, 3, conv.weight.shape, generator=g).float())
+        conv.bias.copy_(torch.randint(-3, 4, (cout,), generator=g).float())
+        ops.invalidate_caches(conv)
+        xi = torch.randint(-3, 4, (b, cin, H, W), generator=g).float()
+        ref = F.conv2d(xi, conv.weight.cpu(), conv.bias.cpu(), padding=1)
+        y = ops.conv2d(ops.to_nhwc(xi.to(DEV)), conv, out_mode=ops.RC_OUT_NCHW)
+    assert torch.equal(y.cpu(), ref)
+
+
 def test_thin_stage_kernel_equals_kernel_4(hip):
     """Kernel 4b (one barrier per stage, weights and tile by LDS-DMA two stages ahead, dense LDS pixels) against kernel 4 (`thin` 0) on the
     layers it takes over: folded stride-2 3x3 (its structurally-zero taps skipped in both), 3x3 with a 16-wide cout tile over several chunks, 16-channel
