@@ -67,6 +67,8 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
     else if (ksize == 1 && cout % 80 == 0) p->nt = 5;          // 80-wide cout tiles for the GroupMix Linears
     else if (cout % 64 == 0) p->nt = 4;
     else if (cout % 48 == 0) p->nt = 3;
+    else if (dtype == RC_BF16 && ksize == 3 && p->ck == 32 && cout % 32 == 0) p->nt = 2;   // e.g. the codec's 320..640 -> 224 slice transforms: 7 exact 32-wide tiles instead of 14
+                                                                                             // 16-wide ones (each re-staging the input): 286 -> 192 us at 576 -> 224, 8 x 72 x 120 (tools/cout_tile_probe.py)
     else p->nt = 1;
     // Caller-chosen cout tile width (rc_conv_desc.cout_tile, the *_ct packers): narrower tiles = more blocks for the general kernel on maps too small to fill the chip
     // with the automatic width (fp32 at 1080p, B = 1: 72-272 blocks of 64 couts for 256 CUs at the 128-channel levels).  Plain stores only; the packed order depends on
