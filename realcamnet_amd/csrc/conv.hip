@@ -47,6 +47,7 @@ static bool make_plan(int cin, int cout, int ksize, int dtype, int out_mode, Con
         else if (cin % 64 == 0) p->ck = 64;
         else if (cin % 48 == 0) p->ck = 48;
         else if (ksize == 3 && cin == 32) p->ck = 32;                              // the 32-channel nets (ISPUNet family): ONE chunk -> persistent kernel
+        else if (ksize == 3 && cin % 32 == 0 && cin > 64) p->ck = 32;              // 160, 224, 352 ...: half as many stages as 16-channel chunks (the codec's 224 -> 128 slice transforms)
         else p->ck = 16;
     } else {
         p->ck = cin <= 4 ? 4 : 16;
