@@ -1015,11 +1015,21 @@ template <int C> __host__ __device__ constexpr int lsc_weight_bytes(int n_mid, b
     return (C / 16) * 512 + n_mid * (C / 16) * tile_bytes(C) + (head ? (C / 16) * 1536 : 0);
 }
 
-// acc[m][nt] = W[tile m] . in with a literal-zero C operand on the first K-step (no accumulator initialisation instructions)
+// acc[m][nt] = W[tile m] . in with a literal-zero C operand on the first K-step (no accumulator initialisation instructions) -- or, with `bias` (the fp32 bias rows
+// of tiles 0 .. MT-1 for lane group g), bias + W . in: the bias as the MFMA chain's initial C operand, as rc_conv2d has it, instead of a packed add per pair of values
+// afterwards (the lens-shading chain is VALU-bound: 2.5 issues per value and layer were its 1.1 ms)
 template <int CIN, int MT>
-__device__ __forceinline__ void gemm_fresh(const char* w, int lane, const Act<CIN> (&in)[kNT], f32x4 (&acc)[MT][kNT]) {
+__device__ __forceinline__ void gemm_fresh(const char* w, int lane, const Act<CIN> (&in)[kNT], f32x4 (&acc)[MT][kNT], const float* bias = nullptr, int g = 0) {
     constexpr int KS = CIN / 32, TB = tile_bytes(CIN);
     const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const f32x4 b = bias4(bias, m, g);
+#pragma unroll
+            for (int nt = 0; nt < kNT; ++nt) acc[m][nt] = b;
+        }
+    }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         uint4 a[MT];
@@ -1029,7 +1039,7 @@ __device__ __forceinline__ void gemm_fresh(const char* w, int lane, const Act<CI
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int nt = 0; nt < kNT; ++nt) {
-                if (s == 0) { acc[m][nt] = z; }
+                if (s == 0 && bias == nullptr) { acc[m][nt] = z; }
                 mma32(a[m], in[nt].f[s], acc[m][nt]);
             }
     }
@@ -1039,7 +1049,7 @@ __device__ __forceinline__ void gemm_fresh(const char* w, int lane, const Act<CI
             const uint2 a = *reinterpret_cast<const uint2*>(w + m * TB + KS * 1024 + lane * 8);
 #pragma unroll
             for (int nt = 0; nt < kNT; ++nt) {
-                if (KS == 0) { acc[m][nt] = z; }
+                if (KS == 0 && bias == nullptr) { acc[m][nt] = z; }
                 mma16(a, in[nt].t, acc[m][nt]);
             }
         }
@@ -1047,11 +1057,11 @@ __device__ __forceinline__ void gemm_fresh(const char* w, int lane, const Act<CI
 }
 
 // fp32 accumulator tiles (+ bias [, LeakyReLU]) -> the next layer's B fragments
-template <int C, bool ACT>
+template <int C, bool ACT, bool BIASED = false>
 __device__ __forceinline__ void lsc_pack(const f32x4 (&acc)[C / 16][kNT], const float* bias, int g, float slope, Act<C> (&out)[kNT]) {
     constexpr int MT = C / 16;
     auto fin = [&](const f32x4& v, const f32x4& b) {
-        f32x4 r = v + b;
+        f32x4 r = BIASED ? v : v + b;                  // BIASED: the accumulators started from the bias (gemm_fresh)
         if constexpr (ACT) {
             const f32x4 s = r * slope;
             r = f32x4{fmaxf(r[0], s[0]), fmaxf(r[1], s[1]), fmaxf(r[2], s[2]), fmaxf(r[3], s[3])};      // 0 <= slope <= 1
@@ -1160,9 +1170,9 @@ __global__ __launch_bounds__(lsc_threads<C>(), 2) void lsc_chain_kernel(const Ls
                 const f32x4 b0 = bias4(s_b, 2 * p, g), b1 = bias4(s_b, 2 * p + 1, g);
 #pragma unroll
                 for (int nt = 0; nt < kNT; ++nt) {
-                    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+                    f32x4 a0 = b0, a1 = b1;                         // bias = the initial C operand
                     mma16(w0, in.x[nt], a0); mma16(w1, in.x[nt], a1);
-                    cur[nt].f[p] = pack_pair(leaky(a0 + b0), leaky(a1 + b1));
+                    cur[nt].f[p] = pack_pair(leaky(a0), leaky(a1));
                 }
             }
             if constexpr (MT & 1) {
@@ -1170,9 +1180,9 @@ __global__ __launch_bounds__(lsc_threads<C>(), 2) void lsc_chain_kernel(const Ls
                 const f32x4 b0 = bias4(s_b, MT - 1, g);
 #pragma unroll
                 for (int nt = 0; nt < kNT; ++nt) {
-                    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 a0 = b0;
                     mma16(w0, in.x[nt], a0);
-                    cur[nt].t = pack_tail(leaky(a0 + b0));
+                    cur[nt].t = pack_tail(leaky(a0));
                 }
             }
         }
@@ -1180,24 +1190,23 @@ __global__ __launch_bounds__(lsc_threads<C>(), 2) void lsc_chain_kernel(const Ls
         for (int l = 0; l < a.n_mid; ++l) {
             if constexpr (MT <= 4) {
                 f32x4 acc[MT][kNT];
-                gemm_fresh<C, MT>(s_mid + l * MT * TBM, lane, cur, acc);
-                if (l + 1 < a.n_mid) lsc_pack<C, true>(acc, s_b + (1 + l) * MT * 16, g, a.slope, cur);
-                else lsc_pack<C, false>(acc, s_b + (1 + l) * MT * 16, g, a.slope, cur);
+                gemm_fresh<C, MT>(s_mid + l * MT * TBM, lane, cur, acc, s_b + (1 + l) * MT * 16, g);
+                if (l + 1 < a.n_mid) lsc_pack<C, true, true>(acc, s_b + (1 + l) * MT * 16, g, a.slope, cur);
+                else lsc_pack<C, false, true>(acc, s_b + (1 + l) * MT * 16, g, a.slope, cur);
             } else {      // wide chains: 4 output tiles at a time (all MT accumulators + both activation sets do not fit 256 registers)
                 static_assert(MT % 4 == 0, "wide chain: whole groups of 4 output tiles");
                 Act<C> nxt[kNT];
 #pragma unroll
                 for (int h = 0; h < MT / 4; ++h) {
                     f32x4 acc[4][kNT];
-                    gemm_fresh<C, 4>(s_mid + (l * MT + 4 * h) * TBM, lane, cur, acc);
                     const float* bias = s_b + (1 + l) * MT * 16 + 4 * h * 16;
+                    gemm_fresh<C, 4>(s_mid + (l * MT + 4 * h) * TBM, lane, cur, acc, bias, g);
                     const bool act = l + 1 < a.n_mid;
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
-                        const f32x4 b0 = bias4(bias, 2 * p, g), b1 = bias4(bias, 2 * p + 1, g);
 #pragma unroll
                         for (int nt = 0; nt < kNT; ++nt) {
-                            f32x4 v0 = acc[2 * p][nt] + b0, v1 = acc[2 * p + 1][nt] + b1;
+                            f32x4 v0 = acc[2 * p][nt], v1 = acc[2 * p + 1][nt];
                             if (act) {
                                 const f32x4 s0 = v0 * a.slope, s1 = v1 * a.slope;
 #pragma unroll
@@ -1213,23 +1222,24 @@ __global__ __launch_bounds__(lsc_threads<C>(), 2) void lsc_chain_kernel(const Ls
         }
         if constexpr (HEAD) {   // out = (conv3x3(raw) + bias) * (lsc + 1), lsc = cur as the two-launch path would re-read it (bf16); pair by pair
             const float* hb = s_b + (1 + a.n_mid) * MT * 16;
-            auto head_tile = [&](int m, int nt) {
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto head_tile = [&](int m, int nt, const f32x4& b) {        // conv3x3(raw) + bias: the bias is the initial C operand
+                f32x4 acc = b;
                 mma32(*reinterpret_cast<const uint4*>(s_head + m * 1536 + lane * 16), in.rf[nt], acc);
                 mma16(*reinterpret_cast<const uint2*>(s_head + m * 1536 + 1024 + lane * 8), in.rt[nt], acc);
                 return acc;
             };
+            auto mulp1 = [](const f32x4& h, const f32x4& l) { return __builtin_elementwise_fma(h, l, h); };     // h (l + 1) as one packed fma per pair of values
 #pragma unroll
             for (int p = 0; p < MT / 2; ++p) {
                 const f32x4 b0 = bias4(hb, 2 * p, g), b1 = bias4(hb, 2 * p + 1, g);
 #pragma unroll
                 for (int nt = 0; nt < kNT; ++nt)
-                    cur[nt].f[p] = pack_pair((head_tile(2 * p, nt) + b0) * (up_lo(cur[nt].f[p]) + 1.f), (head_tile(2 * p + 1, nt) + b1) * (up_hi(cur[nt].f[p]) + 1.f));
+                    cur[nt].f[p] = pack_pair(mulp1(head_tile(2 * p, nt, b0), up_lo(cur[nt].f[p])), mulp1(head_tile(2 * p + 1, nt, b1), up_hi(cur[nt].f[p])));
             }
             if constexpr (MT & 1) {
                 const f32x4 b0 = bias4(hb, MT - 1, g);
 #pragma unroll
-                for (int nt = 0; nt < kNT; ++nt) cur[nt].t = pack_tail((head_tile(MT - 1, nt) + b0) * (up_tail(cur[nt].t) + 1.f));
+                for (int nt = 0; nt < kNT; ++nt) cur[nt].t = pack_tail(mulp1(head_tile(MT - 1, nt, b0), up_tail(cur[nt].t)));
             }
         }
         if constexpr (STAGE) {
