@@ -1652,11 +1652,15 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_wsm_kernel(const ConvAr
 }
 
 // ==================================================================================================
-// Kernel 4b: kernel 4 for THIN stages -- layers whose per-chunk weights are small enough (<= 20 KB) that the weights can be double-buffered whole
-// and the input tile triple-buffered: the folded stride-2 layers (ksize 2, 32-channel chunks: 64 MFMAs per wave and stage), the 16/32-wide cout tiles
-// (128 -> 12, 32 -> 16) and the 16-channel chunks.  Kernel 4's stage is two halves, each ended by a barrier that waits for an LDS-DMA of weights
-// issued at its start, with the tile's loads issued at the start of half a and written to LDS in half b: a stage cannot be shorter than two memory
-// latencies in series (measured 2.3 us per stage on the codec's folded 128 -> 128 layer, whose MFMAs need 0.85 us: 2.5 TB/s and half the matrix rate).
+// Kernel 4b: kernel 4 with ONE barrier per stage.  Kernel 4's stage is two halves, each ended by a barrier that waits for an LDS-DMA of weights issued at its
+// start, with the tile's loads issued at the start of half a and written to LDS in half b: a stage cannot be shorter than two memory latencies in series.  Where
+// the packed weights of a chunk can be double-buffered WHOLE beside the tile buffers (and the pixels can sit dense in LDS: 2- and 4-unit chunks), everything stage
+// g + 1 reads is requested at the start of stage g and waited for once.  Two forms (wst_form() below):
+//   form 3 -- THIN stages, <= 20 KB of weights a chunk: the folded stride-2 layers (ksize 2, 32-channel chunks: 64 MFMAs per wave and stage; measured 2.3 us per
+//             stage in kernel 4 where the MFMAs need 0.85), the 16/32-wide cout tiles (128 -> 12, 320 -> 224), the 16-channel chunks.  Three tile buffers, filled by
+//             LDS-DMA TWO stages ahead; the scheme drawn below.
+//   form 2 -- <= 36 KB of weights a chunk: the 64/48-wide cout tiles of the 3x3 layers over 32-channel chunks (cfg3's 128 / 192 / 512-channel levels).  Two tile
+//             buffers; the loader waves fetch tile(g+1) into registers and W(g+1) by LDS-DMA back to back, wait, write the tile, meet the barrier.
 // Here a stage is ONE barrier and nothing waits for a load younger than a stage:
 //
 //            compute waves 0-7                                          tile waves 8-11
