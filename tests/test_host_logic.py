@@ -186,3 +186,28 @@ def test_debug_knobs_are_mirrored_host_side():
     assert L.rc_debug_set(b"conv32", 4) == 0 and b"conv32" not in _lib._knobs and _lib.knob(b"conv32") == 4
     assert L.rc_debug_set(b"conv32", 0) == 0 and _lib.knob(b"conv32") == 0
     assert L.rc_debug_get(b"persist_auto") == 1                                     # default: kernel 6 for the plain / +sums forms
+
+
+def test_small_map_cout_tile_policy():
+    """ops.small_map_cout_tile: 16-wide cout tiles only for fp32 3x3 layers with 64 | cout and 16 | cin whose automatic 64-wide tiling gives the general kernel fewer
+    than two blocks per CU (256 CUs assumed without a GPU) -- cfg2's 128-channel levels at 1080p, B = 1 -- and never for bf16, pixel-shuffle stores, 1x1 or odd widths."""
+    import torch.nn as nn
+    from realcamnet_amd import ops
+    from realcamnet_amd._lib import RC_OUT_NHWC, RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2
+    conv = nn.Conv2d(128, 128, 3, 1, 1)
+    x = lambda b, h, w, c=128, dt=torch.float32: torch.empty(b, h, w, c, dtype=dt)
+    assert ops.small_map_cout_tile(x(1, 135, 240), conv, RC_OUT_NHWC) == 16            # 17 x 8 tiles x 2 cout tiles = 272 blocks < 512
+    assert ops.small_map_cout_tile(x(1, 68, 120), conv, RC_OUT_NCHW) == 16
+    assert ops.small_map_cout_tile(x(1, 270, 480), conv, RC_OUT_NHWC) == 0             # 34 x 15 x 2 = 1 020 blocks: enough
+    assert ops.small_map_cout_tile(x(8, 135, 240), conv, RC_OUT_NHWC) == 0             # a batch fills the chip
+    assert ops.small_map_cout_tile(x(1, 135, 240, dt=torch.bfloat16), conv.to(torch.bfloat16), RC_OUT_NHWC) == 0
+    assert ops.small_map_cout_tile(x(1, 135, 240), conv, RC_OUT_PIXEL_SHUFFLE2) == 0
+    assert ops.small_map_cout_tile(x(1, 135, 240), nn.Conv2d(128, 128, 1), RC_OUT_NHWC) == 0
+    assert ops.small_map_cout_tile(x(1, 135, 240), nn.Conv2d(128, 96, 3, 1, 1), RC_OUT_NHWC) == 0
+    assert ops.small_map_cout_tile(x(1, 135, 240, c=4), nn.Conv2d(4, 64, 3, 1, 1), RC_OUT_NHWC) == 0
+    old = ops.SMALL_MAP_COUT_TILE
+    try:
+        ops.SMALL_MAP_COUT_TILE = False
+        assert ops.small_map_cout_tile(x(1, 135, 240), conv, RC_OUT_NHWC) == 0
+    finally:
+        ops.SMALL_MAP_COUT_TILE = old
