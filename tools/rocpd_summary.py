@@ -24,6 +24,11 @@ def demangle(name: str) -> str:
     m = re.match(r"_ZN2rc(\d+)(conv_mfma_auto(?:64)?_kernel)INS_7ConvCfgI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)E(?:Li\d+E)*EELi(\d)E", name)
     if m:       # kernels 6 / 7: mode 0 plain epilogues, 1 carried channel sums, 2 prefetched residual
         return f"rc::{m.group(2)}<{_DT[m.group(3)]},CK={m.group(4)},NT={m.group(5)},K={m.group(6)},mode={m.group(7)}>"
+    m = re.match(r"_ZN2rc(\d+)(conv_mfma_wst_kernel)INS_7ConvCfgI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)E(?:Li\d+E)?EELb([01])E", name)
+    if m:       # kernel 4b (one barrier per stage): form 3 = tiles by LDS-DMA two stages ahead (<= 20 KB of weights a chunk), form 2 = tile through registers
+        ck, nt, k = int(m.group(4)), int(m.group(5)), int(m.group(6))
+        steps = (k * k * (ck // 8) + 3) // 4
+        return f"rc::{m.group(2)}<{_DT[m.group(3)]},CK={ck},NT={nt},K={k},form={3 if steps * nt <= 20 else 2}>"
     m = re.match(r"_ZN2rc13conv32_kernelINS_6C32CfgILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEELb([01])ELb([01])E", name)
     if m:
         return f"rc::conv32_kernel<bf16,CK={m.group(1)},TH={m.group(2)},NCW={m.group(3)},NT32={m.group(4)},gated={m.group(5)},defer={m.group(6)}>"
