@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 11
+#define RC_ABI_VERSION 12
 
 typedef enum rc_status {
     RC_OK = 0,
@@ -154,6 +154,12 @@ typedef struct rc_conv_desc {
      * general kernel more blocks on maps too small to fill the chip (fp32 128 -> 128 at 135 x 240, B = 1: 272 blocks of 64 couts for 256 CUs; 16-wide tiles: 1 088).
      * The packed order depends on it: pack weights and bias with rc_conv_pack_weights_ct / rc_conv_pack_bias_ct and the SAME value.  Plain NHWC / NCHW stores, ksize 1 / 3. */
     int32_t cout_tile;
+    /* ABI 12: 0 = the implicit GEMM (every shape above).  1 = Winograd F(2x2, 3x3) (csrc/wino.hip): the same stride-1 3x3 convolution with 2.25x fewer
+     * multiplications -- 16 products M_xi = U_xi V_xi per 2x2 output tile, U = G g G^T packed by rc_wino_pack_weights (NOT rc_conv_pack_weights), V = B^T d B and
+     * Y = A^T M A formed in registers.  fp32, ksize 3, cin % 8 == 0, cout % 16 == 0, RC_OUT_NHWC; bias / film vectors in NATURAL channel order (no rc_conv_pack_bias);
+     * epilogue: bias, film, act (none / relu / leaky / relu_post), out_scale, residual, chan_sums (rc_conv_sum_slots(desc) slots); no gated input, mul_plus1, GELU,
+     * cout_tile or src_h.  Anything else returns RC_ERR_UNSUPPORTED.  Results differ from algo 0 by fp32 rounding only (exact on small-integer data). */
+    int32_t algo;
 } rc_conv_desc;
 
 /* Size in bytes of the packed weight buffer for (cin,cout,ksize,dtype,out_mode); 0 on error. */
@@ -172,6 +178,10 @@ size_t rc_conv_packed_bytes_ct(int cin, int cout, int ksize, int dtype, int out_
 int rc_conv_packed_cout_ct(int cin, int cout, int ksize, int dtype, int out_mode, int cout_tile);
 int rc_conv_pack_weights_ct(const float* w_oihw_host, int cin, int cout, int ksize, int dtype, int out_mode, int cout_tile, void* dst_host);
 int rc_conv_pack_bias_ct(const float* bias_host, int cin, int cout, int ksize, int dtype, int out_mode, int cout_tile, float* dst_host);
+/* Winograd form (rc_conv_desc.algo == 1): bytes of the packed U = G g G^T buffer (16 * cin * cout elements; 0 on an unsupported shape) and the host-side packer
+ * (w_oihw: host fp32 (cout, cin, 3, 3); products accumulated in double, rounded once). */
+size_t rc_wino_packed_bytes(int cin, int cout, int dtype);
+int rc_wino_pack_weights(const float* w_oihw_host, int cin, int cout, int dtype, void* dst_host);
 /* Number of partial-sum slots per image the conv kernel writes to chan_sums (4 waves per 8x32 tile; depends only on H,W). */
 int rc_conv_sum_tiles(int height, int width);
 /* Slots per image the launch described by `d` fills in chan_sums (pointers are only tested for NULL; d->chan_sums_slots is ignored): the answer comes from

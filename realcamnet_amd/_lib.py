@@ -17,7 +17,7 @@ HEADER = PKG.parent / "include" / "realcam_hip.h"
 RC_F32, RC_BF16, RC_U16 = 0, 1, 2
 RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY, RC_ACT_GELU, RC_ACT_RELU_POST = 0, 1, 2, 3, 4
 RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW = 0, 1, 2, 3
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class ConvDesc(C.Structure):
@@ -37,6 +37,7 @@ class ConvDesc(C.Structure):
         ("src_h", C.c_int32), ("src_w", C.c_int32),
         ("out_scale", C.c_void_p),
         ("chan_sums_slots", C.c_int32), ("cout_tile", C.c_int32),
+        ("algo", C.c_int32),
     ]
 
 
@@ -76,6 +77,8 @@ _SIGS = {
     "rc_conv_packed_cout": (C.c_int, [_I, _I, _I, _I, _I]),
     "rc_conv_pack_bias": (C.c_int, [_P, _I, _I, _I, _I, _I, _P]),
     "rc_conv_packed_bytes_ct": (_SZ, [_I, _I, _I, _I, _I, _I]),
+    "rc_wino_packed_bytes": (_SZ, [_I, _I, _I]),
+    "rc_wino_pack_weights": (C.c_int, [_P, _I, _I, _I, _P]),
     "rc_conv_packed_cout_ct": (C.c_int, [_I, _I, _I, _I, _I, _I]),
     "rc_conv_pack_weights_ct": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _P]),
     "rc_conv_pack_bias_ct": (C.c_int, [_P, _I, _I, _I, _I, _I, _I, _P]),

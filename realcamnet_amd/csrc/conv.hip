@@ -120,6 +120,11 @@ static int packed_to_cout(const ConvPlan& p, int cout, int out_mode, int j) {
     return j < cout ? j : -1;
 }
 
+// wino.hip: Winograd F(2x2, 3x3) (rc_conv_desc.algo == 1)
+int wino_conv(const rc_conv_desc* d, hipStream_t stream);
+int wino_sum_slots(int H, int W);
+bool wino_supported(const rc_conv_desc* d, std::string* why);
+
 static int g_dbg_flags = 0;
 static int g_pair_impl = 0;         // rc_debug_set("pair_impl", v): 0 = the faster one per form (gated: the first pair kernel; else pair2), 1 = the first pair kernel
                                    // (weights in LDS, 8 + 4 waves), 2 = pair2 (weights in registers, two teams of four waves)
@@ -466,6 +471,12 @@ static int conv_build_args(const rc_conv_desc* d, ConvPlan& p, ConvArgs& a, size
 }
 
 int rc_conv2d(const rc_conv_desc* d, void* stream_) {
+    RC_REQUIRE(d != nullptr, "rc_conv2d: null desc");
+    RC_REQUIRE(d->algo == 0 || d->algo == 1, "rc_conv2d: algo must be 0 (implicit GEMM) or 1 (Winograd F(2x2,3x3))");
+    if (d->algo == 1) {
+        if (g_poison) { if (int e = rc_debug_poison_lds(0x7FC07FC0u, stream_)) return e; }
+        return wino_conv(d, as_stream(stream_));
+    }
     ConvPlan p;
     ConvArgs a;
     size_t es = 0;
@@ -488,6 +499,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
 }
 
 int rc_conv_sum_slots(const rc_conv_desc* d) {
+    if (d != nullptr && d->algo == 1) return wino_supported(d, nullptr) ? wino_sum_slots(d->height, d->width) : -1;
     ConvPlan p;
     ConvArgs a;
     size_t es = 0;

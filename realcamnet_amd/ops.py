@@ -494,6 +494,43 @@ def small_map_cout_tile(x: torch.Tensor, mod, out_mode: int) -> int:
     return 16 if blocks < _SMALL_MAP_FACTOR * cus else 0
 
 
+# Winograd F(2x2, 3x3) for the stride-1 3x3 layers (rc_conv_desc.algo = 1, csrc/wino.hip): 2.25x fewer multiplications; fp32 results differ from the implicit GEMM's by
+# rounding only.  RC_WINOGRAD=0 (or ops.WINOGRAD = False) keeps every layer on the implicit GEMM (A/B runs, tests).
+WINOGRAD = os.environ.get("RC_WINOGRAD", "1") != "0"
+
+
+def winograd_ok(x: torch.Tensor, mod, *, act=None, gate=None, skip=None, mul_plus1=None, out_mode: int = RC_OUT_NHWC, store_input: bool = False) -> bool:
+    """Does this conv call take the Winograd form?  fp32 3x3 stride-1 layers with cin % 8 == 0 and cout % 16 == 0, a plain NHWC store and the
+    epilogue forms the kernel has (bias, film, none / relu / leaky / relu_post, out_scale, residual, channel sums)."""
+    w = mod.weight
+    if not WINOGRAD or x.dtype != torch.float32 or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
+        return False
+    if w.shape[1] % 8 != 0 or w.shape[0] % 64 != 0 or out_mode != RC_OUT_NHWC:       # the library also runs cout % 16 == 0 (narrower blocks: one wave per SIMD); the
+        return False                                                                    # measured win is on the 64-cout-per-block form (tools/wino_probe.py)
+    if gate is not None or skip is not None or mul_plus1 is not None or store_input or act == "gelu":
+        return False
+    return True
+
+
+def packed_wino(mod, act_dtype: torch.dtype) -> PackedConv:
+    """U = G g G^T of a 3x3 conv in the Winograd kernel's fragment order (realcam::wino_pack_weights) + its bias in natural order, cached on the module."""
+    w, b = mod.weight, mod.bias
+    c = _cache(mod)
+    k = ("wino", act_dtype)
+    key = _key(w, b)
+    hit = c.get(k)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if not w.is_cuda:
+        raise RuntimeError("conv weights are not on a HIP device; move the module with .cuda() first")
+    pc = PackedConv()
+    pc.wpacked = _R.wino_pack_weights(w.detach(), act_dtype)
+    pc.bias = b.detach().float().contiguous() if b is not None else None
+    pc.cout, pc.cin, pc.ksize, pc.dtype, pc.out_mode = w.shape[0], w.shape[1], 3, _DT[act_dtype], RC_OUT_NHWC
+    c[k] = (key, pc)
+    return pc
+
+
 def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.0,
            residual: Optional[torch.Tensor] = None, mul_plus1: Optional[torch.Tensor] = None,
            film: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
@@ -512,8 +549,13 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
         check_conv_module(mod)
     x = _req(x, "conv input")
     b, H, W, cin = x.shape
-    ct = small_map_cout_tile(x, mod, out_mode)
-    pc = packed_conv(mod, x.dtype, out_mode, ct)
+    algo = 1 if mod.weight.dim() == 4 and winograd_ok(x, mod, act=act, gate=gate, skip=skip, mul_plus1=mul_plus1, out_mode=out_mode, store_input=store_input) else 0
+    if algo:
+        ct = 0
+        pc = packed_wino(mod, x.dtype)
+    else:
+        ct = small_map_cout_tile(x, mod, out_mode)
+        pc = packed_conv(mod, x.dtype, out_mode, ct)
     if cin != pc.cin:
         raise ValueError(f"conv expects {pc.cin} input channels, got {cin}")
     if gate is not None:
@@ -545,7 +587,7 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
         _DT[out_dtype]
     out, stored, sums = _R.conv2d(x, pc.wpacked, pc.bias, pc.cout, pc.ksize, _ACT[act], float(slope), residual, mul_plus1, fs, ft, gate, skip,
                                   bool(store_input), int(out_mode), bool(want_sums), int(ch), int(cw),
-                                  out_dtype if planar else None, out_scale, ct)
+                                  out_dtype if planar else None, out_scale, ct, algo)
     extras = [t for t in (_opt(stored), _opt(sums)) if t is not None]
     return (out, *extras) if extras else out
 

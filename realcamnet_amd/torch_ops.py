@@ -153,8 +153,28 @@ def _pack_launch(outs, weight, bias, act_dtype, out_mode, cout_tile=0):
 define("conv_pack_weights(Tensor weight, Tensor? bias, ScalarType act_dtype, int out_mode, int cout_tile=0) -> (Tensor, Tensor)", _pack_alloc, _pack_launch)
 
 
+def _wino_pack_alloc(weight, act_dtype):
+    cout, cin, k = _wshape(weight)
+    nbytes = lib().rc_wino_packed_bytes(cin, cout, _DT[act_dtype]) if k == 3 else 0
+    if nbytes == 0:
+        raise _lib.HipError(f"rc_wino_packed_bytes: {lib().rc_last_error().decode() if k == 3 else 'a 3x3 form'}")
+    return weight.new_empty((nbytes,), dtype=torch.uint8)
+
+
+def _wino_pack_launch(out, weight, act_dtype):
+    cout, cin, _ = _wshape(weight)
+    w_host = np.ascontiguousarray(weight.detach().float().cpu().numpy())
+    dst = np.empty(out.numel(), dtype=np.uint8)
+    check(lib().rc_wino_pack_weights(w_host.ctypes.data, cin, cout, _DT[act_dtype], dst.ctypes.data), "rc_wino_pack_weights")
+    out.copy_(torch.from_numpy(dst))
+
+
+# Winograd F(2x2, 3x3) form of a 3x3 conv (rc_conv_desc.algo = 1): U = G g G^T in MFMA fragment order; bias / film vectors stay in natural order
+define("wino_pack_weights(Tensor weight, ScalarType act_dtype) -> Tensor", _wino_pack_alloc, _wino_pack_launch)
+
+
 def _conv_alloc(x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, film_scale, film_shift, gate, skip, store_input, out_mode,
-                want_sums, crop_h, crop_w, out_dtype, out_scale=None, cout_tile=0):
+                want_sums, crop_h, crop_w, out_dtype, out_scale=None, cout_tile=0, algo=0):
     b, H, W, _ = x.shape
     if out_mode == RC_OUT_NHWC:
         out = x.new_empty((b, H, W, cout))
@@ -182,6 +202,7 @@ def _conv_alloc(x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, 
                 setattr(d, name, dummy)
         d.act, d.act_slope, d.out_mode, d.out_dtype = act, float(slope), out_mode, _DT[out.dtype]
         d.cout_tile = cout_tile
+        d.algo = algo
         if out_mode in (RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW):
             d.out_h, d.out_w = out.shape[2], out.shape[3]
         n = lib().rc_conv_sum_slots(C.byref(d))
@@ -192,7 +213,7 @@ def _conv_alloc(x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, 
 
 
 def _conv_launch(outs, x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, film_scale, film_shift, gate, skip, store_input,
-                 out_mode, want_sums, crop_h, crop_w, out_dtype, out_scale=None, cout_tile=0):
+                 out_mode, want_sums, crop_h, crop_w, out_dtype, out_scale=None, cout_tile=0, algo=0):
     out, stored, sums = outs
     b, H, W, cin = x.shape
     d = ConvDesc()
@@ -209,6 +230,7 @@ def _conv_launch(outs, x, wpacked, bias, cout, ksize, act, slope, residual, mul_
     d.out, d.out_mode = out.data_ptr(), out_mode
     d.out_dtype = _dt(out)
     d.cout_tile = cout_tile
+    d.algo = algo
     if out_mode in (RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW):
         d.out_h, d.out_w = out.shape[2], out.shape[3]
     if want_sums:
@@ -219,7 +241,7 @@ def _conv_launch(outs, x, wpacked, bias, cout, ksize, act, slope, residual, mul_
 
 define("conv2d(Tensor x, Tensor wpacked, Tensor? bias, int cout, int ksize, int act, float slope, Tensor? residual, Tensor? mul_plus1, "
        "Tensor? film_scale, Tensor? film_shift, Tensor? gate, Tensor? skip, bool store_input, int out_mode, bool want_sums, "
-       "int crop_h, int crop_w, ScalarType? out_dtype, Tensor? out_scale=None, int cout_tile=0) -> (Tensor, Tensor, Tensor)", _conv_alloc, _conv_launch)
+       "int crop_h, int crop_w, ScalarType? out_dtype, Tensor? out_scale=None, int cout_tile=0, int algo=0) -> (Tensor, Tensor, Tensor)", _conv_alloc, _conv_launch)
 
 
 def _conv_fold2_launch(out, x, wpacked, bias, cout, act, slope):
