@@ -125,14 +125,40 @@ def encode(symbols: torch.Tensor, indexes: torch.Tensor, tables: Tables, fmt: st
         return out[:nb].tobytes()
     if fmt != "chunked":
         raise ValueError(f"unknown stream format {fmt!r}")
-    words, nbytes = _R.rans_encode_chunks(symbols, indexes, tables.cdf, tables.sizes, tables.offsets, int(chunk))
-    if int(nbytes.min()) < 0:
-        raise _lib.HipError("rc_rans_encode_chunks: CDF index out of range")
-    ends = torch.cumsum(nbytes.to(torch.int64), 0)
-    total = int(ends[-1])
-    payload = _R.rans_compact(words, nbytes, (ends - nbytes).contiguous(), int(chunk), total)
-    sizes = nbytes.cpu().numpy().astype("<u4")
-    return struct.pack("<4sIII", MAGIC, n, int(chunk), sizes.size) + sizes.tobytes() + payload.cpu().numpy().tobytes()
+    return finish([encode_async(symbols, indexes, tables, chunk)])[0]
+
+
+class PendingStream:
+    """A "chunked" container whose chunk streams have been coded on the device but not yet read back (encode_async -> finish)."""
+    __slots__ = ("words", "nbytes", "ends", "n", "chunk")
+
+
+def encode_async(symbols: torch.Tensor, indexes: torch.Tensor, tables: Tables, chunk: int = DEFAULT_CHUNK) -> PendingStream:
+    """The device half of encode(fmt="chunked"): every chunk coded into the word arena, byte counts and their running sum on the device.  No host sync:
+    the codec enqueues the whole slice loop this way and calls finish() once (upstream models/tcm.py:515-570 hands every slice to the host coder in turn)."""
+    symbols, indexes = symbols.reshape(-1).contiguous(), indexes.reshape(-1).contiguous()
+    p = PendingStream()
+    p.n, p.chunk = symbols.numel(), int(chunk)
+    p.words, p.nbytes = _R.rans_encode_chunks(symbols, indexes, tables.cdf, tables.sizes, tables.offsets, p.chunk)
+    p.ends = torch.cumsum(p.nbytes.to(torch.int64), 0)
+    return p
+
+
+def finish(pending: List[PendingStream]) -> List[bytes]:
+    """The host half: ONE sync for all pending containers (their chunk byte counts in one transfer), then compaction + read-back of each payload."""
+    if not pending:
+        return []
+    counts = torch.cat([p.nbytes for p in pending]).cpu().numpy()          # the sync
+    out, pos, payloads = [], 0, []
+    for p in pending:
+        sizes = counts[pos:pos + p.nbytes.numel()]
+        pos += p.nbytes.numel()
+        if int(sizes.min()) < 0:
+            raise _lib.HipError("rc_rans_encode_chunks: CDF index out of range")
+        total = int(sizes.astype(np.int64).sum())
+        payloads.append(_R.rans_compact(p.words, p.nbytes, (p.ends - p.nbytes).contiguous(), p.chunk, total))
+        out.append((p, sizes.astype("<u4")))
+    return [struct.pack("<4sIII", MAGIC, p.n, p.chunk, sizes.size) + sizes.tobytes() + pl.cpu().numpy().tobytes() for (p, sizes), pl in zip(out, payloads)]
 
 
 class Decoder:
@@ -144,10 +170,24 @@ class Decoder:
         self.buf = np.frombuffer(stream, dtype=np.uint8)
         self.pos = 0
         self.state = (C.c_ulonglong * 2)(0, 0)
+        self.errs: List[torch.Tensor] = []          # device error flags of decode_async launches not yet looked at (check())
         if fmt == "compressai":
             self.buf = np.ascontiguousarray(self.buf)
 
-    def decode(self, indexes: torch.Tensor) -> torch.Tensor:
+    def check(self) -> None:
+        """Look at the error flags of every decode_async() since the last check (one sync)."""
+        errs, self.errs = self.errs, []
+        if errs:
+            e = int(torch.cat(errs).max().item())
+            if e:
+                raise _lib.HipError("rc_rans_decode_chunks: " + ("CDF index out of range" if e == 1 else "truncated or corrupt stream"))
+
+    def decode_async(self, indexes: torch.Tensor) -> torch.Tensor:
+        """decode() without the host's look at the kernel's error flag ("chunked" only; the container is still validated on the host first): the symbols may be
+        consumed by further launches at once, check() must be called before the result is trusted."""
+        return self.decode(indexes, _async=True)
+
+    def decode(self, indexes: torch.Tensor, _async: bool = False) -> torch.Tensor:
         indexes = indexes.reshape(-1).contiguous()
         n = indexes.numel()
         if self.fmt == "compressai":
@@ -177,4 +217,8 @@ class Decoder:
         payload = torch.from_numpy(self.buf[p:p + total].copy()).to(self.device)
         offsets = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)).to(self.device)
         self.pos = p + total
+        if _async:
+            sym, err = _R.rans_decode_chunks_async(payload, offsets, indexes, self.tables.cdf, self.tables.sizes, self.tables.offsets, int(chunk))
+            self.errs.append(err)
+            return sym
         return _R.rans_decode_chunks(payload, offsets, indexes, self.tables.cdf, self.tables.sizes, self.tables.offsets, int(chunk))

@@ -143,10 +143,11 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     return LIB
 
 
-def build_variant(name: str, defines, only=("wino.hip",)) -> Path:
+def build_variant(name: str, defines, only=None) -> Path:
     """Kernel experiments: recompile `only` with extra -D flags and link them with the library's other objects into realcamnet_amd/_alt/lib_<name>.so
     (select it with RC_HIP_LIB=...; git-ignored, travels with gpurun)."""
     build(verbose=False)
+    only = only or tuple(os.environ.get("RC_VARIANT_TUS", "wino.hip").split(","))
     alt = PKG / "_alt"
     alt.mkdir(exist_ok=True)
     hipcc = _hipcc()

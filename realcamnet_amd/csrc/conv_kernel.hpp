@@ -2156,8 +2156,12 @@ __global__ __launch_bounds__(kWsmThreads) void conv_mfma_pss_kernel(const ConvAr
 // cout tiles) with a PRIVATE 4 x 34 halo strip in LDS (13 KB; 8 x 13 + 43 KB of weights), loads it itself (13 x 16 B per lane,
 // prefetched one strip ahead in registers), and never meets another wave after the block's first barrier: no barrier in the loop,
 // 8 strips = 104 KB of loads in flight per CU instead of 65 KB, and the waves drift apart instead of marching in two groups.
-// The price is halo traffic through L2 -> LDS: 136 halo pixels per 64 outputs (2.1x) instead of 340 per 256 (1.33x) -- rows shared
-// with the neighbouring strips are read by sibling waves of the same CU at about the same time (L2 hits; HBM traffic unchanged).
+// The price is halo traffic through L2 -> LDS: 136 halo pixels per 64 outputs (2.1x) instead of 340 per 256 (1.33x) -- and, because free-running
+// waves drift apart by more than the L2 keeps a row (each XCD's 4 MB also holds the layer's write stream), a good part of those re-reads comes from
+// BEYOND L2: FETCH_SIZE x 2 = 1.54x the input map in mode 0 and 1.39x in mode 1, where kernel 2 reads 1.00x (profiles/r05_pmc_bench.json, r06_kernel6_fetch.md).
+// Round 6 measured what that costs: with the waves held together (one s_barrier per region, or a ticket that bounds the drift to one region) the
+// ratio falls to 1.02-1.09x and the launch takes THE SAME time in mode 0 (772 vs 773 us) and 3 % MORE in mode 1 (817 vs 795 us): the 0.5-0.8 GB of
+// extra HBM reads per launch are not what paces these layers.  Mode 0 keeps the barrier (free, fewer bytes), modes 1 / 2 run free.
 // Same unit map, same MFMA chain, same epilogues (a strip IS wave j & 3 of an ordinary 8 x 32 tile) -> bit-identical to kernels 1-4.
 // Every load of the loop is issued unconditionally (out-of-range strips load from offset kOOB = no memory access), so hipcc can count
 // them; per-image vectors an epilogue needs (the CALayer gate of key EP_GATE | EP_RES) are copied to LDS once per block: a global load
@@ -2284,6 +2288,10 @@ __global__ __launch_bounds__(kAutoThreads) void conv_mfma_auto_kernel(const Conv
     [[maybe_unused]] int covered = 0;                                // compact sums: images [0, covered) have this wave's slot written (a run total or zeros)
 
     while (cu >= 0) {
+        // MODE 0 only: the eight waves meet once per region, so the rows two neighbouring strips share are fetched within one region's time of each other and
+        // the second fetch hits L2 (see the header: 1.54x -> 1.02x of the input from beyond L2, same time).  A wave that has run out of strips has ended and is
+        // not waited for; a wave that skipped a region (bottom band) is one region ahead from then on -- ordering only, never correctness.
+        if constexpr (MODE == 0) __builtin_amdgcn_s_barrier();
         // ---- commit: the strip's units, registers -> this wave's LDS strip (the same wave reads them back: program order, no barrier)
 #pragma unroll
         for (int k = 0; k < NI; ++k) {

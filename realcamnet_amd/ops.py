@@ -74,7 +74,7 @@ def invalidate_caches(module) -> None:
     """Drop every derived-parameter cache (packed MFMA weights, fp32 views, folded BatchNorm, CDF tables ...) below `module`.
     load_state_dict / optimizer steps / .to() are detected automatically; edits through `.data` are not."""
     for m in module.modules():
-        for k in ("_rc_cache", "_pk", "_eff", "_coder_tables", "_f32_masters"):
+        for k in ("_rc_cache", "_pk", "_eff", "_coder_tables", "_f32_masters", "_graphs", "_f32_verdict"):
             m.__dict__.pop(k, None)
 
 
@@ -710,6 +710,7 @@ def pointwise_chain(x: torch.Tensor, convs, slope: float) -> torch.Tensor:
     return _R.pointwise_chain48(x, p0.wpacked, p0.bias, [p.wpacked for p in packs], [p.bias for p in packs], float(slope))
 
 
+GRAPH_FORK = True            # keep the two-stream forks as graph branches under HIP-graph capture (False: one stream inside a capture)
 BRANCH_STREAMS = True        # run independent small sub-graphs (the codec's mean / scale branches, the ISP nets' colour prior) on two HIP streams
 _SIDE_STREAMS = {}
 
@@ -725,10 +726,16 @@ def fork_join(side_fn, main_fn, inputs):
     current stream, main_fn on the current stream, which then waits for the side stream.  `inputs`: tensors side_fn reads (the caching
     allocator is told about the second stream; the side branch's outputs likewise).  Calls NEST: a fork inside either branch of another gets a
     side stream of its own (one per position in the call tree), so the codec's slice loop runs mean || scale and, inside each, conv_a || conv_b
-    as four concurrent chains of small launches.  One stream under graph capture, fake tensors or BRANCH_STREAMS = False."""
+    as four concurrent chains of small launches.  One stream under fake tensors or BRANCH_STREAMS = False.
+    Under HIP-graph capture the fork becomes two branches of the graph (the side stream joins the capture through wait_stream); the allocator's
+    record_stream bookkeeping is skipped there: a capture's private pool is not reused across streams before the join, and every side tensor is
+    consumed on the main stream only after it."""
     from torch._subclasses.fake_tensor import FakeTensor
     probe = inputs[0]
-    if not BRANCH_STREAMS or not probe.is_cuda or isinstance(probe, FakeTensor) or torch.cuda.is_current_stream_capturing():
+    if not BRANCH_STREAMS or not probe.is_cuda or isinstance(probe, FakeTensor):
+        return side_fn(), main_fn()
+    capturing = torch.cuda.is_current_stream_capturing()
+    if capturing and not GRAPH_FORK:
         return side_fn(), main_fn()
     path = getattr(_FORK_PATH, "p", "")
     if len(path) >= FORK_DEPTH:                          # depth cap: 8 streams are plenty for 256 CUs (1 = round 4's single fork)
@@ -739,8 +746,9 @@ def fork_join(side_fn, main_fn, inputs):
     if side is None:
         side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=probe.device)
     side.wait_stream(main)
-    for t in inputs:
-        t.record_stream(side)
+    if not capturing:
+        for t in inputs:
+            t.record_stream(side)
     try:
         _FORK_PATH.p = path + "s"
         with torch.cuda.stream(side):
@@ -750,8 +758,9 @@ def fork_join(side_fn, main_fn, inputs):
     finally:
         _FORK_PATH.p = path
     main.wait_stream(side)
-    for t in (a if isinstance(a, (tuple, list)) else (a,)):
-        t.record_stream(main)
+    if not capturing:
+        for t in (a if isinstance(a, (tuple, list)) else (a,)):
+            t.record_stream(main)
     return a, b
 
 

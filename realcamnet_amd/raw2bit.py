@@ -370,11 +370,14 @@ class raw_compression_tcm_final(nn.Module):
         dt = self._act_dtype()
         return self._analysis(ops.to_nhwc(raw, dtype=dt), cond, ops.to_nhwc(coord, dtype=dt))[0]
 
-    def compress(self, x, fmt: str = "chunked", chunk: int = T.bitstream.DEFAULT_CHUNK):
+    def compress(self, x, fmt: str = "chunked", chunk: int = T.bitstream.DEFAULT_CHUNK, graph: bool = False):
         """upstream models/raw2bit.py:1876-1944: x = [raw, cond, coord] -> {"strings": [y_strings, z_strings], "shape"} (one string per
-        image; fmt "chunked": GPU coder, "compressai": one CompressAI-layout stream per image)."""
+        image; fmt "chunked": GPU coder, "compressai": one CompressAI-layout stream per image).  graph (chunked only): the analysis transform and the
+        slice loop replayed as ONE HIP graph captured per input shape (tcm._codec_compress_graphed): the same strings in less host time at low batch."""
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        if graph and fmt == "chunked":
+            return T._codec_compress_graphed(self, lambda r, c, k: self._latent([r, c, k]), [ops._req(t, "x") for t in x[:3]], chunk)
         return T._codec_compress(self, self._latent(x), fmt, chunk)
 
     def decompress(self, strings, shape, fmt: str = "chunked"):

@@ -433,9 +433,15 @@ class _Fp32Masters:
         if live.dtype == torch.float32 or m is None or m.shape != live.shape:
             return live.detach().float()
         m = m.to(live.device)
-        if not torch.equal(m.to(live.dtype), live.detach()):          # the low-precision tensor was written after the cast: it is the truth, the master is stale
-            return live.detach().float()
-        return m
+        # Is the live low-precision tensor still the master's rounding?  A value written after the cast is the truth and the master stale.  The comparison
+        # costs a full-tensor compare and a host sync (and cannot run under HIP-graph capture), so its verdict is remembered per write generation of the live
+        # tensor: `_version` moves on every in-place write (`.data` edits do not move it: ops.invalidate_caches(module) after those, as for packed weights).
+        key = (live.data_ptr(), live._version, live.dtype, str(live.device))
+        verdicts = self.__dict__.setdefault("_f32_verdict", {})
+        hit = verdicts.get(name)
+        if hit is None or hit[0] != key:
+            hit = verdicts[name] = (key, bool(torch.equal(m.to(live.dtype), live.detach())))
+        return m if hit[1] else live.detach().float()
 
     def _apply(self, fn, recurse=True):
         masters = self.__dict__.setdefault("_f32_masters", {})
@@ -465,6 +471,13 @@ class _Fp32Masters:
                 masters[n] = masters[n].to(new.device)
                 if n in self._buffers:                                # a buffer (scale_table) simply stays fp32: the state_dict keeps exact values
                     self._buffers[n] = masters.pop(n)
+        # a master that survived this cast IS the new live tensor's source (also across bf16 -> fp16, whose double rounding a value compare would misread)
+        verdicts = self.__dict__.setdefault("_f32_verdict", {})
+        verdicts.clear()
+        for n, m in masters.items():
+            live = getattr(self, n)
+            if live.dtype != torch.float32 and m.shape == live.shape:
+                verdicts[n] = ((live.data_ptr(), live._version, live.dtype, str(live.device)), True)
         self.__dict__.pop("_coder_tables", None)
         return out
 
@@ -518,14 +531,26 @@ class EntropyBottleneck(_Fp32Masters, nn.Module):
         tables = _coder_tables(self)
         return [bitstream.encode(sym[i], idx[i], tables, fmt, chunk) for i in range(b)], z_hat
 
-    def _decompress_nhwc(self, strings, size, dtype, fmt="chunked"):
+    def _compress_nhwc_async(self, z, chunk=bitstream.DEFAULT_CHUNK):
+        """_compress_nhwc(fmt="chunked") without the read-back: (pending containers, one per image; z_hat) -- bitstream.finish() turns them into strings."""
+        b, h, w, c = z.shape
+        med = self._master("quantiles")[:, 0, 1].contiguous()
+        sym, idx, z_hat = torch.ops.realcam.eb_symbols(ops._req(z, "z"), None, med, b, h, w, z.dtype)
+        tables = _coder_tables(self)
+        return [bitstream.encode_async(sym[i], idx[i], tables, chunk) for i in range(b)], z_hat
+
+    def _decompress_nhwc(self, strings, size, dtype, fmt="chunked", _decoders=None):
         h, w = size
         b, c = len(strings), self.channels
         dev = self.quantiles.device
         med = self._master("quantiles")[:, 0, 1].contiguous()
         tables = _coder_tables(self)
         idx = torch.arange(c, dtype=torch.int32, device=dev).view(c, 1).expand(c, h * w).contiguous()
-        sym = torch.stack([bitstream.Decoder(s, tables, dev, fmt).decode(idx).view(c, h * w) for s in strings])
+        if _decoders is not None and fmt == "chunked":          # the codec's decompress: error flags looked at once, at its end
+            _decoders.extend(bitstream.Decoder(s, tables, dev, fmt) for s in strings)
+            sym = torch.stack([d.decode_async(idx).view(c, h * w) for d in _decoders[-b:]])
+        else:
+            sym = torch.stack([bitstream.Decoder(s, tables, dev, fmt).decode(idx).view(c, h * w) for s in strings])
         return torch.ops.realcam.eb_symbols(None, sym, med, b, h, w, dtype)[2]
 
     def compress(self, x, fmt="chunked"):
@@ -629,6 +654,7 @@ def _codec_update(self, scale_table=None, force: bool = False) -> bool:
     for mod in self.modules():
         if isinstance(mod, EntropyBottleneck):
             updated |= mod.update(force=force)
+    self.__dict__.pop("_graphs", None)               # captured compress graphs hold the old tables' addresses
     return updated
 
 
@@ -691,13 +717,16 @@ class TCM(nn.Module):
     update = _codec_update
     load_state_dict = _codec_load_state_dict
 
-    def compress(self, x, fmt: str = "chunked", chunk: int = bitstream.DEFAULT_CHUNK):
+    def compress(self, x, fmt: str = "chunked", chunk: int = bitstream.DEFAULT_CHUNK, graph: bool = False):
         """upstream models/tcm.py:511-570: x (B,3,H,W) -> {"strings": [y_strings, z_strings], "shape": z spatial size}; one string per
         image in each list.  fmt "chunked" (GPU coder) or "compressai" (one stream per image in CompressAI's layout, host coder).
         chunk: symbols per independent rANS stream of the chunked format -- a field of every container's header, so decompress() needs no argument;
-        shorter chunks decode faster (more parallel lanes) and cost a 64-bit state flush + a 4-byte size each."""
+        shorter chunks decode faster (more parallel lanes) and cost a 64-bit state flush + a 4-byte size each.
+        graph (chunked only): replay the device half as a HIP graph captured per input shape (_codec_compress_graphed) -- same strings, less host time."""
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
+        if graph and fmt == "chunked":
+            return _codec_compress_graphed(self, lambda t: self.g_a._nhwc(ops.to_nhwc(t, dtype=self._act_dtype())), [ops._req(x, "x")], chunk)
         return _codec_compress(self, self.g_a._nhwc(ops.to_nhwc(x, dtype=self._act_dtype())), fmt, chunk)
 
     def decompress(self, strings, shape, fmt: str = "chunked"):
@@ -751,38 +780,83 @@ def _refine(m, i, mean_support, y_hat_slice):
     return ops.tanh_half_add(y_hat_slice, m.lrp_transforms[i]._nhwc(ops.channel_concat([mean_support, y_hat_slice])))
 
 
-def _codec_compress(m, y, fmt, chunk=bitstream.DEFAULT_CHUNK):
-    """Shared by TCM.compress and raw_compression_tcm_final.compress (models/tcm.py:515-570, raw2bit.py:1901-1944): y NHWC latent ->
-    strings.  The symbols and CDF indexes of every slice are produced on the device (realcam::gc_symbols); "chunked": every slice
-    becomes one container of GPU-coded chunk streams, an image's y string is the concatenation of its slices' containers;
-    "compressai": the slices' symbols are concatenated and coded as ONE stream per image, as upstream's single BufferedRansEncoder."""
+def _codec_compress_device(m, y, chunk):
+    """The device half of compress(fmt="chunked"): h_a, the bottleneck's symbols, the hyper-synthesis and the slice loop, every container coded into its
+    word arena -- NO host sync, so the whole of it can be enqueued ahead of the GPU or captured as a HIP graph.  -> (pending containers: z per image, then
+    slice-major y per image; z's spatial size)."""
     gc = m.gaussian_conditional
     z = m.h_a._nhwc(y)
-    chunk = int(chunk)
-    if not 1 <= chunk <= (1 << 24):
-        raise ValueError("chunk: symbols per independent rANS stream, 1 .. 2^24")
-    z_strings, z_hat = m.entropy_bottleneck._compress_nhwc(z, fmt, chunk)
+    z_pending, z_hat = m.entropy_bottleneck._compress_nhwc_async(z, chunk)
     latent_scales, latent_means = _hyper_synthesis(m, z_hat)
     if latent_means.shape[1:3] != y.shape[1:3]:
         raise NotImplementedError("latent size must be a multiple of 4; upstream crops here")
     b = y.shape[0]
     per = y.shape[-1] // m.num_slices
     tables, table = _coder_tables(gc), gc._table(y.device)
-    y_hat_slices, pieces, syms, idxs = [], [[] for _ in range(b)], [], []
+    y_hat_slices, pending = [], []
     for i in range(m.num_slices):
         mean_support, mu, scale = _slice_params(m, i, latent_means, latent_scales, y_hat_slices)
         sym, idx, y_hat_slice = torch.ops.realcam.gc_symbols(ops.channel_slice(y, i * per, per), mu, scale, table, gc.scale_bound_value)
-        if fmt == "chunked":
-            for k in range(b):
-                pieces[k].append(bitstream.encode(sym[k], idx[k], tables, fmt, chunk))
-        else:
-            syms.append(sym); idxs.append(idx)
-        y_hat_slices.append(_refine(m, i, mean_support, y_hat_slice))
+        pending.extend(bitstream.encode_async(sym[k], idx[k], tables, chunk) for k in range(b))
+        if i + 1 < m.num_slices:                     # (the last slice's refinement feeds nothing on the encoder side)
+            y_hat_slices.append(_refine(m, i, mean_support, y_hat_slice))
+    return z_pending + pending, tuple(z.shape[1:3])
+
+
+def _codec_compress_finish(m, pending, shape, b):
+    done = bitstream.finish(pending)                 # the one sync
+    z_strings, done = done[:b], done[b:]
+    return {"strings": [[b"".join(done[i * b + k] for i in range(m.num_slices)) for k in range(b)], z_strings], "shape": shape}
+
+
+def _check_chunk(chunk):
+    chunk = int(chunk)
+    if not 1 <= chunk <= (1 << 24):
+        raise ValueError("chunk: symbols per independent rANS stream, 1 .. 2^24")
+    return chunk
+
+
+def _codec_compress_graphed(m, latent_fn, inputs, chunk):
+    """compress(fmt="chunked", graph=True): latent_fn(*inputs) -> y NHWC and _codec_compress_device captured as ONE HIP graph per input signature and chunk
+    length (realcamnet_amd.graphs.GraphedCall; the capture lives on the module, `ops.invalidate_caches(module)` / update() drop it), replayed, then the
+    usual single read-back.  At one 4K frame the host needs longer to enqueue the ~800 launches than the GPU to run them."""
+    from .graphs import GraphedCall
+    chunk = _check_chunk(chunk)
+    graphs = m.__dict__.setdefault("_graphs", {})
+    g = graphs.get(("compress", chunk))
+    if g is None:
+        g = graphs[("compress", chunk)] = GraphedCall(lambda *ts: _codec_compress_device(m, latent_fn(*ts), chunk))
+    pending, shape = g(*inputs)
+    return _codec_compress_finish(m, pending, shape, inputs[0].shape[0])
+
+
+def _codec_compress(m, y, fmt, chunk=bitstream.DEFAULT_CHUNK):
+    """Shared by TCM.compress and raw_compression_tcm_final.compress (models/tcm.py:515-570, raw2bit.py:1901-1944): y NHWC latent ->
+    strings.  The symbols and CDF indexes of every slice are produced on the device (realcam::gc_symbols); "chunked": every slice
+    becomes one container of GPU-coded chunk streams, an image's y string is the concatenation of its slices' containers -- the device half of
+    every container is enqueued first, ONE sync (bitstream.finish) reads them all back;
+    "compressai": the slices' symbols are concatenated and coded as ONE stream per image, as upstream's single BufferedRansEncoder."""
+    chunk = _check_chunk(chunk)
+    b = y.shape[0]
     if fmt == "chunked":
-        y_strings = [b"".join(p) for p in pieces]
-    else:
-        sym, idx = torch.cat([t.reshape(b, -1) for t in syms], dim=1), torch.cat([t.reshape(b, -1) for t in idxs], dim=1)
-        y_strings = [bitstream.encode(sym[k], idx[k], tables, fmt) for k in range(b)]
+        pending, shape = _codec_compress_device(m, y, chunk)
+        return _codec_compress_finish(m, pending, shape, b)
+    gc = m.gaussian_conditional
+    z = m.h_a._nhwc(y)
+    z_strings, z_hat = m.entropy_bottleneck._compress_nhwc(z, fmt, chunk)
+    latent_scales, latent_means = _hyper_synthesis(m, z_hat)
+    if latent_means.shape[1:3] != y.shape[1:3]:
+        raise NotImplementedError("latent size must be a multiple of 4; upstream crops here")
+    per = y.shape[-1] // m.num_slices
+    tables, table = _coder_tables(gc), gc._table(y.device)
+    y_hat_slices, syms, idxs = [], [], []
+    for i in range(m.num_slices):
+        mean_support, mu, scale = _slice_params(m, i, latent_means, latent_scales, y_hat_slices)
+        sym, idx, y_hat_slice = torch.ops.realcam.gc_symbols(ops.channel_slice(y, i * per, per), mu, scale, table, gc.scale_bound_value)
+        syms.append(sym); idxs.append(idx)
+        y_hat_slices.append(_refine(m, i, mean_support, y_hat_slice))
+    sym, idx = torch.cat([t.reshape(b, -1) for t in syms], dim=1), torch.cat([t.reshape(b, -1) for t in idxs], dim=1)
+    y_strings = [bitstream.encode(sym[k], idx[k], tables, fmt) for k in range(b)]
     return {"strings": [y_strings, z_strings], "shape": tuple(z.shape[1:3])}
 
 
@@ -790,18 +864,23 @@ def _codec_decompress(m, strings, shape, dtype, fmt):
     """Shared decompress (models/tcm.py:592-637, raw2bit.py:1961-2027): -> x_hat NCHW clamped to [0, 1]."""
     gc = m.gaussian_conditional
     y_strings, z_strings = strings
-    z_hat = m.entropy_bottleneck._decompress_nhwc(z_strings, tuple(shape), dtype, fmt)
+    z_decoders = []
+    z_hat = m.entropy_bottleneck._decompress_nhwc(z_strings, tuple(shape), dtype, fmt, _decoders=z_decoders)
     latent_scales, latent_means = _hyper_synthesis(m, z_hat)
     b, dev = z_hat.shape[0], z_hat.device
     tables, table = _coder_tables(gc), gc._table(dev)
     decoders = [bitstream.Decoder(s, tables, dev, fmt) for s in y_strings]
+    dec = (lambda d, ix: d.decode_async(ix)) if fmt == "chunked" else (lambda d, ix: d.decode(ix))      # chunked: the kernels' error flags are looked at ONCE, below
     y_hat_slices = []
     for i in range(m.num_slices):
         mean_support, mu, scale = _slice_params(m, i, latent_means, latent_scales, y_hat_slices)
         _, idx, _ = torch.ops.realcam.gc_symbols(None, None, scale, table, gc.scale_bound_value)
-        sym = torch.stack([decoders[k].decode(idx[k]).view(idx.shape[1], idx.shape[2]) for k in range(b)])
+        sym = torch.stack([dec(decoders[k], idx[k]).view(idx.shape[1], idx.shape[2]) for k in range(b)])
         y_hat_slices.append(_refine(m, i, mean_support, torch.ops.realcam.gc_dequantize(sym, mu)))
-    return _synthesis_nchw(m, ops.channel_concat(y_hat_slices)).clamp_(0, 1)
+    x_hat = _synthesis_nchw(m, ops.channel_concat(y_hat_slices)).clamp_(0, 1)
+    for d in z_decoders + decoders:              # everything is enqueued: one look at the decode kernels' flags (a corrupt stream raises here, before x_hat is returned)
+        d.check()
+    return x_hat
 
 
 def _synthesis_nchw(m, y_hat):

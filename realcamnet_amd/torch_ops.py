@@ -754,6 +754,20 @@ define("rans_decode_chunks(Tensor stream, Tensor offsets, Tensor indexes, Tensor
        lambda stream, offsets, idx, *a: torch.empty_like(idx), _dec_launch)
 
 
+def _dec_async_launch(outs, stream, offsets, idx, cdf, sizes, cdf_offsets, chunk):
+    out, err = outs
+    err.zero_()
+    check(lib().rc_rans_decode_chunks(stream.data_ptr(), stream.numel(), offsets.data_ptr(), idx.data_ptr(), idx.numel(), chunk, cdf.data_ptr(),
+                                      cdf.shape[1], cdf.shape[0], sizes.data_ptr(), cdf_offsets.data_ptr(), out.data_ptr(), err.data_ptr(), _stream()),
+          "rc_rans_decode_chunks")
+
+
+# the same launch without the host's look at the error flag: (symbols, err int32[1]) -- 0 ok, 1 CDF index out of range, 2 truncated / corrupt stream.  The
+# caller checks `err` once, after everything that depends on the symbols has been enqueued (one sync per decompress() instead of one per slice and image)
+define("rans_decode_chunks_async(Tensor stream, Tensor offsets, Tensor indexes, Tensor cdf, Tensor cdf_sizes, Tensor cdf_offsets, int chunk) -> (Tensor, Tensor)",
+       lambda stream, offsets, idx, *a: (torch.empty_like(idx), idx.new_empty((1,), dtype=torch.int32)), _dec_async_launch)
+
+
 define("film_apply(Tensor x, Tensor scale, Tensor shift) -> Tensor",
        lambda x, s, t: torch.empty_like(x),
        lambda out, x, s, t: check(lib().rc_film_apply(x.data_ptr(), s.data_ptr(), t.data_ptr(), out.data_ptr(), _dt(x), x.shape[0], x.shape[1] * x.shape[2],

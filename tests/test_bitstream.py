@@ -381,3 +381,30 @@ def test_state_dict_contract_equals_the_reference_classes():
         assert sha(sd["entropy_bottleneck._quantized_cdf"]) == str(g[pre + ".sha_eb_cdf"])
         assert sha(sd["gaussian_conditional._offset"]) == str(g[pre + ".sha_gc_offset"])
         assert sha(sd["entropy_bottleneck._cdf_length"]) == str(g[pre + ".sha_eb_length"])
+
+
+@pytest.mark.gpu
+def test_compress_as_a_hip_graph_gives_the_same_strings(hip):
+    """compress(graph=True) replays the analysis transform + slice loop + chunk coder as ONE HIP graph captured per input shape; the strings are
+    byte-identical to the eager path's (same kernels, same order), a second input goes through the same capture, decompress() of them equals forward()'s x_hat up to
+    the clamp, and update() drops the capture (it holds the old tables' addresses)."""
+    import realcamnet_amd as M
+    from realcamnet_amd import ops
+    torch.manual_seed(0)
+    net = M.raw2bit.raw_compression_tcm_final().eval().to("cuda", torch.bfloat16)
+    net.update()
+    g = torch.Generator().manual_seed(3)
+    for rep in range(2):
+        raw = torch.rand(1, 4, 256, 384, generator=g).to("cuda", torch.bfloat16)
+        cond = torch.rand(1, 4, 64, 64, generator=g).to("cuda", torch.bfloat16)
+        coord = ops.make_coord(1, 256, 384, device="cuda", dtype=torch.bfloat16)
+        with torch.no_grad():
+            eager = net.compress([raw, cond, coord])
+            graphed = net.compress([raw, cond, coord], graph=True)
+            assert graphed["strings"] == eager["strings"] and graphed["shape"] == eager["shape"]
+            x_hat = net.decompress(graphed["strings"], graphed["shape"])["x_hat"]
+            ref = net([raw, cond, coord])["x_hat"].clamp(0, 1)
+        assert torch.equal(x_hat, ref)
+    assert len(net.__dict__["_graphs"]) == 1
+    net.update(force=True)
+    assert "_graphs" not in net.__dict__

@@ -973,6 +973,44 @@ def test_bench_codec_leg_prints_one_contract_json_line(hip):
     assert d["psnr_db_vs_cpu_fp32"]["x_hat"] >= 41.0
 
 
+def test_codec_forward_replayed_as_a_hip_graph_equals_the_eager_forward(hip):
+    """realcamnet_amd.GraphedCall: raw_compression_tcm_final.forward_mosaic captured per input signature and replayed -- every tensor of the
+    result dict bit-identical to the eager run, with the slice loop's two-stream forks captured as graph branches and with one stream; a second input through the
+    same graph; a new shape gets its own capture."""
+    import realcamnet_amd as M
+    torch.manual_seed(0)
+    net = M.raw2bit.raw_compression_tcm_final().eval().to(DEV, torch.bfloat16)
+    g = torch.Generator().manual_seed(11)
+
+    def inputs(h2, w2):
+        return (torch.rand(1, 1, h2, w2, generator=g).to(DEV, torch.bfloat16), ops.make_coord(1, h2 // 2, w2 // 2, device=DEV, dtype=torch.bfloat16))
+
+    def flat(d, pre=""):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                yield from flat(v, pre + k + ".")
+            else:
+                yield pre + k, v
+
+    fwd = lambda m, c: net.forward_mosaic(m, None, c)
+    for fork in (True, False):
+        ops.GRAPH_FORK = fork
+        try:
+            gf = M.GraphedCall(fwd)
+            for h2, w2 in ((512, 768), (512, 768), (768, 512)):
+                m, c = inputs(h2, w2)
+                with torch.no_grad():
+                    ref = {k: v.clone() for k, v in flat(fwd(m, c))}
+                out = dict(flat(gf(m, c)))
+                torch.cuda.synchronize()
+                assert set(out) == set(ref)
+                for k in ref:
+                    assert torch.equal(out[k], ref[k]), (fork, k)
+            assert len(gf._graphs) == 2
+        finally:
+            ops.GRAPH_FORK = True
+
+
 def test_forward_is_hip_graph_capturable(hip):
     """Every op launches on the current stream, allocates through the caching allocator and never syncs with the host, so a
     whole forward can be captured in a HIP graph; the replay is bit-identical to the eager run."""

@@ -1,4 +1,3 @@
-mkdir -p gpurun_out/w10
-timeout 1500 python -m pytest tests/test_winograd.py tests/test_gpu_parity.py tests/test_full_size.py -x -q -m gpu 2>&1 | tail -8 | tee gpurun_out/w10/pytest.log
-timeout 600 python bench.py --model LiteISPNet --dtype f32 --frames 1 --height 1080 --width 1920 --steps 20 --warmup 5 2>&1 | tail -1 | tee gpurun_out/w10/cfg2.log
-RC_WINOGRAD=0 timeout 600 python bench.py --model LiteISPNet --dtype f32 --frames 1 --height 1080 --width 1920 --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/w10/cfg2_direct.log
+mkdir -p gpurun_out/g3
+timeout 1200 python -m pytest tests/test_bitstream.py tests/test_gpu_parity.py -x -q -m gpu -k "graph" 2>&1 | grep -v amdgpu | tail -12 | tee gpurun_out/g3/pytest.log
+python tools/codec_b1.py 1 --codec 2>&1 | grep -v amdgpu.ids | tee gpurun_out/g3/b1.log
