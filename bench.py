@@ -230,6 +230,55 @@ def codec_leg(dev, dt, H2, W2, frames=8, steps=4, warmup=2, with_psnr=True):
     return leg
 
 
+def cfg2_leg(dev, steps=20, warmup=5, with_psnr=True):
+    """SURVEY cfg2 inside the default run: one 1920 x 1080 mosaic through LiteISPNet in fp32 (the configuration whose 3x3 layers take the Winograd F(2x2,3x3)
+    kernel, csrc/wino.hip), timed like the headline (synchronize on both sides, K steps after W warm-up steps), with the same forward's PSNR against the
+    fp32 CPU oracle on the whole frame (~4 s of CPU work).  Returned as the extra key `cfg2_leg`; the contract keys of the headline line are untouched."""
+    import realcamnet_amd as M
+    from realcamnet_amd import ops
+    H2, W2 = 1080, 1920
+    torch.manual_seed(0)
+    net = M.LiteISPNet().eval()
+    sd_cpu = {k: v.clone() for k, v in net.state_dict().items()} if with_psnr else None
+    net = net.to(device=dev, dtype=torch.float32)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    mosaic = torch.rand(1, 1, H2, W2, generator=g, device=dev)
+    coord = ops.make_coord(1, H2 // 2, W2 // 2, device=dev, dtype=torch.float32)
+
+    def step():
+        with torch.no_grad():
+            return net.forward_mosaic(mosaic, None, coord)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    ops.prof_enable(True)
+    y = step()
+    n_conv, conv_ms, conv_flops = ops.prof_collect()
+    ops.prof_enable(False)
+    leg = {"metric": "megapixels/sec RAW->sRGB at 1920x1080", "value": round(H2 * W2 / 1e6 / el, 2), "unit": "MP/s", "ms_per_step": round(1e3 * el, 3), "steps": steps, "warmup": warmup,
+           "dtype": "f32", "workload": "cfg2: 1920x1080 Bayer mosaic -> unshuffle+pad16 -> LiteISPNet -> sRGB 1920x1080, 1 frame, fp32",
+           "conv_launches": int(n_conv), "conv_ms_per_step": round(conv_ms, 3), "flops_executed": conv_flops,
+           "flops_algorithmic": 4 * 716896.0 * (H2 // 2 + (-(H2 // 2)) % 16) * (W2 // 2 + (-(W2 // 2)) % 16),        # SURVEY 8(d): 716 896 FLOP per OUTPUT pixel = 4x per packed pixel of the padded frame
+           "winograd": bool(ops.WINOGRAD)}
+    leg["frac_algorithmic_of_fp32_mfma_peak"] = round(leg["flops_algorithmic"] / el / 157.3e12, 4)
+    if with_psnr:
+        import liteisp_oracle as O                          # the oracle: checker only
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        with torch.no_grad():
+            packed, cond = O.raw_ingest(mosaic.cpu())
+            ref = O.run_padded("LiteISPNet", sd_cpu, packed, cond, O.make_coord(1, H2 // 2, W2 // 2))
+        leg["psnr_db_vs_cpu_fp32"] = round(O.psnr(y.float().cpu(), ref), 2)
+    del net, mosaic, coord
+    torch.cuda.empty_cache()
+    return leg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,6 +292,7 @@ def main():
                     help="default = cfg3: the flagship net plus one GroupMix GMA_Block(80,8) at H/2 (build-defined placement); "
                          "raw_compression_tcm_final = the RAW codec's forward (likelihood path), SURVEY cfg5's codec leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sample-power", action="store_true", help="diagnostic: one rocm-smi sample (socket W, shader clock) from a side thread INSIDE the timed region (rank 0)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of the output frames (replicas only)")
     ap.add_argument("--no-codec-leg", action="store_true", help="default cfg3 run: skip the extra codec_leg key (raw_compression_tcm_final at 4 frames)")
     ap.add_argument("--layer-by-layer-tail", action="store_true", help="A/B: the tail as the module list's two launches (ops.FOLD_TAIL = False) instead of the folded 5x5 conv")
@@ -309,7 +359,9 @@ def main():
         est = (time.perf_counter() - tw) * args.steps
     shard.barrier()
     torch.cuda.synchronize()
-    sampler = PowerSampler(0.1 * est) if (rank == 0 and est > 0.25) else None     # rocm-smi itself takes ~0.2 s: only runs long enough to contain it (the result says whether it did)
+    # --sample-power: one rocm-smi sample inside the timed region (a subprocess on rank 0 + SMI queries against the GPU being timed: a diagnostic that
+    # perturbs what it measures, so it is OFF for the recorded metric -- ADVICE r5)
+    sampler = PowerSampler(0.1 * est) if (args.sample_power and rank == 0 and est > 0.25) else None     # rocm-smi itself takes ~0.2 s: only runs long enough to contain it
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -366,7 +418,9 @@ def main():
     if fa is not None:
         rf["flops_algorithmic"] = fa
         rf["frac_algorithmic_whole_step"] = round(fa / (elapsed / args.steps) / 1e12 / peak, 4)
-        rf["flops_note"] = "flops_per_step = executed by the conv launches (the folded 5x5 tail executes 4.6x fewer than the two convolutions it replaces); flops_algorithmic = SURVEY 8(d): reference net at the padded size + GroupMix block"
+        rf["flops_note"] = ("flops_per_step = executed by the conv launches (the folded 5x5 tail executes 4.6x fewer than the two convolutions it replaces; a Winograd F(2x2,3x3) "
+                            "launch -- the fp32 3x3 layers with 64 | cout -- executes 4/9 of its layer's multiplications, so frac_algorithmic_whole_step can exceed frac and, in fp32, 1); "
+                            "flops_algorithmic = SURVEY 8(d): reference net at the padded size + GroupMix block")
     if rows:
         d0 = rows[0]
         es = 2 if args.dtype == "bf16" else 4
@@ -407,6 +461,7 @@ def main():
         del out, gathered
         torch.cuda.empty_cache()
         res["codec_leg"] = codec_leg(dev, dt, H2, W2, frames=args.frames, steps=4, with_psnr=not args.no_cpu_baseline)     # cfg5: the same frames per GPU as the headline (8)
+        res["cfg2_leg"] = cfg2_leg(dev, with_psnr=not args.no_cpu_baseline)
     if world == 1 and not args.no_cpu_baseline:
         info, (m_c, c_c, co_c, ref) = cpu_baseline(args.model, sd_cpu, (H2, W2))
         with torch.no_grad():

@@ -551,7 +551,7 @@ int rc_window_attention(const void* d_qkv, const float* d_relpos, void* d_out, i
  * window: results are then meaningless; 64 one persistent block per CU instead of two: results unchanged, an occupancy experiment);
  * "persist_auto" [1] the wave-autonomous kernels 6 / 7 (0 off, 1 all but the residual forms of kernel 6, 2 every eligible form); "sums_compact" [1] the compact
  * channel-sum slot layout (rc_conv_sum_slots); "thin" [2] kernel 4b (one barrier per stage) in place of the multi-chunk kernel 4: 1 = only where the stages are thin (weights and tiles by LDS-DMA, tiles two stages
- * ahead), 2 = also the 3x3 layers with <= 36 KB of weights per chunk (tile through registers, one stage ahead), 0 = kernel 4; "lds_poison" [0] test aid: every rc_conv2d launch is preceded by rc_debug_poison_lds (NaNs in all LDS). */
+ * ahead), 2 = also the 3x3 layers with <= 36 KB of weights per chunk (tile through registers, one stage ahead), 0 = kernel 4; "lds_poison" [0] test aid: every rc_conv2d launch is preceded by rc_debug_poison_lds (NaNs in all LDS). "wino_nnt" [0] the Winograd kernel's item size: 0 automatic (4 x 16-pixel items where one image's 4 x 32 regions quantise badly over the chip, 4 x 32 otherwise), 1 / 2 forced. */
 int rc_debug_set(const char* key, int value);
 /* Current value of an integer knob ("persist", "conv32", "conv_flags", "pss"), -1 for an unknown key.  The host mirror keys its packed-weight cache
  * on "conv32" (the packed order of the 32x32x16 layers depends on it and on nothing else). */

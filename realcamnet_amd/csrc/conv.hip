@@ -122,7 +122,9 @@ static int packed_to_cout(const ConvPlan& p, int cout, int out_mode, int j) {
 
 // wino.hip: Winograd F(2x2, 3x3) (rc_conv_desc.algo == 1)
 int wino_conv(const rc_conv_desc* d, hipStream_t stream);
-int wino_sum_slots(int H, int W);
+int wino_sum_slots(int H, int W, int cout);
+void wino_set_nnt(int v);
+int wino_get_nnt();
 bool wino_supported(const rc_conv_desc* d, std::string* why);
 
 static int g_dbg_flags = 0;
@@ -296,6 +298,7 @@ int rc_debug_set(const char* key, int value) {
     if (std::string(key) == "thin") { g_thin = value < 0 ? 0 : (value > 2 ? 2 : value); return RC_OK; }
     if (std::string(key) == "lds_poison") { g_poison = value != 0; return RC_OK; }
     if (std::string(key) == "conv32") { g_conv32 = value < 0 ? 0 : (value > 4 ? 4 : value); return RC_OK; }
+    if (std::string(key) == "wino_nnt") { wino_set_nnt(value); return RC_OK; }
     return fail(RC_ERR_INVALID, std::string("rc_debug_set: unknown key ") + key);
 }
 
@@ -309,6 +312,7 @@ int rc_debug_get(const char* key) {
     if (std::string(key) == "persist_auto") return g_auto;
     if (std::string(key) == "thin") return g_thin;
     if (std::string(key) == "lds_poison") return g_poison;
+    if (std::string(key) == "wino_nnt") return wino_get_nnt();
     return -1;
 }
 
@@ -499,7 +503,7 @@ int rc_conv2d(const rc_conv_desc* d, void* stream_) {
 }
 
 int rc_conv_sum_slots(const rc_conv_desc* d) {
-    if (d != nullptr && d->algo == 1) return wino_supported(d, nullptr) ? wino_sum_slots(d->height, d->width) : -1;
+    if (d != nullptr && d->algo == 1) return wino_supported(d, nullptr) ? wino_sum_slots(d->height, d->width, d->cout) : -1;
     ConvPlan p;
     ConvArgs a;
     size_t es = 0;

@@ -38,27 +38,32 @@ struct WinoArgs {
     long long* dbg;                    // rc_debug_set_ptr("conv_phase_timing"): s_memtime stamps of block 0, waves 0 and 1: [wave][stage < 32][8]
 };
 
-constexpr int kWRH = 4, kWRW = 32;                 // output region of one item: 2 x 16 Winograd tiles
-constexpr int kWHH = kWRH + 2, kWHW = kWRW + 2;    // its halo tile
-constexpr int kWNPIX = kWHH * kWHW;                // 204
+constexpr int kWRH = 4;                            // output rows of one item: two Winograd tile rows
+constexpr int kWHH = kWRH + 2;                     // halo rows
 constexpr int kWCK = 8;                            // input channels per stage (two K = 4 MFMA steps)
-// Raw halo tile in LDS: channel-PLANAR fp32 [channel][row][col], 48 dwords per row.  The transform thread of (channel, tile row tr, tile column tc) reads its
-// 4 x 4 patch as ds_read_b64 of columns (2 tc, 2 tc + 1) and (2 tc + 2, 2 tc + 3): the 16 tc lanes cover 32 consecutive banks and the row pitch puts tile row
-// tr + 1 on the other 32 (2 * 48 = 96 == 32 mod 64) -- conflict-free as b64 and as the read2_b64 pairs hipcc merges them into.
-constexpr int kWRP = 48;                           // dwords per halo row
-constexpr int kWPLANE = 384;                       // dwords per channel plane: 6 halo rows x 48 + 2 pad rows (where pieces past the tile are parked), a multiple of 64
-                                                   // (plane-to-plane ds_write2st64 pairs)
-constexpr int kWRAW = kWCK * kWPLANE * 4;          // 12 288 bytes per raw buffer
-static_assert(kWPLANE >= (kWHH + 1) * kWRP, "plane holds the halo tile and a pad row");
-constexpr int kWV = 2 * 2 * 4 * 1024;              // transformed tile V of one stage: [ks][tile row][q][lane (n, k)][4 xi] floats = 16 KB
 
-template <int NCW>
+// NNT = n-tiles (16 Winograd tiles) per wave.  2: the item is a 4 x 32-pixel region (2 x 16 tiles, n-tile = one tile row); 1: a 4 x 16-pixel region
+// (2 x 8 tiles = ONE n-tile) for maps with too few 4 x 32 regions to fill two blocks per CU (cfg2's 128-channel levels at 136 x 240 and 68 x 120).
+// Raw halo tile in LDS: channel-PLANAR fp32 [channel][row][col].  The transform thread of (channel, tile row tr, tile column tc) reads its 4 x 4 patch as
+// ds_read_b64 of columns (2 tc, 2 tc + 1) and (2 tc + 2, 2 tc + 3).  NNT 2: a 32-lane group is (tr 0..1) x (tc 0..15) of one channel: 48 dwords per row put
+// tile row tr + 1 on the other 32 banks (2 * 48 == 32 mod 64).  NNT 1: a group is 2 channels x (tr 0..1) x (tc 0..7): 24 dwords per row (2 * 24 = 48) and a plane
+// pitch == 32 mod 64 give the four (channel, tr) quarters four disjoint runs of 16 banks.  Conflict-free as b64 and as the read2_b64 pairs hipcc merges them into.
+template <int NCW, int NNT>
 struct WinoCfg {
     static constexpr int WAVES = NCW, THREADS = 64 * WAVES;
+    static constexpr int TC = 8 * NNT;                                 // tile columns of a region
+    static constexpr int RW = 2 * TC, HW = RW + 2;                     // region / halo width in pixels
+    static constexpr int NPIX = kWHH * HW;                             // halo pixels
+    static constexpr int RP = NNT == 2 ? 48 : 24;                      // dwords per halo row in LDS
+    static constexpr int PLANE = NNT == 2 ? 384 : 224;                 // dwords per channel plane: 6 halo rows + pad rows (where pieces past the tile are parked)
+    static constexpr int RAW = kWCK * PLANE * 4;                       // bytes per raw buffer
+    static constexpr int V = 2 * NNT * 4 * 1024;                       // transformed tile V of one stage: [ks][n-tile][q][lane (n, k)][4 xi] floats
     static constexpr int U_STAGE = 2 * NCW * 4 * 1024;                 // [ks][cw][q][lane][4 xi] floats of one stage (global memory only)
-    static constexpr int NIP = (2 * kWNPIX + THREADS - 1) / THREADS;   // 16-byte input pieces per thread and stage (a halo pixel = 2 pieces)
-    static constexpr int NTR = (32 * kWCK + THREADS - 1) / THREADS;    // (tile, channel) transforms per thread and stage (1 with 4 waves)
-    static constexpr int LDS_BYTES = 2 * kWV + 2 * kWRAW;              // 50 KB: two (three) blocks per CU
+    static constexpr int NIP = (2 * NPIX + THREADS - 1) / THREADS;     // 16-byte input pieces per thread and stage (a halo pixel = 2 pieces)
+    static constexpr int NPAIR = 16 * NNT * kWCK;                      // (tile, channel) pairs of a stage
+    static constexpr int NTR = (NPAIR + THREADS - 1) / THREADS;        // transforms per thread and stage (1 with 4 waves)
+    static constexpr int LDS_BYTES = 2 * V + 2 * RAW;                  // 56 KB (NNT 2) / 30 KB: two blocks per CU
+    static_assert(PLANE >= (kWHH + 1) * RP, "plane holds the halo tile and a pad row");
 };
 
 // Block = NCW waves, wave cw owns cout tile cw (16 couts) x the region's 32 tiles x 16 xi (128 accumulator registers); two blocks share a CU and drift freely,
@@ -70,12 +75,12 @@ struct WinoCfg {
 //   epilogue if stage g closes an item
 //   commit   registers -> raw[g & 1] (stage g's raw tile was consumed an iteration ago);  barrier
 // DBG: knock-out flags (rc_debug_set("conv_flags")) and s_memtime stamps of block 0 (rc_debug_set_ptr("conv_phase_timing")) -- experiments only.
-template <int NCW, bool DBG>
+template <int NCW, int NNT, bool DBG>
 __global__ __launch_bounds__(64 * NCW, (NCW == 4 ? 2 : 1)) void wino_f32_kernel(const WinoArgs a) {
-    using C = WinoCfg<NCW>;
+    using C = WinoCfg<NCW, NNT>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* const vbuf = lds;                                  // 2 x kWV
-    char* const rbuf = vbuf + 2 * kWV;                       // 2 x kWRAW
+    char* const vbuf = lds;                                  // 2 x C::V
+    char* const rbuf = vbuf + 2 * C::V;                      // 2 x C::RAW
     const int tid = threadIdx.x, lane = tid & 63, cw = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kq = lane >> 4;
     const int flags = DBG ? a.dbg_flags : 0;
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(64 * NCW, (NCW == 4 ? 2 : 1)) void wino_f32_kernel(
         it.b = magic_div(q, a.d_img);
         it.reg = q - it.b * (a.rx * a.ry);
         const int ty = magic_div(it.reg, a.d_rx);
-        it.y0 = ty * kWRH; it.x0 = (it.reg - ty * a.rx) * kWRW;
+        it.y0 = ty * kWRH; it.x0 = (it.reg - ty * a.rx) * C::RW;
         return it;
     };
 
@@ -104,8 +109,8 @@ __global__ __launch_bounds__(64 * NCW, (NCW == 4 ? 2 : 1)) void wino_f32_kernel(
     const int lane16 = lane * 16;
     // LDS byte offset of raw piece p (plane 4 q, halo pixel); pieces past the tile park in the pad rows
     auto piece_lds = [](int p) {
-        const int pix = p >> 1, hy = pix / kWHW;
-        return p < 2 * kWNPIX ? ((4 * (p & 1)) * kWPLANE + hy * kWRP + pix - hy * kWHW) * 4 : ((4 * (p & 1)) * kWPLANE + kWHH * kWRP + (p & 31)) * 4;
+        const int pix = p >> 1, hy = pix / C::HW;
+        return p < 2 * C::NPIX ? ((4 * (p & 1)) * C::PLANE + hy * C::RP + pix - hy * C::HW) * 4 : ((4 * (p & 1)) * C::PLANE + kWHH * C::RP + (p & 15)) * 4;
     };
     constexpr bool KEEP_PLDS = NCW == 4;                     // narrower blocks carry more pieces per thread: there the offsets are recomputed at the commit (from a
     int p_lds[KEEP_PLDS ? C::NIP : 1];                       // laundered thread id, or hipcc hoists them back out of the loop and spills)
@@ -125,9 +130,9 @@ __global__ __launch_bounds__(64 * NCW, (NCW == 4 ? 2 : 1)) void wino_f32_kernel(
             rs_in = make_rsrc(static_cast<const float*>(a.in0) + (size_t)it.b * img_in, live ? (unsigned)(img_in * 4) : 0u);
 #pragma unroll
             for (int i = 0; i < C::NIP; ++i) {
-                const int p = tid + i * C::THREADS, pix = p >> 1, hy = pix / kWHW;
-                const int gy = it.y0 - 1 + hy, gx = it.x0 - 1 + pix - hy * kWHW;
-                const bool ok = p < 2 * kWNPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const int p = tid + i * C::THREADS, pix = p >> 1, hy = pix / C::HW;
+                const int gy = it.y0 - 1 + hy, gx = it.x0 - 1 + pix - hy * C::HW;
+                const bool ok = p < 2 * C::NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 voff[i] = ok ? ((gy * a.W + gx) * a.cin + 4 * (p & 1)) * 4 : kOOB;
             }
         }
@@ -140,9 +145,9 @@ __global__ __launch_bounds__(64 * NCW, (NCW == 4 ? 2 : 1)) void wino_f32_kernel(
         if constexpr (!KEEP_PLDS) asm volatile("" : "+v"(t0));
 #pragma unroll
         for (int i = 0; i < C::NIP; ++i) {
-            float* dst = reinterpret_cast<float*>(rbuf + buf * kWRAW + (KEEP_PLDS ? p_lds[KEEP_PLDS ? i : 0] : piece_lds(t0 + i * C::THREADS)));
-            dst[0] = __uint_as_float(in_r[i].x); dst[kWPLANE] = __uint_as_float(in_r[i].y);
-            dst[2 * kWPLANE] = __uint_as_float(in_r[i].z); dst[3 * kWPLANE] = __uint_as_float(in_r[i].w);
+            float* dst = reinterpret_cast<float*>(rbuf + buf * C::RAW + (KEEP_PLDS ? p_lds[KEEP_PLDS ? i : 0] : piece_lds(t0 + i * C::THREADS)));
+            dst[0] = __uint_as_float(in_r[i].x); dst[C::PLANE] = __uint_as_float(in_r[i].y);
+            dst[2 * C::PLANE] = __uint_as_float(in_r[i].z); dst[3 * C::PLANE] = __uint_as_float(in_r[i].w);
         }
     };
     // this wave's A fragments, half-stage by half-stage: 4 x 1 KB [q][lane][4 xi] per half; a UNIFORM base pointer walks (chunk, ks) and re-bases per item
@@ -159,39 +164,40 @@ __global__ __launch_bounds__(64 * NCW, (NCW == 4 ? 2 : 1)) void wino_f32_kernel(
         ua += NCW * 4096;
         if (++ca == 2 * a.n_chunks) { ca = 0; ++ka; }
     };
-    // B^T d B of this thread's (tile, channel) pairs: raw[buf] -> V[buf].  Pair p: channel p >> 5, tile row (p >> 4) & 1, tile column p & 15.
+    // B^T d B of this thread's (tile, channel) pairs: raw[buf] -> V[buf].  Pair p: channel p / (16 NNT), tile row, tile column from the rest.
     int t_src[C::NTR], t_dst[C::NTR];
 #pragma unroll
     for (int t = 0; t < C::NTR; ++t) {
-        const int p = tid + t * C::THREADS, ch = (p >> 5) & 7, tr = (p >> 4) & 1, tc = p & 15;
-        t_src[t] = (ch * kWPLANE + (2 * tr) * kWRP + 2 * tc) * 4;
-        // V[ks = ch & 1][tr][q][lane (n = tc, k = ch >> 1)][e]: the B-operand lane of tile tc, channel 2 k + ks
-        t_dst[t] = (((ch & 1) * 2 + tr) * 4) * 1024 + (tc + 16 * (ch >> 1)) * 16;
+        const int p = tid + t * C::THREADS, ch = (p / (16 * NNT)) & 7, tr = (p / C::TC) & 1, tc = p % C::TC;
+        t_src[t] = (ch * C::PLANE + (2 * tr) * C::RP + 2 * tc) * 4;
+        // V[ks = ch & 1][n-tile][q][lane (n, k = ch >> 1)][e]: the B-operand lane of the tile, channel 2 k + ks.  NNT 2: n-tile = tile row, n = tc; NNT 1: n = 8 tr + tc
+        const int nti = NNT == 2 ? tr : 0, n_ = NNT == 2 ? tc : 8 * tr + tc;
+        t_dst[t] = (((ch & 1) * NNT + nti) * 4) * 1024 + (n_ + 16 * (ch >> 1)) * 16;
     }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 tx[C::NTR][4][2];                                  // the patches between transform_read and transform_finish: [row][column pair]
     auto transform_read = [&](int buf) {
 #pragma unroll
         for (int t = 0; t < C::NTR; ++t) {
-            const char* src = rbuf + buf * kWRAW + t_src[t];
+            const char* src = rbuf + buf * C::RAW + t_src[t];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                tx[t][r][0] = *reinterpret_cast<const f32x2*>(src + r * (kWRP * 4));
-                tx[t][r][1] = *reinterpret_cast<const f32x2*>(src + r * (kWRP * 4) + 8);
+                tx[t][r][0] = *reinterpret_cast<const f32x2*>(src + r * (C::RP * 4));
+                tx[t][r][1] = *reinterpret_cast<const f32x2*>(src + r * (C::RP * 4) + 8);
             }
         }
     };
     auto transform_finish = [&](int buf) {
 #pragma unroll
         for (int t = 0; t < C::NTR; ++t) {
-            if (C::NTR * C::THREADS == 32 * kWCK || tid + t * C::THREADS < 32 * kWCK) {
+            if (C::NTR * C::THREADS == C::NPAIR || tid + t * C::THREADS < C::NPAIR) {
                 f32x2 w[4][2];                                   // rows of B^T d, as column pairs (packed adds)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     w[0][h] = tx[t][0][h] - tx[t][2][h]; w[1][h] = tx[t][1][h] + tx[t][2][h];
                     w[2][h] = tx[t][2][h] - tx[t][1][h]; w[3][h] = tx[t][1][h] - tx[t][3][h];
                 }
-                char* dst = vbuf + buf * kWV + t_dst[t];
+                char* dst = vbuf + buf * C::V + t_dst[t];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     *reinterpret_cast<f32x4*>(dst + r * 1024) = f32x4{w[r][0].x - w[r][1].x, w[r][0].y + w[r][1].x, w[r][1].x - w[r][0].y, w[r][0].y - w[r][1].y};
@@ -199,14 +205,16 @@ __global__ __launch_bounds__(64 * NCW, (NCW == 4 ? 2 : 1)) void wino_f32_kernel(
         }
     };
 
-    f32x4 acc[16][2];
+    f32x4 acc[16][NNT];
 #pragma unroll
-    for (int x = 0; x < 16; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int nt = 0; nt < NNT; ++nt) acc[x][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     // one half-stage.  (Reading the 8 B-fragment quads up front behind a sched_barrier measured 3 % SLOWER than hipcc's own pairing of two reads with the
     // eight MFMAs they feed: 183 vs 178 us on the 64 -> 64 layer, same box, alternating.)
     auto mfma_half = [&](const char* vb, const f32x4 (&aq)[4]) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NNT; ++nt) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 vq = *reinterpret_cast<const f32x4*>(vb + nt * 4096 + q * 1024);
@@ -244,12 +252,12 @@ __global__ __launch_bounds__(64 * NCW, (NCW == 4 ? 2 : 1)) void wino_f32_kernel(
         load_a(a1);
         if (!(flags & 8)) transform_finish(buf ^ 1);
         mark(g, 1);
-        const char* vb = vbuf + buf * kWV + lane16;
+        const char* vb = vbuf + buf * C::V + lane16;
         if (!(flags & 2)) mfma_half(vb, a0);
         mark(g, 2);
         load_a(a0);
         mark(g, 3);
-        if (!(flags & 2)) mfma_half(vb + 8192, a1);
+        if (!(flags & 2)) mfma_half(vb + NNT * 4096, a1);
         mark(g, 4);
 
         if (++cc == a.n_chunks && !(flags & 1)) {
@@ -261,9 +269,11 @@ __global__ __launch_bounds__(64 * NCW, (NCW == 4 ? 2 : 1)) void wino_f32_kernel(
             f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f}, osc = f32x4{1.f, 1.f, 1.f, 1.f};
             if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + co0);              // (their latency runs under the 192 adds of A^T M A)
             if (a.out_scale) osc = *reinterpret_cast<const f32x4*>(a.out_scale + (size_t)it.b * a.cout + co0);
-            f32x4 y[2][2][2];                                               // [nt][i][j]
+            // a lane's tile: NNT 2: (tile row nt, tile column n); NNT 1: (tile row n >> 3, tile column n & 7).  Below, index m = (nt, i, j) runs over the lane's 4 NNT pixels
+            constexpr int NPX = 4 * NNT;
+            f32x4 y[NNT][2][2];                                             // [nt][i][j]
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NNT; ++nt) {
                 f32x4 t0[4], t1[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -274,28 +284,30 @@ __global__ __launch_bounds__(64 * NCW, (NCW == 4 ? 2 : 1)) void wino_f32_kernel(
                 y[nt][1][0] = t1[0] + t1[1] + t1[2]; y[nt][1][1] = t1[1] - t1[2] - t1[3];
             }
 #pragma unroll
-            for (int m = 0; m < 8; ++m) y[m >> 2][(m >> 1) & 1][m & 1] = y[m >> 2][(m >> 1) & 1][m & 1] + bias4;
+            for (int m = 0; m < NPX; ++m) y[m >> 2][(m >> 1) & 1][m & 1] = y[m >> 2][(m >> 1) & 1][m & 1] + bias4;
 #pragma unroll
-            for (int x = 0; x < 16; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            // pixel (nt, i, j) = (y0 + 2 nt + i, x0 + 2 n + j): row validity is uniform, column validity per lane
-            const int px = it.x0 + 2 * n;
-            const int off00 = ((it.y0 * a.W + px) * a.cout + co0) * 4;
+            for (int x = 0; x < 16; ++x)
+#pragma unroll
+                for (int nt = 0; nt < NNT; ++nt) acc[x][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // pixel (nt, i, j) = (py + 2 nt + i, px + j)
+            const int px = it.x0 + 2 * (NNT == 2 ? n : (n & 7)), py = it.y0 + (NNT == 2 ? 0 : 2 * (n >> 3));
+            const int off00 = ((py * a.W + px) * a.cout + co0) * 4;
             const bool vx0 = px < a.W, vx1 = px + 1 < a.W;
-            int off[2][2][2];
+            int off[NNT][2][2];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NNT; ++nt)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const bool vy = it.y0 + 2 * nt + i < a.H;
+                    const bool vy = py + 2 * nt + i < a.H;
                     const int o = off00 + ((2 * nt + i) * a.W * a.cout) * 4;
                     off[nt][i][0] = (vy && vx0) ? o : kOOB;
                     off[nt][i][1] = (vy && vx1) ? o + a.cout * 4 : kOOB;
                 }
-            f32x4 res[2][2][2];
+            f32x4 res[NNT][2][2];
             if (a.residual) {
                 const __amdgpu_buffer_rsrc_t r_res = make_rsrc(static_cast<const float*>(a.residual) + (size_t)it.b * img_out, (unsigned)(img_out * 4));
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
+                for (int m = 0; m < NPX; ++m) {
                     const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(r_res, off[m >> 2][(m >> 1) & 1][m & 1], 0, 0);
                     res[m >> 2][(m >> 1) & 1][m & 1] = f32x4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
                 }
@@ -304,35 +316,35 @@ __global__ __launch_bounds__(64 * NCW, (NCW == 4 ? 2 : 1)) void wino_f32_kernel(
                 const f32x4 fs = *reinterpret_cast<const f32x4*>(a.film_scale + (size_t)it.b * a.cout + co0);
                 const f32x4 ft = *reinterpret_cast<const f32x4*>(a.film_shift + (size_t)it.b * a.cout + co0);
 #pragma unroll
-                for (int m = 0; m < 8; ++m) { f32x4& v = y[m >> 2][(m >> 1) & 1][m & 1]; v = v * fs + ft + v; }
+                for (int m = 0; m < NPX; ++m) { f32x4& v = y[m >> 2][(m >> 1) & 1][m & 1]; v = v * fs + ft + v; }
             }
             if (a.act == RC_ACT_RELU) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m)
+                for (int m = 0; m < NPX; ++m)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const float v = y[m >> 2][(m >> 1) & 1][m & 1][e]; y[m >> 2][(m >> 1) & 1][m & 1][e] = v > 0.f ? v : 0.f; }
             } else if (a.act == RC_ACT_LEAKY) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m)
+                for (int m = 0; m < NPX; ++m)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const float v = y[m >> 2][(m >> 1) & 1][m & 1][e]; y[m >> 2][(m >> 1) & 1][m & 1][e] = v > 0.f ? v : v * a.act_slope; }
             }
             if (a.out_scale) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) y[m >> 2][(m >> 1) & 1][m & 1] = y[m >> 2][(m >> 1) & 1][m & 1] * osc;
+                for (int m = 0; m < NPX; ++m) y[m >> 2][(m >> 1) & 1][m & 1] = y[m >> 2][(m >> 1) & 1][m & 1] * osc;
             }
             if (a.residual) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) y[m >> 2][(m >> 1) & 1][m & 1] = y[m >> 2][(m >> 1) & 1][m & 1] + res[m >> 2][(m >> 1) & 1][m & 1];
+                for (int m = 0; m < NPX; ++m) y[m >> 2][(m >> 1) & 1][m & 1] = y[m >> 2][(m >> 1) & 1][m & 1] + res[m >> 2][(m >> 1) & 1][m & 1];
                 if (a.act == RC_ACT_RELU_POST) {
 #pragma unroll
-                    for (int m = 0; m < 8; ++m)
+                    for (int m = 0; m < NPX; ++m)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { const float v = y[m >> 2][(m >> 1) & 1][m & 1][e]; y[m >> 2][(m >> 1) & 1][m & 1][e] = v > 0.f ? v : 0.f; }
                 }
             }
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
+            for (int m = 0; m < NPX; ++m) {
                 const f32x4 v = y[m >> 2][(m >> 1) & 1][m & 1];
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)},
                                                        r_out, off[m >> 2][(m >> 1) & 1][m & 1], 0, 0);
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(64 * NCW, (NCW == 4 ? 2 : 1)) void wino_f32_kernel(
                 // pixels outside the image do not count; fixed-order butterfly over the 16 tiles of a lane row, then one slot per region
                 f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
+                for (int m = 0; m < NPX; ++m) {
                     const f32x4 v = y[m >> 2][(m >> 1) & 1][m & 1];
                     const bool ok = off[m >> 2][(m >> 1) & 1][m & 1] != kOOB;
 #pragma unroll
@@ -368,14 +380,15 @@ __global__ __launch_bounds__(64 * NCW, (NCW == 4 ? 2 : 1)) void wino_f32_kernel(
 
 long long* conv_dbg_ptr();
 
-template <int NCW, bool DBG = false>
+template <int NCW, int NNT, bool DBG = false>
 static int wino_launch_f32(const WinoArgs& a, int num_cus, hipStream_t stream) {
-    using C = WinoCfg<NCW>;
+    using C = WinoCfg<NCW, NNT>;
     static PerDeviceFlag attr_set;
     if (!attr_set.test_and_set())
-        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32_kernel<NCW, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    const int grid = a.n_items < 2 * num_cus ? a.n_items : 2 * num_cus;      // two blocks per CU
-    hipLaunchKernelGGL((wino_f32_kernel<NCW, DBG>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, stream, a);
+        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_f32_kernel<NCW, NNT, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    const int per_cu = NNT == 1 && NCW == 4 ? 3 : 2;                        // resident blocks per CU (registers, LDS)
+    const int grid = a.n_items < per_cu * num_cus ? a.n_items : per_cu * num_cus;
+    hipLaunchKernelGGL((wino_f32_kernel<NCW, NNT, DBG>), dim3(grid), dim3(C::THREADS), C::LDS_BYTES, stream, a);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
@@ -388,7 +401,24 @@ static int wino_ncw(int cout) {
     return cout % 16 == 0 ? 1 : 0;
 }
 
-int wino_sum_slots(int H, int W) { return ceil_div(H, kWRH) * ceil_div(W, kWRW); }
+// n-tiles per wave for a layer: 1 (4 x 16-pixel items) when ONE image's 4 x 32 regions quantise badly over the chip's 2 x CUs block slots -- cfg2's 128-channel
+// levels: 544 items = 1.06 rounds at 136 x 240, 136 items = a quarter round at 68 x 120 (half-size items: 3 x 0.5 / 1 x 0.5 rounds instead of 2 / 1).  Decided per IMAGE,
+// not per batch, so that frame i of a batch and frame i alone get the same channel-sum slot layout (tested slot for slot).
+static int g_wino_nnt = 0;                              // rc_debug_set("wino_nnt", v): 0 automatic, 1 / 2 forced (tests, A/B)
+void wino_set_nnt(int v) { g_wino_nnt = v < 0 || v > 2 ? 0 : v; }
+int wino_get_nnt() { return g_wino_nnt; }
+static int wino_nnt(int H, int W, int cout, int num_cus) {
+    const int ncw = wino_ncw(cout);
+    if (ncw != 4) return 2;
+    if (g_wino_nnt) return g_wino_nnt;
+    const long ry = ceil_div(H, kWRH), n_cg = cout / 64;
+    const long i2 = ry * ceil_div(W, 32) * n_cg, i1 = ry * ceil_div(W, 16) * n_cg;
+    const long s2 = 2L * num_cus, s1 = 3L * num_cus;    // block slots: the half-size form needs 155 registers and 30 KB of LDS -> three blocks per CU
+    const long r2 = (i2 + s2 - 1) / s2, r1 = (i1 + s1 - 1) / s1;
+    return 11 * r1 < 20 * r2 ? 1 : 2;                  // a half-size item costs ~0.55 of a full one (per-stage overheads do not halve)
+}
+
+int wino_sum_slots(int H, int W, int cout) { return ceil_div(H, kWRH) * ceil_div(W, 16 * wino_nnt(H, W, cout, device_cu_count())); }
 
 bool wino_supported(const rc_conv_desc* d, std::string* why) {
     auto no = [&](const char* m) { if (why) *why = m; return false; };
@@ -419,7 +449,9 @@ int wino_conv(const rc_conv_desc* d, hipStream_t stream) {
     WinoArgs a{};
     a.batch = d->batch; a.H = d->height; a.W = d->width; a.cin = d->cin; a.cout = d->cout;
     const int ncw = wino_ncw(d->cout);
-    a.rx = ceil_div(d->width, kWRW); a.ry = ceil_div(d->height, kWRH);
+    const int cus = device_cu_count();
+    const int nnt = wino_nnt(d->height, d->width, d->cout, cus);
+    a.rx = ceil_div(d->width, 16 * nnt); a.ry = ceil_div(d->height, kWRH);
     a.n_cg = d->cout / (16 * ncw);
     a.n_chunks = d->cin / kWCK;
     a.d_cg = make_magic(a.n_cg); a.d_img = make_magic(a.rx * a.ry); a.d_rx = make_magic(a.rx); a.d_chunks = make_magic(a.n_chunks);
@@ -429,26 +461,25 @@ int wino_conv(const rc_conv_desc* d, hipStream_t stream) {
     a.in0 = d->in0; a.wpacked = d->wpacked; a.bias = d->bias;
     a.film_scale = d->film_scale; a.film_shift = d->film_shift; a.act = d->act; a.act_slope = d->act_slope;
     a.out_scale = d->out_scale; a.residual = d->residual; a.out = d->out; a.chan_sums = d->chan_sums;
-    a.sum_slots = wino_sum_slots(d->height, d->width);
+    a.sum_slots = wino_sum_slots(d->height, d->width, d->cout);
     a.dbg_flags = rc_debug_get("conv_flags");
     a.dbg = conv_dbg_ptr();
     if (d->chan_sums) RC_REQUIRE(d->chan_sums_slots == a.sum_slots, "rc_conv2d (algo 1): chan_sums_slots must be rc_conv_sum_slots()");
     const double px = (double)d->batch * d->height * d->width;
     void* tok = nullptr;
     // executed MFMA FLOPs: 16 MACs per (cin, cout) and 2x2 tile (tiles counted over the regions actually computed)
-    conv_prof_begin(2.0 * 4.0 * (double)d->cin * d->cout * ((double)d->batch * a.rx * a.ry * kWRH * kWRW), stream, &tok,
+    conv_prof_begin(2.0 * 4.0 * (double)d->cin * d->cout * ((double)d->batch * a.rx * a.ry * kWRH * 16 * nnt), stream, &tok,
                     px * 4.0 * (d->cin + d->cout * (d->residual ? 2.0 : 1.0)), d->cin, d->cout, 3);
-    const int cus = device_cu_count();
     int rc_ = RC_OK;
     switch (ncw) {
 #ifdef RC_WINO_DBG          // the instrumented instantiation (knock-out flags, s_memtime stamps) is an experiment build: python -m realcamnet_amd.build --variant dbg RC_WINO_DBG
-        case 4: rc_ = (a.dbg_flags || a.dbg) ? wino_launch_f32<4, true>(a, cus, stream) : wino_launch_f32<4>(a, cus, stream); break;
+        case 4: rc_ = nnt == 1 ? wino_launch_f32<4, 1>(a, cus, stream) : (a.dbg_flags || a.dbg) ? wino_launch_f32<4, 2, true>(a, cus, stream) : wino_launch_f32<4, 2>(a, cus, stream); break;
 #else
-        case 4: rc_ = wino_launch_f32<4>(a, cus, stream); break;
+        case 4: rc_ = nnt == 1 ? wino_launch_f32<4, 1>(a, cus, stream) : wino_launch_f32<4, 2>(a, cus, stream); break;
 #endif
-        case 3: rc_ = wino_launch_f32<3>(a, cus, stream); break;
-        case 2: rc_ = wino_launch_f32<2>(a, cus, stream); break;
-        default: rc_ = wino_launch_f32<1>(a, cus, stream); break;
+        case 3: rc_ = wino_launch_f32<3, 2>(a, cus, stream); break;
+        case 2: rc_ = wino_launch_f32<2, 2>(a, cus, stream); break;
+        default: rc_ = wino_launch_f32<1, 2>(a, cus, stream); break;
     }
     conv_prof_end(tok, stream);
     return rc_;

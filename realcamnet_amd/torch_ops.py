@@ -191,21 +191,30 @@ def _conv_alloc(x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, 
         # across tiles write grid x waves slots, the others 4 per 8 x 32 tile); only the NULL-ness of the pointers matters for the question.
         d = ConvDesc()
         d.batch, d.height, d.width, d.cin, d.cout, d.ksize, d.dtype = b, H, W, x.shape[-1], cout, ksize, _DT[x.dtype]
-        dummy = 4096                                                   # non-NULL, 16-byte aligned
-        d.in0 = d.wpacked = d.out = d.chan_sums = dummy
+        # Non-NULL stand-ins that carry the REAL tensors' 16-byte alignment: the launcher's branch (vector vs scalar staging, fast vs generic epilogue) depends
+        # on it, and a slot count asked about perfectly aligned pointers would not match a launch on a tensor at an odd storage offset.
+        from torch._subclasses.fake_tensor import FakeTensor
+
+        def stand_in(t):
+            return 4096 + (0 if (t is None or isinstance(t, FakeTensor) or not t.is_cuda) else t.data_ptr() % 16)
+        d.in0, d.wpacked, d.out, d.chan_sums = stand_in(x), stand_in(wpacked), stand_in(out), 4096
         if gate is not None:
-            d.in1 = d.in_gate = dummy
+            d.in1, d.in_gate = stand_in(skip), stand_in(gate)
             if store_input:
-                d.in_store = dummy
+                d.in_store = 4096                                      # (allocated below: the caching allocator's blocks are 512-byte aligned)
         for name, t in (("bias", bias), ("film_scale", film_scale), ("film_shift", film_shift), ("mul_plus1", mul_plus1), ("residual", residual), ("out_scale", out_scale)):
             if t is not None:
-                setattr(d, name, dummy)
+                setattr(d, name, stand_in(t))
         d.act, d.act_slope, d.out_mode, d.out_dtype = act, float(slope), out_mode, _DT[out.dtype]
         d.cout_tile = cout_tile
         d.algo = algo
         if out_mode in (RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW):
             d.out_h, d.out_w = out.shape[2], out.shape[3]
-        n = lib().rc_conv_sum_slots(C.byref(d))
+        if x.is_cuda and not isinstance(x, FakeTensor):                # the launcher sizes its grid by the CURRENT device's CU count: ask on the tensor's device
+            with torch.cuda.device(x.device):
+                n = lib().rc_conv_sum_slots(C.byref(d))
+        else:
+            n = lib().rc_conv_sum_slots(C.byref(d))
         if n <= 0:                                                     # an invalid description: the launch reports it (with its own message); allocate the per-tile count
             n = lib().rc_conv_sum_tiles(H, W)
         sums = x.new_empty((b, n, cout), dtype=torch.float32)

@@ -282,7 +282,7 @@ def test_bench_path_kernels_do_not_spill_and_the_count_cannot_grow():
         "conv_mfma_persist_kernelINS_7ConvCfgIDF16bLi48ELi1ELi5ELi8EEELb0ELb0E",
         "conv_mfma_persist_kernelINS_7ConvCfgIDF16bLi48ELi1ELi3ELi8EEELb0ELb0E",    # 48 -> 3 on the ring strips
         "conv_mfma_kernelINS_7ConvCfgIDF16bLi64ELi5ELi1ELi8EEELb0E",                 # GroupMix in-projection 192 -> 80
-        "wino_f32_kernelILi4ELb0E",                                                   # fp32 Winograd F(2x2,3x3): cfg2's 64 -> 64 / 128 -> 128 layers
+        "wino_f32_kernelILi4ELi",                                                   # fp32 Winograd F(2x2,3x3): cfg2's 64 -> 64 / 128 -> 128 layers
         "conv_mfma_wst_kernel",                                                       # kernel 4b, every instantiation (the codec's folded stride-2 layers, 16-wide cout tiles, 16-channel chunks)
         "conv_mfma_wsm_kernelINS_7ConvCfgIDF16bLi32ELi4ELi2ELi8EEELb0ELb1E",        # ... and kernel 4 on the same folded layers (`thin` 0)
         "2gf", "ca_gate", "ca_reduce", "color_", "instance_stats", "gfm_vector", "dwt_", "raw_ingest", "tail_ring", "nchw_to_nhwc", "nhwc_to_nchw",

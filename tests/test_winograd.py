@@ -99,9 +99,21 @@ SHAPES = [(64, 64, 8, 32, 1), (64, 64, 16, 64, 2), (8, 16, 5, 7, 2), (16, 32, 9,
           (256, 64, 12, 40, 1)]
 
 
+@pytest.fixture(params=[0, 1, 2], ids=["nnt_auto", "nnt1", "nnt2"])
+def nnt(request, hip):
+    """The kernel's two item sizes (4 x 16 / 4 x 32 pixels; rc_debug_set("wino_nnt")): forced in turn, and the automatic choice."""
+    assert hip.rc_debug_set(b"wino_nnt", request.param) == 0
+    yield request.param
+    hip.rc_debug_set(b"wino_nnt", 0)
+
+
+def _regions(h, w, nnt):
+    return ((h + 3) // 4) * ((w + 16 * nnt - 1) // (16 * nnt))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", SHAPES)
-def test_winograd_conv_exact_on_small_integer_data(hip, shape):
+def test_winograd_conv_exact_on_small_integer_data(hip, nnt, shape):
     """Multiples of 1/2 in, multiples of 1/8 in U: every intermediate is exact in fp32, so the Winograd kernel equals F.conv2d bit for bit --
     ragged, odd, tiny and multi-region images, every cout-tile count, several cout groups and stages."""
     cin, cout, h, w, b = shape
@@ -124,7 +136,7 @@ def test_winograd_conv_exact_on_small_integer_data(hip, shape):
 @pytest.mark.gpu
 @pytest.mark.parametrize("form", ["relu", "leaky", "residual", "relu_post", "scale_residual", "film_leaky", "relu_sums", "leaky_sums", "nobias"])
 @pytest.mark.parametrize("shape", [(64, 64, 19, 45, 2), (16, 48, 8, 32, 1)])
-def test_winograd_epilogues_exact_on_small_integer_data(hip, form, shape):
+def test_winograd_epilogues_exact_on_small_integer_data(hip, nnt, form, shape):
     cin, cout, h, w, b = shape
     c, g = _int_conv(cin, cout, 77 + cin + len(form))
     if form == "nobias":
@@ -155,14 +167,14 @@ def test_winograd_epilogues_exact_on_small_integer_data(hip, form, shape):
     out = _wino(xn, c, want_sums=sums, **kw)
     if sums:
         out, s = out
-        assert s.shape[0] == b and s.shape[2] == cout and s.shape[1] == ((h + 3) // 4) * ((w + 31) // 32)
+        assert s.shape[0] == b and s.shape[2] == cout and s.shape[1] in ([_regions(h, w, nnt)] if nnt and cout % 64 == 0 else [_regions(h, w, 1), _regions(h, w, 2)])
         assert torch.equal(s.sum(dim=1).cpu(), v.sum(dim=(2, 3)))          # exact data: any summation order gives the same total
     assert torch.equal(out.cpu(), v.permute(0, 2, 3, 1).contiguous())
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(64, 64, 40, 72, 2), (128, 128, 17, 30, 1), (48, 96, 33, 65, 1), (512, 128, 9, 15, 1)])
-def test_winograd_conv_real_valued_within_fp32_block_tolerance(hip, shape):
+def test_winograd_conv_real_valued_within_fp32_block_tolerance(hip, nnt, shape):
     """Real-valued data: F(2,3) in fp32 differs from a direct fp32 convolution by rounding only -- the block tolerance of the fp32 path (2e-5 * max|ref|),
     against a float64 reference; frame i of a batch equals frame i alone bit for bit; run to run bit for bit."""
     cin, cout, h, w, b = shape
