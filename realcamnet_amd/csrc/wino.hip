@@ -415,7 +415,8 @@ static int wino_nnt(int H, int W, int cout, int num_cus) {
     const long i2 = ry * ceil_div(W, 32) * n_cg, i1 = ry * ceil_div(W, 16) * n_cg;
     const long s2 = 2L * num_cus, s1 = 3L * num_cus;    // block slots: the half-size form needs 155 registers and 30 KB of LDS -> three blocks per CU
     const long r2 = (i2 + s2 - 1) / s2, r1 = (i1 + s1 - 1) / s1;
-    return 11 * r1 < 20 * r2 ? 1 : 2;                  // a half-size item costs ~0.55 of a full one (per-stage overheads do not halve)
+    return 81 * r1 < 100 * r2 ? 1 : 2;                 // measured (tools/wino_probe.py, RC_DEBUG=wino_nnt=1|2): a round of half-size items on three blocks per CU takes 0.81 of a round of
+                                                       // full ones on two (64 -> 64 at 544 x 960: 192 us / 10.6 rounds vs 178 us / 7.97) -- half items win only where they save rounds
 }
 
 int wino_sum_slots(int H, int W, int cout) { return ceil_div(H, kWRH) * ceil_div(W, 16 * wino_nnt(H, W, cout, device_cu_count())); }

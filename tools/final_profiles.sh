@@ -2,8 +2,8 @@
 # Round-end evidence: PMC traffic passes, kernel-trace of the bench command, default bench line (with CPU baseline),
 # the other table rows, MFMA calibration.  usage: tools/final_profiles.sh TAG [ROUND]   (outputs under gpurun_out/)
 TAG=${1:-fin}
-ROUND=${2:-r05}
-mkdir -p gpurun_out
+ROUND=${2:-r06}
+mkdir -p gpurun_out gpurun_out/profiles_$TAG
 bash tools/pmc_bench.sh $TAG > gpurun_out/pmc_${TAG}.log 2>&1
 
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -35,13 +35,23 @@ bash tools/pmc_mfma.sh $TAG > gpurun_out/pmc_mfma_${TAG}.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_cmp_$TAG -o trace -- python tools/compress_trace.py > gpurun_out/compress_$TAG.txt 2>&1
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_torchrun_$TAG.json 2>/dev/null
 
+# round 6: the fp32 Winograd kernel (cfg2) -- kernel trace of the cfg2 command, layer-by-layer A/B against the implicit GEMM, both item sizes, the MFMA / VALU overlap
+# microbenchmark its structure rests on; the codec at one frame (eager / HIP-graph replay / compress / decompress)
+timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_cfg2_$TAG -o trace -- python bench.py --model LiteISPNet --dtype f32 --frames 1 --height 1080 --width 1920 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_cfg2_trace_$TAG.json 2> gpurun_out/bench_cfg2_trace_$TAG.err
+python tools/rocpd_summary.py gpurun_out/prof_cfg2_$TAG/trace_results.db > gpurun_out/cfg2_kernel_stats_$TAG.txt 2>&1
+RC_WINOGRAD=0 timeout 300 python bench.py --model LiteISPNet --dtype f32 --frames 1 --height 1080 --width 1920 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_cfg2_direct_$TAG.json 2>/dev/null
+( timeout 300 python tools/wino_probe.py; for v in 2 1; do echo "== RC_DEBUG=wino_nnt=$v"; RC_DEBUG=wino_nnt=$v timeout 300 python tools/wino_probe.py; done ) > gpurun_out/wino_probe_$TAG.txt 2>&1
+( cd tools/ubench && hipcc --offload-arch=gfx950 -O3 mfma_valu_overlap.hip -o /tmp/mvo 2>/dev/null && /tmp/mvo ) > gpurun_out/mvo_$TAG.txt 2>&1
+timeout 300 python tools/pmc_any.py $TAG "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_VALU_MFMA_BUSY_CYCLES;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY;GRBM_GUI_ACTIVE" -- python tools/wino_one.py 64 64 544 960 10 > gpurun_out/wino_pmc_$TAG.txt 2>&1
+timeout 400 python tools/codec_b1.py 1 --codec > gpurun_out/codec_b1_$TAG.txt 2>&1
+cp gpurun_out/cfg2_kernel_stats_$TAG.txt gpurun_out/wino_probe_$TAG.txt gpurun_out/mvo_$TAG.txt gpurun_out/wino_pmc_$TAG.txt gpurun_out/codec_b1_$TAG.txt gpurun_out/bench_cfg2_direct_$TAG.json gpurun_out/bench_cfg2_trace_$TAG.json gpurun_out/profiles_$TAG/ 2>/dev/null
+
 tail -c 400 gpurun_out/bench_default_$TAG.json; echo; cut -c1-160 gpurun_out/bench_nogma_$TAG.json gpurun_out/bench_cfg2_$TAG.json gpurun_out/bench_ispunet_$TAG.json gpurun_out/bench_codec_$TAG.json gpurun_out/bench_torchrun_$TAG.json
 
 # summaries are written ON the box (gpurun_out/ is capped at 64 MiB on the way back): keep them, the bench trace database and the small logs
-mkdir -p gpurun_out/profiles_$TAG
 cp gpurun_out/tail_fold_$TAG.txt gpurun_out/codec_probes_$TAG.txt gpurun_out/power_probe_$TAG.txt gpurun_out/auto_probe_$TAG.txt gpurun_out/thin_$TAG.txt gpurun_out/profiles_$TAG/ 2>/dev/null
 python tools/write_profiles.py $TAG $ROUND gpurun_out/profiles_$TAG > gpurun_out/profiles_$TAG/summary.json 2> gpurun_out/write_profiles_$TAG.err
 mkdir -p gpurun_out/keep_$TAG && cp gpurun_out/prof_$TAG/trace_results.db gpurun_out/keep_$TAG/bench_trace_results.db 2>/dev/null
 cp gpurun_out/prof_codec_$TAG/trace_results.db gpurun_out/keep_$TAG/codec_trace_results.db 2>/dev/null
-rm -rf gpurun_out/prof_* gpurun_out/pmc_${TAG}_* gpurun_out/pmcm_${TAG}_*
+rm -rf gpurun_out/prof_* gpurun_out/pmc_${TAG}_* gpurun_out/pmcm_${TAG}_* gpurun_out/pmca_${TAG}_*
 du -sh gpurun_out
