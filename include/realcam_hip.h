@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 12
+#define RC_ABI_VERSION 13
 
 typedef enum rc_status {
     RC_OK = 0,
@@ -453,6 +453,18 @@ int rc_gma_tail(const void* d_qkvp, const void* d_convv, const void* d_loc, cons
 int rc_gma_aggregate(const void* d_qkv, void* d_qkvp, void* d_loc, int batch, int H, int W, const float* d_dw3, const float* d_dw5,
                      const float* d_dw7, const float* d_dwl, const float* d_pw, const float* d_pwl, const float* d_bn_scale,
                      const float* d_bn_shift, const float* d_ln_g, const float* d_ln_b, float* d_kmax, void* stream);
+
+/* rc_gma_qkv_aggregate (ABI 13): rc_gma_ln_qkv + rc_gma_aggregate as ONE launch (groupmix.py:178 after :293, then :56-105) -- the 240-channel
+ * qkv map is never written: a block LayerNorms x (B,H,W,80) for a 16 x 32 tile + 3-pixel halo once, keeps the normalised tokens in registers as
+ * MFMA B fragments and produces qkv one 16-channel segment at a time into an LDS halo tile that the aggregator's depth-wise / point-wise /
+ * BatchNorm / Hardswish chain consumes.  d_wq_natural: the (240, 80) qkv weight as rc_chain_pack_weights_natural fragments (output rows in
+ * natural channel order: 16-row tile m = segment m); d_bq (240) fp32 or NULL; the other arguments as rc_gma_ln_qkv / rc_gma_aggregate.
+ * Results (qkvp, loc, kmax) are bitwise those of the two-launch path. */
+int rc_chain_pack_weights_natural(const float* w, int cin, int cout, void* dst);   /* host; rc_chain_packed_bytes(cin, cout) bytes; 16 | cin, 16 | cout */
+int rc_gma_qkv_aggregate(const void* d_x, const void* d_wq_natural, const float* d_bq, const float* d_ln1_gamma, const float* d_ln1_beta, float eps,
+                         void* d_qkvp, void* d_loc, int batch, int H, int W, const float* d_dw3, const float* d_dw5, const float* d_dw7,
+                         const float* d_dwl, const float* d_pw, const float* d_pwl, const float* d_bn_scale, const float* d_bn_shift,
+                         const float* d_ln_g, const float* d_ln_b, float* d_kmax, void* stream);
 
 /* d_kmax (optional, may be NULL): (batch, 64) fp32, on return the per-channel maximum over the image of the aggregated k (the stored bf16
  * values) -- the shift of softmax_N(k) (models/groupmix.py:190) -- accumulated by the aggregator itself with integer atomics (a maximum is

@@ -17,7 +17,7 @@ HEADER = PKG.parent / "include" / "realcam_hip.h"
 RC_F32, RC_BF16, RC_U16 = 0, 1, 2
 RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY, RC_ACT_GELU, RC_ACT_RELU_POST = 0, 1, 2, 3, 4
 RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW = 0, 1, 2, 3
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class ConvDesc(C.Structure):
@@ -140,6 +140,8 @@ _SIGS = {
     "rc_gma_ln_qkv": (C.c_int, [_P, _P, C.c_longlong, _P, _P, _P, _P, _F, _P]),
     "rc_gma_tail": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "rc_gma_aggregate": (C.c_int, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rc_chain_pack_weights_natural": (C.c_int, [_P, _I, _I, _P]),
+    "rc_gma_qkv_aggregate": (C.c_int, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rc_cat_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_longlong, _I, _P, _P, _P]),
     "rc_gdn_chain": (C.c_int, [_P, _P, _P, C.c_longlong, _I, _P, _P, _I, _P]),
     "rc_ln_linear": (C.c_int, [_P, _P, C.c_longlong, _I, _I, _P, _P, _P, _P, _F, _P]),

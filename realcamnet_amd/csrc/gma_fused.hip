@@ -62,6 +62,17 @@ __device__ __forceinline__ uint4 pack_pair(const f32x4& lo, const f32x4& hi) {
     return make_uint4(pk(lo[0], lo[1]), pk(lo[2], lo[3]), pk(hi[0], hi[1]), pk(hi[2], hi[3]));
 }
 __device__ __forceinline__ uint2 pack_tail(const f32x4& v) { return make_uint2(pk(v[0], v[1]), pk(v[2], v[3])); }
+// fp32 quad -> packed bf16 with the conversion visible to the compiler (the same v_cvt_pk_bf16_f32, round-to-nearest-even): in rc_gma_qkv_aggregate the
+// packed values are MFMA B operands a few instructions later and their registers are recycled between the point-wise MFMAs; with the inline-asm
+// form (pack_tail) hipcc's hazard recogniser did not see those writes -- it rewrote an in-flight MFMA's B registers in the slot right behind
+// it and fed the next MFMA one instruction after the conversion, and the third pixel of every 7x7 patch came out wrong, differently run to run.
+typedef __bf16 qa_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float qa_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t qa_pk(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(qa_f32x2{lo, hi}, qa_bf16x2));
+}
+__device__ __forceinline__ uint2 qa_pack(const f32x4& v) { return make_uint2(qa_pk(v[0], v[1]), qa_pk(v[2], v[3])); }
+
 // bf16 pairs -> fp32, as vectors (no float arrays: with the vector-typed conversion above they would not be promoted to registers)
 __device__ __forceinline__ f32x4 up_lo(const uint4& r) {
     return f32x4{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
@@ -697,7 +708,7 @@ __device__ __forceinline__ void agg_conv_job(const AggArgs& a, char* s_x, float*
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-            mma16(apw, pack_tail(acc[o][c]), d);
+            mma16(apw, qa_pack(acc[o][c]), d);
             f32x4 v = d * sc + sh;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
@@ -783,7 +794,7 @@ __global__ __launch_bounds__(AG_THREADS) void gma_agg_kernel(AggArgs a) {
 #pragma unroll
             for (int o = 0; o < 2; ++o)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) mma16(apw, pack_tail(acc[o][c]), d[o][c]);
+                for (int c = 0; c < 4; ++c) mma16(apw, qa_pack(acc[o][c]), d[o][c]);
         }
         const f32x4 lg = ld4(a.ln_g + 4 * q), lb = ld4(a.ln_b + 4 * q);
 #pragma unroll
@@ -898,6 +909,382 @@ extern "C" int rc_gma_crpe(const void* d_qkvp, void* d_convv, int batch, int H, 
     const size_t blocks = (((size_t)a.tiles_x * a.tiles_y * batch + 7) / 8) * 8 * 4;
     RC_REQUIRE(blocks < (1ull << 31), "rc_gma_crpe: too many tiles");
     hipLaunchKernelGGL(gma_crpe_kernel, dim3((unsigned)blocks), dim3(AG_THREADS), 0, as_stream(stream), a);
+    RC_HIP_CHECK(hipGetLastError());
+    return RC_OK;
+}
+
+// ======================================================================================================================================
+// LayerNorm1 + qkv Linear + Aggregator as ONE launch (rc_gma_qkv_aggregate; groupmix.py:178 after :293, then :56-105).
+// rc_gma_ln_qkv wrote the 240-channel qkv map (2.0 GB at cfg3) and rc_gma_aggregate read it back with halos: 6.4 GB for the pair.  Here a
+// block of 8 waves owns a 16 x 32 pixel tile: it loads x (80 channels) for the tile + a 3-pixel halo ONCE (836 tokens), LayerNorms them and
+// keeps the normalised tokens in registers as MFMA B fragments (7 column tiles of 16 tokens per wave = 70 VGPRs); then, segment by segment
+// (15 segments of 16 channels = 5 x {q, k, v}): one 16-row slice of the qkv GEMM (3 K-steps per column tile) -> bf16 -> an LDS halo tile in
+// the aggregator's pixel-major layout (zero outside the image, which is the zero padding of the depth-wise convs) -> the aggregator's own
+// depth-wise K x K / point-wise / BatchNorm / Hardswish chain on a 2 x 2 pixel patch per lane -> 8-byte stores.  qkv never exists in HBM:
+// x in (0.67 GB + halo re-reads through L2), qkv' + loc out (1.7 GB).  The LDS tile is double-buffered: segment s + 1's MFMAs are issued before
+// segment s's depth-wise FMAs and their results are packed after them, so there is ONE barrier per segment.
+// Arithmetic (K-step order, bias after the chain, fmaf taps in (dy, dx) order, every bf16 rounding point) is that of the two-launch
+// path: the results are bitwise equal to rc_gma_ln_qkv + rc_gma_aggregate (tests/test_gma.py).
+namespace rc {
+namespace gf {
+
+constexpr int QA_WAVES = 8, QA_THREADS = 64 * QA_WAVES;
+constexpr int QA_THH = AG_TH + 6, QA_TWH = AG_TW + 6, QA_TOK = QA_THH * QA_TWH;            // 22 x 38 = 836 tokens
+constexpr int QA_RS = QA_TWH * AG_PS + AG_RPAD;                                            // LDS row stride: 1528 bytes
+constexpr int QA_S = QA_THH * QA_RS;                                                       // one halo tile of one segment: 33 616 bytes
+constexpr int QA_NC = ((QA_TOK + 15) / 16 + QA_WAVES - 1) / QA_WAVES;                      // column tiles of 16 tokens per wave: 7
+constexpr int QA_WSEG = tile_bytes(kC);                                                    // 2560 bytes of A fragments per segment
+constexpr int QA_OFF_W = 2 * QA_S, QA_OFF_BQ = QA_OFF_W + 15 * QA_WSEG, QA_OFF_GB = QA_OFF_BQ + 240 * 4, QA_OFF_TAPS = QA_OFF_GB + 160 * 4,
+              QA_N_TAPS = 9 * 16 + 25 * 16 + 49 * 16 + 3 * 9 * 16, QA_OFF_BN = QA_OFF_TAPS + QA_N_TAPS * 4, QA_OFF_PW = QA_OFF_BN + 160 * 4,
+              QA_OFF_RED = QA_OFF_PW + 6 * 64 * 8, QA_OFF_SOFF = QA_OFF_RED + 4 * QA_WAVES * 16 * 4, QA_OFF_PYX = QA_OFF_SOFF + QA_NC * QA_THREADS * 4, QA_LDS = QA_OFF_PYX + QA_NC * QA_THREADS * 4;
+static_assert(QA_S % 16 == 0 && QA_OFF_W % 16 == 0 && QA_OFF_PW % 8 == 0 && QA_LDS <= 160 * 1024, "qkv + aggregate LDS layout");
+
+struct QaArgs {
+    const bf16_t* x; bf16_t* qkvp; bf16_t* loc; float* kmax;
+    int batch, H, W, tiles_x, tiles_y, n_tiles, tiles_per_block;
+    size_t plane;
+    const void* wq; const float* bq;                 // rc_chain_pack_weights_natural(80 -> 240) fragments; bias [240] or NULL
+    const float* ln1_g; const float* ln1_b; float eps;
+    const float* dw[3]; const float* dwl; const float* pw; const float* pwl;
+    const float* bn_scale; const float* bn_shift; const float* ln_g; const float* ln_b;
+    int dbg;                                         // rc_debug_set("qa_flags"): knock-outs for timing (1 no depth-wise FMAs, 2 no qkv' stores, 4 no GEMM, 8 no x loads)
+};
+
+// one token column tile of layernorm80 (same expressions, same order)
+__device__ __forceinline__ void ln80_one(const Act<kC>& in, Act<kC>& out, const float* gb, int g, float eps) {
+    const f32x4 g0 = ld4(gb + 8 * g), g1 = ld4(gb + 8 * g + 4), g2 = ld4(gb + 32 + 8 * g), g3 = ld4(gb + 32 + 8 * g + 4), g4 = ld4(gb + 64 + 4 * g);
+    const float* bb = gb + kC;
+    const f32x4 e0 = ld4(bb + 8 * g), e1 = ld4(bb + 8 * g + 4), e2 = ld4(bb + 32 + 8 * g), e3 = ld4(bb + 32 + 8 * g + 4), e4 = ld4(bb + 64 + 4 * g);
+    const f32x4 v0 = up_lo(in.f[0]), v1 = up_hi(in.f[0]), v2 = up_lo(in.f[1]), v3 = up_hi(in.f[1]), v4 = up_tail(in.t);
+    const f32x4 sv = ((v0 + v1) + (v2 + v3)) + v4;
+    float s = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+    const float mean = s / (float)kC;
+    const f32x4 d0 = v0 - mean, d1 = v1 - mean, d2 = v2 - mean, d3 = v3 - mean, d4 = v4 - mean;
+    const f32x4 qv = ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + d4 * d4;
+    float q = (qv[0] + qv[1]) + (qv[2] + qv[3]);
+    q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+    const float rstd = 1.f / sqrtf(q / (float)kC + eps);
+    const uint2 p0 = qa_pack(d0 * rstd * g0 + e0), p1 = qa_pack(d1 * rstd * g1 + e1), p2 = qa_pack(d2 * rstd * g2 + e2), p3 = qa_pack(d3 * rstd * g3 + e3);
+    out.f[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
+    out.f[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
+    out.t = qa_pack(d4 * rstd * g4 + e4);
+}
+
+// depth-wise K x K of this lane's 2 x 2 patch (tile rows prow, prow + 1; columns pcol, pcol + 1), channels 4 q .. 4 q + 3, from the halo-3 tile S;
+// taps in (dy, dx) order by fmaf, as agg_dw
+template <int K>
+__device__ __forceinline__ void qa_dw(const char* S, const float* s_w, int prow, int pcol, int q, f32x4 (&acc)[2][2]) {
+    constexpr int R = K / 2;
+    const char* base = S + (prow + 3 - R) * QA_RS + (pcol + 3 - R) * AG_PS + q * 8;
+#pragma unroll 1
+    for (int iy = 0; iy < K + 1; ++iy) {
+        f32x4 xin[K + 1];
+#pragma unroll
+        for (int c = 0; c < K + 1; ++c) xin[c] = up_tail(*reinterpret_cast<const uint2*>(base + iy * QA_RS + c * AG_PS));
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int dy = iy - o;
+            if (dy < 0 || dy >= K) continue;
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+                const f32x4 w = ld4(s_w + (dy * K + dx) * 16 + 4 * q);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[o][c][e] = __builtin_fmaf(w[e], xin[c + dx][e], acc[o][c][e]);
+            }
+        }
+    }
+}
+
+struct QaGeom { int y0, x0, prow, pcol, q, H, W, dbg; size_t pix0; };
+
+// maximum over the 16 lanes of a DPP row (lanes with the same q): xor 1, xor 2 inside quads, then the mirrored half and the mirrored row
+__device__ __forceinline__ float row_max16(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)));   // row_half_mirror
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true)));   // row_mirror
+    return v;
+}
+
+// one conv group of one of q / k / v: depth-wise -> point-wise (MFMA) -> [between(): the next segment's GEMM is issued here, behind the four
+// point-wise MFMAs and under the VALU work below] -> BN + Hardswish -> qkvp; returns the maximum of the stored values
+template <int K, typename F>
+__device__ __forceinline__ f32x4 qa_conv_group(const char* S, const float* s_w, uint2 apw, f32x4 sc, f32x4 sh, bf16_t* outp, const QaGeom& t, F&& between) {
+    f32x4 d[2][2];
+    {
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[o][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (K > 1) { if (!(t.dbg & 1)) qa_dw<K>(S, s_w, t.prow, t.pcol, t.q, acc); }
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                d[o][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (K > 1) mma16(apw, qa_pack(acc[o][c]), d[o][c]);
+                else d[o][c] = up_tail(*reinterpret_cast<const uint2*>(S + (t.prow + 3 + o) * QA_RS + (t.pcol + 3 + c) * AG_PS + t.q * 8));   // pass-through group
+            }
+    }
+    between();
+    f32x4 vmax = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 v = d[o][c] * sc + sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
+            if (t.y0 + t.prow + o < t.H && t.x0 + t.pcol + c < t.W && !(t.dbg & 2)) {
+                const uint2 pkd = qa_pack(v);
+                *reinterpret_cast<uint2*>(outp + (t.pix0 + (size_t)o * t.W + c) * kSEG) = pkd;
+                const f32x4 r = up_tail(pkd);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vmax[e] = fmaxf(vmax[e], r[e]);
+            }
+        }
+    return vmax;
+}
+
+__global__ __launch_bounds__(QA_THREADS) void gma_qkv_agg_kernel(QaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* s_wq = lds + QA_OFF_W;
+    float* s_bq = reinterpret_cast<float*>(lds + QA_OFF_BQ);
+    float* s_gb = reinterpret_cast<float*>(lds + QA_OFF_GB);
+    float* s_taps = reinterpret_cast<float*>(lds + QA_OFF_TAPS);            // dw3 [144] | dw5 [400] | dw7 [784] | local [3][144]
+    float* s_bn = reinterpret_cast<float*>(lds + QA_OFF_BN);                // scale [64] | shift [64] | ln_g [16] | ln_b [16]
+    uint2* s_pw = reinterpret_cast<uint2*>(lds + QA_OFF_PW);                // A fragments: groups 1..3, local q / k / v
+    float* s_red = reinterpret_cast<float*>(lds + QA_OFF_RED);              // [4 groups][8 waves][16 channels]: row maxima of the aggregated k
+    int* s_soff = reinterpret_cast<int*>(lds + QA_OFF_SOFF);                // [QA_NC][512]: LDS offset of each thread's tokens in the halo tile
+    int* s_pyx = reinterpret_cast<int*>(lds + QA_OFF_PYX);                  // [QA_NC][512]: (row << 8) | column of the token in the halo tile, -1 beyond the last
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+    for (int i = tid; i < 15 * QA_WSEG / 16; i += QA_THREADS) reinterpret_cast<uint4*>(s_wq)[i] = reinterpret_cast<const uint4*>(a.wq)[i];
+    for (int i = tid; i < 240; i += QA_THREADS) s_bq[i] = a.bq ? a.bq[i] : 0.f;
+    for (int i = tid; i < kC; i += QA_THREADS) { s_gb[i] = a.ln1_g[i]; s_gb[kC + i] = a.ln1_b[i]; }
+    for (int i = tid; i < 144; i += QA_THREADS) s_taps[i] = a.dw[0][i];
+    for (int i = tid; i < 400; i += QA_THREADS) s_taps[144 + i] = a.dw[1][i];
+    for (int i = tid; i < 784; i += QA_THREADS) s_taps[544 + i] = a.dw[2][i];
+    for (int i = tid; i < 432; i += QA_THREADS) s_taps[1328 + i] = a.dwl[i];
+    for (int i = tid; i < 64; i += QA_THREADS) { s_bn[i] = a.bn_scale[i]; s_bn[64 + i] = a.bn_shift[i]; }
+    if (tid < 16) { s_bn[128 + tid] = a.ln_g[tid]; s_bn[144 + tid] = a.ln_b[tid]; }
+    for (int i = tid; i < 6 * 64; i += QA_THREADS) {
+        const int f = i >> 6;
+        s_pw[i] = f < 3 ? agg_afrag(a.pw + f * 256, 16, 0, i & 63) : agg_afrag(a.pwl, 48, 16 * (f - 3), i & 63);
+    }
+    // token t = 16 (wave + 8 i) + n of the 22 x 38 halo tile, row-major: its LDS offset (tile-invariant), -1 beyond the last token
+#pragma unroll
+    for (int i = 0; i < QA_NC; ++i) {
+        const int tk = 16 * (wave + QA_WAVES * i) + n;
+        const int py = tk / QA_TWH, px = tk - py * QA_TWH;
+        s_soff[i * QA_THREADS + tid] = tk < QA_TOK ? py * QA_RS + px * AG_PS + 8 * q : -1;
+        s_pyx[i * QA_THREADS + tid] = tk < QA_TOK ? (py << 8) | px : -1;
+    }
+    __syncthreads();
+
+    QaGeom t;
+    t.prow = 2 * wave; t.pcol = 2 * n; t.q = q; t.H = a.H; t.W = a.W; t.dbg = a.dbg;
+
+    const int t_begin = blockIdx.x * a.tiles_per_block;
+    const int t_end = t_begin + a.tiles_per_block < a.n_tiles ? t_begin + a.tiles_per_block : a.n_tiles;
+#pragma unroll 1
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        int r = tile;
+        const int tx = r % a.tiles_x; r /= a.tiles_x;
+        const int ty = r % a.tiles_y;
+        const int b = r / a.tiles_y;
+        t.y0 = ty * AG_TH; t.x0 = tx * AG_TW;
+        t.pix0 = ((size_t)b * a.H + t.y0 + t.prow) * a.W + t.x0 + t.pcol;
+
+        // ---- x of the halo tile -> LayerNorm1 -> B fragments in registers
+        Act<kC> n1[QA_NC];
+        unsigned inimg = 0;
+        {
+            Act<kC> xin[QA_NC];
+#pragma unroll
+            for (int i = 0; i < QA_NC; ++i) {
+                const int pyx = s_pyx[i * QA_THREADS + tid];
+                const int gy = t.y0 - 3 + (pyx >> 8), gx = t.x0 - 3 + (pyx & 255);
+                const bool ok = pyx >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                xin[i].f[0] = make_uint4(0u, 0u, 0u, 0u); xin[i].f[1] = make_uint4(0u, 0u, 0u, 0u); xin[i].t = make_uint2(0u, 0u);
+                if (ok) {
+                    if (!(a.dbg & 8)) load_act<kC>(a.x + (((size_t)b * a.H + gy) * a.W + gx) * kC, q, xin[i]);
+                    inimg |= 1u << i;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < QA_NC; ++i) ln80_one(xin[i], n1[i], s_gb, q, a.eps);
+        }
+
+        f32x4 ga[QA_NC];
+        auto g_issue = [&](int seg) {
+            const char* w = s_wq + seg * QA_WSEG;
+            const uint4 a0 = *reinterpret_cast<const uint4*>(w + lane * 16), a1 = *reinterpret_cast<const uint4*>(w + 1024 + lane * 16);
+            const uint2 at = *reinterpret_cast<const uint2*>(w + 2048 + lane * 8);
+#pragma unroll
+            for (int i = 0; i < QA_NC; ++i) {
+                ga[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!(a.dbg & 4)) { mma32(a0, n1[i].f[0], ga[i]); mma32(a1, n1[i].f[1], ga[i]); mma16(at, n1[i].t, ga[i]); }
+            }
+        };
+        auto g_store = [&](int seg, char* S) {
+            const f32x4 bias = ld4(s_bq + 16 * seg + 4 * q);
+#pragma unroll
+            for (int i = 0; i < QA_NC; ++i) {
+                uint2 pkd = qa_pack(ga[i] + bias);
+                if (!((inimg >> i) & 1u)) pkd = make_uint2(0u, 0u);
+                const int so = s_soff[i * QA_THREADS + tid];
+                if (so >= 0) *reinterpret_cast<uint2*>(S + so) = pkd;
+            }
+        };
+        // segment order: the local branch's three segments first (its 16 accumulators are then dead during the wide windows), then q, k, v
+        auto seg_at = [](int k) { return k < 3 ? 5 * k + 4 : (k - 3) + (k - 3) / 4; };
+
+        g_issue(seg_at(0));
+        g_store(seg_at(0), lds);
+        __syncthreads();
+        {   // ---- k = 0..2: local branch, dw 3x3 of q4 / k4 / v4 -> 48 -> 16 (accumulated over the three) -> LayerNorm(16) -> Hardswish
+            f32x4 dl[2][2];
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) dl[o][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int which = 0; which < 3; ++which) {
+                const char* S = lds + (which & 1) * QA_S;
+                {
+                    f32x4 acc[2][2];
+#pragma unroll
+                    for (int o = 0; o < 2; ++o)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) acc[o][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    qa_dw<3>(S, s_taps + 1328 + which * 144, t.prow, t.pcol, q, acc);
+                    const uint2 apw = s_pw[(3 + which) * 64 + lane];
+#pragma unroll
+                    for (int o = 0; o < 2; ++o)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) mma16(apw, qa_pack(acc[o][c]), dl[o][c]);
+                }
+                g_issue(seg_at(which + 1));
+                g_store(seg_at(which + 1), lds + ((which + 1) & 1) * QA_S);
+                __syncthreads();
+            }
+            const f32x4 lg = ld4(s_bn + 128 + 4 * q), lb = ld4(s_bn + 144 + 4 * q);
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const f32x4 tt = dl[o][c] + 0.f;
+                    float s = (tt[0] + tt[1]) + (tt[2] + tt[3]);
+                    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+                    const float mean = s / 16.f;
+                    const f32x4 dd = tt - mean;
+                    const f32x4 d2 = dd * dd;
+                    float var = (d2[0] + d2[1]) + (d2[2] + d2[3]);
+                    var += __shfl_xor(var, 16); var += __shfl_xor(var, 32);
+                    const float rstd = 1.f / sqrtf(var / 16.f + 1e-5f);
+                    f32x4 v = dd * rstd * lg + lb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
+                    if (t.y0 + t.prow + o < a.H && t.x0 + t.pcol + c < a.W)
+                        *reinterpret_cast<uint2*>(a.loc + (t.pix0 + (size_t)o * a.W + c) * kSEG + 4 * q) = qa_pack(v);
+                }
+        }
+#pragma unroll 1
+        for (int k = 3; k < 15; ++k) {   // ---- the four groups of q, k, v
+            const char* S = lds + (k & 1) * QA_S;
+            const int seg = seg_at(k), nseg = seg_at(k + 1);
+            const int which = seg / 5, g5 = seg - 5 * which;
+            auto between = [&]() { if (k + 1 < 15) g_issue(nseg); };
+            bf16_t* outp = a.qkvp + (size_t)(4 * which + g5) * a.plane + 4 * q;
+            const f32x4 sc = ld4(s_bn + 16 * g5 + 4 * q), sh = ld4(s_bn + 64 + 16 * g5 + 4 * q);
+            f32x4 vmax;
+            if (g5 == 3) vmax = qa_conv_group<7>(S, s_taps + 544, s_pw[2 * 64 + lane], sc, sh, outp, t, between);
+            else if (g5 == 2) vmax = qa_conv_group<5>(S, s_taps + 144, s_pw[1 * 64 + lane], sc, sh, outp, t, between);
+            else if (g5 == 1) vmax = qa_conv_group<3>(S, s_taps, s_pw[lane], sc, sh, outp, t, between);
+            else vmax = qa_conv_group<1>(S, s_taps, s_pw[lane], sc, sh, outp, t, between);
+            if (which == 1 && a.kmax != nullptr) {                            // rows of 16 lanes share a channel quad: row maximum -> LDS
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vmax[e] = row_max16(vmax[e]);
+                if (n == 0) *reinterpret_cast<float4*>(s_red + (g5 * QA_WAVES + wave) * 16 + 4 * q) = make_float4(vmax[0], vmax[1], vmax[2], vmax[3]);
+            }
+            if (seg == 10 && a.kmax != nullptr && tid < 64) {                 // all four k segments are done (a barrier ago): one atomic per channel and tile
+                const float* p = s_red + (tid >> 4) * QA_WAVES * 16 + (tid & 15);
+                float m = p[0];
+#pragma unroll
+                for (int w = 1; w < QA_WAVES; ++w) m = fmaxf(m, p[16 * w]);
+                atomic_max_f32(a.kmax + (size_t)b * 64 + tid, m);
+            }
+            if (k + 1 < 15) g_store(nseg, lds + ((k + 1) & 1) * QA_S);
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace gf
+}  // namespace rc
+
+namespace rc { int g_qa_flags = 0; }   // rc_debug_set("qa_flags", v): timing knock-outs of rc_gma_qkv_aggregate (results are wrong with any bit set)
+
+extern "C" int rc_chain_pack_weights_natural(const float* w, int cin, int cout, void* dst) {
+    using namespace rc;
+    using namespace rc::gf;
+    RC_REQUIRE(w && dst, "rc_chain_pack_weights_natural: null pointer");
+    RC_REQUIRE(cin >= 16 && cin % 16 == 0 && cout >= 16 && cout % 16 == 0, "rc_chain_pack_weights_natural: cin and cout must be multiples of 16");
+    const int mt = cout / 16, ks = cin / 32, tb = tile_bytes(cin);
+    uint16_t* out = static_cast<uint16_t*>(dst);
+    for (int m = 0; m < mt; ++m) {
+        uint16_t* tile = out + (size_t)m * tb / 2;
+        for (int s = 0; s < ks; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i)
+                    tile[(s * 64 + lane) * 8 + i] = host_f32_to_bf16(w[(size_t)(16 * m + (lane & 15)) * cin + 32 * s + 8 * (lane >> 4) + i]);
+        if (cin % 32)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i)
+                    tile[ks * 512 + lane * 4 + i] = host_f32_to_bf16(w[(size_t)(16 * m + (lane & 15)) * cin + 32 * ks + 4 * (lane >> 4) + i]);
+    }
+    return RC_OK;
+}
+
+extern "C" int rc_gma_qkv_aggregate(const void* d_x, const void* d_wq_natural, const float* d_bq, const float* d_ln1_g, const float* d_ln1_b, float eps,
+                                    void* d_qkvp, void* d_loc, int batch, int H, int W, const float* d_dw3, const float* d_dw5, const float* d_dw7,
+                                    const float* d_dwl, const float* d_pw, const float* d_pwl, const float* d_bn_scale, const float* d_bn_shift,
+                                    const float* d_ln_g, const float* d_ln_b, float* d_kmax, void* stream) {
+    using namespace rc;
+    using namespace rc::gf;
+    RC_REQUIRE(d_x && d_wq_natural && d_ln1_g && d_ln1_b && d_qkvp && d_loc && d_dw3 && d_dw5 && d_dw7 && d_dwl && d_pw && d_pwl && d_bn_scale &&
+               d_bn_shift && d_ln_g && d_ln_b, "rc_gma_qkv_aggregate: null pointer");
+    RC_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "rc_gma_qkv_aggregate: bad shape");
+    QaArgs a;
+    a.x = static_cast<const bf16_t*>(d_x); a.qkvp = static_cast<bf16_t*>(d_qkvp); a.loc = static_cast<bf16_t*>(d_loc); a.kmax = d_kmax;
+    a.batch = batch; a.H = H; a.W = W; a.tiles_x = ceil_div(W, AG_TW); a.tiles_y = ceil_div(H, AG_TH);
+    const long long n_tiles = (long long)a.tiles_x * a.tiles_y * batch;
+    RC_REQUIRE(n_tiles < (1ll << 31), "rc_gma_qkv_aggregate: too many tiles");
+    a.n_tiles = (int)n_tiles;
+    a.plane = (size_t)batch * H * W * kSEG;
+    a.wq = d_wq_natural; a.bq = d_bq; a.ln1_g = d_ln1_g; a.ln1_b = d_ln1_b; a.eps = eps;
+    a.dw[0] = d_dw3; a.dw[1] = d_dw5; a.dw[2] = d_dw7; a.dwl = d_dwl; a.pw = d_pw; a.pwl = d_pwl;
+    a.bn_scale = d_bn_scale; a.bn_shift = d_bn_shift; a.ln_g = d_ln_g; a.ln_b = d_ln_b;
+    a.dbg = g_qa_flags;
+    int dev = 0;
+    RC_HIP_CHECK(hipGetDevice(&dev));
+    RC_REQUIRE(dev >= 0 && dev < 64, "rc_gma_qkv_aggregate: device index out of range");
+    static int cus[64] = {};
+    static bool attr[64] = {};
+    if (!cus[dev]) RC_HIP_CHECK(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    if (!attr[dev]) {
+        RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gma_qkv_agg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr[dev] = true;
+    }
+    if (d_kmax) RC_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_kmax), (int)0xff800000u /* -inf */, (size_t)batch * 64, as_stream(stream)));
+    int blocks = a.n_tiles < cus[dev] ? a.n_tiles : cus[dev];                // one 8-wave block per CU (115 KB of LDS), a contiguous run of tiles each
+    a.tiles_per_block = (a.n_tiles + blocks - 1) / blocks;
+    blocks = (a.n_tiles + a.tiles_per_block - 1) / a.tiles_per_block;
+    hipLaunchKernelGGL(gma_qkv_agg_kernel, dim3((unsigned)blocks), dim3(QA_THREADS), QA_LDS, as_stream(stream), a);
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }

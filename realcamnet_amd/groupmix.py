@@ -145,6 +145,25 @@ class Aggregator(nn.Module):
         return torch.ops.realcam.gma_aggregate(qkv, dw3, dw5, dw7, dwl, pw, pwl, scale, shift, ops.f32_param(ln, "weight"),
                                                ops.f32_param(ln, "bias"))
 
+    def _run_front(self, x, norm1, qkv_linear):
+        """x (B,H,W,80) bf16 -> (qkvp, loc, kmax) = _run_fused(qkv(LayerNorm1(x))) in ONE launch (rc_gma_qkv_aggregate): the 240-channel qkv map is
+        produced 16 channels at a time into LDS and consumed there (upstream groupmix.py:178 after :293, then :56-105)."""
+        seg = 16
+
+        def taps(w1, w2, w3, w0):
+            return (ops.dw_taps(w1), ops.dw_taps(w2), ops.dw_taps(w3),
+                    ops.dw_taps(w0).reshape(9, 3, seg).permute(1, 0, 2).contiguous())      # local: (which, tap, channel)
+        dw3, dw5, dw7, dwl = ops.host_cached(self, "taps_exact", [self.agg1.conv1.weight, self.agg2.conv1.weight, self.agg3.conv1.weight,
+                                                                 self.agg0.conv.conv1.weight], taps)
+        scale, shift, pw, pwl = self._folded()
+        ln = self.agg0.norm
+        if abs(ln.eps - 1e-5) > 0:
+            raise NotImplementedError("Aggregator: LayerNorm eps must be the default 1e-5")
+        f32 = ops.f32_param
+        return torch.ops.realcam.gma_qkv_aggregate(x, ops.packed_chain_natural(qkv_linear), f32(qkv_linear, "bias") if qkv_linear.bias is not None else None,
+                                                   f32(norm1, "weight"), f32(norm1, "bias"), float(norm1.eps), dw3, dw5, dw7, dwl, pw, pwl,
+                                                   scale, shift, f32(ln, "weight"), f32(ln, "bias"))
+
 
 class ConvRelPosEnc(nn.Module):
     """q * depth-wise conv(v) with per-head-group windows (upstream groupmix.py:108-156)."""
@@ -286,9 +305,14 @@ class GMA_Block(nn.Module):
         if self._fusable(a) and (post is None or post[0].weight.shape[0] == 192):
             R = torch.ops.realcam
             f32 = ops.f32_param
-            wq, bq = ops.packed_chain(self.att.qkv)
-            qkv = R.gma_ln_qkv(x, wq, bq, f32(self.norm1, "weight"), f32(self.norm1, "bias"), float(self.norm1.eps))
-            qkvp, loc, convv, ktv = self.att._context(qkv)
+            if ops.FUSE_GMA_FRONT:                                          # LayerNorm1 + qkv + aggregators: one launch, qkv stays on chip
+                qkvp, loc, kmax = self.att.aggregator._run_front(x, self.norm1, self.att.qkv)
+                convv = self.att.crpe._conv_v(qkvp)
+                ktv = R.gma_kv_mfma(qkvp, kmax, float(self.att.scale))
+            else:
+                wq, bq = ops.packed_chain(self.att.qkv)
+                qkv = R.gma_ln_qkv(x, wq, bq, f32(self.norm1, "weight"), f32(self.norm1, "bias"), float(self.norm1.eps))
+                qkvp, loc, convv, ktv = self.att._context(qkv)
             wp, bp = ops.packed_chain(self.att.proj)
             w1, b1 = ops.packed_chain(self.mlp.fc1)
             w2, b2 = ops.packed_chain(self.mlp.fc2)

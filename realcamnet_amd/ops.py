@@ -150,9 +150,27 @@ def packed_chain(mod):
     return pair
 
 
+def packed_chain_natural(mod):
+    """bf16 MFMA A fragments of an nn.Linear / 1x1 conv with the output rows in NATURAL channel order (16-row tile m = channels 16 m ..), for
+    kernels that consume the accumulators by 16-channel segment (realcam::gma_qkv_aggregate); cached on the module."""
+    w = mod.weight
+    c = _cache(mod)
+    key = _key(w)
+    hit = c.get("chain_natural")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if not w.is_cuda:
+        raise RuntimeError("weights are not on a HIP device; move the module with .cuda() first")
+    packed = _R.chain_pack_weights_natural(w.detach().reshape(w.shape[0], w.shape[1]))
+    c["chain_natural"] = (key, packed)
+    return packed
+
+
 # The per-token stages of GMA_Block (LayerNorm1 + qkv; attention read-out + proj + LayerNorm2 + MLP [+ the net's output conv]) as
 # two launches with register-resident activations (csrc/gma_fused.hip) instead of nine layer-by-layer ones.  Built for dim 80, bf16.
 FUSE_GMA = True
+# LayerNorm1 + qkv + Aggregator as one launch (rc_gma_qkv_aggregate: qkv never reaches HBM) instead of rc_gma_ln_qkv + rc_gma_aggregate; same bits.
+FUSE_GMA_FRONT = os.environ.get("RC_GMA_FRONT", "0") != "0"
 
 
 class _ConvView:

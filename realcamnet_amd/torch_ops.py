@@ -671,6 +671,28 @@ define("gma_aggregate(Tensor qkv, Tensor dw3, Tensor dw5, Tensor dw7, Tensor dwl
                                   lg.data_ptr(), lb.data_ptr(), outs[2].data_ptr(), _stream()), "rc_gma_aggregate"))
 
 
+def _cpackn_launch(wp, weight):
+    cout, cin = weight.shape[0], weight.shape[1]
+    w_host = np.ascontiguousarray(weight.detach().float().reshape(cout, cin).cpu().numpy())
+    dst = np.empty(wp.numel(), dtype=np.uint8)
+    check(lib().rc_chain_pack_weights_natural(w_host.ctypes.data, cin, cout, dst.ctypes.data), "rc_chain_pack_weights_natural")
+    wp.copy_(torch.from_numpy(dst))
+
+
+define("chain_pack_weights_natural(Tensor weight) -> Tensor",
+       lambda weight: weight.new_empty((lib().rc_chain_packed_bytes(weight.shape[1], weight.shape[0]),), dtype=torch.uint8), _cpackn_launch)
+
+define("gma_qkv_aggregate(Tensor x, Tensor wq_natural, Tensor? bq, Tensor ln1_gamma, Tensor ln1_beta, float eps, Tensor dw3, Tensor dw5, Tensor dw7, "
+       "Tensor dwl, Tensor pw, Tensor pwl, Tensor bn_scale, Tensor bn_shift, Tensor ln_gamma, Tensor ln_beta) -> (Tensor, Tensor, Tensor)",
+       lambda x, *a: (x.new_empty((12, *x.shape[:3], 16)), x.new_empty((*x.shape[:3], 16)),                  # x: (B, H, W, 80)
+                      x.new_empty((x.shape[0], 64), dtype=torch.float32)),
+       lambda outs, x, wq, bq, g1, b1, eps, dw3, dw5, dw7, dwl, pw, pwl, sc, sh, lg, lb: check(
+           lib().rc_gma_qkv_aggregate(x.data_ptr(), wq.data_ptr(), _p(bq), g1.data_ptr(), b1.data_ptr(), float(eps), outs[0].data_ptr(),
+                                      outs[1].data_ptr(), x.shape[0], x.shape[1], x.shape[2], dw3.data_ptr(), dw5.data_ptr(), dw7.data_ptr(),
+                                      dwl.data_ptr(), pw.data_ptr(), pwl.data_ptr(), sc.data_ptr(), sh.data_ptr(), lg.data_ptr(), lb.data_ptr(),
+                                      outs[2].data_ptr(), _stream()), "rc_gma_qkv_aggregate"))
+
+
 def _kvm_launch(ktv, qkvp, kmax, scale):
     b, n = qkvp.shape[1], qkvp.shape[2] * qkvp.shape[3]
     scratch = torch.empty(lib().rc_gma_kv_mfma_scratch_bytes(b, n) // 4, dtype=torch.float32, device=qkvp.device)

@@ -205,6 +205,42 @@ def test_kv_on_matrix_cores_equals_two_pass_form(hip):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,hw", [(2, (37, 53)), (1, (16, 32)), (3, (5, 7)), (1, (1, 1)), (2, (48, 96)), (1, (130, 201))])
+@pytest.mark.parametrize("qkv_bias", [False, True])
+def test_qkv_aggregate_in_one_launch_equals_the_two_launch_path(hip, b, hw, qkv_bias):
+    """rc_gma_qkv_aggregate (LayerNorm1 + qkv + Aggregator, qkv kept on chip) against rc_gma_ln_qkv + rc_gma_aggregate: the same K-step order,
+    bias point, tap order and bf16 rounding points -> bitwise equal qkvp, loc and per-channel k maximum; ragged tiles, images smaller than
+    one tile and than the 7x7 window, several tiles per block, an outlier token, with and without a qkv bias; run-to-run bitwise."""
+    R = torch.ops.realcam
+    torch.manual_seed(b * 1000 + hw[0])
+    blk = M.GMA_Block(80, 8, qkv_bias=qkv_bias)
+    with torch.no_grad():
+        for p_ in blk.att.aggregator.parameters():
+            p_.add_(0.1 * torch.randn_like(p_))
+        for m_ in (blk.att.aggregator.norm0, blk.att.aggregator.norm1, blk.att.aggregator.norm2, blk.att.aggregator.norm3):
+            m_.running_mean.normal_(0, 0.3); m_.running_var.uniform_(0.5, 2.0)
+        blk.norm1.weight.normal_(1.0, 0.2); blk.norm1.bias.normal_(0, 0.2)
+        if qkv_bias:
+            blk.att.qkv.bias.normal_(0, 0.5)
+    blk = blk.to("cuda", torch.bfloat16).eval()
+    g = torch.Generator().manual_seed(21 + hw[1])
+    x = torch.randn(b, *hw, 80, generator=g)
+    x[b - 1, hw[0] // 2, hw[1] // 2] *= 25.0
+    x = x.to("cuda", torch.bfloat16)
+    with torch.no_grad():
+        wq, bq = ops.packed_chain(blk.att.qkv)
+        qkv = R.gma_ln_qkv(x, wq, bq, ops.f32_param(blk.norm1, "weight"), ops.f32_param(blk.norm1, "bias"), 1e-5)
+        want = blk.att.aggregator._run_fused(qkv)
+        got = blk.att.aggregator._run_front(x, blk.norm1, blk.att.qkv)
+        again = blk.att.aggregator._run_front(x, blk.norm1, blk.att.qkv)
+    torch.cuda.synchronize()
+    for name, w_, g_, a_ in zip(("qkvp", "loc", "kmax"), want, got, again):
+        assert w_.shape == g_.shape and w_.dtype == g_.dtype, name
+        assert torch.equal(g_, a_), name
+        assert torch.equal(w_, g_), (name, (w_.float() - g_.float()).abs().max().item())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("c,hw", [(80, (37, 70)), (80, (16, 32)), (48, (130, 65)), (160, (9, 200))])
 @pytest.mark.parametrize("identity", [True, False])
 def test_depthwise3x3_segment_kernel_equals_the_general_one(hip, c, hw, identity):

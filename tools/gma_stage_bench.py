@@ -37,6 +37,7 @@ with torch.no_grad():
     wq, bq = ops.packed_chain(blk.att.qkv)
     qkv = timeit("ln_qkv", lambda: R.gma_ln_qkv(x, wq, bq, f32(blk.norm1, "weight"), f32(blk.norm1, "bias"), 1e-5))
     qkvp, loc, kmax = timeit("aggregate (+ per-channel max of k)", lambda: blk.att.aggregator._run_fused(qkv))
+    timeit("ln_qkv + aggregate in ONE launch", lambda: blk.att.aggregator._run_front(x, blk.norm1, blk.att.qkv))
     convv = timeit("crpe", lambda: blk.att.crpe._conv_v(qkvp))
     timeit("kv, two-pass VALU form (max, sums, merge)", lambda: R.gma_kv(qkvp, 8, 8, float(blk.att.scale)))
     ktv = timeit("kv on the matrix cores (sums, merge)", lambda: R.gma_kv_mfma(qkvp, kmax, float(blk.att.scale)))
