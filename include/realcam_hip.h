@@ -455,16 +455,20 @@ int rc_gma_aggregate(const void* d_qkv, void* d_qkvp, void* d_loc, int batch, in
                      const float* d_bn_shift, const float* d_ln_g, const float* d_ln_b, float* d_kmax, void* stream);
 
 /* rc_gma_qkv_aggregate (ABI 13): rc_gma_ln_qkv + rc_gma_aggregate as ONE launch (groupmix.py:178 after :293, then :56-105) -- the 240-channel
- * qkv map is never written: a block LayerNorms x (B,H,W,80) for a 16 x 32 tile + 3-pixel halo once, keeps the normalised tokens in registers as
- * MFMA B fragments and produces qkv one 16-channel segment at a time into an LDS halo tile that the aggregator's depth-wise / point-wise /
- * BatchNorm / Hardswish chain consumes.  d_wq_natural: the (240, 80) qkv weight as rc_chain_pack_weights_natural fragments (output rows in
- * natural channel order: 16-row tile m = segment m); d_bq (240) fp32 or NULL; the other arguments as rc_gma_ln_qkv / rc_gma_aggregate.
- * Results (qkvp, loc, kmax) are bitwise those of the two-launch path. */
+ * qkv map is never written: a block LayerNorms x (B,H,W,80) for a 16 x 32 tile + halo once, keeps the normalised tokens in registers as MFMA B
+ * fragments and produces qkv one 16-channel segment at a time into an LDS tile; the depth-wise K x K windows run ON THE MATRIX CORES as banded
+ * Toeplitz products (one MFMA per channel, kernel row and 16-pixel group), then point-wise / BatchNorm / Hardswish as rc_gma_aggregate.
+ * d_wq_natural: the (240, 80) qkv weight as rc_chain_pack_weights_natural fragments (output rows in natural channel order: 16-row tile m =
+ * segment m); d_bq (240) fp32 or NULL; d_toeplitz: rc_gma_toeplitz_bytes() bytes from rc_gma_toeplitz_pack (host) over the same tap tensors
+ * rc_gma_aggregate takes (dw3 / dw5 / dw7 tap-major (K*K,16), dwl (3,9,16)); the other arguments as rc_gma_ln_qkv / rc_gma_aggregate.
+ * Same rounding points as the two-launch path; the depth-wise sums are formed in the matrix pipe's order (exact bf16 products, fp32 sums), so
+ * results agree with it to the last fp32 bits before the bf16 rounding (tests hold: >= 99.9 % of the values bit-equal, the rest 1 bf16 ulp). */
 int rc_chain_pack_weights_natural(const float* w, int cin, int cout, void* dst);   /* host; rc_chain_packed_bytes(cin, cout) bytes; 16 | cin, 16 | cout */
+size_t rc_gma_toeplitz_bytes(void);
+int rc_gma_toeplitz_pack(const float* dw3, const float* dw5, const float* dw7, const float* dwl, void* dst);   /* host */
 int rc_gma_qkv_aggregate(const void* d_x, const void* d_wq_natural, const float* d_bq, const float* d_ln1_gamma, const float* d_ln1_beta, float eps,
-                         void* d_qkvp, void* d_loc, int batch, int H, int W, const float* d_dw3, const float* d_dw5, const float* d_dw7,
-                         const float* d_dwl, const float* d_pw, const float* d_pwl, const float* d_bn_scale, const float* d_bn_shift,
-                         const float* d_ln_g, const float* d_ln_b, float* d_kmax, void* stream);
+                         void* d_qkvp, void* d_loc, int batch, int H, int W, const void* d_toeplitz, const float* d_pw, const float* d_pwl,
+                         const float* d_bn_scale, const float* d_bn_shift, const float* d_ln_g, const float* d_ln_b, float* d_kmax, void* stream);
 
 /* d_kmax (optional, may be NULL): (batch, 64) fp32, on return the per-channel maximum over the image of the aggregated k (the stored bf16
  * values) -- the shift of softmax_N(k) (models/groupmix.py:190) -- accumulated by the aggregator itself with integer atomics (a maximum is

@@ -14,7 +14,6 @@ struct ConvPlan {
 
 static int g_persist_on = 1;       // rc_debug_set("persist", v): 0 general kernel only, 1 automatic (default), 2 producer/consumer wherever eligible, 3 persistent only
 extern int g_dw3_seg16;            // gma.hip
-extern int g_qa_flags;             // gma_fused.hip
 extern int g_dec_lds;              // rans.hip
 static int g_pss = 0;              // rc_debug_set("pss", v): 1: single-chunk pixel-shuffle layers (the tail 48 -> 192) take kernel 5 (output staged through LDS, stored by the
                                    // loader waves); 0 (default): kernel 4.  Measured on MI355X at 8 x 1088 x 1920: 3.16-3.29 vs 3.24-3.27 ms (conv_kernel.hpp, kernel 5)
@@ -293,7 +292,6 @@ int rc_debug_set(const char* key, int value) {
     if (std::string(key) == "pair_impl") { g_pair_impl = value < 0 || value > 2 ? 0 : value; return RC_OK; }
     if (std::string(key) == "dec_lds") { g_dec_lds = value != 0; return RC_OK; }
     if (std::string(key) == "dw3_seg16") { g_dw3_seg16 = value != 0; return RC_OK; }
-    if (std::string(key) == "qa_flags") { g_qa_flags = value; return RC_OK; }
     if (std::string(key) == "pss") { g_pss = value != 0; return RC_OK; }
     if (std::string(key) == "sums_compact") { g_sums_compact = value != 0; return RC_OK; }
     if (std::string(key) == "persist_auto") { g_auto = value < 0 ? 0 : (value > 2 ? 2 : value); return RC_OK; }

@@ -914,30 +914,42 @@ extern "C" int rc_gma_crpe(const void* d_qkvp, void* d_convv, int batch, int H, 
 }
 
 // ======================================================================================================================================
-// LayerNorm1 + qkv Linear + Aggregator as ONE launch (rc_gma_qkv_aggregate; groupmix.py:178 after :293, then :56-105).
-// rc_gma_ln_qkv wrote the 240-channel qkv map (2.0 GB at cfg3) and rc_gma_aggregate read it back with halos: 6.4 GB for the pair.  Here a
-// block of 8 waves owns a 16 x 32 pixel tile: it loads x (80 channels) for the tile + a 3-pixel halo ONCE (836 tokens), LayerNorms them and
-// keeps the normalised tokens in registers as MFMA B fragments (7 column tiles of 16 tokens per wave = 70 VGPRs); then, segment by segment
-// (15 segments of 16 channels = 5 x {q, k, v}): one 16-row slice of the qkv GEMM (3 K-steps per column tile) -> bf16 -> an LDS halo tile in
-// the aggregator's pixel-major layout (zero outside the image, which is the zero padding of the depth-wise convs) -> the aggregator's own
-// depth-wise K x K / point-wise / BatchNorm / Hardswish chain on a 2 x 2 pixel patch per lane -> 8-byte stores.  qkv never exists in HBM:
-// x in (0.67 GB + halo re-reads through L2), qkv' + loc out (1.7 GB).  The LDS tile is double-buffered: segment s + 1's MFMAs are issued before
-// segment s's depth-wise FMAs and their results are packed after them, so there is ONE barrier per segment.
-// Arithmetic (K-step order, bias after the chain, fmaf taps in (dy, dx) order, every bf16 rounding point) is that of the two-launch
-// path: the results are bitwise equal to rc_gma_ln_qkv + rc_gma_aggregate (tests/test_gma.py).
+// LayerNorm1 + qkv Linear + Aggregator as ONE launch (rc_gma_qkv_aggregate; groupmix.py:178 after :293, then :56-105), with the
+// depth-wise convolutions ON THE MATRIX CORES.
+// rc_gma_ln_qkv wrote the 240-channel qkv map (2.0 GB at cfg3) and rc_gma_aggregate read it back with halos: 6.4 GB for the pair, and the
+// aggregator's K x K windows were 0.5 G VALU instructions (its SIMDs 64 % VALU-busy).  Here a block of 16 waves owns a 16 x 32 pixel tile:
+//   L   x (80 channels) of the tile + halo, 22 rows x 40 pixel slots, ONCE -> LayerNorm1 -> MFMA B fragments in registers (a lane's 4 column tiles
+//       are 4 consecutive pixels of one row: 40 VGPRs);
+//   then per 16-channel segment (15 = 5 x {q, k, v}; the local branch's three first):
+//   P1  a 16-row slice of the qkv GEMM (3 K-steps per column tile) -> bias -> bf16 -> LDS tile S, CHANNEL-PLANAR [16][22 rows][40 slots] (zero
+//       outside the image = the convolutions' zero padding); a lane packs 4 pixels of a channel into one 8-byte write;
+//   P2  depth-wise K x K as MFMAs: for channel c and kernel row dy, D[ox][y] += T(c, dy)[ox][slot] . S[c][y + dy][slot] with T the banded
+//       Toeplitz matrix of the 7 (5, 3) taps of that row (16 outputs x 32 input slots; rc_gma_toeplitz_pack builds the fragments on the host,
+//       a wave streams its channel's K fragments from L2 one segment ahead) and the B fragment one ds_read_b128 (8 consecutive slots of a
+//       row): K MFMAs per (channel, 16-pixel group) instead of 16 K^2 packed FMAs + unpacking; products are exact (bf16 x bf16), sums fp32;
+//       D (4 pixels of a channel per lane) -> bf16 -> LDS tile R, PIXEL-MAJOR;
+//   P3  point-wise 16 x 16 (MFMA, B = 8 bytes of R) -> BatchNorm -> Hardswish -> 8-byte stores (512 contiguous bytes per wave instruction);
+//       k's per-channel maximum by DPP row reductions.  The pass-through group skips P2 (P1 writes R), the local branch accumulates its
+//       48 -> 16 point-wise product over q / k / v in registers and finishes with LayerNorm(16) + Hardswish.
+// qkv never exists in HBM: x in (0.67 GB + halo re-reads through L2), qkv' + loc out (1.7 GB).  Rounding points are those of the two-launch
+// path; the depth-wise sums are formed in the matrix pipe's order instead of (dy, dx) fmaf order (fp32 either way).
 namespace rc {
 namespace gf {
 
-constexpr int QA_WAVES = 8, QA_THREADS = 64 * QA_WAVES;
-constexpr int QA_THH = AG_TH + 6, QA_TWH = AG_TW + 6, QA_TOK = QA_THH * QA_TWH;            // 22 x 38 = 836 tokens
-constexpr int QA_RS = QA_TWH * AG_PS + AG_RPAD;                                            // LDS row stride: 1528 bytes
-constexpr int QA_S = QA_THH * QA_RS;                                                       // one halo tile of one segment: 33 616 bytes
-constexpr int QA_NC = ((QA_TOK + 15) / 16 + QA_WAVES - 1) / QA_WAVES;                      // column tiles of 16 tokens per wave: 7
-constexpr int QA_WSEG = tile_bytes(kC);                                                    // 2560 bytes of A fragments per segment
-constexpr int QA_OFF_W = 2 * QA_S, QA_OFF_BQ = QA_OFF_W + 15 * QA_WSEG, QA_OFF_GB = QA_OFF_BQ + 240 * 4, QA_OFF_TAPS = QA_OFF_GB + 160 * 4,
-              QA_N_TAPS = 9 * 16 + 25 * 16 + 49 * 16 + 3 * 9 * 16, QA_OFF_BN = QA_OFF_TAPS + QA_N_TAPS * 4, QA_OFF_PW = QA_OFF_BN + 160 * 4,
-              QA_OFF_RED = QA_OFF_PW + 6 * 64 * 8, QA_OFF_SOFF = QA_OFF_RED + 4 * QA_WAVES * 16 * 4, QA_OFF_PYX = QA_OFF_SOFF + QA_NC * QA_THREADS * 4, QA_LDS = QA_OFF_PYX + QA_NC * QA_THREADS * 4;
-static_assert(QA_S % 16 == 0 && QA_OFF_W % 16 == 0 && QA_OFF_PW % 8 == 0 && QA_LDS <= 160 * 1024, "qkv + aggregate LDS layout");
+constexpr int QA_WAVES = 16, QA_THREADS = 64 * QA_WAVES;                                        // 4 waves per SIMD, <= 128 VGPRs each
+constexpr int QT_ROWS = AG_TH + 6, QT_SLOTS = 40, QT_SR = QT_SLOTS * 2, QT_SP = QT_ROWS * QT_SR;   // slot s of a row = pixel x0 - 4 + s; 80-byte rows, 1760-byte channel planes
+constexpr int QT_S = 16 * QT_SP + 64;                                                           // + zeroed tail (the last channel's last-row window reads 16 bytes past)
+constexpr int QT_RR = AG_TW * AG_PS + 8, QT_R = AG_TH * QT_RR;                                  // pixel-major tile: 40-byte pixels, 1288-byte rows
+constexpr int QT_QUADS = QT_ROWS * (QT_SLOTS / 4), QT_QPW = (QT_QUADS + QA_WAVES - 1) / QA_WAVES;   // 220 quads of 4 slots, 14 per wave (one per lane n)
+constexpr int QA_WSEG = tile_bytes(kC);                                                         // 2560 bytes of A fragments per segment
+constexpr int QA_OFF_R = QT_S, QA_OFF_W = QA_OFF_R + 2 * QT_R, QA_OFF_BQ = QA_OFF_W + 15 * QA_WSEG, QA_OFF_GB = QA_OFF_BQ + 240 * 4,
+              QA_OFF_BN = QA_OFF_GB + 160 * 4, QA_OFF_PW = QA_OFF_BN + 160 * 4, QA_OFF_RED = QA_OFF_PW + 6 * 64 * 8,
+              QA_LDS = QA_OFF_RED + 4 * QA_WAVES * 16 * 4;
+static_assert(QT_S % 16 == 0 && QT_R % 16 == 0 && QA_OFF_W % 16 == 0 && QA_OFF_PW % 8 == 0 && QT_QPW <= 16 && QA_WAVES == AG_TH && QA_LDS <= 160 * 1024,
+              "qkv + aggregate LDS layout");
+// Toeplitz fragment table (rc_gma_toeplitz_pack): [group][dy][channel][lane] 16 bytes; groups: K = 3, 5, 7, then the local branch's q / k / v (K = 3)
+constexpr int QT_TAB_K3 = 0, QT_TAB_K5 = QT_TAB_K3 + 3 * 16 * 1024, QT_TAB_K7 = QT_TAB_K5 + 5 * 16 * 1024, QT_TAB_LOC = QT_TAB_K7 + 7 * 16 * 1024,
+              QT_TAB_BYTES = QT_TAB_LOC + 3 * 3 * 16 * 1024;
 
 struct QaArgs {
     const bf16_t* x; bf16_t* qkvp; bf16_t* loc; float* kmax;
@@ -945,16 +957,14 @@ struct QaArgs {
     size_t plane;
     const void* wq; const float* bq;                 // rc_chain_pack_weights_natural(80 -> 240) fragments; bias [240] or NULL
     const float* ln1_g; const float* ln1_b; float eps;
-    const float* dw[3]; const float* dwl; const float* pw; const float* pwl;
+    const char* toep;                                // rc_gma_toeplitz_pack
+    const float* pw; const float* pwl;
     const float* bn_scale; const float* bn_shift; const float* ln_g; const float* ln_b;
-    int dbg;                                         // rc_debug_set("qa_flags"): knock-outs for timing (1 no depth-wise FMAs, 2 no qkv' stores, 4 no GEMM, 8 no x loads)
 };
 
-// one token column tile of layernorm80 (same expressions, same order)
+// one token column tile of layernorm80 (same expressions, same order; gamma / beta fetched where they are used: 128 VGPRs to live in)
 __device__ __forceinline__ void ln80_one(const Act<kC>& in, Act<kC>& out, const float* gb, int g, float eps) {
-    const f32x4 g0 = ld4(gb + 8 * g), g1 = ld4(gb + 8 * g + 4), g2 = ld4(gb + 32 + 8 * g), g3 = ld4(gb + 32 + 8 * g + 4), g4 = ld4(gb + 64 + 4 * g);
     const float* bb = gb + kC;
-    const f32x4 e0 = ld4(bb + 8 * g), e1 = ld4(bb + 8 * g + 4), e2 = ld4(bb + 32 + 8 * g), e3 = ld4(bb + 32 + 8 * g + 4), e4 = ld4(bb + 64 + 4 * g);
     const f32x4 v0 = up_lo(in.f[0]), v1 = up_hi(in.f[0]), v2 = up_lo(in.f[1]), v3 = up_hi(in.f[1]), v4 = up_tail(in.t);
     const f32x4 sv = ((v0 + v1) + (v2 + v3)) + v4;
     float s = (sv[0] + sv[1]) + (sv[2] + sv[3]);
@@ -965,42 +975,14 @@ __device__ __forceinline__ void ln80_one(const Act<kC>& in, Act<kC>& out, const 
     float q = (qv[0] + qv[1]) + (qv[2] + qv[3]);
     q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
     const float rstd = 1.f / sqrtf(q / (float)kC + eps);
-    const uint2 p0 = qa_pack(d0 * rstd * g0 + e0), p1 = qa_pack(d1 * rstd * g1 + e1), p2 = qa_pack(d2 * rstd * g2 + e2), p3 = qa_pack(d3 * rstd * g3 + e3);
+    const uint2 p0 = qa_pack(d0 * rstd * ld4(gb + 8 * g) + ld4(bb + 8 * g)), p1 = qa_pack(d1 * rstd * ld4(gb + 8 * g + 4) + ld4(bb + 8 * g + 4));
     out.f[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
+    const uint2 p2 = qa_pack(d2 * rstd * ld4(gb + 32 + 8 * g) + ld4(bb + 32 + 8 * g)), p3 = qa_pack(d3 * rstd * ld4(gb + 32 + 8 * g + 4) + ld4(bb + 32 + 8 * g + 4));
     out.f[1] = make_uint4(p2.x, p2.y, p3.x, p3.y);
-    out.t = qa_pack(d4 * rstd * g4 + e4);
+    out.t = qa_pack(d4 * rstd * ld4(gb + 64 + 4 * g) + ld4(bb + 64 + 4 * g));
 }
 
-// depth-wise K x K of this lane's 2 x 2 patch (tile rows prow, prow + 1; columns pcol, pcol + 1), channels 4 q .. 4 q + 3, from the halo-3 tile S;
-// taps in (dy, dx) order by fmaf, as agg_dw
-template <int K>
-__device__ __forceinline__ void qa_dw(const char* S, const float* s_w, int prow, int pcol, int q, f32x4 (&acc)[2][2]) {
-    constexpr int R = K / 2;
-    const char* base = S + (prow + 3 - R) * QA_RS + (pcol + 3 - R) * AG_PS + q * 8;
-#pragma unroll 1
-    for (int iy = 0; iy < K + 1; ++iy) {
-        f32x4 xin[K + 1];
-#pragma unroll
-        for (int c = 0; c < K + 1; ++c) xin[c] = up_tail(*reinterpret_cast<const uint2*>(base + iy * QA_RS + c * AG_PS));
-#pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const int dy = iy - o;
-            if (dy < 0 || dy >= K) continue;
-#pragma unroll
-            for (int dx = 0; dx < K; ++dx) {
-                const f32x4 w = ld4(s_w + (dy * K + dx) * 16 + 4 * q);
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[o][c][e] = __builtin_fmaf(w[e], xin[c + dx][e], acc[o][c][e]);
-            }
-        }
-    }
-}
-
-struct QaGeom { int y0, x0, prow, pcol, q, H, W, dbg; size_t pix0; };
-
-// maximum over the 16 lanes of a DPP row (lanes with the same q): xor 1, xor 2 inside quads, then the mirrored half and the mirrored row
+// maximum over the 16 lanes of a DPP row (lanes with the same channel quad): xor 1, xor 2 inside quads, then the mirrored half and the mirrored row
 __device__ __forceinline__ float row_max16(float v) {
     v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)));    // quad_perm [1,0,3,2]
     v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)));    // quad_perm [2,3,0,1]
@@ -1009,45 +991,36 @@ __device__ __forceinline__ float row_max16(float v) {
     return v;
 }
 
-// one conv group of one of q / k / v: depth-wise -> point-wise (MFMA) -> [between(): the next segment's GEMM is issued here, behind the four
-// point-wise MFMAs and under the VALU work below] -> BN + Hardswish -> qkvp; returns the maximum of the stored values
-template <int K, typename F>
-__device__ __forceinline__ f32x4 qa_conv_group(const char* S, const float* s_w, uint2 apw, f32x4 sc, f32x4 sh, bf16_t* outp, const QaGeom& t, F&& between) {
-    f32x4 d[2][2];
-    {
-        f32x4 acc[2][2];
+// this wave's Toeplitz fragments of a K x K group (channel = wave): T[dy].  Buffer loads: ONE 32-bit lane offset (wave * 1 KiB + lane * 16) and a scalar
+// offset per fragment -- with flat pointers hipcc kept a 64-bit address per (group, dy) alive across the tile loop
+typedef unsigned int qt_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int qt_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void qt_load(__amdgpu_buffer_rsrc_t tab, int group_off, int K, int voff, uint4 (&T)[7]) {
 #pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[o][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (K > 1) { if (!(t.dbg & 1)) qa_dw<K>(S, s_w, t.prow, t.pcol, t.q, acc); }
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                d[o][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (K > 1) mma16(apw, qa_pack(acc[o][c]), d[o][c]);
-                else d[o][c] = up_tail(*reinterpret_cast<const uint2*>(S + (t.prow + 3 + o) * QA_RS + (t.pcol + 3 + c) * AG_PS + t.q * 8));   // pass-through group
-            }
+    for (int dy = 0; dy < 7; ++dy) {     // always seven loads (rows past K - 1 repeat the last one: an L1 hit): no K-dependent control flow, so T[dy] is never a copy of its old value
+        const qt_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(tab, voff, group_off + (dy < K ? dy : K - 1) * 16 * 1024, 0);
+        T[dy] = make_uint4(t[0], t[1], t[2], t[3]);
     }
-    between();
-    f32x4 vmax = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+}
+
+// P2: depth-wise K x K of this wave's channel over the 16 x 32 tile: S (channel-planar) -> R (pixel-major, bf16).  src = S + c plane + n rows + 16 g bytes,
+// dst = R + n rows + 4 g pixels + 2 c bytes (lane constants of the caller)
+template <int K>
+__device__ __forceinline__ void qt_dw(const char* src0, char* dst0, const uint4 (&T)[7]) {
+    constexpr int Rk = K / 2;
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+    for (int h = 0; h < 2; ++h) {
+        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* src = src0 + (3 - Rk) * QT_SR + 32 * h;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            f32x4 v = d[o][c] * sc + sh;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
-            if (t.y0 + t.prow + o < t.H && t.x0 + t.pcol + c < t.W && !(t.dbg & 2)) {
-                const uint2 pkd = qa_pack(v);
-                *reinterpret_cast<uint2*>(outp + (t.pix0 + (size_t)o * t.W + c) * kSEG) = pkd;
-                const f32x4 r = up_tail(pkd);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) vmax[e] = fmaxf(vmax[e], r[e]);
-            }
-        }
-    return vmax;
+        for (int dy = 0; dy < K; ++dy) mma32(T[dy], *reinterpret_cast<const uint4*>(src + dy * QT_SR), d);
+        const uint32_t p01 = qa_pk(d[0], d[1]), p23 = qa_pk(d[2], d[3]);
+        char* dst = dst0 + 16 * h * AG_PS;
+        *reinterpret_cast<uint16_t*>(dst) = (uint16_t)(p01 & 0xffffu);
+        *reinterpret_cast<uint16_t*>(dst + AG_PS) = (uint16_t)(p01 >> 16);
+        *reinterpret_cast<uint16_t*>(dst + 2 * AG_PS) = (uint16_t)(p23 & 0xffffu);
+        *reinterpret_cast<uint16_t*>(dst + 3 * AG_PS) = (uint16_t)(p23 >> 16);
+    }
 }
 
 __global__ __launch_bounds__(QA_THREADS) void gma_qkv_agg_kernel(QaArgs a) {
@@ -1055,179 +1028,220 @@ __global__ __launch_bounds__(QA_THREADS) void gma_qkv_agg_kernel(QaArgs a) {
     char* s_wq = lds + QA_OFF_W;
     float* s_bq = reinterpret_cast<float*>(lds + QA_OFF_BQ);
     float* s_gb = reinterpret_cast<float*>(lds + QA_OFF_GB);
-    float* s_taps = reinterpret_cast<float*>(lds + QA_OFF_TAPS);            // dw3 [144] | dw5 [400] | dw7 [784] | local [3][144]
     float* s_bn = reinterpret_cast<float*>(lds + QA_OFF_BN);                // scale [64] | shift [64] | ln_g [16] | ln_b [16]
     uint2* s_pw = reinterpret_cast<uint2*>(lds + QA_OFF_PW);                // A fragments: groups 1..3, local q / k / v
-    float* s_red = reinterpret_cast<float*>(lds + QA_OFF_RED);              // [4 groups][8 waves][16 channels]: row maxima of the aggregated k
-    int* s_soff = reinterpret_cast<int*>(lds + QA_OFF_SOFF);                // [QA_NC][512]: LDS offset of each thread's tokens in the halo tile
-    int* s_pyx = reinterpret_cast<int*>(lds + QA_OFF_PYX);                  // [QA_NC][512]: (row << 8) | column of the token in the halo tile, -1 beyond the last
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, q = lane >> 4;
+    float* s_red = reinterpret_cast<float*>(lds + QA_OFF_RED);              // [4 groups][16 waves][16 channels]: row maxima of the aggregated k
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // the wave index as a scalar: everything derived from it stays in SGPRs
+    const int lane = tid & 63, g0 = lane >> 4;
+    int n = lane & 15;
     for (int i = tid; i < 15 * QA_WSEG / 16; i += QA_THREADS) reinterpret_cast<uint4*>(s_wq)[i] = reinterpret_cast<const uint4*>(a.wq)[i];
     for (int i = tid; i < 240; i += QA_THREADS) s_bq[i] = a.bq ? a.bq[i] : 0.f;
     for (int i = tid; i < kC; i += QA_THREADS) { s_gb[i] = a.ln1_g[i]; s_gb[kC + i] = a.ln1_b[i]; }
-    for (int i = tid; i < 144; i += QA_THREADS) s_taps[i] = a.dw[0][i];
-    for (int i = tid; i < 400; i += QA_THREADS) s_taps[144 + i] = a.dw[1][i];
-    for (int i = tid; i < 784; i += QA_THREADS) s_taps[544 + i] = a.dw[2][i];
-    for (int i = tid; i < 432; i += QA_THREADS) s_taps[1328 + i] = a.dwl[i];
     for (int i = tid; i < 64; i += QA_THREADS) { s_bn[i] = a.bn_scale[i]; s_bn[64 + i] = a.bn_shift[i]; }
     if (tid < 16) { s_bn[128 + tid] = a.ln_g[tid]; s_bn[144 + tid] = a.ln_b[tid]; }
     for (int i = tid; i < 6 * 64; i += QA_THREADS) {
         const int f = i >> 6;
         s_pw[i] = f < 3 ? agg_afrag(a.pw + f * 256, 16, 0, i & 63) : agg_afrag(a.pwl, 48, 16 * (f - 3), i & 63);
     }
-    // token t = 16 (wave + 8 i) + n of the 22 x 38 halo tile, row-major: its LDS offset (tile-invariant), -1 beyond the last token
-#pragma unroll
-    for (int i = 0; i < QA_NC; ++i) {
-        const int tk = 16 * (wave + QA_WAVES * i) + n;
-        const int py = tk / QA_TWH, px = tk - py * QA_TWH;
-        s_soff[i * QA_THREADS + tid] = tk < QA_TOK ? py * QA_RS + px * AG_PS + 8 * q : -1;
-        s_pyx[i * QA_THREADS + tid] = tk < QA_TOK ? (py << 8) | px : -1;
-    }
+    for (int i = tid; i < (QT_S + 2 * QT_R) / 16; i += QA_THREADS) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);   // finite everywhere: zero-weighted slots are still multiplied
     __syncthreads();
 
-    QaGeom t;
-    t.prow = 2 * wave; t.pcol = 2 * n; t.q = q; t.H = a.H; t.W = a.W; t.dbg = a.dbg;
+    const __amdgpu_buffer_rsrc_t r_toep = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.toep), 0, QT_TAB_BYTES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_loc = __builtin_amdgcn_make_buffer_rsrc(a.loc, 0, (int)(a.plane * 2), 0x00020000);
+    // this lane's quad of the halo tile: 4 consecutive slots of one row (the same for all four g: they hold different channels of the same pixels)
+    int qrc, idm = 0;                                                        // ((row << 8) | quad column) << 4 | which of its 4 pixels lie in the tile proper; -1 if this lane has no quad
+    {
+        const int quad = wave * QT_QPW + n;
+        const bool has_quad = n < QT_QPW && quad < QT_QUADS;
+        const int qrow = quad / (QT_SLOTS / 4), qcol = quad - qrow * (QT_SLOTS / 4);
+        if (has_quad && qrow >= 3 && qrow < 3 + AG_TH)
+            for (int i = 0; i < 4; ++i) idm |= (4 * qcol + i - 4 >= 0 && 4 * qcol + i - 4 < AG_TW) ? 1 << i : 0;
+        qrc = has_quad ? (((qrow << 8) | qcol) << 4) | idm : -1;
+    }
+    const int qrow = qrc >> 12, qcol = (qrc >> 4) & 255;                    // (only for the lane constants below; the loops re-derive them from qrc)
+    // Lane constants of the segment loops, ONE register each.  hipcc otherwise hoists every address it can form from lane / n / g out of those loops (dozens of
+    // VGPRs, spilled, and each reload waits for ALL outstanding memory operations); QT_KEEP makes the loops see them as opaque values: adds stay inside.
+    int o_p1s = (4 * g0) * QT_SP + qrow * QT_SR + qcol * 8;                  // P1 -> S: + j planes
+    int o_p1r = QA_OFF_R + (qrow - 3) * QT_RR + (4 * qcol - 4) * AG_PS + 8 * g0;   // P1 -> R (pass-through segments): + i pixels
+    int o_p2s = wave * QT_SP + n * QT_SR + 16 * g0;                         // P2 <- S
+    int o_p2d = QA_OFF_R + n * QT_RR + 4 * g0 * AG_PS + 2 * wave;            // P2 -> R
+    int o_p3 = QA_OFF_R + wave * QT_RR + n * AG_PS + 8 * g0;                // P3 <- R: + 16 nt pixels
+    int o_l16 = lane * 16, o_g16 = g0 * 16;                                  // A fragments; bias / BatchNorm quads
+#define QT_KEEP() asm volatile("" : "+v"(o_p1s), "+v"(o_p1r), "+v"(o_p2s), "+v"(o_p2d), "+v"(o_p3), "+v"(o_l16), "+v"(o_g16), "+v"(n), "+v"(qrc))
 
     const int t_begin = blockIdx.x * a.tiles_per_block;
     const int t_end = t_begin + a.tiles_per_block < a.n_tiles ? t_begin + a.tiles_per_block : a.n_tiles;
 #pragma unroll 1
     for (int tile = t_begin; tile < t_end; ++tile) {
-        int r = tile;
-        const int tx = r % a.tiles_x; r /= a.tiles_x;
-        const int ty = r % a.tiles_y;
-        const int b = r / a.tiles_y;
-        t.y0 = ty * AG_TH; t.x0 = tx * AG_TW;
-        t.pix0 = ((size_t)b * a.H + t.y0 + t.prow) * a.W + t.x0 + t.pcol;
+        int r_ = tile;
+        const int tx = r_ % a.tiles_x; r_ /= a.tiles_x;
+        const int ty = r_ % a.tiles_y;
+        const int b = r_ / a.tiles_y;
+        const int y0 = ty * AG_TH, x0 = tx * AG_TW;
+        QT_KEEP();
 
-        // ---- x of the halo tile -> LayerNorm1 -> B fragments in registers
-        Act<kC> n1[QA_NC];
-        unsigned inimg = 0;
+        // ---- L: x of the halo tile -> LayerNorm1 -> B fragments in registers; pm[p]: which halves of the bf16 pair (slot 2 p, 2 p + 1) lie in the image
+        Act<kC> n1[4];
+        uint32_t pm[2] = {0u, 0u};
         {
-            Act<kC> xin[QA_NC];
+            const int gy = y0 - 3 + (qrc >> 12), gx0 = x0 - 4 + 4 * ((qrc >> 4) & 255), g = o_g16 >> 4;
+            const bool row_ok = qrc >= 0 && gy >= 0 && gy < a.H;
+            // per-image buffer descriptor, 32-bit byte offsets, out-of-image pixels at an offset past the image: the hardware returns zeros, no branches, no 64-bit address math
+            const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x) + (size_t)b * a.H * a.W * kC, 0, a.H * a.W * kC * 2, 0x00020000);
+            Act<kC> xin[4];
 #pragma unroll
-            for (int i = 0; i < QA_NC; ++i) {
-                const int pyx = s_pyx[i * QA_THREADS + tid];
-                const int gy = t.y0 - 3 + (pyx >> 8), gx = t.x0 - 3 + (pyx & 255);
-                const bool ok = pyx >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                xin[i].f[0] = make_uint4(0u, 0u, 0u, 0u); xin[i].f[1] = make_uint4(0u, 0u, 0u, 0u); xin[i].t = make_uint2(0u, 0u);
-                if (ok) {
-                    if (!(a.dbg & 8)) load_act<kC>(a.x + (((size_t)b * a.H + gy) * a.W + gx) * kC, q, xin[i]);
-                    inimg |= 1u << i;
-                }
+            for (int i = 0; i < 4; ++i) {
+                const int gx = gx0 + i;
+                const bool ok = row_ok && gx >= 0 && gx < a.W;
+                const int vo = ok ? (gy * a.W + gx) * (kC * 2) + 16 * g : (int)0x80000000;
+                const qt_u32x4 f0 = __builtin_amdgcn_raw_buffer_load_b128(r_x, vo, 0, 0), f1 = __builtin_amdgcn_raw_buffer_load_b128(r_x, vo, 64, 0);
+                const qt_u32x2 ft = __builtin_amdgcn_raw_buffer_load_b64(r_x, ok ? vo - 8 * g : vo, 128, 0);
+                xin[i].f[0] = make_uint4(f0[0], f0[1], f0[2], f0[3]); xin[i].f[1] = make_uint4(f1[0], f1[1], f1[2], f1[3]); xin[i].t = make_uint2(ft[0], ft[1]);
+                if (ok) pm[i >> 1] |= (i & 1) ? 0xffff0000u : 0x0000ffffu;
             }
 #pragma unroll
-            for (int i = 0; i < QA_NC; ++i) ln80_one(xin[i], n1[i], s_gb, q, a.eps);
+            for (int i = 0; i < 4; ++i) {
+                ln80_one(xin[i], n1[i], s_gb, g, a.eps);
+                __builtin_amdgcn_sched_barrier(0);                             // one pixel at a time: interleaved, the four LayerNorms' temporaries do not fit 128 VGPRs
+            }
         }
+        // this wave's 32 pixels of P3: tile row `wave`, column tile nt = pixels 16 nt + n; the lane's first output pixel (an offset in 16-channel records)
+        // (byte offsets of its two pixel records inside a 16-channel plane; past the plane where the pixel is outside the image: such stores are dropped)
+        const bool p3_row = y0 + wave < a.H;
+        const unsigned p3_cols = (p3_row && x0 + n < a.W ? 1u : 0u) | (p3_row && x0 + 16 + n < a.W ? 2u : 0u);
+        const int p3_off = ((b * a.H + y0 + wave) * a.W + x0 + n) * kSEG * 2 + (o_g16 >> 1);
 
-        f32x4 ga[QA_NC];
-        auto g_issue = [&](int seg) {
+        // P1: segment `seg` of the qkv GEMM for this lane's 4 pixels -> S (channel-planar; zero outside the image), or, for a pass-through segment, -> R
+        auto p1 = [&](int seg, bool to_r, int rbuf) {
             const char* w = s_wq + seg * QA_WSEG;
-            const uint4 a0 = *reinterpret_cast<const uint4*>(w + lane * 16), a1 = *reinterpret_cast<const uint4*>(w + 1024 + lane * 16);
-            const uint2 at = *reinterpret_cast<const uint2*>(w + 2048 + lane * 8);
+            const uint4 a0 = *reinterpret_cast<const uint4*>(w + o_l16), a1 = *reinterpret_cast<const uint4*>(w + 1024 + o_l16);
+            const uint2 at = *reinterpret_cast<const uint2*>(w + 2048 + (o_l16 >> 1));
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_bq) + 64 * seg + o_g16);
+            f32x4 v[4];
 #pragma unroll
-            for (int i = 0; i < QA_NC; ++i) {
-                ga[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (!(a.dbg & 4)) { mma32(a0, n1[i].f[0], ga[i]); mma32(a1, n1[i].f[1], ga[i]); mma16(at, n1[i].t, ga[i]); }
+            for (int i = 0; i < 4; ++i) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                mma32(a0, n1[i].f[0], acc); mma32(a1, n1[i].f[1], acc); mma16(at, n1[i].t, acc);
+                v[i] = acc + bias;
+            }
+            if (!to_r) {
+                if (qrc >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<uint2*>(lds + o_p1s + j * QT_SP) = make_uint2(qa_pk(v[0][j], v[1][j]) & pm[0], qa_pk(v[2][j], v[3][j]) & pm[1]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (qrc >= 0 && ((qrc >> i) & 1)) *reinterpret_cast<uint2*>(lds + o_p1r + rbuf * QT_R + i * AG_PS) = qa_pack(v[i]);
             }
         };
-        auto g_store = [&](int seg, char* S) {
-            const f32x4 bias = ld4(s_bq + 16 * seg + 4 * q);
-#pragma unroll
-            for (int i = 0; i < QA_NC; ++i) {
-                uint2 pkd = qa_pack(ga[i] + bias);
-                if (!((inimg >> i) & 1u)) pkd = make_uint2(0u, 0u);
-                const int so = s_soff[i * QA_THREADS + tid];
-                if (so >= 0) *reinterpret_cast<uint2*>(S + so) = pkd;
-            }
-        };
-        // segment order: the local branch's three segments first (its 16 accumulators are then dead during the wide windows), then q, k, v
+        // segment order: the local branch's three segments first (its accumulators are then dead), then q, k, v
         auto seg_at = [](int k) { return k < 3 ? 5 * k + 4 : (k - 3) + (k - 3) / 4; };
 
-        g_issue(seg_at(0));
-        g_store(seg_at(0), lds);
+        uint4 T[7];
+        qt_load(r_toep, QT_TAB_LOC, 3, o_l16 + wave * 1024, T);
+        p1(seg_at(0), false, 0);
         __syncthreads();
         {   // ---- k = 0..2: local branch, dw 3x3 of q4 / k4 / v4 -> 48 -> 16 (accumulated over the three) -> LayerNorm(16) -> Hardswish
-            f32x4 dl[2][2];
-#pragma unroll
-            for (int o = 0; o < 2; ++o)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) dl[o][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 dl[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 1
             for (int which = 0; which < 3; ++which) {
-                const char* S = lds + (which & 1) * QA_S;
-                {
-                    f32x4 acc[2][2];
+                QT_KEEP();
+                const int rb = (which & 1) * QT_R;
+                qt_dw<3>(lds + o_p2s, lds + o_p2d + rb, T);
+                __syncthreads();
+                // P1 of the next segment first (its accumulators and the Toeplitz fragments are then never live together), the fragments' loads next, P3 under them
+                p1(seg_at(which + 1), which == 2, (which + 1) & 1);
+                qt_load(r_toep, which < 2 ? QT_TAB_LOC + (which + 1) * 3 * 16 * 1024 : QT_TAB_K3, 3, o_l16 + wave * 1024, T);   // k = 3 is q's pass-through segment, k = 4 its 3 x 3 group
+                const uint2 apw = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_pw) + (3 + which) * 512 + (o_l16 >> 1));
 #pragma unroll
-                    for (int o = 0; o < 2; ++o)
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) acc[o][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    qa_dw<3>(S, s_taps + 1328 + which * 144, t.prow, t.pcol, q, acc);
-                    const uint2 apw = s_pw[(3 + which) * 64 + lane];
-#pragma unroll
-                    for (int o = 0; o < 2; ++o)
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) mma16(apw, qa_pack(acc[o][c]), dl[o][c]);
-                }
-                g_issue(seg_at(which + 1));
-                g_store(seg_at(which + 1), lds + ((which + 1) & 1) * QA_S);
+                for (int nt = 0; nt < 2; ++nt) mma16(apw, *reinterpret_cast<const uint2*>(lds + o_p3 + rb + 16 * nt * AG_PS), dl[nt]);
                 __syncthreads();
             }
-            const f32x4 lg = ld4(s_bn + 128 + 4 * q), lb = ld4(s_bn + 144 + 4 * q);
+            const f32x4 lg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_bn) + 512 + o_g16), lb = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_bn) + 576 + o_g16);
 #pragma unroll
-            for (int o = 0; o < 2; ++o)
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x4 tt = dl[nt] + 0.f;
+                float s = (tt[0] + tt[1]) + (tt[2] + tt[3]);
+                s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+                const float mean = s / 16.f;
+                const f32x4 dd = tt - mean;
+                const f32x4 d2 = dd * dd;
+                float var = (d2[0] + d2[1]) + (d2[2] + d2[3]);
+                var += __shfl_xor(var, 16); var += __shfl_xor(var, 32);
+                const float rstd = 1.f / sqrtf(var / 16.f + 1e-5f);
+                f32x4 v = dd * rstd * lg + lb;
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const f32x4 tt = dl[o][c] + 0.f;
-                    float s = (tt[0] + tt[1]) + (tt[2] + tt[3]);
-                    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-                    const float mean = s / 16.f;
-                    const f32x4 dd = tt - mean;
-                    const f32x4 d2 = dd * dd;
-                    float var = (d2[0] + d2[1]) + (d2[2] + d2[3]);
-                    var += __shfl_xor(var, 16); var += __shfl_xor(var, 32);
-                    const float rstd = 1.f / sqrtf(var / 16.f + 1e-5f);
-                    f32x4 v = dd * rstd * lg + lb;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
-                    if (t.y0 + t.prow + o < a.H && t.x0 + t.pcol + c < a.W)
-                        *reinterpret_cast<uint2*>(a.loc + (t.pix0 + (size_t)o * a.W + c) * kSEG + 4 * q) = qa_pack(v);
-                }
+                for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
+                const uint2 pkd = qa_pack(v);
+                __builtin_amdgcn_raw_buffer_store_b64(qt_u32x2{pkd.x, pkd.y}, r_loc, ((p3_cols >> nt) & 1u) ? p3_off + 16 * nt * kSEG * 2 : (int)0x80000000, 0, 0);
+            }
         }
 #pragma unroll 1
         for (int k = 3; k < 15; ++k) {   // ---- the four groups of q, k, v
-            const char* S = lds + (k & 1) * QA_S;
+            QT_KEEP();
+            const int rb = (k & 1) * QT_R;
             const int seg = seg_at(k), nseg = seg_at(k + 1);
-            const int which = seg / 5, g5 = seg - 5 * which;
-            auto between = [&]() { if (k + 1 < 15) g_issue(nseg); };
-            bf16_t* outp = a.qkvp + (size_t)(4 * which + g5) * a.plane + 4 * q;
-            const f32x4 sc = ld4(s_bn + 16 * g5 + 4 * q), sh = ld4(s_bn + 64 + 16 * g5 + 4 * q);
-            f32x4 vmax;
-            if (g5 == 3) vmax = qa_conv_group<7>(S, s_taps + 544, s_pw[2 * 64 + lane], sc, sh, outp, t, between);
-            else if (g5 == 2) vmax = qa_conv_group<5>(S, s_taps + 144, s_pw[1 * 64 + lane], sc, sh, outp, t, between);
-            else if (g5 == 1) vmax = qa_conv_group<3>(S, s_taps, s_pw[lane], sc, sh, outp, t, between);
-            else vmax = qa_conv_group<1>(S, s_taps, s_pw[lane], sc, sh, outp, t, between);
-            if (which == 1 && a.kmax != nullptr) {                            // rows of 16 lanes share a channel quad: row maximum -> LDS
-#pragma unroll
-                for (int e = 0; e < 4; ++e) vmax[e] = row_max16(vmax[e]);
-                if (n == 0) *reinterpret_cast<float4*>(s_red + (g5 * QA_WAVES + wave) * 16 + 4 * q) = make_float4(vmax[0], vmax[1], vmax[2], vmax[3]);
+            const int which = seg / 5, g5 = seg - 5 * which, ng5 = nseg % 5;
+            if (g5 != 0) {
+                if (g5 == 3) qt_dw<7>(lds + o_p2s, lds + o_p2d + rb, T);
+                else if (g5 == 2) qt_dw<5>(lds + o_p2s, lds + o_p2d + rb, T);
+                else qt_dw<3>(lds + o_p2s, lds + o_p2d + rb, T);
+                __syncthreads();
             }
-            if (seg == 10 && a.kmax != nullptr && tid < 64) {                 // all four k segments are done (a barrier ago): one atomic per channel and tile
-                const float* p = s_red + (tid >> 4) * QA_WAVES * 16 + (tid & 15);
-                float m = p[0];
-#pragma unroll
-                for (int w = 1; w < QA_WAVES; ++w) m = fmaxf(m, p[16 * w]);
-                atomic_max_f32(a.kmax + (size_t)b * 64 + tid, m);
+            if (k + 1 < 15) {                                                 // P1 of the next segment, then its Toeplitz fragments: in flight during P3
+                p1(nseg, ng5 == 0, (k + 1) & 1);
+                if (ng5 != 0) qt_load(r_toep, ng5 == 3 ? QT_TAB_K7 : ng5 == 2 ? QT_TAB_K5 : QT_TAB_K3, 2 * ng5 + 1, o_l16 + wave * 1024, T);
             }
-            if (k + 1 < 15) g_store(nseg, lds + ((k + 1) & 1) * QA_S);
+            {   // P3: point-wise (identity for the pass-through group) -> BatchNorm -> Hardswish -> qkvp
+                const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(a.qkvp + (size_t)(4 * which + g5) * a.plane, 0, (int)(a.plane * 2), 0x00020000);
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_bn) + 64 * g5 + o_g16);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_bn) + 256 + 64 * g5 + o_g16);
+                const uint2 apw = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_pw) + (g5 > 0 ? g5 - 1 : 0) * 512 + (o_l16 >> 1));
+                const bool want_max = which == 1 && a.kmax != nullptr;
+                f32x4 vmax = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const uint2 in = *reinterpret_cast<const uint2*>(lds + o_p3 + rb + 16 * nt * AG_PS);
+                    f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (g5 != 0) mma16(apw, in, d);
+                    else d = up_tail(in);
+                    f32x4 v = d * sc + sh;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
+                    if ((p3_cols >> nt) & 1u) {
+                        const uint2 pkd = qa_pack(v);
+                        __builtin_amdgcn_raw_buffer_store_b64(qt_u32x2{pkd.x, pkd.y}, r_out, p3_off + 16 * nt * kSEG * 2, 0, 0);
+                        if (want_max) {
+                            const f32x4 rr = up_tail(pkd);                     // the stored (bf16) values are what rc_gma_kv sees
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) vmax[e] = fmaxf(vmax[e], rr[e]);
+                        }
+                    }
+                }
+                if (want_max) {                                               // rows of 16 lanes share a channel quad: row maximum -> LDS
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vmax[e] = row_max16(vmax[e]);
+                    if (n == 0) *reinterpret_cast<float4*>(reinterpret_cast<char*>(s_red) + (g5 * QA_WAVES + wave) * 64 + o_g16) = make_float4(vmax[0], vmax[1], vmax[2], vmax[3]);
+                }
+                if (seg == 10 && a.kmax != nullptr && wave == 0) {            // all four k segments are done (a barrier ago): one atomic per channel and tile
+                    const int ch = o_l16 >> 4;                                // = lane (re-derived here: as `tid` the address was hoisted out of the tile loop and spilled)
+                    const float* p = s_red + (ch >> 4) * QA_WAVES * 16 + (ch & 15);
+                    float m = p[0];
+#pragma unroll
+                    for (int w = 1; w < QA_WAVES; ++w) m = fmaxf(m, p[16 * w]);
+                    atomic_max_f32(a.kmax + (size_t)b * 64 + ch, m);
+                }
+            }
             __syncthreads();
         }
     }
 }
+#undef QT_KEEP
 
 }  // namespace gf
 }  // namespace rc
-
-namespace rc { int g_qa_flags = 0; }   // rc_debug_set("qa_flags", v): timing knock-outs of rc_gma_qkv_aggregate (results are wrong with any bit set)
 
 extern "C" int rc_chain_pack_weights_natural(const float* w, int cin, int cout, void* dst) {
     using namespace rc;
@@ -1250,26 +1264,52 @@ extern "C" int rc_chain_pack_weights_natural(const float* w, int cin, int cout, 
     return RC_OK;
 }
 
-extern "C" int rc_gma_qkv_aggregate(const void* d_x, const void* d_wq_natural, const float* d_bq, const float* d_ln1_g, const float* d_ln1_b, float eps,
-                                    void* d_qkvp, void* d_loc, int batch, int H, int W, const float* d_dw3, const float* d_dw5, const float* d_dw7,
-                                    const float* d_dwl, const float* d_pw, const float* d_pwl, const float* d_bn_scale, const float* d_bn_shift,
-                                    const float* d_ln_g, const float* d_ln_b, float* d_kmax, void* stream) {
+extern "C" size_t rc_gma_toeplitz_bytes(void) { return (size_t)rc::gf::QT_TAB_BYTES; }
+
+// Banded Toeplitz A fragments of the aggregator's depth-wise kernels: for kernel row dy of channel c (tap-major fp32 taps [K*K][16]),
+// T[ox][slot] = tap[dy][dx] with dx = slot - 4 - ox + K / 2 (slot s of a 32-slot window = input pixel s - 4 relative to the window's first
+// output), zero outside 0 <= dx < K; lane (ox = lane & 15, q = lane >> 4) holds slots 8 q .. 8 q + 7.  Taps must be bf16-representable
+// (they are: the module's parameters are bf16 on this path); they are rounded to nearest even otherwise.
+extern "C" int rc_gma_toeplitz_pack(const float* dw3, const float* dw5, const float* dw7, const float* dwl, void* dst) {
     using namespace rc;
     using namespace rc::gf;
-    RC_REQUIRE(d_x && d_wq_natural && d_ln1_g && d_ln1_b && d_qkvp && d_loc && d_dw3 && d_dw5 && d_dw7 && d_dwl && d_pw && d_pwl && d_bn_scale &&
-               d_bn_shift && d_ln_g && d_ln_b, "rc_gma_qkv_aggregate: null pointer");
+    RC_REQUIRE(dw3 && dw5 && dw7 && dwl && dst, "rc_gma_toeplitz_pack: null pointer");
+    uint16_t* out = static_cast<uint16_t*>(dst);
+    auto group = [&](const float* taps, int K, int off_bytes) {
+        for (int dy = 0; dy < K; ++dy)
+            for (int c = 0; c < 16; ++c)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 8; ++i) {
+                        const int ox = lane & 15, slot = 8 * (lane >> 4) + i, dx = slot - 4 - ox + K / 2;
+                        out[off_bytes / 2 + ((size_t)(dy * 16 + c) * 64 + lane) * 8 + i] =
+                            (dx >= 0 && dx < K) ? host_f32_to_bf16(taps[(dy * K + dx) * 16 + c]) : (uint16_t)0;
+                    }
+    };
+    group(dw3, 3, QT_TAB_K3); group(dw5, 5, QT_TAB_K5); group(dw7, 7, QT_TAB_K7);
+    for (int which = 0; which < 3; ++which) group(dwl + which * 144, 3, QT_TAB_LOC + which * 3 * 16 * 1024);
+    return RC_OK;
+}
+
+extern "C" int rc_gma_qkv_aggregate(const void* d_x, const void* d_wq_natural, const float* d_bq, const float* d_ln1_g, const float* d_ln1_b, float eps,
+                                    void* d_qkvp, void* d_loc, int batch, int H, int W, const void* d_toeplitz, const float* d_pw, const float* d_pwl,
+                                    const float* d_bn_scale, const float* d_bn_shift, const float* d_ln_g, const float* d_ln_b, float* d_kmax, void* stream) {
+    using namespace rc;
+    using namespace rc::gf;
+    RC_REQUIRE(d_x && d_wq_natural && d_ln1_g && d_ln1_b && d_qkvp && d_loc && d_toeplitz && d_pw && d_pwl && d_bn_scale && d_bn_shift && d_ln_g && d_ln_b,
+               "rc_gma_qkv_aggregate: null pointer");
     RC_REQUIRE(batch >= 1 && H >= 1 && W >= 1, "rc_gma_qkv_aggregate: bad shape");
     QaArgs a;
     a.x = static_cast<const bf16_t*>(d_x); a.qkvp = static_cast<bf16_t*>(d_qkvp); a.loc = static_cast<bf16_t*>(d_loc); a.kmax = d_kmax;
     a.batch = batch; a.H = H; a.W = W; a.tiles_x = ceil_div(W, AG_TW); a.tiles_y = ceil_div(H, AG_TH);
     const long long n_tiles = (long long)a.tiles_x * a.tiles_y * batch;
     RC_REQUIRE(n_tiles < (1ll << 31), "rc_gma_qkv_aggregate: too many tiles");
+    RC_REQUIRE((long long)batch * H * W * kSEG * 2 < (1ll << 31) && (long long)H * W * kC * 2 < (1ll << 31),
+               "rc_gma_qkv_aggregate: a 16-channel plane of the batch and an 80-channel image must stay below 2 GiB (32-bit buffer offsets)");
     a.n_tiles = (int)n_tiles;
     a.plane = (size_t)batch * H * W * kSEG;
     a.wq = d_wq_natural; a.bq = d_bq; a.ln1_g = d_ln1_g; a.ln1_b = d_ln1_b; a.eps = eps;
-    a.dw[0] = d_dw3; a.dw[1] = d_dw5; a.dw[2] = d_dw7; a.dwl = d_dwl; a.pw = d_pw; a.pwl = d_pwl;
+    a.toep = static_cast<const char*>(d_toeplitz); a.pw = d_pw; a.pwl = d_pwl;
     a.bn_scale = d_bn_scale; a.bn_shift = d_bn_shift; a.ln_g = d_ln_g; a.ln_b = d_ln_b;
-    a.dbg = g_qa_flags;
     int dev = 0;
     RC_HIP_CHECK(hipGetDevice(&dev));
     RC_REQUIRE(dev >= 0 && dev < 64, "rc_gma_qkv_aggregate: device index out of range");
@@ -1281,7 +1321,7 @@ extern "C" int rc_gma_qkv_aggregate(const void* d_x, const void* d_wq_natural, c
         attr[dev] = true;
     }
     if (d_kmax) RC_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_kmax), (int)0xff800000u /* -inf */, (size_t)batch * 64, as_stream(stream)));
-    int blocks = a.n_tiles < cus[dev] ? a.n_tiles : cus[dev];                // one 8-wave block per CU (115 KB of LDS), a contiguous run of tiles each
+    int blocks = a.n_tiles < cus[dev] ? a.n_tiles : cus[dev];                // one 8-wave block per CU, a contiguous run of tiles each
     a.tiles_per_block = (a.n_tiles + blocks - 1) / blocks;
     blocks = (a.n_tiles + a.tiles_per_block - 1) / a.tiles_per_block;
     hipLaunchKernelGGL(gma_qkv_agg_kernel, dim3((unsigned)blocks), dim3(QA_THREADS), QA_LDS, as_stream(stream), a);

@@ -147,21 +147,26 @@ class Aggregator(nn.Module):
 
     def _run_front(self, x, norm1, qkv_linear):
         """x (B,H,W,80) bf16 -> (qkvp, loc, kmax) = _run_fused(qkv(LayerNorm1(x))) in ONE launch (rc_gma_qkv_aggregate): the 240-channel qkv map is
-        produced 16 channels at a time into LDS and consumed there (upstream groupmix.py:178 after :293, then :56-105)."""
+        produced 16 channels at a time into LDS and consumed there, the depth-wise windows as banded Toeplitz products on the matrix cores
+        (upstream groupmix.py:178 after :293, then :56-105)."""
         seg = 16
-
-        def taps(w1, w2, w3, w0):
-            return (ops.dw_taps(w1), ops.dw_taps(w2), ops.dw_taps(w3),
-                    ops.dw_taps(w0).reshape(9, 3, seg).permute(1, 0, 2).contiguous())      # local: (which, tap, channel)
-        dw3, dw5, dw7, dwl = ops.host_cached(self, "taps_exact", [self.agg1.conv1.weight, self.agg2.conv1.weight, self.agg3.conv1.weight,
-                                                                 self.agg0.conv.conv1.weight], taps)
+        dws = [self.agg1.conv1.weight, self.agg2.conv1.weight, self.agg3.conv1.weight, self.agg0.conv.conv1.weight]
+        c = ops._cache(self)
+        key = ops._key(*dws)
+        hit = c.get("toeplitz")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                w1, w2, w3, w0 = [p.detach().float().cpu() for p in dws]
+                hit = (key, torch.ops.realcam.gma_toeplitz_pack(ops.dw_taps(w1).to(x.device), ops.dw_taps(w2).to(x.device), ops.dw_taps(w3).to(x.device),
+                                                                ops.dw_taps(w0).reshape(9, 3, seg).permute(1, 0, 2).contiguous().to(x.device)))
+            c["toeplitz"] = hit
         scale, shift, pw, pwl = self._folded()
         ln = self.agg0.norm
         if abs(ln.eps - 1e-5) > 0:
             raise NotImplementedError("Aggregator: LayerNorm eps must be the default 1e-5")
         f32 = ops.f32_param
         return torch.ops.realcam.gma_qkv_aggregate(x, ops.packed_chain_natural(qkv_linear), f32(qkv_linear, "bias") if qkv_linear.bias is not None else None,
-                                                   f32(norm1, "weight"), f32(norm1, "bias"), float(norm1.eps), dw3, dw5, dw7, dwl, pw, pwl,
+                                                   f32(norm1, "weight"), f32(norm1, "bias"), float(norm1.eps), hit[1], pw, pwl,
                                                    scale, shift, f32(ln, "weight"), f32(ln, "bias"))
 
 

@@ -170,7 +170,7 @@ def packed_chain_natural(mod):
 # two launches with register-resident activations (csrc/gma_fused.hip) instead of nine layer-by-layer ones.  Built for dim 80, bf16.
 FUSE_GMA = True
 # LayerNorm1 + qkv + Aggregator as one launch (rc_gma_qkv_aggregate: qkv never reaches HBM) instead of rc_gma_ln_qkv + rc_gma_aggregate; same bits.
-FUSE_GMA_FRONT = os.environ.get("RC_GMA_FRONT", "0") != "0"
+FUSE_GMA_FRONT = os.environ.get("RC_GMA_FRONT", "1") != "0"
 
 
 class _ConvView:

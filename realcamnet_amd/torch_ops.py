@@ -682,15 +682,25 @@ def _cpackn_launch(wp, weight):
 define("chain_pack_weights_natural(Tensor weight) -> Tensor",
        lambda weight: weight.new_empty((lib().rc_chain_packed_bytes(weight.shape[1], weight.shape[0]),), dtype=torch.uint8), _cpackn_launch)
 
-define("gma_qkv_aggregate(Tensor x, Tensor wq_natural, Tensor? bq, Tensor ln1_gamma, Tensor ln1_beta, float eps, Tensor dw3, Tensor dw5, Tensor dw7, "
-       "Tensor dwl, Tensor pw, Tensor pwl, Tensor bn_scale, Tensor bn_shift, Tensor ln_gamma, Tensor ln_beta) -> (Tensor, Tensor, Tensor)",
+def _toep_launch(out, dw3, dw5, dw7, dwl):
+    arrs = [np.ascontiguousarray(t.detach().float().cpu().numpy()) for t in (dw3, dw5, dw7, dwl)]
+    dst = np.empty(out.numel(), dtype=np.uint8)
+    check(lib().rc_gma_toeplitz_pack(*[a.ctypes.data for a in arrs], dst.ctypes.data), "rc_gma_toeplitz_pack")
+    out.copy_(torch.from_numpy(dst))
+
+
+define("gma_toeplitz_pack(Tensor dw3, Tensor dw5, Tensor dw7, Tensor dwl) -> Tensor",
+       lambda dw3, *a: dw3.new_empty((lib().rc_gma_toeplitz_bytes(),), dtype=torch.uint8), _toep_launch)
+
+define("gma_qkv_aggregate(Tensor x, Tensor wq_natural, Tensor? bq, Tensor ln1_gamma, Tensor ln1_beta, float eps, Tensor toeplitz, "
+       "Tensor pw, Tensor pwl, Tensor bn_scale, Tensor bn_shift, Tensor ln_gamma, Tensor ln_beta) -> (Tensor, Tensor, Tensor)",
        lambda x, *a: (x.new_empty((12, *x.shape[:3], 16)), x.new_empty((*x.shape[:3], 16)),                  # x: (B, H, W, 80)
                       x.new_empty((x.shape[0], 64), dtype=torch.float32)),
-       lambda outs, x, wq, bq, g1, b1, eps, dw3, dw5, dw7, dwl, pw, pwl, sc, sh, lg, lb: check(
+       lambda outs, x, wq, bq, g1, b1, eps, toep, pw, pwl, sc, sh, lg, lb: check(
            lib().rc_gma_qkv_aggregate(x.data_ptr(), wq.data_ptr(), _p(bq), g1.data_ptr(), b1.data_ptr(), float(eps), outs[0].data_ptr(),
-                                      outs[1].data_ptr(), x.shape[0], x.shape[1], x.shape[2], dw3.data_ptr(), dw5.data_ptr(), dw7.data_ptr(),
-                                      dwl.data_ptr(), pw.data_ptr(), pwl.data_ptr(), sc.data_ptr(), sh.data_ptr(), lg.data_ptr(), lb.data_ptr(),
-                                      outs[2].data_ptr(), _stream()), "rc_gma_qkv_aggregate"))
+                                      outs[1].data_ptr(), x.shape[0], x.shape[1], x.shape[2], toep.data_ptr(), pw.data_ptr(), pwl.data_ptr(),
+                                      sc.data_ptr(), sh.data_ptr(), lg.data_ptr(), lb.data_ptr(), outs[2].data_ptr(), _stream()),
+           "rc_gma_qkv_aggregate"))
 
 
 def _kvm_launch(ktv, qkvp, kmax, scale):

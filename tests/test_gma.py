@@ -208,9 +208,13 @@ def test_kv_on_matrix_cores_equals_two_pass_form(hip):
 @pytest.mark.parametrize("b,hw", [(2, (37, 53)), (1, (16, 32)), (3, (5, 7)), (1, (1, 1)), (2, (48, 96)), (1, (130, 201))])
 @pytest.mark.parametrize("qkv_bias", [False, True])
 def test_qkv_aggregate_in_one_launch_equals_the_two_launch_path(hip, b, hw, qkv_bias):
-    """rc_gma_qkv_aggregate (LayerNorm1 + qkv + Aggregator, qkv kept on chip) against rc_gma_ln_qkv + rc_gma_aggregate: the same K-step order,
-    bias point, tap order and bf16 rounding points -> bitwise equal qkvp, loc and per-channel k maximum; ragged tiles, images smaller than
-    one tile and than the 7x7 window, several tiles per block, an outlier token, with and without a qkv bias; run-to-run bitwise."""
+    """rc_gma_qkv_aggregate (LayerNorm1 + qkv + Aggregator in one launch, qkv kept on chip, the depth-wise windows as banded Toeplitz products on the
+    matrix cores) against rc_gma_ln_qkv + rc_gma_aggregate.  Same K-step order, bias point and bf16 rounding points; the depth-wise sums are exact
+    bf16 products added in fp32 in the matrix pipe's order instead of (dy, dx) fmaf order, so a value may land on the other side of a bf16 rounding
+    boundary: the bar is >= 99.9 % of the values bit-equal and no value further than 2 bf16 ulps of the tensor's largest magnitude (measured at
+    8 x 544 x 960: 3 685 of 8.0e8 values differ, largest 0.002; loc 155 of 6.7e7).  The pass-through segments, the per-channel maximum of k (a maximum of
+    stored values) and run-to-run results are bitwise.  Ragged tiles, images smaller than a tile and than the 7x7 window, several tiles per block, an
+    outlier token, with and without a qkv bias."""
     R = torch.ops.realcam
     torch.manual_seed(b * 1000 + hw[0])
     blk = M.GMA_Block(80, 8, qkv_bias=qkv_bias)
@@ -237,7 +241,17 @@ def test_qkv_aggregate_in_one_launch_equals_the_two_launch_path(hip, b, hw, qkv_
     for name, w_, g_, a_ in zip(("qkvp", "loc", "kmax"), want, got, again):
         assert w_.shape == g_.shape and w_.dtype == g_.dtype, name
         assert torch.equal(g_, a_), name
-        assert torch.equal(w_, g_), (name, (w_.float() - g_.float()).abs().max().item())
+    qw, qg = want[0].float(), got[0].float()
+    for seg in (0, 4, 8):                                             # pass-through groups of q, k, v: no depth-wise sum
+        assert torch.equal(qw[seg], qg[seg]), seg
+    for name, w_, g_ in (("qkvp", qw, qg), ("loc", want[1].float(), got[1].float())):
+        diff = (w_ - g_).abs()
+        assert (diff != 0).float().mean().item() <= 1e-3, (name, (diff != 0).float().mean().item())
+        assert diff.max().item() <= 2.0 ** -7 * w_.abs().max().item(), (name, diff.max().item(), w_.abs().max().item())
+    kw, kg = want[2], got[2]
+    assert (kw - kg).abs().max().item() <= 2.0 ** -7 * kw.abs().max().item()
+    k = got[0][4:8].float().permute(1, 2, 3, 0, 4).reshape(b, hw[0] * hw[1], 64)
+    assert torch.equal(kg, k.amax(dim=1))                             # the maximum of the values this launch stored
 
 
 @pytest.mark.gpu

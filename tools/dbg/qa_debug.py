@@ -6,7 +6,7 @@ from realcamnet_amd import ops
 R = torch.ops.realcam
 torch.manual_seed(0)
 blk = M.GMA_Block(80, 8).to("cuda", torch.bfloat16).eval()
-for (b, H, W) in [(2, 37, 53)]:
+for (b, H, W) in [(1, 16, 32), (2, 37, 53), (1, 130, 201), (8, 544, 960)]:
     x = torch.randn(b, H, W, 80, device="cuda").to(torch.bfloat16)
     with torch.no_grad():
         wq, bq = ops.packed_chain(blk.att.qkv)
@@ -27,9 +27,7 @@ for (b, H, W) in [(2, 37, 53)]:
         if name == "loc" and (d1 != 0).any():
             print("    first:", (d1 != 0).nonzero()[:6].tolist())
 
-# ---- timing knock-outs at the cfg3 size
-from realcamnet_amd import _lib
-L = _lib.load()
+
 def timeit(fn, n=5):
     for _ in range(2): fn()
     torch.cuda.synchronize()
@@ -40,8 +38,4 @@ def timeit(fn, n=5):
     return e0.elapsed_time(e1) / n * 1e3
 x = torch.randn(8, 544, 960, 80, device="cuda").to(torch.bfloat16)
 with torch.no_grad():
-    for flags in (0, 1, 2, 4, 8, 3, 5, 7, 15):
-        L.rc_debug_set(b"qa_flags", flags)
-        t = timeit(lambda: blk.att.aggregator._run_front(x, blk.norm1, blk.att.qkv))
-        print(f"qa_flags {flags:2d} (1 no dw, 2 no stores, 4 no GEMM, 8 no x loads): {t:8.1f} us")
-    L.rc_debug_set(b"qa_flags", 0)
+    print(f"front: {timeit(lambda: blk.att.aggregator._run_front(x, blk.norm1, blk.att.qkv)):8.1f} us")
