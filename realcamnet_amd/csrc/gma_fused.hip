@@ -942,7 +942,7 @@ constexpr int QT_S = 16 * QT_SP + 64;                                           
 constexpr int QT_RR = AG_TW * AG_PS + 8, QT_R = AG_TH * QT_RR;                                  // pixel-major tile: 40-byte pixels, 1288-byte rows
 constexpr int QT_QUADS = QT_ROWS * (QT_SLOTS / 4), QT_QPW = (QT_QUADS + QA_WAVES - 1) / QA_WAVES;   // 220 quads of 4 slots, 14 per wave (one per lane n)
 constexpr int QA_WSEG = tile_bytes(kC);                                                         // 2560 bytes of A fragments per segment
-constexpr int QA_OFF_R = QT_S, QA_OFF_W = QA_OFF_R + 2 * QT_R, QA_OFF_BQ = QA_OFF_W + 15 * QA_WSEG, QA_OFF_GB = QA_OFF_BQ + 240 * 4,
+constexpr int QA_OFF_R = 2 * QT_S, QA_OFF_W = QA_OFF_R + 2 * QT_R, QA_OFF_BQ = QA_OFF_W + 15 * QA_WSEG, QA_OFF_GB = QA_OFF_BQ + 240 * 4,
               QA_OFF_BN = QA_OFF_GB + 160 * 4, QA_OFF_PW = QA_OFF_BN + 160 * 4, QA_OFF_RED = QA_OFF_PW + 6 * 64 * 8,
               QA_LDS = QA_OFF_RED + 4 * QA_WAVES * 16 * 4;
 static_assert(QT_S % 16 == 0 && QT_R % 16 == 0 && QA_OFF_W % 16 == 0 && QA_OFF_PW % 8 == 0 && QT_QPW <= 16 && QA_WAVES == AG_TH && QA_LDS <= 160 * 1024,
@@ -962,18 +962,28 @@ struct QaArgs {
     const float* bn_scale; const float* bn_shift; const float* ln_g; const float* ln_b;
 };
 
+// s + the values of the three other lane groups (lanes n, n + 16, n + 32, n + 48): the two __shfl_xor steps of layernorm80 as gfx950's row / half swaps.
+// Operand order differs from own + partner only by commutation, so the sums are the same bits; no lane-index registers (hipcc kept the bpermute
+// addresses of __shfl_xor alive across the whole tile loop: three spilled VGPRs) and no LDS crossbar traffic.  Inline asm because the builtin's
+// second result is mis-lowered by this hipcc (both results come back as the first); s_nop on both sides: the swap is opaque to the hazard recogniser.
+__device__ __forceinline__ float sum_lane_groups(float s) {
+    float a = s, b = s;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    s = a + b; a = s; b = s;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 // one token column tile of layernorm80 (same expressions, same order; gamma / beta fetched where they are used: 128 VGPRs to live in)
 __device__ __forceinline__ void ln80_one(const Act<kC>& in, Act<kC>& out, const float* gb, int g, float eps) {
     const float* bb = gb + kC;
     const f32x4 v0 = up_lo(in.f[0]), v1 = up_hi(in.f[0]), v2 = up_lo(in.f[1]), v3 = up_hi(in.f[1]), v4 = up_tail(in.t);
     const f32x4 sv = ((v0 + v1) + (v2 + v3)) + v4;
-    float s = (sv[0] + sv[1]) + (sv[2] + sv[3]);
-    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+    const float s = sum_lane_groups((sv[0] + sv[1]) + (sv[2] + sv[3]));
     const float mean = s / (float)kC;
     const f32x4 d0 = v0 - mean, d1 = v1 - mean, d2 = v2 - mean, d3 = v3 - mean, d4 = v4 - mean;
     const f32x4 qv = ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + d4 * d4;
-    float q = (qv[0] + qv[1]) + (qv[2] + qv[3]);
-    q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+    const float q = sum_lane_groups((qv[0] + qv[1]) + (qv[2] + qv[3]));
     const float rstd = 1.f / sqrtf(q / (float)kC + eps);
     const uint2 p0 = qa_pack(d0 * rstd * ld4(gb + 8 * g) + ld4(bb + 8 * g)), p1 = qa_pack(d1 * rstd * ld4(gb + 8 * g + 4) + ld4(bb + 8 * g + 4));
     out.f[0] = make_uint4(p0.x, p0.y, p1.x, p1.y);
@@ -1043,7 +1053,7 @@ __global__ __launch_bounds__(QA_THREADS) void gma_qkv_agg_kernel(QaArgs a) {
         const int f = i >> 6;
         s_pw[i] = f < 3 ? agg_afrag(a.pw + f * 256, 16, 0, i & 63) : agg_afrag(a.pwl, 48, 16 * (f - 3), i & 63);
     }
-    for (int i = tid; i < (QT_S + 2 * QT_R) / 16; i += QA_THREADS) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);   // finite everywhere: zero-weighted slots are still multiplied
+    for (int i = tid; i < (2 * QT_S + 2 * QT_R) / 16; i += QA_THREADS) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0u, 0u, 0u, 0u);   // finite everywhere: zero-weighted slots are still multiplied
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t r_toep = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.toep), 0, QT_TAB_BYTES, 0x00020000);
@@ -1062,12 +1072,11 @@ __global__ __launch_bounds__(QA_THREADS) void gma_qkv_agg_kernel(QaArgs a) {
     // Lane constants of the segment loops, ONE register each.  hipcc otherwise hoists every address it can form from lane / n / g out of those loops (dozens of
     // VGPRs, spilled, and each reload waits for ALL outstanding memory operations); QT_KEEP makes the loops see them as opaque values: adds stay inside.
     int o_p1s = (4 * g0) * QT_SP + qrow * QT_SR + qcol * 8;                  // P1 -> S: + j planes
-    int o_p1r = QA_OFF_R + (qrow - 3) * QT_RR + (4 * qcol - 4) * AG_PS + 8 * g0;   // P1 -> R (pass-through segments): + i pixels
     int o_p2s = wave * QT_SP + n * QT_SR + 16 * g0;                         // P2 <- S
     int o_p2d = QA_OFF_R + n * QT_RR + 4 * g0 * AG_PS + 2 * wave;            // P2 -> R
     int o_p3 = QA_OFF_R + wave * QT_RR + n * AG_PS + 8 * g0;                // P3 <- R: + 16 nt pixels
     int o_l16 = lane * 16, o_g16 = g0 * 16;                                  // A fragments; bias / BatchNorm quads
-#define QT_KEEP() asm volatile("" : "+v"(o_p1s), "+v"(o_p1r), "+v"(o_p2s), "+v"(o_p2d), "+v"(o_p3), "+v"(o_l16), "+v"(o_g16), "+v"(n), "+v"(qrc))
+#define QT_KEEP() asm volatile("" : "+v"(o_p1s), "+v"(o_p2s), "+v"(o_p2d), "+v"(o_p3), "+v"(o_l16), "+v"(o_g16), "+v"(n), "+v"(qrc))
 
     const int t_begin = blockIdx.x * a.tiles_per_block;
     const int t_end = t_begin + a.tiles_per_block < a.n_tiles ? t_begin + a.tiles_per_block : a.n_tiles;
@@ -1080,9 +1089,9 @@ __global__ __launch_bounds__(QA_THREADS) void gma_qkv_agg_kernel(QaArgs a) {
         const int y0 = ty * AG_TH, x0 = tx * AG_TW;
         QT_KEEP();
 
-        // ---- L: x of the halo tile -> LayerNorm1 -> B fragments in registers; pm[p]: which halves of the bf16 pair (slot 2 p, 2 p + 1) lie in the image
+        // ---- L: x of the halo tile -> LayerNorm1 -> B fragments in registers
         Act<kC> n1[4];
-        uint32_t pm[2] = {0u, 0u};
+        unsigned tfl = 0;                                                     // bits 0..3: which of this lane's 4 pixels lie in the image; bits 4, 5: which of its two P3 pixels do
         {
             const int gy = y0 - 3 + (qrc >> 12), gx0 = x0 - 4 + 4 * ((qrc >> 4) & 255), g = o_g16 >> 4;
             const bool row_ok = qrc >= 0 && gy >= 0 && gy < a.H;
@@ -1097,7 +1106,7 @@ __global__ __launch_bounds__(QA_THREADS) void gma_qkv_agg_kernel(QaArgs a) {
                 const qt_u32x4 f0 = __builtin_amdgcn_raw_buffer_load_b128(r_x, vo, 0, 0), f1 = __builtin_amdgcn_raw_buffer_load_b128(r_x, vo, 64, 0);
                 const qt_u32x2 ft = __builtin_amdgcn_raw_buffer_load_b64(r_x, ok ? vo - 8 * g : vo, 128, 0);
                 xin[i].f[0] = make_uint4(f0[0], f0[1], f0[2], f0[3]); xin[i].f[1] = make_uint4(f1[0], f1[1], f1[2], f1[3]); xin[i].t = make_uint2(ft[0], ft[1]);
-                if (ok) pm[i >> 1] |= (i & 1) ? 0xffff0000u : 0x0000ffffu;
+                if (ok) tfl |= 1u << i;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1108,11 +1117,11 @@ __global__ __launch_bounds__(QA_THREADS) void gma_qkv_agg_kernel(QaArgs a) {
         // this wave's 32 pixels of P3: tile row `wave`, column tile nt = pixels 16 nt + n; the lane's first output pixel (an offset in 16-channel records)
         // (byte offsets of its two pixel records inside a 16-channel plane; past the plane where the pixel is outside the image: such stores are dropped)
         const bool p3_row = y0 + wave < a.H;
-        const unsigned p3_cols = (p3_row && x0 + n < a.W ? 1u : 0u) | (p3_row && x0 + 16 + n < a.W ? 2u : 0u);
-        const int p3_off = ((b * a.H + y0 + wave) * a.W + x0 + n) * kSEG * 2 + (o_g16 >> 1);
+        tfl |= (p3_row && x0 + n < a.W ? 16u : 0u) | (p3_row && x0 + 16 + n < a.W ? 32u : 0u);
+        int p3_off = ((b * a.H + y0 + wave) * a.W + x0 + n) * kSEG * 2 + (o_g16 >> 1);
 
-        // P1: segment `seg` of the qkv GEMM for this lane's 4 pixels -> S (channel-planar; zero outside the image), or, for a pass-through segment, -> R
-        auto p1 = [&](int seg, bool to_r, int rbuf) {
+        // P1: segment `seg` of the qkv GEMM for this lane's 4 pixels -> S[sb] (channel-planar; zero outside the image)
+        auto p1 = [&](int seg, int sb) {
             const char* w = s_wq + seg * QA_WSEG;
             const uint4 a0 = *reinterpret_cast<const uint4*>(w + o_l16), a1 = *reinterpret_cast<const uint4*>(w + 1024 + o_l16);
             const uint2 at = *reinterpret_cast<const uint2*>(w + 2048 + (o_l16 >> 1));
@@ -1124,115 +1133,136 @@ __global__ __launch_bounds__(QA_THREADS) void gma_qkv_agg_kernel(QaArgs a) {
                 mma32(a0, n1[i].f[0], acc); mma32(a1, n1[i].f[1], acc); mma16(at, n1[i].t, acc);
                 v[i] = acc + bias;
             }
-            if (!to_r) {
-                if (qrc >= 0) {
+            if (qrc >= 0) {                                                   // halves of a bf16 pair that lie outside the image are zeroed: the convolutions' zero padding
+                const uint32_t pm0 = ((tfl & 1u) ? 0x0000ffffu : 0u) | ((tfl & 2u) ? 0xffff0000u : 0u), pm1 = ((tfl & 4u) ? 0x0000ffffu : 0u) | ((tfl & 8u) ? 0xffff0000u : 0u);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        *reinterpret_cast<uint2*>(lds + o_p1s + j * QT_SP) = make_uint2(qa_pk(v[0][j], v[1][j]) & pm[0], qa_pk(v[2][j], v[3][j]) & pm[1]);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (qrc >= 0 && ((qrc >> i) & 1)) *reinterpret_cast<uint2*>(lds + o_p1r + rbuf * QT_R + i * AG_PS) = qa_pack(v[i]);
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<uint2*>(lds + sb * QT_S + o_p1s + j * QT_SP) = make_uint2(qa_pk(v[0][j], v[1][j]) & pm0, qa_pk(v[2][j], v[3][j]) & pm1);
             }
+        };
+        // P2 of segment `seg`: S[sb] -> R[sb]; the pass-through group is a plain transposition (4 pixels of this wave's channel per lane)
+        uint4 T[7];
+        auto p2 = [&](int seg, int sb) {
+            const char* src = lds + sb * QT_S + o_p2s;
+            char* dst = lds + sb * QT_R + o_p2d;
+            const int g5 = seg % 5;
+            if (g5 == 3) qt_dw<7>(src, dst, T);
+            else if (g5 == 2) qt_dw<5>(src, dst, T);
+            else if (g5 != 0) qt_dw<3>(src, dst, T);
+            else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint2 c4 = *reinterpret_cast<const uint2*>(src - (o_g16 >> 1) + 3 * QT_SR + 8 + 32 * h);
+                    char* d = dst + 16 * h * AG_PS;
+                    *reinterpret_cast<uint16_t*>(d) = (uint16_t)(c4.x & 0xffffu);
+                    *reinterpret_cast<uint16_t*>(d + AG_PS) = (uint16_t)(c4.x >> 16);
+                    *reinterpret_cast<uint16_t*>(d + 2 * AG_PS) = (uint16_t)(c4.y & 0xffffu);
+                    *reinterpret_cast<uint16_t*>(d + 3 * AG_PS) = (uint16_t)(c4.y >> 16);
+                }
+            }
+        };
+        // the Toeplitz fragments of segment `seg` (none for a pass-through segment)
+        auto tload = [&](int seg) {
+            const int which = seg / 5, g5 = seg - 5 * which;
+            if (g5 == 4) qt_load(r_toep, QT_TAB_LOC + which * 3 * 16 * 1024, 3, o_l16 + wave * 1024, T);
+            else if (g5 != 0) qt_load(r_toep, g5 == 3 ? QT_TAB_K7 : g5 == 2 ? QT_TAB_K5 : QT_TAB_K3, 2 * g5 + 1, o_l16 + wave * 1024, T);
         };
         // segment order: the local branch's three segments first (its accumulators are then dead), then q, k, v
         auto seg_at = [](int k) { return k < 3 ? 5 * k + 4 : (k - 3) + (k - 3) / 4; };
 
-        uint4 T[7];
-        qt_load(r_toep, QT_TAB_LOC, 3, o_l16 + wave * 1024, T);
-        p1(seg_at(0), false, 0);
+        // P3 of segment `seg` <- R[rb]: point-wise (identity for the pass-through group) -> BatchNorm -> Hardswish -> qkvp (+ k's per-channel maximum)
+        auto p3 = [&](int seg, int rb) {
+            const int which = seg / 5, g5 = seg - 5 * which;
+            const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(a.qkvp + (size_t)(4 * which + g5) * a.plane, 0, (int)(a.plane * 2), 0x00020000);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_bn) + 64 * g5 + o_g16);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_bn) + 256 + 64 * g5 + o_g16);
+            const uint2 apw = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_pw) + (g5 > 0 ? g5 - 1 : 0) * 512 + (o_l16 >> 1));
+            const bool want_max = which == 1 && a.kmax != nullptr;
+            f32x4 vmax = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const uint2 in = *reinterpret_cast<const uint2*>(lds + o_p3 + rb * QT_R + 16 * nt * AG_PS);
+                f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (g5 != 0) mma16(apw, in, d);
+                else d = up_tail(in);
+                f32x4 v = d * sc + sh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
+                if ((tfl >> (4 + nt)) & 1u) {
+                    const uint2 pkd = qa_pack(v);
+                    __builtin_amdgcn_raw_buffer_store_b64(qt_u32x2{pkd.x, pkd.y}, r_out, p3_off + 16 * nt * kSEG * 2, 0, 0);
+                    if (want_max) {
+                        const f32x4 rr = up_tail(pkd);                         // the stored (bf16) values are what rc_gma_kv sees
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vmax[e] = fmaxf(vmax[e], rr[e]);
+                    }
+                }
+            }
+            if (want_max) {                                                   // rows of 16 lanes share a channel quad: row maximum -> LDS
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vmax[e] = row_max16(vmax[e]);
+                if (n == 0) *reinterpret_cast<float4*>(reinterpret_cast<char*>(s_red) + (g5 * QA_WAVES + wave) * 64 + o_g16) = make_float4(vmax[0], vmax[1], vmax[2], vmax[3]);
+            }
+        };
+
+        // Software pipeline, ONE barrier per segment: interval k = { P2(k): S[k & 1] -> R[k & 1] | P1(k + 1) -> S[(k + 1) & 1], its fragments' loads | P3(k - 1) <- R[(k - 1) & 1] }.
+        // The three are independent inside an interval, and the waves of a SIMD (w, w + 4, w + 8, w + 12) take them in two different orders: while two of
+        // them run the LDS / MFMA-bound P2 the other two run the VALU-bound P3 (in one order for all, the SIMD's units took turns: 6.6 k cycles an interval)
+        const bool p3_first = (wave & 4) != 0;
+        tload(seg_at(0));
+        p1(seg_at(0), 0);
         __syncthreads();
-        {   // ---- k = 0..2: local branch, dw 3x3 of q4 / k4 / v4 -> 48 -> 16 (accumulated over the three) -> LayerNorm(16) -> Hardswish
+        {   // ---- k = 0..3: the local branch, dw 3x3 of q4 / k4 / v4 -> 48 -> 16 (accumulated over the three) -> LayerNorm(16) -> Hardswish
             f32x4 dl[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 1
-            for (int which = 0; which < 3; ++which) {
-                QT_KEEP();
-                const int rb = (which & 1) * QT_R;
-                qt_dw<3>(lds + o_p2s, lds + o_p2d + rb, T);
-                __syncthreads();
-                // P1 of the next segment first (its accumulators and the Toeplitz fragments are then never live together), the fragments' loads next, P3 under them
-                p1(seg_at(which + 1), which == 2, (which + 1) & 1);
-                qt_load(r_toep, which < 2 ? QT_TAB_LOC + (which + 1) * 3 * 16 * 1024 : QT_TAB_K3, 3, o_l16 + wave * 1024, T);   // k = 3 is q's pass-through segment, k = 4 its 3 x 3 group
-                const uint2 apw = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_pw) + (3 + which) * 512 + (o_l16 >> 1));
+            for (int k = 0; k < 4; ++k) {
+                QT_KEEP(); asm volatile("" : "+v"(tfl), "+v"(p3_off));
+                p2(seg_at(k), k & 1);
+                p1(seg_at(k + 1), (k + 1) & 1);
+                tload(seg_at(k + 1));
+                if (k >= 1) {
+                    const uint2 apw = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_pw) + (3 + k - 1) * 512 + (o_l16 >> 1));
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) mma16(apw, *reinterpret_cast<const uint2*>(lds + o_p3 + rb + 16 * nt * AG_PS), dl[nt]);
+                    for (int nt = 0; nt < 2; ++nt) mma16(apw, *reinterpret_cast<const uint2*>(lds + o_p3 + ((k - 1) & 1) * QT_R + 16 * nt * AG_PS), dl[nt]);
+                }
                 __syncthreads();
             }
             const f32x4 lg = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_bn) + 512 + o_g16), lb = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_bn) + 576 + o_g16);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const f32x4 tt = dl[nt] + 0.f;
-                float s = (tt[0] + tt[1]) + (tt[2] + tt[3]);
-                s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+                const float s = sum_lane_groups((tt[0] + tt[1]) + (tt[2] + tt[3]));
                 const float mean = s / 16.f;
                 const f32x4 dd = tt - mean;
                 const f32x4 d2 = dd * dd;
-                float var = (d2[0] + d2[1]) + (d2[2] + d2[3]);
-                var += __shfl_xor(var, 16); var += __shfl_xor(var, 32);
+                const float var = sum_lane_groups((d2[0] + d2[1]) + (d2[2] + d2[3]));
                 const float rstd = 1.f / sqrtf(var / 16.f + 1e-5f);
                 f32x4 v = dd * rstd * lg + lb;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
                 const uint2 pkd = qa_pack(v);
-                __builtin_amdgcn_raw_buffer_store_b64(qt_u32x2{pkd.x, pkd.y}, r_loc, ((p3_cols >> nt) & 1u) ? p3_off + 16 * nt * kSEG * 2 : (int)0x80000000, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(qt_u32x2{pkd.x, pkd.y}, r_loc, ((tfl >> (4 + nt)) & 1u) ? p3_off + 16 * nt * kSEG * 2 : (int)0x80000000, 0, 0);
             }
         }
 #pragma unroll 1
-        for (int k = 3; k < 15; ++k) {   // ---- the four groups of q, k, v
-            QT_KEEP();
-            const int rb = (k & 1) * QT_R;
-            const int seg = seg_at(k), nseg = seg_at(k + 1);
-            const int which = seg / 5, g5 = seg - 5 * which, ng5 = nseg % 5;
-            if (g5 != 0) {
-                if (g5 == 3) qt_dw<7>(lds + o_p2s, lds + o_p2d + rb, T);
-                else if (g5 == 2) qt_dw<5>(lds + o_p2s, lds + o_p2d + rb, T);
-                else qt_dw<3>(lds + o_p2s, lds + o_p2d + rb, T);
-                __syncthreads();
+        for (int k = 4; k < 16; ++k) {   // ---- the four groups of q, k, v
+            QT_KEEP(); asm volatile("" : "+v"(tfl), "+v"(p3_off));
+            if (p3_first) p3(seg_at(k - 1), (k - 1) & 1);
+            if (k < 15) {
+                p2(seg_at(k), k & 1);
+                if (k + 1 < 15) {
+                    p1(seg_at(k + 1), (k + 1) & 1);
+                    tload(seg_at(k + 1));
+                }
             }
-            if (k + 1 < 15) {                                                 // P1 of the next segment, then its Toeplitz fragments: in flight during P3
-                p1(nseg, ng5 == 0, (k + 1) & 1);
-                if (ng5 != 0) qt_load(r_toep, ng5 == 3 ? QT_TAB_K7 : ng5 == 2 ? QT_TAB_K5 : QT_TAB_K3, 2 * ng5 + 1, o_l16 + wave * 1024, T);
-            }
-            {   // P3: point-wise (identity for the pass-through group) -> BatchNorm -> Hardswish -> qkvp
-                const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(a.qkvp + (size_t)(4 * which + g5) * a.plane, 0, (int)(a.plane * 2), 0x00020000);
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_bn) + 64 * g5 + o_g16);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_bn) + 256 + 64 * g5 + o_g16);
-                const uint2 apw = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_pw) + (g5 > 0 ? g5 - 1 : 0) * 512 + (o_l16 >> 1));
-                const bool want_max = which == 1 && a.kmax != nullptr;
-                f32x4 vmax = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+            if (!p3_first) p3(seg_at(k - 1), (k - 1) & 1);
+            if (k == 12 && a.kmax != nullptr && wave == 0) {                  // all four k segments' maxima are in LDS (the last one, segment 8 = P3 of interval 11, a barrier ago)
+                const int ch = o_l16 >> 4;                                    // = lane (re-derived here: as `tid` the address was hoisted out of the tile loop and spilled)
+                const float* p = s_red + (ch >> 4) * QA_WAVES * 16 + (ch & 15);
+                float m = p[0];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const uint2 in = *reinterpret_cast<const uint2*>(lds + o_p3 + rb + 16 * nt * AG_PS);
-                    f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (g5 != 0) mma16(apw, in, d);
-                    else d = up_tail(in);
-                    f32x4 v = d * sc + sh;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = hswish(v[e]);
-                    if ((p3_cols >> nt) & 1u) {
-                        const uint2 pkd = qa_pack(v);
-                        __builtin_amdgcn_raw_buffer_store_b64(qt_u32x2{pkd.x, pkd.y}, r_out, p3_off + 16 * nt * kSEG * 2, 0, 0);
-                        if (want_max) {
-                            const f32x4 rr = up_tail(pkd);                     // the stored (bf16) values are what rc_gma_kv sees
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) vmax[e] = fmaxf(vmax[e], rr[e]);
-                        }
-                    }
-                }
-                if (want_max) {                                               // rows of 16 lanes share a channel quad: row maximum -> LDS
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) vmax[e] = row_max16(vmax[e]);
-                    if (n == 0) *reinterpret_cast<float4*>(reinterpret_cast<char*>(s_red) + (g5 * QA_WAVES + wave) * 64 + o_g16) = make_float4(vmax[0], vmax[1], vmax[2], vmax[3]);
-                }
-                if (seg == 10 && a.kmax != nullptr && wave == 0) {            // all four k segments are done (a barrier ago): one atomic per channel and tile
-                    const int ch = o_l16 >> 4;                                // = lane (re-derived here: as `tid` the address was hoisted out of the tile loop and spilled)
-                    const float* p = s_red + (ch >> 4) * QA_WAVES * 16 + (ch & 15);
-                    float m = p[0];
-#pragma unroll
-                    for (int w = 1; w < QA_WAVES; ++w) m = fmaxf(m, p[16 * w]);
-                    atomic_max_f32(a.kmax + (size_t)b * 64 + ch, m);
-                }
+                for (int w = 1; w < QA_WAVES; ++w) m = fmaxf(m, p[16 * w]);
+                atomic_max_f32(a.kmax + (size_t)b * 64 + ch, m);
             }
             __syncthreads();
         }

@@ -39,3 +39,4 @@ def timeit(fn, n=5):
 x = torch.randn(8, 544, 960, 80, device="cuda").to(torch.bfloat16)
 with torch.no_grad():
     print(f"front: {timeit(lambda: blk.att.aggregator._run_front(x, blk.norm1, blk.att.qkv)):8.1f} us")
+
