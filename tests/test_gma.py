@@ -255,6 +255,23 @@ def test_qkv_aggregate_in_one_launch_equals_the_two_launch_path(hip, b, hw, qkv_
 
 
 @pytest.mark.gpu
+def test_qkv_aggregate_is_bitwise_stable_under_load(hip):
+    """rc_gma_qkv_aggregate keeps MFMA operands in registers that later loads recycle (Toeplitz fragments one segment ahead, A fragments per segment) and
+    runs 16 waves a block with one barrier per segment: 24 launches on 4 x 272 x 480 tokens (510 tiles, two per block), every output compared with the
+    first launch's.  (A sibling kernel written the same round, gma_in + ConvPosEnc in one launch, failed exactly this check -- single products of its
+    1x1 convolution came out differently from run to run -- and was not shipped: profiles/r06_gma_stages.md.)"""
+    torch.manual_seed(3)
+    blk = M.GMA_Block(80, 8).to("cuda", torch.bfloat16).eval()
+    x = torch.randn(4, 272, 480, 80, device="cuda").to(torch.bfloat16)
+    with torch.no_grad():
+        ref = blk.att.aggregator._run_front(x, blk.norm1, blk.att.qkv)
+        for i in range(24):
+            out = blk.att.aggregator._run_front(x, blk.norm1, blk.att.qkv)
+            for name, r_, o_ in zip(("qkvp", "loc", "kmax"), ref, out):
+                assert torch.equal(r_, o_), (i, name, int((r_.float() != o_.float()).sum()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("c,hw", [(80, (37, 70)), (80, (16, 32)), (48, (130, 65)), (160, (9, 200))])
 @pytest.mark.parametrize("identity", [True, False])
 def test_depthwise3x3_segment_kernel_equals_the_general_one(hip, c, hw, identity):
