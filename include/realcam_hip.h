@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 13
+#define RC_ABI_VERSION 14
 
 typedef enum rc_status {
     RC_OK = 0,
@@ -49,9 +49,16 @@ typedef enum rc_out_mode {
                                   out[b][2y+i][2x+j][c] <- conv channel 4c+2i+j; out is NHWC (2H,2W,cout/4) */
     RC_OUT_NCHW = 2,           /* planar out[b][cout][y][x], cropped to (out_h,out_w); the network's
                                   final tensor (reference forward returns NCHW)                   */
-    RC_OUT_PIXEL_SHUFFLE2_NCHW = 3 /* nn.PixelShuffle(2) + planar store: out[b][c][2y+i][2x+j] <- conv channel 4c+2i+j, cropped to
+    RC_OUT_PIXEL_SHUFFLE2_NCHW = 3, /* nn.PixelShuffle(2) + planar store: out[b][c][2y+i][2x+j] <- conv channel 4c+2i+j, cropped to
                                   (out_h,out_w) <= (2 height, 2 width); out_dtype fp32 or bf16.  The folded tail's store
                                   (rc_tail_fold_weights)                                          */
+    RC_OUT_NHWC_DWT = 4        /* (ABI 14) the convolution followed by networks.DWTForward (models/networks.py:224-235, the `conv -> DWT`
+                                  end of LiteISP's down1, models/LiteISP.py:1950-1953) in ONE launch: out is NHWC (height/2, width/2, 4 cout),
+                                  out[b][y][x][4c+k] = sum_ij haar[k][i][j] * bf16(conv[b][2y+i][2x+j][c]) with the reference's frozen taps
+                                  haar = .5 * {++++, ++--, +-+-, +--+}; the full-resolution map is never written.  Bit-identical to rc_conv2d
+                                  (RC_OUT_NHWC) + rc_dwt_forward with those taps.  bf16, ksize 3, one Cin chunk and one cout tile of 32 or
+                                  48 channels (the layers of the wave-autonomous kernel), even height / width, act NONE / RELU / LEAKY,
+                                  no residual / film / mul_plus1 / gate / chan_sums: anything else is RC_ERR_UNSUPPORTED */
 } rc_out_mode;
 
 /* ---- library -------------------------------------------------------------------------------- */

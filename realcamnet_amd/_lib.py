@@ -16,8 +16,8 @@ HEADER = PKG.parent / "include" / "realcam_hip.h"
 
 RC_F32, RC_BF16, RC_U16 = 0, 1, 2
 RC_ACT_NONE, RC_ACT_RELU, RC_ACT_LEAKY, RC_ACT_GELU, RC_ACT_RELU_POST = 0, 1, 2, 3, 4
-RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW = 0, 1, 2, 3
-ABI_VERSION = 13
+RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_NCHW, RC_OUT_PIXEL_SHUFFLE2_NCHW, RC_OUT_NHWC_DWT = 0, 1, 2, 3, 4
+ABI_VERSION = 14
 
 
 class ConvDesc(C.Structure):

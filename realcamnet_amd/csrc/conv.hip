@@ -369,11 +369,20 @@ int rc_prof_collect_rows(rc_prof_row* rows, int max_rows, int* n_rows) {
 // Validation + launch arguments of one rc_conv2d call; shared with rc_conv_sum_slots (which asks the launcher what it WOULD do with them).
 static int conv_build_args(const rc_conv_desc* d, ConvPlan& p, ConvArgs& a, size_t& es_out) {
     RC_REQUIRE(d != nullptr, "rc_conv2d: null desc");
-    RC_REQUIRE(make_plan(d->cin, d->cout, d->ksize, d->dtype, d->out_mode, &p, d->cout_tile), "rc_conv2d: unsupported cin/cout/ksize/dtype/cout_tile");
+    const bool dwt = d->out_mode == RC_OUT_NHWC_DWT;      // conv -> Haar DWT: packed, planned and validated as the RC_OUT_NHWC layer it replaces
+    RC_REQUIRE(make_plan(d->cin, d->cout, d->ksize, d->dtype, dwt ? (int)RC_OUT_NHWC : d->out_mode, &p, d->cout_tile), "rc_conv2d: unsupported cin/cout/ksize/dtype/cout_tile");
     RC_REQUIRE(d->batch >= 1 && d->height >= 1 && d->width >= 1, "rc_conv2d: empty tensor");
     RC_REQUIRE(d->batch <= 65535, "rc_conv2d: batch > 65535");
     RC_REQUIRE(d->in0 && d->wpacked && d->out, "rc_conv2d: null in0/wpacked/out");
-    RC_REQUIRE(d->out_mode >= RC_OUT_NHWC && d->out_mode <= RC_OUT_PIXEL_SHUFFLE2_NCHW, "rc_conv2d: bad out_mode");
+    RC_REQUIRE(d->out_mode >= RC_OUT_NHWC && d->out_mode <= RC_OUT_NHWC_DWT, "rc_conv2d: bad out_mode");
+    if (dwt) {
+        RC_REQUIRE(d->height % 2 == 0 && d->width % 2 == 0, "rc_conv2d: RC_OUT_NHWC_DWT needs even height and width");
+        RC_REQUIRE(d->out_dtype == d->dtype && reinterpret_cast<uintptr_t>(d->out) % 16 == 0, "rc_conv2d: RC_OUT_NHWC_DWT: out_dtype must equal dtype, out 16-byte aligned");
+        RC_REQUIRE(!d->residual && !d->mul_plus1 && !d->film_scale && !d->out_scale && !d->chan_sums && !d->in_gate && !d->in1 && !d->in_store && !d->src_h && !d->src_w && !d->cout_tile,
+                   "rc_conv2d: RC_OUT_NHWC_DWT excludes residual / mul_plus1 / film / out_scale / chan_sums / gated input / src_h / cout_tile");
+        if (d->dtype != RC_BF16 || d->ksize != 3 || p.m32 || !(d->act == RC_ACT_NONE || d->act == RC_ACT_RELU || d->act == RC_ACT_LEAKY))
+            return fail(RC_ERR_UNSUPPORTED, "rc_conv2d: RC_OUT_NHWC_DWT is a bf16 3x3 form with act NONE / RELU / LEAKY");
+    }
     RC_REQUIRE(d->act >= RC_ACT_NONE && d->act <= RC_ACT_RELU_POST, "rc_conv2d: bad act");
     RC_REQUIRE(d->act != RC_ACT_RELU_POST || (d->residual != nullptr && d->mul_plus1 == nullptr && d->film_scale == nullptr && d->chan_sums == nullptr),
                "rc_conv2d: RC_ACT_RELU_POST is relu(conv + residual): needs residual, excludes film / mul_plus1 / chan_sums");
@@ -388,7 +397,9 @@ static int conv_build_args(const rc_conv_desc* d, ConvPlan& p, ConvArgs& a, size
         RC_REQUIRE(reinterpret_cast<uintptr_t>(d->out_scale) % 4 == 0, "rc_conv2d: out_scale must be 4-byte aligned");
     }
     const size_t es = dtype_size(d->dtype);
-    if (d->out_mode == RC_OUT_NHWC) {
+    if (dwt) {
+        // validated above; the store is whole 16-byte pieces of (H / 2, W / 2, 4 cout) pixel records
+    } else if (d->out_mode == RC_OUT_NHWC) {
         RC_REQUIRE(d->out_dtype == d->dtype, "rc_conv2d: out_dtype must equal dtype for RC_OUT_NHWC");
         RC_REQUIRE(!full_tiles || (d->cout * es) % 8 == 0, "rc_conv2d: cout*elem_size must be a multiple of 8 bytes for RC_OUT_NHWC");
         RC_REQUIRE(reinterpret_cast<uintptr_t>(d->out) % 16 == 0, "rc_conv2d: out must be 16-byte aligned");

@@ -965,6 +965,73 @@ struct ConvDev {
         }
     }
 
+    // ---- kernel 6, RC_OUT_NHWC_DWT: conv [+ ReLU / LeakyReLU] -> networks.DWTForward (models/networks.py:224-235) without the full-resolution map ------
+    // The wave's strip (wave `tid >> 6` of an 8 x 32 tile: rows y0 + 2 w, + 1, columns x0 .. x0 + 31, one cout tile) is 16 whole 2 x 2 blocks per channel:
+    // ONE row of 16 output pixels with 4 COUT_TILE channels.  The values are rounded to bf16 exactly as the NHWC store rounds them and parked, pixel-major, in
+    // the wave's own LDS strip `st` (its halo strip, dead once the MFMA loop is over; the same wave writes and reads: the LDS queue is in order, no barrier);
+    // lane (n, q) then reads the 2 x 2 block of output pixel n for its channel group q (the NV channels it computed) and forms, per channel, in the order of
+    // dwt_forward_kernel's fma chain with the reference's frozen taps haar[k] = .5 {++++, ++--, +-+-, +--+} over (a b / c d):
+    //     ((.5 a +- .5 b) +- .5 c) +- .5 d         (every product exact, so fma(in, tap, s) == s + in * tap)
+    // as packed fp32 adds over channel pairs, and stores channels 4 (q NV) .. + 4 NV of the output pixel: 8 NV contiguous bytes.  Bit-identical to the two launches.
+    template <int F>
+    __device__ static __forceinline__ void epilogue_dwt(const ConvArgs& a, int b, int y0, int x0, int tid, f32x4 (&acc)[4][NT], char* st) {
+        static_assert(ES == 2 && NV % 4 == 0 && (F & ~(EP_RELU | EP_LEAKY)) == 0, "bf16, plain / ReLU / LeakyReLU");
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
+        constexpr int REC = Cfg::COUT_TILE * 2 + 8, ROW = kTW * REC;      // bytes of a parked pixel (+ 8: the 2 x 2 reads of 16 lanes at a 2-pixel pitch spread over the banks) / strip row
+        const float inf = __builtin_inff();
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            float v[NV];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[pt][nt][r];
+            if constexpr ((F & EP_RELU) != 0) {
+#pragma unroll
+                for (int e = 0; e < NV; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.f, inf);
+            }
+            if constexpr ((F & EP_LEAKY) != 0) {
+#pragma unroll
+                for (int e = 0; e < NV; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], v[e] * a.act_slope, inf);
+            }
+            char* dst = st + (pt >> 1) * ROW + (16 * (pt & 1) + n) * REC + q * (NV * 2);
+#pragma unroll
+            for (int i = 0; i < NV / 4; ++i)
+                *reinterpret_cast<uint2*>(dst + 8 * i) = make_uint2(pack_bf16x2(v[4 * i], v[4 * i + 1]), pack_bf16x2(v[4 * i + 2], v[4 * i + 3]));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");             // other lanes' writes are read back below: keep the compiler from moving the
+        __builtin_amdgcn_wave_barrier();                                   // reads above them (the LDS queue itself is in order)
+        f32x2 in[4][NV / 2];                                               // [2 i + j][channel pair], already times .5
+        const char* src = st + (2 * n) * REC + q * (NV * 2);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < NV / 4; ++i) {
+                const uint2 w = *reinterpret_cast<const uint2*>(src + (t >> 1) * ROW + (t & 1) * REC + 8 * i);
+                in[t][2 * i] = f32x2{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u)} * 0.5f;
+                in[t][2 * i + 1] = f32x2{__uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)} * 0.5f;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");             // ... and the next strip's commit (same buffer) below these reads
+        __builtin_amdgcn_wave_barrier();
+        unsigned o[2 * NV];                                                // channels 4 e + k of the output pixel, e = q NV + (0 .. NV - 1): bf16 pairs (k 0 1), (k 2 3)
+#pragma unroll
+        for (int p = 0; p < NV / 2; ++p) {
+            const f32x2 sab = in[0][p] + in[1][p], dab = in[0][p] - in[1][p];
+            const f32x2 k0 = (sab + in[2][p]) + in[3][p], k1 = (sab - in[2][p]) - in[3][p];
+            const f32x2 k2 = (dab + in[2][p]) - in[3][p], k3 = (dab - in[2][p]) + in[3][p];
+            o[4 * p] = pack_bf16x2(k0.x, k1.x); o[4 * p + 1] = pack_bf16x2(k2.x, k3.x);
+            o[4 * p + 2] = pack_bf16x2(k0.y, k1.y); o[4 * p + 3] = pack_bf16x2(k2.y, k3.y);
+        }
+        const int Hh = a.H >> 1, Wh = a.W >> 1, oy = (y0 >> 1) + wave, ox = (x0 >> 1) + n;
+        const size_t img_out = (size_t)a.H * a.W * a.cout;                  // (H / 2) (W / 2) (4 cout): the same bytes per image
+        const __amdgpu_buffer_rsrc_t r_out = make_rsrc(static_cast<T*>(a.out) + (size_t)b * img_out, (unsigned)(img_out * ES));
+        const int oo = (oy < Hh && ox < Wh && !(a.dbg_flags & 1)) ? ((oy * Wh + ox) * (4 * a.cout) + 4 * q * NV) * ES : kOOB;
+#pragma unroll
+        for (int i = 0; i < NV / 2; ++i)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]}, r_out, oo, 16 * i, 0);
+    }
+
     __device__ static __forceinline__ void epilogue_generic(const ConvArgs& a, int b, int y0, int x0, int sp, int ct, int tid,
                                                             f32x4 (&acc)[4][NT]) {
         const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
@@ -2291,7 +2358,7 @@ __global__ __launch_bounds__(kAutoThreads) void conv_mfma_auto_kernel(const Conv
         // MODE 0 only: the eight waves meet once per region, so the rows two neighbouring strips share are fetched within one region's time of each other and
         // the second fetch hits L2 (see the header: 1.54x -> 1.02x of the input from beyond L2, same time).  A wave that has run out of strips has ended and is
         // not waited for; a wave that skipped a region (bottom band) is one region ahead from then on -- ordering only, never correctness.
-        if constexpr (MODE == 0) __builtin_amdgcn_s_barrier();
+        if constexpr (MODE == 0) { if (!(a.dbg_flags & 32)) __builtin_amdgcn_s_barrier(); }   // conv_flags 32: A/B, free-running waves
         // ---- commit: the strip's units, registers -> this wave's LDS strip (the same wave reads them back: program order, no barrier)
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
@@ -2333,7 +2400,13 @@ __global__ __launch_bounds__(kAutoThreads) void conv_mfma_auto_kernel(const Conv
         } else if constexpr (MODE == 2) {
             D8::epilogue_res_pre(a, cb, y0, x0, 0, ftid, acc, rpre, gated_out ? s_gate + cb * a.cout : nullptr);
         } else {
-            D8::template epilogue<true>(a, cb, y0, x0, sp, 0, ftid, acc);
+            if (a.out_mode == RC_OUT_NHWC_DWT) {                      // uniform: conv -> Haar DWT, the strip's output staged through its own (now dead) halo strip
+                if (a.ep_key == D8::EP_RELU) D8::template epilogue_dwt<D8::EP_RELU>(a, cb, y0, x0, ftid, acc, s_my);
+                else if (a.ep_key == D8::EP_LEAKY) D8::template epilogue_dwt<D8::EP_LEAKY>(a, cb, y0, x0, ftid, acc, s_my);
+                else D8::template epilogue_dwt<0>(a, cb, y0, x0, ftid, acc, s_my);
+            } else {
+                D8::template epilogue<true>(a, cb, y0, x0, sp, 0, ftid, acc);
+            }
         }
         cu = nu; cb = nb; cty8 = nty8; ctx = ntx;
     }
@@ -2584,6 +2657,29 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
         if (compact_slots > 0 && a.sum_slots == compact_slots) { compact = 1; return RC_OK; }
         return fail(RC_ERR_INVALID, "rc_conv2d: chan_sums_slots matches neither layout of the kernel this launch takes (ask rc_conv_sum_slots)");
     };
+    if (a.out_mode == RC_OUT_NHWC_DWT) {
+        // conv -> networks.DWTForward in one launch: a form of kernel 6 (mode 0) only, whatever the `persist` / `persist_auto` knobs say
+        if constexpr (!GATED && FAST && auto_eligible<Cfg>()) {
+            using DD = ConvDev<Cfg>;
+            static_assert(StripCfg<Cfg>::IN_BYTES >= 2 * kTW * (Cfg::COUT_TILE * 2 + 8), "the strip's output fits its own halo strip");
+            if ((a.ep_key == 0 || a.ep_key == DD::EP_RELU || a.ep_key == DD::EP_LEAKY) && a.n_chunks == 1 && a.n_ct == 1 && a.cout == Cfg::COUT_TILE && a.cin_vec_ok &&
+                a.cin_chunk_ok && n_tiles < (1 << 24)) {
+                if (report(0, legacy_slots)) return RC_OK;
+                constexpr int A_LDS = auto_lds_bytes<Cfg>();
+                const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch;
+                int grid = a.num_cus;
+                if (grid > n_items) grid = n_items;
+                grid = (grid + 7) / 8 * 8;
+                static PerDeviceFlag attr_set;
+                if (!attr_set.test_and_set())
+                    RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_auto_kernel<Cfg, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
+                hipLaunchKernelGGL((conv_mfma_auto_kernel<Cfg, 0>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, a);
+                RC_HIP_CHECK(hipGetLastError());
+                return RC_OK;
+            }
+        }
+        return fail(RC_ERR_UNSUPPORTED, "rc_conv2d: RC_OUT_NHWC_DWT needs a bf16 3x3 layer of one Cin chunk and one 32- or 48-wide cout tile (cin == cout == 32 or 48), 16-byte aligned operands");
+    }
     constexpr int WS_LDS = ws_lds_bytes<Cfg>();
     if constexpr (WS_LDS <= 150 * 1024) {              // one 8-wave producer/consumer block per CU
         // persist_ok: 1 = automatic (producer/consumer form for the register-starved variants: gated input or 80-wide

@@ -89,6 +89,10 @@ class Sequential(nn.Sequential):
                     else:                             # narrow tails (the codec's subpel_conv3x3(2N, 3, 2)): separate shuffle
                         shuffle_after = True
                     j += 1
+                if (j < n and isinstance(mods[j], DWTForward) and "out_mode" not in kw and not shuffle_after and
+                        ops.conv_dwt_ok(a, m, mods[j], kw.get("act"), kw.get("slope", 0.0))):
+                    kw["out_mode"] = ops.RC_OUT_NHWC_DWT          # conv [+ act] -> Haar DWT in one launch: the full-resolution map is never written
+                    j += 1
                 if j == n and residual is not None and kw.get("out_mode", RC_OUT_NHWC) == RC_OUT_NHWC and not shuffle_after:
                     kw["residual"], residual = residual, None
                 a = m._nhwc(a, **kw)

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from . import torch_ops as _T  # noqa: F401  (registers torch.ops.realcam.*)
-from ._lib import (RC_ACT_GELU, RC_ACT_LEAKY, RC_ACT_NONE, RC_ACT_RELU, RC_ACT_RELU_POST, RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC,
+from ._lib import (RC_ACT_GELU, RC_ACT_LEAKY, RC_ACT_NONE, RC_ACT_RELU, RC_ACT_RELU_POST, RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC, RC_OUT_NHWC_DWT,
                    RC_OUT_PIXEL_SHUFFLE2, RC_OUT_PIXEL_SHUFFLE2_NCHW, ConvDesc, ConvPairDesc, check)
 
 _DT = {torch.float32: RC_F32, torch.bfloat16: RC_BF16}
@@ -573,7 +573,7 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
         pc = packed_wino(mod, x.dtype)
     else:
         ct = small_map_cout_tile(x, mod, out_mode)
-        pc = packed_conv(mod, x.dtype, out_mode, ct)
+        pc = packed_conv(mod, x.dtype, RC_OUT_NHWC if out_mode == RC_OUT_NHWC_DWT else out_mode, ct)      # conv -> DWT: the NHWC layer's packed weights
     if cin != pc.cin:
         raise ValueError(f"conv expects {pc.cin} input channels, got {cin}")
     if gate is not None:
@@ -608,6 +608,38 @@ def conv2d(x: torch.Tensor, mod, *, act: Optional[str] = None, slope: float = 0.
                                   out_dtype if planar else None, out_scale, ct, algo)
     extras = [t for t in (_opt(stored), _opt(sums)) if t is not None]
     return (out, *extras) if extras else out
+
+
+FUSE_DWT = os.environ.get("RC_FUSE_DWT", "1") != "0"   # conv [+ act] -> DWTForward as one launch (RC_OUT_NHWC_DWT) where the kernel has that form; 0: two launches (A/B, tests)
+_HAAR_TAPS = (0.5, 0.5, 0.5, 0.5, 0.5, 0.5, -0.5, -0.5, 0.5, -0.5, 0.5, -0.5, 0.5, -0.5, -0.5, 0.5)
+
+
+def conv_dwt_ok(x: torch.Tensor, conv, dwt, act: Optional[str] = None, slope: float = 0.0) -> bool:
+    """Can `conv [+ act] -> dwt` (networks.Conv2d, networks.DWTForward; upstream models/LiteISP.py:1950-1953 `down1`) run as ONE rc_conv2d launch with
+    RC_OUT_NHWC_DWT?  The kernel form exists for the bf16 3x3 layers of the wave-autonomous kernel (cin == cout == 32 or 48) and computes with the
+    reference's frozen Haar taps, so the module's taps must BE those (checked once per write of the tap tensor)."""
+    if not FUSE_DWT or x.dtype != torch.bfloat16 or x.dim() != 4 or conv.weight.dim() != 4:
+        return False
+    cout, cin, kh, kw = conv.weight.shape
+    if not (kh == kw == 3 and cin == cout and cin in (32, 48) and x.shape[3] == cin and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0):
+        return False
+    if tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (1, 1) or tuple(conv.dilation) != (1, 1) or conv.groups != 1:
+        return False
+    if act not in (None, "relu", "leaky") or (act == "leaky" and not (0.0 <= slope <= 1.0)):
+        return False
+    w = getattr(dwt, "weight", None)
+    if w is None or tuple(w.shape) != (4 * cout, 1, 2, 2):
+        return False
+    from torch._subclasses.fake_tensor import FakeTensor
+    if isinstance(w, FakeTensor):                 # shape tracing: values are not there to look at; a DWTForward is built with these taps and frozen
+        return True
+    c = _cache(dwt)
+    hit = c.get("haar_ok")
+    if hit is None or hit[0] != _key(w):
+        want = torch.tensor(_HAAR_TAPS, dtype=torch.float32).reshape(4, 1, 2, 2).repeat(cout, 1, 1, 1)
+        hit = (_key(w), bool(torch.equal(w.detach().float().cpu(), want)))
+        c["haar_ok"] = hit
+    return hit[1]
 
 
 FUSE_SHUFFLE_STORE = True    # narrow subpel tails (conv -> PixelShuffle(2), 3 output channels: the codecs' x_hat): shuffle + NCHW in the conv's store

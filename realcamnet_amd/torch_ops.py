@@ -21,7 +21,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_PIXEL_SHUFFLE2_NCHW, ConvDesc, ConvPairDesc, check
+from ._lib import RC_BF16, RC_F32, RC_OUT_NCHW, RC_OUT_NHWC, RC_OUT_NHWC_DWT, RC_OUT_PIXEL_SHUFFLE2, RC_OUT_PIXEL_SHUFFLE2_NCHW, ConvDesc, ConvPairDesc, check
 
 _DT = {torch.float32: RC_F32, torch.bfloat16: RC_BF16}
 _LIB = torch.library.Library("realcam", "DEF")
@@ -180,6 +180,8 @@ def _conv_alloc(x, wpacked, bias, cout, ksize, act, slope, residual, mul_plus1, 
         out = x.new_empty((b, H, W, cout))
     elif out_mode == RC_OUT_PIXEL_SHUFFLE2:
         out = x.new_empty((b, 2 * H, 2 * W, cout // 4))
+    elif out_mode == RC_OUT_NHWC_DWT:                                  # conv -> Haar DWT in one launch: (H / 2, W / 2, 4 cout)
+        out = x.new_empty((b, H // 2, W // 2, 4 * cout))
     elif out_mode == RC_OUT_PIXEL_SHUFFLE2_NCHW:
         out = x.new_empty((b, cout // 4, crop_h if crop_h > 0 else 2 * H, crop_w if crop_w > 0 else 2 * W), dtype=out_dtype or x.dtype)
     else:

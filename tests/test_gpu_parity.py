@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
+import torch.utils._python_dispatch
 
 import liteisp_oracle as O
 import realcamnet_amd as M
@@ -202,6 +203,66 @@ def test_wave_autonomous_kernels_equal_the_kernels_they_replace(hip, c):
                     assert torch.allclose(outs[0][1].sum(1), outs[1][1].sum(1), rtol=1e-5, atol=1e-3), (c, B, H, W, name)
     finally:
         lib.rc_debug_set(b"persist_auto", 1)
+
+
+class _OpLog(torch.utils._python_dispatch.TorchDispatchMode):
+    """Names of the realcam:: ops dispatched inside the context."""
+
+    def __init__(self, log):
+        super().__init__()
+        self.log = log
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if name.startswith("realcam"):
+            self.log.append(name)
+        return func(*args, **(kwargs or {}))
+
+
+@pytest.mark.parametrize("c", [48, 32])
+def test_conv_then_haar_dwt_in_one_launch_equals_the_two_launches(hip, c):
+    """RC_OUT_NHWC_DWT (ABI 14): conv [+ ReLU / LeakyReLU] -> networks.DWTForward as ONE launch of the wave-autonomous kernel -- the strip's outputs are rounded to
+    bf16 as the NHWC store rounds them, parked in the wave's LDS strip and combined in dwt_forward_kernel's order with the reference's frozen taps
+    (models/networks.py:224-235) -- must equal rc_conv2d + rc_dwt_forward BIT FOR BIT: single-tile, ragged (even) sizes whose last strips hang over the image,
+    several images, and a map with interior strips; and the Sequential peephole (LiteISP `down1`: conv -> DWT, models/LiteISP.py:1950-1953) must take it."""
+    g = torch.Generator().manual_seed(11 * c)
+    conv = N.Conv2d(c, c, 3, 1, 1).to(DEV, torch.bfloat16).eval()
+    dwt = N.DWTForward(c).to(DEV, torch.bfloat16).eval()
+    assert ops.FUSE_DWT
+    for (B, H, W) in ((1, 8, 32), (2, 22, 70), (3, 40, 98), (5, 18, 34), (1, 130, 260), (1, 2, 2)):
+        x = torch.randn(B, H, W, c, generator=g).to(DEV, torch.bfloat16)
+        for kw in (dict(), dict(act="relu"), dict(act="leaky", slope=0.1)):
+            assert ops.conv_dwt_ok(x, conv, dwt, kw.get("act"), kw.get("slope", 0.0))
+            with torch.no_grad():
+                want = ops.dwt_forward(ops.conv2d(x, conv, **kw), dwt)
+                got = ops.conv2d(x, conv, out_mode=ops.RC_OUT_NHWC_DWT, **kw)
+            torch.cuda.synchronize()
+            assert got.shape == (B, H // 2, W // 2, 4 * c) and torch.equal(got, want), (c, B, H, W, kw)
+    # the executor: seq(conv, DWT) and seq(conv, ReLU, DWT) are one launch each; with the switch off, two -- the same bits
+    x = torch.randn(2, 24, 64, c, generator=g).to(DEV, torch.bfloat16)
+    for mods in ((conv, dwt), (conv, torch.nn.ReLU(), dwt)):
+        sq = N.Sequential(*mods)
+        outs = []
+        for on in (True, False):
+            ops.FUSE_DWT = on
+            log = []
+            try:
+                with _OpLog(log), torch.no_grad():
+                    outs.append(sq._nhwc(x))
+            finally:
+                ops.FUSE_DWT = True
+            assert sum(1 for n in log if "haar_dwt" in n) == (0 if on else 1) and sum(1 for n in log if "conv2d" in n) == 1, log
+        assert torch.equal(outs[0], outs[1])
+    # odd sizes and other layers have no such form: the peephole declines, the C ABI says so
+    assert not ops.conv_dwt_ok(torch.zeros(1, 9, 32, c, device=DEV, dtype=torch.bfloat16), conv, dwt)
+    assert not ops.conv_dwt_ok(torch.zeros(1, 8, 32, c, device=DEV), conv, dwt)
+    c64 = N.Conv2d(64, 64, 3, 1, 1).to(DEV, torch.bfloat16).eval()
+    with pytest.raises(RuntimeError, match="RC_OUT_NHWC_DWT"):
+        ops.conv2d(torch.zeros(1, 8, 32, 64, device=DEV, dtype=torch.bfloat16), c64, out_mode=ops.RC_OUT_NHWC_DWT)
+    bad = N.DWTForward(c).to(DEV, torch.bfloat16).eval()
+    with torch.no_grad():
+        bad.weight.mul_(2.0)
+    assert not ops.conv_dwt_ok(x, conv, bad)
 
 
 @pytest.mark.parametrize("cin,cout,shape", [(128, 128, (1, 135, 240)), (128, 128, (1, 68, 120)), (64, 128, (2, 40, 70)), (128, 256, (1, 33, 65)), (512, 128, (1, 17, 30))])

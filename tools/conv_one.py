@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One 3x3 layer launched N times (profiling target): conv_one.py cin cout H W B [n] [form]   (DT=bf16|f32; forms: relu, relu_sums, res, scale_res, none)"""
+"""One 3x3 layer launched N times (profiling target): conv_one.py cin cout H W B [n] [form]   (DT=bf16|f32; forms: relu, relu_sums, res, scale_res, none, dwt = conv -> Haar DWT in one launch, conv+dwt = the two launches)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
@@ -22,6 +22,11 @@ def timed(fn, n, warm=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+if form == "dwt": kw["out_mode"] = ops.RC_OUT_NHWC_DWT
 with torch.no_grad():
-    t = timed(lambda: ops.conv2d(x, c, **kw), n)
+    if form == "conv+dwt":
+        dwt = N.DWTForward(cout).to("cuda", dt).eval()
+        t = timed(lambda: ops.dwt_forward(ops.conv2d(x, c), dwt), n)
+    else:
+        t = timed(lambda: ops.conv2d(x, c, **kw), n)
 print(f"{cin}->{cout} {H}x{W} B={B} {form}: {t:.1f} us  lib={os.environ.get('RC_HIP_LIB', 'in-tree')}")
