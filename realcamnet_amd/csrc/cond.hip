@@ -251,6 +251,10 @@ __global__ __launch_bounds__(256) void color_block_kernel(const TI* __restrict__
     float* s_cnt = cb_pooled + (size_t)cin * CB_PX;
     const int npx = ho * wo;
     const int tiles = (npx + CB_PX - 1) / CB_PX;
+    // gridDim.y = cout slices: the late blocks of the prior are a handful of pixel tiles (8 x 8 outputs per image, 128 -> 128), and ONE block per tile left a thread
+    // 32 outputs x 128 serial multiply-adds on scalar weight loads (296 us for 8 blocks on 256 CUs); a slice re-pools its tile (cheap) and does cout / slices of them
+    const int per_slice = (cout + (int)gridDim.y - 1) / (int)gridDim.y, co_begin = (int)blockIdx.y * per_slice;
+    const int co_end = co_begin + per_slice < cout ? co_begin + per_slice : cout;
     const int b = blockIdx.x / tiles, p0 = (blockIdx.x % tiles) * CB_PX;
     const int tid = threadIdx.x;
     for (int i = tid; i < cin * CB_PX; i += 256) {
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256) void color_block_kernel(const TI* __restrict__
     const int px = tid & (CB_PX - 1), quarter = tid / CB_PX, p = p0 + px;
     if (p >= npx) return;
     const float cnt = s_cnt[px];
-    for (int co = quarter; co < cout; co += 256 / CB_PX) {
+    for (int co = co_begin + quarter; co < co_end; co += 256 / CB_PX) {
         const float* wr = wgt + (size_t)co * cin;        // uniform over the wave: scalar loads
         float acc = 0.f;
         for (int ci = 0; ci < cin; ++ci) acc += wr[ci] * cb_pooled[ci * CB_PX + px];
@@ -502,12 +506,15 @@ int rc_color_block(const void* d_x, int x_dtype, float* d_y, int batch, int cin,
     }
     const size_t g = (size_t)batch * (((size_t)ho * wo + CB_PX - 1) / CB_PX);
     RC_REQUIRE(g < (1ull << 31), "rc_color_block: too many tiles");
+    // cout slices (gridDim.y): enough blocks for the chip on the small late maps, never fewer than 4 outputs per thread and slice (same sums, same order: bit-identical)
+    int slices = 1;
+    while (g * slices < 2 * (size_t)device_cu_count() && cout / (2 * slices) >= 16) slices *= 2;
     if (x_dtype == RC_F32)
-        hipLaunchKernelGGL(color_block_kernel<float>, dim3((unsigned)g), dim3(256), lds, as_stream(stream),
+        hipLaunchKernelGGL(color_block_kernel<float>, dim3((unsigned)g, (unsigned)slices), dim3(256), lds, as_stream(stream),
                            static_cast<const float*>(d_x), d_y, batch, cin, cout, h, w, ho, wo, d_w, d_b,
                            d_in_mean, d_in_rstd, d_in_gamma, d_in_beta);
     else
-        hipLaunchKernelGGL(color_block_kernel<bf16_t>, dim3((unsigned)g), dim3(256), lds, as_stream(stream),
+        hipLaunchKernelGGL(color_block_kernel<bf16_t>, dim3((unsigned)g, (unsigned)slices), dim3(256), lds, as_stream(stream),
                            static_cast<const bf16_t*>(d_x), d_y, batch, cin, cout, h, w, ho, wo, d_w, d_b,
                            d_in_mean, d_in_rstd, d_in_gamma, d_in_beta);
     RC_HIP_CHECK(hipGetLastError());

@@ -1513,28 +1513,46 @@ __device__ __forceinline__ void gemm_fresh(const char* w, int lane, const Act<CI
     }
 }
 
+// LeakyReLU with 0 <= slope <= 1 (host-checked) as med3(v, slope v, FLT_MAX) = max(v, slope v): ONE VALU op per value behind the packed multiply.  fmaxf() is two:
+// without fast-math hipcc quiets each operand first (v_max_f32 v, v, v), and an MFMA accumulator is not known to be quiet -- 96 v_max per 48 values and layer --
+// and med3 against +inf is folded back into exactly that maxnum.  (v = +inf stays +inf: the median of {inf, inf, FLT_MAX}.)
+__device__ __forceinline__ f32x4 leaky4(const f32x4& v, float slope) {
+    const f32x4 s = v * slope;
+    const float inf = 3.402823466e+38f;
+    return f32x4{__builtin_amdgcn_fmed3f(v[0], s[0], inf), __builtin_amdgcn_fmed3f(v[1], s[1], inf), __builtin_amdgcn_fmed3f(v[2], s[2], inf), __builtin_amdgcn_fmed3f(v[3], s[3], inf)};
+}
+
 // fp32 accumulator tiles (+ bias [, LeakyReLU]) -> the next layer's B fragments
 template <int C, bool ACT, bool BIASED = false>
 __device__ __forceinline__ void lsc_pack(const f32x4 (&acc)[C / 16][kNT], const float* bias, int g, float slope, Act<C> (&out)[kNT]) {
     constexpr int MT = C / 16;
     auto fin = [&](const f32x4& v, const f32x4& b) {
         f32x4 r = BIASED ? v : v + b;                  // BIASED: the accumulators started from the bias (gemm_fresh)
-        if constexpr (ACT) {
-            const f32x4 s = r * slope;
-            r = f32x4{fmaxf(r[0], s[0]), fmaxf(r[1], s[1]), fmaxf(r[2], s[2]), fmaxf(r[3], s[3])};      // 0 <= slope <= 1
-        }
+        if constexpr (ACT) r = leaky4(r, slope);
         return r;
     };
+    // BIASED && !ACT: the value packed is the bare MFMA accumulator -- never through the inline-asm conversion (HAZARD RULE at pk()): the compiler-visible one
+    constexpr bool RAW_ACC = BIASED && !ACT;
 #pragma unroll
     for (int p = 0; p < MT / 2; ++p) {
         const f32x4 b0 = bias4(bias, 2 * p, g), b1 = bias4(bias, 2 * p + 1, g);
 #pragma unroll
-        for (int nt = 0; nt < kNT; ++nt) out[nt].f[p] = pack_pair(fin(acc[2 * p][nt], b0), fin(acc[2 * p + 1][nt], b1));
+        for (int nt = 0; nt < kNT; ++nt) {
+            if constexpr (RAW_ACC) {
+                const uint2 lo = qa_pack(acc[2 * p][nt]), hi = qa_pack(acc[2 * p + 1][nt]);
+                out[nt].f[p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            } else {
+                out[nt].f[p] = pack_pair(fin(acc[2 * p][nt], b0), fin(acc[2 * p + 1][nt], b1));
+            }
+        }
     }
     if constexpr (MT & 1) {
         const f32x4 b0 = bias4(bias, MT - 1, g);
 #pragma unroll
-        for (int nt = 0; nt < kNT; ++nt) out[nt].t = pack_tail(fin(acc[MT - 1][nt], b0));
+        for (int nt = 0; nt < kNT; ++nt) {
+            if constexpr (RAW_ACC) out[nt].t = qa_pack(acc[MT - 1][nt]);
+            else out[nt].t = pack_tail(fin(acc[MT - 1][nt], b0));
+        }
     }
 }
 
@@ -1590,6 +1608,45 @@ __device__ __forceinline__ void lsc_load(const LscArgs& a, long long p0, int n, 
     }
 }
 
+// The same loads for the shapes the nets have (2 coordinates; a 4-channel packed RAW; rows of at least 64 pixels), written for instruction count: the generic
+// form above re-derives (row, column) of every pixel with loops and decides every tap's bounds from scratch -- ~450 VALU, ~400 SALU and ~250 branches per
+// 64-pixel tile, half of what the kernel issued (1.08 ms at cfg3 against 0.27 ms for its bytes).  Here the tile's first pixel (tx0, ty0) is WAVE-UNIFORM state
+// walked by the caller, a lane's (x, y) is one conditional wrap away from it (W >= 64), the two taps of lane group g and their offsets are lane constants
+// (LscTaps), and a tap is {2 adds, 2 unsigned compares, 1 select} + its load.  Same addresses, same zero padding.
+struct LscTaps { int dy0, dx0, dy1, dx1, d0, d1, d8; };          // taps 2 g and 2 g + 1 of this lane group; byte offsets relative to the pixel's own record
+__device__ __forceinline__ LscTaps lsc_taps(int g, int W) {
+    LscTaps t;
+    t.dy0 = (2 * g) / 3 - 1; t.dx0 = (2 * g) % 3 - 1; t.dy1 = (2 * g + 1) / 3 - 1; t.dx1 = (2 * g + 1) % 3 - 1;
+    t.d0 = (t.dy0 * W + t.dx0) * 8; t.d1 = (t.dy1 * W + t.dx1) * 8; t.d8 = (W + 1) * 8;
+    return t;
+}
+template <bool HEAD>
+__device__ __forceinline__ void lsc_load_fast(const LscArgs& a, int p0, unsigned tx0, unsigned ty0, int n, int g, const LscTaps& tp, __amdgpu_buffer_rsrc_t r_x,
+                                              __amdgpu_buffer_rsrc_t r_raw, LscIn& in) {
+    const unsigned uW = (unsigned)a.W, uH = (unsigned)a.H;
+    const int npix = (int)a.pixels;
+#pragma unroll
+    for (int nt = 0; nt < kNT; ++nt) {
+        const int p = p0 + 16 * nt + n;
+        const bool live = p < npix;
+        in.x[nt] = make_uint2(__builtin_amdgcn_raw_buffer_load_b32(r_x, (live && g == 0) ? p * 4 : kOOBoff, 0, 0), 0u);
+        if constexpr (HEAD) {
+            unsigned x = tx0 + 16 * nt + n, y = ty0;
+            const bool wrap = x >= uW;                                           // W >= 64: at most one row further
+            x = wrap ? x - uW : x; y = wrap ? y + 1 : y; y = y == uH ? 0u : y;
+            const int pb = p * 8;
+            const bool ok0 = live && (unsigned)((int)y + tp.dy0) < uH && (unsigned)((int)x + tp.dx0) < uW;
+            const bool ok1 = live && (unsigned)((int)y + tp.dy1) < uH && (unsigned)((int)x + tp.dx1) < uW;
+            const bool ok8 = live && g == 0 && y + 1 < uH && x + 1 < uW;
+            const auto t0 = __builtin_amdgcn_raw_buffer_load_b64(r_raw, ok0 ? pb + tp.d0 : kOOBoff, 0, 0);
+            const auto t1 = __builtin_amdgcn_raw_buffer_load_b64(r_raw, ok1 ? pb + tp.d1 : kOOBoff, 0, 0);
+            const auto t8 = __builtin_amdgcn_raw_buffer_load_b64(r_raw, ok8 ? pb + tp.d8 : kOOBoff, 0, 0);
+            in.rf[nt] = make_uint4(t0[0], t0[1], t1[0], t1[1]);
+            in.rt[nt] = make_uint2(t8[0], t8[1]);
+        }
+    }
+}
+
 template <int C> constexpr int lsc_threads() { return C > 64 ? 512 : 256; }   // wide chains keep ~100 KB of weights in LDS: one 8-wave block per CU
 template <int C, bool HEAD>
 __global__ __launch_bounds__(lsc_threads<C>(), 2) void lsc_chain_kernel(const LscArgs a) {    // <= 256 registers: VGPR-form MFMA, no AGPR copies
@@ -1612,15 +1669,32 @@ __global__ __launch_bounds__(lsc_threads<C>(), 2) void lsc_chain_kernel(const Ls
     const __amdgpu_buffer_rsrc_t r_raw = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(HEAD ? a.raw : a.x), 0,
                                                                            (int)(a.pixels * (HEAD ? a.raw_c : a.cin0) * 2), 0x00020000);
     const long long n_tiles = (a.pixels + 63) / 64, n_waves = (long long)gridDim.x * (kLscThreads / 64);
-    long long tile = (long long)blockIdx.x * (kLscThreads / 64) + (tid >> 6);
+    long long tile = (long long)blockIdx.x * (kLscThreads / 64) + __builtin_amdgcn_readfirstlane(tid >> 6);
+    // fast loads (lsc_load_fast): 2 coordinates, a 4-channel RAW, rows of >= 64 pixels, everything inside 32-bit pixel indexes (the host checks pixels * 8 < 2^31)
+    const bool fast = a.cin0 == 2 && (!HEAD || a.raw_c == 4) && a.W >= 64;                                  // uniform
+    const LscTaps tp = lsc_taps(g, a.W);
+    const unsigned uW = (unsigned)a.W, uH = (unsigned)a.H;
+    const unsigned step = (unsigned)(64 * n_waves), sx = step % uW, sy = (step / uW) % uH;                  // the walk of (tx0, ty0): uniform, no division in the loop
+    unsigned tx0 = 0, ty0 = 0;                                                                               // first pixel of the tile whose loads are issued NEXT
+    if (tile < n_tiles) { const unsigned p0 = (unsigned)(tile * 64), row0 = p0 / uW; tx0 = p0 - row0 * uW; ty0 = row0 % uH; }
+    auto load = [&](long long t, LscIn& dst) {
+        if (fast) {
+            lsc_load_fast<HEAD>(a, (int)(t * 64), tx0, ty0, n, g, tp, r_x, r_raw, dst);
+            tx0 += sx; ty0 += sy;
+            if (tx0 >= uW) { tx0 -= uW; ++ty0; }
+            if (ty0 >= uH) ty0 -= uH;
+        } else {
+            lsc_load<HEAD>(a, t * 64, n, g, r_x, r_raw, dst);
+        }
+    };
     LscIn nxt;
-    if (tile < n_tiles) lsc_load<HEAD>(a, tile * 64, n, g, r_x, r_raw, nxt);
+    if (tile < n_tiles) load(tile, nxt);
     for (; tile < n_tiles; tile += n_waves) {
         const LscIn in = nxt;
-        if (tile + n_waves < n_tiles) lsc_load<HEAD>(a, (tile + n_waves) * 64, n, g, r_x, r_raw, nxt);     // next tile's operands in flight
+        if (tile + n_waves < n_tiles) load(tile + n_waves, nxt);     // next tile's operands in flight
         Act<C> cur[kNT];
         {   // layer 0, one output tile pair at a time (the accumulators of all MT tiles are never live together)
-            auto leaky = [&](f32x4 v) { const f32x4 sl = v * a.slope; return f32x4{fmaxf(v[0], sl[0]), fmaxf(v[1], sl[1]), fmaxf(v[2], sl[2]), fmaxf(v[3], sl[3])}; };
+            auto leaky = [&](f32x4 v) { return leaky4(v, a.slope); };
 #pragma unroll
             for (int p = 0; p < MT / 2; ++p) {
                 const uint2 w0 = *reinterpret_cast<const uint2*>(s_l0 + (2 * p) * 512 + lane * 8), w1 = *reinterpret_cast<const uint2*>(s_l0 + (2 * p + 1) * 512 + lane * 8);
@@ -1665,11 +1739,11 @@ __global__ __launch_bounds__(lsc_threads<C>(), 2) void lsc_chain_kernel(const Ls
                         for (int nt = 0; nt < kNT; ++nt) {
                             f32x4 v0 = acc[2 * p][nt], v1 = acc[2 * p + 1][nt];
                             if (act) {
-                                const f32x4 s0 = v0 * a.slope, s1 = v1 * a.slope;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], s0[e]); v1[e] = fmaxf(v1[e], s1[e]); }
+                                nxt[nt].f[2 * h + p] = pack_pair(leaky4(v0, a.slope), leaky4(v1, a.slope));
+                            } else {                                     // the bare accumulators: the compiler-visible conversion (HAZARD RULE at pk())
+                                const uint2 lo = qa_pack(v0), hi = qa_pack(v1);
+                                nxt[nt].f[2 * h + p] = make_uint4(lo.x, lo.y, hi.x, hi.y);
                             }
-                            nxt[nt].f[2 * h + p] = pack_pair(v0, v1);
                         }
                     }
                 }
