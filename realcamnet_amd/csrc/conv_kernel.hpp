@@ -67,6 +67,7 @@ struct ConvArgs {
     int ep_key;                        // epilogue_fast feature mask, or -1 for the generic epilogue (ep_key_for)
     TileDecode td, td_wsm;             // division constants of the persistent kernels' tile decode (8- and 16-row tiles)
     MagicDiv div_n_ct;
+    int w_resident;                    // kernel 2 with several cout tiles whose packed weights ALL fit LDS beside the tile (set by the launcher): staged once per block, no per-tile DMA
     int pss;                           // single-chunk pixel-shuffle layer: kernel 5 (output staged through LDS)
     int auto_impl;                     // single-chunk, single-cout-tile bf16 3x3 layers: kernel 6 (wave-autonomous strips)
     int thin;                          // kernel 4b (one barrier per stage) where kernel 4 would run a layer with thin stages
@@ -450,6 +451,21 @@ struct ConvDev {
         const T* in0 = static_cast<const T*>(a.in0);
         const T* in1 = static_cast<const T*>(a.in1);
         const size_t img_base = (size_t)b * a.H * a.W;
+        if constexpr (ES == 2 && UNIT == 8 && VPP == 1) {
+            // a 4-channel bf16 map (the packed RAW in front of the codec's 4 -> 128 head, models/raw2bit.py:1791): a pixel is ONE 8-byte load, its unit the 8 bytes + 8 of zeros
+            // (the element loop below -- 4 two-byte loads, 4 conversions and a re-pack per pixel -- was 2.2 ms of the codec step for a layer that writes 4.5 GB)
+            if (a.cin == 4 && a.in_gate == nullptr && (reinterpret_cast<uintptr_t>(in0) & 7) == 0) {      // uniform
+                for (int i = tid; i < NPIX; i += kThreads) {
+                    const int py = i / TWH, px = i - py * TWH;
+                    const int gy = y0 + py - HALO, gx = x0 + px - HALO;
+                    uint2 w = make_uint2(0u, 0u);
+                    if (chunk == 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                        w = *reinterpret_cast<const uint2*>(in0 + (img_base + (size_t)gy * a.W + gx) * 4);
+                    *reinterpret_cast<uint4*>(s_in + i * SPIX) = make_uint4(w.x, w.y, 0u, 0u);
+                }
+                return;
+            }
+        }
         for (int i = tid; i < NPIX * VPP; i += kThreads) {
             const int pix = i / VPP, v = i - pix * VPP;
             const int py = pix / TWH, px = pix - py * TWH;
@@ -1278,10 +1294,14 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
     using D = ConvDev<Cfg>;
     constexpr int NT = Cfg::NT, STEPS = Cfg::STEPS, NV = 4 * NT;
 
+    // w_resident (uniform): the packed weights of ALL n_ct cout tiles stay in LDS for the block's lifetime (small-Cin layers: the codec's 4 -> 128 head is 2 x 12 KB).
+    // Re-staging one tile's worth per (pixel tile, cout tile) -- an L2 round trip between two workgroup barriers, 135 x 2 times per block -- was what that layer
+    // waited for: 2.17 ms to write 4.5 GB.
+    const int w_copies = a.w_resident ? a.n_ct : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_w = smem;                                  // weights first: their ds_read immediates stay below 64 KiB
-    float* s_bias = reinterpret_cast<float*>(smem + Cfg::CHUNK_W_BYTES);
-    char* s_in = smem + Cfg::CHUNK_W_BYTES + persist_bias_slots<Cfg>() * 4;
+    float* s_bias = reinterpret_cast<float*>(smem + w_copies * Cfg::CHUNK_W_BYTES);
+    char* s_in = smem + w_copies * Cfg::CHUNK_W_BYTES + persist_bias_slots<Cfg>() * 4;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, n = lane & 15;
@@ -1300,7 +1320,7 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
     const int slots = gridDim.x >> 3;                  // gridDim.x is a multiple of 8
     const int pos = (blockIdx.x & 7) * slots + (blockIdx.x >> 3);
 
-    if (n_ct == 1) D::dma_weights(static_cast<const char*>(a.wpacked), s_w, STEPS * NT, wave, lane_w);
+    if (n_ct == 1 || a.w_resident) D::dma_weights(static_cast<const char*>(a.wpacked), s_w, STEPS * NT * w_copies, wave, lane_w);
     for (int i = tid; i < a.cout_packed; i += kThreads) s_bias[i] = a.bias ? a.bias[i] : 0.f;
 
     uint4 r0[D::NI], r1[GATED ? D::NI : 1];
@@ -1356,11 +1376,11 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
         }
 
         for (int ct = 0; ct < n_ct; ++ct) {
-            if (n_ct > 1) {
+            if (n_ct > 1 && !a.w_resident) {
                 if (ct > 0) __syncthreads();           // previous cout tile's weights fully consumed
                 D::dma_weights(static_cast<const char*>(a.wpacked) + (size_t)ct * Cfg::CHUNK_W_BYTES, s_w, STEPS * NT, wave, lane_w);
             }
-            __syncthreads();                           // input tile, weights (+ first time: bias) visible
+            if (ct == 0 || !a.w_resident) __syncthreads();   // input tile, weights (+ first time: bias) visible
             if (ct == n_ct - 1 && tile >= 0) {         // prefetch the next tile: in flight during the MFMA loop
                 b = magic_div(tile, a.td.sp_total);
                 int ty, tx;
@@ -1389,7 +1409,7 @@ __global__ __launch_bounds__(kThreads, persist_blocks_per_cu<Cfg>()) void conv_m
                     D::res_prefetch(a, cb, cy0, cx0, ct, tid, rpre);
                 }
             }
-            D::template mma_steps<0, STEPS, 0, (!GATED && NT < 5)>(s_in, s_w, lane_x, lane_w, q, lo, acc);
+            D::template mma_steps<0, STEPS, 0, (!GATED && NT < 5)>(s_in, a.w_resident ? s_w + ct * (int)Cfg::CHUNK_W_BYTES : s_w, lane_x, lane_w, q, lo, acc);
             if constexpr (FAST && sizeof(typename Cfg::elem) == 2) {
                 const int rslot = a.sums_compact ? 4 * D::compact_residue(pos, cb, sp_total, (int)gridDim.x) : -1;                 // uniform
                 if (RUN_SUMS && a.ep_key == D::EP_SUMS && n_ct == 1)    // uniform
@@ -2829,12 +2849,16 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
             if (report(2, cslots ? cslots : legacy_slots)) return RC_OK;
             ConvArgs aa = a;
             if (int e_ = sums_mode(cslots, aa.sums_compact)) return e_;
+            // several cout tiles whose packed weights all fit beside the tile with two blocks per CU: resident (the kernel's header comment)
+            const int lds_res = P_LDS + (a.n_ct - 1) * (int)Cfg::CHUNK_W_BYTES;
+            aa.w_resident = (a.n_ct > 1 && lds_res <= 80 * 1024 && !(a.dbg_flags & 128)) ? 1 : 0;       // conv_flags 128: A/B
+            const int lds_bytes = one_per_cu ? 100 * 1024 : (aa.w_resident ? lds_res : P_LDS);
             static PerDeviceFlag attr_set;                       // function attributes are per device (common.hpp)
             if (!attr_set.test_and_set()) {
                 RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_persist_kernel<Cfg, GATED, FAST>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS > 100 * 1024 ? P_LDS : 100 * 1024));
             }
-            hipLaunchKernelGGL((conv_mfma_persist_kernel<Cfg, GATED, FAST>), dim3((unsigned)grid), dim3(kThreads), one_per_cu ? 100 * 1024 : P_LDS, stream, aa);
+            hipLaunchKernelGGL((conv_mfma_persist_kernel<Cfg, GATED, FAST>), dim3((unsigned)grid), dim3(kThreads), lds_bytes, stream, aa);
             RC_HIP_CHECK(hipGetLastError());
             return RC_OK;
         }
