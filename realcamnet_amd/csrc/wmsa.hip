@@ -156,28 +156,52 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void wmsa_mfma_kernel(const bf16_
     for (int i = lane; i < DT * 16 * VROW; i += 64) s_vt[i] = from_f32<bf16_t>(0.f);
     __syncthreads();
     const float scale = rsqrtf((float)HD) * kLog2e;
-    const size_t rec = (size_t)3 * C;                                   // elements per pixel record
-    // this lane's token roles: A operand of key tile mt: key(mt, R = n); B operand of query tile nt: query 16 nt + n; V staging: token = lane
-    for (long long win = w_begin + wave; win < w_end; win += kWmWaves) {
-        const int b = (int)(win / (hw * ww)), w1 = (int)((win / ww) % hw), w2 = (int)(win % ww);
-        auto pixel = [&](int t) -> size_t {                            // window token t -> element offset of its pixel record
-            int y = w1 * WS + (t >> 3) + shift, x = w2 * WS + (t & 7) + shift;
+    const int rec = 3 * C;                                              // elements per pixel record
+    // this lane's token roles: A operand of key tile mt: key(mt, R = n); B operand of query tile nt: query 16 nt + n; V staging: token = lane.
+    // Addressing is written for instruction count (the head_dim 8 call spends as much on it as on its softmax): the window walk (b, w1, w2) is WAVE-UNIFORM
+    // state advanced without divisions (it was three 64-bit divisions per window, in vector registers: `wave` was not known uniform), a role's pixel is the
+    // window's first pixel + a lane constant unless the window wraps (last row / column of a shifted call: uniform), offsets are 32-bit inside one image
+    // (host: H W 3C < 2^31).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int role_k[4], role_q[4];                                           // (row, column) of the role's token inside the window, as row * W + column
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int key = 32 * (t >> 1) + 8 * (n >> 2) + 4 * (t & 1) + (n & 3), tq = 16 * t + n;
+        role_k[t] = (key >> 3) * W + (key & 7); role_q[t] = (tq >> 3) * W + (tq & 7);
+    }
+    const int role_v = (lane >> 3) * W + (lane & 7);
+    int win = (int)w_begin + wave_u;
+    int b = win / (hw * ww), w1 = (win - b * (hw * ww)) / ww, w2 = win - b * (hw * ww) - w1 * ww;
+    for (; win < (int)w_end; win += kWmWaves) {
+        const int cur_w1 = w1, cur_w2 = w2;                             // (the walk below moves w1 / w2 on: everything about THIS window uses these)
+        const bool wraps = shift > 0 && (cur_w1 == hw - 1 || cur_w2 == ww - 1);         // uniform
+        const int base = (cur_w1 * WS + shift) * W + cur_w2 * WS + shift;
+        auto pixel = [&](int role, int t) -> int {                      // window token t (role = its lane constant) -> pixel index inside image b
+            if (!wraps) return base + role;
+            int y = cur_w1 * WS + (t >> 3) + shift, x = cur_w2 * WS + (t & 7) + shift;
             if (y >= H) y -= H;
             if (x >= W) x -= W;
-            return (((size_t)b * H + y) * W + x);
+            return y * W + x;
         };
+        const bf16_t* img_in = qkv + (size_t)b * H * W * rec;           // uniform
+        bf16_t* img_out = out + (size_t)b * H * W * C;
+        w2 += kWmWaves;                                                 // the walk: the next window of this wave
+        while (w2 >= ww) { w2 -= ww; ++w1; }
+        while (w1 >= hw) { w1 -= hw; ++b; }
         const bool chan = 8 * g < HD;                                   // this lane group carries channels 8 g .. 8 g + 7 of the head
         uint4 qf[4], kf[4];
+        int q_px[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int key = 32 * (t >> 1) + 8 * (n >> 2) + 4 * (t & 1) + (n & 3);
-            const bf16_t* kp = qkv + pixel(key) * rec + C + h * HD + 8 * g;
-            const bf16_t* qp = qkv + pixel(16 * t + n) * rec + h * HD + 8 * g;
+            q_px[t] = pixel(role_q[t], 16 * t + n);
+            const bf16_t* kp = img_in + (unsigned)(pixel(role_k[t], key) * rec + C + h * HD + 8 * g);
+            const bf16_t* qp = img_in + (unsigned)(q_px[t] * rec + h * HD + 8 * g);
             kf[t] = chan ? *reinterpret_cast<const uint4*>(kp) : make_uint4(0u, 0u, 0u, 0u);
             qf[t] = chan ? *reinterpret_cast<const uint4*>(qp) : make_uint4(0u, 0u, 0u, 0u);
         }
         {   // V^T slab: lane = token, rows = channels
-            const bf16_t* vp = qkv + pixel(lane) * rec + 2 * C + h * HD;
+            const bf16_t* vp = img_in + (unsigned)(pixel(role_v, lane) * rec + 2 * C + h * HD);
 #pragma unroll
             for (int c8 = 0; c8 < HD / 8; ++c8) {
                 const uint4 v = *reinterpret_cast<const uint4*>(vp + 8 * c8);
@@ -188,7 +212,7 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void wmsa_mfma_kernel(const bf16_
             }
         }
         // ---- scores: S^T[key][query], scaled + biased in the log2 domain
-        const bool last_r = shift > 0 && w1 == hw - 1, last_c = shift > 0 && w2 == ww - 1;
+        const bool last_r = shift > 0 && cur_w1 == hw - 1, last_c = shift > 0 && cur_w2 == ww - 1;
         const bool q_side_c = (n & 7) >= WS - shift;                    // query column side (queries 16 nt + n: p2 = n & 7)
         uint4 pf[4][2];                                                 // P^T fragments: [query tile][K-step]
         float inv_den[4];
@@ -246,7 +270,7 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void wmsa_mfma_kernel(const bf16_
                 wm_mma(vf[1], pf[nt][1], o);
                 o = o * inv_den[nt];
                 if (16 * dt + 4 * g < HD) {                              // rows 4 g .. 4 g + 3 of this tile are real channels
-                    bf16_t* op = out + pixel(16 * nt + n) * C + h * HD + 16 * dt + 4 * g;
+                    bf16_t* op = img_out + (unsigned)(q_px[nt] * C + h * HD + 16 * dt + 4 * g);
                     *reinterpret_cast<uint2*>(op) = make_uint2(wm_pk(o[0], o[1]), wm_pk(o[2], o[3]));
                 }
             }
@@ -270,7 +294,8 @@ int rc_window_attention(const void* d_qkv, const float* d_relpos, void* d_out, i
     RC_REQUIRE(batch >= 1 && H >= window && W >= window && H % window == 0 && W % window == 0, "rc_window_attention: H, W must be multiples of the window size");
     RC_REQUIRE(C >= head_dim && C % head_dim == 0, "rc_window_attention: C must be a multiple of head_dim");
     RC_REQUIRE(shift == 0 || shift == window / 2, "rc_window_attention: shift must be 0 (W-MSA) or window/2 (SW-MSA)");
-    if (dtype == RC_BF16 && window == 8) {                             // matrix-core form
+    // matrix-core form: 32-bit window counts and in-image element offsets (larger maps take the one-lane-per-query kernel below)
+    if (dtype == RC_BF16 && window == 8 && (long long)batch * (H / 8) * (W / 8) < (1LL << 30) && (long long)H * W * 3 * C < (1LL << 31)) {
         const int nh = C / head_dim;
         const long long n_win = (long long)batch * (H / 8) * (W / 8);
         const int dtiles = (head_dim + 15) / 16;
