@@ -48,6 +48,15 @@ timeout 400 python tools/codec_b1.py 1 --codec > gpurun_out/codec_b1_$TAG.txt 2>
 ( cd tools/ubench && hipcc --offload-arch=gfx950 -O3 mfma_valu_samewave.hip -o /tmp/mvs 2>/dev/null && /tmp/mvs ) > gpurun_out/mvs_$TAG.txt 2>&1
 timeout 400 python tools/pmc_any.py ${TAG}qa "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_BRANCH SQ_INSTS_SMEM;SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES;GRBM_GUI_ACTIVE" -- python tools/dbg/qa_pmc_run.py > gpurun_out/qa_pmc_$TAG.txt 2>&1
 ( for i in 1 2 3; do for v in 0 1; do echo -n "RC_GMA_FRONT=$v: "; RC_GMA_FRONT=$v timeout 200 python bench.py --no-cpu-baseline --no-codec-leg --steps 10 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms', d['value'], 'MP/s')"; done; done; timeout 200 python tools/dbg/qa_stress.py 40 ) > gpurun_out/gma_front_ab_$TAG.txt 2>&1
+# round 6, third session: conv -> Haar DWT in one launch (RC_OUT_NHWC_DWT) alone and in the whole bench, the front end (lens-shading head against the colour-prior chain), the codec's
+# small dependent launches, the 4 -> 128 head with its weights resident
+( for f in none dwt conv+dwt none dwt conv+dwt; do timeout 100 python tools/conv_one.py 48 48 1088 1920 8 30 $f 2>/dev/null; done
+  for i in 1 2 3; do for v in 0 1; do echo -n "RC_FUSE_DWT=$v: "; RC_FUSE_DWT=$v timeout 200 python bench.py --no-cpu-baseline --no-codec-leg --steps 10 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms', d['value'], 'MP/s')"; done; done
+  timeout 200 python tools/front_probe.py 2>&1 | grep -v amdgpu.ids
+  timeout 200 python tools/lsc_bench.py 2>&1 | grep -v amdgpu.ids
+  timeout 200 python tools/small_launch_probe.py 8 2>&1 | grep -v amdgpu.ids; timeout 200 python tools/small_launch_probe.py 1 2>&1 | grep -v amdgpu.ids
+  for fl in 128 0 128 0; do echo -n "conv_flags=$fl (128: weights re-staged per cout tile) "; RC_DEBUG=conv_flags=$fl timeout 100 python tools/conv_one.py 4 128 1152 1920 8 20 none 2>/dev/null; done ) > gpurun_out/session3_$TAG.txt 2>&1
+cp gpurun_out/session3_$TAG.txt gpurun_out/profiles_$TAG/ 2>/dev/null
 cp gpurun_out/mvs_$TAG.txt gpurun_out/qa_pmc_$TAG.txt gpurun_out/gma_front_ab_$TAG.txt gpurun_out/gma_stages_$TAG.txt gpurun_out/profiles_$TAG/ 2>/dev/null
 cp gpurun_out/cfg2_kernel_stats_$TAG.txt gpurun_out/wino_probe_$TAG.txt gpurun_out/mvo_$TAG.txt gpurun_out/wino_pmc_$TAG.txt gpurun_out/codec_b1_$TAG.txt gpurun_out/bench_cfg2_direct_$TAG.json gpurun_out/bench_cfg2_trace_$TAG.json gpurun_out/profiles_$TAG/ 2>/dev/null
 
