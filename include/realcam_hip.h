@@ -494,6 +494,9 @@ int rc_ln_mlp(const void* d_x, void* d_out, long long tokens, int c, const void*
  * Linear(LayerNorm(d_x (tokens, c))), bf16, c = 32 or 64, cout a multiple of 32 (<= 512); weights by rc_chain_pack_weights(c -> cout). */
 int rc_ln_linear(const void* d_x, void* d_out, long long tokens, int c, int cout, const void* d_w, const float* d_b, const float* d_ln_gamma,
                  const float* d_ln_beta, float eps, void* stream);
+/* (ABI 14) the same launch with d_out SEGMENT-PLANAR: [cout / 8 segments][tokens][8 channels] -- the q / k / v layout rc_window_attention_planar8 reads. */
+int rc_ln_linear_planar8(const void* d_x, void* d_out, long long tokens, int c, int cout, const void* d_w, const float* d_b, const float* d_ln_gamma,
+                         const float* d_ln_beta, float eps, void* stream);
 
 /* GDN / inverse GDN (compressai.layers.GDN inside ResidualBlockWithStride / ResidualBlockUpsample; call sites models/tcm.py:336-364) as one
  * per-token launch: d_out = d_x * rsqrt(beta + gamma . d_x^2)  (inverse != 0: * sqrt(..))  [+ d_identity], bf16, c = 64 or 128 channels,
@@ -558,6 +561,13 @@ int rc_channel_concat(const void* const* d_parts, const int* widths, int n_parts
  * LayerNorms and the MLP of tcm.Block (:214-236) are rc_conv2d (1x1) / rc_layernorm. */
 int rc_window_attention(const void* d_qkv, const float* d_relpos, void* d_out, int dtype, int batch, int H, int W, int C,
                         int head_dim, int window, int shift, void* stream);
+/* (ABI 14) the same attention over a SEGMENT-PLANAR d_qkv: [3C / 8 segments][B H W pixels][8 channels], segment = channel / 8 of the (B,H,W,3C) form above
+ * (rc_ln_linear_planar8 writes it).  With head_dim 8 a lane of the interleaved form reads 16 of a pixel record's 384 bytes -- one 64-byte sector per lane; in its
+ * segment's plane the 8 pixels of a window row are 128 contiguous bytes.  Exists for the matrix-core form only (bf16, 8 x 8 windows, B H W 3C < 2^31:
+ * rc_window_attention_planar8_ok() != 0); RC_ERR_UNSUPPORTED otherwise.  Same arithmetic, same bits as rc_window_attention on the interleaved tensor. */
+int rc_window_attention_planar8(const void* d_qkv, const float* d_relpos, void* d_out, int dtype, int batch, int H, int W, int C,
+                                int head_dim, int window, int shift, void* stream);
+int rc_window_attention_planar8_ok(int dtype, int batch, int H, int W, int C, int window);
 
 /* ---- measurement helpers (bench.py): HIP-event timing of every rc_conv2d launch on its stream -
  * rc_prof_enable(1) brackets each subsequent rc_conv2d with hipEventRecord on the launch stream;

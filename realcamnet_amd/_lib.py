@@ -114,6 +114,8 @@ _SIGS = {
     "rc_channel_copy": (C.c_int, [_P, _I, _I, _P, _I, _I, _I, C.c_longlong, _I, _P]),
     "rc_channel_concat": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), _I, _P, C.c_longlong, _I, _P]),
     "rc_window_attention": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "rc_window_attention_planar8": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "rc_window_attention_planar8_ok": (C.c_int, [_I, _I, _I, _I, _I, _I]),
     "rc_conv_pair": (C.c_int, [C.POINTER(ConvPairDesc), _P]),
     "rc_conv_pair_sum_slots": (C.c_int, [_I, _I]),
     "rc_conv_pair_desc_size": (_SZ, []),
@@ -147,6 +149,7 @@ _SIGS = {
     "rc_cat_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_longlong, _I, _P, _P, _P]),
     "rc_gdn_chain": (C.c_int, [_P, _P, _P, C.c_longlong, _I, _P, _P, _I, _P]),
     "rc_ln_linear": (C.c_int, [_P, _P, C.c_longlong, _I, _I, _P, _P, _P, _P, _F, _P]),
+    "rc_ln_linear_planar8": (C.c_int, [_P, _P, C.c_longlong, _I, _I, _P, _P, _P, _P, _F, _P]),
     "rc_ln_mlp": (C.c_int, [_P, _P, C.c_longlong, _I, _P, _P, _P, _P, _P, _P, _F, _P]),
     "rc_gma_kv_mfma_blocks": (C.c_int, [_I]),
     "rc_gma_kv_mfma_scratch_bytes": (C.c_size_t, [_I, _I]),

@@ -2157,7 +2157,8 @@ extern "C" int rc_ln_mlp(const void* d_x, void* d_out, long long tokens, int c, 
 namespace rc {
 namespace gf {
 
-struct LnLinArgs { const bf16_t* x; bf16_t* out; size_t tokens; int cout; const void* w; const float* b; const float* ln_g; const float* ln_b; float eps; };
+struct LnLinArgs { const bf16_t* x; bf16_t* out; size_t tokens; int cout; const void* w; const float* b; const float* ln_g; const float* ln_b; float eps;
+                   int planar8; };   // planar8: out as [cout / 8 segments][tokens][8 channels] (rc_window_attention_planar8's q / k / v layout) instead of (tokens, cout)
 
 template <int C>
 __global__ __launch_bounds__(kMlpThreads, 2) void ln_linear_kernel(const LnLinArgs a) {
@@ -2199,7 +2200,10 @@ __global__ __launch_bounds__(kMlpThreads, 2) void ln_linear_kernel(const LnLinAr
 #pragma unroll
             for (int nt = 0; nt < kNT; ++nt) {
                 const size_t t = tile * 64 + 16 * nt + n;
-                if (t < a.tokens) *reinterpret_cast<uint4*>(a.out + t * a.cout + 32 * p + 8 * g) = pack_pair(acc[0][nt] + b0, acc[1][nt] + b1);
+                if (t < a.tokens) {
+                    bf16_t* dst = a.planar8 ? a.out + ((size_t)(4 * p + g) * a.tokens + t) * 8 : a.out + t * a.cout + 32 * p + 8 * g;      // planar: 16 tokens x 16 B = 256-byte runs
+                    *reinterpret_cast<uint4*>(dst) = pack_pair(acc[0][nt] + b0, acc[1][nt] + b1);
+                }
             }
         }
     }
@@ -2208,14 +2212,24 @@ __global__ __launch_bounds__(kMlpThreads, 2) void ln_linear_kernel(const LnLinAr
 }  // namespace gf
 }  // namespace rc
 
+static int ln_linear_launch(const void* d_x, void* d_out, long long tokens, int c, int cout, const void* d_w, const float* d_b, const float* d_ln_gamma,
+                            const float* d_ln_beta, float eps, int planar8, void* stream);
 extern "C" int rc_ln_linear(const void* d_x, void* d_out, long long tokens, int c, int cout, const void* d_w, const float* d_b, const float* d_ln_gamma,
                             const float* d_ln_beta, float eps, void* stream) {
+    return ln_linear_launch(d_x, d_out, tokens, c, cout, d_w, d_b, d_ln_gamma, d_ln_beta, eps, 0, stream);
+}
+extern "C" int rc_ln_linear_planar8(const void* d_x, void* d_out, long long tokens, int c, int cout, const void* d_w, const float* d_b, const float* d_ln_gamma,
+                                    const float* d_ln_beta, float eps, void* stream) {
+    return ln_linear_launch(d_x, d_out, tokens, c, cout, d_w, d_b, d_ln_gamma, d_ln_beta, eps, 1, stream);
+}
+static int ln_linear_launch(const void* d_x, void* d_out, long long tokens, int c, int cout, const void* d_w, const float* d_b, const float* d_ln_gamma,
+                            const float* d_ln_beta, float eps, int planar8, void* stream) {
     using namespace rc;
     using namespace rc::gf;
     RC_REQUIRE(d_x && d_out && d_w && d_ln_gamma && d_ln_beta, "rc_ln_linear: null pointer");
     RC_REQUIRE(tokens >= 1 && (c == 32 || c == 64) && cout >= 32 && cout % 32 == 0 && cout <= 512, "rc_ln_linear: width 32 / 64 -> a multiple of 32 (<= 512)");
     RC_REQUIRE(reinterpret_cast<uintptr_t>(d_x) % 16 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0, "rc_ln_linear: misaligned tensor");
-    LnLinArgs a{static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_out), (size_t)tokens, cout, d_w, d_b, d_ln_gamma, d_ln_beta, eps};
+    LnLinArgs a{static_cast<const bf16_t*>(d_x), static_cast<bf16_t*>(d_out), (size_t)tokens, cout, d_w, d_b, d_ln_gamma, d_ln_beta, eps, planar8};
     const size_t lds = (size_t)(cout / 16) * tile_bytes(c) + (size_t)(cout + 2 * c) * 4;
     const long long tiles = (tokens + 63) / 64;
     long long grid = (tiles + 3) / 4;

@@ -124,7 +124,7 @@ __device__ __forceinline__ void wm_mma(const uint4& a, const uint4& b, f32x4& c)
 template <int HD>
 __global__ __launch_bounds__(kWmWaves * 64, 2) void wmsa_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ relpos,
                                                                         bf16_t* __restrict__ out, int batch, int H, int W, int C, int shift,
-                                                                        int windows_per_block) {
+                                                                        int windows_per_block, int planar8) {
     constexpr int WS = 8, RP = 15, DT = (HD + 15) / 16;                 // DT: 16-row tiles of O^T
     constexpr int VROW = 64 + 8;                                        // V^T slab row (bf16 elements): 144 B, 16-byte aligned, spreads banks
     extern __shared__ __attribute__((aligned(16))) char wm_lds[];
@@ -183,7 +183,15 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void wmsa_mfma_kernel(const bf16_
             if (x >= W) x -= W;
             return y * W + x;
         };
-        const bf16_t* img_in = qkv + (size_t)b * H * W * rec;           // uniform
+        // element offset of 8 channels starting at channel c0 of pixel px of image b.  Interleaved (B, H, W, 3C): inside the image's records.  planar8
+        // ([3C / 8 segments][B H W pixels][8]; rc_ln_linear_planar8 writes it): a head_dim-8 lane reads 16 of a record's 384 bytes, so the interleaved form pulls a
+        // 64-byte sector per lane (6.6 GB of sectors per call for 1.7 GB of q, k, v: the L2 -> L1 path was what the call waited for); in the plane of its segment
+        // the 8 pixels of a window row are 128 contiguous bytes.
+        const unsigned plane = (unsigned)batch * (unsigned)(H * W);
+        const bf16_t* img_in = planar8 ? qkv + (size_t)b * H * W * 8 : qkv + (size_t)b * H * W * rec;           // uniform
+        auto at = [&](int px, int c0) -> unsigned {
+            return planar8 ? ((unsigned)(c0 >> 3) * plane + (unsigned)px) * 8u : (unsigned)(px * rec + c0);
+        };
         bf16_t* img_out = out + (size_t)b * H * W * C;
         w2 += kWmWaves;                                                 // the walk: the next window of this wave
         while (w2 >= ww) { w2 -= ww; ++w1; }
@@ -195,16 +203,16 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void wmsa_mfma_kernel(const bf16_
         for (int t = 0; t < 4; ++t) {
             const int key = 32 * (t >> 1) + 8 * (n >> 2) + 4 * (t & 1) + (n & 3);
             q_px[t] = pixel(role_q[t], 16 * t + n);
-            const bf16_t* kp = img_in + (unsigned)(pixel(role_k[t], key) * rec + C + h * HD + 8 * g);
-            const bf16_t* qp = img_in + (unsigned)(q_px[t] * rec + h * HD + 8 * g);
+            const bf16_t* kp = img_in + at(pixel(role_k[t], key), C + h * HD + 8 * g);
+            const bf16_t* qp = img_in + at(q_px[t], h * HD + 8 * g);
             kf[t] = chan ? *reinterpret_cast<const uint4*>(kp) : make_uint4(0u, 0u, 0u, 0u);
             qf[t] = chan ? *reinterpret_cast<const uint4*>(qp) : make_uint4(0u, 0u, 0u, 0u);
         }
         {   // V^T slab: lane = token, rows = channels
-            const bf16_t* vp = img_in + (unsigned)(pixel(role_v, lane) * rec + 2 * C + h * HD);
+            const int v_px = pixel(role_v, lane);
 #pragma unroll
             for (int c8 = 0; c8 < HD / 8; ++c8) {
-                const uint4 v = *reinterpret_cast<const uint4*>(vp + 8 * c8);
+                const uint4 v = *reinterpret_cast<const uint4*>(img_in + at(v_px, 2 * C + h * HD + 8 * c8));
                 const unsigned wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
@@ -285,8 +293,23 @@ using namespace rc;
 
 extern "C" {
 
+static int window_attention_impl(const void* d_qkv, const float* d_relpos, void* d_out, int dtype, int batch, int H, int W, int C,
+                                 int head_dim, int window, int shift, int planar8, void* stream);
 int rc_window_attention(const void* d_qkv, const float* d_relpos, void* d_out, int dtype, int batch, int H, int W, int C,
                         int head_dim, int window, int shift, void* stream) {
+    return window_attention_impl(d_qkv, d_relpos, d_out, dtype, batch, H, W, C, head_dim, window, shift, 0, stream);
+}
+int rc_window_attention_planar8(const void* d_qkv, const float* d_relpos, void* d_out, int dtype, int batch, int H, int W, int C,
+                                int head_dim, int window, int shift, void* stream) {
+    return window_attention_impl(d_qkv, d_relpos, d_out, dtype, batch, H, W, C, head_dim, window, shift, 1, stream);
+}
+int rc_window_attention_planar8_ok(int dtype, int batch, int H, int W, int C, int window) {
+    return dtype == RC_BF16 && window == 8 && batch >= 1 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0 && (long long)batch * (H / 8) * (W / 8) < (1LL << 30) &&
+           (long long)batch * H * W * 3 * C < (1LL << 31);
+}
+}  // extern "C"
+static int window_attention_impl(const void* d_qkv, const float* d_relpos, void* d_out, int dtype, int batch, int H, int W, int C,
+                                 int head_dim, int window, int shift, int planar8, void* stream) {
     RC_REQUIRE(d_qkv && d_relpos && d_out, "rc_window_attention: null pointer");
     RC_REQUIRE(dtype == RC_F32 || dtype == RC_BF16, "rc_window_attention: bad dtype");
     RC_REQUIRE(window == 4 || window == 8, "rc_window_attention: window size must be 4 or 8 (as models/tcm.py uses)");
@@ -294,6 +317,8 @@ int rc_window_attention(const void* d_qkv, const float* d_relpos, void* d_out, i
     RC_REQUIRE(batch >= 1 && H >= window && W >= window && H % window == 0 && W % window == 0, "rc_window_attention: H, W must be multiples of the window size");
     RC_REQUIRE(C >= head_dim && C % head_dim == 0, "rc_window_attention: C must be a multiple of head_dim");
     RC_REQUIRE(shift == 0 || shift == window / 2, "rc_window_attention: shift must be 0 (W-MSA) or window/2 (SW-MSA)");
+    if (planar8 && !rc_window_attention_planar8_ok(dtype, batch, H, W, C, window))
+        return fail(RC_ERR_UNSUPPORTED, "rc_window_attention_planar8: the segment-planar q / k / v layout exists for the bf16 8 x 8-window matrix-core form with B H W 3C < 2^31");
     // matrix-core form: 32-bit window counts and in-image element offsets (larger maps take the one-lane-per-query kernel below)
     if (dtype == RC_BF16 && window == 8 && (long long)batch * (H / 8) * (W / 8) < (1LL << 30) && (long long)H * W * 3 * C < (1LL << 31)) {
         const int nh = C / head_dim;
@@ -312,7 +337,7 @@ int rc_window_attention(const void* d_qkv, const float* d_relpos, void* d_out, i
         RC_REQUIRE(chunks * nh < (1LL << 31), "rc_window_attention: too many windows");
 #define RC_WMM(HD)                                                                                                                          \
         hipLaunchKernelGGL((wmsa_mfma_kernel<HD>), dim3((unsigned)(chunks * nh)), dim3(kWmWaves * 64), lds, as_stream(stream),              \
-                           static_cast<const bf16_t*>(d_qkv), d_relpos, static_cast<bf16_t*>(d_out), batch, H, W, C, shift, (int)per_block)
+                           static_cast<const bf16_t*>(d_qkv), d_relpos, static_cast<bf16_t*>(d_out), batch, H, W, C, shift, (int)per_block, planar8)
         if (head_dim == 8) RC_WMM(8); else if (head_dim == 16) RC_WMM(16); else RC_WMM(32);
 #undef RC_WMM
         RC_HIP_CHECK(hipGetLastError());
@@ -342,5 +367,3 @@ int rc_window_attention(const void* d_qkv, const float* d_relpos, void* d_out, i
     RC_HIP_CHECK(hipGetLastError());
     return RC_OK;
 }
-
-}  // extern "C"

@@ -831,14 +831,25 @@ def ln_mlp(x: torch.Tensor, ln, fc1, fc2):
                      b2 if fc2.bias is not None else None)
 
 
-def ln_linear(x: torch.Tensor, ln, lin):
-    """lin(ln(x)) in ONE launch (realcam::ln_linear) for bf16 tokens of width 32 / 64 and an output width that is a multiple of 32; None otherwise."""
+PLANAR_QKV = os.environ.get("RC_PLANAR_QKV", "1") != "0"   # W-MSA: q / k / v written segment-planar by the embedding launch and read so by the attention launch (A/B, tests)
+
+
+def planar_qkv_ok(x: torch.Tensor, window: int) -> bool:
+    """Does rc_window_attention have its segment-planar form for this map (bf16, 8 x 8 windows, sizes inside 32-bit offsets)?"""
+    b, h, w, c = x.shape
+    return bool(PLANAR_QKV and x.dtype == torch.bfloat16 and _lib.load().rc_window_attention_planar8_ok(RC_BF16, b, h, w, c, window))
+
+
+def ln_linear(x: torch.Tensor, ln, lin, planar8: bool = False):
+    """lin(ln(x)) in ONE launch (realcam::ln_linear) for bf16 tokens of width 32 / 64 and an output width that is a multiple of 32; None otherwise.
+    planar8: the result's MEMORY is [cout / 8 segments][tokens][8] (for torch.ops.realcam.window_attention_planar8 only; the shape stays (.., cout))."""
     c, cout = x.shape[-1], lin.weight.shape[0]
     if not (FUSE_MLP and x.dtype == torch.bfloat16 and c in (32, 64) and lin.weight.dim() == 2 and lin.weight.shape[1] == c and cout % 32 == 0 and
             cout <= 512 and tuple(ln.normalized_shape) == (c,)):
         return None
     w, b = packed_chain(lin)
-    return _R.ln_linear(_req(x, "tokens"), f32_param(ln, "weight"), f32_param(ln, "bias"), float(ln.eps), w, b if lin.bias is not None else None, int(cout))
+    op = _R.ln_linear_planar8 if planar8 else _R.ln_linear
+    return op(_req(x, "tokens"), f32_param(ln, "weight"), f32_param(ln, "bias"), float(ln.eps), w, b if lin.bias is not None else None, int(cout))
 
 
 def cat_linear(a: torch.Tensor, b: torch.Tensor, conv, residual: Optional[torch.Tensor] = None, a_add: Optional[torch.Tensor] = None):

@@ -46,11 +46,13 @@ class WMSA(nn.Module):
         ws = self.window_size
         if c != self.input_dim or h % ws or w % ws:
             raise ValueError(f"WMSA: expected (b, h, w, {self.input_dim}) with h, w multiples of {ws}, got {tuple(t.shape)}")
-        qkv = ops.ln_linear(t, ln, self.embedding_layer) if ln is not None else None
+        planar = ln is not None and ops.planar_qkv_ok(t, ws)            # q / k / v segment-planar between the two launches (rc_window_attention_planar8: sector-sized reads)
+        qkv = ops.ln_linear(t, ln, self.embedding_layer, planar8=planar) if ln is not None else None
         if qkv is None:
+            planar = False
             qkv = ops.conv2d(t if ln is None else ops.layernorm(t, ln), self.embedding_layer)
-        att = torch.ops.realcam.window_attention(qkv, ops.f32_param(self, "relative_position_params"), self.head_dim, ws,
-                                                 0 if self.type == 'W' else ws // 2)
+        attend = torch.ops.realcam.window_attention_planar8 if planar else torch.ops.realcam.window_attention
+        att = attend(qkv, ops.f32_param(self, "relative_position_params"), self.head_dim, ws, 0 if self.type == 'W' else ws // 2)
         return ops.conv2d(att, self.linear, residual=residual)
 
     def forward(self, x):

@@ -611,6 +611,12 @@ define("window_attention(Tensor qkv, Tensor rel_pos, int head_dim, int window, i
        lambda out, qkv, rel, hd, ws, sh: check(lib().rc_window_attention(qkv.data_ptr(), rel.data_ptr(), out.data_ptr(), _dt(qkv), qkv.shape[0],
                                                                          qkv.shape[1], qkv.shape[2], qkv.shape[3] // 3, hd, ws, sh, _stream()),
                                                "rc_window_attention"))
+# qkv SEGMENT-PLANAR ([3C / 8][B H W][8], the memory ln_linear_planar8 fills; the tensor keeps the (B,H,W,3C) shape as a size carrier only)
+define("window_attention_planar8(Tensor qkv, Tensor rel_pos, int head_dim, int window, int shift) -> Tensor",
+       lambda qkv, rel, hd, ws, sh: qkv.new_empty((*qkv.shape[:3], qkv.shape[3] // 3)),
+       lambda out, qkv, rel, hd, ws, sh: check(lib().rc_window_attention_planar8(qkv.data_ptr(), rel.data_ptr(), out.data_ptr(), _dt(qkv), qkv.shape[0],
+                                                                                 qkv.shape[1], qkv.shape[2], qkv.shape[3] // 3, hd, ws, sh, _stream()),
+                                               "rc_window_attention_planar8"))
 
 
 # ---- a15/a16 fused per-token stages of GMA_Block at dim 80 (csrc/gma_fused.hip) ---------------------------------------------------
@@ -833,6 +839,11 @@ define("ln_linear(Tensor x, Tensor ln_gamma, Tensor ln_beta, float eps, Tensor w
        lambda out, x, g, b, eps, w, bias, cout: check(lib().rc_ln_linear(x.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], cout,
                                                                          w.data_ptr(), _p(bias), g.data_ptr(), b.data_ptr(), float(eps), _stream()),
                                                       "rc_ln_linear"))
+define("ln_linear_planar8(Tensor x, Tensor ln_gamma, Tensor ln_beta, float eps, Tensor w, Tensor? b, int cout) -> Tensor",
+       lambda x, g, b, eps, w, bias, cout: x.new_empty((*x.shape[:-1], cout)),
+       lambda out, x, g, b, eps, w, bias, cout: check(lib().rc_ln_linear_planar8(x.data_ptr(), out.data_ptr(), x.numel() // x.shape[-1], x.shape[-1], cout,
+                                                                                 w.data_ptr(), _p(bias), g.data_ptr(), b.data_ptr(), float(eps), _stream()),
+                                                      "rc_ln_linear_planar8"))
 
 define("pixel_shuffle2_nchw(Tensor x) -> Tensor",
        lambda x: x.new_empty((x.shape[0], x.shape[3] // 4, 2 * x.shape[1], 2 * x.shape[2])),

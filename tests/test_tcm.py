@@ -697,6 +697,47 @@ def test_hip_window_attention_mfma_form_vs_oracle(head_dim, typ):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("typ", ["W", "SW"])
+@pytest.mark.parametrize("head_dim", [8, 16, 32])
+def test_hip_window_attention_over_segment_planar_qkv_equals_the_interleaved_form(head_dim, typ):
+    """ABI 14: rc_ln_linear_planar8 writes q / k / v as [3C / 8 segments][pixels][8] and rc_window_attention_planar8 reads them there (sector-sized reads for the
+    head_dim-8 call) -- the same LayerNorm, GEMM and attention arithmetic, so the attention output must equal the interleaved pair BIT FOR BIT: every head size, W and SW
+    (wrapping windows), several images / window rows / columns; the planar tensor itself must be the interleaved one re-laid; tcm.Block takes the planar pair by default."""
+    import realcamnet_amd.tcm as T
+    from realcamnet_amd import ops as OPS
+    torch.manual_seed(7 + head_dim)
+    c, ws = 64, 8
+    blk = T.Block(c, c, head_dim, ws, 0.0, typ).eval().to("cuda", torch.bfloat16)
+    with torch.no_grad():
+        blk.msa.relative_position_params.mul_(20.0)
+    rel = OPS.f32_param(blk.msa, "relative_position_params")
+    shift = 0 if typ == "W" else ws // 2
+    for (b, h, w) in ((2, 24, 40), (3, 8, 16), (1, 64, 8)):
+        x = (torch.randn(b, h, w, c) * 2).cuda().bfloat16()
+        assert OPS.planar_qkv_ok(x, ws)
+        with torch.no_grad():
+            q_i = OPS.ln_linear(x, blk.ln1, blk.msa.embedding_layer)
+            q_p = OPS.ln_linear(x, blk.ln1, blk.msa.embedding_layer, planar8=True)
+            a_i = torch.ops.realcam.window_attention(q_i, rel, head_dim, ws, shift)
+            a_p = torch.ops.realcam.window_attention_planar8(q_p, rel, head_dim, ws, shift)
+        torch.cuda.synchronize()
+        relaid = q_i.reshape(b * h * w, 3 * c // 8, 8).permute(1, 0, 2).contiguous().reshape(-1)
+        assert torch.equal(q_p.reshape(-1), relaid), (head_dim, typ, b, h, w)
+        assert torch.equal(a_p, a_i), (head_dim, typ, b, h, w)
+    x = (torch.randn(2, 24, 40, c) * 2).cuda().bfloat16()
+    outs = []
+    for on in (True, False):
+        OPS.PLANAR_QKV = on
+        try:
+            with torch.no_grad():
+                outs.append(blk(x))                                    # tcm.Block.forward takes the NHWC map
+        finally:
+            OPS.PLANAR_QKV = True
+    assert torch.equal(outs[0], outs[1])
+    assert not OPS.planar_qkv_ok(x.float(), ws) and not OPS.planar_qkv_ok(x, 4)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("c", [32, 64])
 def test_hip_block_mlp_as_one_launch_vs_layer_by_layer(c):
     """rc_ln_mlp (x + fc2(gelu(fc1(ln2(x)))) with register-resident activations) against rc_layernorm + two rc_conv2d launches on the same bf16
