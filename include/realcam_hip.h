@@ -57,8 +57,9 @@ typedef enum rc_out_mode {
                                   out[b][y][x][4c+k] = sum_ij haar[k][i][j] * bf16(conv[b][2y+i][2x+j][c]) with the reference's frozen taps
                                   haar = .5 * {++++, ++--, +-+-, +--+}; the full-resolution map is never written.  Bit-identical to rc_conv2d
                                   (RC_OUT_NHWC) + rc_dwt_forward with those taps.  bf16, ksize 3, one Cin chunk and one cout tile of 32 or
-                                  48 channels (the layers of the wave-autonomous kernel), even height / width, act NONE / RELU / LEAKY,
-                                  no residual / film / mul_plus1 / gate / chan_sums: anything else is RC_ERR_UNSUPPORTED */
+                                  48 channels (the layers of the wave-autonomous kernel), even height / width, act NONE / RELU / LEAKY, or act NONE with a
+                                  residual (NHWC, the conv's own shape: an RCAGroup's closing conv + group skip in front of the DWT, LiteISP down2);
+                                  no film / mul_plus1 / gate / chan_sums: anything else is RC_ERR_UNSUPPORTED */
 } rc_out_mode;
 
 /* ---- library -------------------------------------------------------------------------------- */

@@ -378,10 +378,10 @@ static int conv_build_args(const rc_conv_desc* d, ConvPlan& p, ConvArgs& a, size
     if (dwt) {
         RC_REQUIRE(d->height % 2 == 0 && d->width % 2 == 0, "rc_conv2d: RC_OUT_NHWC_DWT needs even height and width");
         RC_REQUIRE(d->out_dtype == d->dtype && reinterpret_cast<uintptr_t>(d->out) % 16 == 0, "rc_conv2d: RC_OUT_NHWC_DWT: out_dtype must equal dtype, out 16-byte aligned");
-        RC_REQUIRE(!d->residual && !d->mul_plus1 && !d->film_scale && !d->out_scale && !d->chan_sums && !d->in_gate && !d->in1 && !d->in_store && !d->src_h && !d->src_w && !d->cout_tile,
-                   "rc_conv2d: RC_OUT_NHWC_DWT excludes residual / mul_plus1 / film / out_scale / chan_sums / gated input / src_h / cout_tile");
-        if (d->dtype != RC_BF16 || d->ksize != 3 || p.m32 || !(d->act == RC_ACT_NONE || d->act == RC_ACT_RELU || d->act == RC_ACT_LEAKY))
-            return fail(RC_ERR_UNSUPPORTED, "rc_conv2d: RC_OUT_NHWC_DWT is a bf16 3x3 form with act NONE / RELU / LEAKY");
+        RC_REQUIRE(!d->mul_plus1 && !d->film_scale && !d->out_scale && !d->chan_sums && !d->in_gate && !d->in1 && !d->in_store && !d->src_h && !d->src_w && !d->cout_tile,
+                   "rc_conv2d: RC_OUT_NHWC_DWT excludes mul_plus1 / film / out_scale / chan_sums / gated input / src_h / cout_tile");
+        if (d->dtype != RC_BF16 || d->ksize != 3 || p.m32 || !(d->act == RC_ACT_NONE || ((d->act == RC_ACT_RELU || d->act == RC_ACT_LEAKY) && !d->residual)))
+            return fail(RC_ERR_UNSUPPORTED, "rc_conv2d: RC_OUT_NHWC_DWT is a bf16 3x3 form with act NONE / RELU / LEAKY, or act NONE + residual");
     }
     RC_REQUIRE(d->act >= RC_ACT_NONE && d->act <= RC_ACT_RELU_POST, "rc_conv2d: bad act");
     RC_REQUIRE(d->act != RC_ACT_RELU_POST || (d->residual != nullptr && d->mul_plus1 == nullptr && d->film_scale == nullptr && d->chan_sums == nullptr),
@@ -390,7 +390,7 @@ static int conv_build_args(const rc_conv_desc* d, ConvPlan& p, ConvArgs& a, size
     RC_REQUIRE((d->film_scale == nullptr) == (d->film_shift == nullptr), "rc_conv2d: film_scale/film_shift must come together");
     const bool full_tiles = d->cout == p.cout_packed;
     if (d->mul_plus1 || d->residual)   // a lane's 4-channel group must be wholly inside or outside [0, cout)
-        RC_REQUIRE((full_tiles || d->cout % 4 == 0) && d->out_mode == RC_OUT_NHWC, "rc_conv2d: mul_plus1/residual need cout % 4 == 0 and RC_OUT_NHWC");
+        RC_REQUIRE((full_tiles || d->cout % 4 == 0) && (d->out_mode == RC_OUT_NHWC || (dwt && !d->mul_plus1)), "rc_conv2d: mul_plus1/residual need cout % 4 == 0 and RC_OUT_NHWC (residual: or RC_OUT_NHWC_DWT)");
     if (d->chan_sums) RC_REQUIRE(d->out_mode == RC_OUT_NHWC, "rc_conv2d: chan_sums needs RC_OUT_NHWC");
     if (d->out_scale) {
         RC_REQUIRE(d->out_mode == RC_OUT_NHWC && !p.m32, "rc_conv2d: out_scale needs RC_OUT_NHWC and a layer outside the 32x32x16 forms");

@@ -989,9 +989,11 @@ struct ConvDev {
     // dwt_forward_kernel's fma chain with the reference's frozen taps haar[k] = .5 {++++, ++--, +-+-, +--+} over (a b / c d):
     //     ((.5 a +- .5 b) +- .5 c) +- .5 d         (every product exact, so fma(in, tap, s) == s + in * tap)
     // as packed fp32 adds over channel pairs, and stores channels 4 (q NV) .. + 4 NV of the output pixel: 8 NV contiguous bytes.  Bit-identical to the two launches.
+    // F == EP_RES: + the residual (an RCAGroup's closing conv + group skip, then DWT: LiteISP down2), prefetched into rp by res_prefetch as in epilogue_res_pre.
     template <int F>
-    __device__ static __forceinline__ void epilogue_dwt(const ConvArgs& a, int b, int y0, int x0, int tid, f32x4 (&acc)[4][NT], char* st) {
-        static_assert(ES == 2 && NV % 4 == 0 && (F & ~(EP_RELU | EP_LEAKY)) == 0, "bf16, plain / ReLU / LeakyReLU");
+    __device__ static __forceinline__ void epilogue_dwt(const ConvArgs& a, int b, int y0, int x0, int tid, f32x4 (&acc)[4][NT], char* st,
+                                                        const unsigned (&rp)[(F & EP_RES) ? 4 : 1][(F & EP_RES) ? NV / 2 : 1]) {
+        static_assert(ES == 2 && NV % 4 == 0 && (F == 0 || F == EP_RELU || F == EP_LEAKY || F == EP_RES), "bf16; plain / ReLU / LeakyReLU / + residual");
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
         constexpr int REC = Cfg::COUT_TILE * 2 + 8, ROW = kTW * REC;      // bytes of a parked pixel (+ 8: the 2 x 2 reads of 16 lanes at a 2-pixel pitch spread over the banks) / strip row
@@ -1010,6 +1012,13 @@ struct ConvDev {
             if constexpr ((F & EP_LEAKY) != 0) {
 #pragma unroll
                 for (int e = 0; e < NV; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], v[e] * a.act_slope, inf);
+            }
+            if constexpr ((F & EP_RES) != 0) {
+#pragma unroll
+                for (int i = 0; i < NV / 2; ++i) {
+                    v[2 * i] += __uint_as_float(rp[pt][i] << 16);
+                    v[2 * i + 1] += __uint_as_float(rp[pt][i] & 0xffff0000u);
+                }
             }
             char* dst = st + (pt >> 1) * ROW + (16 * (pt & 1) + n) * REC + q * (NV * 2);
 #pragma unroll
@@ -2418,12 +2427,14 @@ __global__ __launch_bounds__(kAutoThreads) void conv_mfma_auto_kernel(const Conv
             if (a.ep_key == D8::EP_SUMS) D8::template epilogue_fast_impl<D8::EP_SUMS, true>(a, cb, y0, x0, sp, 0, ftid, acc, run, flush, rslot);
             else D8::template epilogue_fast_impl<D8::EP_RELU | D8::EP_SUMS, true>(a, cb, y0, x0, sp, 0, ftid, acc, run, flush, rslot);
         } else if constexpr (MODE == 2) {
-            D8::epilogue_res_pre(a, cb, y0, x0, 0, ftid, acc, rpre, gated_out ? s_gate + cb * a.cout : nullptr);
+            if (a.out_mode == RC_OUT_NHWC_DWT) D8::template epilogue_dwt<D8::EP_RES>(a, cb, y0, x0, ftid, acc, s_my, rpre);      // uniform: (conv + skip) -> Haar DWT
+            else D8::epilogue_res_pre(a, cb, y0, x0, 0, ftid, acc, rpre, gated_out ? s_gate + cb * a.cout : nullptr);
         } else {
             if (a.out_mode == RC_OUT_NHWC_DWT) {                      // uniform: conv -> Haar DWT, the strip's output staged through its own (now dead) halo strip
-                if (a.ep_key == D8::EP_RELU) D8::template epilogue_dwt<D8::EP_RELU>(a, cb, y0, x0, ftid, acc, s_my);
-                else if (a.ep_key == D8::EP_LEAKY) D8::template epilogue_dwt<D8::EP_LEAKY>(a, cb, y0, x0, ftid, acc, s_my);
-                else D8::template epilogue_dwt<0>(a, cb, y0, x0, ftid, acc, s_my);
+                const unsigned nor[1][1] = {{0u}};
+                if (a.ep_key == D8::EP_RELU) D8::template epilogue_dwt<D8::EP_RELU>(a, cb, y0, x0, ftid, acc, s_my, nor);
+                else if (a.ep_key == D8::EP_LEAKY) D8::template epilogue_dwt<D8::EP_LEAKY>(a, cb, y0, x0, ftid, acc, s_my, nor);
+                else D8::template epilogue_dwt<0>(a, cb, y0, x0, ftid, acc, s_my, nor);
             } else {
                 D8::template epilogue<true>(a, cb, y0, x0, sp, 0, ftid, acc);
             }
@@ -2682,8 +2693,8 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
         if constexpr (!GATED && FAST && auto_eligible<Cfg>()) {
             using DD = ConvDev<Cfg>;
             static_assert(StripCfg<Cfg>::IN_BYTES >= 2 * kTW * (Cfg::COUT_TILE * 2 + 8), "the strip's output fits its own halo strip");
-            if ((a.ep_key == 0 || a.ep_key == DD::EP_RELU || a.ep_key == DD::EP_LEAKY) && a.n_chunks == 1 && a.n_ct == 1 && a.cout == Cfg::COUT_TILE && a.cin_vec_ok &&
-                a.cin_chunk_ok && n_tiles < (1 << 24)) {
+            if ((a.ep_key == 0 || a.ep_key == DD::EP_RELU || a.ep_key == DD::EP_LEAKY || a.ep_key == DD::EP_RES) && a.n_chunks == 1 && a.n_ct == 1 && a.cout == Cfg::COUT_TILE &&
+                a.cin_vec_ok && a.cin_chunk_ok && n_tiles < (1 << 24)) {
                 if (report(0, legacy_slots)) return RC_OK;
                 constexpr int A_LDS = auto_lds_bytes<Cfg>();
                 const int n_items = a.tiles_x * ((a.H + kWsmTH - 1) / kWsmTH) * a.batch;
@@ -2691,9 +2702,12 @@ int launch_conv_g(const ConvArgs& a, hipStream_t stream) {
                 if (grid > n_items) grid = n_items;
                 grid = (grid + 7) / 8 * 8;
                 static PerDeviceFlag attr_set;
-                if (!attr_set.test_and_set())
+                if (!attr_set.test_and_set()) {
                     RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_auto_kernel<Cfg, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
-                hipLaunchKernelGGL((conv_mfma_auto_kernel<Cfg, 0>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, a);
+                    RC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_auto_kernel<Cfg, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, A_LDS));
+                }
+                if (a.ep_key == DD::EP_RES) hipLaunchKernelGGL((conv_mfma_auto_kernel<Cfg, 2>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, a);      // residual prefetched
+                else hipLaunchKernelGGL((conv_mfma_auto_kernel<Cfg, 0>), dim3((unsigned)grid), dim3(kAutoThreads), A_LDS, stream, a);
                 RC_HIP_CHECK(hipGetLastError());
                 return RC_OK;
             }

@@ -100,6 +100,10 @@ class Sequential(nn.Sequential):
                     a = ops.pixel_shuffle2(a)
                 i = j
                 continue
+            if isinstance(m, RCAGroup) and i + 1 < n and isinstance(mods[i + 1], DWTForward) and not isinstance(a, (tuple, list)):
+                a = m._nhwc(a, dwt=mods[i + 1])              # the group's closing conv + skip -> Haar DWT in one launch where the kernel has that form
+                i += 2
+                continue
             if isinstance(m, (nn.Dropout, nn.Identity)):
                 i += 1
                 continue
@@ -322,16 +326,29 @@ class RCAGroup(HipModule):
         RG.append(conv(out_channels, out_channels, mode='C'))
         self.rg = nn.Sequential(*RG)
 
-    def _nhwc(self, a):
+    def _nhwc(self, a, dwt=None):
+        """dwt: the networks.DWTForward that follows the group (LiteISP `down2` / `down3`): applied here, inside the closing conv's launch where that form exists."""
+        if dwt is not None:
+            fused = self._run(a, dwt)
+            return fused if fused is not None else dwt._nhwc(self._run(a))
+        return self._run(a)
+
+    def _run(self, a, dwt=None):
         blocks = list(self.rg)
         last = blocks[-1]
         if not isinstance(last, Conv2d) or not all(isinstance(b, RCABlock) for b in blocks[:-1]):
             raise NotImplementedError("RCAGroup: unexpected layout")
         if not ops.FUSE_GATE or (len(blocks) > 1 and all(blk._early(a) for blk in blocks[:-1])):
+            if dwt is not None and not ops.conv_dwt_ok(a, last, dwt, residual=True):
+                return None
             y = a                                    # early-gate schedule: every block is two plain launches, nothing is carried between blocks
             for blk in blocks[:-1]:
                 y = blk._nhwc(y)
+            if dwt is not None:
+                return last._nhwc(y, residual=a, out_mode=ops.RC_OUT_NHWC_DWT)
             return last._nhwc(y, residual=a)
+        if dwt is not None:
+            return None
         # fused: each block's "res*gate + skip" is formed inside the NEXT conv's input staging
         skip, r, gate = a, None, None
         for blk in blocks[:-1]:

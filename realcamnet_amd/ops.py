@@ -614,10 +614,12 @@ FUSE_DWT = os.environ.get("RC_FUSE_DWT", "1") != "0"   # conv [+ act] -> DWTForw
 _HAAR_TAPS = (0.5, 0.5, 0.5, 0.5, 0.5, 0.5, -0.5, -0.5, 0.5, -0.5, 0.5, -0.5, 0.5, -0.5, -0.5, 0.5)
 
 
-def conv_dwt_ok(x: torch.Tensor, conv, dwt, act: Optional[str] = None, slope: float = 0.0) -> bool:
-    """Can `conv [+ act] -> dwt` (networks.Conv2d, networks.DWTForward; upstream models/LiteISP.py:1950-1953 `down1`) run as ONE rc_conv2d launch with
-    RC_OUT_NHWC_DWT?  The kernel form exists for the bf16 3x3 layers of the wave-autonomous kernel (cin == cout == 32 or 48) and computes with the
-    reference's frozen Haar taps, so the module's taps must BE those (checked once per write of the tap tensor)."""
+def conv_dwt_ok(x: torch.Tensor, conv, dwt, act: Optional[str] = None, slope: float = 0.0, residual: bool = False) -> bool:
+    """Can `conv [+ act | + residual] -> dwt` (networks.Conv2d, networks.DWTForward; upstream models/LiteISP.py:1950-1958: `down1`'s closing conv, `down2`'s RCAGroup
+    = conv + group skip) run as ONE rc_conv2d launch with RC_OUT_NHWC_DWT?  The kernel form exists for the bf16 3x3 layers of the wave-autonomous kernel
+    (cin == cout == 32 or 48) and computes with the reference's frozen Haar taps, so the module's taps must BE those (checked once per write of the tap tensor)."""
+    if residual and act is not None:
+        return False
     if not FUSE_DWT or x.dtype != torch.bfloat16 or x.dim() != 4 or conv.weight.dim() != 4:
         return False
     cout, cin, kh, kw = conv.weight.shape

@@ -253,6 +253,30 @@ def test_conv_then_haar_dwt_in_one_launch_equals_the_two_launches(hip, c):
                 ops.FUSE_DWT = True
             assert sum(1 for n in log if "haar_dwt" in n) == (0 if on else 1) and sum(1 for n in log if "conv2d" in n) == 1, log
         assert torch.equal(outs[0], outs[1])
+    # + residual (an RCAGroup's closing conv + group skip in front of the DWT, LiteISP down2): kernel 6's residual mode, the same bits as the two launches
+    for (B, H, W) in ((2, 22, 70), (1, 130, 260), (3, 8, 32)):
+        x = torch.randn(B, H, W, c, generator=g).to(DEV, torch.bfloat16)
+        res = torch.randn(B, H, W, c, generator=g).to(DEV, torch.bfloat16)
+        assert ops.conv_dwt_ok(x, conv, dwt, residual=True) and not ops.conv_dwt_ok(x, conv, dwt, act="relu", residual=True)
+        with torch.no_grad():
+            want = ops.dwt_forward(ops.conv2d(x, conv, residual=res), dwt)
+            got = ops.conv2d(x, conv, residual=res, out_mode=ops.RC_OUT_NHWC_DWT)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (c, B, H, W, "residual")
+    grp = N.RCAGroup(c, c, nb=2).to(DEV, torch.bfloat16).eval()
+    x = torch.randn(2, 24, 64, c, generator=g).to(DEV, torch.bfloat16)
+    sq = N.Sequential(grp, dwt)
+    outs = []
+    for on in (True, False):
+        ops.FUSE_DWT = on
+        log = []
+        try:
+            with _OpLog(log), torch.no_grad():
+                outs.append(sq._nhwc(x))
+        finally:
+            ops.FUSE_DWT = True
+        assert sum(1 for n in log if "haar_dwt" in n) == (0 if on else 1), log
+    assert torch.equal(outs[0], outs[1])
     # odd sizes and other layers have no such form: the peephole declines, the C ABI says so
     assert not ops.conv_dwt_ok(torch.zeros(1, 9, 32, c, device=DEV, dtype=torch.bfloat16), conv, dwt)
     assert not ops.conv_dwt_ok(torch.zeros(1, 8, 32, c, device=DEV), conv, dwt)
