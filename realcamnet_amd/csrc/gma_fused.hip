@@ -142,6 +142,18 @@ template <int C> __device__ __forceinline__ void store_act(bf16_t* p, int g, con
     if constexpr (Act<C>::TAIL) *reinterpret_cast<uint2*>(p + 32 * Act<C>::KS + 4 * g) = a.t;
 }
 
+// s + the values of the three other lane groups (lanes n, n + 16, n + 32, n + 48): the two __shfl_xor steps of layernorm80 as gfx950's row / half swaps.
+// Operand order differs from own + partner only by commutation, so the sums are the same bits; no lane-index registers (hipcc kept the bpermute
+// addresses of __shfl_xor alive across the whole tile loop: three spilled VGPRs) and no LDS crossbar traffic.  Inline asm because the builtin's
+// second result is mis-lowered by this hipcc (both results come back as the first); s_nop on both sides: the swap is opaque to the hazard recogniser.
+__device__ __forceinline__ float sum_lane_groups(float s) {
+    float a = s, b = s;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    s = a + b; a = s; b = s;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 // nn.LayerNorm over the 80 channels of each token (two-pass like rc_layernorm: mean, then centred second moment);
 // gamma / beta in natural channel order at LDS address gb (gamma[80] | beta[80])
 __device__ __forceinline__ void layernorm80(const Act<kC> (&in)[kNT], Act<kC> (&out)[kNT], const float* gb, int g, float eps) {
@@ -154,12 +166,12 @@ __device__ __forceinline__ void layernorm80(const Act<kC> (&in)[kNT], Act<kC> (&
         const f32x4 v0 = up_lo(in[nt].f[0]), v1 = up_hi(in[nt].f[0]), v2 = up_lo(in[nt].f[1]), v3 = up_hi(in[nt].f[1]), v4 = up_tail(in[nt].t);
         const f32x4 sv = ((v0 + v1) + (v2 + v3)) + v4;
         float s = (sv[0] + sv[1]) + (sv[2] + sv[3]);
-        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        s = sum_lane_groups(s);
         const float mean = s / (float)kC;
         const f32x4 d0 = v0 - mean, d1 = v1 - mean, d2 = v2 - mean, d3 = v3 - mean, d4 = v4 - mean;
         const f32x4 qv = ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + d4 * d4;
         float q = (qv[0] + qv[1]) + (qv[2] + qv[3]);
-        q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+        q = sum_lane_groups(q);
         const float rstd = 1.f / sqrtf(q / (float)kC + eps);
         out[nt].f[0] = pack_pair(d0 * rstd * g0 + e0, d1 * rstd * g1 + e1);
         out[nt].f[1] = pack_pair(d2 * rstd * g2 + e2, d3 * rstd * g3 + e3);
@@ -799,12 +811,12 @@ __global__ __launch_bounds__(AG_THREADS) void gma_agg_kernel(AggArgs a) {
             for (int c = 0; c < 4; ++c) {
                 const f32x4 tt = d[o][c] + 0.f;
                 float s = (tt[0] + tt[1]) + (tt[2] + tt[3]);
-                s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+                s = sum_lane_groups(s);
                 const float mean = s / 16.f;
                 const f32x4 dd = tt - mean;
                 const f32x4 d2 = dd * dd;
                 float var = (d2[0] + d2[1]) + (d2[2] + d2[3]);
-                var += __shfl_xor(var, 16); var += __shfl_xor(var, 32);
+                var = sum_lane_groups(var);
                 const float rstd = 1.f / sqrtf(var / 16.f + 1e-5f);
                 f32x4 v = dd * rstd * lg + lb;
 #pragma unroll
@@ -957,18 +969,6 @@ struct QaArgs {
     const float* pw; const float* pwl;
     const float* bn_scale; const float* bn_shift; const float* ln_g; const float* ln_b;
 };
-
-// s + the values of the three other lane groups (lanes n, n + 16, n + 32, n + 48): the two __shfl_xor steps of layernorm80 as gfx950's row / half swaps.
-// Operand order differs from own + partner only by commutation, so the sums are the same bits; no lane-index registers (hipcc kept the bpermute
-// addresses of __shfl_xor alive across the whole tile loop: three spilled VGPRs) and no LDS crossbar traffic.  Inline asm because the builtin's
-// second result is mis-lowered by this hipcc (both results come back as the first); s_nop on both sides: the swap is opaque to the hazard recogniser.
-__device__ __forceinline__ float sum_lane_groups(float s) {
-    float a = s, b = s;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    s = a + b; a = s; b = s;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    return a + b;
-}
 
 // one token column tile of layernorm80 (same expressions, same order; gamma / beta fetched where they are used: 128 VGPRs to live in)
 __device__ __forceinline__ void ln80_one(const Act<kC>& in, Act<kC>& out, const float* gb, int g, float eps) {
@@ -2034,13 +2034,13 @@ __device__ __forceinline__ void layernorm_c(const Act<C> (&in)[kNT], Act<C> (&ou
 #pragma unroll
         for (int s = 0; s < KS; ++s) { v[2 * s] = up_lo(in[nt].f[s]); v[2 * s + 1] = up_hi(in[nt].f[s]); sv += v[2 * s] + v[2 * s + 1]; }
         float sm = (sv[0] + sv[1]) + (sv[2] + sv[3]);
-        sm += __shfl_xor(sm, 16); sm += __shfl_xor(sm, 32);
+        sm = sum_lane_groups(sm);
         const float mean = sm / (float)C;
         f32x4 qv = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 2 * KS; ++i) { v[i] = v[i] - mean; qv += v[i] * v[i]; }
         float q = (qv[0] + qv[1]) + (qv[2] + qv[3]);
-        q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+        q = sum_lane_groups(q);
         const float rstd = 1.f / sqrtf(q / (float)C + eps);
 #pragma unroll
         for (int s = 0; s < KS; ++s) out[nt].f[s] = pack_pair(v[2 * s] * rstd * gam[2 * s] + bet[2 * s], v[2 * s + 1] * rstd * gam[2 * s + 1] + bet[2 * s + 1]);

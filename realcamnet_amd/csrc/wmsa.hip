@@ -121,6 +121,25 @@ __device__ __forceinline__ void wm_mma(const uint4& a, const uint4& b, f32x4& c)
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// max / sum over the four lane groups of a query (lanes n, n + 16, n + 32, n + 48) by gfx950's row / half swaps instead of two __shfl_xor steps each: a
+// ds_bpermute is an LDS round trip the wave sits out (16 of them per window and head, in a dependent chain with three waves per SIMD to cover it).  Operand order differs
+// from own-op-partner only by commutation: the same bits.  Inline asm with s_nop on both sides: this hipcc mis-lowers the builtin's second result and the swap is opaque
+// to the hazard recogniser (csrc/gma_fused.hip sum_lane_groups).
+__device__ __forceinline__ float wm_sum_groups(float s) {
+    float a = s, b = s;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    s = a + b; a = s; b = s;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float wm_max_groups(float s) {
+    float a = s, b = s;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    s = fmaxf(a, b); a = s; b = s;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+
 template <int HD>
 __global__ __launch_bounds__(kWmWaves * 64, 2) void wmsa_mfma_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ relpos,
                                                                         bf16_t* __restrict__ out, int batch, int H, int W, int C, int shift,
@@ -245,8 +264,7 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void wmsa_mfma_kernel(const bf16_
                 sc[mt] = v;
                 mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = wm_max_groups(mx);
             float den = 0.f;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
@@ -256,8 +274,7 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void wmsa_mfma_kernel(const bf16_
                 den += (e[0] + e[1]) + (e[2] + e[3]);
                 sc[mt] = e;
             }
-            den += __shfl_xor(den, 16);
-            den += __shfl_xor(den, 32);
+            den = wm_sum_groups(den);
             inv_den[nt] = 1.f / den;
 #pragma unroll
             for (int st = 0; st < 2; ++st)
