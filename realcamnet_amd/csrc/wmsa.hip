@@ -11,6 +11,7 @@
 // (2ws-1)^2 bias table beside them; every lane computes its ws^2 scores (hd FMAs each), the max-subtracted softmax
 // exactly as torch does, then the weighted sum of V.  The work is tiny next to the block's Linear layers
 // (2 * ws^2 * C FMAs per token vs 12 * C^2 MACs), so plain FMAs are fine.
+#include <type_traits>
 #include "common.hpp"
 
 namespace rc {
@@ -243,44 +244,51 @@ __global__ __launch_bounds__(kWmWaves * 64, 2) void wmsa_mfma_kernel(const bf16_
         const bool q_side_c = (n & 7) >= WS - shift;                    // query column side (queries 16 nt + n: p2 = n & 7)
         uint4 pf[4][2];                                                 // P^T fragments: [query tile][K-step]
         float inv_den[4];
+        // Two copies behind ONE uniform branch: left as a condition inside the loop, the wrap mask was if-converted into 64 selects (and 48 operand-quieting v_max
+        // in front of the row maximum) per (window, head) for the 99 % of windows that do not wrap -- a sixth of this kernel's vector instructions.
+        auto softmax = [&](auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            f32x4 sc[4];
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x4 sc[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) { sc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; wm_mma(kf[mt], qf[nt], sc[mt]); }
-            const float* brow = s_bias + (16 * nt + n) * kWmBiasRow + 4 * g;
-            float mx = -__builtin_inff();
+                for (int mt = 0; mt < 4; ++mt) { sc[mt] = f32x4{0.f, 0.f, 0.f, 0.f}; wm_mma(kf[mt], qf[nt], sc[mt]); }
+                const float* brow = s_bias + (16 * nt + n) * kWmBiasRow + 4 * g;
+                float mx = -__builtin_inff();
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const float4 bb = *reinterpret_cast<const float4*>(brow + 16 * mt);
-                f32x4 v = sc[mt] * scale + f32x4{bb.x, bb.y, bb.z, bb.w};
-                if (last_r | last_c) {                                  // wave-uniform
-                    // rows: key j1 = 4 (mt >> 1) + g >= 4  <=>  mt >= 2;  query p1 = 2 nt + (n >> 3) >= 4  <=>  nt >= 2   (shift = 4)
-                    const bool mr = last_r && ((mt >> 1) != (nt >> 1));
-                    // columns: key j2 = 4 (mt & 1) + j >= 4  <=>  mt odd
-                    const bool mc = last_c && (((mt & 1) != 0) != q_side_c);
-                    if (mr || mc) v = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+                for (int mt = 0; mt < 4; ++mt) {
+                    const float4 bb = *reinterpret_cast<const float4*>(brow + 16 * mt);
+                    f32x4 v = sc[mt] * scale + f32x4{bb.x, bb.y, bb.z, bb.w};
+                    if constexpr (MASKED) {
+                        // rows: key j1 = 4 (mt >> 1) + g >= 4  <=>  mt >= 2;  query p1 = 2 nt + (n >> 3) >= 4  <=>  nt >= 2   (shift = 4)
+                        const bool mr = last_r && ((mt >> 1) != (nt >> 1));
+                        // columns: key j2 = 4 (mt & 1) + j >= 4  <=>  mt odd
+                        const bool mc = last_c && (((mt & 1) != 0) != q_side_c);
+                        if (mr || mc) v = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+                    }
+                    sc[mt] = v;
+                    mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
                 }
-                sc[mt] = v;
-                mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+                mx = wm_max_groups(mx);
+                float den = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    f32x4 e;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(sc[mt][j] - mx);
+                    den += (e[0] + e[1]) + (e[2] + e[3]);
+                    sc[mt] = e;
+                }
+                den = wm_sum_groups(den);
+                inv_den[nt] = 1.f / den;
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+                    pf[nt][st] = make_uint4(wm_pk(sc[2 * st][0], sc[2 * st][1]), wm_pk(sc[2 * st][2], sc[2 * st][3]),
+                                            wm_pk(sc[2 * st + 1][0], sc[2 * st + 1][1]), wm_pk(sc[2 * st + 1][2], sc[2 * st + 1][3]));
             }
-            mx = wm_max_groups(mx);
-            float den = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                f32x4 e;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(sc[mt][j] - mx);
-                den += (e[0] + e[1]) + (e[2] + e[3]);
-                sc[mt] = e;
-            }
-            den = wm_sum_groups(den);
-            inv_den[nt] = 1.f / den;
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-                pf[nt][st] = make_uint4(wm_pk(sc[2 * st][0], sc[2 * st][1]), wm_pk(sc[2 * st][2], sc[2 * st][3]),
-                                        wm_pk(sc[2 * st + 1][0], sc[2 * st + 1][1]), wm_pk(sc[2 * st + 1][2], sc[2 * st + 1][3]));
-        }
+        };
+        if (last_r | last_c) softmax(std::true_type{});                 // wave-uniform
+        else softmax(std::false_type{});
         __builtin_amdgcn_wave_barrier();                                // the slab writes above are complete (one wave's LDS ops are in order)
         // ---- O^T[d][query] = sum_key V^T[d][key] P^T[key][query]
 #pragma unroll
