@@ -166,12 +166,12 @@ __device__ __forceinline__ void layernorm80(const Act<kC> (&in)[kNT], Act<kC> (&
         const f32x4 v0 = up_lo(in[nt].f[0]), v1 = up_hi(in[nt].f[0]), v2 = up_lo(in[nt].f[1]), v3 = up_hi(in[nt].f[1]), v4 = up_tail(in[nt].t);
         const f32x4 sv = ((v0 + v1) + (v2 + v3)) + v4;
         float s = (sv[0] + sv[1]) + (sv[2] + sv[3]);
-        s = sum_lane_groups(s);
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);          // (sum_lane_groups here costs gma_tail<192> three spilled registers: the swaps' operands are tied pairs)
         const float mean = s / (float)kC;
         const f32x4 d0 = v0 - mean, d1 = v1 - mean, d2 = v2 - mean, d3 = v3 - mean, d4 = v4 - mean;
         const f32x4 qv = ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + d4 * d4;
         float q = (qv[0] + qv[1]) + (qv[2] + qv[3]);
-        q = sum_lane_groups(q);
+        q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
         const float rstd = 1.f / sqrtf(q / (float)kC + eps);
         out[nt].f[0] = pack_pair(d0 * rstd * g0 + e0, d1 * rstd * g1 + e1);
         out[nt].f[1] = pack_pair(d2 * rstd * g2 + e2, d3 * rstd * g3 + e3);
