@@ -474,6 +474,15 @@ int rc_gma_aggregate(const void* d_qkv, void* d_qkvp, void* d_loc, int batch, in
 int rc_chain_pack_weights_natural(const float* w, int cin, int cout, void* dst);   /* host; rc_chain_packed_bytes(cin, cout) bytes; 16 | cin, 16 | cout */
 size_t rc_gma_toeplitz_bytes(void);
 int rc_gma_toeplitz_pack(const float* dw3, const float* dw5, const float* dw7, const float* dwl, void* dst);   /* host */
+/* rc_gma_in_cpe (ABI 14): the cfg3 net's `gma_in` (Conv1x1 192 -> 80, realcamnet_amd/LiteISP.py) followed by the block's ConvPosEnc (depth-wise 3x3 + identity,
+ * groupmix.py:203-217, :293) as ONE launch: d_x (B,H,W,80) = a + dw3x3(a) + b_cpe, a = W_in d_d1 + b_in rounded to bf16 (zero outside the image: the depth-wise
+ * convolution's padding); the 80-channel map a never reaches HBM.  bf16.  d_w_in_natural: rc_chain_pack_weights_natural(192 -> 80) fragments; d_b_in / d_b_cpe (80)
+ * fp32 or NULL; d_toeplitz3: 3 * 80 KiB from rc_dw_toeplitz_pack(taps, 3, 80, .) (host; taps tap-major (9, 80) fp32).  The depth-wise sums are formed in the
+ * matrix pipe's order and the 1x1 sums add the bias last: equal to rc_conv2d + rc_dwconv2d on > 99.8 % of the values, the rest within a few bf16 ulps of the
+ * intermediate (tested); bitwise stable from run to run (tested). */
+int rc_dw_toeplitz_pack(const float* taps, int K, int n_ch, void* dst);        /* host; K * n_ch KiB; K = 3, 5 or 7 */
+int rc_gma_in_cpe(const void* d_d1, const void* d_w_in_natural, const float* d_b_in, const void* d_toeplitz3, const float* d_b_cpe, void* d_x,
+                  int batch, int H, int W, void* stream);
 int rc_gma_qkv_aggregate(const void* d_x, const void* d_wq_natural, const float* d_bq, const float* d_ln1_gamma, const float* d_ln1_beta, float eps,
                          void* d_qkvp, void* d_loc, int batch, int H, int W, const void* d_toeplitz, const float* d_pw, const float* d_pwl,
                          const float* d_bn_scale, const float* d_bn_shift, const float* d_ln_g, const float* d_ln_b, float* d_kmax, void* stream);

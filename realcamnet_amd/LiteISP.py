@@ -721,4 +721,4 @@ class LiteISPNet_GFM_LSC_GMA(LiteISPNet_GFM_LSC):
         self.gma_out = N.Conv2d(gma_dim, c1, 1, 1, 0)
 
     def _refine_d1(self, d1):
-        return self.gma._nhwc(self.gma_in._nhwc(d1), post=(self.gma_out, d1))        # gma_out(GMA(.)) + d1 in the block's last launch
+        return self.gma._nhwc(d1, pre=self.gma_in, post=(self.gma_out, d1))          # gma_in + ConvPosEnc in the block's first launch, gma_out(GMA(.)) + d1 in its last

@@ -145,6 +145,8 @@ _SIGS = {
     "rc_chain_pack_weights_natural": (C.c_int, [_P, _I, _I, _P]),
     "rc_gma_toeplitz_bytes": (_SZ, []),
     "rc_gma_toeplitz_pack": (C.c_int, [_P, _P, _P, _P, _P]),
+    "rc_dw_toeplitz_pack": (C.c_int, [_P, _I, _I, _P]),
+    "rc_gma_in_cpe": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "rc_gma_qkv_aggregate": (C.c_int, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rc_cat_linear": (C.c_int, [_P, _P, _P, _P, _P, C.c_longlong, _I, _P, _P, _P]),
     "rc_gdn_chain": (C.c_int, [_P, _P, _P, C.c_longlong, _I, _P, _P, _I, _P]),

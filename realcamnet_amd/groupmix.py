@@ -302,11 +302,32 @@ class GMA_Block(nn.Module):
         return (ops.FUSE_GMA and a.dtype == torch.bfloat16 and a.shape[-1] == 80 and self.att.num_heads == 8 and
                 self.mlp.fc1.out_features == 320 and self.att.qkv.in_features == 80 and self.norm1.eps == self.norm2.eps)
 
-    def _nhwc(self, a, post=None):
-        """post = (conv1x1 module, residual): fold `conv(block(a)) + residual` into the block's last launch (the cfg3 net's gma_out)."""
+    def _entry(self, a, pre):
+        """cpe(pre(a)): the 1x1 convolution in front of the block (the cfg3 net's gma_in, 192 -> 80) and ConvPosEnc as ONE launch (realcam::gma_in_cpe) where that
+        form exists (bf16, 192 -> 80, the block's fused path), else the two launches."""
+        w = pre.weight
+        if (ops.FUSE_GMA_ENTRY and a.dtype == torch.bfloat16 and tuple(w.shape) == (80, 192, 1, 1) and tuple(self.cpe.proj.weight.shape) == (80, 1, 3, 3) and
+                a.shape[0] * a.shape[1] * a.shape[2] > 0 and a.shape[1] * a.shape[2] * 192 * 2 < 2 ** 31):
+            c = ops._cache(self.cpe)
+            key = ops._key(self.cpe.proj.weight)
+            hit = c.get("toeplitz3")
+            if hit is None or hit[0] != key:
+                hit = (key, torch.ops.realcam.dw_toeplitz_pack(ops.dw_taps(self.cpe.proj.weight.detach().float()).to(a.device), 3))
+                c["toeplitz3"] = hit
+            return torch.ops.realcam.gma_in_cpe(ops._req(a, "gma_in input"), ops.packed_chain_natural(pre), ops.f32_param(pre, "bias") if pre.bias is not None else None,
+                                                hit[1], ops.f32_param(self.cpe.proj, "bias") if self.cpe.proj.bias is not None else None)
+        return self.cpe._nhwc(pre._nhwc(a))
+
+    def _nhwc(self, a, post=None, pre=None):
+        """post = (conv1x1 module, residual): fold `conv(block(a)) + residual` into the block's last launch (the cfg3 net's gma_out).
+        pre = the conv1x1 module in front of the block (gma_in): `a` is ITS input, and conv + ConvPosEnc run as one launch where possible."""
         if self.training:
             raise RuntimeError("realcamnet_amd is an inference path: call .eval() first")
-        x = self.cpe._nhwc(a)
+        if pre is not None:
+            x = self._entry(a, pre)
+            a = x                                   # (only its dtype / width matter below)
+        else:
+            x = self.cpe._nhwc(a)
         if self._fusable(a) and (post is None or post[0].weight.shape[0] == 192):
             R = torch.ops.realcam
             f32 = ops.f32_param

@@ -171,6 +171,7 @@ def packed_chain_natural(mod):
 FUSE_GMA = True
 # LayerNorm1 + qkv + Aggregator as one launch (rc_gma_qkv_aggregate: qkv never reaches HBM) instead of rc_gma_ln_qkv + rc_gma_aggregate; same bits.
 FUSE_GMA_FRONT = os.environ.get("RC_GMA_FRONT", "1") != "0"
+FUSE_GMA_ENTRY = os.environ.get("RC_GMA_ENTRY", "1") != "0"    # gma_in (1x1 192 -> 80) + ConvPosEnc in one launch (realcam::gma_in_cpe); 0: two launches (A/B, tests)
 
 
 class _ConvView:

@@ -700,6 +700,21 @@ def _toep_launch(out, dw3, dw5, dw7, dwl):
 define("gma_toeplitz_pack(Tensor dw3, Tensor dw5, Tensor dw7, Tensor dwl) -> Tensor",
        lambda dw3, *a: dw3.new_empty((lib().rc_gma_toeplitz_bytes(),), dtype=torch.uint8), _toep_launch)
 
+def _dwtoep_launch(out, taps, ksize):
+    t = np.ascontiguousarray(taps.detach().float().cpu().numpy())
+    dst = np.empty(out.numel(), dtype=np.uint8)
+    check(lib().rc_dw_toeplitz_pack(t.ctypes.data, int(ksize), t.shape[1], dst.ctypes.data), "rc_dw_toeplitz_pack")
+    out.copy_(torch.from_numpy(dst))
+
+
+define("dw_toeplitz_pack(Tensor taps, int ksize) -> Tensor",                       # taps: tap-major (K * K, n_ch) fp32 (ops.dw_taps)
+       lambda taps, ksize: taps.new_empty((int(ksize) * taps.shape[1] * 1024,), dtype=torch.uint8), _dwtoep_launch)
+
+define("gma_in_cpe(Tensor d1, Tensor w_in_natural, Tensor? b_in, Tensor toeplitz3, Tensor? b_cpe) -> Tensor",      # (B, H, W, 192) -> (B, H, W, 80)
+       lambda d1, *a: d1.new_empty((*d1.shape[:3], 80)),
+       lambda out, d1, w, bi, toep, bc: check(lib().rc_gma_in_cpe(d1.data_ptr(), w.data_ptr(), _p(bi), toep.data_ptr(), _p(bc), out.data_ptr(), d1.shape[0], d1.shape[1],
+                                                                  d1.shape[2], _stream()), "rc_gma_in_cpe"))
+
 define("gma_qkv_aggregate(Tensor x, Tensor wq_natural, Tensor? bq, Tensor ln1_gamma, Tensor ln1_beta, float eps, Tensor toeplitz, "
        "Tensor pw, Tensor pwl, Tensor bn_scale, Tensor bn_shift, Tensor ln_gamma, Tensor ln_beta) -> (Tensor, Tensor, Tensor)",
        lambda x, *a: (x.new_empty((12, *x.shape[:3], 16)), x.new_empty((*x.shape[:3], 16)),                  # x: (B, H, W, 80)

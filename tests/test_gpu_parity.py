@@ -205,6 +205,44 @@ def test_wave_autonomous_kernels_equal_the_kernels_they_replace(hip, c):
         lib.rc_debug_set(b"persist_auto", 1)
 
 
+def test_gma_in_and_conv_pos_enc_as_one_launch(hip):
+    """rc_gma_in_cpe (ABI 14): the cfg3 net's gma_in (1x1 192 -> 80) + the block's ConvPosEnc in one launch.  Against the two launches on the same bf16 input: the 1x1 sums
+    start from zero and add the bias last (rc_conv2d starts from the bias) and the depth-wise sums are formed in the matrix pipe's order, so equality is up to a few bf16 ulps of the
+    intermediate on < 0.2 % of the values; run-to-run it must be BITWISE stable (the first build of this kernel was not: its 1x1 stage alternated two accumulators, each revisited
+    one MFMA later -- DESIGN 4.7); ragged sizes; and the net's _refine_d1 must take it."""
+    import realcamnet_amd.groupmix as G
+    torch.manual_seed(3)
+    blk = G.GMA_Block(80, 8).to(DEV, torch.bfloat16).eval()
+    pre = N.Conv2d(192, 80, 1, 1, 0).to(DEV, torch.bfloat16).eval()
+    assert ops.FUSE_GMA_ENTRY
+    for (B, H, W) in ((1, 8, 32), (2, 23, 70), (1, 130, 260), (8, 136, 240)):
+        d1 = torch.randn(B, H, W, 192, device=DEV).to(torch.bfloat16)
+        with torch.no_grad():
+            want = blk.cpe._nhwc(pre._nhwc(d1))
+            got = blk._entry(d1, pre)
+            again = [blk._entry(d1, pre) for _ in range(6)]
+        torch.cuda.synchronize()
+        assert got.shape == want.shape == (B, H, W, 80)
+        diff = (got.float() - want.float()).abs()
+        # a one-ulp difference of the intermediate `a` (|a| <~ 4: ulp 2^-6) reaches the output through the identity and nine taps: a few ulps of a, never more
+        assert float(diff.max()) <= 2.0 ** -5 and rel_err(got.float().cpu(), want.float().cpu()) < 1e-2, (B, H, W, float(diff.max()))
+        assert float((got != want).float().mean()) < 2e-3, (B, H, W, float((got != want).float().mean()))
+        assert all(torch.equal(a_, got) for a_ in again), (B, H, W)
+    d1 = torch.randn(2, 24, 64, 192, device=DEV).to(torch.bfloat16)
+    post = N.Conv2d(80, 192, 1, 1, 0).to(DEV, torch.bfloat16).eval()
+    outs = []
+    for on in (True, False):
+        ops.FUSE_GMA_ENTRY = on
+        log = []
+        try:
+            with _OpLog(log), torch.no_grad():
+                outs.append(blk._nhwc(d1, pre=pre, post=(post, d1)))
+        finally:
+            ops.FUSE_GMA_ENTRY = True
+        assert sum(1 for n in log if "gma_in_cpe" in n) == (1 if on else 0), log
+    assert rel_err(outs[0].float().cpu(), outs[1].float().cpu()) < 2e-2
+
+
 class _OpLog(torch.utils._python_dispatch.TorchDispatchMode):
     """Names of the realcam:: ops dispatched inside the context."""
 
