@@ -34,6 +34,7 @@ def timeit(name, fn, n=10):
 with torch.no_grad():
     t = timeit("gma_in 1x1 192->80", lambda: gin._nhwc(d1))
     x = timeit("cpe dw3x3 + identity", lambda: blk.cpe._nhwc(t))
+    timeit("gma_in + cpe in ONE launch", lambda: blk._entry(d1, gin))
     wq, bq = ops.packed_chain(blk.att.qkv)
     qkv = timeit("ln_qkv", lambda: R.gma_ln_qkv(x, wq, bq, f32(blk.norm1, "weight"), f32(blk.norm1, "bias"), 1e-5))
     qkvp, loc, kmax = timeit("aggregate (+ per-channel max of k)", lambda: blk.att.aggregator._run_fused(qkv))
@@ -45,4 +46,5 @@ with torch.no_grad():
     wo, bo = ops.packed_chain(gout)
     timeit("tail (+ out conv)", lambda: R.gma_tail(qkvp, convv, loc, x, ktv, wp, bp, f32(blk.norm2, "weight"), f32(blk.norm2, "bias"), 1e-5,
                                                    w1, b1, w2, b2, d1, wo, bo))
-    timeit("whole block (+in/out conv)", lambda: blk._nhwc(gin._nhwc(d1), post=(gout, d1)))
+    timeit("whole block (+in/out conv), entry as two launches", lambda: blk._nhwc(gin._nhwc(d1), post=(gout, d1)))
+    timeit("whole block (+in/out conv)", lambda: blk._nhwc(d1, pre=gin, post=(gout, d1)))
