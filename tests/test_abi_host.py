@@ -360,3 +360,29 @@ def test_sum_slot_query_follows_the_dispatch():
         lib.rc_debug_set(b"persist", 1); lib.rc_debug_set(b"persist_auto", 1); lib.rc_debug_set(b"sums_compact", 1)
     d = _lib.ConvDesc()
     assert lib.rc_conv_sum_slots(C.byref(d)) == -1 and lib.rc_conv_sum_slots(None) == -1
+
+
+def test_no_new_mfma_accumulator_revisit_after_one_mfma(tmp_path):
+    """on gfx950 an MFMA whose SrcC is the result of the MFMA issued TWO slots earlier (two accumulators alternating) read stale partial sums in the first build of
+    rc_gma_in_cpe -- 40 of 40 launches differed from the first; each accumulator's K-steps back to back: 0 of 80 (tools/ubench/gi_experiment.hip).  Neither the hardware interlock nor
+    hipcc's hazard recogniser covers it, and the instruction scheduler is free to produce that order again, so the ISA of the fused GroupMix / chain kernels is scanned here
+    (tools/mfma_hazard_scan.py): rc_gma_in_cpe's kernel must have NO revisit with one MFMA and fewer than four other instructions in between, and the set of kernels that have one is
+    frozen at the two that are stress-tested bitwise stable (gma_tail<192>, gma_qkv_agg: tools/dbg/block_stress.py, 300 forwards at the cfg3 size)."""
+    import os, shutil, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from mfma_hazard_scan import scan
+    from realcamnet_amd import build
+    out = tmp_path / "gma_fused.s"
+    flags = [f for f in build.FLAGS if not f.startswith("-Rpass")]
+    r = subprocess.run([hipcc, *flags, "-S", "--cuda-device-only", "-o", str(out), os.path.join(ROOT, "realcamnet_amd", "csrc", "gma_fused.hip")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    close = {k: [p for p in v if p[0] == 1 and p[1] < 4] for k, v in scan(str(out), 1).items()}
+    close = {k: v for k, v in close.items() if v}
+    assert not any("gma_in_cpe" in k for k in close), close
+    known = ("gma_tail_kernelILi192", "gma_qkv_agg_kernel")
+    assert all(any(n in k for n in known) for k in close), sorted(close)
+    assert sum(len(v) for v in close.values()) <= 3, {k: len(v) for k, v in close.items()}
